@@ -1,0 +1,225 @@
+/*
+ * svtyper_hip.h -- C ABI of the MI355X-native SVTyper likelihood hot path.
+ *
+ * The library behind this header (svtyper_amd/csrc/libsvtyper_hip.so) is the
+ * drop-in for ONE path of hall-lab/svtyper v0.7.1: per (breakpoint, sample)
+ * "evidence tally -> bayes_gt likelihood -> GT/GQ/SQ decision".  Everything a
+ * caller hands over is a plain pointer + size; nothing here depends on torch,
+ * numpy or Python.  A Python binding (ctypes) lives in svtyper_amd/hip.py; the
+ * binding a maintainer of the reference would add is shown in INTEGRATION.md.
+ *
+ * Reference interfaces replaced (paths relative to the reference checkout):
+ *
+ *   svt_batch_create + svt_batch_genotype + svt_batch_results
+ *       == the per-sample block of svtyper/classic.py:286-513 (sv_genotype)
+ *       == svtyper/singlesample.py:355-404 tally_variant_read_fragments()
+ *          + svtyper/singlesample.py:406-473 bayesian_genotype()
+ *          + svtyper/singlesample.py:207-243,478-496 blank results
+ *   inside the kernels:
+ *       svtyper/utils.py:74-75          prob_mapq()
+ *       svtyper/parsers.py:861-882      SamFragment.p_concordant()
+ *       svtyper/parsers.py:579-583      Library.calc_insert_density()
+ *       svtyper/statistics.py:9-20      log_choose()
+ *       svtyper/statistics.py:23-37     bayes_gt()
+ *
+ * There is NO CPU fallback in this library: every compute entry point needs a
+ * gfx950 device and returns SVT_ERR_NO_DEVICE otherwise.  The CPU restatement
+ * used to check it lives under oracle/ and is test infrastructure only.
+ */
+#ifndef SVTYPER_HIP_H
+#define SVTYPER_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SVT_ABI_VERSION 1
+
+/* ---- error codes (0 = ok, <0 = error; text via svt_last_error()) ---------- */
+#define SVT_OK 0
+#define SVT_ERR_INVALID (-1)   /* malformed batch (bad offsets, lib index, ...) */
+#define SVT_ERR_NO_DEVICE (-2) /* no HIP device / device index out of range   */
+#define SVT_ERR_HIP (-3)       /* a HIP runtime call failed                   */
+#define SVT_ERR_NOMEM (-4)
+#define SVT_ERR_STATE (-5)     /* results requested before genotype, ...      */
+
+/* ---- SV types (classic.py:228 accepts exactly these four) ----------------- */
+#define SVT_SVTYPE_DEL 0
+#define SVT_SVTYPE_DUP 1
+#define SVT_SVTYPE_INV 2
+#define SVT_SVTYPE_BND 3
+
+/* ---- flags of svt_batch_create ------------------------------------------- */
+/* floating-point association of the three split-read tallies:
+ *   0 (classic): site total += each contribution directly (classic.py:306-328)
+ *   1 (sso)    : contributions are first summed per fragment starting from 0,
+ *                then added to the site total (singlesample.py:246-276,367-372) */
+#define SVT_FLAG_SSO_ASSOCIATION 0x1u
+
+/* ---- evidence record: one per read-fragment (query name) of a unit, 16 B --
+ * Records of a unit are stored in the order the reference walks them:
+ * sorted(query_name) (classic.py:296, singlesample.py:364).                   */
+typedef struct svt_record {
+    int32_t ospan_len; /* |readB.reference_end - readA.reference_start|
+                          (parsers.py:792-796,866-869); 0 when < 2 primaries  */
+    uint8_t mapq_a;    /* MAPQ of primary read A = primary_reads[0]
+                          (parsers.py:756-768); 0 when absent                 */
+    uint8_t mapq_b;    /* MAPQ of primary read B = primary_reads[1]           */
+    uint8_t s0_left;   /* split candidate 0: MAPQ of query_left  (parsers.py:1017-1028;
+                          0 for the dummy piece of a soft-clip-only candidate, :976-981) */
+    uint8_t s0_right;  /* split candidate 0: MAPQ of query_right              */
+    uint8_t s1_left;   /* split candidate 1 (second primary's candidate)      */
+    uint8_t s1_right;
+    uint8_t lib;       /* index into svt_evidence_batch.libs (fragment.lib)   */
+    uint8_t reserved;  /* must be 0                                           */
+    uint32_t flags;    /* SVT_REC_* bits                                      */
+} svt_record;
+
+#define SVT_REC_REFSEQ_A (1u << 0)   /* is_ref_seq(readA) at A or B (classic.py:306-311) */
+#define SVT_REC_REFSEQ_B (1u << 1)   /* is_ref_seq(readB) at A or B           */
+#define SVT_REC_S0_PRESENT (1u << 2) /* split candidate 0 passed is_valid()   */
+#define SVT_REC_S0_SOFT (1u << 3)    /* candidate 0 is_soft_clip (parsers.py:983) */
+#define SVT_REC_S0_L (1u << 4)       /* is_split_straddle()[0] (parsers.py:1136-1215) */
+#define SVT_REC_S0_R (1u << 5)       /* is_split_straddle()[1]                */
+#define SVT_REC_S1_PRESENT (1u << 6)
+#define SVT_REC_S1_SOFT (1u << 7)
+#define SVT_REC_S1_L (1u << 8)
+#define SVT_REC_S1_R (1u << 9)
+#define SVT_REC_ALT_STRADDLE (1u << 10) /* is_pair_straddle(A,B,o1,o2) OR, for INV, the
+                                           strand-flipped reciprocal (classic.py:342-359).
+                                           Evaluated WITHOUT the small-DEL gate: the
+                                           kernel applies classic.py:339-340 itself.    */
+#define SVT_REC_REF_STRADDLE_A (1u << 11) /* is_pair_straddle(A,A,[0,0],F,T) (classic.py:387-391) */
+#define SVT_REC_REF_STRADDLE_B (1u << 12) /* is_pair_straddle(B,B,[0,0],F,T) (classic.py:392-396) */
+#define SVT_REC_HAS_PAIR (1u << 13)       /* num_primary == 2 (parsers.py:827); informational */
+#define SVT_REC_CONTINUATION (1u << 14)   /* this record continues the previous record's
+                                             fragment (a fragment with > 2 primaries or > 2
+                                             split candidates); only affects the
+                                             SVT_FLAG_SSO_ASSOCIATION summation order      */
+
+/* ---- unit header: one per (breakpoint, sample), 16 B ---------------------- */
+typedef struct svt_unit {
+    int32_t var_length; /* DEL: posB - posA before the strand increments
+                           (classic.py:268, parsers.py:182); ignored otherwise:
+                           non-DEL uses lib.mean + 3*lib.sd (parsers.py:874-875) */
+    int32_t pos_delta;  /* posB - posA AFTER the +1 strand increments
+                           (classic.py:276-277); the small-DEL gate
+                           "posB - posA < 2 * lib.sd" (classic.py:339,383)      */
+    uint16_t sample;    /* sample index (informational; libraries are per record) */
+    uint8_t svtype;     /* SVT_SVTYPE_*                                          */
+    uint8_t flags;      /* SVT_UNIT_* bits                                       */
+    uint32_t reserved;  /* must be 0                                             */
+} svt_unit;
+
+#define SVT_UNIT_SKIP (1u << 0) /* too many reads: GT './.' only (classic.py:282-284,
+                                   singlesample.py:478-480)                      */
+
+/* ---- library: insert-size histogram + moments (parsers.py:406-587) -------- */
+typedef struct svt_library {
+    const uint32_t* hist; /* dense counts: hist[k - key_min] = Library.hist[k]   */
+    int32_t key_min;      /* smallest histogram key                              */
+    uint32_t n_bins;      /* key_max - key_min + 1                               */
+    double mean;          /* Library.mean                                        */
+    double sd;            /* Library.sd                                          */
+} svt_library;
+
+/* ---- a batch of units in CSR form (host memory, caller-owned, read-only) --- */
+typedef struct svt_evidence_batch {
+    uint64_t n_units;
+    const uint64_t* rec_offset; /* n_units + 1 entries, rec_offset[0] == 0        */
+    const svt_unit* units;      /* n_units                                        */
+    const svt_record* records;  /* rec_offset[n_units]                            */
+    uint32_t n_libs;            /* 1..256                                         */
+    const svt_library* libs;
+    double split_weight;        /* --split_weight (classic.py:38)                 */
+    double disc_weight;         /* --disc_weight  (classic.py:39)                 */
+} svt_evidence_batch;
+
+/* ---- results, SoA, caller-allocated host arrays --------------------------- */
+#define SVT_GT_HOMREF 0    /* '0/0' */
+#define SVT_GT_HET 1       /* '0/1' */
+#define SVT_GT_HOMALT 2    /* '1/1' */
+#define SVT_GT_MISSING (-1) /* evidence present but sum(10**GL) underflowed to 0:
+                               GT './.', GQ '.', SQ '.' (classic.py:492-495); GL and
+                               the counts are still valid                          */
+#define SVT_GT_BLANK (-2)   /* all five tallies are 0: blank result (classic.py:496-513) */
+#define SVT_GT_SKIPPED (-3) /* SVT_UNIT_SKIP                                        */
+
+/* order of the ten integer FORMAT counts + GQ inside svt_results.counts */
+enum {
+    SVT_CNT_QR = 0, SVT_CNT_QA, SVT_CNT_GQ, SVT_CNT_DP, SVT_CNT_RO, SVT_CNT_AO,
+    SVT_CNT_RS, SVT_CNT_AS, SVT_CNT_ASC, SVT_CNT_RP, SVT_CNT_AP, SVT_N_COUNTS
+};
+/* order inside svt_results.tallies (after the zeroing rules, classic.py:425-435) */
+enum { SVT_TAL_REF_SEQ = 0, SVT_TAL_ALT_SEQ, SVT_TAL_ALT_CLIP, SVT_TAL_REF_SPAN,
+       SVT_TAL_ALT_SPAN, SVT_N_TALLIES };
+
+typedef struct svt_results {
+    uint64_t n_units;
+    double* gl;       /* [3][n_units]  log10 likelihoods homref/het/homalt       */
+    double* sq;       /* [n_units]     0 when gt < 0                             */
+    double* tallies;  /* [5][n_units]  SVT_TAL_* order                            */
+    int32_t* counts;  /* [SVT_N_COUNTS][n_units]; GQ = -1 when gt < 0             */
+    int8_t* gt;       /* [n_units]     SVT_GT_*                                   */
+} svt_results;
+
+typedef struct svt_batch svt_batch; /* opaque: device-resident packed batch */
+
+/* ---- entry points ---------------------------------------------------------- */
+
+/* ABI version of the loaded library (== SVT_ABI_VERSION). */
+int svt_version(void);
+
+/* Number of usable HIP devices (0 when none; never fails). */
+int svt_device_count(void);
+
+/* Text of the last error raised on the calling thread ("" when none). */
+const char* svt_last_error(void);
+
+/* Pack `in` for the device and make it resident in HBM on `device`:
+ * validates the CSR, sorts units by record count inside 4096-unit chunks,
+ * uploads records/headers/tables and re-tiles the records on the device into
+ * 64-unit lane-interleaved tiles (DESIGN.md "HBM layout").  `flags`: SVT_FLAG_*.
+ * Replaces the hand-over of `read_batch` to the per-sample block of
+ * classic.py:279-296 / the `sam_fragments` argument of singlesample.py:355.     */
+int svt_batch_create(const svt_evidence_batch* in, int device, unsigned flags,
+                     svt_batch** out);
+
+/* One pass of the hot path over the resident batch: tally -> zeroing rules ->
+ * QR/QA -> bayes_gt -> GT/GQ/SQ, results left in HBM.  Asynchronous on the
+ * batch's stream unless `sync` != 0.   (classic.py:296-513)                     */
+int svt_batch_genotype(svt_batch* b, int sync);
+
+/* Run `iters` back-to-back passes bracketed by HIP events on the batch's stream;
+ * *ms_total receives the elapsed milliseconds of all `iters` launches.          */
+int svt_batch_genotype_timed(svt_batch* b, int iters, float* ms_total);
+
+/* Copy the results of the last svt_batch_genotype to host arrays (blocking).   */
+int svt_batch_results(svt_batch* b, svt_results* out);
+
+/* Device pointers of the result arrays (same SoA shapes as svt_results), for a
+ * caller that keeps working on the GPU (e.g. an RCCL gather of shard results).
+ * Valid until svt_batch_destroy.                                               */
+int svt_batch_device_results(svt_batch* b, svt_results* dev_ptrs);
+
+/* Bytes the genotype kernel must move per pass by the definition of SURVEY.md
+ * section 8(d): sum_u (16*F(u) + 16 + 96); and what the tiled layout really
+ * holds (padding included).                                                     */
+int svt_batch_bytes(const svt_batch* b, uint64_t* algorithmic, uint64_t* resident);
+
+/* The HIP stream (hipStream_t) the batch launches on, as an opaque pointer.    */
+void* svt_batch_stream(svt_batch* b);
+
+void svt_batch_destroy(svt_batch* b);
+
+/* Convenience: create + genotype + results + destroy.                          */
+int svt_genotype(const svt_evidence_batch* in, svt_results* out, int device,
+                 unsigned flags);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SVTYPER_HIP_H */

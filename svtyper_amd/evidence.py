@@ -1,0 +1,275 @@
+"""Packed read-evidence batches: the data that crosses the C ABI (include/svtyper_hip.h).
+
+The host side of the hot path turns every read-fragment the reference would visit in
+its per-variant loop (svtyper/classic.py:296-408, svtyper/singlesample.py:246-353)
+into one 16-byte ``svt_record``; a (breakpoint, sample) *unit* owns a contiguous,
+sorted-by-query-name run of records (CSR).  This module holds the numpy mirrors of the
+C structs, the batch container and the ctypes views handed to the library.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+# --------------------------------------------------------------------------- constants
+SVTYPE_CODE = {"DEL": 0, "DUP": 1, "INV": 2, "BND": 3}  # classic.py:228
+SVTYPE_NAME = {v: k for k, v in SVTYPE_CODE.items()}
+
+FLAG_SSO_ASSOCIATION = 0x1
+
+REC_REFSEQ_A = 1 << 0
+REC_REFSEQ_B = 1 << 1
+REC_S0_PRESENT = 1 << 2
+REC_S0_SOFT = 1 << 3
+REC_S0_L = 1 << 4
+REC_S0_R = 1 << 5
+REC_S1_PRESENT = 1 << 6
+REC_S1_SOFT = 1 << 7
+REC_S1_L = 1 << 8
+REC_S1_R = 1 << 9
+REC_ALT_STRADDLE = 1 << 10
+REC_REF_STRADDLE_A = 1 << 11
+REC_REF_STRADDLE_B = 1 << 12
+REC_HAS_PAIR = 1 << 13
+REC_CONTINUATION = 1 << 14
+
+UNIT_SKIP = 1 << 0
+
+GT_HOMREF, GT_HET, GT_HOMALT = 0, 1, 2
+GT_MISSING, GT_BLANK, GT_SKIPPED = -1, -2, -3
+GT_STRING = {0: "0/0", 1: "0/1", 2: "1/1", -1: "./.", -2: "./.", -3: "./."}
+
+COUNT_NAMES = ("QR", "QA", "GQ", "DP", "RO", "AO", "RS", "AS", "ASC", "RP", "AP")
+TALLY_NAMES = ("ref_seq", "alt_seq", "alt_clip", "ref_span", "alt_span")
+N_COUNTS = len(COUNT_NAMES)
+N_TALLIES = len(TALLY_NAMES)
+
+# --------------------------------------------------------------------------- dtypes
+RECORD_DTYPE = np.dtype(
+    [
+        ("ospan_len", "<i4"),
+        ("mapq_a", "u1"),
+        ("mapq_b", "u1"),
+        ("s0_left", "u1"),
+        ("s0_right", "u1"),
+        ("s1_left", "u1"),
+        ("s1_right", "u1"),
+        ("lib", "u1"),
+        ("reserved", "u1"),
+        ("flags", "<u4"),
+    ],
+    align=False,
+)
+assert RECORD_DTYPE.itemsize == 16
+
+UNIT_DTYPE = np.dtype(
+    [
+        ("var_length", "<i4"),
+        ("pos_delta", "<i4"),
+        ("sample", "<u2"),
+        ("svtype", "u1"),
+        ("flags", "u1"),
+        ("reserved", "<u4"),
+    ],
+    align=False,
+)
+assert UNIT_DTYPE.itemsize == 16
+
+
+# --------------------------------------------------------------------------- ctypes structs
+class CLibrary(C.Structure):
+    _fields_ = [
+        ("hist", C.POINTER(C.c_uint32)),
+        ("key_min", C.c_int32),
+        ("n_bins", C.c_uint32),
+        ("mean", C.c_double),
+        ("sd", C.c_double),
+    ]
+
+
+class CEvidenceBatch(C.Structure):
+    _fields_ = [
+        ("n_units", C.c_uint64),
+        ("rec_offset", C.POINTER(C.c_uint64)),
+        ("units", C.c_void_p),
+        ("records", C.c_void_p),
+        ("n_libs", C.c_uint32),
+        ("libs", C.POINTER(CLibrary)),
+        ("split_weight", C.c_double),
+        ("disc_weight", C.c_double),
+    ]
+
+
+class CResults(C.Structure):
+    _fields_ = [
+        ("n_units", C.c_uint64),
+        ("gl", C.POINTER(C.c_double)),
+        ("sq", C.POINTER(C.c_double)),
+        ("tallies", C.POINTER(C.c_double)),
+        ("counts", C.POINTER(C.c_int32)),
+        ("gt", C.POINTER(C.c_int8)),
+    ]
+
+
+# --------------------------------------------------------------------------- library table
+@dataclass
+class LibraryTable:
+    """Dense insert-size histogram of one library (svtyper/parsers.py:406-430).
+
+    ``hist[k - key_min]`` is ``Library.hist[k]``; ``mean``/``sd`` are the library
+    moments used for the small-DEL gate (classic.py:339) and the non-DEL
+    ``var_length`` default (parsers.py:874-875)."""
+
+    hist: np.ndarray
+    key_min: int
+    mean: float
+    sd: float
+    name: str = ""
+
+    @classmethod
+    def from_counter(cls, hist: dict, mean: float, sd: float, name: str = "") -> "LibraryTable":
+        keys = [int(k) for k in hist.keys()]
+        if not keys:
+            return cls(np.zeros(1, np.uint32), 0, float(mean), float(sd), name)
+        kmin, kmax = min(keys), max(keys)
+        dense = np.zeros(kmax - kmin + 1, dtype=np.uint32)
+        for k, v in hist.items():
+            dense[int(k) - kmin] = int(v)
+        return cls(dense, kmin, float(mean), float(sd), name)
+
+    @property
+    def n_total(self) -> int:
+        return int(self.hist.sum(dtype=np.uint64))
+
+
+# --------------------------------------------------------------------------- batch
+@dataclass
+class EvidenceBatch:
+    """CSR batch of units (include/svtyper_hip.h: svt_evidence_batch)."""
+
+    rec_offset: np.ndarray  # uint64 [n_units + 1]
+    units: np.ndarray  # UNIT_DTYPE [n_units]
+    records: np.ndarray  # RECORD_DTYPE [n_records]
+    libs: List[LibraryTable]
+    split_weight: float = 1.0
+    disc_weight: float = 1.0
+    _keep: list = field(default_factory=list, repr=False)
+
+    def __post_init__(self):
+        self.rec_offset = np.ascontiguousarray(self.rec_offset, dtype=np.uint64)
+        self.units = np.ascontiguousarray(self.units, dtype=UNIT_DTYPE)
+        self.records = np.ascontiguousarray(self.records, dtype=RECORD_DTYPE)
+        if self.rec_offset.shape[0] != self.units.shape[0] + 1:
+            raise ValueError("rec_offset must have n_units + 1 entries")
+        if self.units.shape[0] and int(self.rec_offset[-1]) != self.records.shape[0]:
+            raise ValueError("rec_offset[-1] must equal the number of records")
+
+    @property
+    def n_units(self) -> int:
+        return int(self.units.shape[0])
+
+    @property
+    def n_records(self) -> int:
+        return int(self.records.shape[0])
+
+    def algorithmic_bytes(self) -> int:
+        """sum_u (16 F(u) + 16 + 96)."""
+        return 16 * self.n_records + (16 + 96) * self.n_units
+
+    def slice(self, lo: int, hi: int) -> "EvidenceBatch":
+        """Units [lo, hi) as an independent batch (used to shard across ranks)."""
+        r0, r1 = int(self.rec_offset[lo]), int(self.rec_offset[hi])
+        return EvidenceBatch(
+            self.rec_offset[lo : hi + 1] - np.uint64(r0),
+            self.units[lo:hi],
+            self.records[r0:r1],
+            self.libs,
+            self.split_weight,
+            self.disc_weight,
+        )
+
+    def as_c(self) -> CEvidenceBatch:
+        """ctypes view; the returned struct borrows this object's buffers."""
+        clibs = (CLibrary * max(1, len(self.libs)))()
+        keep = []
+        for i, lib in enumerate(self.libs):
+            h = np.ascontiguousarray(lib.hist, dtype=np.uint32)
+            keep.append(h)
+            clibs[i].hist = h.ctypes.data_as(C.POINTER(C.c_uint32))
+            clibs[i].key_min = int(lib.key_min)
+            clibs[i].n_bins = int(h.shape[0])
+            clibs[i].mean = float(lib.mean)
+            clibs[i].sd = float(lib.sd)
+        cb = CEvidenceBatch()
+        cb.n_units = self.n_units
+        cb.rec_offset = self.rec_offset.ctypes.data_as(C.POINTER(C.c_uint64))
+        cb.units = self.units.ctypes.data
+        cb.records = self.records.ctypes.data
+        cb.n_libs = len(self.libs)
+        cb.libs = clibs
+        cb.split_weight = float(self.split_weight)
+        cb.disc_weight = float(self.disc_weight)
+        self._keep = [clibs, keep]
+        return cb
+
+
+@dataclass
+class Results:
+    """SoA results (include/svtyper_hip.h: svt_results)."""
+
+    gl: np.ndarray  # float64 [3, n]
+    sq: np.ndarray  # float64 [n]
+    tallies: np.ndarray  # float64 [5, n]
+    counts: np.ndarray  # int32 [11, n]
+    gt: np.ndarray  # int8 [n]
+
+    @classmethod
+    def empty(cls, n: int) -> "Results":
+        return cls(
+            np.zeros((3, n), np.float64),
+            np.zeros(n, np.float64),
+            np.zeros((N_TALLIES, n), np.float64),
+            np.zeros((N_COUNTS, n), np.int32),
+            np.zeros(n, np.int8),
+        )
+
+    @property
+    def n_units(self) -> int:
+        return int(self.gt.shape[0])
+
+    def as_c(self) -> CResults:
+        cr = CResults()
+        cr.n_units = self.n_units
+        cr.gl = self.gl.ctypes.data_as(C.POINTER(C.c_double))
+        cr.sq = self.sq.ctypes.data_as(C.POINTER(C.c_double))
+        cr.tallies = self.tallies.ctypes.data_as(C.POINTER(C.c_double))
+        cr.counts = self.counts.ctypes.data_as(C.POINTER(C.c_int32))
+        cr.gt = self.gt.ctypes.data_as(C.POINTER(C.c_int8))
+        return cr
+
+    def count(self, name: str) -> np.ndarray:
+        return self.counts[COUNT_NAMES.index(name)]
+
+    def tally(self, name: str) -> np.ndarray:
+        return self.tallies[TALLY_NAMES.index(name)]
+
+
+def concat_batches(batches: Sequence[EvidenceBatch]) -> EvidenceBatch:
+    """Concatenate batches that share libraries and weights."""
+    first = batches[0]
+    offs = [np.zeros(1, np.uint64)]
+    base = 0
+    for b in batches:
+        offs.append(b.rec_offset[1:] + np.uint64(base))
+        base += b.n_records
+    return EvidenceBatch(
+        np.concatenate(offs),
+        np.concatenate([b.units for b in batches]),
+        np.concatenate([b.records for b in batches]),
+        first.libs,
+        first.split_weight,
+        first.disc_weight,
+    )
