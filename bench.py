@@ -1,0 +1,248 @@
+#!/usr/bin/env python
+"""bench.py -- breakpoints genotyped per second on N x MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A *step* is one pass of the hot path (evidence tally -> bayes_gt -> GT/GQ/SQ, one fused HIP
+kernel launch) over one synthetic batch that is already resident in HBM.  Workload at every
+N: BASELINE.json configs[2] -- 1 M mixed DEL/DUP/INV breakpoints, one library (the reference
+fixture's empirical insert-size histogram, staged in LDS), ~100 fragment records (~200 reads)
+per breakpoint -- PER GPU (weak scaling: independent units, no data-path collective inside a
+step).  configs[1] (100 k sites = 160 MB) is not used for the headline because it fits the
+256 MiB Infinity Cache and would not measure HBM.  After the timed region every rank's result
+records are gathered onto rank 0 with ONE RCCL gather over xGMI (north_star: "a single RCCL
+gather ... at the end"); its time is reported separately under "gather".
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def fixture_library():
+    from svtyper_amd.evidence import LibraryTable
+    with open(os.path.join(ROOT, "tests", "data", "NA12878.bam.json")) as f:
+        info = json.load(f)
+    lib = info["NA12878"]["libraryArray"][0]
+    return LibraryTable.from_counter({int(k): int(v) for k, v in lib["histogram"].items()},
+                                     float(lib["mean"]), float(lib["sd"]), "NA12878")
+
+
+def _gen_chunk(args):
+    name, n, idx, rank = args
+    from svtyper_amd import synth
+    cfg = synth.CONFIGS[name]
+    return synth.make_units(n, synth.BASE_SEED + cfg["config_no"] + 1000 * idx + 7919 * rank,
+                            [fixture_library()], svtype_mix=cfg["svtype_mix"])
+
+
+def generate(name: str, n_units: int, rank: int, workers: int):
+    """The synthetic workload of this rank (chunks generated in parallel host processes)."""
+    from svtyper_amd import evidence as ev
+    chunk = 50_000
+    jobs = [(name, min(chunk, n_units - i), i // chunk, rank) for i in range(0, n_units, chunk)]
+    if workers > 1 and len(jobs) > 1:
+        import multiprocessing as mp
+        with mp.get_context("fork").Pool(min(workers, len(jobs))) as pool:
+            parts = pool.map(_gen_chunk, jobs)
+    else:
+        parts = [_gen_chunk(j) for j in jobs]
+    return parts[0] if len(parts) == 1 else ev.concat_batches(parts)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--units", type=int, default=1_000_000, help="breakpoints per GPU")
+    ap.add_argument("--workload", default="c3_mixed_1m", choices=["c3_mixed_1m", "c2_del_100k"])
+    ap.add_argument("--sso", action="store_true", help="singlesample.py floating-point association")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
+        args.gpus = world
+
+    # generate on the host BEFORE importing torch (fork-safe, and no GPU context in the workers)
+    n_cpu = len(os.sched_getaffinity(0))
+    t0 = time.time()
+    batch = generate(args.workload, args.units, rank, max(1, n_cpu // max(1, min(world, 8))))
+    gen_s = time.time() - t0
+
+    import torch
+    import torch.distributed as dist
+    from svtyper_amd import evidence as ev
+    from svtyper_amd import hip
+
+    hip.load()
+    if hip.device_count() <= local_rank:
+        sys.exit("bench.py needs %d MI355X device(s); the HIP path has no CPU fallback" % (local_rank + 1))
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+
+    flags = ev.FLAG_SSO_ASSOCIATION if args.sso else 0
+    t0 = time.time()
+    dbatch = hip.DeviceBatch(batch, device=local_rank, flags=flags)
+    upload_s = time.time() - t0
+    n = batch.n_units
+    alg_bytes, resident_bytes = dbatch.bytes()
+
+    # results straight into one torch buffer (so the final RCCL gather needs no extra copy)
+    off, sizes = {}, dict(gl=24 * n, sq=8 * n, tallies=40 * n, counts=4 * ev.N_COUNTS * n, gt=n)
+    cur = 0
+    for k in ("gl", "sq", "tallies", "counts", "gt"):
+        off[k] = cur
+        cur += (sizes[k] + 255) // 256 * 256
+    res_buf = torch.zeros(cur, dtype=torch.uint8, device="cuda")
+    base = res_buf.data_ptr()
+    dbatch.bind_device_results(**{k: base + off[k] for k in off})
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        dbatch.genotype(sync=False)
+    torch.cuda.synchronize()
+
+    # ---- the timed region: EXACTLY `steps` passes, barrier + device sync on both sides
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        dbatch.genotype(sync=False)
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- dominant-kernel time by HIP events on the launch stream (for the roofline)
+    kern_ms = dbatch.genotype_timed(args.steps) / args.steps
+
+    # ---- the single RCCL gather of the result records onto rank 0
+    gather = None
+    if world > 1:
+        bufs = [torch.empty_like(res_buf) for _ in range(world)] if rank == 0 else None
+        barrier()
+        torch.cuda.synchronize()
+        g0 = time.perf_counter()
+        dist.gather(res_buf, bufs, dst=0)
+        torch.cuda.synchronize()
+        barrier()
+        g_s = time.perf_counter() - g0
+        gather = {"bytes_per_rank": int(cur), "ms": g_s * 1e3,
+                  "GB/s_into_root": cur * (world - 1) / g_s / 1e9, "collective": "rccl gather"}
+
+    if rank == 0:
+        got = dbatch.results()
+        total_units = n * world
+        value = total_units * args.steps / elapsed
+        ach = alg_bytes / (kern_ms * 1e-3) / 1e9
+        out = {
+            "metric": "breakpoints genotyped/sec",
+            "value": value,
+            "unit": "breakpoints/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": "BASELINE.json configs[2]: %d mixed DEL/DUP/INV breakpoints per GPU, 1 library "
+                            "(fixture insert-size histogram in LDS), %.1f fragment records/site"
+                            % (n, batch.n_records / max(1, n)) if args.workload == "c3_mixed_1m" else
+                            "BASELINE.json configs[1]: %d DEL breakpoints per GPU, 1 library" % n,
+                "units_per_gpu": n,
+                "records_per_gpu": batch.n_records,
+                "association": "sso" if args.sso else "classic",
+                "parallelism": "units sharded over %d GPU(s), no data-path collective per step" % world,
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "svt_genotype_kernel",
+                "achieved": ach,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": ach / HBM_PEAK_GBS,
+                "traffic": None,
+                "algorithmic_bytes_per_launch": alg_bytes,
+                "resident_bytes_per_launch": resident_bytes,
+                "kernel_ms": kern_ms,
+            },
+            "host": {"generate_s": gen_s, "pack_upload_s": upload_s,
+                     "pcie_inclusive_breakpoints_per_s": n / (upload_s + kern_ms * 1e-3)},
+        }
+        if gather:
+            out["gather"] = gather
+
+        if world == 1 and not args.no_cpu_baseline:
+            # CPU baseline: the C restatement (oracle/, a port of the reference's algorithm) on the
+            # host cores over a bounded sample of the same workload, also used as parity check
+            from oracle import c_oracle
+            sample_n = min(n, 200_000)
+            sample = batch.slice(0, sample_n)
+            threads = c_oracle.max_threads()
+            t0 = time.perf_counter()
+            reps = 0
+            want = None
+            while True:
+                want = c_oracle.genotype_batch(sample, flags=flags)
+                reps += 1
+                if time.perf_counter() - t0 >= args.cpu_seconds or reps >= 50:
+                    break
+            cpu_s = time.perf_counter() - t0
+            out["cpu_baseline"] = {
+                "value": sample_n * reps / cpu_s,
+                "unit": "breakpoints/s",
+                "cores": threads,
+                "kind": "port",
+                "sample": "first %d units of the workload x %d repetitions, oracle/svt_oracle.c "
+                          "(OpenMP, %d threads)" % (sample_n, reps, threads),
+            }
+            ints_bad = int((got.counts[:, :sample_n] != want.counts).sum() + (got.gt[:sample_n] != want.gt).sum())
+            out["parity"] = {
+                "units_checked": sample_n,
+                "integer_mismatches": ints_bad,
+                "max_abs_dGL": float(np.max(np.abs(got.gl[:, :sample_n] - want.gl))),
+                "max_abs_dSQ": float(np.max(np.abs(got.sq[:sample_n] - want.sq))),
+            }
+        print(json.dumps(out), flush=True)
+
+    dbatch.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -205,6 +205,11 @@ int svt_batch_results(svt_batch* b, svt_results* out);
  * Valid until svt_batch_destroy.                                               */
 int svt_batch_device_results(svt_batch* b, svt_results* dev_ptrs);
 
+/* Make the kernel write its results straight into caller-owned DEVICE buffers (same SoA
+ * shapes; e.g. a torch tensor that is then gathered over RCCL).  The buffers must stay alive
+ * until svt_batch_destroy or the next bind; pass NULL to return to the internal buffers.      */
+int svt_batch_bind_device_results(svt_batch* b, const svt_results* dev_ptrs);
+
 /* Bytes the genotype kernel must move per pass by the definition of SURVEY.md
  * section 8(d): sum_u (16*F(u) + 16 + 96); and what the tiled layout really
  * holds (padding included).                                                     */

@@ -268,11 +268,12 @@ int svt_oracle_batch(const svt_evidence_batch* in, svt_results* out, unsigned fl
     if (!totals) return -2;
     for (uint32_t l = 0; l < in->n_libs; ++l) totals[l] = lib_total(&in->libs[l]);
 #ifdef _OPENMP
-    if (n_threads > 0) omp_set_num_threads(n_threads);
+    const int nt = n_threads > 0 ? n_threads : omp_get_max_threads();
 #else
+    const int nt = 1;
     (void)n_threads;
 #endif
-#pragma omp parallel for schedule(dynamic, 256)
+#pragma omp parallel for schedule(dynamic, 256) num_threads(nt)
     for (int64_t u = 0; u < (int64_t)n; ++u) {
         double t[SVT_N_TALLIES], gl[3], sq;
         int32_t c[SVT_N_COUNTS];

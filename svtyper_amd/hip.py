@@ -1,0 +1,170 @@
+"""ctypes binding of the gfx950 C-ABI library (include/svtyper_hip.h).
+
+This is the ONLY compute backend of the package: if ``libsvtyper_hip.so`` is missing or no
+MI355X is visible, every entry point raises -- there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import Optional
+
+from .evidence import CEvidenceBatch, CResults, EvidenceBatch, Results
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libsvtyper_hip.so")
+ABI_VERSION = 1
+
+EXPORTS = (
+    "svt_version", "svt_device_count", "svt_last_error", "svt_batch_create", "svt_batch_genotype",
+    "svt_batch_genotype_timed", "svt_batch_results", "svt_batch_device_results", "svt_batch_bind_device_results", "svt_batch_bytes",
+    "svt_batch_stream", "svt_batch_destroy", "svt_genotype",
+)
+
+_lib: Optional[C.CDLL] = None
+
+
+class SvtyperHipError(RuntimeError):
+    pass
+
+
+def build(force: bool = False) -> str:
+    """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    src = os.path.join(_HERE, "csrc", "svtyper_hip.hip")
+    hdr = os.path.join(_HERE, "..", "include", "svtyper_hip.h")
+    stale = (not os.path.exists(LIB_PATH)
+             or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(src), os.path.getmtime(hdr)))
+    if force or stale:
+        subprocess.check_call(["make", "-C", os.path.join(_HERE, "csrc"), "-B", "libsvtyper_hip.so"])
+    return LIB_PATH
+
+
+def load() -> C.CDLL:
+    """dlopen the library and declare prototypes.  Raises if the .so is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SvtyperHipError(
+            "HIP extension not built: %s is missing (run `python -c 'import __graft_entry__ as g; "
+            "g.build()'`); svtyper_amd has no CPU fallback" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    L.svt_version.restype = C.c_int
+    L.svt_device_count.restype = C.c_int
+    L.svt_last_error.restype = C.c_char_p
+    L.svt_batch_create.restype = C.c_int
+    L.svt_batch_create.argtypes = [C.POINTER(CEvidenceBatch), C.c_int, C.c_uint, C.POINTER(C.c_void_p)]
+    L.svt_batch_genotype.restype = C.c_int
+    L.svt_batch_genotype.argtypes = [C.c_void_p, C.c_int]
+    L.svt_batch_genotype_timed.restype = C.c_int
+    L.svt_batch_genotype_timed.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float)]
+    L.svt_batch_results.restype = C.c_int
+    L.svt_batch_results.argtypes = [C.c_void_p, C.POINTER(CResults)]
+    L.svt_batch_device_results.restype = C.c_int
+    L.svt_batch_device_results.argtypes = [C.c_void_p, C.POINTER(CResults)]
+    L.svt_batch_bind_device_results.restype = C.c_int
+    L.svt_batch_bind_device_results.argtypes = [C.c_void_p, C.POINTER(CResults)]
+    L.svt_batch_bytes.restype = C.c_int
+    L.svt_batch_bytes.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.svt_batch_stream.restype = C.c_void_p
+    L.svt_batch_stream.argtypes = [C.c_void_p]
+    L.svt_batch_destroy.restype = None
+    L.svt_batch_destroy.argtypes = [C.c_void_p]
+    L.svt_genotype.restype = C.c_int
+    L.svt_genotype.argtypes = [C.POINTER(CEvidenceBatch), C.POINTER(CResults), C.c_int, C.c_uint]
+    if L.svt_version() != ABI_VERSION:
+        raise SvtyperHipError("ABI mismatch: library %d, binding %d" % (L.svt_version(), ABI_VERSION))
+    _lib = L
+    return L
+
+
+def _check(rc: int):
+    if rc != 0:
+        msg = load().svt_last_error()
+        raise SvtyperHipError("svtyper_hip error %d: %s" % (rc, msg.decode() if msg else ""))
+
+
+def device_count() -> int:
+    return int(load().svt_device_count())
+
+
+class DeviceBatch:
+    """A batch resident in HBM (svt_batch)."""
+
+    def __init__(self, batch: EvidenceBatch, device: int = 0, flags: int = 0):
+        L = load()
+        self._lib = L
+        self._h = C.c_void_p()
+        self.n_units = batch.n_units
+        self.n_records = batch.n_records
+        cb = batch.as_c()
+        _check(L.svt_batch_create(C.byref(cb), int(device), int(flags), C.byref(self._h)))
+
+    def genotype(self, sync: bool = True):
+        _check(self._lib.svt_batch_genotype(self._h, int(sync)))
+
+    def genotype_timed(self, iters: int) -> float:
+        """Elapsed milliseconds (HIP events on the batch stream) of `iters` passes."""
+        ms = C.c_float()
+        _check(self._lib.svt_batch_genotype_timed(self._h, int(iters), C.byref(ms)))
+        return float(ms.value)
+
+    def results(self) -> Results:
+        out = Results.empty(self.n_units)
+        cr = out.as_c()
+        _check(self._lib.svt_batch_results(self._h, C.byref(cr)))
+        return out
+
+    def device_pointers(self) -> dict:
+        cr = CResults()
+        _check(self._lib.svt_batch_device_results(self._h, C.byref(cr)))
+        addr = lambda p: C.cast(p, C.c_void_p).value
+        return dict(n_units=int(cr.n_units), gl=addr(cr.gl), sq=addr(cr.sq), tallies=addr(cr.tallies),
+                    counts=addr(cr.counts), gt=addr(cr.gt))
+
+    def bind_device_results(self, gl: int, sq: int, tallies: int, counts: int, gt: int):
+        """Device addresses (ints) of caller-owned SoA result buffers, e.g. torch data_ptr()s."""
+        cr = CResults()
+        cr.n_units = self.n_units
+        cr.gl = C.cast(C.c_void_p(gl), C.POINTER(C.c_double))
+        cr.sq = C.cast(C.c_void_p(sq), C.POINTER(C.c_double))
+        cr.tallies = C.cast(C.c_void_p(tallies), C.POINTER(C.c_double))
+        cr.counts = C.cast(C.c_void_p(counts), C.POINTER(C.c_int32))
+        cr.gt = C.cast(C.c_void_p(gt), C.POINTER(C.c_int8))
+        _check(self._lib.svt_batch_bind_device_results(self._h, C.byref(cr)))
+
+    def bytes(self):
+        a, r = C.c_uint64(), C.c_uint64()
+        _check(self._lib.svt_batch_bytes(self._h, C.byref(a), C.byref(r)))
+        return int(a.value), int(r.value)
+
+    def stream(self) -> int:
+        return int(self._lib.svt_batch_stream(self._h) or 0)
+
+    def close(self):
+        if self._h:
+            self._lib.svt_batch_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
+def genotype_batch(batch: EvidenceBatch, device: int = 0, flags: int = 0) -> Results:
+    """create + genotype + results + destroy (svt_genotype)."""
+    L = load()
+    out = Results.empty(batch.n_units)
+    cb = batch.as_c()
+    cr = out.as_c()
+    _check(L.svt_genotype(C.byref(cb), C.byref(cr), int(device), int(flags)))
+    return out

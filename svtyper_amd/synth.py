@@ -1,0 +1,236 @@
+"""Synthetic read-evidence batches at the *evidence-record* level.
+
+The generator draws, per (breakpoint, sample) unit, a true genotype and then per
+read-fragment the evidence bits / MAPQs / outer-span lengths the reference's geometry
+predicates would have produced, with the marginal frequencies measured on the
+reference's own fixture: ~100 fragments per unit (18..183),
+99.6 % two-primary fragments, MAPQ 60 for 94 %, one split candidate on 14.6 % of the
+fragments (56 % soft-clip-only), outer spans drawn from the library's insert-size
+histogram (shifted by the variant length for alt-supporting pairs).
+
+Everything is vectorised numpy and deterministic in (seed, config).
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from . import evidence as ev
+from .evidence import EvidenceBatch, LibraryTable, RECORD_DTYPE, UNIT_DTYPE
+
+BASE_SEED = 20260927
+
+
+def normal_library(mu: float = 320.0, sigma: float = 80.0, n: int = 1_000_000, seed: int = 7,
+                   name: str = "synthetic") -> LibraryTable:
+    """A rounded N(mu, sigma) insert-size library truncated to [1, mu + 10 sigma]."""
+    rng = np.random.default_rng(seed)
+    x = np.rint(rng.normal(mu, sigma, n)).astype(np.int64)
+    x = x[(x >= 1) & (x <= int(mu + 10 * sigma))]
+    keys, counts = np.unique(x, return_counts=True)
+    hist = {int(k): int(c) for k, c in zip(keys, counts)}
+    tot = float(counts.sum())
+    mean = float((keys * counts).sum() / tot)
+    sd = float(np.sqrt((counts * (keys - mean) ** 2).sum() / tot))
+    return LibraryTable.from_counter(hist, mean, sd, name)
+
+
+def _mapq(rng, n):
+    """MAPQ ~ {60: 94 %, 40: 1.75 %, 0: 0.3 %, rest uniform on 1..59}."""
+    u = rng.random(n)
+    q = np.full(n, 60, np.uint8)
+    q[u < 0.0605] = 40  # overwritten below except for a 1.75 % band
+    rest = u < 0.043
+    q[rest] = rng.integers(1, 60, int(rest.sum()), dtype=np.uint8)
+    q[u < 0.003] = 0
+    return q
+
+
+def _sample_hist(rng, lib: LibraryTable, n):
+    cdf = np.cumsum(lib.hist, dtype=np.float64)
+    cdf /= cdf[-1]
+    return (np.searchsorted(cdf, rng.random(n), side="right") + lib.key_min).astype(np.int64)
+
+
+def make_units(n_units: int, seed: int, libs: Sequence[LibraryTable], svtype_mix=(1.0, 0.0, 0.0, 0.0),
+               mean_frags: float = 100.0, sd_frags: float = 25.0, min_frags: int = 18,
+               max_frags: int = 183, sample: int = 0, lib_choices: Optional[Sequence[int]] = None,
+               alt_af: Optional[np.ndarray] = None, split_weight: float = 1.0,
+               disc_weight: float = 1.0, frac_empty: float = 0.0, frac_skip: float = 0.0) -> EvidenceBatch:
+    """One chunk of synthetic units.  svtype_mix = probabilities of (DEL, DUP, INV, BND)."""
+    rng = np.random.default_rng(seed)
+    libs = list(libs)
+    if lib_choices is None:
+        lib_choices = list(range(len(libs)))
+    lib_choices = np.asarray(lib_choices, dtype=np.uint8)
+
+    # ---- units
+    svtype = rng.choice(4, size=n_units, p=np.asarray(svtype_mix, float) / np.sum(svtype_mix)).astype(np.uint8)
+    # var_length log-uniform on [50, 1e5] (includes the < 2*sd small-DEL gate)
+    var_len = np.exp(rng.uniform(np.log(50.0), np.log(1e5), n_units)).astype(np.int64)
+    if alt_af is None:
+        genotype = rng.integers(0, 3, n_units)
+    else:
+        genotype = (rng.random(n_units) < alt_af).astype(np.int64) + (rng.random(n_units) < alt_af)
+    F = np.clip(np.rint(rng.normal(mean_frags, sd_frags, n_units)), min_frags, max_frags).astype(np.int64)
+    empty = rng.random(n_units) < frac_empty
+    skip = rng.random(n_units) < frac_skip
+    F[empty | skip] = 0
+    units = np.zeros(n_units, UNIT_DTYPE)
+    units["svtype"] = svtype
+    units["var_length"] = np.where(svtype == 0, var_len, 0)
+    # posB - posA after the +1 increments: DEL (o2 reverse) +1, DUP (o1 reverse) -1, INV 0
+    units["pos_delta"] = var_len + np.where(svtype == 0, 1, np.where(svtype == 1, -1, 0))
+    units["sample"] = sample
+    units["flags"] = np.where(skip, ev.UNIT_SKIP, 0)
+    rec_offset = np.zeros(n_units + 1, np.uint64)
+    np.cumsum(F, out=rec_offset[1:])
+    R = int(rec_offset[-1])
+
+    # ---- per-record unit attributes
+    unit_of = np.repeat(np.arange(n_units), F)
+    g = genotype[unit_of]
+    sv = svtype[unit_of]
+    vlen = var_len[unit_of]
+    is_del = sv == 0
+
+    rec = np.zeros(R, RECORD_DTYPE)
+    lib_idx = lib_choices[rng.integers(0, len(lib_choices), R)]
+    rec["lib"] = lib_idx
+    two = rng.random(R) < 0.996
+    mq_a = _mapq(rng, R)
+    mq_b = np.where(two, _mapq(rng, R), 0).astype(np.uint8)
+    rec["mapq_a"] = mq_a
+    rec["mapq_b"] = mq_b
+    flags = np.zeros(R, np.uint32)
+    flags |= np.where(two, ev.REC_HAS_PAIR, 0).astype(np.uint32)
+
+    # fragment class: alt-supporting with probability by genotype
+    p_alt_frag = np.array([0.01, 0.45, 0.93])[g]
+    alt_like = rng.random(R) < p_alt_frag
+
+    # reference split-read evidence: 37 % of fragments, mostly ref-like ones
+    u = rng.random(R)
+    rs = u < np.where(alt_like, 0.08, 0.45)
+    which = rng.random(R)
+    flags |= np.where(rs & (which < 0.55), ev.REC_REFSEQ_A, 0).astype(np.uint32)
+    flags |= np.where(rs & two & (which > 0.45), ev.REC_REFSEQ_B, 0).astype(np.uint32)
+
+    # split candidates: one 14.6 %, two 0.6 %; 56 % soft-clip-only
+    u = rng.random(R)
+    s0 = u < 0.152
+    s1 = (u < 0.006) & two
+    for k, (present, fp, fs, fl, fr, nl, nr) in enumerate(
+            ((s0, ev.REC_S0_PRESENT, ev.REC_S0_SOFT, ev.REC_S0_L, ev.REC_S0_R, "s0_left", "s0_right"),
+             (s1, ev.REC_S1_PRESENT, ev.REC_S1_SOFT, ev.REC_S1_L, ev.REC_S1_R, "s1_left", "s1_right"))):
+        soft = present & (rng.random(R) < 0.56)
+        # a candidate supports the breakpoint on a side mostly when the fragment is alt-like
+        sup_l = present & (rng.random(R) < np.where(alt_like, 0.85, 0.03))
+        sup_r = present & (rng.random(R) < np.where(alt_like, 0.85, 0.03))
+        left_is_dummy = soft & (rng.random(R) < 0.5)   # soft-clip: the other piece has MAPQ 0
+        ql = np.where(present, _mapq(rng, R), 0).astype(np.uint8)
+        qr = np.where(present, _mapq(rng, R), 0).astype(np.uint8)
+        ql = np.where(soft & left_is_dummy, 0, ql).astype(np.uint8)
+        qr = np.where(soft & ~left_is_dummy, 0, qr).astype(np.uint8)
+        rec[nl] = ql
+        rec[nr] = qr
+        flags |= np.where(present, fp, 0).astype(np.uint32)
+        flags |= np.where(soft, fs, 0).astype(np.uint32)
+        flags |= np.where(sup_l, fl, 0).astype(np.uint32)
+        flags |= np.where(sup_r, fr, 0).astype(np.uint32)
+
+    # paired-end evidence
+    near = two & (rng.random(R) < 0.90)            # pair close enough to straddle something
+    alt_st = near & alt_like & (rng.random(R) < 0.9)
+    # ref-like pairs straddle one breakend (A or B); short variants are jumped by both
+    ref_any = near & (~alt_like | (vlen < 500))
+    side = rng.random(R)
+    both = ref_any & ((vlen < 500) & (rng.random(R) < 0.6))
+    ref_a = ref_any & (both | (side < 0.5))
+    ref_b = ref_any & (both | (side >= 0.5))
+    flags |= np.where(alt_st, ev.REC_ALT_STRADDLE, 0).astype(np.uint32)
+    flags |= np.where(ref_a, ev.REC_REF_STRADDLE_A, 0).astype(np.uint32)
+    flags |= np.where(ref_b, ev.REC_REF_STRADDLE_B, 0).astype(np.uint32)
+
+    # outer span: concordant ~ hist, alt-supporting DEL pairs ~ hist + var_length; 14 % beyond the
+    # histogram's range
+    osp = np.zeros(R, np.int64)
+    for li, lib in enumerate(libs):
+        m = lib_idx == li
+        if m.any():
+            osp[m] = _sample_hist(rng, lib, int(m.sum()))
+    osp = np.where(alt_like & is_del, osp + vlen, osp)
+    far = rng.random(R) < 0.14
+    osp = np.where(far, osp + rng.integers(400, 5000, R), osp)
+    osp = np.where(two, osp, 0)
+    rec["ospan_len"] = np.clip(osp, 0, 2**31 - 1).astype(np.int32)
+    rec["flags"] = flags
+    return EvidenceBatch(rec_offset, units, rec, libs, split_weight, disc_weight)
+
+
+CONFIGS = {
+    # BASELINE.json configs[1]: 100k synthetic DEL breakpoints, 1 library, ~200 reads/site
+    "c2_del_100k": dict(n_units=100_000, svtype_mix=(1, 0, 0, 0), config_no=2),
+    # configs[2]: 1M mixed DEL/DUP/INV breakpoints
+    "c3_mixed_1m": dict(n_units=1_000_000, svtype_mix=(0.70, 0.15, 0.15, 0.0), config_no=3),
+}
+
+
+def make_config(name: str, libs: Sequence[LibraryTable], n_units: Optional[int] = None,
+                chunk: int = 100_000, seed_offset: int = 0) -> EvidenceBatch:
+    """A BASELINE.json configuration, generated in chunks (seeds BASE_SEED + config# ...)."""
+    cfg = CONFIGS[name]
+    n = int(n_units if n_units is not None else cfg["n_units"])
+    parts: List[EvidenceBatch] = []
+    done = 0
+    i = 0
+    while done < n:
+        m = min(chunk, n - done)
+        parts.append(make_units(m, BASE_SEED + cfg["config_no"] + 1000 * i + seed_offset, libs,
+                                svtype_mix=cfg["svtype_mix"]))
+        done += m
+        i += 1
+    return parts[0] if len(parts) == 1 else ev.concat_batches(parts)
+
+
+def make_edge_cases(libs: Sequence[LibraryTable], seed: int = 1) -> EvidenceBatch:
+    """Small adversarial batch: empty/skip units, ragged record counts 0..300, all svtypes,
+    MAPQ values whose weights do not sum associatively (0.9, 0.99, ...), multi-record fragments
+    (continuation records), duplications with very deep alt support (GT './.' by underflow)."""
+    rng = np.random.default_rng(seed)
+    parts = [
+        make_units(700, seed + 1, libs, svtype_mix=(0.4, 0.2, 0.2, 0.2), mean_frags=60, sd_frags=60,
+                   min_frags=0, max_frags=300, frac_empty=0.05, frac_skip=0.03),
+    ]
+    # low-MAPQ heavy units: sums of 0.9 / 0.99 / 0.5 that land next to integers
+    b = make_units(300, seed + 2, libs, svtype_mix=(0.5, 0.2, 0.2, 0.1), mean_frags=40, sd_frags=20,
+                   min_frags=1, max_frags=120)
+    for fld in ("mapq_a", "mapq_b", "s0_left", "s0_right"):
+        m = rng.random(b.n_records) < 0.7
+        b.records[fld] = np.where(m & (b.records[fld] > 0), rng.choice([3, 10, 20, 30, 255], b.n_records),
+                                  b.records[fld]).astype(np.uint8)
+    parts.append(b)
+    # continuation records (fragments with more than two primaries / candidates)
+    c = make_units(200, seed + 3, libs, svtype_mix=(0.4, 0.2, 0.2, 0.2), mean_frags=30, sd_frags=10,
+                   min_frags=2, max_frags=80)
+    first = np.zeros(c.n_records, bool)
+    first[c.rec_offset[:-1][c.rec_offset[:-1] < c.n_records].astype(np.int64)] = True
+    cont = (~first) & (rng.random(c.n_records) < 0.15)
+    fl = c.records["flags"].copy()
+    # a continuation record carries no pair evidence
+    fl[cont] &= ~np.uint32(ev.REC_ALT_STRADDLE | ev.REC_REF_STRADDLE_A | ev.REC_REF_STRADDLE_B | ev.REC_HAS_PAIR)
+    fl[cont] |= np.uint32(ev.REC_CONTINUATION)
+    c.records["flags"] = fl
+    parts.append(c)
+    # very deep duplications: QA > 679 with QR == 0 underflows sum(10**GL)
+    d = make_units(64, seed + 4, libs, svtype_mix=(0, 1, 0, 0), mean_frags=900, sd_frags=150,
+                   min_frags=600, max_frags=1300, alt_af=np.full(64, 1.0))
+    fl = d.records["flags"]
+    fl &= ~np.uint32(ev.REC_REFSEQ_A | ev.REC_REFSEQ_B | ev.REC_REF_STRADDLE_A | ev.REC_REF_STRADDLE_B)
+    fl |= np.uint32(ev.REC_ALT_STRADDLE | ev.REC_HAS_PAIR)
+    d.records["flags"] = fl
+    d.records["mapq_a"] = 60
+    d.records["mapq_b"] = 60
+    parts.append(d)
+    return ev.concat_batches(parts)

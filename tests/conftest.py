@@ -1,0 +1,33 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def fixture_library():
+    """The reference fixture's single library (tests/data/NA12878.bam.json)."""
+    import json
+    from svtyper_amd.evidence import LibraryTable
+    with open(os.path.join(ROOT, "tests", "data", "NA12878.bam.json")) as f:
+        info = json.load(f)
+    lib = info["NA12878"]["libraryArray"][0]
+    hist = {int(k): int(v) for k, v in lib["histogram"].items()}
+    return LibraryTable.from_counter(hist, float(lib["mean"]), float(lib["sd"]), lib["library_name"])
+
+
+@pytest.fixture(scope="session")
+def hip_device():
+    """Loads the HIP library and requires a device; fails loudly otherwise."""
+    from svtyper_amd import hip
+    hip.load()
+    assert hip.device_count() > 0, "no MI355X visible: the gpu-marked tests need the real device"
+    return 0

@@ -1,0 +1,153 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on identical inputs.
+
+Bars (BASELINE.json north_star): integer outputs (GT, GQ, QR, QA, DP, RO, AO, RS, AS, ASC, RP,
+AP) bit-exact; GL and SQ within 1e-6 absolute.  The tallies and GL are in fact produced by the
+same sequence of binary64 operations on both sides, so they are additionally required to be
+bit-identical; only SQ goes through the device's pow/log.
+"""
+import numpy as np
+import pytest
+
+from svtyper_amd import evidence as ev
+from svtyper_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-6  # north_star tolerance on GL / SQ
+
+
+def assert_parity(got: ev.Results, want: ev.Results, exact_float=True):
+    assert np.array_equal(got.gt, want.gt), "GT mismatch at %s" % np.nonzero(got.gt != want.gt)[0][:10]
+    for i, name in enumerate(ev.COUNT_NAMES):
+        bad = np.nonzero(got.counts[i] != want.counts[i])[0]
+        assert bad.size == 0, "%s mismatch at units %s: %s vs %s" % (
+            name, bad[:10], got.counts[i][bad[:10]], want.counts[i][bad[:10]])
+    assert np.max(np.abs(got.gl - want.gl), initial=0.0) <= TOL
+    assert np.max(np.abs(got.sq - want.sq), initial=0.0) <= TOL
+    assert np.max(np.abs(got.tallies - want.tallies), initial=0.0) <= TOL
+    if exact_float:
+        assert np.array_equal(got.tallies.view(np.uint64), want.tallies.view(np.uint64)), "tallies not bit-identical"
+        assert np.array_equal(got.gl.view(np.uint64), want.gl.view(np.uint64)), "GL not bit-identical"
+
+
+def run_both(batch, flags=0, device=0):
+    from oracle import c_oracle
+    from svtyper_amd import hip
+    got = hip.genotype_batch(batch, device=device, flags=flags)
+    want = c_oracle.genotype_batch(batch, flags=flags)
+    return got, want
+
+
+@pytest.mark.parametrize("flags", [0, ev.FLAG_SSO_ASSOCIATION])
+def test_edge_cases(hip_device, fixture_library, flags):
+    batch = synth.make_edge_cases([fixture_library], seed=11)
+    got, want = run_both(batch, flags)
+    assert_parity(got, want)
+    # the edge batch must really exercise the special outcomes
+    assert (want.gt == ev.GT_BLANK).any() and (want.gt == ev.GT_SKIPPED).any()
+    assert (want.gt == ev.GT_MISSING).any(), "no underflow (GT './.') case generated"
+    for g in (0, 1, 2):
+        assert (want.gt == g).any()
+
+
+@pytest.mark.parametrize("flags", [0, ev.FLAG_SSO_ASSOCIATION])
+def test_c2_slice(hip_device, fixture_library, flags):
+    """BASELINE.json configs[1] (100k DEL sites, 1 library), a 20k-unit slice."""
+    batch = synth.make_config("c2_del_100k", [fixture_library], n_units=20_000)
+    got, want = run_both(batch, flags)
+    assert_parity(got, want)
+
+
+def test_c3_slice_mixed(hip_device, fixture_library):
+    """configs[2]: mixed DEL/DUP/INV."""
+    batch = synth.make_config("c3_mixed_1m", [fixture_library], n_units=30_000)
+    got, want = run_both(batch)
+    assert_parity(got, want)
+    assert len(np.unique(batch.units["svtype"])) == 3
+
+
+def test_multi_library(hip_device, fixture_library):
+    libs = [fixture_library, synth.normal_library(420.0, 95.0, seed=3), synth.normal_library(280.0, 40.0, seed=4)]
+    batch = synth.make_units(5000, 99, libs, svtype_mix=(0.5, 0.2, 0.2, 0.1))
+    got, want = run_both(batch)
+    assert_parity(got, want)
+
+
+def test_integral_nondel_var_length(hip_device):
+    """mean + 3 sd integral: the float Counter key of parsers.py:874-878 matches integer bins."""
+    lib = synth.normal_library(300.0, 50.0, seed=5)
+    lib.mean, lib.sd = 300.0, 50.0  # v = 450.0 exactly
+    batch = synth.make_units(4000, 5, [lib], svtype_mix=(0.0, 0.4, 0.4, 0.2))
+    got, want = run_both(batch)
+    assert_parity(got, want)
+
+
+def test_weights(hip_device, fixture_library):
+    batch = synth.make_units(4000, 17, [fixture_library], svtype_mix=(0.6, 0.2, 0.1, 0.1),
+                             split_weight=0.7, disc_weight=1.9)
+    got, want = run_both(batch)
+    assert_parity(got, want)
+
+
+def test_empty_and_tiny_batches(hip_device, fixture_library):
+    from svtyper_amd import hip
+    b0 = synth.make_units(0, 1, [fixture_library])
+    r0 = hip.genotype_batch(b0)
+    assert r0.n_units == 0
+    for n in (1, 63, 64, 65, 4095, 4097):
+        b = synth.make_units(n, n, [fixture_library], svtype_mix=(0.5, 0.2, 0.2, 0.1), min_frags=0,
+                             mean_frags=30, sd_frags=30)
+        got, want = run_both(b)
+        assert_parity(got, want)
+
+
+def test_invalid_records_rejected(hip_device, fixture_library):
+    from svtyper_amd import hip
+    b = synth.make_units(100, 3, [fixture_library])
+    b.records["lib"][5] = 7  # only one library
+    with pytest.raises(hip.SvtyperHipError):
+        hip.genotype_batch(b)
+    b = synth.make_units(100, 3, [fixture_library])
+    b.records["flags"][7] = ev.REC_S0_L  # L without PRESENT
+    with pytest.raises(hip.SvtyperHipError):
+        hip.genotype_batch(b)
+
+
+def test_bayes_grid_via_kernel(hip_device, fixture_library):
+    """Drive (QR, QA, is_dup) through the kernel with MAPQ-255 evidence (weight exactly 1.0):
+    QR ref-seq reads and QA alt pairs per unit, grid 0..330 x 0..330 x {DEL-like, DUP}."""
+    from oracle import c_oracle
+    qs = np.array([0, 1, 2, 3, 5, 8, 13, 21, 34, 55, 89, 100, 144, 200, 233, 300, 330])
+    units, recs, offs = [], [], [0]
+    for svt in (ev.SVTYPE_CODE["INV"], ev.SVTYPE_CODE["DUP"]):
+        for qr in qs:
+            for qa in qs:
+                n = max(qr, qa)
+                r = np.zeros(n, ev.RECORD_DTYPE)
+                r["mapq_a"] = 255
+                r["mapq_b"] = 255
+                fl = np.full(n, ev.REC_HAS_PAIR, np.uint32)
+                fl[:qr] |= ev.REC_REFSEQ_A
+                fl[:qa] |= ev.REC_ALT_STRADDLE
+                r["flags"] = fl
+                recs.append(r)
+                offs.append(offs[-1] + n)
+                u = np.zeros(1, ev.UNIT_DTYPE)
+                u["svtype"] = svt
+                units.append(u)
+    batch = ev.EvidenceBatch(np.array(offs, np.uint64), np.concatenate(units), np.concatenate(recs),
+                             [fixture_library])
+    got, want = run_both(batch)
+    assert_parity(got, want)
+    # spot-check the pinned reference values (SURVEY.md 8c iii)
+    k = 0
+    for svt in ("INV", "DUP"):
+        for qr in qs:
+            for qa in qs:
+                if (qr, qa) == (0, 0):
+                    assert got.gt[k] == ev.GT_BLANK
+                elif (qr, qa) == (0, 1) and svt == "INV":
+                    # alt_span >= 1 and no splitters: zeroing rule keeps QA = 1
+                    assert got.gt[k] == 2 and got.count("GQ")[k] == 2
+                    assert abs(got.sq[k] - 31.464381352857743) < TOL
+                k += 1
