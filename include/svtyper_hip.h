@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SVT_ABI_VERSION 1
+#define SVT_ABI_VERSION 2
 
 /* ---- error codes (0 = ok, <0 = error; text via svt_last_error()) ---------- */
 #define SVT_OK 0
@@ -61,44 +61,49 @@ extern "C" {
 
 /* ---- evidence record: one per read-fragment (query name) of a unit, 16 B --
  * Records of a unit are stored in the order the reference walks them:
- * sorted(query_name) (classic.py:296, singlesample.py:364).                   */
+ * sorted(query_name) (classic.py:296, singlesample.py:364).
+ *
+ * The four "weight" byte pairs hold MAPQ values that are already gated by the
+ * reference's geometry predicates, using prob_mapq(0) == 1 - 10**0 == 0.0
+ * exactly (utils.py:74-75): a gated-off read carries MAPQ 0 and therefore adds
+ * +0.0, which is what "not adding" means for the non-negative binary64 sums.  */
 typedef struct svt_record {
     int32_t ospan_len; /* |readB.reference_end - readA.reference_start|
                           (parsers.py:792-796,866-869); 0 when < 2 primaries  */
     uint8_t mapq_a;    /* MAPQ of primary read A = primary_reads[0]
                           (parsers.py:756-768); 0 when absent                 */
     uint8_t mapq_b;    /* MAPQ of primary read B = primary_reads[1]           */
-    uint8_t s0_left;   /* split candidate 0: MAPQ of query_left  (parsers.py:1017-1028;
-                          0 for the dummy piece of a soft-clip-only candidate, :976-981) */
-    uint8_t s0_right;  /* split candidate 0: MAPQ of query_right              */
-    uint8_t s1_left;   /* split candidate 1 (second primary's candidate)      */
-    uint8_t s1_right;
-    uint8_t lib;       /* index into svt_evidence_batch.libs (fragment.lib)   */
-    uint8_t reserved;  /* must be 0                                           */
-    uint32_t flags;    /* SVT_REC_* bits                                      */
+    uint8_t rs_a;      /* mapq_a if is_ref_seq(readA) at A or B else 0
+                          (classic.py:306-311: ref_seq += prob_mapq(read))    */
+    uint8_t rs_b;      /* same for read B                                     */
+    uint8_t seq_l;     /* non-soft-clip split candidate (classic.py:317-328):
+                          MAPQ of query_left  if is_split_straddle()[0] else 0 */
+    uint8_t seq_r;     /* MAPQ of query_right if is_split_straddle()[1] else 0 */
+    uint8_t clip_l;    /* soft-clip-only candidate (is_soft_clip, parsers.py:983):
+                          same two gated MAPQs (the dummy piece has MAPQ 0,
+                          parsers.py:976-981)                                  */
+    uint8_t clip_r;
+    uint32_t flags;    /* SVT_REC_* bits, library index in bits 8..15         */
 } svt_record;
 
-#define SVT_REC_REFSEQ_A (1u << 0)   /* is_ref_seq(readA) at A or B (classic.py:306-311) */
-#define SVT_REC_REFSEQ_B (1u << 1)   /* is_ref_seq(readB) at A or B           */
-#define SVT_REC_S0_PRESENT (1u << 2) /* split candidate 0 passed is_valid()   */
-#define SVT_REC_S0_SOFT (1u << 3)    /* candidate 0 is_soft_clip (parsers.py:983) */
-#define SVT_REC_S0_L (1u << 4)       /* is_split_straddle()[0] (parsers.py:1136-1215) */
-#define SVT_REC_S0_R (1u << 5)       /* is_split_straddle()[1]                */
-#define SVT_REC_S1_PRESENT (1u << 6)
-#define SVT_REC_S1_SOFT (1u << 7)
-#define SVT_REC_S1_L (1u << 8)
-#define SVT_REC_S1_R (1u << 9)
-#define SVT_REC_ALT_STRADDLE (1u << 10) /* is_pair_straddle(A,B,o1,o2) OR, for INV, the
-                                           strand-flipped reciprocal (classic.py:342-359).
-                                           Evaluated WITHOUT the small-DEL gate: the
-                                           kernel applies classic.py:339-340 itself.    */
-#define SVT_REC_REF_STRADDLE_A (1u << 11) /* is_pair_straddle(A,A,[0,0],F,T) (classic.py:387-391) */
-#define SVT_REC_REF_STRADDLE_B (1u << 12) /* is_pair_straddle(B,B,[0,0],F,T) (classic.py:392-396) */
-#define SVT_REC_HAS_PAIR (1u << 13)       /* num_primary == 2 (parsers.py:827); informational */
-#define SVT_REC_CONTINUATION (1u << 14)   /* this record continues the previous record's
-                                             fragment (a fragment with > 2 primaries or > 2
-                                             split candidates); only affects the
-                                             SVT_FLAG_SSO_ASSOCIATION summation order      */
+#define SVT_REC_ALT_STRADDLE (1u << 0)   /* is_pair_straddle(A,B,o1,o2) OR, for INV, the
+                                            strand-flipped reciprocal (classic.py:342-359).
+                                            Evaluated WITHOUT the small-DEL gate: the
+                                            kernel applies classic.py:339-340 itself.    */
+#define SVT_REC_REF_STRADDLE_A (1u << 1) /* is_pair_straddle(A,A,[0,0],F,T) (classic.py:387-391) */
+#define SVT_REC_REF_STRADDLE_B (1u << 2) /* is_pair_straddle(B,B,[0,0],F,T) (classic.py:392-396) */
+#define SVT_REC_CONTINUATION (1u << 3)   /* this record continues the previous record's
+                                            fragment (a fragment with > 2 primaries, or two
+                                            split candidates of the same kind: the extra
+                                            read / candidate goes into an extra record);
+                                            only affects the SVT_FLAG_SSO_ASSOCIATION
+                                            summation order                                */
+#define SVT_REC_HAS_PAIR (1u << 4)       /* num_primary == 2 (parsers.py:827): required by
+                                            the three straddle bits                        */
+#define SVT_REC_LIB_SHIFT 8              /* bits 8..15: index into svt_evidence_batch.libs
+                                            (fragment.lib)                                 */
+#define SVT_REC_LIB(flags) (((flags) >> SVT_REC_LIB_SHIFT) & 0xffu)
+#define SVT_REC_FLAG_MASK 0x0000ff1fu    /* every other bit must be 0                      */
 
 /* ---- unit header: one per (breakpoint, sample), 16 B ---------------------- */
 typedef struct svt_unit {
@@ -138,7 +143,7 @@ typedef struct svt_evidence_batch {
     double disc_weight;         /* --disc_weight  (classic.py:39)                 */
 } svt_evidence_batch;
 
-/* ---- results, SoA, caller-allocated host arrays --------------------------- */
+/* ---- genotype codes --------------------------------------------------------- */
 #define SVT_GT_HOMREF 0    /* '0/0' */
 #define SVT_GT_HET 1       /* '0/1' */
 #define SVT_GT_HOMALT 2    /* '1/1' */
@@ -148,23 +153,24 @@ typedef struct svt_evidence_batch {
 #define SVT_GT_BLANK (-2)   /* all five tallies are 0: blank result (classic.py:496-513) */
 #define SVT_GT_SKIPPED (-3) /* SVT_UNIT_SKIP                                        */
 
-/* order of the ten integer FORMAT counts + GQ inside svt_results.counts */
+/* order of the ten integer FORMAT counts + GQ inside svt_result.counts */
 enum {
     SVT_CNT_QR = 0, SVT_CNT_QA, SVT_CNT_GQ, SVT_CNT_DP, SVT_CNT_RO, SVT_CNT_AO,
     SVT_CNT_RS, SVT_CNT_AS, SVT_CNT_ASC, SVT_CNT_RP, SVT_CNT_AP, SVT_N_COUNTS
 };
-/* order inside svt_results.tallies (after the zeroing rules, classic.py:425-435) */
+/* order inside svt_result.tallies (after the zeroing rules, classic.py:425-435) */
 enum { SVT_TAL_REF_SEQ = 0, SVT_TAL_ALT_SEQ, SVT_TAL_ALT_CLIP, SVT_TAL_REF_SPAN,
        SVT_TAL_ALT_SPAN, SVT_N_TALLIES };
 
-typedef struct svt_results {
-    uint64_t n_units;
-    double* gl;       /* [3][n_units]  log10 likelihoods homref/het/homalt       */
-    double* sq;       /* [n_units]     0 when gt < 0                             */
-    double* tallies;  /* [5][n_units]  SVT_TAL_* order                            */
-    int32_t* counts;  /* [SVT_N_COUNTS][n_units]; GQ = -1 when gt < 0             */
-    int8_t* gt;       /* [n_units]     SVT_GT_*                                   */
-} svt_results;
+/* ---- result record: one per unit, 128 B (one L2 line, written by one lane) -- */
+typedef struct svt_result {
+    double gl[3];                 /* log10 likelihoods homref/het/homalt (statistics.py:33-37) */
+    double sq;                    /* 0 when gt < 0                                             */
+    double tallies[SVT_N_TALLIES];
+    int32_t counts[SVT_N_COUNTS]; /* GQ = -1 when gt < 0                                       */
+    int8_t gt;                    /* SVT_GT_*                                                  */
+    uint8_t pad[11];              /* zero                                                      */
+} svt_result;
 
 typedef struct svt_batch svt_batch; /* opaque: device-resident packed batch */
 
@@ -197,18 +203,18 @@ int svt_batch_genotype(svt_batch* b, int sync);
  * *ms_total receives the elapsed milliseconds of all `iters` launches.          */
 int svt_batch_genotype_timed(svt_batch* b, int iters, float* ms_total);
 
-/* Copy the results of the last svt_batch_genotype to host arrays (blocking).   */
-int svt_batch_results(svt_batch* b, svt_results* out);
+/* Copy the result records of the last svt_batch_genotype to out[n_units] (blocking). */
+int svt_batch_results(svt_batch* b, svt_result* out, uint64_t n_units);
 
-/* Device pointers of the result arrays (same SoA shapes as svt_results), for a
- * caller that keeps working on the GPU (e.g. an RCCL gather of shard results).
- * Valid until svt_batch_destroy.                                               */
-int svt_batch_device_results(svt_batch* b, svt_results* dev_ptrs);
+/* Device pointer of the result records (svt_result[n_units]) the kernel currently
+ * writes to, for a caller that keeps working on the GPU.                          */
+int svt_batch_device_results(svt_batch* b, svt_result** dev_ptr);
 
-/* Make the kernel write its results straight into caller-owned DEVICE buffers (same SoA
- * shapes; e.g. a torch tensor that is then gathered over RCCL).  The buffers must stay alive
- * until svt_batch_destroy or the next bind; pass NULL to return to the internal buffers.      */
-int svt_batch_bind_device_results(svt_batch* b, const svt_results* dev_ptrs);
+/* Make the kernel write its result records straight into a caller-owned DEVICE buffer of
+ * n_units * sizeof(svt_result) bytes, 128-byte aligned (e.g. a torch tensor that is then
+ * gathered over RCCL).  The buffer must stay alive until svt_batch_destroy or the next bind;
+ * pass NULL to return to the library's own buffer.                                         */
+int svt_batch_bind_device_results(svt_batch* b, svt_result* dev_ptr);
 
 /* Bytes the genotype kernel must move per pass by the definition of SURVEY.md
  * section 8(d): sum_u (16*F(u) + 16 + 96); and what the tiled layout really
@@ -221,7 +227,7 @@ void* svt_batch_stream(svt_batch* b);
 void svt_batch_destroy(svt_batch* b);
 
 /* Convenience: create + genotype + results + destroy.                          */
-int svt_genotype(const svt_evidence_batch* in, svt_results* out, int device,
+int svt_genotype(const svt_evidence_batch* in, svt_result* out, int device,
                  unsigned flags);
 
 #ifdef __cplusplus

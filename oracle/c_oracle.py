@@ -7,8 +7,8 @@ import subprocess
 
 import numpy as np
 
-from svtyper_amd.evidence import (CEvidenceBatch, CLibrary, CResults, EvidenceBatch,
-                                  LibraryTable, N_COUNTS, N_TALLIES, Results)
+from svtyper_amd.evidence import (CEvidenceBatch, CLibrary, EvidenceBatch, LibraryTable,
+                                  N_COUNTS, N_TALLIES, Results)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libsvt_oracle.so")
@@ -43,8 +43,7 @@ def lib() -> C.CDLL:
                                           C.POINTER(C.c_double), C.POINTER(C.c_double),
                                           C.POINTER(C.c_int32), C.POINTER(C.c_int8)]
         L.svt_oracle_batch.restype = C.c_int
-        L.svt_oracle_batch.argtypes = [C.POINTER(CEvidenceBatch), C.POINTER(CResults), C.c_uint,
-                                       C.c_int]
+        L.svt_oracle_batch.argtypes = [C.POINTER(CEvidenceBatch), C.c_void_p, C.c_uint, C.c_int]
         L.svt_oracle_threads.restype = C.c_int
         _lib = L
     return _lib
@@ -88,8 +87,7 @@ def genotype_from_tallies(tallies, svtype: int, split_weight=1.0, disc_weight=1.
 def genotype_batch(batch: EvidenceBatch, flags: int = 0, n_threads: int = 0) -> Results:
     out = Results.empty(batch.n_units)
     cb = batch.as_c()
-    cr = out.as_c()
-    rc = lib().svt_oracle_batch(C.byref(cb), C.byref(cr), int(flags), int(n_threads))
+    rc = lib().svt_oracle_batch(C.byref(cb), C.c_void_p(out.ptr()), int(flags), int(n_threads))
     if rc != 0:
         raise RuntimeError("svt_oracle_batch failed: %d" % rc)
     return out

@@ -131,7 +131,7 @@ void svt_oracle_tally(const svt_unit* unit, const svt_record* recs, uint64_t n_r
     for (uint64_t j = 0; j < n_recs; ++j) {
         const svt_record* r = &recs[j];
         const uint32_t f = r->flags;
-        const svt_library* lib = &libs[r->lib];
+        const svt_library* lib = &libs[SVT_REC_LIB(f)];
 
         if (sso && !(f & SVT_REC_CONTINUATION)) {
             /* singlesample.py:370-372: site totals += fragment-local sums */
@@ -139,32 +139,29 @@ void svt_oracle_tally(const svt_unit* unit, const svt_record* recs, uint64_t n_r
             l_ref_seq = 0; l_alt_seq = 0; l_alt_clip = 0;
         }
 
-        /* --- reference split-read evidence: classic.py:306-311 --- */
-        if (f & SVT_REC_REFSEQ_A) { if (sso) l_ref_seq += pmapq[r->mapq_a]; else ref_seq += pmapq[r->mapq_a]; }
-        if (f & SVT_REC_REFSEQ_B) { if (sso) l_ref_seq += pmapq[r->mapq_b]; else ref_seq += pmapq[r->mapq_b]; }
+        /* --- reference split-read evidence: classic.py:306-311.  rs_x is the read's MAPQ when
+         * is_ref_seq holds and 0 otherwise; prob_mapq(0) == 0.0 so the add is a no-op then. */
+        if (sso) { l_ref_seq += pmapq[r->rs_a]; l_ref_seq += pmapq[r->rs_b]; }
+        else     { ref_seq += pmapq[r->rs_a];   ref_seq += pmapq[r->rs_b]; }
 
-        /* --- alternate split-read evidence: classic.py:317-328 --- */
-        for (int s = 0; s < 2; ++s) {
-            if (!(f & (s ? SVT_REC_S1_PRESENT : SVT_REC_S0_PRESENT))) continue;
-            int L = (f & (s ? SVT_REC_S1_L : SVT_REC_S0_L)) != 0;
-            int R = (f & (s ? SVT_REC_S1_R : SVT_REC_S0_R)) != 0;
-            double pl = pmapq[s ? r->s1_left : r->s0_left];
-            double pr = pmapq[s ? r->s1_right : r->s0_right];
-            double p_alt = (pl * L + pr * R) / 2.0;                 /* :324 */
-            if (f & (s ? SVT_REC_S1_SOFT : SVT_REC_S0_SOFT)) {      /* :325-328 */
-                if (sso) l_alt_clip += p_alt; else alt_clip += p_alt;
-            } else {
-                if (sso) l_alt_seq += p_alt; else alt_seq += p_alt;
-            }
+        /* --- alternate split-read evidence: classic.py:317-328
+         *     p_alt = (prob_mapq(left) * L + prob_mapq(right) * R) / 2.0  with the booleans
+         *     L, R already folded into the bytes (MAPQ 0 where False). */
+        {
+            double p_seq = (pmapq[r->seq_l] + pmapq[r->seq_r]) / 2.0;      /* not is_soft_clip */
+            double p_clip = (pmapq[r->clip_l] + pmapq[r->clip_r]) / 2.0;   /* is_soft_clip     */
+            if (sso) { l_alt_seq += p_seq; l_alt_clip += p_clip; }
+            else     { alt_seq += p_seq;   alt_clip += p_clip; }
         }
 
         /* --- paired-end evidence: classic.py:339-408 --- */
         const int small_del = is_del && ((double)unit->pos_delta < 2 * lib->sd); /* :339,383 */
         const int alt_straddle = !small_del && (f & SVT_REC_ALT_STRADDLE);       /* :339-357 */
         const double pm_a = pmapq[r->mapq_a], pm_b = pmapq[r->mapq_b];
+        const uint32_t li = SVT_REC_LIB(f);
         if (alt_straddle) {                                                      /* :359 */
             if (is_del) {                                                        /* :360-364 */
-                int p_conc = svt_oracle_p_concordant(lib, lib_totals[r->lib], r->ospan_len, 1,
+                int p_conc = svt_oracle_p_concordant(lib, lib_totals[li], r->ospan_len, 1,
                                                      unit->var_length);
                 alt_span += (1 - p_conc) * pm_a * pm_b;
             } else {
@@ -175,7 +172,7 @@ void svt_oracle_tally(const svt_unit* unit, const svt_record* recs, uint64_t n_r
         const int rs_b = !small_del && (f & SVT_REC_REF_STRADDLE_B);
         if (rs_a || rs_b) {                                                      /* :398 */
             if (!(rs_a && rs_b) || is_del) {                                     /* :401 */
-                int p_conc = svt_oracle_p_concordant(lib, lib_totals[r->lib], r->ospan_len,
+                int p_conc = svt_oracle_p_concordant(lib, lib_totals[li], r->ospan_len,
                                                      is_del, unit->var_length);  /* :402 */
                 double p_reference = p_conc * pm_a * pm_b;                       /* :404 */
                 ref_span += (rs_a + rs_b) * p_reference / 2;                     /* :405 */
@@ -256,12 +253,11 @@ void svt_oracle_genotype(const double t[SVT_N_TALLIES], int svtype, double split
     }
 }
 
-int svt_oracle_batch(const svt_evidence_batch* in, svt_results* out, unsigned flags,
+int svt_oracle_batch(const svt_evidence_batch* in, svt_result* out, unsigned flags,
                      int n_threads)
 {
     const uint64_t n = in->n_units;
     const int sso = (flags & SVT_FLAG_SSO_ASSOCIATION) != 0;
-    if (out->n_units != n) return -1;
     double pmapq[256];
     for (int q = 0; q < 256; ++q) pmapq[q] = svt_oracle_prob_mapq(q);
     uint64_t* totals = (uint64_t*)malloc(sizeof(uint64_t) * (in->n_libs ? in->n_libs : 1));
@@ -275,24 +271,19 @@ int svt_oracle_batch(const svt_evidence_batch* in, svt_results* out, unsigned fl
 #endif
 #pragma omp parallel for schedule(dynamic, 256) num_threads(nt)
     for (int64_t u = 0; u < (int64_t)n; ++u) {
-        double t[SVT_N_TALLIES], gl[3], sq;
-        int32_t c[SVT_N_COUNTS];
-        int8_t gt;
+        svt_result* r = &out[u];
         const svt_unit* unit = &in->units[u];
+        memset(r, 0, sizeof *r);
         if (unit->flags & SVT_UNIT_SKIP) {
-            memset(t, 0, sizeof t); memset(c, 0, sizeof c);
-            gl[0] = gl[1] = gl[2] = 0; sq = 0; c[SVT_CNT_GQ] = -1; gt = SVT_GT_SKIPPED;
+            r->counts[SVT_CNT_GQ] = -1;
+            r->gt = SVT_GT_SKIPPED;
         } else {
             svt_oracle_tally(unit, in->records + in->rec_offset[u],
                              in->rec_offset[u + 1] - in->rec_offset[u], in->libs, totals,
-                             pmapq, sso, t);
-            svt_oracle_genotype(t, unit->svtype, in->split_weight, in->disc_weight, gl, &sq, c, &gt);
+                             pmapq, sso, r->tallies);
+            svt_oracle_genotype(r->tallies, unit->svtype, in->split_weight, in->disc_weight,
+                                r->gl, &r->sq, r->counts, &r->gt);
         }
-        for (int g = 0; g < 3; ++g) out->gl[(uint64_t)g * n + u] = gl[g];
-        out->sq[u] = sq;
-        for (int k = 0; k < SVT_N_TALLIES; ++k) out->tallies[(uint64_t)k * n + u] = t[k];
-        for (int k = 0; k < SVT_N_COUNTS; ++k) out->counts[(uint64_t)k * n + u] = c[k];
-        out->gt[u] = gt;
     }
     free(totals);
     return 0;

@@ -24,7 +24,7 @@ void svt_oracle_genotype(const double tallies[SVT_N_TALLIES], int svtype, double
                          double disc_weight, double gl[3], double* sq,
                          int32_t counts[SVT_N_COUNTS], int8_t* gt);
 /* whole batch; n_threads <= 0 keeps the OpenMP default */
-int svt_oracle_batch(const svt_evidence_batch* in, svt_results* out, unsigned flags, int n_threads);
+int svt_oracle_batch(const svt_evidence_batch* in, svt_result* out, unsigned flags, int n_threads);
 int svt_oracle_threads(void);
 
 #ifdef __cplusplus

@@ -48,7 +48,7 @@ constexpr int kWavesPerBlock = 4;    // 256-thread workgroups
 constexpr int kBlock = kWave * kWavesPerBlock;
 constexpr uint32_t kChunkUnits = 4096;  // sort window (units); results scatter stays inside it
 constexpr uint32_t kPadUnit = 0xFFFFFFFFu;
-constexpr uint32_t kMaxLdsTableBytes = 96 * 1024;  // hist+T budget before falling back to global
+constexpr uint32_t kMaxLdsTableBytes = 64 * 1024;  // hist+thr budget before falling back to HBM/L2 tables
 constexpr uint32_t kMaxL10Lds = 4096;              // log10 table entries kept in LDS (32 KiB)
 
 thread_local std::string g_err;
@@ -70,7 +70,8 @@ int fail(int code, const std::string& msg)
 // device-side structures
 // ------------------------------------------------------------------------------------------
 struct LibDesc {          // 32 B, one per library
-    uint32_t tab_off;     // offset of this library's bins inside hist[] / thr[]
+    uint32_t tab_off;     // offset of this library's bins inside hist[] / thr[] (each library
+                          // owns n_bins + 1 entries; the last one is the out-of-range sentinel)
     int32_t key_min;
     uint32_t n_bins;
     uint32_t pad;
@@ -100,15 +101,30 @@ struct GtConsts {
     double disc_weight;
 };
 
+// Paired-end decision table (classic.py:359-405), 32 entries of {w_alt, w_ref}:
+//   index = alt_straddle | ref_straddle_A << 1 | ref_straddle_B << 2 | p_concordant << 3 | is_DEL << 4
+//   alt_span += (pmA * pmB) * w_alt      w_alt in {0, 1}
+//   ref_span += (pmA * pmB) * w_ref      w_ref in {0, 0.5, 1}     ((A + B) * p / 2)
+// Multiplying a finite non-negative binary64 by 0, 0.5 or 1 is exact, so this is the reference's
+// arithmetic with the branch structure moved into a lookup.
+struct PairWeights { double w_alt, w_ref; };
+
+enum LibMode : int {
+    kSingleLds = 0,  // one library, descriptor in SGPRs, tables in LDS, 32-bit index math
+    kMultiLds = 1,   // several libraries, descriptors + tables in LDS, 32-bit index math
+    kGeneral = 2     // any geometry: 64-bit index math, exact float Counter key, tables in HBM/L2
+};
+
 struct KernelArgs {
     const uint4* tiled;
     const TileDesc* tiles;
     const LaneHdr* hdr;
-    const double* pm;        // 256
-    const double* l10;       // n_l10
-    const LibDesc* libs;     // n_libs
-    const uint32_t* hist;    // total_bins
-    const int32_t* thr;      // total_bins
+    const double* pm;          // 256
+    const double* l10;         // n_l10
+    const LibDesc* libs;       // n_libs
+    const uint32_t* hist;      // total_bins (sentinels included)
+    const int32_t* thr;        // total_bins
+    const PairWeights* wtab;   // 32
     uint32_t n_l10;
     uint32_t n_libs;
     uint32_t total_bins;
@@ -116,11 +132,8 @@ struct KernelArgs {
     uint32_t l10_in_lds;
     uint32_t pad0;
     uint64_t n_units;
-    double* gl;              // [3][n]
-    double* sq;              // [n]
-    double* tallies;         // [5][n]
-    int32_t* counts;         // [11][n]
-    int8_t* gt;              // [n]
+    svt_result* out;           // [n_units]
+    LibDesc lib0;              // copy of libs[0] (kSingleLds)
     GtConsts c;
 };
 
@@ -128,10 +141,11 @@ struct KernelArgs {
 // genotype kernel
 // ------------------------------------------------------------------------------------------
 struct Tables {
-    const double* pm;        // LDS
-    const LibDesc* libs;     // LDS
-    const uint32_t* hist;    // LDS or global
-    const int32_t* thr;      // LDS or global
+    const double* pm;          // LDS
+    const PairWeights* wtab;   // LDS
+    const LibDesc* libs;       // LDS
+    const uint32_t* hist;      // LDS (kGeneral: global)
+    const int32_t* thr;
 };
 
 struct Acc {
@@ -139,87 +153,105 @@ struct Acc {
     double l_ref_seq, l_alt_seq, l_alt_clip;  // sso fragment-local sums
 };
 
-// One evidence record.  All adds are unconditional adds of (cond ? x : +0.0): x + 0.0 == x
-// bit-for-bit for the non-negative sums involved, so predication never changes a result.
-template <bool SSO>
-__device__ __forceinline__ void tally_record(const uint4 w, const Tables& t, const bool is_del,
-                                             const int32_t var_length, const double pos_delta_d,
-                                             Acc& a)
+// per-lane constants of the unit, hoisted out of the record loop
+struct LaneCtx {
+    uint32_t del16;       // is_DEL ? 16 : 0 (decision-table index bit)
+    uint32_t fmask;       // kSingleLds: flag mask with the small-DEL gate applied
+    uint32_t kmin;        // kSingleLds: (uint32) key_min
+    uint32_t nb;          // kSingleLds: n_bins (== sentinel index)
+    uint32_t sub2;        // kSingleLds: DEL ? var_length + key_min : 0x80000000 (never in range)
+    int32_t var_length;
+    double pos_delta_d;
+    bool is_del;
+};
+
+// One evidence record.  Every add is unconditional: gated-off evidence arrives as MAPQ 0, whose
+// weight prob_mapq(0) is exactly +0.0, and x + 0.0 == x bit-for-bit for these non-negative sums.
+template <bool SSO, int MODE>
+__device__ __forceinline__ void tally_record(const uint4 w, const Tables& t, const LaneCtx& c, Acc& a)
 {
-    const uint32_t f = w.w;
+    // ---- prob_mapq look-ups (utils.py:74-75 through the host-built LUT)
     const double pm_a = t.pm[w.y & 0xffu];
     const double pm_b = t.pm[(w.y >> 8) & 0xffu];
-    const double ps0l = t.pm[(w.y >> 16) & 0xffu];
-    const double ps0r = t.pm[w.y >> 24];
-    const double ps1l = t.pm[w.z & 0xffu];
-    const double ps1r = t.pm[(w.z >> 8) & 0xffu];
-    const LibDesc lib = t.libs[(w.z >> 16) & 0xffu];
+    const double rs_a = t.pm[(w.y >> 16) & 0xffu];
+    const double rs_b = t.pm[w.y >> 24];
+    const double sq_l = t.pm[w.z & 0xffu];
+    const double sq_r = t.pm[(w.z >> 8) & 0xffu];
+    const double cl_l = t.pm[(w.z >> 16) & 0xffu];
+    const double cl_r = t.pm[w.z >> 24];
 
-    // ---- reference split-read evidence (classic.py:306-311)
-    const double rsa = (f & SVT_REC_REFSEQ_A) ? pm_a : 0.0;
-    const double rsb = (f & SVT_REC_REFSEQ_B) ? pm_b : 0.0;
-    // ---- alternate split-read evidence (classic.py:317-328):
-    //      p_alt = (pm(left) * L + pm(right) * R) / 2.0
-    const double p0 = (((f & SVT_REC_S0_L) ? ps0l : 0.0) + ((f & SVT_REC_S0_R) ? ps0r : 0.0)) * 0.5;
-    const double p1 = (((f & SVT_REC_S1_L) ? ps1l : 0.0) + ((f & SVT_REC_S1_R) ? ps1r : 0.0)) * 0.5;
-    const double as0 = (f & SVT_REC_S0_SOFT) ? 0.0 : p0;
-    const double ac0 = (f & SVT_REC_S0_SOFT) ? p0 : 0.0;
-    const double as1 = (f & SVT_REC_S1_SOFT) ? 0.0 : p1;
-    const double ac1 = (f & SVT_REC_S1_SOFT) ? p1 : 0.0;
-
+    // ---- split-read evidence (classic.py:306-328): p_alt = (pm(left)*L + pm(right)*R) / 2.0
+    const double p_seq = (sq_l + sq_r) * 0.5;
+    const double p_clip = (cl_l + cl_r) * 0.5;
     if (SSO) {
-        // singlesample.py:246-276,367-372: per-fragment sums starting from 0, flushed into the
-        // site totals when the next fragment starts
-        const bool cont = (f & SVT_REC_CONTINUATION) != 0;
+        // singlesample.py:246-276,367-372: per-fragment sums starting from 0, added to the site
+        // totals when the next fragment starts
+        const bool cont = (w.w & SVT_REC_CONTINUATION) != 0;
         a.ref_seq += cont ? 0.0 : a.l_ref_seq;
         a.alt_seq += cont ? 0.0 : a.l_alt_seq;
         a.alt_clip += cont ? 0.0 : a.l_alt_clip;
-        a.l_ref_seq = ((cont ? a.l_ref_seq : 0.0) + rsa) + rsb;
-        a.l_alt_seq = ((cont ? a.l_alt_seq : 0.0) + as0) + as1;
-        a.l_alt_clip = ((cont ? a.l_alt_clip : 0.0) + ac0) + ac1;
+        a.l_ref_seq = ((cont ? a.l_ref_seq : 0.0) + rs_a) + rs_b;
+        a.l_alt_seq = (cont ? a.l_alt_seq : 0.0) + p_seq;
+        a.l_alt_clip = (cont ? a.l_alt_clip : 0.0) + p_clip;
     } else {
-        a.ref_seq = (a.ref_seq + rsa) + rsb;
-        a.alt_seq = (a.alt_seq + as0) + as1;
-        a.alt_clip = (a.alt_clip + ac0) + ac1;
+        a.ref_seq = (a.ref_seq + rs_a) + rs_b;
+        a.alt_seq += p_seq;
+        a.alt_clip += p_clip;
     }
 
-    // ---- paired-end evidence (classic.py:339-408)
-    const bool small_del = is_del && (pos_delta_d < lib.sd2);           // :339, :383
-    const bool alt_st = !small_del && (f & SVT_REC_ALT_STRADDLE);
-    const bool rs_a = !small_del && (f & SVT_REC_REF_STRADDLE_A);
-    const bool rs_b = !small_del && (f & SVT_REC_REF_STRADDLE_B);
-    const bool both = rs_a && rs_b;
-    const bool need_ref = (rs_a || rs_b) && (!both || is_del);          // :398-401
-
-    // p_concordant (parsers.py:861-882) as an integer test: with d1 = hist[o]/N fixed, the
+    // ---- p_concordant (parsers.py:861-882) as an integer test: with d1 = hist[o]/N fixed, the
     // reference's binary64 expression d1*0.95/(0.95*d1 + 0.05*d2) > 0.5 is monotone in
-    // h2 = hist[o - v]; thr[o] is the largest h2 for which it still holds (evaluated on the host
-    // with the reference's own expression), -1 where hist[o] == 0 (p == 0 or ZeroDivisionError).
-    const int32_t o = (int32_t)w.x;
-    const int64_t i1 = (int64_t)o - (int64_t)lib.key_min;
-    const bool in1 = (uint64_t)i1 < (uint64_t)lib.n_bins;
-    const int32_t thr1 = in1 ? t.thr[lib.tab_off + (uint32_t)(in1 ? i1 : 0)] : -1;
-    int64_t key2;
-    bool key2_ok = true;
-    if (is_del) {
-        key2 = (int64_t)o - (int64_t)var_length;
+    // h2 = hist[o - v]; thr[o] is the largest h2 for which it still holds (found on the host with
+    // the reference's own expression), -1 where hist[o] == 0 (p == 0 or ZeroDivisionError).
+    const uint32_t o = w.x;
+    uint32_t f;
+    int32_t thr1;
+    uint32_t h2;
+    if (MODE == kSingleLds) {
+        f = w.w & c.fmask;
+        const uint32_t i1 = min(o - c.kmin, c.nb);      // out of range -> sentinel (thr -1)
+        const uint32_t i2 = min(o - c.sub2, c.nb);      // out of range -> sentinel (hist 0)
+        thr1 = t.thr[i1];
+        h2 = t.hist[i2];
+    } else if (MODE == kMultiLds) {
+        const LibDesc lib = t.libs[SVT_REC_LIB(w.w)];
+        const bool small_del = c.is_del && (c.pos_delta_d < lib.sd2);     // classic.py:339,383
+        f = small_del ? (w.w & ~7u) : w.w;
+        const uint32_t kmin = (uint32_t)lib.key_min;
+        const uint32_t sub2 = c.is_del ? (uint32_t)c.var_length + kmin : 0x80000000u;
+        const uint32_t i1 = min(o - kmin, lib.n_bins);
+        const uint32_t i2 = min(o - sub2, lib.n_bins);
+        thr1 = t.thr[lib.tab_off + i1];
+        h2 = t.hist[lib.tab_off + i2];
     } else {
-        // var_length is None: Counter key is the FLOAT o - (mean + 3 sd); it only matches an
-        // integer key when it is integral (parsers.py:874-878)
-        const double kf = (double)o - lib.v_nondel;
-        key2_ok = (kf == floor(kf)) && (fabs(kf) < 4.0e9);
-        key2 = key2_ok ? (int64_t)kf : 0;
+        const LibDesc lib = t.libs[SVT_REC_LIB(w.w)];
+        const bool small_del = c.is_del && (c.pos_delta_d < lib.sd2);
+        f = small_del ? (w.w & ~7u) : w.w;
+        const int64_t i1 = (int64_t)(int32_t)o - (int64_t)lib.key_min;
+        const bool in1 = (uint64_t)i1 < (uint64_t)lib.n_bins;
+        thr1 = t.thr[lib.tab_off + (in1 ? (uint32_t)i1 : lib.n_bins)];
+        int64_t key2;
+        bool ok2 = true;
+        if (c.is_del) {
+            key2 = (int64_t)(int32_t)o - (int64_t)c.var_length;
+        } else {
+            // var_length is None: the Counter key is the FLOAT o - (mean + 3 sd); it only matches
+            // an integer key when it is integral (parsers.py:874-878)
+            const double kf = (double)(int32_t)o - lib.v_nondel;
+            ok2 = (kf == floor(kf)) && (fabs(kf) < 4.0e9);
+            key2 = ok2 ? (int64_t)kf : 0;
+        }
+        const int64_t i2 = key2 - (int64_t)lib.key_min;
+        const bool in2 = ok2 && ((uint64_t)i2 < (uint64_t)lib.n_bins);
+        h2 = t.hist[lib.tab_off + (in2 ? (uint32_t)i2 : lib.n_bins)];
     }
-    const int64_t i2 = key2 - (int64_t)lib.key_min;
-    const bool in2 = key2_ok && ((uint64_t)i2 < (uint64_t)lib.n_bins);
-    const int32_t h2 = in2 ? (int32_t)t.hist[lib.tab_off + (uint32_t)(in2 ? i2 : 0)] : 0;
-    const bool p_conc = h2 <= thr1;
+    const bool p_conc = (int32_t)h2 <= thr1;
 
+    // ---- paired-end evidence (classic.py:339-408) through the decision table
+    const PairWeights pw = t.wtab[(f & 7u) | (p_conc ? 8u : 0u) | c.del16];
     const double pp = pm_a * pm_b;
-    // DEL: alt_span += (1 - p_conc) * pmA * pmB (:363-364); others: pmA * pmB (:376-377)
-    a.alt_span += (alt_st && !(is_del && p_conc)) ? pp : 0.0;
-    // ref_span += (A + B) * (p_conc * pmA * pmB) / 2 (:404-405): 2*pp/2 == pp, 1*pp/2 == pp*0.5
-    a.ref_span += (need_ref && p_conc) ? (both ? pp : pp * 0.5) : 0.0;
+    a.alt_span += pp * pw.w_alt;
+    a.ref_span += pp * pw.w_ref;
 }
 
 __device__ __forceinline__ double log_choose_dev(const double* __restrict__ l10, int32_t n, int32_t k)
@@ -235,24 +267,33 @@ __device__ __forceinline__ double log_choose_dev(const double* __restrict__ l10,
     return r;
 }
 
-template <bool SSO, bool LDS_TABLES>
+__device__ __forceinline__ uint4 pack2d(double x, double y)
+{
+    const uint64_t a = (uint64_t)__double_as_longlong(x), b = (uint64_t)__double_as_longlong(y);
+    return make_uint4((uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32));
+}
+
+template <bool SSO, int MODE>
 __global__ __launch_bounds__(kBlock) void svt_genotype_kernel(const KernelArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // LDS layout: pm[256] | wtab[32] | l10[n_l10 (even)] | libs[n_libs] | hist[total_bins] | thr[total_bins]
     double* s_pm = reinterpret_cast<double*>(smem);
+    PairWeights* s_wtab = reinterpret_cast<PairWeights*>(s_pm + 256);
+    double* s_l10 = reinterpret_cast<double*>(s_wtab + 32);
     const uint32_t n_l10_lds = a.l10_in_lds ? ((a.n_l10 + 1u) & ~1u) : 0u;
-    double* s_l10 = s_pm + 256;
     LibDesc* s_lib = reinterpret_cast<LibDesc*>(s_l10 + n_l10_lds);
     uint32_t* s_hist = reinterpret_cast<uint32_t*>(s_lib + a.n_libs);
-    int32_t* s_thr = reinterpret_cast<int32_t*>(s_hist + (LDS_TABLES ? a.total_bins : 0u));
+    int32_t* s_thr = reinterpret_cast<int32_t*>(s_hist + (MODE != kGeneral ? a.total_bins : 0u));
 
-    // ---- stage the tables in LDS (L2-resident after the first workgroups)
+    // ---- stage the tables in LDS (they are L2-resident after the first workgroups)
     for (uint32_t i = threadIdx.x; i < 256; i += kBlock) s_pm[i] = a.pm[i];
+    if (threadIdx.x < 32) s_wtab[threadIdx.x] = a.wtab[threadIdx.x];
     if (a.l10_in_lds)
         for (uint32_t i = threadIdx.x; i < a.n_l10; i += kBlock) s_l10[i] = a.l10[i];
-    for (uint32_t i = threadIdx.x; i < a.n_libs * (sizeof(LibDesc) / 8); i += kBlock)
+    for (uint32_t i = threadIdx.x; i < a.n_libs * (uint32_t)(sizeof(LibDesc) / 8); i += kBlock)
         reinterpret_cast<uint64_t*>(s_lib)[i] = reinterpret_cast<const uint64_t*>(a.libs)[i];
-    if (LDS_TABLES) {
+    if (MODE != kGeneral) {
         for (uint32_t i = threadIdx.x; i < a.total_bins; i += kBlock) {
             s_hist[i] = a.hist[i];
             s_thr[i] = a.thr[i];
@@ -269,35 +310,49 @@ __global__ __launch_bounds__(kBlock) void svt_genotype_kernel(const KernelArgs a
     const LaneHdr h = a.hdr[td.lane_base + lane];
     const uint32_t svtype = h.packed & 0xffu;
     const uint32_t uflags = (h.packed >> 8) & 0xffu;
-    const bool is_del = svtype == SVT_SVTYPE_DEL;
-    const double pos_delta_d = (double)h.pos_delta;
 
     Tables t;
     t.pm = s_pm;
+    t.wtab = s_wtab;
     t.libs = s_lib;
-    t.hist = LDS_TABLES ? s_hist : a.hist;
-    t.thr = LDS_TABLES ? s_thr : a.thr;
+    t.hist = MODE != kGeneral ? s_hist : a.hist;
+    t.thr = MODE != kGeneral ? s_thr : a.thr;
+
+    LaneCtx c;
+    c.is_del = svtype == SVT_SVTYPE_DEL;
+    c.del16 = c.is_del ? 16u : 0u;
+    c.var_length = h.var_length;
+    c.pos_delta_d = (double)h.pos_delta;
+    {
+        const bool small_del = c.is_del && (c.pos_delta_d < a.lib0.sd2);  // classic.py:339,383
+        c.fmask = small_del ? ~7u : ~0u;
+        c.kmin = (uint32_t)a.lib0.key_min;
+        c.nb = a.lib0.n_bins;
+        c.sub2 = c.is_del ? (uint32_t)h.var_length + (uint32_t)a.lib0.key_min : 0x80000000u;
+    }
 
     Acc acc = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
 
-    // ---- stream the tile: row j is one contiguous 1 KiB line for the wave
+    // ---- stream the tile: row j is one contiguous 1 KiB line for the wave.  Rows are fetched
+    // four at a time, one group ahead of the group being tallied (the buffer has a 4-row tail
+    // pad, so the look-ahead never leaves the allocation).
     const uint4* __restrict__ p = a.tiled + td.rec_base + lane;
     const uint32_t rows = td.rows;
+    uint4 c0 = p[0 * kWave], c1 = p[1 * kWave], c2 = p[2 * kWave], c3 = p[3 * kWave];
     uint32_t j = 0;
     for (; j + 4 <= rows; j += 4) {
-        const uint4 w0 = p[(uint64_t)(j + 0) * kWave];
-        const uint4 w1 = p[(uint64_t)(j + 1) * kWave];
-        const uint4 w2 = p[(uint64_t)(j + 2) * kWave];
-        const uint4 w3 = p[(uint64_t)(j + 3) * kWave];
-        tally_record<SSO>(w0, t, is_del, h.var_length, pos_delta_d, acc);
-        tally_record<SSO>(w1, t, is_del, h.var_length, pos_delta_d, acc);
-        tally_record<SSO>(w2, t, is_del, h.var_length, pos_delta_d, acc);
-        tally_record<SSO>(w3, t, is_del, h.var_length, pos_delta_d, acc);
+        const uint4* __restrict__ q = p + (uint64_t)(j + 4) * kWave;
+        const uint4 n0 = q[0 * kWave], n1 = q[1 * kWave], n2 = q[2 * kWave], n3 = q[3 * kWave];
+        tally_record<SSO, MODE>(c0, t, c, acc);
+        tally_record<SSO, MODE>(c1, t, c, acc);
+        tally_record<SSO, MODE>(c2, t, c, acc);
+        tally_record<SSO, MODE>(c3, t, c, acc);
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
     }
-    for (; j < rows; ++j) {
-        const uint4 w0 = p[(uint64_t)j * kWave];
-        tally_record<SSO>(w0, t, is_del, h.var_length, pos_delta_d, acc);
-    }
+    const uint32_t rem = rows - j;  // wave-uniform
+    if (rem > 0) tally_record<SSO, MODE>(c0, t, c, acc);
+    if (rem > 1) tally_record<SSO, MODE>(c1, t, c, acc);
+    if (rem > 2) tally_record<SSO, MODE>(c2, t, c, acc);
     if (SSO) {  // flush the last fragment (singlesample.py:370-372)
         acc.ref_seq += acc.l_ref_seq;
         acc.alt_seq += acc.l_alt_seq;
@@ -382,21 +437,20 @@ __global__ __launch_bounds__(kBlock) void svt_genotype_kernel(const KernelArgs a
         }
     }
 
-    // ---- scatter to the unit's slot (stays inside the unit's 4096-unit chunk)
-    const uint64_t u = h.unit;
-    const uint64_t n = a.n_units;
-    a.gl[u] = gl[0];
-    a.gl[n + u] = gl[1];
-    a.gl[2 * n + u] = gl[2];
-    a.sq[u] = sq;
-    a.tallies[0 * n + u] = ref_seq;
-    a.tallies[1 * n + u] = alt_seq;
-    a.tallies[2 * n + u] = alt_clip;
-    a.tallies[3 * n + u] = ref_span;
-    a.tallies[4 * n + u] = alt_span;
-#pragma unroll
-    for (int i = 0; i < SVT_N_COUNTS; ++i) a.counts[(uint64_t)i * n + u] = cnt[i];
-    a.gt[u] = (int8_t)gt;
+    // ---- one 128-byte result record per unit = one full L2 line written by one lane: the
+    // scatter back to the unit's original position costs no partial-line traffic
+    uint4* __restrict__ dst = reinterpret_cast<uint4*>(a.out + h.unit);
+    dst[0] = pack2d(gl[0], gl[1]);
+    dst[1] = pack2d(gl[2], sq);
+    dst[2] = pack2d(ref_seq, alt_seq);
+    dst[3] = pack2d(alt_clip, ref_span);
+    {
+        const uint64_t t4 = (uint64_t)__double_as_longlong(alt_span);
+        dst[4] = make_uint4((uint32_t)t4, (uint32_t)(t4 >> 32), (uint32_t)cnt[0], (uint32_t)cnt[1]);
+    }
+    dst[5] = make_uint4((uint32_t)cnt[2], (uint32_t)cnt[3], (uint32_t)cnt[4], (uint32_t)cnt[5]);
+    dst[6] = make_uint4((uint32_t)cnt[6], (uint32_t)cnt[7], (uint32_t)cnt[8], (uint32_t)cnt[9]);
+    dst[7] = make_uint4((uint32_t)cnt[10], (uint32_t)gt & 0xffu, 0u, 0u);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -428,14 +482,11 @@ __global__ __launch_bounds__(kBlock) void svt_repack_kernel(const RepackArgs a)
         if (j < nrec) {
             w = a.csr[src + j];
             const uint32_t f = w.w;
-            // contract of include/svtyper_hip.h: split bits need PRESENT, straddle bits need
-            // HAS_PAIR, lib < n_libs, reserved == 0, no undefined flag bits
-            if (!(f & SVT_REC_S0_PRESENT) && (f & (SVT_REC_S0_SOFT | SVT_REC_S0_L | SVT_REC_S0_R))) bad |= 1u;
-            if (!(f & SVT_REC_S1_PRESENT) && (f & (SVT_REC_S1_SOFT | SVT_REC_S1_L | SVT_REC_S1_R))) bad |= 1u;
+            // contract of include/svtyper_hip.h
             if (!(f & SVT_REC_HAS_PAIR) &&
                 (f & (SVT_REC_ALT_STRADDLE | SVT_REC_REF_STRADDLE_A | SVT_REC_REF_STRADDLE_B))) bad |= 2u;
-            if (((w.z >> 16) & 0xffu) >= a.n_libs) bad |= 4u;
-            if ((w.z >> 24) != 0u || (f >> 15) != 0u) bad |= 8u;
+            if (SVT_REC_LIB(f) >= a.n_libs) bad |= 4u;
+            if (f & ~SVT_REC_FLAG_MASK) bad |= 8u;
             if ((int32_t)w.x < 0) bad |= 16u;
         }
         a.tiled[td.rec_base + (uint64_t)j * kWave + lane] = w;
@@ -487,10 +538,9 @@ struct svt_batch {
     hipStream_t stream = nullptr;
     uint64_t n_units = 0, n_records = 0, tiled_records = 0;
     uint32_t n_tiles = 0;
-    bool lds_tables = true;
+    int mode = kSingleLds;
     size_t lds_bytes = 0;
     bool have_results = false;
-    bool bound_external = false;
     // device buffers
     uint4* d_tiled = nullptr;
     TileDesc* d_tiles = nullptr;  // dispatch order
@@ -500,11 +550,8 @@ struct svt_batch {
     LibDesc* d_libs = nullptr;
     uint32_t* d_hist = nullptr;
     int32_t* d_thr = nullptr;
-    double* d_gl = nullptr;
-    double* d_sq = nullptr;
-    double* d_tallies = nullptr;
-    int32_t* d_counts = nullptr;
-    int8_t* d_gt = nullptr;
+    PairWeights* d_wtab = nullptr;
+    svt_result* d_out = nullptr;
     KernelArgs args{};
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
@@ -517,7 +564,7 @@ void free_batch(svt_batch* b)
     (void)hipSetDevice(b->device);
     auto F = [](void* p) { if (p) (void)hipFree(p); };
     F(b->d_tiled); F(b->d_tiles); F(b->d_hdr); F(b->d_pm); F(b->d_l10); F(b->d_libs);
-    F(b->d_hist); F(b->d_thr); F(b->d_gl); F(b->d_sq); F(b->d_tallies); F(b->d_counts); F(b->d_gt);
+    F(b->d_hist); F(b->d_thr); F(b->d_wtab); F(b->d_out);
     if (b->ev0) (void)hipEventDestroy(b->ev0);
     if (b->ev1) (void)hipEventDestroy(b->ev1);
     if (b->stream) (void)hipStreamDestroy(b->stream);
@@ -533,18 +580,22 @@ int upload(T** dptr, const std::vector<T>& v, hipStream_t s)
     return SVT_OK;
 }
 
+template <bool SSO>
+void launch_mode(svt_batch* b, dim3 grid, dim3 block)
+{
+    switch (b->mode) {
+    case kSingleLds: hipLaunchKernelGGL((svt_genotype_kernel<SSO, kSingleLds>), grid, block, b->lds_bytes, b->stream, b->args); break;
+    case kMultiLds:  hipLaunchKernelGGL((svt_genotype_kernel<SSO, kMultiLds>), grid, block, b->lds_bytes, b->stream, b->args); break;
+    default:         hipLaunchKernelGGL((svt_genotype_kernel<SSO, kGeneral>), grid, block, b->lds_bytes, b->stream, b->args); break;
+    }
+}
+
 int launch_genotype(svt_batch* b)
 {
     if (b->n_tiles == 0) return SVT_OK;
     const dim3 grid((b->n_tiles + kWavesPerBlock - 1) / kWavesPerBlock), block(kBlock);
-    const bool sso = (b->flags & SVT_FLAG_SSO_ASSOCIATION) != 0;
-    if (sso) {
-        if (b->lds_tables) hipLaunchKernelGGL((svt_genotype_kernel<true, true>), grid, block, b->lds_bytes, b->stream, b->args);
-        else hipLaunchKernelGGL((svt_genotype_kernel<true, false>), grid, block, b->lds_bytes, b->stream, b->args);
-    } else {
-        if (b->lds_tables) hipLaunchKernelGGL((svt_genotype_kernel<false, true>), grid, block, b->lds_bytes, b->stream, b->args);
-        else hipLaunchKernelGGL((svt_genotype_kernel<false, false>), grid, block, b->lds_bytes, b->stream, b->args);
-    }
+    if (b->flags & SVT_FLAG_SSO_ASSOCIATION) launch_mode<true>(b, grid, block);
+    else launch_mode<false>(b, grid, block);
     HIP_TRY(hipGetLastError());
     return SVT_OK;
 }
@@ -614,6 +665,7 @@ int svt_batch_create(const svt_evidence_batch* in, int device, unsigned flags, s
     std::vector<LibDesc> libs(in->n_libs);
     std::vector<uint32_t> hist;
     std::vector<int32_t> thr;
+    bool fast_geometry = true;  // 32-bit index math + "non-DEL key never integral" shortcut valid?
     for (uint32_t l = 0; l < in->n_libs; ++l) {
         const svt_library& L = in->libs[l];
         if (!L.hist || L.n_bins == 0) return fail(SVT_ERR_INVALID, "library without histogram");
@@ -633,6 +685,11 @@ int svt_batch_create(const svt_evidence_batch* in, int device, unsigned flags, s
         d.v_nondel = L.mean + L.sd * 3;  // parsers.py:873-875
         d.sd2 = 2 * L.sd;                // classic.py:339
         libs[l] = d;
+        // fast modes need |key_min| <= 2^29, n_bins <= 2^24 and a non-DEL float key
+        // o - (mean + 3 sd) that can never round to an integer for o in [0, 2^31)
+        if (L.key_min < -(1 << 29) || L.key_min > (1 << 29)) fast_geometry = false;
+        if (!(std::fabs(d.v_nondel - std::nearbyint(d.v_nondel)) > 4e-6) || !(std::fabs(d.v_nondel) < 1e12))
+            fast_geometry = false;
         for (uint32_t i = 0; i < L.n_bins; ++i) {
             const uint32_t h1 = L.hist[i];
             hist.push_back(h1);
@@ -651,8 +708,23 @@ int svt_batch_create(const svt_evidence_batch* in, int device, unsigned flags, s
             }
             thr.push_back(t);
         }
+        hist.push_back(0);   // out-of-range sentinel: Counter miss -> 0
+        thr.push_back(-1);   //                        hist[o] == 0 -> never concordant
     }
     const uint32_t total_bins = (uint32_t)hist.size();
+    for (uint64_t u = 0; u < n; ++u) {
+        const int32_t v = in->units[u].var_length;
+        if (v < -(1 << 30) || v > (1 << 30)) { fast_geometry = false; break; }
+    }
+    // paired-end decision table (see PairWeights)
+    std::vector<PairWeights> wtab(32);
+    for (int i = 0; i < 32; ++i) {
+        const bool alt = i & 1, ra = i & 2, rb = i & 4, pc = i & 8, del = i & 16;
+        const bool both = ra && rb, any = ra || rb;
+        const bool need = any && (!both || del);                 // classic.py:398-401
+        wtab[i].w_alt = (alt && !(del && pc)) ? 1.0 : 0.0;       // classic.py:359-377
+        wtab[i].w_ref = (need && pc) ? (both ? 1.0 : 0.5) : 0.0; // classic.py:402-405
+    }
 
     // ---- log10 table: n = QR + QA <= 2 * (2 * split_weight + disc_weight) * max F ----------
     const double bound = 2.0 * (2.0 * in->split_weight + in->disc_weight) * (double)max_f + 4.0;
@@ -770,16 +842,15 @@ int svt_batch_create(const svt_evidence_batch* in, int device, unsigned flags, s
     HIP_OR_CLEAN(hipMalloc(reinterpret_cast<void**>(&d_csr), std::max<uint64_t>(n_rec, 1) * sizeof(uint4)));
     if (n_rec)
         HIP_OR_CLEAN(hipMemcpyAsync(d_csr, in->records, n_rec * sizeof(uint4), hipMemcpyHostToDevice, b->stream));
-    HIP_OR_CLEAN(hipMalloc(reinterpret_cast<void**>(&b->d_tiled), std::max<uint64_t>(tiled_records, 1) * sizeof(uint4)));
+    // + 8 rows of tail pad: the kernel's look-ahead loads may run past the last tile
+    HIP_OR_CLEAN(hipMalloc(reinterpret_cast<void**>(&b->d_tiled), (tiled_records + 8 * kWave) * sizeof(uint4)));
+    HIP_OR_CLEAN(hipMemsetAsync(b->d_tiled + tiled_records, 0, 8 * kWave * sizeof(uint4), b->stream));
     HIP_OR_CLEAN(hipMalloc(reinterpret_cast<void**>(&d_err), sizeof(uint32_t)));
     HIP_OR_CLEAN(hipMemsetAsync(d_err, 0, sizeof(uint32_t), b->stream));
 
     const uint64_t n1 = std::max<uint64_t>(n, 1);
-    HIP_OR_CLEAN(hipMalloc(reinterpret_cast<void**>(&b->d_gl), 3 * n1 * sizeof(double)));
-    HIP_OR_CLEAN(hipMalloc(reinterpret_cast<void**>(&b->d_sq), n1 * sizeof(double)));
-    HIP_OR_CLEAN(hipMalloc(reinterpret_cast<void**>(&b->d_tallies), SVT_N_TALLIES * n1 * sizeof(double)));
-    HIP_OR_CLEAN(hipMalloc(reinterpret_cast<void**>(&b->d_counts), SVT_N_COUNTS * n1 * sizeof(int32_t)));
-    HIP_OR_CLEAN(hipMalloc(reinterpret_cast<void**>(&b->d_gt), n1 * sizeof(int8_t)));
+    HIP_OR_CLEAN(hipMalloc(reinterpret_cast<void**>(&b->d_out), n1 * sizeof(svt_result)));
+    TRY_OR_CLEAN(upload(&b->d_wtab, wtab, b->stream));
 
     // ---- re-tile on the device ------------------------------------------------------------------
     if (b->n_tiles) {
@@ -804,7 +875,6 @@ int svt_batch_create(const svt_evidence_batch* in, int device, unsigned flags, s
     if (err_bits) {
         free_batch(b);
         std::string m = "invalid evidence records:";
-        if (err_bits & 1u) m += " split bits without PRESENT;";
         if (err_bits & 2u) m += " straddle bits without HAS_PAIR;";
         if (err_bits & 4u) m += " lib index >= n_libs;";
         if (err_bits & 8u) m += " reserved/undefined bits set;";
@@ -828,11 +898,9 @@ int svt_batch_create(const svt_evidence_batch* in, int device, unsigned flags, s
     a.n_tiles = b->n_tiles;
     a.l10_in_lds = n_l10 <= kMaxL10Lds ? 1u : 0u;
     a.n_units = n;
-    a.gl = b->d_gl;
-    a.sq = b->d_sq;
-    a.tallies = b->d_tallies;
-    a.counts = b->d_counts;
-    a.gt = b->d_gt;
+    a.out = b->d_out;
+    a.wtab = b->d_wtab;
+    a.lib0 = libs[0];
     {
         const double p_alt[2][3] = {{1e-3, 0.5, 0.9}, {1e-2, 0.2, 1 / 3.0}};  // statistics.py:26,28
         for (int d = 0; d < 2; ++d)
@@ -846,16 +914,19 @@ int svt_batch_create(const svt_evidence_batch* in, int device, unsigned flags, s
         a.c.disc_weight = in->disc_weight;
     }
     const size_t table_bytes = (size_t)total_bins * 8;
-    b->lds_tables = table_bytes <= kMaxLdsTableBytes;
+    if (fast_geometry && table_bytes <= kMaxLdsTableBytes) b->mode = in->n_libs == 1 ? kSingleLds : kMultiLds;
+    else b->mode = kGeneral;
     const uint32_t n_l10_lds = a.l10_in_lds ? ((n_l10 + 1u) & ~1u) : 0u;
-    b->lds_bytes = 256 * 8 + (size_t)n_l10_lds * 8 + (size_t)in->n_libs * sizeof(LibDesc) +
-                   (b->lds_tables ? table_bytes : 0);
+    b->lds_bytes = 256 * 8 + 32 * sizeof(PairWeights) + (size_t)n_l10_lds * 8 +
+                   (size_t)in->n_libs * sizeof(LibDesc) + (b->mode != kGeneral ? table_bytes : 0);
     b->lds_bytes = (b->lds_bytes + 15) & ~size_t(15);
     if (b->lds_bytes > 160 * 1024) { free_batch(b); return fail(SVT_ERR_INVALID, "LDS budget exceeded"); }
-    TRY_OR_CLEAN(allow_big_lds(svt_genotype_kernel<false, true>, b->lds_bytes));
-    TRY_OR_CLEAN(allow_big_lds(svt_genotype_kernel<true, true>, b->lds_bytes));
-    TRY_OR_CLEAN(allow_big_lds(svt_genotype_kernel<false, false>, b->lds_bytes));
-    TRY_OR_CLEAN(allow_big_lds(svt_genotype_kernel<true, false>, b->lds_bytes));
+    TRY_OR_CLEAN(allow_big_lds(svt_genotype_kernel<false, kSingleLds>, b->lds_bytes));
+    TRY_OR_CLEAN(allow_big_lds(svt_genotype_kernel<true, kSingleLds>, b->lds_bytes));
+    TRY_OR_CLEAN(allow_big_lds(svt_genotype_kernel<false, kMultiLds>, b->lds_bytes));
+    TRY_OR_CLEAN(allow_big_lds(svt_genotype_kernel<true, kMultiLds>, b->lds_bytes));
+    TRY_OR_CLEAN(allow_big_lds(svt_genotype_kernel<false, kGeneral>, b->lds_bytes));
+    TRY_OR_CLEAN(allow_big_lds(svt_genotype_kernel<true, kGeneral>, b->lds_bytes));
 #undef TRY_OR_CLEAN
 #undef HIP_OR_CLEAN
     *out = b;
@@ -889,51 +960,30 @@ int svt_batch_genotype_timed(svt_batch* b, int iters, float* ms_total)
     return SVT_OK;
 }
 
-int svt_batch_results(svt_batch* b, svt_results* out)
+int svt_batch_results(svt_batch* b, svt_result* out, uint64_t n_units)
 {
-    if (!b || !out) return fail(SVT_ERR_INVALID, "null argument");
+    if (!b || (!out && n_units)) return fail(SVT_ERR_INVALID, "null argument");
     if (!b->have_results) return fail(SVT_ERR_STATE, "svt_batch_genotype has not run");
-    if (out->n_units != b->n_units) return fail(SVT_ERR_INVALID, "results n_units mismatch");
+    if (n_units != b->n_units) return fail(SVT_ERR_INVALID, "results n_units mismatch");
     HIP_TRY(hipSetDevice(b->device));
-    const uint64_t n = b->n_units;
-    if (n) {
-        HIP_TRY(hipMemcpyAsync(out->gl, b->args.gl, 3 * n * sizeof(double), hipMemcpyDeviceToHost, b->stream));
-        HIP_TRY(hipMemcpyAsync(out->sq, b->args.sq, n * sizeof(double), hipMemcpyDeviceToHost, b->stream));
-        HIP_TRY(hipMemcpyAsync(out->tallies, b->args.tallies, SVT_N_TALLIES * n * sizeof(double), hipMemcpyDeviceToHost, b->stream));
-        HIP_TRY(hipMemcpyAsync(out->counts, b->args.counts, SVT_N_COUNTS * n * sizeof(int32_t), hipMemcpyDeviceToHost, b->stream));
-        HIP_TRY(hipMemcpyAsync(out->gt, b->args.gt, n * sizeof(int8_t), hipMemcpyDeviceToHost, b->stream));
-    }
+    if (b->n_units)
+        HIP_TRY(hipMemcpyAsync(out, b->args.out, b->n_units * sizeof(svt_result), hipMemcpyDeviceToHost, b->stream));
     HIP_TRY(hipStreamSynchronize(b->stream));
     return SVT_OK;
 }
 
-int svt_batch_device_results(svt_batch* b, svt_results* dev)
+int svt_batch_device_results(svt_batch* b, svt_result** dev)
 {
     if (!b || !dev) return fail(SVT_ERR_INVALID, "null argument");
-    dev->n_units = b->n_units;
-    dev->gl = b->args.gl;
-    dev->sq = b->args.sq;
-    dev->tallies = b->args.tallies;
-    dev->counts = b->args.counts;
-    dev->gt = b->args.gt;
+    *dev = b->args.out;
     return SVT_OK;
 }
 
-int svt_batch_bind_device_results(svt_batch* b, const svt_results* dev)
+int svt_batch_bind_device_results(svt_batch* b, svt_result* dev)
 {
     if (!b) return fail(SVT_ERR_INVALID, "null batch");
-    if (!dev) {
-        b->args.gl = b->d_gl; b->args.sq = b->d_sq; b->args.tallies = b->d_tallies;
-        b->args.counts = b->d_counts; b->args.gt = b->d_gt;
-        b->bound_external = false;
-        return SVT_OK;
-    }
-    if (dev->n_units != b->n_units) return fail(SVT_ERR_INVALID, "bound results n_units mismatch");
-    if (b->n_units && (!dev->gl || !dev->sq || !dev->tallies || !dev->counts || !dev->gt))
-        return fail(SVT_ERR_INVALID, "null device result pointer");
-    b->args.gl = dev->gl; b->args.sq = dev->sq; b->args.tallies = dev->tallies;
-    b->args.counts = dev->counts; b->args.gt = dev->gt;
-    b->bound_external = true;
+    if (dev && (reinterpret_cast<uintptr_t>(dev) & 127u)) return fail(SVT_ERR_INVALID, "result buffer must be 128-byte aligned");
+    b->args.out = dev ? dev : b->d_out;
     b->have_results = false;
     return SVT_OK;
 }
@@ -950,13 +1000,13 @@ void* svt_batch_stream(svt_batch* b) { return b ? (void*)b->stream : nullptr; }
 
 void svt_batch_destroy(svt_batch* b) { free_batch(b); }
 
-int svt_genotype(const svt_evidence_batch* in, svt_results* out, int device, unsigned flags)
+int svt_genotype(const svt_evidence_batch* in, svt_result* out, int device, unsigned flags)
 {
     svt_batch* b = nullptr;
     int rc = svt_batch_create(in, device, flags, &b);
     if (rc != SVT_OK) return rc;
     rc = svt_batch_genotype(b, 1);
-    if (rc == SVT_OK) rc = svt_batch_results(b, out);
+    if (rc == SVT_OK) rc = svt_batch_results(b, out, in->n_units);
     std::string keep = g_err;
     svt_batch_destroy(b);
     g_err = keep;

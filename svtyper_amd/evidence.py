@@ -20,21 +20,13 @@ SVTYPE_NAME = {v: k for k, v in SVTYPE_CODE.items()}
 
 FLAG_SSO_ASSOCIATION = 0x1
 
-REC_REFSEQ_A = 1 << 0
-REC_REFSEQ_B = 1 << 1
-REC_S0_PRESENT = 1 << 2
-REC_S0_SOFT = 1 << 3
-REC_S0_L = 1 << 4
-REC_S0_R = 1 << 5
-REC_S1_PRESENT = 1 << 6
-REC_S1_SOFT = 1 << 7
-REC_S1_L = 1 << 8
-REC_S1_R = 1 << 9
-REC_ALT_STRADDLE = 1 << 10
-REC_REF_STRADDLE_A = 1 << 11
-REC_REF_STRADDLE_B = 1 << 12
-REC_HAS_PAIR = 1 << 13
-REC_CONTINUATION = 1 << 14
+REC_ALT_STRADDLE = 1 << 0
+REC_REF_STRADDLE_A = 1 << 1
+REC_REF_STRADDLE_B = 1 << 2
+REC_CONTINUATION = 1 << 3
+REC_HAS_PAIR = 1 << 4
+REC_LIB_SHIFT = 8
+REC_FLAG_MASK = 0x0000FF1F
 
 UNIT_SKIP = 1 << 0
 
@@ -53,12 +45,12 @@ RECORD_DTYPE = np.dtype(
         ("ospan_len", "<i4"),
         ("mapq_a", "u1"),
         ("mapq_b", "u1"),
-        ("s0_left", "u1"),
-        ("s0_right", "u1"),
-        ("s1_left", "u1"),
-        ("s1_right", "u1"),
-        ("lib", "u1"),
-        ("reserved", "u1"),
+        ("rs_a", "u1"),
+        ("rs_b", "u1"),
+        ("seq_l", "u1"),
+        ("seq_r", "u1"),
+        ("clip_l", "u1"),
+        ("clip_r", "u1"),
         ("flags", "<u4"),
     ],
     align=False,
@@ -77,6 +69,19 @@ UNIT_DTYPE = np.dtype(
     align=False,
 )
 assert UNIT_DTYPE.itemsize == 16
+
+RESULT_DTYPE = np.dtype(
+    [
+        ("gl", "<f8", (3,)),
+        ("sq", "<f8"),
+        ("tallies", "<f8", (N_TALLIES,)),
+        ("counts", "<i4", (N_COUNTS,)),
+        ("gt", "i1"),
+        ("pad", "u1", (11,)),
+    ],
+    align=False,
+)
+assert RESULT_DTYPE.itemsize == 128
 
 
 # --------------------------------------------------------------------------- ctypes structs
@@ -100,17 +105,6 @@ class CEvidenceBatch(C.Structure):
         ("libs", C.POINTER(CLibrary)),
         ("split_weight", C.c_double),
         ("disc_weight", C.c_double),
-    ]
-
-
-class CResults(C.Structure):
-    _fields_ = [
-        ("n_units", C.c_uint64),
-        ("gl", C.POINTER(C.c_double)),
-        ("sq", C.POINTER(C.c_double)),
-        ("tallies", C.POINTER(C.c_double)),
-        ("counts", C.POINTER(C.c_int32)),
-        ("gt", C.POINTER(C.c_int8)),
     ]
 
 
@@ -216,45 +210,48 @@ class EvidenceBatch:
         return cb
 
 
-@dataclass
 class Results:
-    """SoA results (include/svtyper_hip.h: svt_results)."""
+    """Result records (include/svtyper_hip.h: svt_result[n_units]), one 128-byte record per unit."""
 
-    gl: np.ndarray  # float64 [3, n]
-    sq: np.ndarray  # float64 [n]
-    tallies: np.ndarray  # float64 [5, n]
-    counts: np.ndarray  # int32 [11, n]
-    gt: np.ndarray  # int8 [n]
+    def __init__(self, rec: np.ndarray):
+        self.rec = np.ascontiguousarray(rec, dtype=RESULT_DTYPE)
 
     @classmethod
     def empty(cls, n: int) -> "Results":
-        return cls(
-            np.zeros((3, n), np.float64),
-            np.zeros(n, np.float64),
-            np.zeros((N_TALLIES, n), np.float64),
-            np.zeros((N_COUNTS, n), np.int32),
-            np.zeros(n, np.int8),
-        )
+        return cls(np.zeros(n, RESULT_DTYPE))
 
     @property
     def n_units(self) -> int:
-        return int(self.gt.shape[0])
+        return int(self.rec.shape[0])
 
-    def as_c(self) -> CResults:
-        cr = CResults()
-        cr.n_units = self.n_units
-        cr.gl = self.gl.ctypes.data_as(C.POINTER(C.c_double))
-        cr.sq = self.sq.ctypes.data_as(C.POINTER(C.c_double))
-        cr.tallies = self.tallies.ctypes.data_as(C.POINTER(C.c_double))
-        cr.counts = self.counts.ctypes.data_as(C.POINTER(C.c_int32))
-        cr.gt = self.gt.ctypes.data_as(C.POINTER(C.c_int8))
-        return cr
+    @property
+    def gl(self) -> np.ndarray:  # [n, 3]
+        return self.rec["gl"]
+
+    @property
+    def sq(self) -> np.ndarray:
+        return self.rec["sq"]
+
+    @property
+    def tallies(self) -> np.ndarray:  # [n, 5] in TALLY_NAMES order
+        return self.rec["tallies"]
+
+    @property
+    def counts(self) -> np.ndarray:  # [n, 11] in COUNT_NAMES order
+        return self.rec["counts"]
+
+    @property
+    def gt(self) -> np.ndarray:
+        return self.rec["gt"]
 
     def count(self, name: str) -> np.ndarray:
-        return self.counts[COUNT_NAMES.index(name)]
+        return self.rec["counts"][:, COUNT_NAMES.index(name)]
 
     def tally(self, name: str) -> np.ndarray:
-        return self.tallies[TALLY_NAMES.index(name)]
+        return self.rec["tallies"][:, TALLY_NAMES.index(name)]
+
+    def ptr(self) -> int:
+        return int(self.rec.ctypes.data)
 
 
 def concat_batches(batches: Sequence[EvidenceBatch]) -> EvidenceBatch:

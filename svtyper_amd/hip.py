@@ -10,15 +10,16 @@ import os
 import subprocess
 from typing import Optional
 
-from .evidence import CEvidenceBatch, CResults, EvidenceBatch, Results
+from .evidence import CEvidenceBatch, EvidenceBatch, RESULT_DTYPE, Results
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libsvtyper_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 EXPORTS = (
     "svt_version", "svt_device_count", "svt_last_error", "svt_batch_create", "svt_batch_genotype",
-    "svt_batch_genotype_timed", "svt_batch_results", "svt_batch_device_results", "svt_batch_bind_device_results", "svt_batch_bytes",
+    "svt_batch_genotype_timed", "svt_batch_results", "svt_batch_device_results",
+    "svt_batch_bind_device_results", "svt_batch_bytes",
     "svt_batch_stream", "svt_batch_destroy", "svt_genotype",
 )
 
@@ -60,11 +61,11 @@ def load() -> C.CDLL:
     L.svt_batch_genotype_timed.restype = C.c_int
     L.svt_batch_genotype_timed.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float)]
     L.svt_batch_results.restype = C.c_int
-    L.svt_batch_results.argtypes = [C.c_void_p, C.POINTER(CResults)]
+    L.svt_batch_results.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
     L.svt_batch_device_results.restype = C.c_int
-    L.svt_batch_device_results.argtypes = [C.c_void_p, C.POINTER(CResults)]
+    L.svt_batch_device_results.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
     L.svt_batch_bind_device_results.restype = C.c_int
-    L.svt_batch_bind_device_results.argtypes = [C.c_void_p, C.POINTER(CResults)]
+    L.svt_batch_bind_device_results.argtypes = [C.c_void_p, C.c_void_p]
     L.svt_batch_bytes.restype = C.c_int
     L.svt_batch_bytes.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.svt_batch_stream.restype = C.c_void_p
@@ -72,7 +73,7 @@ def load() -> C.CDLL:
     L.svt_batch_destroy.restype = None
     L.svt_batch_destroy.argtypes = [C.c_void_p]
     L.svt_genotype.restype = C.c_int
-    L.svt_genotype.argtypes = [C.POINTER(CEvidenceBatch), C.POINTER(CResults), C.c_int, C.c_uint]
+    L.svt_genotype.argtypes = [C.POINTER(CEvidenceBatch), C.c_void_p, C.c_int, C.c_uint]
     if L.svt_version() != ABI_VERSION:
         raise SvtyperHipError("ABI mismatch: library %d, binding %d" % (L.svt_version(), ABI_VERSION))
     _lib = L
@@ -112,27 +113,19 @@ class DeviceBatch:
 
     def results(self) -> Results:
         out = Results.empty(self.n_units)
-        cr = out.as_c()
-        _check(self._lib.svt_batch_results(self._h, C.byref(cr)))
+        _check(self._lib.svt_batch_results(self._h, C.c_void_p(out.ptr()), self.n_units))
         return out
 
-    def device_pointers(self) -> dict:
-        cr = CResults()
-        _check(self._lib.svt_batch_device_results(self._h, C.byref(cr)))
-        addr = lambda p: C.cast(p, C.c_void_p).value
-        return dict(n_units=int(cr.n_units), gl=addr(cr.gl), sq=addr(cr.sq), tallies=addr(cr.tallies),
-                    counts=addr(cr.counts), gt=addr(cr.gt))
+    def device_results_ptr(self) -> int:
+        """Device address of the svt_result[n_units] array the kernel writes to."""
+        p = C.c_void_p()
+        _check(self._lib.svt_batch_device_results(self._h, C.byref(p)))
+        return int(p.value or 0)
 
-    def bind_device_results(self, gl: int, sq: int, tallies: int, counts: int, gt: int):
-        """Device addresses (ints) of caller-owned SoA result buffers, e.g. torch data_ptr()s."""
-        cr = CResults()
-        cr.n_units = self.n_units
-        cr.gl = C.cast(C.c_void_p(gl), C.POINTER(C.c_double))
-        cr.sq = C.cast(C.c_void_p(sq), C.POINTER(C.c_double))
-        cr.tallies = C.cast(C.c_void_p(tallies), C.POINTER(C.c_double))
-        cr.counts = C.cast(C.c_void_p(counts), C.POINTER(C.c_int32))
-        cr.gt = C.cast(C.c_void_p(gt), C.POINTER(C.c_int8))
-        _check(self._lib.svt_batch_bind_device_results(self._h, C.byref(cr)))
+    def bind_device_results(self, dev_ptr: int):
+        """Caller-owned device buffer (n_units * 128 bytes, 128-byte aligned), e.g. a torch
+        tensor's data_ptr(); 0 returns to the library's own buffer."""
+        _check(self._lib.svt_batch_bind_device_results(self._h, C.c_void_p(int(dev_ptr) or None)))
 
     def bytes(self):
         a, r = C.c_uint64(), C.c_uint64()
@@ -165,6 +158,5 @@ def genotype_batch(batch: EvidenceBatch, device: int = 0, flags: int = 0) -> Res
     L = load()
     out = Results.empty(batch.n_units)
     cb = batch.as_c()
-    cr = out.as_c()
-    _check(L.svt_genotype(C.byref(cb), C.byref(cr), int(device), int(flags)))
+    _check(L.svt_genotype(C.byref(cb), C.c_void_p(out.ptr()), int(device), int(flags)))
     return out

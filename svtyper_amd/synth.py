@@ -97,48 +97,42 @@ def make_units(n_units: int, seed: int, libs: Sequence[LibraryTable], svtype_mix
 
     rec = np.zeros(R, RECORD_DTYPE)
     lib_idx = lib_choices[rng.integers(0, len(lib_choices), R)]
-    rec["lib"] = lib_idx
     two = rng.random(R) < 0.996
     mq_a = _mapq(rng, R)
     mq_b = np.where(two, _mapq(rng, R), 0).astype(np.uint8)
     rec["mapq_a"] = mq_a
     rec["mapq_b"] = mq_b
-    flags = np.zeros(R, np.uint32)
+    flags = lib_idx.astype(np.uint32) << np.uint32(ev.REC_LIB_SHIFT)
     flags |= np.where(two, ev.REC_HAS_PAIR, 0).astype(np.uint32)
 
     # fragment class: alt-supporting with probability by genotype
     p_alt_frag = np.array([0.01, 0.45, 0.93])[g]
     alt_like = rng.random(R) < p_alt_frag
 
-    # reference split-read evidence: 37 % of fragments, mostly ref-like ones
+    # reference split-read evidence (is_ref_seq): 37 % of fragments, mostly ref-like ones
     u = rng.random(R)
     rs = u < np.where(alt_like, 0.08, 0.45)
     which = rng.random(R)
-    flags |= np.where(rs & (which < 0.55), ev.REC_REFSEQ_A, 0).astype(np.uint32)
-    flags |= np.where(rs & two & (which > 0.45), ev.REC_REFSEQ_B, 0).astype(np.uint32)
+    rec["rs_a"] = np.where(rs & (which < 0.55), mq_a, 0)
+    rec["rs_b"] = np.where(rs & two & (which > 0.45), mq_b, 0)
 
-    # split candidates: one 14.6 %, two 0.6 %; 56 % soft-clip-only
+    # split candidates: one on 14.6 % of the fragments, two on 0.6 %; 56 % soft-clip-only.  A
+    # record holds one candidate of each kind; MAPQs are gated by is_split_straddle()'s (L, R)
     u = rng.random(R)
-    s0 = u < 0.152
-    s1 = (u < 0.006) & two
-    for k, (present, fp, fs, fl, fr, nl, nr) in enumerate(
-            ((s0, ev.REC_S0_PRESENT, ev.REC_S0_SOFT, ev.REC_S0_L, ev.REC_S0_R, "s0_left", "s0_right"),
-             (s1, ev.REC_S1_PRESENT, ev.REC_S1_SOFT, ev.REC_S1_L, ev.REC_S1_R, "s1_left", "s1_right"))):
-        soft = present & (rng.random(R) < 0.56)
-        # a candidate supports the breakpoint on a side mostly when the fragment is alt-like
+    have = u < 0.152
+    soft = have & (rng.random(R) < 0.56)
+    second = (u < 0.006) & two          # second candidate of the OTHER kind in the same record
+    for kind, present in (("seq", (have & ~soft) | (second & soft)), ("clip", soft | (second & have & ~soft))):
         sup_l = present & (rng.random(R) < np.where(alt_like, 0.85, 0.03))
         sup_r = present & (rng.random(R) < np.where(alt_like, 0.85, 0.03))
-        left_is_dummy = soft & (rng.random(R) < 0.5)   # soft-clip: the other piece has MAPQ 0
-        ql = np.where(present, _mapq(rng, R), 0).astype(np.uint8)
-        qr = np.where(present, _mapq(rng, R), 0).astype(np.uint8)
-        ql = np.where(soft & left_is_dummy, 0, ql).astype(np.uint8)
-        qr = np.where(soft & ~left_is_dummy, 0, qr).astype(np.uint8)
-        rec[nl] = ql
-        rec[nr] = qr
-        flags |= np.where(present, fp, 0).astype(np.uint32)
-        flags |= np.where(soft, fs, 0).astype(np.uint32)
-        flags |= np.where(sup_l, fl, 0).astype(np.uint32)
-        flags |= np.where(sup_r, fr, 0).astype(np.uint32)
+        ql = _mapq(rng, R)
+        qr = _mapq(rng, R)
+        if kind == "clip":  # the dummy other piece of a soft-clip-only candidate has MAPQ 0
+            dummy_left = rng.random(R) < 0.5
+            ql = np.where(dummy_left, 0, ql)
+            qr = np.where(dummy_left, qr, 0)
+        rec[kind + "_l"] = np.where(sup_l, ql, 0)
+        rec[kind + "_r"] = np.where(sup_r, qr, 0)
 
     # paired-end evidence
     near = two & (rng.random(R) < 0.90)            # pair close enough to straddle something
@@ -156,10 +150,13 @@ def make_units(n_units: int, seed: int, libs: Sequence[LibraryTable], svtype_mix
     # outer span: concordant ~ hist, alt-supporting DEL pairs ~ hist + var_length; 14 % beyond the
     # histogram's range
     osp = np.zeros(R, np.int64)
-    for li, lib in enumerate(libs):
-        m = lib_idx == li
-        if m.any():
-            osp[m] = _sample_hist(rng, lib, int(m.sum()))
+    if len(libs) == 1:
+        osp = _sample_hist(rng, libs[0], R)
+    else:
+        for li, lib in enumerate(libs):
+            m = lib_idx == li
+            if m.any():
+                osp[m] = _sample_hist(rng, lib, int(m.sum()))
     osp = np.where(alt_like & is_del, osp + vlen, osp)
     far = rng.random(R) < 0.14
     osp = np.where(far, osp + rng.integers(400, 5000, R), osp)
@@ -206,7 +203,7 @@ def make_edge_cases(libs: Sequence[LibraryTable], seed: int = 1) -> EvidenceBatc
     # low-MAPQ heavy units: sums of 0.9 / 0.99 / 0.5 that land next to integers
     b = make_units(300, seed + 2, libs, svtype_mix=(0.5, 0.2, 0.2, 0.1), mean_frags=40, sd_frags=20,
                    min_frags=1, max_frags=120)
-    for fld in ("mapq_a", "mapq_b", "s0_left", "s0_right"):
+    for fld in ("mapq_a", "mapq_b", "rs_a", "rs_b", "seq_l", "seq_r", "clip_l"):
         m = rng.random(b.n_records) < 0.7
         b.records[fld] = np.where(m & (b.records[fld] > 0), rng.choice([3, 10, 20, 30, 255], b.n_records),
                                   b.records[fld]).astype(np.uint8)
@@ -227,9 +224,11 @@ def make_edge_cases(libs: Sequence[LibraryTable], seed: int = 1) -> EvidenceBatc
     d = make_units(64, seed + 4, libs, svtype_mix=(0, 1, 0, 0), mean_frags=900, sd_frags=150,
                    min_frags=600, max_frags=1300, alt_af=np.full(64, 1.0))
     fl = d.records["flags"]
-    fl &= ~np.uint32(ev.REC_REFSEQ_A | ev.REC_REFSEQ_B | ev.REC_REF_STRADDLE_A | ev.REC_REF_STRADDLE_B)
+    fl &= ~np.uint32(ev.REC_REF_STRADDLE_A | ev.REC_REF_STRADDLE_B)
     fl |= np.uint32(ev.REC_ALT_STRADDLE | ev.REC_HAS_PAIR)
     d.records["flags"] = fl
+    d.records["rs_a"] = 0
+    d.records["rs_b"] = 0
     d.records["mapq_a"] = 60
     d.records["mapq_b"] = 60
     parts.append(d)

@@ -19,15 +19,18 @@ TOL = 1e-6  # north_star tolerance on GL / SQ
 def assert_parity(got: ev.Results, want: ev.Results, exact_float=True):
     assert np.array_equal(got.gt, want.gt), "GT mismatch at %s" % np.nonzero(got.gt != want.gt)[0][:10]
     for i, name in enumerate(ev.COUNT_NAMES):
-        bad = np.nonzero(got.counts[i] != want.counts[i])[0]
+        bad = np.nonzero(got.counts[:, i] != want.counts[:, i])[0]
         assert bad.size == 0, "%s mismatch at units %s: %s vs %s" % (
-            name, bad[:10], got.counts[i][bad[:10]], want.counts[i][bad[:10]])
+            name, bad[:10], got.counts[bad[:10], i], want.counts[bad[:10], i])
     assert np.max(np.abs(got.gl - want.gl), initial=0.0) <= TOL
     assert np.max(np.abs(got.sq - want.sq), initial=0.0) <= TOL
     assert np.max(np.abs(got.tallies - want.tallies), initial=0.0) <= TOL
     if exact_float:
-        assert np.array_equal(got.tallies.view(np.uint64), want.tallies.view(np.uint64)), "tallies not bit-identical"
-        assert np.array_equal(got.gl.view(np.uint64), want.gl.view(np.uint64)), "GL not bit-identical"
+        assert np.array_equal(np.ascontiguousarray(got.tallies).view(np.uint64),
+                              np.ascontiguousarray(want.tallies).view(np.uint64)), "tallies not bit-identical"
+        assert np.array_equal(np.ascontiguousarray(got.gl).view(np.uint64),
+                              np.ascontiguousarray(want.gl).view(np.uint64)), "GL not bit-identical"
+    assert not got.rec["pad"].any()
 
 
 def run_both(batch, flags=0, device=0):
@@ -73,6 +76,18 @@ def test_multi_library(hip_device, fixture_library):
     assert_parity(got, want)
 
 
+def test_wide_geometry_general_mode(hip_device, fixture_library):
+    """DEL lengths beyond 2^30 and histogram keys far from 0 force the 64-bit 'general' kernel."""
+    lib = synth.normal_library(300.0, 50.0, seed=6)
+    batch = synth.make_units(3000, 8, [lib, fixture_library], svtype_mix=(0.6, 0.2, 0.1, 0.1))
+    batch.units["var_length"][::7] = 2**30 + 12345
+    batch.units["pos_delta"][::7] = 2**30 + 12346
+    big = batch.units["var_length"][batch.units["svtype"] == 0].max()
+    batch.records["ospan_len"][::5] = np.minimum(2**31 - 1, batch.records["ospan_len"][::5].astype(np.int64) + big)
+    got, want = run_both(batch)
+    assert_parity(got, want)
+
+
 def test_integral_nondel_var_length(hip_device):
     """mean + 3 sd integral: the float Counter key of parsers.py:874-878 matches integer bins."""
     lib = synth.normal_library(300.0, 50.0, seed=5)
@@ -104,11 +119,15 @@ def test_empty_and_tiny_batches(hip_device, fixture_library):
 def test_invalid_records_rejected(hip_device, fixture_library):
     from svtyper_amd import hip
     b = synth.make_units(100, 3, [fixture_library])
-    b.records["lib"][5] = 7  # only one library
+    b.records["flags"][5] |= 7 << ev.REC_LIB_SHIFT  # only one library
     with pytest.raises(hip.SvtyperHipError):
         hip.genotype_batch(b)
     b = synth.make_units(100, 3, [fixture_library])
-    b.records["flags"][7] = ev.REC_S0_L  # L without PRESENT
+    b.records["flags"][7] = ev.REC_ALT_STRADDLE  # straddle bit without HAS_PAIR
+    with pytest.raises(hip.SvtyperHipError):
+        hip.genotype_batch(b)
+    b = synth.make_units(100, 3, [fixture_library])
+    b.records["flags"][9] |= 1 << 20  # undefined flag bit
     with pytest.raises(hip.SvtyperHipError):
         hip.genotype_batch(b)
 
@@ -127,7 +146,7 @@ def test_bayes_grid_via_kernel(hip_device, fixture_library):
                 r["mapq_a"] = 255
                 r["mapq_b"] = 255
                 fl = np.full(n, ev.REC_HAS_PAIR, np.uint32)
-                fl[:qr] |= ev.REC_REFSEQ_A
+                r["rs_a"][:qr] = 255
                 fl[:qa] |= ev.REC_ALT_STRADDLE
                 r["flags"] = fl
                 recs.append(r)
