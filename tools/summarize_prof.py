@@ -1,40 +1,33 @@
 #!/usr/bin/env python
-"""Condense rocprofv3 output dirs (tools/profile.sh) into a small text summary."""
-import csv
+"""Condense the rocprofv3 output of tools/profile.sh (rocpd sqlite databases) into a text summary
+that is small enough to commit under profiles/."""
 import glob
 import os
+import sqlite3
 import sys
-from collections import defaultdict
 
 out = sys.argv[1]
 
 
-def find(pattern):
-    return sorted(glob.glob(os.path.join(out, pattern), recursive=True))
+def dbs(sub):
+    return sorted(glob.glob(os.path.join(out, sub, "**", "*.db"), recursive=True))
 
 
-for f in find("stats/**/*kernel_stats.csv"):
-    print("== kernel stats (%s)" % os.path.relpath(f, out))
-    with open(f) as fh:
-        for row in csv.DictReader(fh):
-            print("  %-60s calls=%s avg_ns=%s total_ns=%s pct=%s" % (
-                row.get("Name", "")[:60], row.get("Calls"), row.get("AverageNs"), row.get("TotalDurationNs"),
-                row.get("Percentage")))
+for f in dbs("stats"):
+    c = sqlite3.connect(f)
+    print("# rocprofv3 --kernel-trace --stats   (%s)" % os.path.relpath(f, out))
+    print("name,total_calls,total_duration_us,average_us,percentage")
+    for r in c.execute("select name,total_calls,total_duration,average,percentage from top_kernels"):
+        print(",".join(str(x) for x in r))
 
-for d in ("pmc_sq1", "pmc_sq2", "pmc_fetch", "pmc_write"):
-    for f in find(d + "/**/*counter_collection.csv"):
-        agg = defaultdict(lambda: defaultdict(list))
-        extra = {}
-        with open(f) as fh:
-            for row in csv.DictReader(fh):
-                k = row.get("Kernel_Name", "")
-                agg[k][row.get("Counter_Name")].append(float(row.get("Counter_Value", 0)))
-                extra[k] = (row.get("VGPR_Count"), row.get("Accum_VGPR_Count"), row.get("SGPR_Count"),
-                            row.get("LDS_Block_Size"), row.get("Grid_Size"), row.get("Workgroup_Size"))
-        print("== counters (%s)" % os.path.relpath(f, out))
-        for k, cs in agg.items():
-            if "genotype" not in k and "repack" not in k:
-                continue
-            print("  kernel %s  vgpr/agpr/sgpr/lds/grid/wg=%s" % (k[:70], extra[k]))
-            for c, v in sorted(cs.items()):
-                print("    %-28s n=%d mean=%.6g" % (c, len(v), sum(v) / len(v)))
+for sub in ("pmc_sq1", "pmc_sq2", "pmc_fetch", "pmc_write"):
+    for f in dbs(sub):
+        c = sqlite3.connect(f)
+        print("# rocprofv3 --pmc pass %s   (per-dispatch mean over the svt_* kernels)" % sub)
+        print("kernel,counter,mean,dispatches,vgpr_count,lds_block_size,sgpr_count,grid,workgroup")
+        q = ("select kernel_name, counter_name, avg(value), count(*), max(vgpr_count), max(lds_block_size), "
+             "max(sgpr_count), max(grid_size), max(workgroup_size) from counters_collection "
+             "where kernel_name like '%svt_%' group by kernel_name, counter_name")
+        for r in c.execute(q):
+            name = r[0].replace("(anonymous namespace)::", "")
+            print(",".join([name] + [str(x) for x in r[1:]]))
