@@ -267,6 +267,29 @@ __device__ __forceinline__ double log_choose_dev(const double* __restrict__ l10,
     return r;
 }
 
+#ifndef SVT_NT_LOADS
+#define SVT_NT_LOADS 1
+#endif
+#ifndef SVT_MIN_WAVES
+#define SVT_MIN_WAVES 1
+#endif
+#ifndef SVT_GROUP
+#define SVT_GROUP 4
+#endif
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// streaming read of one evidence record (read exactly once per pass)
+__device__ __forceinline__ uint4 ld_stream(const uint4* __restrict__ p)
+{
+#if SVT_NT_LOADS
+    const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+#else
+    return *p;
+#endif
+}
+
 __device__ __forceinline__ uint4 pack2d(double x, double y)
 {
     const uint64_t a = (uint64_t)__double_as_longlong(x), b = (uint64_t)__double_as_longlong(y);
@@ -274,7 +297,7 @@ __device__ __forceinline__ uint4 pack2d(double x, double y)
 }
 
 template <bool SSO, int MODE>
-__global__ __launch_bounds__(kBlock) void svt_genotype_kernel(const KernelArgs a)
+__global__ __launch_bounds__(kBlock, SVT_MIN_WAVES) void svt_genotype_kernel(const KernelArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // LDS layout: pm[256] | wtab[32] | l10[n_l10 (even)] | libs[n_libs] | hist[total_bins] | thr[total_bins]
@@ -338,21 +361,23 @@ __global__ __launch_bounds__(kBlock) void svt_genotype_kernel(const KernelArgs a
     // pad, so the look-ahead never leaves the allocation).
     const uint4* __restrict__ p = a.tiled + td.rec_base + lane;
     const uint32_t rows = td.rows;
-    uint4 c0 = p[0 * kWave], c1 = p[1 * kWave], c2 = p[2 * kWave], c3 = p[3 * kWave];
+    uint4 cur[SVT_GROUP], nxt[SVT_GROUP];
+#pragma unroll
+    for (int k = 0; k < SVT_GROUP; ++k) cur[k] = ld_stream(p + k * kWave);
     uint32_t j = 0;
-    for (; j + 4 <= rows; j += 4) {
-        const uint4* __restrict__ q = p + (uint64_t)(j + 4) * kWave;
-        const uint4 n0 = q[0 * kWave], n1 = q[1 * kWave], n2 = q[2 * kWave], n3 = q[3 * kWave];
-        tally_record<SSO, MODE>(c0, t, c, acc);
-        tally_record<SSO, MODE>(c1, t, c, acc);
-        tally_record<SSO, MODE>(c2, t, c, acc);
-        tally_record<SSO, MODE>(c3, t, c, acc);
-        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    for (; j + SVT_GROUP <= rows; j += SVT_GROUP) {
+        const uint4* __restrict__ q = p + (uint64_t)(j + SVT_GROUP) * kWave;
+#pragma unroll
+        for (int k = 0; k < SVT_GROUP; ++k) nxt[k] = ld_stream(q + k * kWave);
+#pragma unroll
+        for (int k = 0; k < SVT_GROUP; ++k) tally_record<SSO, MODE>(cur[k], t, c, acc);
+#pragma unroll
+        for (int k = 0; k < SVT_GROUP; ++k) cur[k] = nxt[k];
     }
     const uint32_t rem = rows - j;  // wave-uniform
-    if (rem > 0) tally_record<SSO, MODE>(c0, t, c, acc);
-    if (rem > 1) tally_record<SSO, MODE>(c1, t, c, acc);
-    if (rem > 2) tally_record<SSO, MODE>(c2, t, c, acc);
+#pragma unroll
+    for (int k = 0; k < SVT_GROUP - 1; ++k)
+        if ((uint32_t)k < rem) tally_record<SSO, MODE>(cur[k], t, c, acc);
     if (SSO) {  // flush the last fragment (singlesample.py:370-372)
         acc.ref_seq += acc.l_ref_seq;
         acc.alt_seq += acc.l_alt_seq;
@@ -843,8 +868,8 @@ int svt_batch_create(const svt_evidence_batch* in, int device, unsigned flags, s
     if (n_rec)
         HIP_OR_CLEAN(hipMemcpyAsync(d_csr, in->records, n_rec * sizeof(uint4), hipMemcpyHostToDevice, b->stream));
     // + 8 rows of tail pad: the kernel's look-ahead loads may run past the last tile
-    HIP_OR_CLEAN(hipMalloc(reinterpret_cast<void**>(&b->d_tiled), (tiled_records + 8 * kWave) * sizeof(uint4)));
-    HIP_OR_CLEAN(hipMemsetAsync(b->d_tiled + tiled_records, 0, 8 * kWave * sizeof(uint4), b->stream));
+    HIP_OR_CLEAN(hipMalloc(reinterpret_cast<void**>(&b->d_tiled), (tiled_records + 2 * SVT_GROUP * kWave) * sizeof(uint4)));
+    HIP_OR_CLEAN(hipMemsetAsync(b->d_tiled + tiled_records, 0, 2 * SVT_GROUP * kWave * sizeof(uint4), b->stream));
     HIP_OR_CLEAN(hipMalloc(reinterpret_cast<void**>(&d_err), sizeof(uint32_t)));
     HIP_OR_CLEAN(hipMemsetAsync(d_err, 0, sizeof(uint32_t), b->stream));
 

@@ -13,7 +13,7 @@ from typing import Optional
 from .evidence import CEvidenceBatch, EvidenceBatch, RESULT_DTYPE, Results
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libsvtyper_hip.so")
+LIB_PATH = os.environ.get("SVTYPER_HIP_LIB") or os.path.join(_HERE, "csrc", "libsvtyper_hip.so")
 ABI_VERSION = 2
 
 EXPORTS = (
