@@ -1,0 +1,41 @@
+"""Device result records -> the reference's per-sample result (FORMAT values).
+
+Pure formatting of what the kernels computed: '%.0f' GL strings, '%.2g' allele balance, the
+'.'-for-missing conventions of svtyper/classic.py:454-513 and svtyper/singlesample.py:207-227,
+430-471.  No likelihood arithmetic happens here.
+"""
+from __future__ import annotations
+
+from . import evidence as ev
+
+FORMAT_ORDER = ("GT", "GQ", "SQ", "GL", "DP", "AO", "RO", "AS", "ASC", "RS", "AP", "RP", "QR", "QA", "AB")
+_CNT = {name: i for i, name in enumerate(ev.COUNT_NAMES)}
+
+
+def blank_result() -> dict:
+    """singlesample.py:207-227 / classic.py:496-513"""
+    return {"qual": 0, "formats": {"GT": "./.", "GQ": ".", "SQ": ".", "GL": ".", "DP": 0, "AO": 0, "RO": 0,
+                                   "AS": 0, "ASC": 0, "RS": 0, "AP": 0, "RP": 0, "QR": 0, "QA": 0, "AB": "."}}
+
+
+def result_from_record(rec) -> dict:
+    """One element of Results.rec -> {'qual': float|0, 'formats': {...}} shaped like the output of
+    svtyper/singlesample.py:406-473 bayesian_genotype()."""
+    gt = int(rec["gt"])
+    if gt in (ev.GT_BLANK, ev.GT_SKIPPED):
+        return blank_result()
+    c = rec["counts"]
+    out = blank_result()
+    f = out["formats"]
+    f["GL"] = ",".join("%.0f" % float(x) for x in rec["gl"])           # classic.py:454
+    for name in ("DP", "RO", "AO", "QR", "QA", "RS", "AS", "ASC", "RP", "AP"):
+        f[name] = int(c[_CNT[name]])
+    qr, qa = f["QR"], f["QA"]
+    f["AB"] = "%.2g" % (qa / float(qr + qa)) if (qr + qa) != 0 else "."  # classic.py:466-469
+    if gt >= 0:
+        sq = float(rec["sq"])
+        f["GQ"] = int(c[_CNT["GQ"]])
+        f["SQ"] = sq
+        f["GT"] = ev.GT_STRING[gt]
+        out["qual"] = sq
+    return out
