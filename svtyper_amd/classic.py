@@ -1,0 +1,238 @@
+"""`svtyper` (multi-sample) driver with the reference's call surface.
+
+    sv_genotype(bam_string, vcf_in, vcf_out, min_aligned, split_weight, disc_weight, num_samp,
+                lib_info_path, debug, alignment_outpath, ref_fasta, sum_quals, max_reads, max_ci_dist)
+
+Same arguments, defaults and output bytes as svtyper/classic.py:107-533, but the per-sample
+likelihood block (classic.py:286-513) does not run here: evidence is packed on the host and
+genotyped in device batches (pipeline.py).  `engine` is an extra, keyword-only seam; it
+defaults to the HIP library and there is no CPU implementation in this package.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import logging
+import os
+import sys
+from typing import List, Optional
+
+from . import __version__
+from . import evidence as ev
+from .bam import open_alignment_file
+from .library import Sample, setup_sample, write_sample_json
+from .pipeline import (MIN_LIB_PREVALENCE, UnitCollector, add_read_to, default_engine, fetch_window)
+from .results import result_from_record
+from .vcf import VALID_SVTYPES, Variant, Vcf
+
+CHUNK_UNITS = 200_000   # (breakpoint, sample) units per device batch
+
+
+def gather_all_reads(sample: Sample, bp: dict, max_reads):
+    """Fragments of both breakends, or ({}, True) when a side has more than max_reads reads
+    (classic.py:54-100: the counter runs over every fetched record of that side)."""
+    fragments = {}
+    for side in ("A", "B"):
+        chrom, lo, hi = fetch_window(sample, bp[side]["chrom"], bp[side]["pos"], bp[side]["ci"], as_int=False)
+        for i, read in enumerate(sample.bam.fetch(chrom, lo, hi)):
+            if read.is_unmapped or read.is_duplicate:
+                continue
+            lib = sample.get_lib(read.get_tag("RG"))
+            if lib.name not in sample.active_libs:
+                continue
+            if max_reads is not None and i > max_reads:
+                return {}, True
+            add_read_to(fragments, read, lib)
+    return fragments, False
+
+
+def apply_result(var: Variant, sample_name: str, rec) -> None:
+    """Result record -> FORMAT fields and QUAL of one sample (classic.py:454-513)."""
+    g = var.genotype(sample_name)
+    gt = int(rec["gt"])
+    if gt == ev.GT_SKIPPED:                       # classic.py:282-284
+        g.set_format("GT", "./.")
+        return
+    res = result_from_record(rec)
+    f = res["formats"]
+    if gt == ev.GT_BLANK:                         # classic.py:496-513 (QUAL is reset, not kept)
+        var.qual = 0
+    for key in ("GL", "DP", "RO", "AO", "QR", "QA", "RS", "AS", "ASC", "RP", "AP", "AB", "GQ", "SQ", "GT"):
+        g.set_format(key, f[key])
+    if gt >= 0:
+        var.qual += res["qual"]                   # classic.py:485
+
+
+def sv_genotype(bam_string, vcf_in, vcf_out, min_aligned, split_weight, disc_weight, num_samp, lib_info_path,
+                debug, alignment_outpath, ref_fasta, sum_quals, max_reads, max_ci_dist, *, engine=None):
+    if alignment_outpath is not None:
+        raise NotImplementedError("-w/--write_alignment (evidence BAM dump) is outside the MI355X hot path build")
+    bams = []
+    for path in bam_string.split(","):
+        if not (path.endswith(".bam") or path.endswith(".cram")):
+            sys.stderr.write("Error: %s is not a valid alignment file (*.bam or *.cram)\n" % path)
+            sys.exit(1)
+        bams.append(open_alignment_file(path, ref_fasta))
+
+    lib_info = None
+    if lib_info_path is not None and os.path.isfile(lib_info_path):
+        with open(lib_info_path) as f:
+            lib_info = json.load(f)
+    if vcf_in is None:
+        sys.stderr.write("Warning: VCF not found.\n")
+    samples: List[Sample] = [setup_sample(b, lib_info, num_samp, MIN_LIB_PREVALENCE) for b in bams]
+    if lib_info_path is not None and not os.path.isfile(lib_info_path):
+        logging.info("Writing library metrics to %s..." % lib_info_path)
+        write_sample_json(samples, open(lib_info_path, "w"))
+    if vcf_in is None:
+        return
+
+    if engine is None:
+        engine = default_engine()
+    vcf = Vcf()
+    collector = UnitCollector(samples, split_weight, disc_weight, min_aligned)
+    pending: list = []      # ordered output actions of the current chunk
+    header_lines: list = []
+    in_header = True
+
+    def flush():
+        results = collector.run(engine, 0)
+        for action in pending:
+            if action[0] == "raw":
+                vcf_out.write(action[1].get_var_string() + "\n")
+                continue
+            _, var, var2, first_unit = action
+            for k, sample in enumerate(samples):
+                rec = results.rec[first_unit + k]
+                if debug:
+                    _debug_print(rec)
+                apply_result(var, sample.name, rec)
+            vcf_out.write(var.get_var_string() + "\n")
+            if var2 is not None:                   # BND: second mate carries the same genotypes
+                var.share_genotypes_with(var2)
+                vcf_out.write(var2.get_var_string() + "\n")
+        pending.clear()
+
+    for line in vcf_in:
+        if in_header:
+            if line[0] == "#":
+                header_lines.append(line)
+                continue
+            in_header = False
+            vcf.add_header(header_lines)
+            vcf.add_custom_svtyper_headers()
+            for sample in samples:
+                if sample.name not in vcf.sample_list:
+                    vcf.add_sample(sample.name)
+            vcf_out.write(vcf.get_header() + "\n")
+
+        var = Variant(line.rstrip().split("\t"), vcf)
+        if not sum_quals:
+            var.qual = 0
+        if not var.has_svtype():
+            sys.stderr.write("Warning: SVTYPE missing at variant %s. Skipping.\n" % var.var_id)
+            pending.append(("raw", var))
+            continue
+        if var.get_svtype() not in VALID_SVTYPES:
+            sys.stderr.write("Warning: Unsupported SVTYPE at variant %s (%s). Skipping.\n"
+                             % (var.var_id, var.get_svtype()))
+            pending.append(("raw", var))
+            continue
+        bp = vcf.get_variant_breakpoints(var, max_ci_dist)
+        if bp is None:          # first mate of a BND pair: wait for its partner (classic.py:256-258)
+            continue
+        var2 = None
+        if var.get_svtype() == "BND":
+            var2 = var
+            var = _take_first_mate(vcf, bp, var2)
+
+        first_unit = len(collector)
+        for k, sample in enumerate(samples):
+            fragments, many = gather_all_reads(sample, bp, max_reads)
+            collector.add(bp, k, fragments, skip=many)
+        pending.append(("gt", var, var2, first_unit))
+        if len(collector) >= CHUNK_UNITS:
+            flush()
+
+    if in_header and header_lines:   # header-only VCF: the reference writes nothing
+        pass
+    flush()
+    if vcf._bnd_pending:
+        logging.warning("Unpaired breakends found in file. These will not be present in output.")
+    vcf_in.close()
+    vcf_out.close()
+
+
+# the first mate of a BND pair is kept by the Vcf until its partner shows up
+def _take_first_mate(vcf: Vcf, bp: dict, second: Variant) -> Variant:
+    return vcf._bnd_first.pop(bp["id"])
+
+
+def _debug_print(rec):
+    t = dict(zip(ev.TALLY_NAMES, (float(x) for x in rec["tallies"])))
+    print("--------------------------")
+    for key in ("ref_span", "alt_span", "ref_seq", "alt_seq", "alt_clip"):
+        print("%s: %s" % (key, t[key]))
+    if int(rec["gt"]) not in (ev.GT_BLANK, ev.GT_SKIPPED):
+        print([float(x) for x in rec["gl"]])
+
+
+# ------------------------------------------------------------------------------------------ CLI
+def get_args():
+    p = argparse.ArgumentParser(formatter_class=argparse.RawTextHelpFormatter, description=(
+        "svtyper (MI355X-native likelihood path)\nversion: %s\n"
+        "description: Compute genotype of structural variants based on breakpoint depth" % __version__))
+    p.add_argument("-i", "--input_vcf", metavar="FILE", type=argparse.FileType("r"), default=None,
+                   help="VCF input (default: stdin)")
+    p.add_argument("-o", "--output_vcf", metavar="FILE", type=argparse.FileType("w"), default=sys.stdout,
+                   help="output VCF to write (default: stdout)")
+    p.add_argument("-B", "--bam", metavar="FILE", type=str, required=True,
+                   help="BAM or CRAM file(s), comma-separated if genotyping multiple samples")
+    p.add_argument("-T", "--ref_fasta", metavar="FILE", type=str, default=None,
+                   help="Indexed reference FASTA file (recommended for reading CRAM files)")
+    p.add_argument("-S", "--split_bam", type=str, help=argparse.SUPPRESS)
+    p.add_argument("-l", "--lib_info", metavar="FILE", dest="lib_info_path", type=str, default=None,
+                   help="create/read JSON file of library information")
+    p.add_argument("-m", "--min_aligned", metavar="INT", type=int, default=20,
+                   help="minimum number of aligned bases to consider read as evidence [20]")
+    p.add_argument("-n", dest="num_samp", metavar="INT", type=int, default=1000000,
+                   help="number of reads to sample from BAM file for building insert size distribution [1000000]")
+    p.add_argument("-q", "--sum_quals", action="store_true",
+                   help="add genotyping quality to existing QUAL (default: overwrite QUAL field)")
+    p.add_argument("--max_reads", metavar="INT", type=int, default=None,
+                   help="maximum number of reads to assess at any variant (default: unlimited)")
+    p.add_argument("--max_ci_dist", metavar="INT", type=int, default=1e10,
+                   help="maximum size of a confidence interval before 95%% CI is used intead (default: 1e10)")
+    p.add_argument("--split_weight", metavar="FLOAT", type=float, default=1, help="weight for split reads [1]")
+    p.add_argument("--disc_weight", metavar="FLOAT", type=float, default=1,
+                   help="weight for discordant paired-end reads [1]")
+    p.add_argument("-w", "--write_alignment", metavar="FILE", dest="alignment_outpath", type=str, default=None,
+                   help="write relevant reads to BAM file")
+    p.add_argument("--debug", action="store_true", help=argparse.SUPPRESS)
+    p.add_argument("--verbose", action="store_true", default=False, help="Report status updates")
+    args = p.parse_args()
+    if args.input_vcf is None and not sys.stdin.isatty():
+        args.input_vcf = sys.stdin
+    return args
+
+
+def main():
+    args = get_args()
+    logging.basicConfig(format="%(message)s", level=logging.INFO if args.verbose else logging.WARNING)
+    if args.split_bam is not None:
+        sys.stderr.write("Warning: --split_bam (-S) is deprecated. Ignoring %s.\n" % args.split_bam)
+    sv_genotype(args.bam, args.input_vcf, args.output_vcf, args.min_aligned, args.split_weight, args.disc_weight,
+                args.num_samp, args.lib_info_path, args.debug, args.alignment_outpath, args.ref_fasta,
+                args.sum_quals, args.max_reads, args.max_ci_dist)
+
+
+def cli():
+    try:
+        sys.exit(main())
+    except IOError as e:
+        if e.errno != 32:   # EPIPE
+            raise
+
+
+if __name__ == "__main__":
+    cli()

@@ -1,0 +1,107 @@
+"""Shared host machinery of the two drivers (classic.sv_genotype, singlesample.sso_genotype).
+
+The reference genotypes one (variant, sample) at a time inside its VCF loop; here the loop is
+split so the likelihood path can run as ONE device batch:
+
+    pass 1  VCF -> breakpoints -> BAM fetch -> fragments -> 16-byte evidence records (host)
+    device  tally -> bayes_gt -> GT/GQ/SQ for every (breakpoint, sample) unit (HIP kernel)
+    pass 2  results -> FORMAT fields / QUAL -> VCF text (host)
+
+`engine` is the callable that turns an EvidenceBatch into Results.  The product engine is the
+HIP library (`HipEngine`); there is no CPU engine in this package -- the tests plug the oracle in
+through the same seam.
+"""
+from __future__ import annotations
+
+import sys
+from typing import Callable, Dict, List, Optional, Tuple
+
+from . import evidence as ev
+from .evidence import EvidenceBatch, Results
+from .fragments import SamFragment
+from .library import Sample
+from .packer import BatchBuilder, pack_fragments, unit_header
+
+Engine = Callable[[EvidenceBatch, int], Results]
+
+Z = 3            # fetch / straddle flank in standard deviations (classic.py:183)
+SPLIT_SLOP = 3   # slop around the breakpoint for split reads (classic.py:184)
+MIN_LIB_PREVALENCE = 1e-3
+
+
+class HipEngine:
+    """EvidenceBatch -> Results on one MI355X through the C ABI (include/svtyper_hip.h)."""
+
+    def __init__(self, device: int = 0):
+        from . import hip
+        hip.load()   # raises if libsvtyper_hip.so is missing
+        if hip.device_count() <= device:
+            raise hip.SvtyperHipError(
+                "no MI355X visible as device %d: svtyper_amd has no CPU fallback for the likelihood path" % device)
+        self._hip = hip
+        self.device = device
+
+    def __call__(self, batch: EvidenceBatch, flags: int = 0) -> Results:
+        return self._hip.genotype_batch(batch, device=self.device, flags=flags)
+
+
+def default_engine() -> Engine:
+    return HipEngine(0)
+
+
+class UnitCollector:
+    """Packs (breakpoint, sample) units of one chunk of variants and remembers where each went."""
+
+    def __init__(self, samples: List[Sample], split_weight: float, disc_weight: float, min_aligned: int):
+        self.samples = samples
+        self.min_aligned = min_aligned
+        self.lib_tables = []
+        self.lib_index: Dict[int, int] = {}
+        for s in samples:
+            for lib in s.lib_dict.values():
+                self.lib_index[id(lib)] = len(self.lib_tables)
+                self.lib_tables.append(lib.table())
+        if len(self.lib_tables) > 256:
+            raise ValueError("more than 256 libraries in one run are not supported by the evidence record")
+        self.split_weight = split_weight
+        self.disc_weight = disc_weight
+        self.builder = BatchBuilder(self.lib_tables, split_weight, disc_weight)
+
+    def add(self, breakpoint: dict, sample_index: int, fragments: Optional[Dict[str, SamFragment]],
+            skip: bool = False) -> int:
+        unit = unit_header(breakpoint, sample_index, skip)
+        recs = None
+        if fragments and not skip:
+            recs = pack_fragments(fragments, breakpoint, self.lib_index, self.min_aligned, SPLIT_SLOP)
+        return self.builder.add(unit, recs)
+
+    def __len__(self):
+        return len(self.builder)
+
+    def run(self, engine: Engine, flags: int) -> Results:
+        batch = self.builder.build()
+        if batch.n_units == 0:
+            return Results.empty(0)
+        res = engine(batch, flags)
+        self.builder = BatchBuilder(self.lib_tables, self.split_weight, self.disc_weight)
+        return res
+
+
+def add_read_to(fragments: Dict[str, SamFragment], read, lib):
+    frag = fragments.get(read.query_name)
+    if frag is None:
+        fragments[read.query_name] = SamFragment(read, lib)
+    else:
+        frag.add_read(read)
+
+
+def fetch_window(sample: Sample, chrom: str, pos: int, ci, as_int: bool) -> Tuple[str, float, float]:
+    """Fetch region of one breakend: pos + ci +- (mean + 3 sd), clamped to the chromosome
+    (classic.py:73-81; singlesample.py:139-156 truncates to int)."""
+    flank = sample.get_fetch_flank(Z)
+    chrom_length = sample.bam.lengths[sample.bam.gettid(chrom)]
+    lo = max(pos + ci[0] - flank, 0)
+    hi = min(pos + ci[1] + flank, chrom_length)
+    if as_int:
+        lo, hi = int(lo), int(hi)
+    return chrom, lo, hi

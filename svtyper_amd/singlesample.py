@@ -1,0 +1,220 @@
+"""`svtyper-sso` (single sample) driver with the reference's call surface.
+
+    sso_genotype(bam_string, vcf_in, vcf_out, min_aligned, split_weight, disc_weight, num_samp,
+                 lib_info_path, debug, ref_fasta, sum_quals, max_reads, max_ci_dist, cores, batch_size)
+
+Same arguments, defaults and output bytes as svtyper/singlesample.py:764-814.  The reference's
+`--cores N` fans batches of breakpoints out to a multiprocessing.Pool (singlesample.py:710-762);
+here every breakpoint of a chunk goes to the GPU in one batch instead, so `cores` only selects the
+reference's two-pass bookkeeping and `batch_size` is accepted for compatibility.  The kernel runs
+with the singlesample floating-point association (SVT_FLAG_SSO_ASSOCIATION).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+
+from . import __version__
+from . import evidence as ev
+from .bam import open_alignment_file
+from .library import Sample, setup_sample, write_sample_json
+from .pipeline import (MIN_LIB_PREVALENCE, UnitCollector, add_read_to, default_engine, fetch_window)
+from .results import blank_result, result_from_record
+from .vcf import Variant, Vcf
+
+CHUNK_UNITS = 200_000
+_ASSIGN_ORDER = ("GT", "GQ", "SQ", "GL", "DP", "AO", "RO", "AS", "ASC", "RS", "AP", "RP", "QR", "QA", "AB")
+
+
+def logit(msg):
+    import datetime
+    import time
+    ts = time.strftime("[ %Y-%m-%d %T ]", datetime.datetime.now().timetuple())
+    print("%s %s" % (ts, msg), file=sys.stderr)
+    sys.stderr.flush()
+
+
+def gather_reads(sample: Sample, bp: dict, max_reads):
+    """Fragments of both breakends, or ({}, True) when either region holds more than max_reads
+    countable reads (singlesample.py:158-205: bam.count() of both regions first, then fetch)."""
+    regions = [fetch_window(sample, bp[s]["chrom"], bp[s]["pos"], bp[s]["ci"], as_int=True) for s in ("A", "B")]
+    if max_reads is not None:
+        counts = [sample.bam.count(c, lo, hi, read_callback="all") for c, lo, hi in regions]
+        if counts[0] > max_reads or counts[1] > max_reads:
+            logit("SKIPPING -- Variant '%s' has a region with too many reads (> %s)" % (bp["id"], max_reads))
+            return {}, True
+    fragments = {}
+    for chrom, lo, hi in regions:
+        for read in sample.bam.fetch(chrom, lo, hi):
+            if read.is_unmapped or read.is_duplicate:
+                continue
+            lib = sample.rg_to_lib[read.get_tag("RG")]
+            if lib.name not in sample.active_libs:
+                continue
+            add_read_to(fragments, read, lib)
+    return fragments, False
+
+
+def assign_genotype(variant: Variant, sample_name: str, rec) -> None:
+    """singlesample.py:544-575: every FORMAT field is always written; QUAL accumulates."""
+    res = blank_result() if int(rec["gt"]) in (ev.GT_BLANK, ev.GT_SKIPPED) else result_from_record(rec)
+    variant.qual += res["qual"]
+    g = variant.genotype(sample_name)
+    for key in _ASSIGN_ORDER:
+        g.set_format(key, res["formats"][key])
+
+
+def sso_genotype(bam_string, vcf_in, vcf_out, min_aligned, split_weight, disc_weight, num_samp, lib_info_path,
+                 debug, ref_fasta, sum_quals, max_reads, max_ci_dist, cores, batch_size, *, engine=None):
+    if vcf_in is None:
+        return
+    full_bam_path = os.path.abspath(bam_string)
+    if not (full_bam_path.endswith(".bam") or full_bam_path.endswith(".cram")):
+        sys.exit("Error: %s is not a valid alignment file (*.bam or *.cram)\n" % full_bam_path)
+    bam = open_alignment_file(full_bam_path, ref_fasta)
+
+    lib_info = None
+    if lib_info_path is not None and os.path.exists(lib_info_path):
+        logit("Reading library metrics from %s..." % lib_info_path)
+        with open(lib_info_path) as f:
+            lib_info = json.load(f)
+    sample = setup_sample(bam, lib_info, num_samp, MIN_LIB_PREVALENCE)
+    if lib_info_path is not None and not os.path.exists(lib_info_path):
+        logit("Writing library metrics to %s..." % lib_info_path)
+        write_sample_json([sample], open(lib_info_path, "w"))
+
+    if engine is None:
+        engine = default_engine()
+
+    # header: only the '##' lines are parsed, so sample columns of the input are not carried over and
+    # the BAM's sample becomes the only column (singlesample.py:112-125)
+    lines = vcf_in.readlines()
+    header = []
+    for line in lines:
+        if line.startswith("##"):
+            header.append(line)
+        else:
+            break
+    vcf = Vcf()
+    vcf.filename = getattr(vcf_in, "name", "<stdin>")
+    vcf.add_header(header)
+    vcf.add_custom_svtyper_headers()
+    input_samples = []
+    for line in lines:
+        if line.startswith("#CHROM"):
+            input_samples = line.rstrip().split("\t")[9:]
+            break
+    if sample.name not in input_samples:
+        logit("Note: Did not find sample name : '%s' in input vcf: '%s' -- adding" % (sample.name, vcf.filename))
+    vcf.add_sample(sample.name)
+    vcf.write_header(vcf_out)
+
+    logit("Genotyping Input VCF (%s Mode)" % ("Serial" if cores is None else "Parallel"))
+    collector = UnitCollector([sample], split_weight, disc_weight, min_aligned)
+    pending: list = []
+
+    def flush():
+        results = collector.run(engine, ev.FLAG_SSO_ASSOCIATION)
+        for action in pending:
+            if action[0] == "raw":
+                action[1].write(vcf_out)
+                continue
+            _, variant, variant2, unit = action
+            assign_genotype(variant, sample.name, results.rec[unit])
+            variant.write(vcf_out)
+            if variant2 is not None:
+                variant.share_genotypes_with(variant2)
+                variant2.write(vcf_out)
+        pending.clear()
+
+    for line in lines:
+        if line.startswith("#"):
+            continue
+        variant = Variant(line.rstrip().split("\t"), vcf)
+        if not sum_quals:
+            variant.qual = 0
+        if not variant.has_svtype():
+            logit("Warning: SVTYPE missing at variant %s. Skipping.\n" % variant.var_id)
+            pending.append(("raw", variant))
+            continue
+        if not variant.is_valid_svtype():
+            logit("Warning: Unsupported SVTYPE at variant %s (%s). Skipping.\n" % (variant.var_id, variant.get_svtype()))
+            pending.append(("raw", variant))
+            continue
+        bp = vcf.get_variant_breakpoints(variant, max_ci_dist)
+        if bp is None:
+            continue
+        variant2 = None
+        if variant.get_svtype() == "BND":
+            variant2 = variant
+            variant = vcf._bnd_first.pop(bp["id"])
+        fragments, many = gather_reads(sample, bp, max_reads)
+        unit = collector.add(bp, 0, fragments, skip=many)
+        pending.append(("gt", variant, variant2, unit))
+        if len(collector) >= CHUNK_UNITS:
+            flush()
+    flush()
+    sample.close()
+
+
+# ------------------------------------------------------------------------------------------ CLI
+def get_args():
+    p = argparse.ArgumentParser(formatter_class=argparse.RawTextHelpFormatter, description=(
+        "svtyper-sso (MI355X-native likelihood path)\nversion: %s\n"
+        "description: Compute genotype of structural variants based on breakpoint depth on a SINGLE sample"
+        % __version__))
+    p.add_argument("-i", "--input_vcf", metavar="FILE", type=argparse.FileType("r"), default=None,
+                   help="VCF input (default: stdin)")
+    p.add_argument("-o", "--output_vcf", metavar="FILE", type=argparse.FileType("w"), default=sys.stdout,
+                   help="output VCF to write (default: stdout)")
+    p.add_argument("-B", "--bam", metavar="FILE", type=str, required=True, help="BAM or CRAM file")
+    p.add_argument("-T", "--ref_fasta", metavar="FILE", type=str, default=None,
+                   help="Indexed reference FASTA file (recommended for reading CRAM files)")
+    p.add_argument("-S", "--split_bam", type=str, help=argparse.SUPPRESS)
+    p.add_argument("-l", "--lib_info", metavar="FILE", dest="lib_info_path", type=str, default=None,
+                   help="create/read JSON file of library information")
+    p.add_argument("-m", "--min_aligned", metavar="INT", type=int, default=20,
+                   help="minimum number of aligned bases to consider read as evidence [20]")
+    p.add_argument("-n", dest="num_samp", metavar="INT", type=int, default=1000000,
+                   help="number of reads to sample from BAM file for building insert size distribution [1000000]")
+    p.add_argument("-q", "--sum_quals", action="store_true",
+                   help="add genotyping quality to existing QUAL (default: overwrite QUAL field)")
+    p.add_argument("--max_reads", metavar="INT", type=int, default=1000,
+                   help="maximum number of reads to assess at any variant (default: 1000)")
+    p.add_argument("--max_ci_dist", metavar="INT", type=int, default=1e10,
+                   help="maximum size of a confidence interval before 95%% CI is used intead (default: 1e10)")
+    p.add_argument("--split_weight", metavar="FLOAT", type=float, default=1, help="weight for split reads [1]")
+    p.add_argument("--disc_weight", metavar="FLOAT", type=float, default=1,
+                   help="weight for discordant paired-end reads [1]")
+    p.add_argument("--debug", action="store_true", help=argparse.SUPPRESS)
+    p.add_argument("--cores", type=int, metavar="INT", default=None,
+                   help="accepted for compatibility: breakpoints are batched onto the GPU instead of a worker pool")
+    p.add_argument("--batch_size", type=int, metavar="INT", default=1000,
+                   help="accepted for compatibility with the reference's worker batches")
+    args = p.parse_args()
+    if args.input_vcf is None and not sys.stdin.isatty():
+        args.input_vcf = sys.stdin
+    return args
+
+
+def main():
+    args = get_args()
+    if args.split_bam is not None:
+        sys.stderr.write("Warning: --split_bam (-S) is deprecated. Ignoring %s.\n" % args.split_bam)
+    sso_genotype(args.bam, args.input_vcf, args.output_vcf, args.min_aligned, args.split_weight, args.disc_weight,
+                 args.num_samp, args.lib_info_path, args.debug, args.ref_fasta, args.sum_quals, args.max_reads,
+                 args.max_ci_dist, args.cores, args.batch_size)
+
+
+def cli():
+    try:
+        sys.exit(main())
+    except IOError as e:
+        if e.errno != 32:
+            raise
+
+
+if __name__ == "__main__":
+    cli()
