@@ -145,14 +145,16 @@ def main():
     # ---- the single RCCL gather of the result records onto rank 0
     gather = None
     if world > 1:
-        bufs = [torch.empty_like(res_buf) for _ in range(world)] if rank == 0 else None
+        from svtyper_amd import distributed as D
         barrier()
         torch.cuda.synchronize()
         g0 = time.perf_counter()
-        dist.gather(res_buf, bufs, dst=0)
+        gathered = D.gather_result_records(res_buf, [n] * world, dst=0)
         torch.cuda.synchronize()
         barrier()
         g_s = time.perf_counter() - g0
+        if rank == 0:
+            assert gathered.numel() == cur * world
         gather = {"bytes_per_rank": int(cur), "ms": g_s * 1e3,
                   "GB/s_into_root": cur * (world - 1) / g_s / 1e9, "collective": "rccl gather"}
 
