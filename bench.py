@@ -74,6 +74,8 @@ def main():
     ap.add_argument("--sso", action="store_true", help="singlesample.py floating-point association")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise torch.distributed (RCCL) and run the gather even with one rank")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -99,8 +101,10 @@ def main():
     if hip.device_count() <= local_rank:
         sys.exit("bench.py needs %d MI355X device(s); the HIP path has no CPU fallback" % (local_rank + 1))
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))
 
@@ -118,7 +122,7 @@ def main():
     cur = res_buf.numel()
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     for _ in range(args.warmup):
@@ -134,7 +138,7 @@ def main():
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -144,7 +148,7 @@ def main():
 
     # ---- the single RCCL gather of the result records onto rank 0
     gather = None
-    if world > 1:
+    if use_dist:
         from svtyper_amd import distributed as D
         barrier()
         torch.cuda.synchronize()
@@ -156,7 +160,7 @@ def main():
         if rank == 0:
             assert gathered.numel() == cur * world
         gather = {"bytes_per_rank": int(cur), "ms": g_s * 1e3,
-                  "GB/s_into_root": cur * (world - 1) / g_s / 1e9, "collective": "rccl gather"}
+                  "GB/s_into_root": cur * max(world - 1, 1) / g_s / 1e9, "collective": "rccl gather"}
 
     if rank == 0:
         got = dbatch.results()
@@ -238,7 +242,7 @@ def main():
         print(json.dumps(out), flush=True)
 
     dbatch.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
