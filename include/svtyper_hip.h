@@ -226,6 +226,13 @@ void* svt_batch_stream(svt_batch* b);
 
 void svt_batch_destroy(svt_batch* b);
 
+/* Array form of the reference's inner operator seam statistics.bayes_gt(ref, alt, is_dup)
+ * (svtyper/statistics.py:23-37) and log_choose(ref + alt, alt) (statistics.py:9-20):
+ * out[4*i .. 4*i+3] = { lp_homref, lp_het, lp_homalt, log_choose } for item i.  All pointers
+ * are host memory; ref[i], alt[i] >= 0 and ref[i] + alt[i] < 2^24.                           */
+int svt_bayes_gt(const int32_t* ref, const int32_t* alt, const uint8_t* is_dup, uint64_t n,
+                 double* out, int device);
+
 /* Convenience: create + genotype + results + destroy.                          */
 int svt_genotype(const svt_evidence_batch* in, svt_result* out, int device,
                  unsigned flags);

@@ -520,6 +520,28 @@ __global__ __launch_bounds__(kBlock) void svt_repack_kernel(const RepackArgs a)
 }
 
 // ------------------------------------------------------------------------------------------
+// bayes_gt seam kernel: one (ref, alt, is_dup) item per thread (statistics.py:9-37)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void svt_bayes_kernel(const int32_t* __restrict__ ref,
+                                                           const int32_t* __restrict__ alt,
+                                                           const uint8_t* __restrict__ is_dup,
+                                                           uint64_t n, const double* __restrict__ l10,
+                                                           const GtConsts c, double* __restrict__ out)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const int32_t r = ref[i], a = alt[i];
+    const int d = is_dup[i] ? 1 : 0;
+    const double log_combo = log_choose_dev(l10, r + a, a);
+    double4 o;
+    o.x = (log_combo + (double)a * c.lgp[d][0]) + (double)r * c.lg1p[d][0];
+    o.y = (log_combo + (double)a * c.lgp[d][1]) + (double)r * c.lg1p[d][1];
+    o.z = (log_combo + (double)a * c.lgp[d][2]) + (double)r * c.lg1p[d][2];
+    o.w = log_combo;
+    reinterpret_cast<double4*>(out)[i] = o;
+}
+
+// ------------------------------------------------------------------------------------------
 // host-side table construction (same libm calls CPython makes)
 // ------------------------------------------------------------------------------------------
 
@@ -538,6 +560,9 @@ bool p_concordant_expr(uint32_t h1, uint32_t h2, uint64_t n_total)
 
 double py_log10(double x) { return std::log(x) / std::log(10.0); }  // math.log(x, 10)
 
+struct GtConsts;
+void fill_gt_consts(GtConsts& c, double split_weight, double disc_weight);
+
 // smallest double x with pow(10.0, x) > 0 under this libm (CPython: 10 ** x)
 double find_pow10_underflow()
 {
@@ -550,6 +575,20 @@ double find_pow10_underflow()
     // walk to the exact boundary in ulps
     while (std::pow(10.0, std::nextafter(hi, -INFINITY)) > 0.0) hi = std::nextafter(hi, -INFINITY);
     return hi;
+}
+
+void fill_gt_consts(GtConsts& c, double split_weight, double disc_weight)
+{
+    const double p_alt[2][3] = {{1e-3, 0.5, 0.9}, {1e-2, 0.2, 1 / 3.0}};  // statistics.py:26,28
+    for (int d = 0; d < 2; ++d)
+        for (int g = 0; g < 3; ++g) {
+            c.lgp[d][g] = py_log10(p_alt[d][g]);
+            c.lg1p[d][g] = py_log10(1 - p_alt[d][g]);
+        }
+    c.ln10 = std::log(10.0);
+    c.x_uflow = find_pow10_underflow();
+    c.split_weight = split_weight;
+    c.disc_weight = disc_weight;
 }
 
 }  // namespace
@@ -926,18 +965,7 @@ int svt_batch_create(const svt_evidence_batch* in, int device, unsigned flags, s
     a.out = b->d_out;
     a.wtab = b->d_wtab;
     a.lib0 = libs[0];
-    {
-        const double p_alt[2][3] = {{1e-3, 0.5, 0.9}, {1e-2, 0.2, 1 / 3.0}};  // statistics.py:26,28
-        for (int d = 0; d < 2; ++d)
-            for (int g = 0; g < 3; ++g) {
-                a.c.lgp[d][g] = py_log10(p_alt[d][g]);
-                a.c.lg1p[d][g] = py_log10(1 - p_alt[d][g]);
-            }
-        a.c.ln10 = std::log(10.0);
-        a.c.x_uflow = find_pow10_underflow();
-        a.c.split_weight = in->split_weight;
-        a.c.disc_weight = in->disc_weight;
-    }
+    fill_gt_consts(a.c, in->split_weight, in->disc_weight);
     const size_t table_bytes = (size_t)total_bins * 8;
     if (fast_geometry && table_bytes <= kMaxLdsTableBytes) b->mode = in->n_libs == 1 ? kSingleLds : kMultiLds;
     else b->mode = kGeneral;
@@ -1018,6 +1046,62 @@ int svt_batch_bytes(const svt_batch* b, uint64_t* algorithmic, uint64_t* residen
     if (!b) return fail(SVT_ERR_INVALID, "null batch");
     if (algorithmic) *algorithmic = 16 * b->n_records + (16 + 96) * b->n_units;
     if (resident) *resident = 16 * b->tiled_records + (uint64_t)b->n_tiles * kWave * sizeof(LaneHdr);
+    return SVT_OK;
+}
+
+int svt_bayes_gt(const int32_t* ref, const int32_t* alt, const uint8_t* is_dup, uint64_t n, double* out,
+                 int device)
+{
+    if (n == 0) return SVT_OK;
+    if (!ref || !alt || !is_dup || !out) return fail(SVT_ERR_INVALID, "null argument");
+    int ndev = svt_device_count();
+    if (ndev <= 0) return fail(SVT_ERR_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(SVT_ERR_NO_DEVICE, "device index out of range");
+    int64_t max_total = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        if (ref[i] < 0 || alt[i] < 0) return fail(SVT_ERR_INVALID, "negative read count");
+        max_total = std::max<int64_t>(max_total, (int64_t)ref[i] + alt[i]);
+    }
+    if (max_total >= (1 << 24)) return fail(SVT_ERR_INVALID, "ref + alt must be < 2^24");
+    std::vector<double> l10((size_t)max_total + 2);
+    l10[0] = 0.0;
+    for (size_t i = 1; i < l10.size(); ++i) l10[i] = py_log10((double)i);
+    GtConsts c{};
+    fill_gt_consts(c, 1.0, 1.0);
+    HIP_TRY(hipSetDevice(device));
+    int32_t *d_ref = nullptr, *d_alt = nullptr;
+    uint8_t* d_dup = nullptr;
+    double *d_l10 = nullptr, *d_out = nullptr;
+    auto cleanup = [&]() {
+        if (d_ref) (void)hipFree(d_ref);
+        if (d_alt) (void)hipFree(d_alt);
+        if (d_dup) (void)hipFree(d_dup);
+        if (d_l10) (void)hipFree(d_l10);
+        if (d_out) (void)hipFree(d_out);
+    };
+#define BT(expr)                                                                          \
+    do {                                                                                  \
+        hipError_t _e = (expr);                                                           \
+        if (_e != hipSuccess) {                                                           \
+            cleanup();                                                                    \
+            return fail(SVT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));  \
+        }                                                                                 \
+    } while (0)
+    BT(hipMalloc(reinterpret_cast<void**>(&d_ref), n * sizeof(int32_t)));
+    BT(hipMalloc(reinterpret_cast<void**>(&d_alt), n * sizeof(int32_t)));
+    BT(hipMalloc(reinterpret_cast<void**>(&d_dup), n));
+    BT(hipMalloc(reinterpret_cast<void**>(&d_l10), l10.size() * sizeof(double)));
+    BT(hipMalloc(reinterpret_cast<void**>(&d_out), n * 4 * sizeof(double)));
+    BT(hipMemcpy(d_ref, ref, n * sizeof(int32_t), hipMemcpyHostToDevice));
+    BT(hipMemcpy(d_alt, alt, n * sizeof(int32_t), hipMemcpyHostToDevice));
+    BT(hipMemcpy(d_dup, is_dup, n, hipMemcpyHostToDevice));
+    BT(hipMemcpy(d_l10, l10.data(), l10.size() * sizeof(double), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(svt_bayes_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, 0, d_ref,
+                       d_alt, d_dup, n, d_l10, c, d_out);
+    BT(hipGetLastError());
+    BT(hipMemcpy(out, d_out, n * 4 * sizeof(double), hipMemcpyDeviceToHost));
+#undef BT
+    cleanup();
     return SVT_OK;
 }
 

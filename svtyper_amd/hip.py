@@ -20,7 +20,7 @@ EXPORTS = (
     "svt_version", "svt_device_count", "svt_last_error", "svt_batch_create", "svt_batch_genotype",
     "svt_batch_genotype_timed", "svt_batch_results", "svt_batch_device_results",
     "svt_batch_bind_device_results", "svt_batch_bytes",
-    "svt_batch_stream", "svt_batch_destroy", "svt_genotype",
+    "svt_batch_stream", "svt_batch_destroy", "svt_bayes_gt", "svt_genotype",
 )
 
 _lib: Optional[C.CDLL] = None
@@ -72,6 +72,8 @@ def load() -> C.CDLL:
     L.svt_batch_stream.argtypes = [C.c_void_p]
     L.svt_batch_destroy.restype = None
     L.svt_batch_destroy.argtypes = [C.c_void_p]
+    L.svt_bayes_gt.restype = C.c_int
+    L.svt_bayes_gt.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int]
     L.svt_genotype.restype = C.c_int
     L.svt_genotype.argtypes = [C.POINTER(CEvidenceBatch), C.c_void_p, C.c_int, C.c_uint]
     if L.svt_version() != ABI_VERSION:
@@ -159,4 +161,19 @@ def genotype_batch(batch: EvidenceBatch, device: int = 0, flags: int = 0) -> Res
     out = Results.empty(batch.n_units)
     cb = batch.as_c()
     _check(L.svt_genotype(C.byref(cb), C.c_void_p(out.ptr()), int(device), int(flags)))
+    return out
+
+
+def bayes_gt_array(ref, alt, is_dup, device: int = 0):
+    """svt_bayes_gt: arrays of (ref, alt, is_dup) -> float64 [n, 4] = (lp_homref, lp_het, lp_homalt,
+    log_choose(ref + alt, alt)), evaluated on the device (svtyper/statistics.py:9-37)."""
+    import numpy as np
+    L = load()
+    r = np.ascontiguousarray(ref, dtype=np.int32)
+    a = np.ascontiguousarray(alt, dtype=np.int32)
+    d = np.ascontiguousarray(np.broadcast_to(np.asarray(is_dup, dtype=np.uint8), r.shape))
+    if r.shape != a.shape:
+        raise ValueError("ref and alt must have the same shape")
+    out = np.zeros((r.size, 4), np.float64)
+    _check(L.svt_bayes_gt(r.ctypes.data, a.ctypes.data, d.ctypes.data, r.size, out.ctypes.data, int(device)))
     return out

@@ -9,6 +9,7 @@ Outputs (committed; the reference itself never travels):
   fixture_sites.json.gz  the 211 breakpoints of the reference's own fixture (tests/data): breakpoint
                          dict, packed evidence records (from the reference's fragment objects and
                          predicates), reference tallies in both associations, reference result
+  library_from_bam.json.gz  Sample.from_bam() statistics of the fixture BAM
   fake_sites.json.gz     synthetic fake-read sites: libraries, breakpoint, the reads themselves,
                          packed records, reference tallies + result
 
@@ -213,8 +214,24 @@ def make_fake(ref, n_sites=420):
                                 "min_aligned": 20, "split_slop": 3})
 
 
+def make_library_from_bam(ref):
+    """Library statistics built empirically from the fixture BAM by the reference
+    (parsers.py:472-583, statistics.py:40-121) -- pins svtyper_amd.library.Library.from_bam."""
+    bam = bam_module.AlignmentFile(BAM)
+    sample = ref.parsers.Sample.from_bam(bam, 1000000, 1e-3)
+    libs = []
+    for lib in sample.lib_dict.values():
+        libs.append({"name": lib.name, "readgroups": list(lib.readgroups), "read_length": lib.read_length,
+                     "mean": hx(lib.mean), "sd": hx(lib.sd), "prevalence": hx(lib.prevalence),
+                     "hist": {str(k): int(v) for k, v in lib.hist.items()}})
+    dump("library_from_bam.json.gz", {"sample": sample.name, "active_libs": list(sample.active_libs),
+                                      "fetch_flank_z3": hx(sample.get_fetch_flank(3)), "libraries": libs,
+                                      "mapped": sample.bam_mapped, "unmapped": sample.bam_unmapped})
+
+
 if __name__ == "__main__":
     ref = refload.load_reference(pysam_module=bam_module)
     make_bayes_grid(ref)
     make_fixture(ref)
     make_fake(ref)
+    make_library_from_bam(ref)

@@ -39,3 +39,22 @@ def test_fake_sites(hip_device):
     g = gio.load("fake_sites.json.gz")
     for grp in g["groups"]:
         _check(grp["sites"], grp["libraries"], ev.FLAG_SSO_ASSOCIATION, hip_device)
+
+
+def test_bayes_gt_seam(hip_device):
+    """statistics.bayes_gt / log_choose through svt_bayes_gt: bit-exact against the reference's values
+    (bayes_grid golden + SURVEY.md 8c-iii known answers)."""
+    import numpy as np
+    from svtyper_amd import statistics as st
+    assert st.bayes_gt(10, 5, False) == (-11.526789785541196, -1.0378946027607374, -6.751232120604396)
+    assert st.bayes_gt(10, 5, True) == (-6.566092721825519, -0.9863948195616774, -0.6689635319561438)
+    assert st.bayes_gt(0, 0, True) == (0.0, 0.0, 0.0)
+    assert st.log_choose(200, 100) == 58.956881330608695
+    g = gio.load("bayes_grid.json.gz")
+    ref, alt, dup, want = [], [], [], []
+    for case in g["cases"]:
+        f = gio.golden_result(case["result"])["formats"]
+        ref.append(f["QR"]); alt.append(f["QA"]); dup.append(case["svtype"] == "DUP")
+        want.append([gio.fh(x) for x in case["gl"]])
+    got = st.bayes_gt_array(ref, alt, dup)
+    assert np.array_equal(got.view(np.uint64), np.asarray(want).view(np.uint64))

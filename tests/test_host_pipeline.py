@@ -85,3 +85,42 @@ def test_sso_integration_hip(tmp_path, hip_device, cores):
     out = str(tmp_path / "out.vcf")
     run_sso(out, None, cores)
     same_vcf(EXPECTED, out)
+
+
+def test_library_from_bam_matches_reference():
+    """Library.from_bam / Sample.from_bam against the statistics the imported reference computed
+    from the same BAM (tests/golden/library_from_bam.json.gz)."""
+    import goldenio as gio
+    from svtyper_amd import bam, library
+    g = gio.load("library_from_bam.json.gz")
+    sample = library.Sample.from_bam(bam.AlignmentFile(IN_BAM), 1000000, 1e-3)
+    assert sample.name == g["sample"] and sample.active_libs == g["active_libs"]
+    assert float(sample.get_fetch_flank(3)).hex() == g["fetch_flank_z3"]
+    assert (sample.bam_mapped, sample.bam_unmapped) == (g["mapped"], g["unmapped"])
+    assert len(sample.lib_dict) == len(g["libraries"])
+    for lib, want in zip(sample.lib_dict.values(), g["libraries"]):
+        assert lib.name == want["name"] and lib.readgroups == want["readgroups"]
+        assert lib.read_length == want["read_length"]
+        assert float(lib.mean).hex() == want["mean"] and float(lib.sd).hex() == want["sd"]
+        assert float(lib.prevalence).hex() == want["prevalence"]
+        assert {str(k): int(v) for k, v in lib.hist.items()} == want["hist"]
+
+
+def test_sso_builds_library_json_when_absent(tmp_path):
+    """-l pointing to a missing file: statistics are computed from the BAM and the JSON cache is
+    written in the reference's schema (utils.py:25-51), then reusable."""
+    import json
+    lib_json = str(tmp_path / "lib.json")
+    out = str(tmp_path / "out.vcf")
+    with open(IN_VCF) as inf, open(out, "w") as outf:
+        singlesample.sso_genotype(IN_BAM, inf, outf, 20, 1, 1, 1000000, lib_json, False, None, False, 1000, 1e10,
+                                  None, 1000, engine=oracle_engine)
+    info = json.load(open(lib_json))
+    lib = info["NA12878"]["libraryArray"][0]
+    assert set(lib) == {"library_name", "readgroups", "read_length", "mean", "sd", "prevalence", "histogram"}
+    assert info["NA12878"]["mapped"] == 42801
+    out2 = str(tmp_path / "out2.vcf")
+    with open(IN_VCF) as inf, open(out2, "w") as outf:
+        singlesample.sso_genotype(IN_BAM, inf, outf, 20, 1, 1, 1000000, lib_json, False, None, False, 1000, 1e10,
+                                  None, 1000, engine=oracle_engine)
+    same_vcf(out, out2)
