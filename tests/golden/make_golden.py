@@ -229,9 +229,26 @@ def make_library_from_bam(ref):
                                       "mapped": sample.bam_mapped, "unmapped": sample.bam_unmapped})
 
 
+def make_multisample_vcf(ref):
+    """classic.sv_genotype with the fixture BAM given twice (two 'samples' sharing one column) and
+    --sum_quals: pins the per-sample loop, QUAL accumulation and the blank-result QUAL reset
+    (classic.py:216-217,279,485,498)."""
+    out = io.StringIO()
+    out.close = lambda: None
+    with open(VCF) as fin:
+        ref.classic.sv_genotype(BAM + "," + BAM, fin, out, 20, 1, 1, 1000000, LIBJSON, False, None, None, True,
+                                None, 1e10)
+    text = "\n".join(l for l in out.getvalue().split("\n") if not l.startswith("##fileDate="))
+    path = os.path.join(HERE, "example.twice.sumquals.gt.vcf.gz")
+    with gzip.GzipFile(path, "wb", mtime=0) as f:
+        f.write(text.encode())
+    print("wrote %s (%d bytes)" % (os.path.basename(path), os.path.getsize(path)))
+
+
 if __name__ == "__main__":
     ref = refload.load_reference(pysam_module=bam_module)
     make_bayes_grid(ref)
     make_fixture(ref)
     make_fake(ref)
     make_library_from_bam(ref)
+    make_multisample_vcf(ref)

@@ -124,3 +124,18 @@ def test_sso_builds_library_json_when_absent(tmp_path):
         singlesample.sso_genotype(IN_BAM, inf, outf, 20, 1, 1, 1000000, lib_json, False, None, False, 1000, 1e10,
                                   None, 1000, engine=oracle_engine)
     same_vcf(out, out2)
+
+
+def test_classic_two_bams_sum_quals(tmp_path):
+    """Multi-sample loop + QUAL accumulation (--sum_quals) against the imported reference's output for
+    the same call (tests/golden/example.twice.sumquals.gt.vcf.gz)."""
+    import gzip
+    out = str(tmp_path / "out.vcf")
+    with open(IN_VCF) as inf, open(out, "w") as outf:
+        classic.sv_genotype(IN_BAM + "," + IN_BAM, inf, outf, 20, 1, 1, 1000000, LIB_JSON, False, None, None, True,
+                            None, 1e10, engine=oracle_engine)
+    want = gzip.open(os.path.join(HERE, "golden", "example.twice.sumquals.gt.vcf.gz"), "rt").read().split("\n")
+    got = [l for l in open(out).read().split("\n") if not l.startswith("##fileDate=")]
+    assert len(got) == len(want)
+    for i, (x, y) in enumerate(zip(got, want)):
+        assert x == y, "line %d\n%s\n%s" % (i + 1, x, y)
