@@ -72,6 +72,7 @@ def main():
     ap.add_argument("--units", type=int, default=1_000_000, help="breakpoints per GPU")
     ap.add_argument("--workload", default="c3_mixed_1m", choices=["c3_mixed_1m", "c2_del_100k"])
     ap.add_argument("--sso", action="store_true", help="singlesample.py floating-point association")
+    ap.add_argument("--dense", action="store_true", help="stream the canonical 16-byte records (no sparse re-encoding)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--force-dist", action="store_true",
@@ -108,7 +109,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))
 
-    flags = ev.FLAG_SSO_ASSOCIATION if args.sso else 0
+    flags = (ev.FLAG_SSO_ASSOCIATION if args.sso else 0) | (ev.FLAG_DENSE_LAYOUT if args.dense else 0)
     t0 = time.time()
     dbatch = hip.DeviceBatch(batch, device=local_rank, flags=flags)
     upload_s = time.time() - t0
@@ -199,6 +200,7 @@ def main():
                 "units_per_gpu": n,
                 "records_per_gpu": batch.n_records,
                 "association": "sso" if args.sso else "classic",
+                "device_layout": "dense 16-byte records" if args.dense else "split sparse 8-byte streams",
                 "parallelism": "units sharded over %d GPU(s), no data-path collective per step" % world,
             },
             "roofline": {
@@ -232,7 +234,7 @@ def main():
             reps = 0
             want = None
             while True:
-                want = c_oracle.genotype_batch(sample, flags=flags)
+                want = c_oracle.genotype_batch(sample, flags=flags & ev.FLAG_SSO_ASSOCIATION)
                 reps += 1
                 if time.perf_counter() - t0 >= args.cpu_seconds or reps >= 50:
                     break

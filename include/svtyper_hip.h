@@ -58,6 +58,14 @@ extern "C" {
  *   1 (sso)    : contributions are first summed per fragment starting from 0,
  *                then added to the site total (singlesample.py:246-276,367-372) */
 #define SVT_FLAG_SSO_ASSOCIATION 0x1u
+/* device layout of the resident batch:
+ *   0 (default, "split"): the records are re-encoded once, on the device, into two sparse
+ *       8-byte streams per unit -- pair entries (ospan, mapq_a, mapq_b, straddle bits, library)
+ *       for fragments with a straddle bit, weight entries (the six gated MAPQs) for fragments
+ *       with a non-zero gated MAPQ.  Dropped entries could only have added +0.0.
+ *   SVT_FLAG_DENSE_LAYOUT: the 16-byte records are streamed as they are.
+ * Results are bit-identical between the two.                                              */
+#define SVT_FLAG_DENSE_LAYOUT 0x2u
 
 /* ---- evidence record: one per read-fragment (query name) of a unit, 16 B --
  * Records of a unit are stored in the order the reference walks them:

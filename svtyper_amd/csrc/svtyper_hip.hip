@@ -15,11 +15,17 @@
 //     are sequential binary64 sums in record order, exactly as CPython evaluates them, so the
 //     truncated integer counts are bit-exact.  No FMA contraction (-ffp-contract=off).
 //   * records are re-tiled once per batch into lane-interleaved tiles: row j of a tile holds
-//     the j-th record of its 64 units back to back, so every wave-level load is one contiguous
-//     1 KiB global_load_dwordx4.  Units are sorted by record count inside 4096-unit chunks so
-//     that the zero-padding of a tile stays ~1 %.
-//   * all look-up tables (prob_mapq, insert-size histogram + p_concordant thresholds, log10)
-//     are built on the host with the same libm CPython uses and staged in LDS per workgroup.
+//     the j-th 16 bytes of its 64 units back to back, so every wave-level load is one contiguous
+//     1 KiB global_load_dwordx4.  Units are sorted by length inside 4096-unit chunks so that the
+//     zero-padding of a tile stays small.  Two device layouts:
+//       - split (default): a unit's evidence becomes two sparse 8-byte streams -- pair entries
+//         (only fragments with a straddle bit) and weight entries (only fragments with a non-zero
+//         gated MAPQ); entries that could only add +0.0 are dropped, which the reference's sums
+//         cannot observe;
+//       - dense (SVT_FLAG_DENSE_LAYOUT): the canonical 16-byte records as they are.
+//   * all look-up tables (prob_mapq, insert-size histogram + p_concordant thresholds, log10,
+//     paired-end decision weights) are built on the host with the same libm CPython uses and
+//     staged in LDS per workgroup.
 //   * HBM-bound byte/integer/fp64 streaming: no MFMA anywhere (nothing here is a contraction).
 //
 // There is no CPU fallback in this file.
@@ -31,12 +37,17 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
-#include <limits>
-#include <numeric>
 #include <string>
 #include <vector>
 
 #include "../../include/svtyper_hip.h"
+
+#ifndef SVT_GROUP
+#define SVT_GROUP 4   // rows fetched per look-ahead group
+#endif
+#ifndef SVT_CHUNK
+#define SVT_CHUNK 16384
+#endif
 
 namespace {
 
@@ -46,10 +57,11 @@ namespace {
 constexpr int kWave = 64;            // gfx950 wavefront
 constexpr int kWavesPerBlock = 4;    // 256-thread workgroups
 constexpr int kBlock = kWave * kWavesPerBlock;
-constexpr uint32_t kChunkUnits = 4096;  // sort window (units); results scatter stays inside it
+constexpr uint32_t kChunkUnits = SVT_CHUNK;  // sort window (units)
 constexpr uint32_t kPadUnit = 0xFFFFFFFFu;
 constexpr uint32_t kMaxLdsTableBytes = 64 * 1024;  // hist+thr budget before falling back to HBM/L2 tables
 constexpr uint32_t kMaxL10Lds = 4096;              // log10 table entries kept in LDS (32 KiB)
+constexpr uint32_t kTailPadRows = 2 * SVT_GROUP;   // look-ahead loads may run this far past a tile
 
 thread_local std::string g_err;
 
@@ -64,6 +76,11 @@ int fail(int code, const std::string& msg)
         hipError_t _e = (expr);                                                             \
         if (_e != hipSuccess)                                                               \
             return fail(SVT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));    \
+    } while (0)
+#define SVT_TRY(expr)                  \
+    do {                               \
+        int _rc = (expr);              \
+        if (_rc != SVT_OK) return _rc; \
     } while (0)
 
 // ------------------------------------------------------------------------------------------
@@ -86,10 +103,16 @@ struct LaneHdr {          // 16 B, one per tile lane
     uint32_t packed;      // svtype | flags << 8 | sample << 16
 };
 
-struct TileDesc {         // 16 B, one per 64-unit tile, stored in dispatch (longest-first) order
-    uint64_t rec_base;    // first record of the tile inside tiled[]
-    uint32_t rows;        // records per lane (max F of the tile)
+// One 64-unit tile.  Dense layout: rows_a rows of 16-byte records at base_a (rows_b == 0).
+// Split layout: rows_a rows of pair entries at base_a, rows_b rows of weight entries at base_b
+// (each 16-byte row slot of a lane holds two consecutive 8-byte entries).
+struct TileDesc {         // 32 B, stored in dispatch (longest-first) order
+    uint64_t base_a;
+    uint64_t base_b;
+    uint32_t rows_a;
+    uint32_t rows_b;
     uint32_t lane_base;   // first LaneHdr of the tile
+    uint32_t pad;
 };
 
 struct GtConsts {
@@ -138,7 +161,7 @@ struct KernelArgs {
 };
 
 // ------------------------------------------------------------------------------------------
-// genotype kernel
+// evidence arithmetic shared by both layouts
 // ------------------------------------------------------------------------------------------
 struct Tables {
     const double* pm;          // LDS
@@ -156,7 +179,7 @@ struct Acc {
 // per-lane constants of the unit, hoisted out of the record loop
 struct LaneCtx {
     uint32_t del16;       // is_DEL ? 16 : 0 (decision-table index bit)
-    uint32_t fmask;       // kSingleLds: flag mask with the small-DEL gate applied
+    uint32_t fmask;       // kSingleLds: straddle-bit mask with the small-DEL gate applied
     uint32_t kmin;        // kSingleLds: (uint32) key_min
     uint32_t nb;          // kSingleLds: n_bins (== sentinel index)
     uint32_t sub2;        // kSingleLds: DEL ? var_length + key_min : 0x80000000 (never in range)
@@ -165,28 +188,26 @@ struct LaneCtx {
     bool is_del;
 };
 
-// One evidence record.  Every add is unconditional: gated-off evidence arrives as MAPQ 0, whose
-// weight prob_mapq(0) is exactly +0.0, and x + 0.0 == x bit-for-bit for these non-negative sums.
-template <bool SSO, int MODE>
-__device__ __forceinline__ void tally_record(const uint4 w, const Tables& t, const LaneCtx& c, Acc& a)
+// Split-read / reference-read weights of one fragment record (classic.py:306-328).  Every add is
+// unconditional: gated-off evidence arrives as MAPQ 0, whose weight prob_mapq(0) is exactly +0.0,
+// and x + 0.0 == x bit-for-bit for these non-negative sums.
+//   wa = rs_a | rs_b << 8 | seq_l << 16 | seq_r << 24,  wb = clip_l | clip_r << 8
+template <bool SSO>
+__device__ __forceinline__ void weight_evidence(const uint32_t wa, const uint32_t wb, const bool cont,
+                                                const Tables& t, Acc& a)
 {
-    // ---- prob_mapq look-ups (utils.py:74-75 through the host-built LUT)
-    const double pm_a = t.pm[w.y & 0xffu];
-    const double pm_b = t.pm[(w.y >> 8) & 0xffu];
-    const double rs_a = t.pm[(w.y >> 16) & 0xffu];
-    const double rs_b = t.pm[w.y >> 24];
-    const double sq_l = t.pm[w.z & 0xffu];
-    const double sq_r = t.pm[(w.z >> 8) & 0xffu];
-    const double cl_l = t.pm[(w.z >> 16) & 0xffu];
-    const double cl_r = t.pm[w.z >> 24];
-
-    // ---- split-read evidence (classic.py:306-328): p_alt = (pm(left)*L + pm(right)*R) / 2.0
+    const double rs_a = t.pm[wa & 0xffu];
+    const double rs_b = t.pm[(wa >> 8) & 0xffu];
+    const double sq_l = t.pm[(wa >> 16) & 0xffu];
+    const double sq_r = t.pm[wa >> 24];
+    const double cl_l = t.pm[wb & 0xffu];
+    const double cl_r = t.pm[(wb >> 8) & 0xffu];
+    // p_alt = (pm(left) * L + pm(right) * R) / 2.0   (classic.py:324)
     const double p_seq = (sq_l + sq_r) * 0.5;
     const double p_clip = (cl_l + cl_r) * 0.5;
     if (SSO) {
         // singlesample.py:246-276,367-372: per-fragment sums starting from 0, added to the site
         // totals when the next fragment starts
-        const bool cont = (w.w & SVT_REC_CONTINUATION) != 0;
         a.ref_seq += cont ? 0.0 : a.l_ref_seq;
         a.alt_seq += cont ? 0.0 : a.l_alt_seq;
         a.alt_clip += cont ? 0.0 : a.l_alt_clip;
@@ -198,25 +219,33 @@ __device__ __forceinline__ void tally_record(const uint4 w, const Tables& t, con
         a.alt_seq += p_seq;
         a.alt_clip += p_clip;
     }
+}
 
-    // ---- p_concordant (parsers.py:861-882) as an integer test: with d1 = hist[o]/N fixed, the
+// Paired-end evidence of one fragment (classic.py:339-408).
+//   o = ospan_len, mq = mapq_a | mapq_b << 8, f3 = alt | refA << 1 | refB << 2, lib = library index
+template <int MODE>
+__device__ __forceinline__ void pair_evidence(const uint32_t o, const uint32_t mq, uint32_t f3,
+                                              const uint32_t lib_idx, const Tables& t, const LaneCtx& c, Acc& a)
+{
+    const double pm_a = t.pm[mq & 0xffu];
+    const double pm_b = t.pm[(mq >> 8) & 0xffu];
+
+    // p_concordant (parsers.py:861-882) as an integer test: with d1 = hist[o]/N fixed, the
     // reference's binary64 expression d1*0.95/(0.95*d1 + 0.05*d2) > 0.5 is monotone in
     // h2 = hist[o - v]; thr[o] is the largest h2 for which it still holds (found on the host with
     // the reference's own expression), -1 where hist[o] == 0 (p == 0 or ZeroDivisionError).
-    const uint32_t o = w.x;
-    uint32_t f;
     int32_t thr1;
     uint32_t h2;
     if (MODE == kSingleLds) {
-        f = w.w & c.fmask;
+        f3 &= c.fmask;                                  // small-DEL gate (classic.py:339,383)
         const uint32_t i1 = min(o - c.kmin, c.nb);      // out of range -> sentinel (thr -1)
         const uint32_t i2 = min(o - c.sub2, c.nb);      // out of range -> sentinel (hist 0)
         thr1 = t.thr[i1];
         h2 = t.hist[i2];
     } else if (MODE == kMultiLds) {
-        const LibDesc lib = t.libs[SVT_REC_LIB(w.w)];
-        const bool small_del = c.is_del && (c.pos_delta_d < lib.sd2);     // classic.py:339,383
-        f = small_del ? (w.w & ~7u) : w.w;
+        const LibDesc lib = t.libs[lib_idx];
+        const bool small_del = c.is_del && (c.pos_delta_d < lib.sd2);
+        f3 = small_del ? 0u : f3;
         const uint32_t kmin = (uint32_t)lib.key_min;
         const uint32_t sub2 = c.is_del ? (uint32_t)c.var_length + kmin : 0x80000000u;
         const uint32_t i1 = min(o - kmin, lib.n_bins);
@@ -224,9 +253,9 @@ __device__ __forceinline__ void tally_record(const uint4 w, const Tables& t, con
         thr1 = t.thr[lib.tab_off + i1];
         h2 = t.hist[lib.tab_off + i2];
     } else {
-        const LibDesc lib = t.libs[SVT_REC_LIB(w.w)];
+        const LibDesc lib = t.libs[lib_idx];
         const bool small_del = c.is_del && (c.pos_delta_d < lib.sd2);
-        f = small_del ? (w.w & ~7u) : w.w;
+        f3 = small_del ? 0u : f3;
         const int64_t i1 = (int64_t)(int32_t)o - (int64_t)lib.key_min;
         const bool in1 = (uint64_t)i1 < (uint64_t)lib.n_bins;
         thr1 = t.thr[lib.tab_off + (in1 ? (uint32_t)i1 : lib.n_bins)];
@@ -246,9 +275,7 @@ __device__ __forceinline__ void tally_record(const uint4 w, const Tables& t, con
         h2 = t.hist[lib.tab_off + (in2 ? (uint32_t)i2 : lib.n_bins)];
     }
     const bool p_conc = (int32_t)h2 <= thr1;
-
-    // ---- paired-end evidence (classic.py:339-408) through the decision table
-    const PairWeights pw = t.wtab[(f & 7u) | (p_conc ? 8u : 0u) | c.del16];
+    const PairWeights pw = t.wtab[f3 | (p_conc ? 8u : 0u) | c.del16];
     const double pp = pm_a * pm_b;
     a.alt_span += pp * pw.w_alt;
     a.ref_span += pp * pw.w_ref;
@@ -267,27 +294,13 @@ __device__ __forceinline__ double log_choose_dev(const double* __restrict__ l10,
     return r;
 }
 
-#ifndef SVT_NT_LOADS
-#define SVT_NT_LOADS 1
-#endif
-#ifndef SVT_MIN_WAVES
-#define SVT_MIN_WAVES 1
-#endif
-#ifndef SVT_GROUP
-#define SVT_GROUP 4
-#endif
-
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-// streaming read of one evidence record (read exactly once per pass)
+// streaming read of one 16-byte row slot (read exactly once per pass): non-temporal
 __device__ __forceinline__ uint4 ld_stream(const uint4* __restrict__ p)
 {
-#if SVT_NT_LOADS
     const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
     return make_uint4(v.x, v.y, v.z, v.w);
-#else
-    return *p;
-#endif
 }
 
 __device__ __forceinline__ uint4 pack2d(double x, double y)
@@ -296,8 +309,36 @@ __device__ __forceinline__ uint4 pack2d(double x, double y)
     return make_uint4((uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32));
 }
 
-template <bool SSO, int MODE>
-__global__ __launch_bounds__(kBlock, SVT_MIN_WAVES) void svt_genotype_kernel(const KernelArgs a)
+// Stream `rows` row slots of one lane, SVT_GROUP at a time, one group ahead of the group being
+// consumed (the tiled buffer carries kTailPadRows rows of slack, so the look-ahead never leaves
+// the allocation).
+template <typename F>
+__device__ __forceinline__ void stream_rows(const uint4* __restrict__ p, const uint32_t rows, F&& consume)
+{
+    uint4 cur[SVT_GROUP], nxt[SVT_GROUP];
+#pragma unroll
+    for (int k = 0; k < SVT_GROUP; ++k) cur[k] = ld_stream(p + k * kWave);
+    uint32_t j = 0;
+    for (; j + SVT_GROUP <= rows; j += SVT_GROUP) {
+        const uint4* __restrict__ q = p + (uint64_t)(j + SVT_GROUP) * kWave;
+#pragma unroll
+        for (int k = 0; k < SVT_GROUP; ++k) nxt[k] = ld_stream(q + k * kWave);
+#pragma unroll
+        for (int k = 0; k < SVT_GROUP; ++k) consume(cur[k]);
+#pragma unroll
+        for (int k = 0; k < SVT_GROUP; ++k) cur[k] = nxt[k];
+    }
+    const uint32_t rem = rows - j;  // wave-uniform
+#pragma unroll
+    for (int k = 0; k < SVT_GROUP - 1; ++k)
+        if ((uint32_t)k < rem) consume(cur[k]);
+}
+
+// ------------------------------------------------------------------------------------------
+// genotype kernel
+// ------------------------------------------------------------------------------------------
+template <bool SSO, int MODE, bool SPLIT>
+__global__ __launch_bounds__(kBlock) void svt_genotype_kernel(const KernelArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // LDS layout: pm[256] | wtab[32] | l10[n_l10 (even)] | libs[n_libs] | hist[total_bins] | thr[total_bins]
@@ -348,7 +389,7 @@ __global__ __launch_bounds__(kBlock, SVT_MIN_WAVES) void svt_genotype_kernel(con
     c.pos_delta_d = (double)h.pos_delta;
     {
         const bool small_del = c.is_del && (c.pos_delta_d < a.lib0.sd2);  // classic.py:339,383
-        c.fmask = small_del ? ~7u : ~0u;
+        c.fmask = small_del ? 0u : 7u;
         c.kmin = (uint32_t)a.lib0.key_min;
         c.nb = a.lib0.n_bins;
         c.sub2 = c.is_del ? (uint32_t)h.var_length + (uint32_t)a.lib0.key_min : 0x80000000u;
@@ -356,28 +397,25 @@ __global__ __launch_bounds__(kBlock, SVT_MIN_WAVES) void svt_genotype_kernel(con
 
     Acc acc = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
 
-    // ---- stream the tile: row j is one contiguous 1 KiB line for the wave.  Rows are fetched
-    // four at a time, one group ahead of the group being tallied (the buffer has a 4-row tail
-    // pad, so the look-ahead never leaves the allocation).
-    const uint4* __restrict__ p = a.tiled + td.rec_base + lane;
-    const uint32_t rows = td.rows;
-    uint4 cur[SVT_GROUP], nxt[SVT_GROUP];
-#pragma unroll
-    for (int k = 0; k < SVT_GROUP; ++k) cur[k] = ld_stream(p + k * kWave);
-    uint32_t j = 0;
-    for (; j + SVT_GROUP <= rows; j += SVT_GROUP) {
-        const uint4* __restrict__ q = p + (uint64_t)(j + SVT_GROUP) * kWave;
-#pragma unroll
-        for (int k = 0; k < SVT_GROUP; ++k) nxt[k] = ld_stream(q + k * kWave);
-#pragma unroll
-        for (int k = 0; k < SVT_GROUP; ++k) tally_record<SSO, MODE>(cur[k], t, c, acc);
-#pragma unroll
-        for (int k = 0; k < SVT_GROUP; ++k) cur[k] = nxt[k];
+    // ---- stream the tile: row j is one contiguous 1 KiB line for the wave
+    if (SPLIT) {
+        // pair entries: x = ospan_len, y = mapq_a | mapq_b << 8 | f3 << 16 | lib << 24
+        stream_rows(a.tiled + td.base_a + lane, td.rows_a, [&](const uint4 w) {
+            pair_evidence<MODE>(w.x, w.y & 0xffffu, (w.y >> 16) & 7u, w.y >> 24, t, c, acc);
+            pair_evidence<MODE>(w.z, w.w & 0xffffu, (w.w >> 16) & 7u, w.w >> 24, t, c, acc);
+        });
+        // weight entries: x = rs_a | rs_b << 8 | seq_l << 16 | seq_r << 24, y = clip_l | clip_r << 8 | cont << 16
+        stream_rows(a.tiled + td.base_b + lane, td.rows_b, [&](const uint4 w) {
+            weight_evidence<SSO>(w.x, w.y, (w.y & 0x10000u) != 0, t, acc);
+            weight_evidence<SSO>(w.z, w.w, (w.w & 0x10000u) != 0, t, acc);
+        });
+    } else {
+        // canonical 16-byte records (include/svtyper_hip.h: svt_record)
+        stream_rows(a.tiled + td.base_a + lane, td.rows_a, [&](const uint4 w) {
+            weight_evidence<SSO>(w.y >> 16 | (w.z << 16), w.z >> 16, (w.w & SVT_REC_CONTINUATION) != 0, t, acc);
+            pair_evidence<MODE>(w.x, w.y & 0xffffu, w.w & 7u, SVT_REC_LIB(w.w), t, c, acc);
+        });
     }
-    const uint32_t rem = rows - j;  // wave-uniform
-#pragma unroll
-    for (int k = 0; k < SVT_GROUP - 1; ++k)
-        if ((uint32_t)k < rem) tally_record<SSO, MODE>(cur[k], t, c, acc);
     if (SSO) {  // flush the last fragment (singlesample.py:370-372)
         acc.ref_seq += acc.l_ref_seq;
         acc.alt_seq += acc.l_alt_seq;
@@ -479,8 +517,39 @@ __global__ __launch_bounds__(kBlock, SVT_MIN_WAVES) void svt_genotype_kernel(con
 }
 
 // ------------------------------------------------------------------------------------------
-// re-tiling kernel: CSR records -> lane-interleaved tiles (runs once per batch)
+// batch preparation kernels (run once per batch, outside the genotyping pass)
 // ------------------------------------------------------------------------------------------
+
+// which sparse streams a canonical record feeds
+__device__ __forceinline__ bool has_pair_entry(const uint4 w) { return (w.w & 7u) != 0u; }
+__device__ __forceinline__ bool has_weight_entry(const uint4 w) { return ((w.y >> 16) | w.z) != 0u; }
+
+// one thread per unit: validate the record contract of include/svtyper_hip.h and count the entries
+// of the two sparse streams
+__global__ __launch_bounds__(kBlock) void svt_scan_kernel(const uint4* __restrict__ csr,
+                                                          const uint64_t* __restrict__ rec_offset,
+                                                          uint64_t n_units, uint32_t n_libs,
+                                                          uint2* __restrict__ counts, uint32_t* err)
+{
+    const uint64_t u = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (u >= n_units) return;
+    const uint64_t lo = rec_offset[u], hi = rec_offset[u + 1];
+    uint32_t np = 0, nq = 0, bad = 0;
+    for (uint64_t j = lo; j < hi; ++j) {
+        const uint4 w = csr[j];
+        const uint32_t f = w.w;
+        if (!(f & SVT_REC_HAS_PAIR) &&
+            (f & (SVT_REC_ALT_STRADDLE | SVT_REC_REF_STRADDLE_A | SVT_REC_REF_STRADDLE_B))) bad |= 2u;
+        if (SVT_REC_LIB(f) >= n_libs) bad |= 4u;
+        if (f & ~SVT_REC_FLAG_MASK) bad |= 8u;
+        if ((int32_t)w.x < 0) bad |= 16u;
+        np += has_pair_entry(w) ? 1u : 0u;
+        nq += has_weight_entry(w) ? 1u : 0u;
+    }
+    counts[u] = make_uint2(np, nq);
+    if (bad) atomicOr(err, bad);
+}
+
 struct RepackArgs {
     const uint4* csr;
     const uint64_t* lane_src;   // per tile lane: first CSR record of the unit
@@ -488,11 +557,10 @@ struct RepackArgs {
     const TileDesc* tiles;      // in storage order
     uint4* tiled;
     uint32_t n_tiles;
-    uint32_t n_libs;
-    uint32_t* err;              // OR of violation bits
 };
 
-__global__ __launch_bounds__(kBlock) void svt_repack_kernel(const RepackArgs a)
+// dense layout: CSR records -> lane-interleaved rows of 16-byte records
+__global__ __launch_bounds__(kBlock) void svt_repack_dense_kernel(const RepackArgs a)
 {
     const uint32_t wave = threadIdx.x / kWave;
     const uint32_t lane = threadIdx.x % kWave;
@@ -501,22 +569,53 @@ __global__ __launch_bounds__(kBlock) void svt_repack_kernel(const RepackArgs a)
     const TileDesc td = a.tiles[tile_idx];
     const uint64_t src = a.lane_src[td.lane_base + lane];
     const uint32_t nrec = a.lane_nrec[td.lane_base + lane];
-    uint32_t bad = 0;
-    for (uint32_t j = 0; j < td.rows; ++j) {
-        uint4 w = make_uint4(0, 0, 0, 0);
-        if (j < nrec) {
-            w = a.csr[src + j];
-            const uint32_t f = w.w;
-            // contract of include/svtyper_hip.h
-            if (!(f & SVT_REC_HAS_PAIR) &&
-                (f & (SVT_REC_ALT_STRADDLE | SVT_REC_REF_STRADDLE_A | SVT_REC_REF_STRADDLE_B))) bad |= 2u;
-            if (SVT_REC_LIB(f) >= a.n_libs) bad |= 4u;
-            if (f & ~SVT_REC_FLAG_MASK) bad |= 8u;
-            if ((int32_t)w.x < 0) bad |= 16u;
-        }
-        a.tiled[td.rec_base + (uint64_t)j * kWave + lane] = w;
+    for (uint32_t j = 0; j < td.rows_a; ++j) {
+        const uint4 w = j < nrec ? a.csr[src + j] : make_uint4(0, 0, 0, 0);
+        a.tiled[td.base_a + (uint64_t)j * kWave + lane] = w;
     }
-    if (bad) atomicOr(a.err, bad);
+}
+
+// split layout: CSR records -> pair-entry rows + weight-entry rows.  Entries keep the order of the
+// records they come from; a record that cannot change a sum (no straddle bit / all gated MAPQs 0)
+// produces no entry in that stream.
+__global__ __launch_bounds__(kBlock) void svt_repack_split_kernel(const RepackArgs a)
+{
+    const uint32_t wave = threadIdx.x / kWave;
+    const uint32_t lane = threadIdx.x % kWave;
+    const uint32_t tile_idx = blockIdx.x * kWavesPerBlock + wave;
+    if (tile_idx >= a.n_tiles) return;
+    const TileDesc td = a.tiles[tile_idx];
+    const uint64_t src = a.lane_src[td.lane_base + lane];
+    const uint32_t nrec = a.lane_nrec[td.lane_base + lane];
+    uint4* __restrict__ outp = a.tiled + td.base_a + lane;
+    uint4* __restrict__ outq = a.tiled + td.base_b + lane;
+    uint32_t np = 0, nq = 0;
+    uint2 hold_p = make_uint2(0, 0), hold_q = make_uint2(0, 0);
+    bool frag_has_q = false;  // did the current fragment already emit a weight entry?
+    for (uint32_t j = 0; j < nrec; ++j) {
+        const uint4 w = a.csr[src + j];
+        if (!(w.w & SVT_REC_CONTINUATION)) frag_has_q = false;
+        if (has_pair_entry(w)) {
+            const uint2 e = make_uint2(w.x, (w.y & 0xffffu) | ((w.w & 7u) << 16) | (SVT_REC_LIB(w.w) << 24));
+            if (np & 1u) outp[(uint64_t)(np >> 1) * kWave] = make_uint4(hold_p.x, hold_p.y, e.x, e.y);
+            else hold_p = e;
+            ++np;
+        }
+        if (has_weight_entry(w)) {
+            // the continuation bit only survives if the entry it continues was emitted too; a
+            // dropped predecessor contributed exactly +0.0 to the fragment-local sums
+            const uint2 e = make_uint2((w.y >> 16) | (w.z << 16), (w.z >> 16) | (frag_has_q ? 0x10000u : 0u));
+            if (nq & 1u) outq[(uint64_t)(nq >> 1) * kWave] = make_uint4(hold_q.x, hold_q.y, e.x, e.y);
+            else hold_q = e;
+            ++nq;
+            frag_has_q = true;
+        }
+    }
+    uint32_t rp = np >> 1, rq = nq >> 1;
+    if (np & 1u) outp[(uint64_t)rp++ * kWave] = make_uint4(hold_p.x, hold_p.y, 0, 0);
+    if (nq & 1u) outq[(uint64_t)rq++ * kWave] = make_uint4(hold_q.x, hold_q.y, 0, 0);
+    for (; rp < td.rows_a; ++rp) outp[(uint64_t)rp * kWave] = make_uint4(0, 0, 0, 0);
+    for (; rq < td.rows_b; ++rq) outq[(uint64_t)rq * kWave] = make_uint4(0, 0, 0, 0);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -560,9 +659,6 @@ bool p_concordant_expr(uint32_t h1, uint32_t h2, uint64_t n_total)
 
 double py_log10(double x) { return std::log(x) / std::log(10.0); }  // math.log(x, 10)
 
-struct GtConsts;
-void fill_gt_consts(GtConsts& c, double split_weight, double disc_weight);
-
 // smallest double x with pow(10.0, x) > 0 under this libm (CPython: 10 ** x)
 double find_pow10_underflow()
 {
@@ -591,6 +687,145 @@ void fill_gt_consts(GtConsts& c, double split_weight, double disc_weight)
     c.disc_weight = disc_weight;
 }
 
+struct HostTables {
+    std::vector<LibDesc> libs;
+    std::vector<uint32_t> hist;      // per library: n_bins counts + sentinel 0
+    std::vector<int32_t> thr;        // per library: n_bins thresholds + sentinel -1
+    std::vector<PairWeights> wtab;   // 32
+    std::vector<double> pm;          // 256
+    std::vector<double> l10;
+    bool fast_geometry = true;       // 32-bit index math + "non-DEL key never integral" valid?
+};
+
+int build_tables(const svt_evidence_batch* in, uint64_t max_records_per_unit, HostTables& T)
+{
+    T.libs.resize(in->n_libs);
+    for (uint32_t l = 0; l < in->n_libs; ++l) {
+        const svt_library& L = in->libs[l];
+        if (!L.hist || L.n_bins == 0) return fail(SVT_ERR_INVALID, "library without histogram");
+        if (L.n_bins > (1u << 24)) return fail(SVT_ERR_INVALID, "histogram too wide");
+        if (!std::isfinite(L.mean) || !std::isfinite(L.sd)) return fail(SVT_ERR_INVALID, "library moments not finite");
+        uint64_t total = 0;
+        uint32_t hmax = 0;
+        for (uint32_t i = 0; i < L.n_bins; ++i) {
+            if (L.hist[i] > 0x7FFFFFFFu) return fail(SVT_ERR_INVALID, "histogram count too large");
+            total += L.hist[i];
+            hmax = std::max(hmax, L.hist[i]);
+        }
+        LibDesc d{};
+        d.tab_off = (uint32_t)T.hist.size();
+        d.key_min = L.key_min;
+        d.n_bins = L.n_bins;
+        d.v_nondel = L.mean + L.sd * 3;  // parsers.py:873-875
+        d.sd2 = 2 * L.sd;                // classic.py:339
+        T.libs[l] = d;
+        // the fast kernels need |key_min| <= 2^29 and a non-DEL float key o - (mean + 3 sd) that can
+        // never round to an integer for o in [0, 2^31)
+        if (L.key_min < -(1 << 29) || L.key_min > (1 << 29)) T.fast_geometry = false;
+        if (!(std::fabs(d.v_nondel - std::nearbyint(d.v_nondel)) > 4e-6) || !(std::fabs(d.v_nondel) < 1e12))
+            T.fast_geometry = false;
+        for (uint32_t i = 0; i < L.n_bins; ++i) {
+            const uint32_t h1 = L.hist[i];
+            T.hist.push_back(h1);
+            int32_t t = -1;
+            if (h1 > 0 && total > 0 && p_concordant_expr(h1, 0, total)) {
+                // largest h2 in [0, hmax] with p > 0.5 (the expression is monotone non-increasing in h2)
+                uint32_t lo = 0, hi = hmax;  // invariant: expr(lo) holds
+                if (p_concordant_expr(h1, hi, total)) lo = hi;
+                else
+                    while (hi - lo > 1) {
+                        const uint32_t mid = lo + (hi - lo) / 2;
+                        if (p_concordant_expr(h1, mid, total)) lo = mid; else hi = mid;
+                    }
+                t = (int32_t)lo;
+            }
+            T.thr.push_back(t);
+        }
+        T.hist.push_back(0);   // out-of-range sentinel: Counter miss -> 0
+        T.thr.push_back(-1);   //                        hist[o] == 0 -> never concordant
+    }
+    // paired-end decision table (see PairWeights)
+    T.wtab.resize(32);
+    for (int i = 0; i < 32; ++i) {
+        const bool alt = i & 1, ra = i & 2, rb = i & 4, pc = i & 8, del = i & 16;
+        const bool both = ra && rb, any = ra || rb;
+        const bool need = any && (!both || del);                   // classic.py:398-401
+        T.wtab[i].w_alt = (alt && !(del && pc)) ? 1.0 : 0.0;       // classic.py:359-377
+        T.wtab[i].w_ref = (need && pc) ? (both ? 1.0 : 0.5) : 0.0; // classic.py:402-405
+    }
+    // log10 table: n = QR + QA <= 2 * (2 * split_weight + disc_weight) * max F
+    const double bound = 2.0 * (2.0 * in->split_weight + in->disc_weight) * (double)max_records_per_unit + 4.0;
+    if (bound > 64.0 * 1024 * 1024) return fail(SVT_ERR_INVALID, "weights * records too large for the log table");
+    T.l10.resize((size_t)bound + 1);
+    T.l10[0] = 0.0;  // never read (log_choose only looks up 1..n)
+    for (size_t i = 1; i < T.l10.size(); ++i) T.l10[i] = py_log10((double)i);
+    T.pm.resize(256);
+    for (int q = 0; q < 256; ++q) T.pm[q] = 1.0 - std::pow(10.0, -(double)q / 10.0);  // utils.py:74-75
+    return SVT_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// host-side tiling
+// ------------------------------------------------------------------------------------------
+struct Tiling {
+    std::vector<TileDesc> tiles;       // storage order
+    std::vector<LaneHdr> hdr;
+    std::vector<uint64_t> lane_src;
+    std::vector<uint32_t> lane_nrec;
+    uint64_t slots = 0;                // 16-byte row slots of all tiles
+};
+
+// Sort units by stream length inside chunks, cut into 64-unit tiles.  len_a/len_b are the per-unit
+// row counts of the two streams (dense layout: len_a = F, len_b = 0).
+void build_tiling(const svt_evidence_batch* in, const std::vector<uint32_t>& nrec,
+                  const std::vector<uint32_t>& len_a, const std::vector<uint32_t>& len_b, Tiling& G)
+{
+    const uint64_t n = in->n_units;
+    G.hdr.reserve(n + kWave);
+    G.lane_src.reserve(n + kWave);
+    G.lane_nrec.reserve(n + kWave);
+    std::vector<uint32_t> order(kChunkUnits);
+    for (uint64_t c0 = 0; c0 < n; c0 += kChunkUnits) {
+        const uint32_t cn = (uint32_t)std::min<uint64_t>(kChunkUnits, n - c0);
+        for (uint32_t i = 0; i < cn; ++i) order[i] = i;
+        std::stable_sort(order.begin(), order.begin() + cn, [&](uint32_t x, uint32_t y) {
+            const uint64_t kx = ((uint64_t)len_a[c0 + x] << 32) | len_b[c0 + x];
+            const uint64_t ky = ((uint64_t)len_a[c0 + y] << 32) | len_b[c0 + y];
+            return kx > ky;
+        });
+        for (uint32_t t0 = 0; t0 < cn; t0 += kWave) {
+            TileDesc td{};
+            td.lane_base = (uint32_t)G.hdr.size();
+            for (uint32_t l = 0; l < (uint32_t)kWave; ++l) {
+                LaneHdr h{};
+                uint64_t src = 0;
+                uint32_t f = 0;
+                if (t0 + l < cn) {
+                    const uint64_t u = c0 + order[t0 + l];
+                    const svt_unit& U = in->units[u];
+                    h.var_length = U.var_length;
+                    h.pos_delta = U.pos_delta;
+                    h.unit = (uint32_t)u;
+                    h.packed = (uint32_t)U.svtype | ((uint32_t)U.flags << 8) | ((uint32_t)U.sample << 16);
+                    src = in->rec_offset[u];
+                    f = nrec[u];
+                    td.rows_a = std::max(td.rows_a, len_a[u]);
+                    td.rows_b = std::max(td.rows_b, len_b[u]);
+                } else {
+                    h.unit = kPadUnit;
+                }
+                G.hdr.push_back(h);
+                G.lane_src.push_back(src);
+                G.lane_nrec.push_back(f);
+            }
+            td.base_a = G.slots;
+            td.base_b = G.slots + (uint64_t)td.rows_a * kWave;
+            G.slots += (uint64_t)(td.rows_a + td.rows_b) * kWave;
+            G.tiles.push_back(td);
+        }
+    }
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------
@@ -600,9 +835,10 @@ struct svt_batch {
     int device = 0;
     unsigned flags = 0;
     hipStream_t stream = nullptr;
-    uint64_t n_units = 0, n_records = 0, tiled_records = 0;
+    uint64_t n_units = 0, n_records = 0, slots = 0;
     uint32_t n_tiles = 0;
     int mode = kSingleLds;
+    bool split = true;
     size_t lds_bytes = 0;
     bool have_results = false;
     // device buffers
@@ -635,41 +871,205 @@ void free_batch(svt_batch* b)
     delete b;
 }
 
+// device scratch that only lives during svt_batch_create
+struct DevScratch {
+    void* p = nullptr;
+    ~DevScratch() { if (p) (void)hipFree(p); }
+    int alloc(size_t bytes)
+    {
+        HIP_TRY(hipMalloc(&p, std::max<size_t>(bytes, 16)));
+        return SVT_OK;
+    }
+    template <typename T> T* as() const { return static_cast<T*>(p); }
+};
+
 template <typename T>
 int upload(T** dptr, const std::vector<T>& v, hipStream_t s)
 {
-    size_t bytes = std::max<size_t>(v.size(), 1) * sizeof(T);
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(dptr), bytes));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(dptr), std::max<size_t>(v.size(), 1) * sizeof(T)));
     if (!v.empty()) HIP_TRY(hipMemcpyAsync(*dptr, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s));
     return SVT_OK;
 }
 
-template <bool SSO>
-void launch_mode(svt_batch* b, dim3 grid, dim3 block)
+template <typename T>
+int upload(DevScratch& d, const std::vector<T>& v, hipStream_t s)
 {
-    switch (b->mode) {
-    case kSingleLds: hipLaunchKernelGGL((svt_genotype_kernel<SSO, kSingleLds>), grid, block, b->lds_bytes, b->stream, b->args); break;
-    case kMultiLds:  hipLaunchKernelGGL((svt_genotype_kernel<SSO, kMultiLds>), grid, block, b->lds_bytes, b->stream, b->args); break;
-    default:         hipLaunchKernelGGL((svt_genotype_kernel<SSO, kGeneral>), grid, block, b->lds_bytes, b->stream, b->args); break;
+    SVT_TRY(d.alloc(v.size() * sizeof(T)));
+    if (!v.empty()) HIP_TRY(hipMemcpyAsync(d.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s));
+    return SVT_OK;
+}
+
+template <bool SSO, bool SPLIT>
+const void* kernel_for(int mode)
+{
+    switch (mode) {
+    case kSingleLds: return reinterpret_cast<const void*>(&svt_genotype_kernel<SSO, kSingleLds, SPLIT>);
+    case kMultiLds:  return reinterpret_cast<const void*>(&svt_genotype_kernel<SSO, kMultiLds, SPLIT>);
+    default:         return reinterpret_cast<const void*>(&svt_genotype_kernel<SSO, kGeneral, SPLIT>);
     }
+}
+
+const void* kernel_of(const svt_batch* b)
+{
+    const bool sso = (b->flags & SVT_FLAG_SSO_ASSOCIATION) != 0;
+    if (b->split) return sso ? kernel_for<true, true>(b->mode) : kernel_for<false, true>(b->mode);
+    return sso ? kernel_for<true, false>(b->mode) : kernel_for<false, false>(b->mode);
 }
 
 int launch_genotype(svt_batch* b)
 {
     if (b->n_tiles == 0) return SVT_OK;
     const dim3 grid((b->n_tiles + kWavesPerBlock - 1) / kWavesPerBlock), block(kBlock);
-    if (b->flags & SVT_FLAG_SSO_ASSOCIATION) launch_mode<true>(b, grid, block);
-    else launch_mode<false>(b, grid, block);
-    HIP_TRY(hipGetLastError());
+    void* params[] = {&b->args};
+    HIP_TRY(hipLaunchKernel(kernel_of(b), grid, block, params, b->lds_bytes, b->stream));
     return SVT_OK;
 }
 
-template <typename K>
-int allow_big_lds(K kernel, size_t bytes)
+// everything of svt_batch_create that needs the device; `b` is freed by the caller on failure
+int create_on_device(const svt_evidence_batch* in, svt_batch* b)
 {
-    if (bytes > 64 * 1024)
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    const uint64_t n = in->n_units;
+    const uint64_t n_rec = n ? in->rec_offset[n] : 0;
+
+    // ---- per-unit record counts + validation of the CSR
+    std::vector<uint32_t> nrec(n);
+    uint64_t max_f = 0;
+    bool wide_var_length = false;
+    for (uint64_t u = 0; u < n; ++u) {
+        if (in->rec_offset[u + 1] < in->rec_offset[u]) return fail(SVT_ERR_INVALID, "rec_offset not monotone");
+        const uint64_t f = in->rec_offset[u + 1] - in->rec_offset[u];
+        if (f > 0x3FFFFFFFull) return fail(SVT_ERR_INVALID, "unit with too many records");
+        const svt_unit& U = in->units[u];
+        if (U.svtype > SVT_SVTYPE_BND) return fail(SVT_ERR_INVALID, "bad svtype");
+        if (U.reserved != 0 || (U.flags & ~SVT_UNIT_SKIP)) return fail(SVT_ERR_INVALID, "unit reserved/flags bits must be 0");
+        if (U.var_length < -(1 << 30) || U.var_length > (1 << 30)) wide_var_length = true;
+        nrec[u] = (uint32_t)f;
+        max_f = std::max(max_f, f);
+    }
+
+    HostTables T;
+    SVT_TRY(build_tables(in, max_f, T));
+    if (wide_var_length) T.fast_geometry = false;
+
+    HIP_TRY(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreate(&b->ev0));
+    HIP_TRY(hipEventCreate(&b->ev1));
+
+    // ---- canonical records to the device; validate them and count the sparse-stream entries
+    DevScratch d_csr, d_off, d_counts, d_err;
+    SVT_TRY(d_csr.alloc(n_rec * sizeof(uint4)));
+    if (n_rec) HIP_TRY(hipMemcpyAsync(d_csr.p, in->records, n_rec * sizeof(uint4), hipMemcpyHostToDevice, b->stream));
+    SVT_TRY(d_off.alloc((n + 1) * sizeof(uint64_t)));
+    if (n) HIP_TRY(hipMemcpyAsync(d_off.p, in->rec_offset, (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, b->stream));
+    SVT_TRY(d_counts.alloc(n * sizeof(uint2)));
+    SVT_TRY(d_err.alloc(sizeof(uint32_t)));
+    HIP_TRY(hipMemsetAsync(d_err.p, 0, sizeof(uint32_t), b->stream));
+    std::vector<uint2> counts(n);
+    uint32_t err_bits = 0;
+    if (n) {
+        hipLaunchKernelGGL(svt_scan_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, b->stream,
+                           d_csr.as<uint4>(), d_off.as<uint64_t>(), n, in->n_libs, d_counts.as<uint2>(),
+                           d_err.as<uint32_t>());
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(counts.data(), d_counts.p, n * sizeof(uint2), hipMemcpyDeviceToHost, b->stream));
+    }
+    HIP_TRY(hipMemcpyAsync(&err_bits, d_err.p, sizeof(uint32_t), hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    if (err_bits) {
+        std::string m = "invalid evidence records:";
+        if (err_bits & 2u) m += " straddle bits without HAS_PAIR;";
+        if (err_bits & 4u) m += " lib index >= n_libs;";
+        if (err_bits & 8u) m += " reserved/undefined bits set;";
+        if (err_bits & 16u) m += " negative ospan_len;";
+        return fail(SVT_ERR_INVALID, m);
+    }
+
+    // ---- tiling
+    std::vector<uint32_t> len_a(n), len_b(n);
+    for (uint64_t u = 0; u < n; ++u) {
+        if (b->split) {
+            len_a[u] = (counts[u].x + 1) / 2;   // two 8-byte entries per 16-byte row slot
+            len_b[u] = (counts[u].y + 1) / 2;
+        } else {
+            len_a[u] = nrec[u];
+            len_b[u] = 0;
+        }
+    }
+    Tiling G;
+    build_tiling(in, nrec, len_a, len_b, G);
+    if (G.tiles.size() > 0xFFFFFFF0ull / kWave) return fail(SVT_ERR_INVALID, "too many tiles");
+    b->n_tiles = (uint32_t)G.tiles.size();
+    b->slots = G.slots;
+    // dispatch order: longest tiles first (LPT) so the tail of the grid is made of short tiles
+    std::vector<TileDesc> dispatch = G.tiles;
+    std::stable_sort(dispatch.begin(), dispatch.end(), [](const TileDesc& x, const TileDesc& y) {
+        return x.rows_a + x.rows_b > y.rows_a + y.rows_b;
+    });
+
+    // ---- resident device objects
+    DevScratch d_tiles_store, d_lane_src, d_lane_nrec;
+    SVT_TRY(upload(&b->d_tiles, dispatch, b->stream));
+    SVT_TRY(upload(d_tiles_store, G.tiles, b->stream));
+    SVT_TRY(upload(&b->d_hdr, G.hdr, b->stream));
+    SVT_TRY(upload(d_lane_src, G.lane_src, b->stream));
+    SVT_TRY(upload(d_lane_nrec, G.lane_nrec, b->stream));
+    SVT_TRY(upload(&b->d_pm, T.pm, b->stream));
+    SVT_TRY(upload(&b->d_l10, T.l10, b->stream));
+    SVT_TRY(upload(&b->d_libs, T.libs, b->stream));
+    SVT_TRY(upload(&b->d_hist, T.hist, b->stream));
+    SVT_TRY(upload(&b->d_thr, T.thr, b->stream));
+    SVT_TRY(upload(&b->d_wtab, T.wtab, b->stream));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&b->d_tiled), (G.slots + kTailPadRows * kWave) * sizeof(uint4)));
+    HIP_TRY(hipMemsetAsync(b->d_tiled + G.slots, 0, kTailPadRows * kWave * sizeof(uint4), b->stream));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&b->d_out), std::max<uint64_t>(n, 1) * sizeof(svt_result)));
+
+    // ---- re-tile on the device
+    if (b->n_tiles) {
+        RepackArgs ra{};
+        ra.csr = d_csr.as<uint4>();
+        ra.lane_src = d_lane_src.as<uint64_t>();
+        ra.lane_nrec = d_lane_nrec.as<uint32_t>();
+        ra.tiles = d_tiles_store.as<TileDesc>();
+        ra.tiled = b->d_tiled;
+        ra.n_tiles = b->n_tiles;
+        const dim3 grid((b->n_tiles + kWavesPerBlock - 1) / kWavesPerBlock), block(kBlock);
+        if (b->split) hipLaunchKernelGGL(svt_repack_split_kernel, grid, block, 0, b->stream, ra);
+        else hipLaunchKernelGGL(svt_repack_dense_kernel, grid, block, 0, b->stream, ra);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipStreamSynchronize(b->stream));  // scratch buffers are released on return
+
+    // ---- kernel arguments
+    KernelArgs& a = b->args;
+    a.tiled = b->d_tiled;
+    a.tiles = b->d_tiles;
+    a.hdr = b->d_hdr;
+    a.pm = b->d_pm;
+    a.l10 = b->d_l10;
+    a.libs = b->d_libs;
+    a.hist = b->d_hist;
+    a.thr = b->d_thr;
+    a.wtab = b->d_wtab;
+    a.n_l10 = (uint32_t)T.l10.size();
+    a.n_libs = in->n_libs;
+    a.total_bins = (uint32_t)T.hist.size();
+    a.n_tiles = b->n_tiles;
+    a.l10_in_lds = a.n_l10 <= kMaxL10Lds ? 1u : 0u;
+    a.n_units = n;
+    a.out = b->d_out;
+    a.lib0 = T.libs[0];
+    fill_gt_consts(a.c, in->split_weight, in->disc_weight);
+
+    const size_t table_bytes = (size_t)a.total_bins * 8;
+    if (T.fast_geometry && table_bytes <= kMaxLdsTableBytes) b->mode = in->n_libs == 1 ? kSingleLds : kMultiLds;
+    else b->mode = kGeneral;
+    const uint32_t n_l10_lds = a.l10_in_lds ? ((a.n_l10 + 1u) & ~1u) : 0u;
+    b->lds_bytes = 256 * 8 + 32 * sizeof(PairWeights) + (size_t)n_l10_lds * 8 +
+                   (size_t)in->n_libs * sizeof(LibDesc) + (b->mode != kGeneral ? table_bytes : 0);
+    b->lds_bytes = (b->lds_bytes + 15) & ~size_t(15);
+    if (b->lds_bytes > 160 * 1024) return fail(SVT_ERR_INVALID, "LDS budget exceeded");
+    if (b->lds_bytes > 64 * 1024)
+        HIP_TRY(hipFuncSetAttribute(kernel_of(b), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_bytes));
     return SVT_OK;
 }
 
@@ -696,292 +1096,35 @@ int svt_batch_create(const svt_evidence_batch* in, int device, unsigned flags, s
     if (!in || !out) return fail(SVT_ERR_INVALID, "null argument");
     *out = nullptr;
     const uint64_t n = in->n_units;
+    if (flags & ~(SVT_FLAG_SSO_ASSOCIATION | SVT_FLAG_DENSE_LAYOUT)) return fail(SVT_ERR_INVALID, "unknown flag bits");
     if (n >= 0xFFFFFFF0ull) return fail(SVT_ERR_INVALID, "too many units in one batch (< 2^32)");
-    if (in->n_libs == 0 || in->n_libs > 256) return fail(SVT_ERR_INVALID, "n_libs must be 1..256");
+    if (in->n_libs == 0 || in->n_libs > 256 || !in->libs) return fail(SVT_ERR_INVALID, "n_libs must be 1..256");
     if (n && (!in->rec_offset || !in->units)) return fail(SVT_ERR_INVALID, "null unit arrays");
     if (n && in->rec_offset[0] != 0) return fail(SVT_ERR_INVALID, "rec_offset[0] must be 0");
-    const uint64_t n_rec = n ? in->rec_offset[n] : 0;
-    if (n_rec && !in->records) return fail(SVT_ERR_INVALID, "null records");
+    if (n && in->rec_offset[n] && !in->records) return fail(SVT_ERR_INVALID, "null records");
     if (!(in->split_weight >= 0.0) || !(in->disc_weight >= 0.0) || !std::isfinite(in->split_weight) ||
         !std::isfinite(in->disc_weight))
         return fail(SVT_ERR_INVALID, "weights must be finite and >= 0");
 
-    int ndev = svt_device_count();
+    const int ndev = svt_device_count();
     if (ndev <= 0) return fail(SVT_ERR_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
     if (device < 0 || device >= ndev) return fail(SVT_ERR_NO_DEVICE, "device index out of range");
     HIP_TRY(hipSetDevice(device));
 
-    // ---- per-unit record counts + validation of the CSR
-    std::vector<uint32_t> nrec(n);
-    uint64_t max_f = 0;
-    for (uint64_t u = 0; u < n; ++u) {
-        if (in->rec_offset[u + 1] < in->rec_offset[u]) return fail(SVT_ERR_INVALID, "rec_offset not monotone");
-        uint64_t f = in->rec_offset[u + 1] - in->rec_offset[u];
-        if (f > 0x7FFFFFFFull) return fail(SVT_ERR_INVALID, "unit with too many records");
-        if (in->units[u].svtype > SVT_SVTYPE_BND) return fail(SVT_ERR_INVALID, "bad svtype");
-        if (in->units[u].reserved != 0 || (in->units[u].flags & ~SVT_UNIT_SKIP))
-            return fail(SVT_ERR_INVALID, "unit reserved/flags bits must be 0");
-        nrec[u] = (uint32_t)f;
-        max_f = std::max(max_f, f);
-    }
-
-    // ---- libraries: threshold tables (host, reference expression) ------------------------
-    std::vector<LibDesc> libs(in->n_libs);
-    std::vector<uint32_t> hist;
-    std::vector<int32_t> thr;
-    bool fast_geometry = true;  // 32-bit index math + "non-DEL key never integral" shortcut valid?
-    for (uint32_t l = 0; l < in->n_libs; ++l) {
-        const svt_library& L = in->libs[l];
-        if (!L.hist || L.n_bins == 0) return fail(SVT_ERR_INVALID, "library without histogram");
-        if (L.n_bins > (1u << 24)) return fail(SVT_ERR_INVALID, "histogram too wide");
-        if (!std::isfinite(L.mean) || !std::isfinite(L.sd)) return fail(SVT_ERR_INVALID, "library moments not finite");
-        uint64_t total = 0;
-        uint32_t hmax = 0;
-        for (uint32_t i = 0; i < L.n_bins; ++i) {
-            total += L.hist[i];
-            hmax = std::max(hmax, L.hist[i]);
-            if (L.hist[i] > 0x7FFFFFFFu) return fail(SVT_ERR_INVALID, "histogram count too large");
-        }
-        LibDesc d{};
-        d.tab_off = (uint32_t)hist.size();
-        d.key_min = L.key_min;
-        d.n_bins = L.n_bins;
-        d.v_nondel = L.mean + L.sd * 3;  // parsers.py:873-875
-        d.sd2 = 2 * L.sd;                // classic.py:339
-        libs[l] = d;
-        // fast modes need |key_min| <= 2^29, n_bins <= 2^24 and a non-DEL float key
-        // o - (mean + 3 sd) that can never round to an integer for o in [0, 2^31)
-        if (L.key_min < -(1 << 29) || L.key_min > (1 << 29)) fast_geometry = false;
-        if (!(std::fabs(d.v_nondel - std::nearbyint(d.v_nondel)) > 4e-6) || !(std::fabs(d.v_nondel) < 1e12))
-            fast_geometry = false;
-        for (uint32_t i = 0; i < L.n_bins; ++i) {
-            const uint32_t h1 = L.hist[i];
-            hist.push_back(h1);
-            int32_t t = -1;
-            if (h1 > 0 && total > 0 && p_concordant_expr(h1, 0, total)) {
-                // largest h2 in [0, hmax] with p > 0.5 (monotone non-increasing in h2)
-                uint32_t lo = 0, hi = hmax;  // invariant: expr(lo) true
-                if (p_concordant_expr(h1, hi, total)) lo = hi;
-                else {
-                    while (hi - lo > 1) {
-                        uint32_t mid = lo + (hi - lo) / 2;
-                        if (p_concordant_expr(h1, mid, total)) lo = mid; else hi = mid;
-                    }
-                }
-                t = (int32_t)lo;
-            }
-            thr.push_back(t);
-        }
-        hist.push_back(0);   // out-of-range sentinel: Counter miss -> 0
-        thr.push_back(-1);   //                        hist[o] == 0 -> never concordant
-    }
-    const uint32_t total_bins = (uint32_t)hist.size();
-    for (uint64_t u = 0; u < n; ++u) {
-        const int32_t v = in->units[u].var_length;
-        if (v < -(1 << 30) || v > (1 << 30)) { fast_geometry = false; break; }
-    }
-    // paired-end decision table (see PairWeights)
-    std::vector<PairWeights> wtab(32);
-    for (int i = 0; i < 32; ++i) {
-        const bool alt = i & 1, ra = i & 2, rb = i & 4, pc = i & 8, del = i & 16;
-        const bool both = ra && rb, any = ra || rb;
-        const bool need = any && (!both || del);                 // classic.py:398-401
-        wtab[i].w_alt = (alt && !(del && pc)) ? 1.0 : 0.0;       // classic.py:359-377
-        wtab[i].w_ref = (need && pc) ? (both ? 1.0 : 0.5) : 0.0; // classic.py:402-405
-    }
-
-    // ---- log10 table: n = QR + QA <= 2 * (2 * split_weight + disc_weight) * max F ----------
-    const double bound = 2.0 * (2.0 * in->split_weight + in->disc_weight) * (double)max_f + 4.0;
-    if (bound > 64.0 * 1024 * 1024) return fail(SVT_ERR_INVALID, "weights * records too large for the log table");
-    const uint32_t n_l10 = (uint32_t)bound + 1;
-    std::vector<double> l10(n_l10);
-    l10[0] = 0.0;  // never read (log_choose only looks up 1..n)
-    for (uint32_t i = 1; i < n_l10; ++i) l10[i] = py_log10((double)i);
-    std::vector<double> pm(256);
-    for (int q = 0; q < 256; ++q) pm[q] = 1.0 - std::pow(10.0, -(double)q / 10.0);  // utils.py:74-75
-
-    // ---- tiling: sort by F inside chunks, 64 units per tile ---------------------------------
-    std::vector<TileDesc> tiles_store;   // storage order
-    std::vector<LaneHdr> hdr;
-    std::vector<uint64_t> lane_src;
-    std::vector<uint32_t> lane_nrec;
-    hdr.reserve(n + kWave);
-    lane_src.reserve(n + kWave);
-    lane_nrec.reserve(n + kWave);
-    uint64_t tiled_records = 0;
-    std::vector<uint32_t> order(kChunkUnits);
-    for (uint64_t c0 = 0; c0 < n; c0 += kChunkUnits) {
-        const uint32_t cn = (uint32_t)std::min<uint64_t>(kChunkUnits, n - c0);
-        for (uint32_t i = 0; i < cn; ++i) order[i] = i;
-        std::stable_sort(order.begin(), order.begin() + cn,
-                         [&](uint32_t x, uint32_t y) { return nrec[c0 + x] > nrec[c0 + y]; });
-        for (uint32_t t0 = 0; t0 < cn; t0 += kWave) {
-            TileDesc td{};
-            td.rec_base = tiled_records;
-            td.lane_base = (uint32_t)hdr.size();
-            uint32_t rows = 0;
-            for (uint32_t l = 0; l < (uint32_t)kWave; ++l) {
-                LaneHdr h{};
-                uint64_t src = 0;
-                uint32_t f = 0;
-                if (t0 + l < cn) {
-                    const uint64_t u = c0 + order[t0 + l];
-                    const svt_unit& U = in->units[u];
-                    h.var_length = U.var_length;
-                    h.pos_delta = U.pos_delta;
-                    h.unit = (uint32_t)u;
-                    h.packed = (uint32_t)U.svtype | ((uint32_t)U.flags << 8) | ((uint32_t)U.sample << 16);
-                    src = in->rec_offset[u];
-                    f = nrec[u];
-                } else {
-                    h.unit = kPadUnit;
-                }
-                rows = std::max(rows, f);
-                hdr.push_back(h);
-                lane_src.push_back(src);
-                lane_nrec.push_back(f);
-            }
-            td.rows = rows;
-            tiled_records += (uint64_t)rows * kWave;
-            tiles_store.push_back(td);
-        }
-    }
-    if (tiles_store.size() > 0xFFFFFFF0ull / kWave) return fail(SVT_ERR_INVALID, "too many tiles");
-    // dispatch order: longest tiles first (LPT) so the tail of the grid is made of short tiles
-    std::vector<TileDesc> tiles_dispatch = tiles_store;
-    std::stable_sort(tiles_dispatch.begin(), tiles_dispatch.end(),
-                     [](const TileDesc& x, const TileDesc& y) { return x.rows > y.rows; });
-
-    // ---- device objects ---------------------------------------------------------------------
     svt_batch* b = new (std::nothrow) svt_batch();
     if (!b) return fail(SVT_ERR_NOMEM, "out of host memory");
     b->device = device;
     b->flags = flags;
+    b->split = (flags & SVT_FLAG_DENSE_LAYOUT) == 0;
     b->n_units = n;
-    b->n_records = n_rec;
-    b->tiled_records = tiled_records;
-    b->n_tiles = (uint32_t)tiles_store.size();
-
-    int rc = SVT_OK;
-    uint4* d_csr = nullptr;
-    TileDesc* d_tiles_store = nullptr;
-    uint64_t* d_lane_src = nullptr;
-    uint32_t* d_lane_nrec = nullptr;
-    uint32_t* d_err = nullptr;
-    auto cleanup_tmp = [&]() {
-        if (d_csr) (void)hipFree(d_csr);
-        if (d_tiles_store) (void)hipFree(d_tiles_store);
-        if (d_lane_src) (void)hipFree(d_lane_src);
-        if (d_lane_nrec) (void)hipFree(d_lane_nrec);
-        if (d_err) (void)hipFree(d_err);
-    };
-#define TRY_OR_CLEAN(expr)                                    \
-    do {                                                      \
-        rc = (expr);                                          \
-        if (rc != SVT_OK) { cleanup_tmp(); free_batch(b); return rc; } \
-    } while (0)
-#define HIP_OR_CLEAN(expr)                                                                  \
-    do {                                                                                    \
-        hipError_t _e = (expr);                                                             \
-        if (_e != hipSuccess) {                                                             \
-            cleanup_tmp(); free_batch(b);                                                   \
-            return fail(SVT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));    \
-        }                                                                                   \
-    } while (0)
-
-    HIP_OR_CLEAN(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
-    HIP_OR_CLEAN(hipEventCreate(&b->ev0));
-    HIP_OR_CLEAN(hipEventCreate(&b->ev1));
-    TRY_OR_CLEAN(upload(&b->d_tiles, tiles_dispatch, b->stream));
-    TRY_OR_CLEAN(upload(&d_tiles_store, tiles_store, b->stream));
-    TRY_OR_CLEAN(upload(&b->d_hdr, hdr, b->stream));
-    TRY_OR_CLEAN(upload(&d_lane_src, lane_src, b->stream));
-    TRY_OR_CLEAN(upload(&d_lane_nrec, lane_nrec, b->stream));
-    TRY_OR_CLEAN(upload(&b->d_pm, pm, b->stream));
-    TRY_OR_CLEAN(upload(&b->d_l10, l10, b->stream));
-    TRY_OR_CLEAN(upload(&b->d_libs, libs, b->stream));
-    TRY_OR_CLEAN(upload(&b->d_hist, hist, b->stream));
-    TRY_OR_CLEAN(upload(&b->d_thr, thr, b->stream));
-
-    HIP_OR_CLEAN(hipMalloc(reinterpret_cast<void**>(&d_csr), std::max<uint64_t>(n_rec, 1) * sizeof(uint4)));
-    if (n_rec)
-        HIP_OR_CLEAN(hipMemcpyAsync(d_csr, in->records, n_rec * sizeof(uint4), hipMemcpyHostToDevice, b->stream));
-    // + 8 rows of tail pad: the kernel's look-ahead loads may run past the last tile
-    HIP_OR_CLEAN(hipMalloc(reinterpret_cast<void**>(&b->d_tiled), (tiled_records + 2 * SVT_GROUP * kWave) * sizeof(uint4)));
-    HIP_OR_CLEAN(hipMemsetAsync(b->d_tiled + tiled_records, 0, 2 * SVT_GROUP * kWave * sizeof(uint4), b->stream));
-    HIP_OR_CLEAN(hipMalloc(reinterpret_cast<void**>(&d_err), sizeof(uint32_t)));
-    HIP_OR_CLEAN(hipMemsetAsync(d_err, 0, sizeof(uint32_t), b->stream));
-
-    const uint64_t n1 = std::max<uint64_t>(n, 1);
-    HIP_OR_CLEAN(hipMalloc(reinterpret_cast<void**>(&b->d_out), n1 * sizeof(svt_result)));
-    TRY_OR_CLEAN(upload(&b->d_wtab, wtab, b->stream));
-
-    // ---- re-tile on the device ------------------------------------------------------------------
-    if (b->n_tiles) {
-        RepackArgs ra{};
-        ra.csr = d_csr;
-        ra.lane_src = d_lane_src;
-        ra.lane_nrec = d_lane_nrec;
-        ra.tiles = d_tiles_store;
-        ra.tiled = b->d_tiled;
-        ra.n_tiles = b->n_tiles;
-        ra.n_libs = in->n_libs;
-        ra.err = d_err;
-        const dim3 grid((b->n_tiles + kWavesPerBlock - 1) / kWavesPerBlock), block(kBlock);
-        hipLaunchKernelGGL(svt_repack_kernel, grid, block, 0, b->stream, ra);
-        HIP_OR_CLEAN(hipGetLastError());
-    }
-    uint32_t err_bits = 0;
-    HIP_OR_CLEAN(hipMemcpyAsync(&err_bits, d_err, sizeof(uint32_t), hipMemcpyDeviceToHost, b->stream));
-    HIP_OR_CLEAN(hipStreamSynchronize(b->stream));
-    cleanup_tmp();
-    d_csr = nullptr; d_tiles_store = nullptr; d_lane_src = nullptr; d_lane_nrec = nullptr; d_err = nullptr;
-    if (err_bits) {
+    b->n_records = n ? in->rec_offset[n] : 0;
+    const int rc = create_on_device(in, b);
+    if (rc != SVT_OK) {
+        const std::string keep = g_err;
         free_batch(b);
-        std::string m = "invalid evidence records:";
-        if (err_bits & 2u) m += " straddle bits without HAS_PAIR;";
-        if (err_bits & 4u) m += " lib index >= n_libs;";
-        if (err_bits & 8u) m += " reserved/undefined bits set;";
-        if (err_bits & 16u) m += " negative ospan_len;";
-        return fail(SVT_ERR_INVALID, m);
+        g_err = keep;
+        return rc;
     }
-
-    // ---- kernel arguments ----------------------------------------------------------------------
-    KernelArgs& a = b->args;
-    a.tiled = b->d_tiled;
-    a.tiles = b->d_tiles;
-    a.hdr = b->d_hdr;
-    a.pm = b->d_pm;
-    a.l10 = b->d_l10;
-    a.libs = b->d_libs;
-    a.hist = b->d_hist;
-    a.thr = b->d_thr;
-    a.n_l10 = n_l10;
-    a.n_libs = in->n_libs;
-    a.total_bins = total_bins;
-    a.n_tiles = b->n_tiles;
-    a.l10_in_lds = n_l10 <= kMaxL10Lds ? 1u : 0u;
-    a.n_units = n;
-    a.out = b->d_out;
-    a.wtab = b->d_wtab;
-    a.lib0 = libs[0];
-    fill_gt_consts(a.c, in->split_weight, in->disc_weight);
-    const size_t table_bytes = (size_t)total_bins * 8;
-    if (fast_geometry && table_bytes <= kMaxLdsTableBytes) b->mode = in->n_libs == 1 ? kSingleLds : kMultiLds;
-    else b->mode = kGeneral;
-    const uint32_t n_l10_lds = a.l10_in_lds ? ((n_l10 + 1u) & ~1u) : 0u;
-    b->lds_bytes = 256 * 8 + 32 * sizeof(PairWeights) + (size_t)n_l10_lds * 8 +
-                   (size_t)in->n_libs * sizeof(LibDesc) + (b->mode != kGeneral ? table_bytes : 0);
-    b->lds_bytes = (b->lds_bytes + 15) & ~size_t(15);
-    if (b->lds_bytes > 160 * 1024) { free_batch(b); return fail(SVT_ERR_INVALID, "LDS budget exceeded"); }
-    TRY_OR_CLEAN(allow_big_lds(svt_genotype_kernel<false, kSingleLds>, b->lds_bytes));
-    TRY_OR_CLEAN(allow_big_lds(svt_genotype_kernel<true, kSingleLds>, b->lds_bytes));
-    TRY_OR_CLEAN(allow_big_lds(svt_genotype_kernel<false, kMultiLds>, b->lds_bytes));
-    TRY_OR_CLEAN(allow_big_lds(svt_genotype_kernel<true, kMultiLds>, b->lds_bytes));
-    TRY_OR_CLEAN(allow_big_lds(svt_genotype_kernel<false, kGeneral>, b->lds_bytes));
-    TRY_OR_CLEAN(allow_big_lds(svt_genotype_kernel<true, kGeneral>, b->lds_bytes));
-#undef TRY_OR_CLEAN
-#undef HIP_OR_CLEAN
     *out = b;
     return SVT_OK;
 }
@@ -990,8 +1133,7 @@ int svt_batch_genotype(svt_batch* b, int sync)
 {
     if (!b) return fail(SVT_ERR_INVALID, "null batch");
     HIP_TRY(hipSetDevice(b->device));
-    int rc = launch_genotype(b);
-    if (rc != SVT_OK) return rc;
+    SVT_TRY(launch_genotype(b));
     b->have_results = true;
     if (sync) HIP_TRY(hipStreamSynchronize(b->stream));
     return SVT_OK;
@@ -1002,10 +1144,7 @@ int svt_batch_genotype_timed(svt_batch* b, int iters, float* ms_total)
     if (!b || !ms_total || iters <= 0) return fail(SVT_ERR_INVALID, "bad arguments");
     HIP_TRY(hipSetDevice(b->device));
     HIP_TRY(hipEventRecord(b->ev0, b->stream));
-    for (int i = 0; i < iters; ++i) {
-        int rc = launch_genotype(b);
-        if (rc != SVT_OK) return rc;
-    }
+    for (int i = 0; i < iters; ++i) SVT_TRY(launch_genotype(b));
     HIP_TRY(hipEventRecord(b->ev1, b->stream));
     HIP_TRY(hipEventSynchronize(b->ev1));
     HIP_TRY(hipEventElapsedTime(ms_total, b->ev0, b->ev1));
@@ -1045,7 +1184,7 @@ int svt_batch_bytes(const svt_batch* b, uint64_t* algorithmic, uint64_t* residen
 {
     if (!b) return fail(SVT_ERR_INVALID, "null batch");
     if (algorithmic) *algorithmic = 16 * b->n_records + (16 + 96) * b->n_units;
-    if (resident) *resident = 16 * b->tiled_records + (uint64_t)b->n_tiles * kWave * sizeof(LaneHdr);
+    if (resident) *resident = 16 * b->slots + (uint64_t)b->n_tiles * kWave * sizeof(LaneHdr);
     return SVT_OK;
 }
 
@@ -1054,7 +1193,7 @@ int svt_bayes_gt(const int32_t* ref, const int32_t* alt, const uint8_t* is_dup, 
 {
     if (n == 0) return SVT_OK;
     if (!ref || !alt || !is_dup || !out) return fail(SVT_ERR_INVALID, "null argument");
-    int ndev = svt_device_count();
+    const int ndev = svt_device_count();
     if (ndev <= 0) return fail(SVT_ERR_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
     if (device < 0 || device >= ndev) return fail(SVT_ERR_NO_DEVICE, "device index out of range");
     int64_t max_total = 0;
@@ -1069,39 +1208,21 @@ int svt_bayes_gt(const int32_t* ref, const int32_t* alt, const uint8_t* is_dup, 
     GtConsts c{};
     fill_gt_consts(c, 1.0, 1.0);
     HIP_TRY(hipSetDevice(device));
-    int32_t *d_ref = nullptr, *d_alt = nullptr;
-    uint8_t* d_dup = nullptr;
-    double *d_l10 = nullptr, *d_out = nullptr;
-    auto cleanup = [&]() {
-        if (d_ref) (void)hipFree(d_ref);
-        if (d_alt) (void)hipFree(d_alt);
-        if (d_dup) (void)hipFree(d_dup);
-        if (d_l10) (void)hipFree(d_l10);
-        if (d_out) (void)hipFree(d_out);
-    };
-#define BT(expr)                                                                          \
-    do {                                                                                  \
-        hipError_t _e = (expr);                                                           \
-        if (_e != hipSuccess) {                                                           \
-            cleanup();                                                                    \
-            return fail(SVT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));  \
-        }                                                                                 \
-    } while (0)
-    BT(hipMalloc(reinterpret_cast<void**>(&d_ref), n * sizeof(int32_t)));
-    BT(hipMalloc(reinterpret_cast<void**>(&d_alt), n * sizeof(int32_t)));
-    BT(hipMalloc(reinterpret_cast<void**>(&d_dup), n));
-    BT(hipMalloc(reinterpret_cast<void**>(&d_l10), l10.size() * sizeof(double)));
-    BT(hipMalloc(reinterpret_cast<void**>(&d_out), n * 4 * sizeof(double)));
-    BT(hipMemcpy(d_ref, ref, n * sizeof(int32_t), hipMemcpyHostToDevice));
-    BT(hipMemcpy(d_alt, alt, n * sizeof(int32_t), hipMemcpyHostToDevice));
-    BT(hipMemcpy(d_dup, is_dup, n, hipMemcpyHostToDevice));
-    BT(hipMemcpy(d_l10, l10.data(), l10.size() * sizeof(double), hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(svt_bayes_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, 0, d_ref,
-                       d_alt, d_dup, n, d_l10, c, d_out);
-    BT(hipGetLastError());
-    BT(hipMemcpy(out, d_out, n * 4 * sizeof(double), hipMemcpyDeviceToHost));
-#undef BT
-    cleanup();
+    DevScratch d_ref, d_alt, d_dup, d_l10, d_out;
+    SVT_TRY(d_ref.alloc(n * sizeof(int32_t)));
+    SVT_TRY(d_alt.alloc(n * sizeof(int32_t)));
+    SVT_TRY(d_dup.alloc(n));
+    SVT_TRY(d_l10.alloc(l10.size() * sizeof(double)));
+    SVT_TRY(d_out.alloc(n * 4 * sizeof(double)));
+    HIP_TRY(hipMemcpy(d_ref.p, ref, n * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_alt.p, alt, n * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_dup.p, is_dup, n, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_l10.p, l10.data(), l10.size() * sizeof(double), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(svt_bayes_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, 0,
+                       d_ref.as<int32_t>(), d_alt.as<int32_t>(), d_dup.as<uint8_t>(), n, d_l10.as<double>(), c,
+                       d_out.as<double>());
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(out, d_out.p, n * 4 * sizeof(double), hipMemcpyDeviceToHost));
     return SVT_OK;
 }
 
@@ -1112,11 +1233,10 @@ void svt_batch_destroy(svt_batch* b) { free_batch(b); }
 int svt_genotype(const svt_evidence_batch* in, svt_result* out, int device, unsigned flags)
 {
     svt_batch* b = nullptr;
-    int rc = svt_batch_create(in, device, flags, &b);
-    if (rc != SVT_OK) return rc;
-    rc = svt_batch_genotype(b, 1);
+    SVT_TRY(svt_batch_create(in, device, flags, &b));
+    int rc = svt_batch_genotype(b, 1);
     if (rc == SVT_OK) rc = svt_batch_results(b, out, in->n_units);
-    std::string keep = g_err;
+    const std::string keep = g_err;
     svt_batch_destroy(b);
     g_err = keep;
     return rc;

@@ -37,11 +37,18 @@ def run_both(batch, flags=0, device=0):
     from oracle import c_oracle
     from svtyper_amd import hip
     got = hip.genotype_batch(batch, device=device, flags=flags)
-    want = c_oracle.genotype_batch(batch, flags=flags)
+    want = c_oracle.genotype_batch(batch, flags=flags & ev.FLAG_SSO_ASSOCIATION)
     return got, want
 
 
-@pytest.mark.parametrize("flags", [0, ev.FLAG_SSO_ASSOCIATION])
+ALL_FLAGS = [0, ev.FLAG_SSO_ASSOCIATION, ev.FLAG_DENSE_LAYOUT, ev.FLAG_DENSE_LAYOUT | ev.FLAG_SSO_ASSOCIATION]
+
+
+def oracle_flags(flags):
+    return flags & ev.FLAG_SSO_ASSOCIATION   # the device layout is invisible to the oracle
+
+
+@pytest.mark.parametrize("flags", ALL_FLAGS)
 def test_edge_cases(hip_device, fixture_library, flags):
     batch = synth.make_edge_cases([fixture_library], seed=11)
     got, want = run_both(batch, flags)
@@ -53,7 +60,7 @@ def test_edge_cases(hip_device, fixture_library, flags):
         assert (want.gt == g).any()
 
 
-@pytest.mark.parametrize("flags", [0, ev.FLAG_SSO_ASSOCIATION])
+@pytest.mark.parametrize("flags", ALL_FLAGS)
 def test_c2_slice(hip_device, fixture_library, flags):
     """BASELINE.json configs[1] (100k DEL sites, 1 library), a 20k-unit slice."""
     batch = synth.make_config("c2_del_100k", [fixture_library], n_units=20_000)
@@ -61,18 +68,20 @@ def test_c2_slice(hip_device, fixture_library, flags):
     assert_parity(got, want)
 
 
-def test_c3_slice_mixed(hip_device, fixture_library):
+@pytest.mark.parametrize("flags", [0, ev.FLAG_DENSE_LAYOUT])
+def test_c3_slice_mixed(hip_device, fixture_library, flags):
     """configs[2]: mixed DEL/DUP/INV."""
     batch = synth.make_config("c3_mixed_1m", [fixture_library], n_units=30_000)
-    got, want = run_both(batch)
+    got, want = run_both(batch, flags)
     assert_parity(got, want)
     assert len(np.unique(batch.units["svtype"])) == 3
 
 
-def test_multi_library(hip_device, fixture_library):
+@pytest.mark.parametrize("flags", ALL_FLAGS)
+def test_multi_library(hip_device, fixture_library, flags):
     libs = [fixture_library, synth.normal_library(420.0, 95.0, seed=3), synth.normal_library(280.0, 40.0, seed=4)]
     batch = synth.make_units(5000, 99, libs, svtype_mix=(0.5, 0.2, 0.2, 0.1))
-    got, want = run_both(batch)
+    got, want = run_both(batch, flags)
     assert_parity(got, want)
 
 
@@ -84,8 +93,9 @@ def test_wide_geometry_general_mode(hip_device, fixture_library):
     batch.units["pos_delta"][::7] = 2**30 + 12346
     big = batch.units["var_length"][batch.units["svtype"] == 0].max()
     batch.records["ospan_len"][::5] = np.minimum(2**31 - 1, batch.records["ospan_len"][::5].astype(np.int64) + big)
-    got, want = run_both(batch)
-    assert_parity(got, want)
+    for flags in ALL_FLAGS:
+        got, want = run_both(batch, flags)
+        assert_parity(got, want)
 
 
 def test_integral_nondel_var_length(hip_device):
