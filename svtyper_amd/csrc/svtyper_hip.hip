@@ -43,7 +43,16 @@
 #include "../../include/svtyper_hip.h"
 
 #ifndef SVT_GROUP
-#define SVT_GROUP 4   // rows fetched per look-ahead group
+#define SVT_GROUP 4   // rows fetched per look-ahead group (dense layout)
+#endif
+#ifndef SVT_GROUP_A
+#define SVT_GROUP_A 2 // split layout, pair-entry rows
+#endif
+#ifndef SVT_GROUP_B
+#define SVT_GROUP_B 2 // split layout, weight-entry rows
+#endif
+#ifndef SVT_MIN_WAVES
+#define SVT_MIN_WAVES 1
 #endif
 #ifndef SVT_CHUNK
 #define SVT_CHUNK 16384
@@ -61,7 +70,7 @@ constexpr uint32_t kChunkUnits = SVT_CHUNK;  // sort window (units)
 constexpr uint32_t kPadUnit = 0xFFFFFFFFu;
 constexpr uint32_t kMaxLdsTableBytes = 64 * 1024;  // hist+thr budget before falling back to HBM/L2 tables
 constexpr uint32_t kMaxL10Lds = 4096;              // log10 table entries kept in LDS (32 KiB)
-constexpr uint32_t kTailPadRows = 2 * SVT_GROUP;   // look-ahead loads may run this far past a tile
+constexpr uint32_t kTailPadRows = 16;   // look-ahead loads may run this far past a tile (>= 2 * group)
 
 thread_local std::string g_err;
 
@@ -312,25 +321,25 @@ __device__ __forceinline__ uint4 pack2d(double x, double y)
 // Stream `rows` row slots of one lane, SVT_GROUP at a time, one group ahead of the group being
 // consumed (the tiled buffer carries kTailPadRows rows of slack, so the look-ahead never leaves
 // the allocation).
-template <typename F>
+template <int G, typename F>
 __device__ __forceinline__ void stream_rows(const uint4* __restrict__ p, const uint32_t rows, F&& consume)
 {
-    uint4 cur[SVT_GROUP], nxt[SVT_GROUP];
+    uint4 cur[G], nxt[G];
 #pragma unroll
-    for (int k = 0; k < SVT_GROUP; ++k) cur[k] = ld_stream(p + k * kWave);
+    for (int k = 0; k < G; ++k) cur[k] = ld_stream(p + k * kWave);
     uint32_t j = 0;
-    for (; j + SVT_GROUP <= rows; j += SVT_GROUP) {
-        const uint4* __restrict__ q = p + (uint64_t)(j + SVT_GROUP) * kWave;
+    for (; j + G <= rows; j += G) {
+        const uint4* __restrict__ q = p + (uint64_t)(j + G) * kWave;
 #pragma unroll
-        for (int k = 0; k < SVT_GROUP; ++k) nxt[k] = ld_stream(q + k * kWave);
+        for (int k = 0; k < G; ++k) nxt[k] = ld_stream(q + k * kWave);
 #pragma unroll
-        for (int k = 0; k < SVT_GROUP; ++k) consume(cur[k]);
+        for (int k = 0; k < G; ++k) consume(cur[k]);
 #pragma unroll
-        for (int k = 0; k < SVT_GROUP; ++k) cur[k] = nxt[k];
+        for (int k = 0; k < G; ++k) cur[k] = nxt[k];
     }
     const uint32_t rem = rows - j;  // wave-uniform
 #pragma unroll
-    for (int k = 0; k < SVT_GROUP - 1; ++k)
+    for (int k = 0; k < G - 1; ++k)
         if ((uint32_t)k < rem) consume(cur[k]);
 }
 
@@ -338,7 +347,7 @@ __device__ __forceinline__ void stream_rows(const uint4* __restrict__ p, const u
 // genotype kernel
 // ------------------------------------------------------------------------------------------
 template <bool SSO, int MODE, bool SPLIT>
-__global__ __launch_bounds__(kBlock) void svt_genotype_kernel(const KernelArgs a)
+__global__ __launch_bounds__(kBlock, SVT_MIN_WAVES) void svt_genotype_kernel(const KernelArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // LDS layout: pm[256] | wtab[32] | l10[n_l10 (even)] | libs[n_libs] | hist[total_bins] | thr[total_bins]
@@ -400,18 +409,18 @@ __global__ __launch_bounds__(kBlock) void svt_genotype_kernel(const KernelArgs a
     // ---- stream the tile: row j is one contiguous 1 KiB line for the wave
     if (SPLIT) {
         // pair entries: x = ospan_len, y = mapq_a | mapq_b << 8 | f3 << 16 | lib << 24
-        stream_rows(a.tiled + td.base_a + lane, td.rows_a, [&](const uint4 w) {
+        stream_rows<SVT_GROUP_A>(a.tiled + td.base_a + lane, td.rows_a, [&](const uint4 w) {
             pair_evidence<MODE>(w.x, w.y & 0xffffu, (w.y >> 16) & 7u, w.y >> 24, t, c, acc);
             pair_evidence<MODE>(w.z, w.w & 0xffffu, (w.w >> 16) & 7u, w.w >> 24, t, c, acc);
         });
         // weight entries: x = rs_a | rs_b << 8 | seq_l << 16 | seq_r << 24, y = clip_l | clip_r << 8 | cont << 16
-        stream_rows(a.tiled + td.base_b + lane, td.rows_b, [&](const uint4 w) {
+        stream_rows<SVT_GROUP_B>(a.tiled + td.base_b + lane, td.rows_b, [&](const uint4 w) {
             weight_evidence<SSO>(w.x, w.y, (w.y & 0x10000u) != 0, t, acc);
             weight_evidence<SSO>(w.z, w.w, (w.w & 0x10000u) != 0, t, acc);
         });
     } else {
         // canonical 16-byte records (include/svtyper_hip.h: svt_record)
-        stream_rows(a.tiled + td.base_a + lane, td.rows_a, [&](const uint4 w) {
+        stream_rows<SVT_GROUP>(a.tiled + td.base_a + lane, td.rows_a, [&](const uint4 w) {
             weight_evidence<SSO>(w.y >> 16 | (w.z << 16), w.z >> 16, (w.w & SVT_REC_CONTINUATION) != 0, t, acc);
             pair_evidence<MODE>(w.x, w.y & 0xffffu, w.w & 7u, SVT_REC_LIB(w.w), t, c, acc);
         });
