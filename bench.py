@@ -174,7 +174,8 @@ def main():
         try:
             with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as f:
                 tj = json.load(f)
-            if tj.get("units") == n and tj.get("records") == batch.n_records and not args.sso:
+            tj = tj["dense" if args.dense else "split"]
+            if tj.get("units") == n and tj.get("records") == batch.n_records:
                 traffic = tj["traffic_bytes_per_launch"]
                 traffic_note = "rocprofv3 PMC (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), profiles/hbm_traffic.json"
         except (OSError, ValueError, KeyError):
@@ -213,6 +214,7 @@ def main():
                 "traffic": traffic,
                 "traffic_unit": "bytes per launch",
                 "traffic_source": traffic_note,
+                "traffic_frac_of_peak": (traffic / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "resident_bytes_per_launch": resident_bytes,
                 "kernel_ms": kern_ms,
