@@ -249,6 +249,26 @@ def main():
                 "sample": "the workload's %d units x %d repetitions, oracle/svt_oracle.c "
                           "(OpenMP, %d threads)" % (sample_n, reps, threads),
             }
+            # the closest stand-in for "the reference's own CPU path" that can run here: the pure-Python
+            # restatement, 1 process and a multiprocessing.Pool over all cores with 1000-unit batches
+            # (the structure of svtyper/singlesample.py:746-748), on bounded slices of the workload
+            try:
+                from oracle import py_oracle
+                n1 = min(n, 6000)
+                t0 = time.perf_counter()
+                py_oracle.genotype_batch(batch.slice(0, n1), flags & ev.FLAG_SSO_ASSOCIATION)
+                one = n1 / (time.perf_counter() - t0)
+                npool = min(n, 2000 * threads)
+                t0 = time.perf_counter()
+                py_oracle.genotype_batch_pool(batch.slice(0, npool), flags & ev.FLAG_SSO_ASSOCIATION,
+                                              processes=threads, batch_size=1000)
+                pool = npool / (time.perf_counter() - t0)
+                out["cpu_baseline_python"] = {
+                    "kind": "port", "unit": "breakpoints/s", "one_process": one, "pool": pool, "cores": threads,
+                    "sample": "oracle/py_oracle.py: first %d units (1 process), first %d units "
+                              "(multiprocessing.Pool(%d), batch_size=1000)" % (n1, npool, threads)}
+            except Exception as e:  # never let the extra baseline break the bench line
+                out["cpu_baseline_python"] = {"error": repr(e)}
             ints_bad = int((got.counts[:sample_n] != want.counts).sum() + (got.gt[:sample_n] != want.gt).sum())
             out["parity"] = {
                 "units_checked": sample_n,
