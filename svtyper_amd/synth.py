@@ -191,6 +191,50 @@ def make_config(name: str, libs: Sequence[LibraryTable], n_units: Optional[int] 
     return parts[0] if len(parts) == 1 else ev.concat_batches(parts)
 
 
+def permute_units(batch: EvidenceBatch, order: np.ndarray) -> EvidenceBatch:
+    """Units re-ordered as `order` (records move with their unit)."""
+    order = np.asarray(order, dtype=np.int64)
+    off = batch.rec_offset.astype(np.int64)
+    F = (off[1:] - off[:-1])[order]
+    new_off = np.zeros(len(order) + 1, np.int64)
+    np.cumsum(F, out=new_off[1:])
+    # source record index of every destination record
+    src = np.repeat(off[:-1][order] - new_off[:-1], F) + np.arange(int(new_off[-1]))
+    return EvidenceBatch(new_off.astype(np.uint64), batch.units[order], batch.records[src], batch.libs,
+                         batch.split_weight, batch.disc_weight)
+
+
+def make_multisample(n_sites: int, n_samples: int, seed: int, libs_per_sample=(1, 3), mean_frags: float = 100.0,
+                     sd_frags: float = 25.0, min_frags: int = 18, max_frags: int = 183) -> EvidenceBatch:
+    """BASELINE.json configs[4] shape: (site, sample) units, site-major, every sample with its own 1..3
+    libraries (rounded-normal insert-size histograms) and genotypes drawn per sample from a site allele
+    frequency ~ Beta(0.5, 2)."""
+    rng = np.random.default_rng(seed)
+    libs: List[LibraryTable] = []
+    sample_libs = []
+    for s in range(n_samples):
+        k = int(rng.integers(libs_per_sample[0], libs_per_sample[1] + 1))
+        ids = []
+        for _ in range(k):
+            ids.append(len(libs))
+            libs.append(normal_library(float(rng.uniform(250, 550)), float(rng.uniform(40, 120)), n=200_000,
+                                       seed=int(rng.integers(1 << 30)), name="s%d_l%d" % (s, len(ids))))
+        sample_libs.append(ids)
+    af = rng.beta(0.5, 2.0, n_sites)
+    parts = []
+    for s in range(n_samples):
+        parts.append(make_units(n_sites, seed + 17 * (s + 1), libs, svtype_mix=(0.70, 0.15, 0.15, 0.0),
+                                mean_frags=mean_frags, sd_frags=sd_frags, min_frags=min_frags,
+                                max_frags=max_frags, sample=s, lib_choices=sample_libs[s], alt_af=af))
+    # the same site must have the same svtype / length in every sample: copy sample 0's unit geometry
+    for p in parts[1:]:
+        for fld in ("svtype", "var_length", "pos_delta"):
+            p.units[fld] = parts[0].units[fld]
+    allb = ev.concat_batches(parts)
+    order = (np.arange(n_sites)[:, None] + n_sites * np.arange(n_samples)[None, :]).reshape(-1)
+    return permute_units(allb, order)
+
+
 def make_edge_cases(libs: Sequence[LibraryTable], seed: int = 1) -> EvidenceBatch:
     """Small adversarial batch: empty/skip units, ragged record counts 0..300, all svtypes,
     MAPQ values whose weights do not sum associatively (0.9, 0.99, ...), multi-record fragments

@@ -180,3 +180,14 @@ def test_bayes_grid_via_kernel(hip_device, fixture_library):
                     assert got.gt[k] == 2 and got.count("GQ")[k] == 2
                     assert abs(got.sq[k] - 31.464381352857743) < TOL
                 k += 1
+
+
+def test_multisample_per_sample_libraries(hip_device):
+    """BASELINE.json configs[4] shape at test size: 150 sites x 32 samples, 1..3 libraries per sample
+    (too many tables for LDS -> the general kernel), both layouts and associations."""
+    batch = synth.make_multisample(150, 32, seed=5, mean_frags=40, sd_frags=15, min_frags=5, max_frags=90)
+    assert len(batch.libs) >= 32 and batch.n_units == 150 * 32
+    assert (batch.units["sample"][:32] == np.arange(32)).all()
+    for flags in ALL_FLAGS:
+        got, want = run_both(batch, flags)
+        assert_parity(got, want)
