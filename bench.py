@@ -53,6 +53,12 @@ def _gen_chunk(args):
 def generate(name: str, n_units: int, rank: int, workers: int):
     """The synthetic workload of this rank (chunks generated in parallel host processes)."""
     from svtyper_amd import evidence as ev
+    if name == "c5_multisample":
+        import multiprocessing as mp
+        from svtyper_amd import synth
+        with mp.get_context("fork").Pool(min(max(1, workers), 32)) as pool:
+            return synth.make_multisample(max(1, n_units // 32), 32, synth.BASE_SEED + 5 + 7919 * rank,
+                                          pool_map=pool.map)
     chunk = 50_000
     jobs = [(name, min(chunk, n_units - i), i // chunk, rank) for i in range(0, n_units, chunk)]
     if workers > 1 and len(jobs) > 1:
@@ -70,7 +76,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--units", type=int, default=1_000_000, help="breakpoints per GPU")
-    ap.add_argument("--workload", default="c3_mixed_1m", choices=["c3_mixed_1m", "c2_del_100k"])
+    ap.add_argument("--workload", default="c3_mixed_1m", choices=["c3_mixed_1m", "c2_del_100k", "c5_multisample"])
     ap.add_argument("--sso", action="store_true", help="singlesample.py floating-point association")
     ap.add_argument("--dense", action="store_true", help="stream the canonical 16-byte records (no sparse re-encoding)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -197,7 +203,9 @@ def main():
                 "workload": "BASELINE.json configs[2]: %d mixed DEL/DUP/INV breakpoints per GPU, 1 library "
                             "(fixture insert-size histogram in LDS), %.1f fragment records/site"
                             % (n, batch.n_records / max(1, n)) if args.workload == "c3_mixed_1m" else
-                            "BASELINE.json configs[1]: %d DEL breakpoints per GPU, 1 library" % n,
+                            ("BASELINE.json configs[4] shape: %d sites x 32 samples = %d units per GPU, %d libraries"
+                             % (n // 32, n, len(batch.libs)) if args.workload == "c5_multisample" else
+                             "BASELINE.json configs[1]: %d DEL breakpoints per GPU, 1 library" % n),
                 "units_per_gpu": n,
                 "records_per_gpu": batch.n_records,
                 "association": "sso" if args.sso else "classic",

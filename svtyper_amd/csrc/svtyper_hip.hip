@@ -147,9 +147,18 @@ enum LibMode : int {
     kGeneral = 2     // any geometry: 64-bit index math, exact float Counter key, tables in HBM/L2
 };
 
+// Library window of one workgroup (its 4 tiles): the descriptors [lib_lo, lib_lo + lib_cnt) and the
+// histogram/threshold bins [bin_lo, bin_lo + bin_cnt) are the only ones its records can reference, so
+// only they are staged in LDS (kMultiLds).  Units are sorted by library first, so a window normally
+// holds the 1..3 libraries of one sample.
+struct WgDesc {
+    uint32_t lib_lo, lib_cnt, bin_lo, bin_cnt;
+};
+
 struct KernelArgs {
     const uint4* tiled;
     const TileDesc* tiles;
+    const WgDesc* wg;          // one per workgroup (kMultiLds)
     const LaneHdr* hdr;
     const double* pm;          // 256
     const double* l10;         // n_l10
@@ -162,6 +171,8 @@ struct KernelArgs {
     uint32_t total_bins;
     uint32_t n_tiles;
     uint32_t l10_in_lds;
+    uint32_t lds_libs;         // LDS capacity in library descriptors (largest window)
+    uint32_t lds_bins;         // LDS capacity in histogram bins (largest window)
     uint32_t pad0;
     uint64_t n_units;
     svt_result* out;           // [n_units]
@@ -192,6 +203,8 @@ struct LaneCtx {
     uint32_t kmin;        // kSingleLds: (uint32) key_min
     uint32_t nb;          // kSingleLds: n_bins (== sentinel index)
     uint32_t sub2;        // kSingleLds: DEL ? var_length + key_min : 0x80000000 (never in range)
+    uint32_t lib_lo;      // kMultiLds: first library / first bin staged by this workgroup
+    uint32_t bin_lo;
     int32_t var_length;
     double pos_delta_d;
     bool is_del;
@@ -252,15 +265,16 @@ __device__ __forceinline__ void pair_evidence(const uint32_t o, const uint32_t m
         thr1 = t.thr[i1];
         h2 = t.hist[i2];
     } else if (MODE == kMultiLds) {
-        const LibDesc lib = t.libs[lib_idx];
+        const LibDesc lib = t.libs[lib_idx - c.lib_lo];
         const bool small_del = c.is_del && (c.pos_delta_d < lib.sd2);
         f3 = small_del ? 0u : f3;
         const uint32_t kmin = (uint32_t)lib.key_min;
         const uint32_t sub2 = c.is_del ? (uint32_t)c.var_length + kmin : 0x80000000u;
         const uint32_t i1 = min(o - kmin, lib.n_bins);
         const uint32_t i2 = min(o - sub2, lib.n_bins);
-        thr1 = t.thr[lib.tab_off + i1];
-        h2 = t.hist[lib.tab_off + i2];
+        const uint32_t base = lib.tab_off - c.bin_lo;
+        thr1 = t.thr[base + i1];
+        h2 = t.hist[base + i2];
     } else {
         const LibDesc lib = t.libs[lib_idx];
         const bool small_del = c.is_del && (c.pos_delta_d < lib.sd2);
@@ -356,20 +370,24 @@ __global__ __launch_bounds__(kBlock, SVT_MIN_WAVES) void svt_genotype_kernel(con
     double* s_l10 = reinterpret_cast<double*>(s_wtab + 32);
     const uint32_t n_l10_lds = a.l10_in_lds ? ((a.n_l10 + 1u) & ~1u) : 0u;
     LibDesc* s_lib = reinterpret_cast<LibDesc*>(s_l10 + n_l10_lds);
-    uint32_t* s_hist = reinterpret_cast<uint32_t*>(s_lib + a.n_libs);
-    int32_t* s_thr = reinterpret_cast<int32_t*>(s_hist + (MODE != kGeneral ? a.total_bins : 0u));
+    uint32_t* s_hist = reinterpret_cast<uint32_t*>(s_lib + a.lds_libs);
+    int32_t* s_thr = reinterpret_cast<int32_t*>(s_hist + a.lds_bins);
+    // library window of this workgroup (everything when the tables of the whole batch fit)
+    WgDesc wd = {0u, a.n_libs, 0u, MODE != kGeneral ? a.total_bins : 0u};
+    if (MODE == kMultiLds) wd = a.wg[blockIdx.x];
 
     // ---- stage the tables in LDS (they are L2-resident after the first workgroups)
     for (uint32_t i = threadIdx.x; i < 256; i += kBlock) s_pm[i] = a.pm[i];
     if (threadIdx.x < 32) s_wtab[threadIdx.x] = a.wtab[threadIdx.x];
     if (a.l10_in_lds)
         for (uint32_t i = threadIdx.x; i < a.n_l10; i += kBlock) s_l10[i] = a.l10[i];
-    for (uint32_t i = threadIdx.x; i < a.n_libs * (uint32_t)(sizeof(LibDesc) / 8); i += kBlock)
-        reinterpret_cast<uint64_t*>(s_lib)[i] = reinterpret_cast<const uint64_t*>(a.libs)[i];
+    for (uint32_t i = threadIdx.x; i < wd.lib_cnt * (uint32_t)(sizeof(LibDesc) / 8); i += kBlock)
+        reinterpret_cast<uint64_t*>(s_lib)[i] =
+            reinterpret_cast<const uint64_t*>(a.libs + wd.lib_lo)[i];
     if (MODE != kGeneral) {
-        for (uint32_t i = threadIdx.x; i < a.total_bins; i += kBlock) {
-            s_hist[i] = a.hist[i];
-            s_thr[i] = a.thr[i];
+        for (uint32_t i = threadIdx.x; i < wd.bin_cnt; i += kBlock) {
+            s_hist[i] = a.hist[wd.bin_lo + i];
+            s_thr[i] = a.thr[wd.bin_lo + i];
         }
     }
     __syncthreads();
@@ -380,6 +398,7 @@ __global__ __launch_bounds__(kBlock, SVT_MIN_WAVES) void svt_genotype_kernel(con
     if (tile_idx >= a.n_tiles) return;
 
     const TileDesc td = a.tiles[tile_idx];
+    if (td.lane_base == kPadUnit) return;   // padding of the last workgroup
     const LaneHdr h = a.hdr[td.lane_base + lane];
     const uint32_t svtype = h.packed & 0xffu;
     const uint32_t uflags = (h.packed >> 8) & 0xffu;
@@ -396,6 +415,8 @@ __global__ __launch_bounds__(kBlock, SVT_MIN_WAVES) void svt_genotype_kernel(con
     c.del16 = c.is_del ? 16u : 0u;
     c.var_length = h.var_length;
     c.pos_delta_d = (double)h.pos_delta;
+    c.lib_lo = wd.lib_lo;
+    c.bin_lo = wd.bin_lo;
     {
         const bool small_del = c.is_del && (c.pos_delta_d < a.lib0.sd2);  // classic.py:339,383
         c.fmask = small_del ? 0u : 7u;
@@ -534,19 +555,21 @@ __device__ __forceinline__ bool has_pair_entry(const uint4 w) { return (w.w & 7u
 __device__ __forceinline__ bool has_weight_entry(const uint4 w) { return ((w.y >> 16) | w.z) != 0u; }
 
 // one thread per unit: validate the record contract of include/svtyper_hip.h and count the entries
-// of the two sparse streams
+// of the two sparse streams and the range of libraries the unit references
 __global__ __launch_bounds__(kBlock) void svt_scan_kernel(const uint4* __restrict__ csr,
                                                           const uint64_t* __restrict__ rec_offset,
                                                           uint64_t n_units, uint32_t n_libs,
-                                                          uint2* __restrict__ counts, uint32_t* err)
+                                                          uint4* __restrict__ counts, uint32_t* err)
 {
     const uint64_t u = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
     if (u >= n_units) return;
     const uint64_t lo = rec_offset[u], hi = rec_offset[u + 1];
-    uint32_t np = 0, nq = 0, bad = 0;
+    uint32_t np = 0, nq = 0, bad = 0, lib_min = 0xffu, lib_max = 0u;
     for (uint64_t j = lo; j < hi; ++j) {
         const uint4 w = csr[j];
         const uint32_t f = w.w;
+        lib_min = min(lib_min, SVT_REC_LIB(f));
+        lib_max = max(lib_max, SVT_REC_LIB(f));
         if (!(f & SVT_REC_HAS_PAIR) &&
             (f & (SVT_REC_ALT_STRADDLE | SVT_REC_REF_STRADDLE_A | SVT_REC_REF_STRADDLE_B))) bad |= 2u;
         if (SVT_REC_LIB(f) >= n_libs) bad |= 4u;
@@ -555,7 +578,8 @@ __global__ __launch_bounds__(kBlock) void svt_scan_kernel(const uint4* __restric
         np += has_pair_entry(w) ? 1u : 0u;
         nq += has_weight_entry(w) ? 1u : 0u;
     }
-    counts[u] = make_uint2(np, nq);
+    if (lo == hi) lib_min = 0u;
+    counts[u] = make_uint4(np, nq, lib_min, lib_max);
     if (bad) atomicOr(err, bad);
 }
 
@@ -778,6 +802,7 @@ int build_tables(const svt_evidence_batch* in, uint64_t max_records_per_unit, Ho
 // ------------------------------------------------------------------------------------------
 struct Tiling {
     std::vector<TileDesc> tiles;       // storage order
+    std::vector<uint32_t> tile_lib_lo, tile_lib_hi;  // library range referenced by each tile
     std::vector<LaneHdr> hdr;
     std::vector<uint64_t> lane_src;
     std::vector<uint32_t> lane_nrec;
@@ -787,7 +812,8 @@ struct Tiling {
 // Sort units by stream length inside chunks, cut into 64-unit tiles.  len_a/len_b are the per-unit
 // row counts of the two streams (dense layout: len_a = F, len_b = 0).
 void build_tiling(const svt_evidence_batch* in, const std::vector<uint32_t>& nrec,
-                  const std::vector<uint32_t>& len_a, const std::vector<uint32_t>& len_b, Tiling& G)
+                  const std::vector<uint32_t>& len_a, const std::vector<uint32_t>& len_b,
+                  const std::vector<uint4>& scan, Tiling& G)
 {
     const uint64_t n = in->n_units;
     G.hdr.reserve(n + kWave);
@@ -797,7 +823,11 @@ void build_tiling(const svt_evidence_batch* in, const std::vector<uint32_t>& nre
     for (uint64_t c0 = 0; c0 < n; c0 += kChunkUnits) {
         const uint32_t cn = (uint32_t)std::min<uint64_t>(kChunkUnits, n - c0);
         for (uint32_t i = 0; i < cn; ++i) order[i] = i;
+        // by first library (keeps the units of one sample together so a workgroup's library window
+        // stays small), then longest first
         std::stable_sort(order.begin(), order.begin() + cn, [&](uint32_t x, uint32_t y) {
+            const uint32_t lx = scan[c0 + x].z, ly = scan[c0 + y].z;
+            if (lx != ly) return lx < ly;
             const uint64_t kx = ((uint64_t)len_a[c0 + x] << 32) | len_b[c0 + x];
             const uint64_t ky = ((uint64_t)len_a[c0 + y] << 32) | len_b[c0 + y];
             return kx > ky;
@@ -805,6 +835,7 @@ void build_tiling(const svt_evidence_batch* in, const std::vector<uint32_t>& nre
         for (uint32_t t0 = 0; t0 < cn; t0 += kWave) {
             TileDesc td{};
             td.lane_base = (uint32_t)G.hdr.size();
+            uint32_t lib_lo = 0xffffffffu, lib_hi = 0;
             for (uint32_t l = 0; l < (uint32_t)kWave; ++l) {
                 LaneHdr h{};
                 uint64_t src = 0;
@@ -820,6 +851,10 @@ void build_tiling(const svt_evidence_batch* in, const std::vector<uint32_t>& nre
                     f = nrec[u];
                     td.rows_a = std::max(td.rows_a, len_a[u]);
                     td.rows_b = std::max(td.rows_b, len_b[u]);
+                    if (f) {
+                        lib_lo = std::min(lib_lo, scan[u].z);
+                        lib_hi = std::max(lib_hi, scan[u].w);
+                    }
                 } else {
                     h.unit = kPadUnit;
                 }
@@ -831,6 +866,8 @@ void build_tiling(const svt_evidence_batch* in, const std::vector<uint32_t>& nre
             td.base_b = G.slots + (uint64_t)td.rows_a * kWave;
             G.slots += (uint64_t)(td.rows_a + td.rows_b) * kWave;
             G.tiles.push_back(td);
+            G.tile_lib_lo.push_back(lib_lo == 0xffffffffu ? 0u : lib_lo);
+            G.tile_lib_hi.push_back(lib_lo == 0xffffffffu ? 0u : lib_hi);
         }
     }
 }
@@ -860,6 +897,7 @@ struct svt_batch {
     uint32_t* d_hist = nullptr;
     int32_t* d_thr = nullptr;
     PairWeights* d_wtab = nullptr;
+    WgDesc* d_wg = nullptr;
     svt_result* d_out = nullptr;
     KernelArgs args{};
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -873,7 +911,7 @@ void free_batch(svt_batch* b)
     (void)hipSetDevice(b->device);
     auto F = [](void* p) { if (p) (void)hipFree(p); };
     F(b->d_tiled); F(b->d_tiles); F(b->d_hdr); F(b->d_pm); F(b->d_l10); F(b->d_libs);
-    F(b->d_hist); F(b->d_thr); F(b->d_wtab); F(b->d_out);
+    F(b->d_hist); F(b->d_thr); F(b->d_wtab); F(b->d_wg); F(b->d_out);
     if (b->ev0) (void)hipEventDestroy(b->ev0);
     if (b->ev1) (void)hipEventDestroy(b->ev1);
     if (b->stream) (void)hipStreamDestroy(b->stream);
@@ -970,17 +1008,17 @@ int create_on_device(const svt_evidence_batch* in, svt_batch* b)
     if (n_rec) HIP_TRY(hipMemcpyAsync(d_csr.p, in->records, n_rec * sizeof(uint4), hipMemcpyHostToDevice, b->stream));
     SVT_TRY(d_off.alloc((n + 1) * sizeof(uint64_t)));
     if (n) HIP_TRY(hipMemcpyAsync(d_off.p, in->rec_offset, (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, b->stream));
-    SVT_TRY(d_counts.alloc(n * sizeof(uint2)));
+    SVT_TRY(d_counts.alloc(n * sizeof(uint4)));
     SVT_TRY(d_err.alloc(sizeof(uint32_t)));
     HIP_TRY(hipMemsetAsync(d_err.p, 0, sizeof(uint32_t), b->stream));
-    std::vector<uint2> counts(n);
+    std::vector<uint4> counts(n);
     uint32_t err_bits = 0;
     if (n) {
         hipLaunchKernelGGL(svt_scan_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, b->stream,
-                           d_csr.as<uint4>(), d_off.as<uint64_t>(), n, in->n_libs, d_counts.as<uint2>(),
+                           d_csr.as<uint4>(), d_off.as<uint64_t>(), n, in->n_libs, d_counts.as<uint4>(),
                            d_err.as<uint32_t>());
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(counts.data(), d_counts.p, n * sizeof(uint2), hipMemcpyDeviceToHost, b->stream));
+        HIP_TRY(hipMemcpyAsync(counts.data(), d_counts.p, n * sizeof(uint4), hipMemcpyDeviceToHost, b->stream));
     }
     HIP_TRY(hipMemcpyAsync(&err_bits, d_err.p, sizeof(uint32_t), hipMemcpyDeviceToHost, b->stream));
     HIP_TRY(hipStreamSynchronize(b->stream));
@@ -1005,15 +1043,49 @@ int create_on_device(const svt_evidence_batch* in, svt_batch* b)
         }
     }
     Tiling G;
-    build_tiling(in, nrec, len_a, len_b, G);
+    build_tiling(in, nrec, len_a, len_b, counts, G);
     if (G.tiles.size() > 0xFFFFFFF0ull / kWave) return fail(SVT_ERR_INVALID, "too many tiles");
     b->n_tiles = (uint32_t)G.tiles.size();
     b->slots = G.slots;
-    // dispatch order: longest tiles first (LPT) so the tail of the grid is made of short tiles
-    std::vector<TileDesc> dispatch = G.tiles;
-    std::stable_sort(dispatch.begin(), dispatch.end(), [](const TileDesc& x, const TileDesc& y) {
-        return x.rows_a + x.rows_b > y.rows_a + y.rows_b;
-    });
+    // dispatch order: tiles stay in groups of 4 consecutive (= one workgroup, similar length, same
+    // libraries); the groups go longest first (LPT) so the tail of the grid is made of short tiles
+    const uint32_t n_groups = (b->n_tiles + kWavesPerBlock - 1) / kWavesPerBlock;
+    std::vector<uint32_t> group_order(n_groups);
+    std::vector<uint64_t> group_cost(n_groups, 0);
+    for (uint32_t g = 0; g < n_groups; ++g) {
+        group_order[g] = g;
+        for (uint32_t t = g * kWavesPerBlock; t < std::min(b->n_tiles, (g + 1) * kWavesPerBlock); ++t)
+            group_cost[g] += G.tiles[t].rows_a + G.tiles[t].rows_b;
+    }
+    std::stable_sort(group_order.begin(), group_order.end(),
+                     [&](uint32_t x, uint32_t y) { return group_cost[x] > group_cost[y]; });
+    std::vector<TileDesc> dispatch;
+    std::vector<WgDesc> windows;
+    dispatch.reserve((size_t)n_groups * kWavesPerBlock);
+    uint32_t max_win_libs = 1, max_win_bins = 1;
+    for (uint32_t g : group_order) {
+        uint32_t lo = 0xffffffffu, hi = 0;
+        for (uint32_t k = 0; k < (uint32_t)kWavesPerBlock; ++k) {
+            const uint32_t t = g * kWavesPerBlock + k;
+            if (t < b->n_tiles) {
+                dispatch.push_back(G.tiles[t]);
+                lo = std::min(lo, G.tile_lib_lo[t]);
+                hi = std::max(hi, G.tile_lib_hi[t]);
+            } else {
+                TileDesc pad{};
+                pad.lane_base = kPadUnit;          // marks a tile that does not exist
+                dispatch.push_back(pad);
+            }
+        }
+        WgDesc w{};
+        w.lib_lo = lo;
+        w.lib_cnt = hi - lo + 1;
+        w.bin_lo = T.libs[lo].tab_off;
+        w.bin_cnt = T.libs[hi].tab_off + T.libs[hi].n_bins + 1 - w.bin_lo;
+        windows.push_back(w);
+        max_win_libs = std::max(max_win_libs, w.lib_cnt);
+        max_win_bins = std::max(max_win_bins, w.bin_cnt);
+    }
 
     // ---- resident device objects
     DevScratch d_tiles_store, d_lane_src, d_lane_nrec;
@@ -1028,6 +1100,7 @@ int create_on_device(const svt_evidence_batch* in, svt_batch* b)
     SVT_TRY(upload(&b->d_hist, T.hist, b->stream));
     SVT_TRY(upload(&b->d_thr, T.thr, b->stream));
     SVT_TRY(upload(&b->d_wtab, T.wtab, b->stream));
+    SVT_TRY(upload(&b->d_wg, windows, b->stream));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&b->d_tiled), (G.slots + kTailPadRows * kWave) * sizeof(uint4)));
     HIP_TRY(hipMemsetAsync(b->d_tiled + G.slots, 0, kTailPadRows * kWave * sizeof(uint4), b->stream));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&b->d_out), std::max<uint64_t>(n, 1) * sizeof(svt_result)));
@@ -1062,19 +1135,28 @@ int create_on_device(const svt_evidence_batch* in, svt_batch* b)
     a.n_l10 = (uint32_t)T.l10.size();
     a.n_libs = in->n_libs;
     a.total_bins = (uint32_t)T.hist.size();
-    a.n_tiles = b->n_tiles;
+    a.n_tiles = n_groups * kWavesPerBlock;   // the dispatch list is padded to whole workgroups
     a.l10_in_lds = a.n_l10 <= kMaxL10Lds ? 1u : 0u;
     a.n_units = n;
     a.out = b->d_out;
     a.lib0 = T.libs[0];
     fill_gt_consts(a.c, in->split_weight, in->disc_weight);
 
-    const size_t table_bytes = (size_t)a.total_bins * 8;
-    if (T.fast_geometry && table_bytes <= kMaxLdsTableBytes) b->mode = in->n_libs == 1 ? kSingleLds : kMultiLds;
-    else b->mode = kGeneral;
+    a.wg = b->d_wg;
+    // kernel flavour: tables in LDS when the 32-bit geometry holds and the largest per-workgroup
+    // library window fits the LDS budget; otherwise the general kernel reads them through L2
+    if (T.fast_geometry && (size_t)max_win_bins * 8 <= kMaxLdsTableBytes) {
+        b->mode = in->n_libs == 1 ? kSingleLds : kMultiLds;
+        a.lds_libs = in->n_libs == 1 ? 1u : max_win_libs;
+        a.lds_bins = in->n_libs == 1 ? a.total_bins : max_win_bins;
+    } else {
+        b->mode = kGeneral;
+        a.lds_libs = in->n_libs;   // descriptors only
+        a.lds_bins = 0;
+    }
     const uint32_t n_l10_lds = a.l10_in_lds ? ((a.n_l10 + 1u) & ~1u) : 0u;
     b->lds_bytes = 256 * 8 + 32 * sizeof(PairWeights) + (size_t)n_l10_lds * 8 +
-                   (size_t)in->n_libs * sizeof(LibDesc) + (b->mode != kGeneral ? table_bytes : 0);
+                   (size_t)a.lds_libs * sizeof(LibDesc) + (size_t)a.lds_bins * 8;
     b->lds_bytes = (b->lds_bytes + 15) & ~size_t(15);
     if (b->lds_bytes > 160 * 1024) return fail(SVT_ERR_INVALID, "LDS budget exceeded");
     if (b->lds_bytes > 64 * 1024)

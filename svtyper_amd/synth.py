@@ -204,11 +204,17 @@ def permute_units(batch: EvidenceBatch, order: np.ndarray) -> EvidenceBatch:
                          batch.split_weight, batch.disc_weight)
 
 
+def _multisample_part(args):
+    n_sites, seed, libs, lib_ids, s, af, frag = args
+    return make_units(n_sites, seed + 17 * (s + 1), libs, svtype_mix=(0.70, 0.15, 0.15, 0.0), sample=s,
+                      lib_choices=lib_ids, alt_af=af, **frag)
+
+
 def make_multisample(n_sites: int, n_samples: int, seed: int, libs_per_sample=(1, 3), mean_frags: float = 100.0,
-                     sd_frags: float = 25.0, min_frags: int = 18, max_frags: int = 183) -> EvidenceBatch:
+                     sd_frags: float = 25.0, min_frags: int = 18, max_frags: int = 183, pool_map=map) -> EvidenceBatch:
     """BASELINE.json configs[4] shape: (site, sample) units, site-major, every sample with its own 1..3
     libraries (rounded-normal insert-size histograms) and genotypes drawn per sample from a site allele
-    frequency ~ Beta(0.5, 2)."""
+    frequency ~ Beta(0.5, 2).  `pool_map` may be a multiprocessing Pool.map to generate samples in parallel."""
     rng = np.random.default_rng(seed)
     libs: List[LibraryTable] = []
     sample_libs = []
@@ -221,18 +227,18 @@ def make_multisample(n_sites: int, n_samples: int, seed: int, libs_per_sample=(1
                                        seed=int(rng.integers(1 << 30)), name="s%d_l%d" % (s, len(ids))))
         sample_libs.append(ids)
     af = rng.beta(0.5, 2.0, n_sites)
-    parts = []
-    for s in range(n_samples):
-        parts.append(make_units(n_sites, seed + 17 * (s + 1), libs, svtype_mix=(0.70, 0.15, 0.15, 0.0),
-                                mean_frags=mean_frags, sd_frags=sd_frags, min_frags=min_frags,
-                                max_frags=max_frags, sample=s, lib_choices=sample_libs[s], alt_af=af))
-    # the same site must have the same svtype / length in every sample: copy sample 0's unit geometry
+    frag = dict(mean_frags=mean_frags, sd_frags=sd_frags, min_frags=min_frags, max_frags=max_frags)
+    parts = list(pool_map(_multisample_part,
+                          [(n_sites, seed, libs, sample_libs[s], s, af, frag) for s in range(n_samples)]))
+    # the same site has the same svtype / length in every sample: copy sample 0's unit geometry
     for p in parts[1:]:
         for fld in ("svtype", "var_length", "pos_delta"):
             p.units[fld] = parts[0].units[fld]
     allb = ev.concat_batches(parts)
     order = (np.arange(n_sites)[:, None] + n_sites * np.arange(n_samples)[None, :]).reshape(-1)
-    return permute_units(allb, order)
+    out = permute_units(allb, order)
+    out.libs = libs
+    return out
 
 
 def make_edge_cases(libs: Sequence[LibraryTable], seed: int = 1) -> EvidenceBatch:
