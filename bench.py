@@ -140,8 +140,7 @@ def main():
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        dbatch.genotype(sync=False)
+    dbatch.genotype_n(args.steps)          # `steps` passes enqueued back to back on the batch stream
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0

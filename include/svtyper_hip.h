@@ -207,6 +207,10 @@ int svt_batch_create(const svt_evidence_batch* in, int device, unsigned flags,
  * batch's stream unless `sync` != 0.   (classic.py:296-513)                     */
 int svt_batch_genotype(svt_batch* b, int sync);
 
+/* Enqueue `iters` back-to-back passes on the batch's stream without waiting (the caller
+ * synchronises); equivalent to `iters` calls of svt_batch_genotype(b, 0).                  */
+int svt_batch_genotype_n(svt_batch* b, int iters);
+
 /* Run `iters` back-to-back passes bracketed by HIP events on the batch's stream;
  * *ms_total receives the elapsed milliseconds of all `iters` launches.          */
 int svt_batch_genotype_timed(svt_batch* b, int iters, float* ms_total);

@@ -33,9 +33,11 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -972,11 +974,25 @@ int launch_genotype(svt_batch* b)
     return SVT_OK;
 }
 
+// SVT_TRACE=1 in the environment prints the stage times of svt_batch_create to stderr
+struct StageTimer {
+    bool on = std::getenv("SVT_TRACE") != nullptr;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    void mark(const char* what)
+    {
+        if (!on) return;
+        const auto t1 = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[svt] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    }
+};
+
 // everything of svt_batch_create that needs the device; `b` is freed by the caller on failure
 int create_on_device(const svt_evidence_batch* in, svt_batch* b)
 {
     const uint64_t n = in->n_units;
     const uint64_t n_rec = n ? in->rec_offset[n] : 0;
+    StageTimer tm;
 
     // ---- per-unit record counts + validation of the CSR
     std::vector<uint32_t> nrec(n);
@@ -994,9 +1010,11 @@ int create_on_device(const svt_evidence_batch* in, svt_batch* b)
         max_f = std::max(max_f, f);
     }
 
+    tm.mark("validate units");
     HostTables T;
     SVT_TRY(build_tables(in, max_f, T));
     if (wide_var_length) T.fast_geometry = false;
+    tm.mark("build tables");
 
     HIP_TRY(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreate(&b->ev0));
@@ -1022,6 +1040,7 @@ int create_on_device(const svt_evidence_batch* in, svt_batch* b)
     }
     HIP_TRY(hipMemcpyAsync(&err_bits, d_err.p, sizeof(uint32_t), hipMemcpyDeviceToHost, b->stream));
     HIP_TRY(hipStreamSynchronize(b->stream));
+    tm.mark("H2D records + scan kernel");
     if (err_bits) {
         std::string m = "invalid evidence records:";
         if (err_bits & 2u) m += " straddle bits without HAS_PAIR;";
@@ -1087,6 +1106,7 @@ int create_on_device(const svt_evidence_batch* in, svt_batch* b)
         max_win_bins = std::max(max_win_bins, w.bin_cnt);
     }
 
+    tm.mark("tiling (host sort)");
     // ---- resident device objects
     DevScratch d_tiles_store, d_lane_src, d_lane_nrec;
     SVT_TRY(upload(&b->d_tiles, dispatch, b->stream));
@@ -1120,6 +1140,7 @@ int create_on_device(const svt_evidence_batch* in, svt_batch* b)
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipStreamSynchronize(b->stream));  // scratch buffers are released on return
+    tm.mark("uploads + repack kernel");
 
     // ---- kernel arguments
     KernelArgs& a = b->args;
@@ -1227,6 +1248,15 @@ int svt_batch_genotype(svt_batch* b, int sync)
     SVT_TRY(launch_genotype(b));
     b->have_results = true;
     if (sync) HIP_TRY(hipStreamSynchronize(b->stream));
+    return SVT_OK;
+}
+
+int svt_batch_genotype_n(svt_batch* b, int iters)
+{
+    if (!b || iters <= 0) return fail(SVT_ERR_INVALID, "bad arguments");
+    HIP_TRY(hipSetDevice(b->device));
+    for (int i = 0; i < iters; ++i) SVT_TRY(launch_genotype(b));
+    b->have_results = true;
     return SVT_OK;
 }
 

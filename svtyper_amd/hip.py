@@ -18,7 +18,7 @@ ABI_VERSION = 2
 
 EXPORTS = (
     "svt_version", "svt_device_count", "svt_last_error", "svt_batch_create", "svt_batch_genotype",
-    "svt_batch_genotype_timed", "svt_batch_results", "svt_batch_device_results",
+    "svt_batch_genotype_n", "svt_batch_genotype_timed", "svt_batch_results", "svt_batch_device_results",
     "svt_batch_bind_device_results", "svt_batch_bytes",
     "svt_batch_stream", "svt_batch_destroy", "svt_bayes_gt", "svt_genotype",
 )
@@ -58,6 +58,8 @@ def load() -> C.CDLL:
     L.svt_batch_create.argtypes = [C.POINTER(CEvidenceBatch), C.c_int, C.c_uint, C.POINTER(C.c_void_p)]
     L.svt_batch_genotype.restype = C.c_int
     L.svt_batch_genotype.argtypes = [C.c_void_p, C.c_int]
+    L.svt_batch_genotype_n.restype = C.c_int
+    L.svt_batch_genotype_n.argtypes = [C.c_void_p, C.c_int]
     L.svt_batch_genotype_timed.restype = C.c_int
     L.svt_batch_genotype_timed.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float)]
     L.svt_batch_results.restype = C.c_int
@@ -106,6 +108,10 @@ class DeviceBatch:
 
     def genotype(self, sync: bool = True):
         _check(self._lib.svt_batch_genotype(self._h, int(sync)))
+
+    def genotype_n(self, iters: int):
+        """Enqueue `iters` passes on the batch stream without waiting."""
+        _check(self._lib.svt_batch_genotype_n(self._h, int(iters)))
 
     def genotype_timed(self, iters: int) -> float:
         """Elapsed milliseconds (HIP events on the batch stream) of `iters` passes."""
