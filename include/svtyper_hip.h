@@ -238,6 +238,10 @@ void* svt_batch_stream(svt_batch* b);
 
 void svt_batch_destroy(svt_batch* b);
 
+/* Release the per-device scratch the library keeps between svt_batch_create calls (the device
+ * copy of the canonical records; a large hipMalloc costs ~100 ms, so it is reused).           */
+void svt_trim(void);
+
 /* Array form of the reference's inner operator seam statistics.bayes_gt(ref, alt, is_dup)
  * (svtyper/statistics.py:23-37) and log_choose(ref + alt, alt) (statistics.py:9-20):
  * out[4*i .. 4*i+3] = { lp_homref, lp_het, lp_homalt, log_choose } for item i.  All pointers

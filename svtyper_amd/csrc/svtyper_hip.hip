@@ -39,7 +39,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/svtyper_hip.h"
@@ -811,23 +813,53 @@ struct Tiling {
     uint64_t slots = 0;                // 16-byte row slots of all tiles
 };
 
-// Sort units by stream length inside chunks, cut into 64-unit tiles.  len_a/len_b are the per-unit
-// row counts of the two streams (dense layout: len_a = F, len_b = 0).
+unsigned host_threads()
+{
+    const unsigned hc = std::thread::hardware_concurrency();
+    return std::max(1u, std::min(hc ? hc : 1u, 16u));
+}
+
+// run fn(i) for i in [0, n) on up to host_threads() threads
+template <typename Fn>
+void parallel_for(uint64_t n, Fn&& fn)
+{
+    const unsigned nt = (unsigned)std::min<uint64_t>(host_threads(), n);
+    if (nt <= 1) {
+        for (uint64_t i = 0; i < n; ++i) fn(i);
+        return;
+    }
+    std::vector<std::thread> pool;
+    for (unsigned t = 0; t < nt; ++t)
+        pool.emplace_back([&, t]() { for (uint64_t i = t; i < n; i += nt) fn(i); });
+    for (auto& th : pool) th.join();
+}
+
+// Sort units by library and stream length inside chunks, cut into 64-unit tiles.  len_a/len_b are
+// the per-unit row counts of the two streams (dense layout: len_a = F, len_b = 0).  Chunks are
+// independent and are processed by several host threads.
 void build_tiling(const svt_evidence_batch* in, const std::vector<uint32_t>& nrec,
                   const std::vector<uint32_t>& len_a, const std::vector<uint32_t>& len_b,
                   const std::vector<uint4>& scan, Tiling& G)
 {
     const uint64_t n = in->n_units;
-    G.hdr.reserve(n + kWave);
-    G.lane_src.reserve(n + kWave);
-    G.lane_nrec.reserve(n + kWave);
-    std::vector<uint32_t> order(kChunkUnits);
-    for (uint64_t c0 = 0; c0 < n; c0 += kChunkUnits) {
+    const uint64_t n_chunks = (n + kChunkUnits - 1) / kChunkUnits;
+    const uint64_t tiles_per_chunk = kChunkUnits / kWave;
+    const uint64_t n_tiles = n ? (n_chunks - 1) * tiles_per_chunk +
+                                     ((n - (n_chunks - 1) * kChunkUnits) + kWave - 1) / kWave : 0;
+    G.tiles.assign(n_tiles, TileDesc{});
+    G.tile_lib_lo.assign(n_tiles, 0);
+    G.tile_lib_hi.assign(n_tiles, 0);
+    G.hdr.assign(n_tiles * kWave, LaneHdr{});
+    G.lane_src.assign(n_tiles * kWave, 0);
+    G.lane_nrec.assign(n_tiles * kWave, 0);
+    parallel_for(n_chunks, [&](uint64_t c) {
+        const uint64_t c0 = c * kChunkUnits;
         const uint32_t cn = (uint32_t)std::min<uint64_t>(kChunkUnits, n - c0);
+        std::vector<uint32_t> order(cn);
         for (uint32_t i = 0; i < cn; ++i) order[i] = i;
         // by first library (keeps the units of one sample together so a workgroup's library window
         // stays small), then longest first
-        std::stable_sort(order.begin(), order.begin() + cn, [&](uint32_t x, uint32_t y) {
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
             const uint32_t lx = scan[c0 + x].z, ly = scan[c0 + y].z;
             if (lx != ly) return lx < ly;
             const uint64_t kx = ((uint64_t)len_a[c0 + x] << 32) | len_b[c0 + x];
@@ -835,11 +867,13 @@ void build_tiling(const svt_evidence_batch* in, const std::vector<uint32_t>& nre
             return kx > ky;
         });
         for (uint32_t t0 = 0; t0 < cn; t0 += kWave) {
+            const uint64_t ti = c * tiles_per_chunk + t0 / kWave;
             TileDesc td{};
-            td.lane_base = (uint32_t)G.hdr.size();
+            td.lane_base = (uint32_t)(ti * kWave);
             uint32_t lib_lo = 0xffffffffu, lib_hi = 0;
             for (uint32_t l = 0; l < (uint32_t)kWave; ++l) {
                 LaneHdr h{};
+                h.unit = kPadUnit;
                 uint64_t src = 0;
                 uint32_t f = 0;
                 if (t0 + l < cn) {
@@ -857,21 +891,150 @@ void build_tiling(const svt_evidence_batch* in, const std::vector<uint32_t>& nre
                         lib_lo = std::min(lib_lo, scan[u].z);
                         lib_hi = std::max(lib_hi, scan[u].w);
                     }
-                } else {
-                    h.unit = kPadUnit;
                 }
-                G.hdr.push_back(h);
-                G.lane_src.push_back(src);
-                G.lane_nrec.push_back(f);
+                G.hdr[td.lane_base + l] = h;
+                G.lane_src[td.lane_base + l] = src;
+                G.lane_nrec[td.lane_base + l] = f;
             }
-            td.base_a = G.slots;
-            td.base_b = G.slots + (uint64_t)td.rows_a * kWave;
-            G.slots += (uint64_t)(td.rows_a + td.rows_b) * kWave;
-            G.tiles.push_back(td);
-            G.tile_lib_lo.push_back(lib_lo == 0xffffffffu ? 0u : lib_lo);
-            G.tile_lib_hi.push_back(lib_lo == 0xffffffffu ? 0u : lib_hi);
+            G.tiles[ti] = td;
+            G.tile_lib_lo[ti] = lib_lo == 0xffffffffu ? 0u : lib_lo;
+            G.tile_lib_hi[ti] = lib_lo == 0xffffffffu ? 0u : lib_hi;
         }
+    });
+    // slot offsets: a tile's pair rows, then its weight rows
+    for (TileDesc& td : G.tiles) {
+        td.base_a = G.slots;
+        td.base_b = G.slots + (uint64_t)td.rows_a * kWave;
+        G.slots += (uint64_t)(td.rows_a + td.rows_b) * kWave;
     }
+}
+
+// Device scratch for the canonical records of the batch being created: a 1.6 GB hipMalloc costs
+// ~100 ms, so the buffer is kept per device between calls (grow-only; svt_trim() releases it).
+struct CsrScratchCache {
+    static constexpr int kMaxDevices = 64;
+    void* ptr[kMaxDevices] = {};
+    uint64_t cap[kMaxDevices] = {};
+    std::mutex lock;   // held for the whole svt_batch_create of a device-sharing caller
+    int acquire(int device, uint64_t bytes, void** out)
+    {
+        if (device >= kMaxDevices) return fail(SVT_ERR_INVALID, "device index too large for the scratch cache");
+        if (cap[device] < bytes) {
+            if (ptr[device]) (void)hipFree(ptr[device]);
+            ptr[device] = nullptr;
+            cap[device] = 0;
+            const uint64_t want = bytes + bytes / 8;   // a little slack for the next, slightly larger batch
+            HIP_TRY(hipMalloc(&ptr[device], want));
+            cap[device] = want;
+        }
+        *out = ptr[device];
+        return SVT_OK;
+    }
+    void trim()
+    {
+        std::lock_guard<std::mutex> g(lock);
+        for (int d = 0; d < kMaxDevices; ++d)
+            if (ptr[d]) {
+                (void)hipSetDevice(d);
+                (void)hipFree(ptr[d]);
+                ptr[d] = nullptr;
+                cap[d] = 0;
+            }
+    }
+};
+CsrScratchCache g_csr_cache;
+
+// Pinned staging ring shared by all batches of the process (allocated on first use, per device
+// context of the first caller; pinned host memory is usable from every device).
+struct StagingRing {
+    static constexpr uint64_t kPiece = 64ull << 20;
+    static constexpr int kSlots = 3;
+    void* buf[kSlots] = {nullptr, nullptr, nullptr};
+    std::mutex lock;
+    int ensure()
+    {
+        for (int i = 0; i < kSlots; ++i)
+            if (!buf[i] && hipHostMalloc(&buf[i], kPiece, hipHostMallocDefault) != hipSuccess)
+                return fail(SVT_ERR_HIP, "hipHostMalloc of the pinned staging ring failed");
+        return SVT_OK;
+    }
+};
+StagingRing g_ring;
+
+// Host -> device copy of a large pageable buffer through the pinned ring: a few host threads fill
+// one piece while the previous piece is on the wire (a first hipMemcpy of pageable memory stages at
+// ~13 GB/s on this platform; pinned pieces move at ~56 GB/s, tools/h2d_probe.hip).
+int h2d_staged(void* dst, const void* src, uint64_t bytes, hipStream_t stream)
+{
+    if (bytes < (16ull << 20)) {
+        if (bytes) HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream));
+        return SVT_OK;
+    }
+    std::lock_guard<std::mutex> guard(g_ring.lock);
+    SVT_TRY(g_ring.ensure());
+    hipEvent_t done[StagingRing::kSlots] = {nullptr, nullptr, nullptr};
+    int rc = SVT_OK;
+    for (int i = 0; i < StagingRing::kSlots && rc == SVT_OK; ++i)
+        if (hipEventCreateWithFlags(&done[i], hipEventDisableTiming) != hipSuccess) rc = fail(SVT_ERR_HIP, "hipEventCreate");
+    const unsigned nt = std::min(host_threads(), 6u);   // 4-8 threads saturate the host copy
+    uint64_t off = 0;
+    for (int slot = 0; rc == SVT_OK && off < bytes; slot = (slot + 1) % StagingRing::kSlots) {
+        const uint64_t len = std::min(StagingRing::kPiece, bytes - off);
+        if (hipEventSynchronize(done[slot]) != hipSuccess) { rc = fail(SVT_ERR_HIP, "staging event"); break; }
+        const char* s0 = static_cast<const char*>(src) + off;
+        char* p0 = static_cast<char*>(g_ring.buf[slot]);
+        const uint64_t part = ((len + nt - 1) / nt + 4095) & ~uint64_t(4095);
+        parallel_for(nt, [&](uint64_t t) {
+            const uint64_t lo = t * part, hi = std::min(len, lo + part);
+            if (lo < hi) std::memcpy(p0 + lo, s0 + lo, hi - lo);
+        });
+        if (hipMemcpyAsync(static_cast<char*>(dst) + off, p0, len, hipMemcpyHostToDevice, stream) != hipSuccess ||
+            hipEventRecord(done[slot], stream) != hipSuccess) { rc = fail(SVT_ERR_HIP, "staged hipMemcpyAsync"); break; }
+        off += len;
+    }
+    (void)hipStreamSynchronize(stream);   // the ring is reusable once the last piece has left
+    for (int i = 0; i < StagingRing::kSlots; ++i)
+        if (done[i]) (void)hipEventDestroy(done[i]);
+    return rc;
+}
+
+// Device -> host through the same pinned ring (results: 128 B per unit).
+int d2h_staged(void* dst, const void* src, uint64_t bytes, hipStream_t stream)
+{
+    if (bytes < (16ull << 20)) {
+        if (bytes) HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        return SVT_OK;
+    }
+    std::lock_guard<std::mutex> guard(g_ring.lock);
+    SVT_TRY(g_ring.ensure());
+    const unsigned nt = std::min(host_threads(), 6u);
+    // piece k is copied out of its slot while piece k + 1 is on the wire
+    uint64_t off = 0, prev_off = 0, prev_len = 0;
+    int slot = 0, prev_slot = -1;
+    while (off < bytes || prev_slot >= 0) {
+        uint64_t len = 0;
+        if (off < bytes) {
+            len = std::min(StagingRing::kPiece, bytes - off);
+            HIP_TRY(hipMemcpyAsync(g_ring.buf[slot], static_cast<const char*>(src) + off, len, hipMemcpyDeviceToHost, stream));
+        }
+        if (prev_slot >= 0) {
+            const char* p0 = static_cast<const char*>(g_ring.buf[prev_slot]);
+            char* d0 = static_cast<char*>(dst) + prev_off;
+            const uint64_t part = ((prev_len + nt - 1) / nt + 4095) & ~uint64_t(4095);
+            parallel_for(nt, [&](uint64_t t) {
+                const uint64_t lo = t * part, hi = std::min(prev_len, lo + part);
+                if (lo < hi) std::memcpy(d0 + lo, p0 + lo, hi - lo);
+            });
+        }
+        HIP_TRY(hipStreamSynchronize(stream));
+        prev_slot = len ? slot : -1;
+        prev_off = off;
+        prev_len = len;
+        off += len;
+        slot = (slot + 1) % 2;
+    }
+    return SVT_OK;
 }
 
 }  // namespace
@@ -1021,9 +1184,14 @@ int create_on_device(const svt_evidence_batch* in, svt_batch* b)
     HIP_TRY(hipEventCreate(&b->ev1));
 
     // ---- canonical records to the device; validate them and count the sparse-stream entries
-    DevScratch d_csr, d_off, d_counts, d_err;
-    SVT_TRY(d_csr.alloc(n_rec * sizeof(uint4)));
-    if (n_rec) HIP_TRY(hipMemcpyAsync(d_csr.p, in->records, n_rec * sizeof(uint4), hipMemcpyHostToDevice, b->stream));
+    DevScratch d_off, d_counts, d_err;
+    std::lock_guard<std::mutex> csr_guard(g_csr_cache.lock);   // the cached scratch is ours until we return
+    void* d_csr_p = nullptr;
+    SVT_TRY(g_csr_cache.acquire(b->device, std::max<uint64_t>(n_rec, 1) * sizeof(uint4), &d_csr_p));
+    const uint4* d_csr = static_cast<const uint4*>(d_csr_p);
+    tm.mark("stream/event/alloc");
+    SVT_TRY(h2d_staged(d_csr_p, in->records, n_rec * sizeof(uint4), b->stream));
+    tm.mark("H2D records (staged)");
     SVT_TRY(d_off.alloc((n + 1) * sizeof(uint64_t)));
     if (n) HIP_TRY(hipMemcpyAsync(d_off.p, in->rec_offset, (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, b->stream));
     SVT_TRY(d_counts.alloc(n * sizeof(uint4)));
@@ -1033,14 +1201,14 @@ int create_on_device(const svt_evidence_batch* in, svt_batch* b)
     uint32_t err_bits = 0;
     if (n) {
         hipLaunchKernelGGL(svt_scan_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, b->stream,
-                           d_csr.as<uint4>(), d_off.as<uint64_t>(), n, in->n_libs, d_counts.as<uint4>(),
+                           d_csr, d_off.as<uint64_t>(), n, in->n_libs, d_counts.as<uint4>(),
                            d_err.as<uint32_t>());
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(counts.data(), d_counts.p, n * sizeof(uint4), hipMemcpyDeviceToHost, b->stream));
     }
     HIP_TRY(hipMemcpyAsync(&err_bits, d_err.p, sizeof(uint32_t), hipMemcpyDeviceToHost, b->stream));
     HIP_TRY(hipStreamSynchronize(b->stream));
-    tm.mark("H2D records + scan kernel");
+    tm.mark("scan kernel + counts D2H");
     if (err_bits) {
         std::string m = "invalid evidence records:";
         if (err_bits & 2u) m += " straddle bits without HAS_PAIR;";
@@ -1128,7 +1296,7 @@ int create_on_device(const svt_evidence_batch* in, svt_batch* b)
     // ---- re-tile on the device
     if (b->n_tiles) {
         RepackArgs ra{};
-        ra.csr = d_csr.as<uint4>();
+        ra.csr = d_csr;
         ra.lane_src = d_lane_src.as<uint64_t>();
         ra.lane_nrec = d_lane_nrec.as<uint32_t>();
         ra.tiles = d_tiles_store.as<TileDesc>();
@@ -1279,10 +1447,8 @@ int svt_batch_results(svt_batch* b, svt_result* out, uint64_t n_units)
     if (!b->have_results) return fail(SVT_ERR_STATE, "svt_batch_genotype has not run");
     if (n_units != b->n_units) return fail(SVT_ERR_INVALID, "results n_units mismatch");
     HIP_TRY(hipSetDevice(b->device));
-    if (b->n_units)
-        HIP_TRY(hipMemcpyAsync(out, b->args.out, b->n_units * sizeof(svt_result), hipMemcpyDeviceToHost, b->stream));
-    HIP_TRY(hipStreamSynchronize(b->stream));
-    return SVT_OK;
+    HIP_TRY(hipStreamSynchronize(b->stream));   // the pass that produced the records
+    return d2h_staged(out, b->args.out, b->n_units * sizeof(svt_result), b->stream);
 }
 
 int svt_batch_device_results(svt_batch* b, svt_result** dev)
@@ -1350,6 +1516,8 @@ int svt_bayes_gt(const int32_t* ref, const int32_t* alt, const uint8_t* is_dup, 
 void* svt_batch_stream(svt_batch* b) { return b ? (void*)b->stream : nullptr; }
 
 void svt_batch_destroy(svt_batch* b) { free_batch(b); }
+
+void svt_trim(void) { g_csr_cache.trim(); }
 
 int svt_genotype(const svt_evidence_batch* in, svt_result* out, int device, unsigned flags)
 {

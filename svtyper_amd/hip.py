@@ -20,7 +20,7 @@ EXPORTS = (
     "svt_version", "svt_device_count", "svt_last_error", "svt_batch_create", "svt_batch_genotype",
     "svt_batch_genotype_n", "svt_batch_genotype_timed", "svt_batch_results", "svt_batch_device_results",
     "svt_batch_bind_device_results", "svt_batch_bytes",
-    "svt_batch_stream", "svt_batch_destroy", "svt_bayes_gt", "svt_genotype",
+    "svt_batch_stream", "svt_batch_destroy", "svt_trim", "svt_bayes_gt", "svt_genotype",
 )
 
 _lib: Optional[C.CDLL] = None
@@ -74,6 +74,7 @@ def load() -> C.CDLL:
     L.svt_batch_stream.argtypes = [C.c_void_p]
     L.svt_batch_destroy.restype = None
     L.svt_batch_destroy.argtypes = [C.c_void_p]
+    L.svt_trim.restype = None
     L.svt_bayes_gt.restype = C.c_int
     L.svt_bayes_gt.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int]
     L.svt_genotype.restype = C.c_int
@@ -88,6 +89,11 @@ def _check(rc: int):
     if rc != 0:
         msg = load().svt_last_error()
         raise SvtyperHipError("svtyper_hip error %d: %s" % (rc, msg.decode() if msg else ""))
+
+
+def trim():
+    """Release the device scratch cached between batch creations (svt_trim)."""
+    load().svt_trim()
 
 
 def device_count() -> int:
