@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SVT_ABI_VERSION 2
+#define SVT_ABI_VERSION 3
 
 /* ---- error codes (0 = ok, <0 = error; text via svt_last_error()) ---------- */
 #define SVT_OK 0
@@ -151,6 +151,78 @@ typedef struct svt_evidence_batch {
     double disc_weight;         /* --disc_weight  (classic.py:39)                 */
 } svt_evidence_batch;
 
+/* =====================================================================================
+ * Geometry stage on the device: breakpoint-dependent predicates of
+ * svtyper/parsers.py -- is_ref_seq :801-816, is_pair_straddle :821-857, get_ispan/ospan
+ * :785-796, check_split_support :1122-1134, is_split_straddle :1136-1215 -- evaluated by
+ * svt_geometry_kernel on fixed-size, breakpoint-independent fragment summaries, producing
+ * the svt_record array above (one record per summary, same order).
+ * ===================================================================================== */
+
+/* one primary read of a fragment, 32 B */
+typedef struct svt_read_summary {
+    int32_t tid;        /* reference id of the read (index into the BAM header), -1 when absent */
+    int32_t start;      /* reference_start                                                      */
+    int32_t end;        /* reference_end (start + reference-consuming CIGAR ops)                */
+    int32_t iv_start[2];/* up to two maximal reference intervals covered without a D/N gap by   */
+    int32_t iv_end[2];  /* M/=/X operations (an insertion does not break an interval); a read   */
+                        /* with more intervals keeps the two nearest to the unit's breakends    */
+    uint8_t mapq;
+    uint8_t flags;      /* SVT_READ_* */
+    uint16_t reserved;
+} svt_read_summary;
+#define SVT_READ_PRESENT (1u << 0)
+#define SVT_READ_REVERSE (1u << 1)
+
+/* one piece of a split-read candidate (parsers.py:902-950), 16 B */
+typedef struct svt_piece_summary {
+    int32_t tid;        /* -2 for the dummy piece of a soft-clip-only candidate (chrom None)    */
+    int32_t start;      /* reference_start */
+    int32_t end;        /* reference_end   */
+    uint8_t mapq;
+    uint8_t flags;      /* SVT_READ_PRESENT (candidate exists), SVT_READ_REVERSE                */
+    uint16_t reserved;
+} svt_piece_summary;
+
+/* one read-fragment (query name) of a unit, 128 B.  A fragment with more than two primaries, or
+ * with two split candidates of the same kind, continues in a following summary that has
+ * SVT_FRAG_CONTINUATION set (host side: svtyper_amd/geometry.py).                              */
+typedef struct svt_fragment {
+    svt_read_summary read[2];   /* primary_reads[0], primary_reads[1] (parsers.py:756-768)      */
+    svt_piece_summary seq[2];   /* valid non-soft-clip candidate: query_left, query_right        */
+    svt_piece_summary clip[2];  /* valid soft-clip-only candidate: query_left, query_right       */
+} svt_fragment;
+/* fragment-level bits live in read[0].reserved (low byte = library index) and read[1].reserved */
+#define SVT_FRAG_PAIR (1u << 0)         /* read[1].reserved: num_primary == 2 (parsers.py:827)   */
+#define SVT_FRAG_CONTINUATION (1u << 1) /* read[1].reserved                                       */
+
+/* one (breakpoint, sample) unit for the geometry stage, 48 B (parsers.py:149-154,190-203) */
+typedef struct svt_breakpoint {
+    int32_t tid_a, pos_a, ci_a[2];   /* side A: chromosome id, position (+1 applied on reverse   */
+    int32_t tid_b, pos_b, ci_b[2];   /* sides, classic.py:276-277), confidence interval           */
+    int32_t var_length;              /* DEL: END - POS (classic.py:268); else 0                   */
+    uint16_t sample;
+    uint8_t svtype;                  /* SVT_SVTYPE_* */
+    uint8_t flags;                   /* bit0: side A is_reverse, bit1: side B is_reverse,
+                                        bit2: SVT_UNIT_SKIP                                       */
+    uint32_t reserved[2];
+} svt_breakpoint;
+#define SVT_BP_REV_A (1u << 0)
+#define SVT_BP_REV_B (1u << 1)
+#define SVT_BP_SKIP (1u << 2)
+
+typedef struct svt_fragment_batch {
+    uint64_t n_units;
+    const uint64_t* frag_offset;     /* n_units + 1 */
+    const svt_breakpoint* breakpoints;
+    const svt_fragment* fragments;   /* frag_offset[n_units] */
+    uint32_t n_libs;
+    const svt_library* libs;
+    double split_weight, disc_weight;
+    int32_t min_aligned;             /* -m / --min_aligned (classic.py:34)          */
+    int32_t split_slop;              /* 3 (classic.py:184)                          */
+} svt_fragment_batch;
+
 /* ---- genotype codes --------------------------------------------------------- */
 #define SVT_GT_HOMREF 0    /* '0/0' */
 #define SVT_GT_HET 1       /* '0/1' */
@@ -241,6 +313,14 @@ void svt_batch_destroy(svt_batch* b);
 /* Release the per-device scratch the library keeps between svt_batch_create calls (the device
  * copy of the canonical records; a large hipMalloc costs ~100 ms, so it is reused).           */
 void svt_trim(void);
+
+/* Geometry + packing on the device: evaluates the predicates for every fragment summary of `in`
+ * (svt_geometry_kernel), leaves the evidence records in HBM and builds the resident batch from
+ * them -- the result is the same svt_batch svt_batch_create would build from the records that
+ * svtyper_amd/packer.py derives on the host.  If `records_out` is not NULL the canonical records
+ * (frag_offset[n_units] entries) are also copied back to it (used by the parity tests).        */
+int svt_batch_create_from_fragments(const svt_fragment_batch* in, int device, unsigned flags,
+                                    svt_record* records_out, svt_batch** out);
 
 /* Array form of the reference's inner operator seam statistics.bayes_gt(ref, alt, is_dup)
  * (svtyper/statistics.py:23-37) and log_choose(ref + alt, alt) (statistics.py:9-20):

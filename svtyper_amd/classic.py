@@ -64,7 +64,7 @@ def apply_result(var: Variant, sample_name: str, rec) -> None:
 
 
 def sv_genotype(bam_string, vcf_in, vcf_out, min_aligned, split_weight, disc_weight, num_samp, lib_info_path,
-                debug, alignment_outpath, ref_fasta, sum_quals, max_reads, max_ci_dist, *, engine=None):
+                debug, alignment_outpath, ref_fasta, sum_quals, max_reads, max_ci_dist, *, engine=None, geometry="host"):
     if alignment_outpath is not None:
         raise NotImplementedError("-w/--write_alignment (evidence BAM dump) is outside the MI355X hot path build")
     bams = []
@@ -90,7 +90,7 @@ def sv_genotype(bam_string, vcf_in, vcf_out, min_aligned, split_weight, disc_wei
     if engine is None:
         engine = default_engine()
     vcf = Vcf()
-    collector = UnitCollector(samples, split_weight, disc_weight, min_aligned)
+    collector = UnitCollector(samples, split_weight, disc_weight, min_aligned, geometry)
     pending: list = []      # ordered output actions of the current chunk
     header_lines: list = []
     in_header = True

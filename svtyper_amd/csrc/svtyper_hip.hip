@@ -656,6 +656,158 @@ __global__ __launch_bounds__(kBlock) void svt_repack_split_kernel(const RepackAr
 }
 
 // ------------------------------------------------------------------------------------------
+// geometry kernel: one fragment summary per thread -> one canonical evidence record
+// (svtyper/parsers.py:785-857, 1122-1215; the walk of svtyper/classic.py:296-396 per fragment)
+// ------------------------------------------------------------------------------------------
+struct GeomArgs {
+    const uint4* frags;          // svt_fragment[n_frags] viewed as 8 x uint4
+    const uint32_t* frag_unit;   // unit of every fragment summary
+    const svt_breakpoint* bps;
+    const LibDesc* libs;         // v_nondel = lib.mean + lib.sd * 3 is also is_pair_straddle's flank
+    uint64_t n_frags;
+    uint32_t n_libs;
+    int32_t min_aligned;
+    int32_t split_slop;
+    uint4* records;
+    uint32_t* err;
+};
+
+struct ReadS { int32_t tid, start, end, iv0s, iv1s, iv0e, iv1e; uint32_t mapq, flags, extra; };
+struct PieceS { int32_t tid, start, end; uint32_t mapq, flags; };
+
+__device__ __forceinline__ ReadS unpack_read(const uint4 a, const uint4 b)
+{
+    ReadS r;
+    r.tid = (int32_t)a.x; r.start = (int32_t)a.y; r.end = (int32_t)a.z;
+    r.iv0s = (int32_t)a.w; r.iv1s = (int32_t)b.x; r.iv0e = (int32_t)b.y; r.iv1e = (int32_t)b.z;
+    r.mapq = b.w & 0xffu; r.flags = (b.w >> 8) & 0xffu; r.extra = b.w >> 16;
+    return r;
+}
+
+__device__ __forceinline__ PieceS unpack_piece(const uint4 a)
+{
+    PieceS p;
+    p.tid = (int32_t)a.x; p.start = (int32_t)a.y; p.end = (int32_t)a.z;
+    p.mapq = a.w & 0xffu; p.flags = (a.w >> 8) & 0xffu;
+    return p;
+}
+
+// parsers.py:801-816: same chromosome and get_overlap(max(0, pos - m), pos + m) >= 2 m, i.e. the
+// whole 2m window lies inside one gap-free aligned interval of the read
+__device__ __forceinline__ bool is_ref_seq_dev(const ReadS& r, int32_t tid, int32_t pos, int32_t m)
+{
+    if (!(r.flags & SVT_READ_PRESENT) || r.tid != tid) return false;
+    if (m <= 0) return true;        // get_overlap(...) < 0 never holds
+    if (pos < m) return false;      // window clipped at 0 is shorter than 2 m
+    const int64_t lo = (int64_t)pos - m, hi = (int64_t)pos + m;
+    return (r.iv0s <= lo && hi <= r.iv0e) || (r.iv1s <= lo && hi <= r.iv1e);
+}
+
+// one side of parsers.py:846-855
+__device__ __forceinline__ bool side_ok(int64_t inner, int32_t pos, int32_t ci_lo, int32_t ci_hi, bool rev, double flank)
+{
+    const int64_t lo = (int64_t)pos + ci_lo, hi = (int64_t)pos + ci_hi;
+    if (rev) return !(inner < lo || (double)inner > (double)hi + flank);
+    return !(inner > hi || (double)inner < (double)lo - flank);
+}
+
+// parsers.py:821-857
+__device__ __forceinline__ bool pair_straddle_dev(const ReadS& a, const ReadS& b, bool pair_ok, int32_t tid_a,
+                                                  int32_t pos_a, int32_t cia_lo, int32_t cia_hi, int32_t tid_b,
+                                                  int32_t pos_b, int32_t cib_lo, int32_t cib_hi, bool o1, bool o2,
+                                                  int32_t m, double flank)
+{
+    if (!pair_ok) return false;
+    if (((a.flags & SVT_READ_REVERSE) != 0) != o1 || ((b.flags & SVT_READ_REVERSE) != 0) != o2) return false;
+    if (a.tid != tid_a || b.tid != tid_b) return false;
+    const int64_t i1 = (int64_t)a.start + m, i2 = (int64_t)b.end - m - 1;   // get_ispan :785-789
+    return side_ok(i1, pos_a, cia_lo, cia_hi, o1, flank) && side_ok(i2, pos_b, cib_lo, cib_hi, o2, flank);
+}
+
+// parsers.py:1122-1134
+__device__ __forceinline__ bool split_support_dev(const PieceS& p, int32_t tid, int32_t pos, bool rev, int32_t slop)
+{
+    if (p.tid != tid) return false;
+    const int64_t coord = rev ? p.start : p.end;
+    return !(coord > (int64_t)pos + slop || coord < (int64_t)pos - slop);
+}
+
+// parsers.py:1136-1215 for one candidate; returns gated MAPQs (left | right << 8)
+__device__ __forceinline__ uint32_t split_weights_dev(const PieceS& L, const PieceS& R, bool soft,
+                                                      const svt_breakpoint& bp, int32_t slop)
+{
+    if (!(L.flags & SVT_READ_PRESENT)) return 0u;
+    const bool o1 = (bp.flags & SVT_BP_REV_A) != 0, o2 = (bp.flags & SVT_BP_REV_B) != 0;
+    int32_t tid_lo = bp.tid_a, pos_lo = bp.pos_a, tid_hi = bp.tid_b, pos_hi = bp.pos_b;
+    bool rev_lo = o1, rev_hi = o2;
+    if (bp.tid_a != bp.tid_b || bp.pos_a > bp.pos_b) {   // arrange the breakends left to right (:1143-1161)
+        tid_lo = bp.tid_b; pos_lo = bp.pos_b; rev_lo = o2;
+        tid_hi = bp.tid_a; pos_hi = bp.pos_a; rev_hi = o1;
+    }
+    bool left = false, right = false;
+    if (!soft || bp.svtype == SVT_SVTYPE_DEL) {           // (svtype INS never reaches the genotyper)
+        left = split_support_dev(L, tid_lo, pos_lo, rev_lo, slop);
+        right = split_support_dev(R, tid_hi, pos_hi, rev_hi, slop);
+    } else if (bp.svtype == SVT_SVTYPE_DUP) {
+        left = split_support_dev(L, tid_hi, pos_hi, rev_hi, slop);
+        right = split_support_dev(R, tid_lo, pos_lo, rev_lo, slop);
+    } else if (bp.svtype == SVT_SVTYPE_INV) {
+        left = split_support_dev(L, tid_lo, pos_lo, rev_lo, slop) || split_support_dev(L, tid_hi, pos_hi, rev_hi, slop);
+        right = split_support_dev(R, tid_lo, pos_lo, rev_lo, slop) || split_support_dev(R, tid_hi, pos_hi, rev_hi, slop);
+    }
+    return (left ? L.mapq : 0u) | ((right ? R.mapq : 0u) << 8);
+}
+
+__global__ __launch_bounds__(kBlock) void svt_geometry_kernel(const GeomArgs g)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= g.n_frags) return;
+    const uint4* __restrict__ f = g.frags + i * 8;
+    const ReadS ra = unpack_read(f[0], f[1]);
+    const ReadS rb = unpack_read(f[2], f[3]);
+    const PieceS sl = unpack_piece(f[4]), sr = unpack_piece(f[5]);
+    const PieceS cl = unpack_piece(f[6]), cr = unpack_piece(f[7]);
+    const svt_breakpoint bp = g.bps[g.frag_unit[i]];
+    const uint32_t lib = ra.extra & 0xffu;
+    const bool pair_ok = (rb.extra & SVT_FRAG_PAIR) != 0;
+    const bool cont = (rb.extra & SVT_FRAG_CONTINUATION) != 0;
+    uint32_t bad = 0;
+    if (lib >= g.n_libs) bad |= 4u;
+    const double flank = g.libs[min(lib, g.n_libs - 1)].v_nondel;
+    const int32_t m = g.min_aligned;
+    const bool o1 = (bp.flags & SVT_BP_REV_A) != 0, o2 = (bp.flags & SVT_BP_REV_B) != 0;
+
+    // gated MAPQs of the primary reads (classic.py:306-311)
+    const uint32_t rs_a = (is_ref_seq_dev(ra, bp.tid_a, bp.pos_a, m) || is_ref_seq_dev(ra, bp.tid_b, bp.pos_b, m)) ? ra.mapq : 0u;
+    const uint32_t rs_b = (is_ref_seq_dev(rb, bp.tid_a, bp.pos_a, m) || is_ref_seq_dev(rb, bp.tid_b, bp.pos_b, m)) ? rb.mapq : 0u;
+    // gated MAPQs of the split candidates (classic.py:317-328)
+    const uint32_t wseq = split_weights_dev(sl, sr, false, bp, g.split_slop);
+    const uint32_t wclip = split_weights_dev(cl, cr, true, bp, g.split_slop);
+
+    // paired-end bits (classic.py:339-396), without the small-deletion gate
+    uint32_t flags = (lib << SVT_REC_LIB_SHIFT) | (cont ? SVT_REC_CONTINUATION : 0u);
+    uint32_t mq = 0, ospan = 0;
+    if (pair_ok) {
+        flags |= SVT_REC_HAS_PAIR;
+        mq = ra.mapq | (rb.mapq << 8);
+        const int64_t o = (int64_t)rb.end - (int64_t)ra.start;          // parsers.py:792-796,866-869
+        ospan = (uint32_t)min((int64_t)0x7fffffff, o < 0 ? -o : o);
+        bool alt = pair_straddle_dev(ra, rb, true, bp.tid_a, bp.pos_a, bp.ci_a[0], bp.ci_a[1], bp.tid_b, bp.pos_b,
+                                     bp.ci_b[0], bp.ci_b[1], o1, o2, m, flank);
+        if (!alt && bp.svtype == SVT_SVTYPE_INV)                          // reciprocal orientation (:349-357)
+            alt = pair_straddle_dev(ra, rb, true, bp.tid_a, bp.pos_a, bp.ci_a[0], bp.ci_a[1], bp.tid_b, bp.pos_b,
+                                    bp.ci_b[0], bp.ci_b[1], !o1, !o2, m, flank);
+        if (alt) flags |= SVT_REC_ALT_STRADDLE;
+        if (pair_straddle_dev(ra, rb, true, bp.tid_a, bp.pos_a, 0, 0, bp.tid_a, bp.pos_a, 0, 0, false, true, m, flank))
+            flags |= SVT_REC_REF_STRADDLE_A;                               // :387-391
+        if (pair_straddle_dev(ra, rb, true, bp.tid_b, bp.pos_b, 0, 0, bp.tid_b, bp.pos_b, 0, 0, false, true, m, flank))
+            flags |= SVT_REC_REF_STRADDLE_B;                               // :392-396
+    }
+    g.records[i] = make_uint4(ospan, mq | (rs_a << 16) | (rs_b << 24), wseq | (wclip << 16), flags);
+    if (bad) atomicOr(g.err, bad);
+}
+
+// ------------------------------------------------------------------------------------------
 // bayes_gt seam kernel: one (ref, alt, is_dup) item per thread (statistics.py:9-37)
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void svt_bayes_kernel(const int32_t* __restrict__ ref,
@@ -1151,7 +1303,7 @@ struct StageTimer {
 };
 
 // everything of svt_batch_create that needs the device; `b` is freed by the caller on failure
-int create_on_device(const svt_evidence_batch* in, svt_batch* b)
+int create_on_device(const svt_evidence_batch* in, svt_batch* b, const uint4* d_records_resident = nullptr)
 {
     const uint64_t n = in->n_units;
     const uint64_t n_rec = n ? in->rec_offset[n] : 0;
@@ -1185,13 +1337,17 @@ int create_on_device(const svt_evidence_batch* in, svt_batch* b)
 
     // ---- canonical records to the device; validate them and count the sparse-stream entries
     DevScratch d_off, d_counts, d_err;
-    std::lock_guard<std::mutex> csr_guard(g_csr_cache.lock);   // the cached scratch is ours until we return
-    void* d_csr_p = nullptr;
-    SVT_TRY(g_csr_cache.acquire(b->device, std::max<uint64_t>(n_rec, 1) * sizeof(uint4), &d_csr_p));
-    const uint4* d_csr = static_cast<const uint4*>(d_csr_p);
-    tm.mark("stream/event/alloc");
-    SVT_TRY(h2d_staged(d_csr_p, in->records, n_rec * sizeof(uint4), b->stream));
-    tm.mark("H2D records (staged)");
+    std::unique_lock<std::mutex> csr_guard(g_csr_cache.lock, std::defer_lock);
+    const uint4* d_csr = d_records_resident;
+    if (!d_csr) {
+        csr_guard.lock();   // the cached scratch is ours until we return
+        void* d_csr_p = nullptr;
+        SVT_TRY(g_csr_cache.acquire(b->device, std::max<uint64_t>(n_rec, 1) * sizeof(uint4), &d_csr_p));
+        d_csr = static_cast<const uint4*>(d_csr_p);
+        tm.mark("stream/event/alloc");
+        SVT_TRY(h2d_staged(d_csr_p, in->records, n_rec * sizeof(uint4), b->stream));
+        tm.mark("H2D records (staged)");
+    }
     SVT_TRY(d_off.alloc((n + 1) * sizeof(uint64_t)));
     if (n) HIP_TRY(hipMemcpyAsync(d_off.p, in->rec_offset, (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, b->stream));
     SVT_TRY(d_counts.alloc(n * sizeof(uint4)));
@@ -1399,6 +1555,115 @@ int svt_batch_create(const svt_evidence_batch* in, int device, unsigned flags, s
     b->n_units = n;
     b->n_records = n ? in->rec_offset[n] : 0;
     const int rc = create_on_device(in, b);
+    if (rc != SVT_OK) {
+        const std::string keep = g_err;
+        free_batch(b);
+        g_err = keep;
+        return rc;
+    }
+    *out = b;
+    return SVT_OK;
+}
+
+int svt_batch_create_from_fragments(const svt_fragment_batch* in, int device, unsigned flags,
+                                    svt_record* records_out, svt_batch** out)
+{
+    if (!in || !out) return fail(SVT_ERR_INVALID, "null argument");
+    *out = nullptr;
+    const uint64_t n = in->n_units;
+    if (flags & ~(SVT_FLAG_SSO_ASSOCIATION | SVT_FLAG_DENSE_LAYOUT)) return fail(SVT_ERR_INVALID, "unknown flag bits");
+    if (n >= 0xFFFFFFF0ull) return fail(SVT_ERR_INVALID, "too many units in one batch (< 2^32)");
+    if (in->n_libs == 0 || in->n_libs > 256 || !in->libs) return fail(SVT_ERR_INVALID, "n_libs must be 1..256");
+    if (n && (!in->frag_offset || !in->breakpoints)) return fail(SVT_ERR_INVALID, "null unit arrays");
+    if (n && in->frag_offset[0] != 0) return fail(SVT_ERR_INVALID, "frag_offset[0] must be 0");
+    const uint64_t n_frag = n ? in->frag_offset[n] : 0;
+    if (n_frag && !in->fragments) return fail(SVT_ERR_INVALID, "null fragments");
+    const int ndev = svt_device_count();
+    if (ndev <= 0) return fail(SVT_ERR_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(SVT_ERR_NO_DEVICE, "device index out of range");
+    HIP_TRY(hipSetDevice(device));
+
+    // unit headers and the fragment -> unit map
+    std::vector<svt_unit> units(n);
+    std::vector<uint32_t> frag_unit(n_frag);
+    for (uint64_t u = 0; u < n; ++u) {
+        const svt_breakpoint& bp = in->breakpoints[u];
+        if (in->frag_offset[u + 1] < in->frag_offset[u]) return fail(SVT_ERR_INVALID, "frag_offset not monotone");
+        if (bp.svtype > SVT_SVTYPE_BND) return fail(SVT_ERR_INVALID, "bad svtype");
+        svt_unit U{};
+        U.var_length = bp.svtype == SVT_SVTYPE_DEL ? bp.var_length : 0;
+        const int64_t delta = (int64_t)bp.pos_b - (int64_t)bp.pos_a;            // classic.py:339
+        U.pos_delta = (int32_t)std::max<int64_t>(INT32_MIN, std::min<int64_t>(INT32_MAX, delta));
+        U.sample = bp.sample;
+        U.svtype = bp.svtype;
+        U.flags = (bp.flags & SVT_BP_SKIP) ? SVT_UNIT_SKIP : 0;
+        units[u] = U;
+        for (uint64_t j = in->frag_offset[u]; j < in->frag_offset[u + 1]; ++j) frag_unit[j] = (uint32_t)u;
+    }
+    // library descriptors (the flank of is_pair_straddle is lib.mean + lib.sd * 3)
+    std::vector<LibDesc> libs(in->n_libs);
+    for (uint32_t l = 0; l < in->n_libs; ++l) {
+        if (!std::isfinite(in->libs[l].mean) || !std::isfinite(in->libs[l].sd)) return fail(SVT_ERR_INVALID, "library moments not finite");
+        libs[l].v_nondel = in->libs[l].mean + in->libs[l].sd * 3;
+    }
+
+    // geometry on the device
+    hipStream_t s = nullptr;
+    HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    struct StreamGuard { hipStream_t s; ~StreamGuard() { (void)hipStreamDestroy(s); } } sg{s};
+    DevScratch d_frags, d_frag_unit, d_bps, d_libs, d_records, d_err;
+    SVT_TRY(d_frags.alloc(n_frag * sizeof(svt_fragment)));
+    SVT_TRY(h2d_staged(d_frags.p, in->fragments, n_frag * sizeof(svt_fragment), s));
+    SVT_TRY(upload(d_frag_unit, frag_unit, s));
+    SVT_TRY(d_bps.alloc(n * sizeof(svt_breakpoint)));
+    if (n) HIP_TRY(hipMemcpyAsync(d_bps.p, in->breakpoints, n * sizeof(svt_breakpoint), hipMemcpyHostToDevice, s));
+    SVT_TRY(upload(d_libs, libs, s));
+    SVT_TRY(d_records.alloc(n_frag * sizeof(uint4)));
+    SVT_TRY(d_err.alloc(sizeof(uint32_t)));
+    HIP_TRY(hipMemsetAsync(d_err.p, 0, sizeof(uint32_t), s));
+    if (n_frag) {
+        GeomArgs g{};
+        g.frags = d_frags.as<uint4>();
+        g.frag_unit = d_frag_unit.as<uint32_t>();
+        g.bps = d_bps.as<svt_breakpoint>();
+        g.libs = d_libs.as<LibDesc>();
+        g.n_frags = n_frag;
+        g.n_libs = in->n_libs;
+        g.min_aligned = in->min_aligned;
+        g.split_slop = in->split_slop;
+        g.records = d_records.as<uint4>();
+        g.err = d_err.as<uint32_t>();
+        hipLaunchKernelGGL(svt_geometry_kernel, dim3((unsigned)((n_frag + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, g);
+        HIP_TRY(hipGetLastError());
+    }
+    uint32_t err_bits = 0;
+    HIP_TRY(hipMemcpyAsync(&err_bits, d_err.p, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    if (records_out && n_frag)
+        HIP_TRY(hipMemcpyAsync(records_out, d_records.p, n_frag * sizeof(uint4), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (err_bits) return fail(SVT_ERR_INVALID, "invalid fragment summaries: library index >= n_libs");
+
+    // the resident batch, from the records that are already in HBM
+    svt_evidence_batch eb{};
+    eb.n_units = n;
+    eb.rec_offset = in->frag_offset;
+    eb.units = units.data();
+    eb.records = nullptr;
+    eb.n_libs = in->n_libs;
+    eb.libs = in->libs;
+    eb.split_weight = in->split_weight;
+    eb.disc_weight = in->disc_weight;
+    if (!(eb.split_weight >= 0.0) || !(eb.disc_weight >= 0.0) || !std::isfinite(eb.split_weight) ||
+        !std::isfinite(eb.disc_weight))
+        return fail(SVT_ERR_INVALID, "weights must be finite and >= 0");
+    svt_batch* b = new (std::nothrow) svt_batch();
+    if (!b) return fail(SVT_ERR_NOMEM, "out of host memory");
+    b->device = device;
+    b->flags = flags;
+    b->split = (flags & SVT_FLAG_DENSE_LAYOUT) == 0;
+    b->n_units = n;
+    b->n_records = n_frag;
+    const int rc = create_on_device(&eb, b, d_records.as<uint4>());
     if (rc != SVT_OK) {
         const std::string keep = g_err;
         free_batch(b);

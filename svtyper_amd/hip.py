@@ -14,10 +14,11 @@ from .evidence import CEvidenceBatch, EvidenceBatch, RESULT_DTYPE, Results
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SVTYPER_HIP_LIB") or os.path.join(_HERE, "csrc", "libsvtyper_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 EXPORTS = (
-    "svt_version", "svt_device_count", "svt_last_error", "svt_batch_create", "svt_batch_genotype",
+    "svt_version", "svt_device_count", "svt_last_error", "svt_batch_create", "svt_batch_create_from_fragments",
+    "svt_batch_genotype",
     "svt_batch_genotype_n", "svt_batch_genotype_timed", "svt_batch_results", "svt_batch_device_results",
     "svt_batch_bind_device_results", "svt_batch_bytes",
     "svt_batch_stream", "svt_batch_destroy", "svt_trim", "svt_bayes_gt", "svt_genotype",
@@ -56,6 +57,8 @@ def load() -> C.CDLL:
     L.svt_last_error.restype = C.c_char_p
     L.svt_batch_create.restype = C.c_int
     L.svt_batch_create.argtypes = [C.POINTER(CEvidenceBatch), C.c_int, C.c_uint, C.POINTER(C.c_void_p)]
+    L.svt_batch_create_from_fragments.restype = C.c_int
+    L.svt_batch_create_from_fragments.argtypes = [C.c_void_p, C.c_int, C.c_uint, C.c_void_p, C.POINTER(C.c_void_p)]
     L.svt_batch_genotype.restype = C.c_int
     L.svt_batch_genotype.argtypes = [C.c_void_p, C.c_int]
     L.svt_batch_genotype_n.restype = C.c_int
@@ -112,6 +115,26 @@ class DeviceBatch:
         cb = batch.as_c()
         _check(L.svt_batch_create(C.byref(cb), int(device), int(flags), C.byref(self._h)))
 
+    @classmethod
+    def from_fragments(cls, fbatch, device: int = 0, flags: int = 0, return_records: bool = False):
+        """Geometry on the device: fragment summaries (svtyper_amd.geometry.FragmentBatch) -> evidence
+        records -> resident batch.  With return_records the derived canonical records come back too."""
+        import numpy as np
+        from .evidence import RECORD_DTYPE
+        L = load()
+        self = cls.__new__(cls)
+        self._lib = L
+        self._h = C.c_void_p()
+        self.n_units = fbatch.n_units
+        self.n_records = fbatch.n_fragments
+        recs = np.zeros(fbatch.n_fragments, RECORD_DTYPE) if return_records else None
+        cb = fbatch.as_c()
+        _check(L.svt_batch_create_from_fragments(C.byref(cb), int(device), int(flags),
+                                                 C.c_void_p(recs.ctypes.data) if return_records and recs.size else None,
+                                                 C.byref(self._h)))
+        self.records = recs
+        return self
+
     def genotype(self, sync: bool = True):
         _check(self._lib.svt_batch_genotype(self._h, int(sync)))
 
@@ -165,6 +188,13 @@ class DeviceBatch:
 
     def __exit__(self, *exc):
         self.close()
+
+
+def genotype_fragments(fbatch, device: int = 0, flags: int = 0) -> Results:
+    """Fragment summaries -> results with both the geometry and the likelihood stage on the device."""
+    with DeviceBatch.from_fragments(fbatch, device, flags) as d:
+        d.genotype(sync=True)
+        return d.results()
 
 
 def genotype_batch(batch: EvidenceBatch, device: int = 0, flags: int = 0) -> Results:

@@ -44,15 +44,27 @@ class HipEngine:
     def __call__(self, batch: EvidenceBatch, flags: int = 0) -> Results:
         return self._hip.genotype_batch(batch, device=self.device, flags=flags)
 
+    def genotype_fragments(self, fbatch, flags: int = 0) -> Results:
+        """geometry="device": fragment summaries in, both stages on the GPU."""
+        return self._hip.genotype_fragments(fbatch, device=self.device, flags=flags)
+
 
 def default_engine() -> Engine:
     return HipEngine(0)
 
 
 class UnitCollector:
-    """Packs (breakpoint, sample) units of one chunk of variants and remembers where each went."""
+    """Packs (breakpoint, sample) units of one chunk of variants and remembers where each went.
 
-    def __init__(self, samples: List[Sample], split_weight: float, disc_weight: float, min_aligned: int):
+    geometry="host":   fragments -> evidence records here (packer.py), likelihood on the device;
+    geometry="device": fragments -> breakpoint-independent summaries here (geometry.py), predicates
+                       and likelihood on the device (needs an engine with genotype_fragments)."""
+
+    def __init__(self, samples: List[Sample], split_weight: float, disc_weight: float, min_aligned: int,
+                 geometry: str = "host"):
+        if geometry not in ("host", "device"):
+            raise ValueError("geometry must be 'host' or 'device'")
+        self.geometry = geometry
         self.samples = samples
         self.min_aligned = min_aligned
         self.lib_tables = []
@@ -65,10 +77,24 @@ class UnitCollector:
             raise ValueError("more than 256 libraries in one run are not supported by the evidence record")
         self.split_weight = split_weight
         self.disc_weight = disc_weight
-        self.builder = BatchBuilder(self.lib_tables, split_weight, disc_weight)
+        self.builder = self._new_builder()
+
+    def _new_builder(self):
+        if self.geometry == "device":
+            from .geometry import FragmentBatchBuilder
+            return FragmentBatchBuilder(self.lib_tables, self.split_weight, self.disc_weight, self.min_aligned,
+                                        SPLIT_SLOP)
+        return BatchBuilder(self.lib_tables, self.split_weight, self.disc_weight)
 
     def add(self, breakpoint: dict, sample_index: int, fragments: Optional[Dict[str, SamFragment]],
             skip: bool = False) -> int:
+        if self.geometry == "device":
+            from .geometry import breakpoint_record, summarise_fragments
+            tid_of = self.samples[sample_index].bam.gettid
+            frs = None
+            if fragments and not skip:
+                frs = summarise_fragments(fragments, breakpoint, self.lib_index, tid_of)
+            return self.builder.add(breakpoint_record(breakpoint, tid_of, sample_index, skip), frs)
         unit = unit_header(breakpoint, sample_index, skip)
         recs = None
         if fragments and not skip:
@@ -82,8 +108,13 @@ class UnitCollector:
         batch = self.builder.build()
         if batch.n_units == 0:
             return Results.empty(0)
-        res = engine(batch, flags)
-        self.builder = BatchBuilder(self.lib_tables, self.split_weight, self.disc_weight)
+        if self.geometry == "device":
+            if not hasattr(engine, "genotype_fragments"):
+                raise TypeError("geometry='device' needs an engine with genotype_fragments (the HIP engine)")
+            res = engine.genotype_fragments(batch, flags)
+        else:
+            res = engine(batch, flags)
+        self.builder = self._new_builder()
         return res
 
 

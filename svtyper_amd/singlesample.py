@@ -67,7 +67,7 @@ def assign_genotype(variant: Variant, sample_name: str, rec) -> None:
 
 
 def sso_genotype(bam_string, vcf_in, vcf_out, min_aligned, split_weight, disc_weight, num_samp, lib_info_path,
-                 debug, ref_fasta, sum_quals, max_reads, max_ci_dist, cores, batch_size, *, engine=None):
+                 debug, ref_fasta, sum_quals, max_reads, max_ci_dist, cores, batch_size, *, engine=None, geometry="host"):
     if vcf_in is None:
         return
     full_bam_path = os.path.abspath(bam_string)
@@ -112,7 +112,7 @@ def sso_genotype(bam_string, vcf_in, vcf_out, min_aligned, split_weight, disc_we
     vcf.write_header(vcf_out)
 
     logit("Genotyping Input VCF (%s Mode)" % ("Serial" if cores is None else "Parallel"))
-    collector = UnitCollector([sample], split_weight, disc_weight, min_aligned)
+    collector = UnitCollector([sample], split_weight, disc_weight, min_aligned, geometry)
     pending: list = []
 
     def flush():

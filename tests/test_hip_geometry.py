@@ -1,0 +1,106 @@
+"""GPU: the geometry stage (svt_geometry_kernel, include/svtyper_hip.h: svt_fragment) against the
+evidence records the REFERENCE's own predicates produced (tests/golden/fake_sites.json.gz and the 211
+fixture sites), and both drivers end to end with geometry="device"."""
+import os
+
+import numpy as np
+import pytest
+
+import fakereads
+import goldenio as gio
+from svtyper_amd import evidence as ev
+from svtyper_amd import fragments as fr
+from svtyper_amd import geometry as geo
+from svtyper_amd.results import result_from_record
+
+pytestmark = pytest.mark.gpu
+
+CHROMS = {"1": 0, "2": 1}
+
+
+class _Lib:
+    def __init__(self, name, mean, sd):
+        self.name, self.mean, self.sd = name, mean, sd
+
+
+def _fragment_batch(grp):
+    libs_json = grp["libraries"]
+    libs = [_Lib(L["name"], gio.fh(L["mean"]), gio.fh(L["sd"])) for L in libs_json]
+    rg_to_lib = {rg: lib for lib, L in zip(libs, libs_json) for rg in L["readgroups"]}
+    lib_index = {id(lib): i for i, lib in enumerate(libs)}
+    tid_of = lambda c: CHROMS.get(c, -1)
+    b = geo.FragmentBatchBuilder(gio.libraries(libs_json), 1.0, 1.0, 20, 3)
+    for site in grp["sites"]:
+        frags = {}
+        for t in site["reads"]:
+            r = fakereads.FakeRead(*t)
+            lib = rg_to_lib[r.get_tag("RG")]
+            if r.query_name in frags:
+                frags[r.query_name].add_read(r)
+            else:
+                frags[r.query_name] = fr.SamFragment(r, lib)
+        b.add(geo.breakpoint_record(site["breakpoint"], tid_of),
+              geo.summarise_fragments(frags, site["breakpoint"], lib_index, tid_of))
+    return b.build()
+
+
+def test_fake_sites_device_geometry_matches_reference_records(hip_device):
+    from svtyper_amd import hip
+    g = gio.load("fake_sites.json.gz")
+    n_rec = 0
+    for grp in g["groups"]:
+        fb = _fragment_batch(grp)
+        with hip.DeviceBatch.from_fragments(fb, hip_device, ev.FLAG_SSO_ASSOCIATION, return_records=True) as d:
+            want = np.concatenate([gio.records_from_rows(s["records"]) for s in grp["sites"]])
+            assert d.records.shape == want.shape
+            for name in want.dtype.names:
+                bad = np.nonzero(d.records[name] != want[name])[0]
+                assert bad.size == 0, (name, bad[:5], d.records[name][bad[:5]], want[name][bad[:5]])
+            n_rec += len(want)
+            # ... and the likelihood stage fed from those device-resident records
+            d.genotype()
+            got = d.results()
+            for k, s in enumerate(grp["sites"]):
+                gio.assert_result_equal(result_from_record(got.rec[k]), gio.golden_result(s["result"]), 1e-6,
+                                        s["breakpoint"]["id"])
+    assert n_rec > 5000
+
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+DATA = os.path.join(HERE, "data")
+
+
+def test_fixture_sites_device_geometry(hip_device):
+    """Real reads: the 211 fixture breakpoints, fragments built from the BAM by the host layer,
+    predicates on the device; records must equal the ones derived with the reference's predicates."""
+    import json
+    from svtyper_amd import bam, hip, library, pipeline, singlesample, vcf as vcfmod
+    g = gio.load("fixture_sites.json.gz")
+    sample = library.Sample.from_lib_info(bam.AlignmentFile(os.path.join(DATA, "NA12878.target_loci.sorted.bam")),
+                                          json.load(open(os.path.join(DATA, "NA12878.bam.json"))), 1e-3)
+    coll = pipeline.UnitCollector([sample], 1, 1, 20, geometry="device")
+    for s in g["sites"]:
+        frags, many = singlesample.gather_reads(sample, s["breakpoint"], 1000)
+        assert not many
+        coll.add(s["breakpoint"], 0, frags)
+    fb = coll.builder.build()
+    with hip.DeviceBatch.from_fragments(fb, hip_device, 0, return_records=True) as d:
+        want = np.concatenate([gio.records_from_rows(s["records"]) for s in g["sites"]])
+        assert d.records.shape == want.shape
+        for name in want.dtype.names:
+            assert np.array_equal(d.records[name], want[name]), name
+
+
+@pytest.mark.parametrize("driver", ["classic", "sso"])
+def test_drivers_with_device_geometry(tmp_path, hip_device, driver):
+    import test_host_pipeline as T
+    out = str(tmp_path / "out.vcf")
+    if driver == "classic":
+        with open(T.IN_VCF) as inf, open(out, "w") as outf:
+            T.classic.sv_genotype(T.IN_BAM, inf, outf, 20, 1, 1, 1000000, T.LIB_JSON, False, None, None, False, None,
+                                  1e10, geometry="device")
+    else:
+        with open(T.IN_VCF) as inf, open(out, "w") as outf:
+            T.singlesample.sso_genotype(T.IN_BAM, inf, outf, 20, 1, 1, 1000000, T.LIB_JSON, False, None, False, 1000,
+                                        1e10, None, 1000, geometry="device")
+    T.same_vcf(T.EXPECTED, out)
