@@ -1611,9 +1611,11 @@ int svt_batch_create_from_fragments(const svt_fragment_batch* in, int device, un
     hipStream_t s = nullptr;
     HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
     struct StreamGuard { hipStream_t s; ~StreamGuard() { (void)hipStreamDestroy(s); } } sg{s};
+    StageTimer tm;
     DevScratch d_frags, d_frag_unit, d_bps, d_libs, d_records, d_err;
     SVT_TRY(d_frags.alloc(n_frag * sizeof(svt_fragment)));
     SVT_TRY(h2d_staged(d_frags.p, in->fragments, n_frag * sizeof(svt_fragment), s));
+    tm.mark("H2D fragment summaries");
     SVT_TRY(upload(d_frag_unit, frag_unit, s));
     SVT_TRY(d_bps.alloc(n * sizeof(svt_breakpoint)));
     if (n) HIP_TRY(hipMemcpyAsync(d_bps.p, in->breakpoints, n * sizeof(svt_breakpoint), hipMemcpyHostToDevice, s));
@@ -1641,6 +1643,7 @@ int svt_batch_create_from_fragments(const svt_fragment_batch* in, int device, un
     if (records_out && n_frag)
         HIP_TRY(hipMemcpyAsync(records_out, d_records.p, n_frag * sizeof(uint4), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
+    tm.mark("geometry kernel (+ copies)");
     if (err_bits) return fail(SVT_ERR_INVALID, "invalid fragment summaries: library index >= n_libs");
 
     // the resident batch, from the records that are already in HBM

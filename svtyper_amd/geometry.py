@@ -70,33 +70,33 @@ def _clip32(x) -> int:
     return int(min(max(int(x), -_I32 - 1), _I32))
 
 
-def _fill_read(dst, read, tid_of, near: Sequence[int]):
-    dst["tid"] = tid_of(read.reference_name)
-    dst["start"] = read.reference_start
-    dst["end"] = read.reference_end
+def _mapq8(q) -> int:
+    q = int(q)
+    if q < 0 or q > 255:
+        raise ValueError("MAPQ %d does not fit the fragment summary (0..255)" % q)
+    return q
+
+
+_ABSENT_READ = [-1, 0, 0, 0, 0, 0, 0, 0]   # 8 words of a svt_read_summary
+_ABSENT_PIECE = [0, 0, 0, 0]                # 4 words of a svt_piece_summary
+
+
+def _read_words(read, tid_of, near: Sequence[int]) -> List[int]:
     ivs = aligned_intervals(read)
     if len(ivs) > 2:   # keep the two intervals closest to the unit's breakends (only they can contain a window)
         ivs.sort(key=lambda iv: min(0 if iv[0] <= q <= iv[1] else min(abs(iv[0] - q), abs(iv[1] - q)) for q in near))
         ivs = ivs[:2]
-    for k, (s, e) in enumerate(ivs):
-        dst["iv_start"][k] = s
-        dst["iv_end"][k] = e
-    q = int(read.mapping_quality)
-    if q < 0 or q > 255:
-        raise ValueError("MAPQ %d does not fit the fragment summary (0..255)" % q)
-    dst["mapq"] = q
-    dst["flags"] = READ_PRESENT | (READ_REVERSE if read.is_reverse else 0)
+    while len(ivs) < 2:
+        ivs.append((0, 0))
+    packed = _mapq8(read.mapping_quality) | ((READ_PRESENT | (READ_REVERSE if read.is_reverse else 0)) << 8)
+    return [tid_of(read.reference_name), read.reference_start, read.reference_end, ivs[0][0], ivs[1][0], ivs[0][1],
+            ivs[1][1], packed]
 
 
-def _fill_piece(dst, piece, tid_of):
-    dst["tid"] = -2 if piece.chrom is None else tid_of(piece.chrom)
-    dst["start"] = _clip32(piece.reference_start)
-    dst["end"] = _clip32(piece.reference_end)
-    q = int(piece.mapping_quality)
-    if q < 0 or q > 255:
-        raise ValueError("MAPQ %d does not fit the fragment summary (0..255)" % q)
-    dst["mapq"] = q
-    dst["flags"] = READ_PRESENT | (READ_REVERSE if piece.is_reverse else 0)
+def _piece_words(piece, tid_of) -> List[int]:
+    packed = _mapq8(piece.mapping_quality) | ((READ_PRESENT | (READ_REVERSE if piece.is_reverse else 0)) << 8)
+    return [-2 if piece.chrom is None else tid_of(piece.chrom), _clip32(piece.reference_start),
+            _clip32(piece.reference_end), packed]
 
 
 def summarise_fragments(fragments: Dict[str, object], breakpoint: dict, lib_index: Dict[int, int], tid_of) -> np.ndarray:
@@ -104,33 +104,31 @@ def summarise_fragments(fragments: Dict[str, object], breakpoint: dict, lib_inde
     fragment with more than two primaries or two split candidates of one kind spills into continuation
     summaries, mirroring the records packer.pack_fragments would emit."""
     near = (breakpoint["A"]["pos"], breakpoint["B"]["pos"])
-    rows: List[np.ndarray] = []
+    rows: List[List[int]] = []
     for name in sorted(fragments.keys()):
         frag = fragments[name]
         lib = lib_index[id(frag.lib)]
-        primaries = list(frag.primary_reads)
+        primaries = frag.primary_reads
         seq = [s for s in frag.split_reads if not s.is_soft_clip]
         clip = [s for s in frag.split_reads if s.is_soft_clip]
         n_rec = max(1, (len(primaries) + 1) // 2, len(seq), len(clip))
         for k in range(n_rec):
-            f = np.zeros((), FRAGMENT_DTYPE)
-            f["read"][0]["tid"] = f["read"][1]["tid"] = -1
-            f["read"][0]["reserved"] = lib
-            for j in range(2):
-                if 2 * k + j < len(primaries):
-                    _fill_read(f["read"][j], primaries[2 * k + j], tid_of, near)
-            for cand, fld in ((seq, "seq"), (clip, "clip")):
+            ra = _read_words(primaries[2 * k], tid_of, near) if 2 * k < len(primaries) else list(_ABSENT_READ)
+            rb = _read_words(primaries[2 * k + 1], tid_of, near) if 2 * k + 1 < len(primaries) else list(_ABSENT_READ)
+            ra[7] |= lib << 16                                     # read[0].reserved: library index
+            bits = (FRAG_PAIR if (k == 0 and frag.num_primary == 2) else 0) | (FRAG_CONTINUATION if k > 0 else 0)
+            rb[7] |= bits << 16                                    # read[1].reserved: fragment bits
+            row = ra + rb
+            for cand in (seq, clip):
                 if k < len(cand):
-                    _fill_piece(f[fld][0], cand[k].query_left, tid_of)
-                    _fill_piece(f[fld][1], cand[k].query_right, tid_of)
-            bits = 0
-            if k == 0 and frag.num_primary == 2:
-                bits |= FRAG_PAIR
-            if k > 0:
-                bits |= FRAG_CONTINUATION
-            f["read"][1]["reserved"] = bits
-            rows.append(f)
-    return np.array(rows, dtype=FRAGMENT_DTYPE) if rows else np.zeros(0, FRAGMENT_DTYPE)
+                    row += _piece_words(cand[k].query_left, tid_of) + _piece_words(cand[k].query_right, tid_of)
+                else:
+                    row += _ABSENT_PIECE + _ABSENT_PIECE
+            rows.append(row)
+    if not rows:
+        return np.zeros(0, FRAGMENT_DTYPE)
+    words = np.asarray(rows, dtype=np.int64).astype(np.uint32)    # 32 little-endian words per summary
+    return np.ascontiguousarray(words).view(FRAGMENT_DTYPE).reshape(-1)
 
 
 def breakpoint_record(breakpoint: dict, tid_of, sample_index: int = 0, skip: bool = False) -> np.ndarray:
