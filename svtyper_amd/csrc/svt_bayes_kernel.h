@@ -1,0 +1,35 @@
+// svt_bayes_kernel.h -- array form of statistics.bayes_gt / log_choose
+// Internal header of libsvtyper_hip.so (single translation unit: svtyper_hip.hip).
+#ifndef SVT_BAYES_KERNEL_H
+#define SVT_BAYES_KERNEL_H
+
+#include "svt_genotype_kernel.h"
+
+namespace svt {
+
+// ------------------------------------------------------------------------------------------
+// bayes_gt seam kernel: one (ref, alt, is_dup) item per thread (statistics.py:9-37)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void svt_bayes_kernel(const int32_t* __restrict__ ref,
+                                                           const int32_t* __restrict__ alt,
+                                                           const uint8_t* __restrict__ is_dup,
+                                                           uint64_t n, const double* __restrict__ l10,
+                                                           const GtConsts c, double* __restrict__ out)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const int32_t r = ref[i], a = alt[i];
+    const int d = is_dup[i] ? 1 : 0;
+    const double log_combo = log_choose_dev(l10, r + a, a);
+    double4 o;
+    o.x = (log_combo + (double)a * c.lgp[d][0]) + (double)r * c.lg1p[d][0];
+    o.y = (log_combo + (double)a * c.lgp[d][1]) + (double)r * c.lg1p[d][1];
+    o.z = (log_combo + (double)a * c.lgp[d][2]) + (double)r * c.lg1p[d][2];
+    o.w = log_combo;
+    reinterpret_cast<double4*>(out)[i] = o;
+}
+
+
+}  // namespace svt
+
+#endif  // SVT_BAYES_KERNEL_H

@@ -1,0 +1,121 @@
+// svt_host_tiling.h -- host-side sorting of units into 64-lane tiles
+// Internal header of libsvtyper_hip.so (single translation unit: svtyper_hip.hip).
+#ifndef SVT_HOST_TILING_H
+#define SVT_HOST_TILING_H
+
+#include "svt_device_types.h"
+
+namespace svt {
+
+// ------------------------------------------------------------------------------------------
+// host-side tiling
+// ------------------------------------------------------------------------------------------
+struct Tiling {
+    std::vector<TileDesc> tiles;       // storage order
+    std::vector<uint32_t> tile_lib_lo, tile_lib_hi;  // library range referenced by each tile
+    std::vector<LaneHdr> hdr;
+    std::vector<uint64_t> lane_src;
+    std::vector<uint32_t> lane_nrec;
+    uint64_t slots = 0;                // 16-byte row slots of all tiles
+};
+
+inline unsigned host_threads()
+{
+    const unsigned hc = std::thread::hardware_concurrency();
+    return std::max(1u, std::min(hc ? hc : 1u, 16u));
+}
+
+// run fn(i) for i in [0, n) on up to host_threads() threads
+template <typename Fn>
+inline void parallel_for(uint64_t n, Fn&& fn)
+{
+    const unsigned nt = (unsigned)std::min<uint64_t>(host_threads(), n);
+    if (nt <= 1) {
+        for (uint64_t i = 0; i < n; ++i) fn(i);
+        return;
+    }
+    std::vector<std::thread> pool;
+    for (unsigned t = 0; t < nt; ++t)
+        pool.emplace_back([&, t]() { for (uint64_t i = t; i < n; i += nt) fn(i); });
+    for (auto& th : pool) th.join();
+}
+
+// Sort units by library and stream length inside chunks, cut into 64-unit tiles.  len_a/len_b are
+// the per-unit row counts of the two streams (dense layout: len_a = F, len_b = 0).  Chunks are
+// independent and are processed by several host threads.
+inline void build_tiling(const svt_evidence_batch* in, const std::vector<uint32_t>& nrec,
+                  const std::vector<uint32_t>& len_a, const std::vector<uint32_t>& len_b,
+                  const std::vector<uint4>& scan, Tiling& G)
+{
+    const uint64_t n = in->n_units;
+    const uint64_t n_chunks = (n + kChunkUnits - 1) / kChunkUnits;
+    const uint64_t tiles_per_chunk = kChunkUnits / kWave;
+    const uint64_t n_tiles = n ? (n_chunks - 1) * tiles_per_chunk +
+                                     ((n - (n_chunks - 1) * kChunkUnits) + kWave - 1) / kWave : 0;
+    G.tiles.assign(n_tiles, TileDesc{});
+    G.tile_lib_lo.assign(n_tiles, 0);
+    G.tile_lib_hi.assign(n_tiles, 0);
+    G.hdr.assign(n_tiles * kWave, LaneHdr{});
+    G.lane_src.assign(n_tiles * kWave, 0);
+    G.lane_nrec.assign(n_tiles * kWave, 0);
+    parallel_for(n_chunks, [&](uint64_t c) {
+        const uint64_t c0 = c * kChunkUnits;
+        const uint32_t cn = (uint32_t)std::min<uint64_t>(kChunkUnits, n - c0);
+        std::vector<uint32_t> order(cn);
+        for (uint32_t i = 0; i < cn; ++i) order[i] = i;
+        // by first library (keeps the units of one sample together so a workgroup's library window
+        // stays small), then longest first
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
+            const uint32_t lx = scan[c0 + x].z, ly = scan[c0 + y].z;
+            if (lx != ly) return lx < ly;
+            const uint64_t kx = ((uint64_t)len_a[c0 + x] << 32) | len_b[c0 + x];
+            const uint64_t ky = ((uint64_t)len_a[c0 + y] << 32) | len_b[c0 + y];
+            return kx > ky;
+        });
+        for (uint32_t t0 = 0; t0 < cn; t0 += kWave) {
+            const uint64_t ti = c * tiles_per_chunk + t0 / kWave;
+            TileDesc td{};
+            td.lane_base = (uint32_t)(ti * kWave);
+            uint32_t lib_lo = 0xffffffffu, lib_hi = 0;
+            for (uint32_t l = 0; l < (uint32_t)kWave; ++l) {
+                LaneHdr h{};
+                h.unit = kPadUnit;
+                uint64_t src = 0;
+                uint32_t f = 0;
+                if (t0 + l < cn) {
+                    const uint64_t u = c0 + order[t0 + l];
+                    const svt_unit& U = in->units[u];
+                    h.var_length = U.var_length;
+                    h.pos_delta = U.pos_delta;
+                    h.unit = (uint32_t)u;
+                    h.packed = (uint32_t)U.svtype | ((uint32_t)U.flags << 8) | ((uint32_t)U.sample << 16);
+                    src = in->rec_offset[u];
+                    f = nrec[u];
+                    td.rows_a = std::max(td.rows_a, len_a[u]);
+                    td.rows_b = std::max(td.rows_b, len_b[u]);
+                    if (f) {
+                        lib_lo = std::min(lib_lo, scan[u].z);
+                        lib_hi = std::max(lib_hi, scan[u].w);
+                    }
+                }
+                G.hdr[td.lane_base + l] = h;
+                G.lane_src[td.lane_base + l] = src;
+                G.lane_nrec[td.lane_base + l] = f;
+            }
+            G.tiles[ti] = td;
+            G.tile_lib_lo[ti] = lib_lo == 0xffffffffu ? 0u : lib_lo;
+            G.tile_lib_hi[ti] = lib_lo == 0xffffffffu ? 0u : lib_hi;
+        }
+    });
+    // slot offsets: a tile's pair rows, then its weight rows
+    for (TileDesc& td : G.tiles) {
+        td.base_a = G.slots;
+        td.base_b = G.slots + (uint64_t)td.rows_a * kWave;
+        G.slots += (uint64_t)(td.rows_a + td.rows_b) * kWave;
+    }
+}
+
+
+}  // namespace svt
+
+#endif  // SVT_HOST_TILING_H

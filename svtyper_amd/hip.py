@@ -33,10 +33,10 @@ class SvtyperHipError(RuntimeError):
 
 def build(force: bool = False) -> str:
     """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
-    src = os.path.join(_HERE, "csrc", "svtyper_hip.hip")
-    hdr = os.path.join(_HERE, "..", "include", "svtyper_hip.h")
-    stale = (not os.path.exists(LIB_PATH)
-             or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(src), os.path.getmtime(hdr)))
+    import glob
+    srcs = glob.glob(os.path.join(_HERE, "csrc", "*.hip")) + glob.glob(os.path.join(_HERE, "csrc", "*.h"))
+    srcs.append(os.path.join(_HERE, "..", "include", "svtyper_hip.h"))
+    stale = not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(s) for s in srcs)
     if force or stale:
         subprocess.check_call(["make", "-C", os.path.join(_HERE, "csrc"), "-B", "libsvtyper_hip.so"])
     return LIB_PATH
