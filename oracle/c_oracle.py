@@ -84,8 +84,10 @@ def genotype_from_tallies(tallies, svtype: int, split_weight=1.0, disc_weight=1.
     return dict(gl=(gl[0], gl[1], gl[2]), sq=sq.value, counts=list(counts), gt=gt.value)
 
 
-def genotype_batch(batch: EvidenceBatch, flags: int = 0, n_threads: int = 0) -> Results:
-    out = Results.empty(batch.n_units)
+def genotype_batch(batch: EvidenceBatch, flags: int = 0, n_threads: int = 0, out: Results = None) -> Results:
+    """`out` may be a preallocated Results (bench.py times only the C call with it)."""
+    if out is None:
+        out = Results.empty(batch.n_units)
     cb = batch.as_c()
     rc = lib().svt_oracle_batch(C.byref(cb), C.c_void_p(out.ptr()), int(flags), int(n_threads))
     if rc != 0:
