@@ -1,0 +1,78 @@
+/*
+ * svtyper_reads.h -- native (host, C++) BAM access + fragment summariser of libsvtyper_hip.so.
+ *
+ * The step BEFORE the device path: for every (breakpoint, sample) unit fetch the reads of the two
+ * breakend regions from an indexed BAM, group them into read-fragments, run the
+ * breakpoint-independent split-read QC and emit the fixed-size `svt_fragment` summaries
+ * (include/svtyper_hip.h) that svt_batch_create_from_fragments consumes.  It replaces, for the
+ * native pipeline, what the reference does with pysam objects in
+ *   svtyper/classic.py:54-100   gather_all_reads / gather_reads            (count_mode 0)
+ *   svtyper/singlesample.py:158-205  is_over_threshold / gather_reads      (count_mode 1)
+ *   svtyper/parsers.py:729-768   SamFragment.__init__ / add_read
+ *   svtyper/parsers.py:891-1058  SplitRead / SplitPiece / is_valid
+ * and what svtyper_amd/bam.py + fragments.py + geometry.py do in Python (those stay the portable
+ * implementation and are the checker of this one: tests/test_native_reads.py).
+ *
+ * Plain C ABI, host memory only; no GPU is needed for these calls.  BAM + .bai only (no CRAM).
+ */
+#ifndef SVTYPER_READS_H
+#define SVTYPER_READS_H
+
+#include <stdint.h>
+
+#include "svtyper_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct svt_bam svt_bam; /* opaque: header + index of one BAM file */
+
+/* Open `path` (and `path`.bai or the .bai next to it).  0 or SVT_ERR_*; text via svt_last_error(). */
+int svt_bam_open(const char* path, svt_bam** out);
+void svt_bam_close(svt_bam* bam);
+
+int32_t svt_bam_n_references(const svt_bam* bam);
+const char* svt_bam_reference_name(const svt_bam* bam, int32_t tid);
+int64_t svt_bam_reference_length(const svt_bam* bam, int32_t tid);
+int32_t svt_bam_tid(const svt_bam* bam, const char* name); /* -1 when absent */
+/* the @RG / other header text (NUL-terminated), owned by the handle */
+const char* svt_bam_header_text(const svt_bam* bam);
+
+/* the two fetch windows of one unit (already clamped to the chromosome, pysam semantics:
+ * reads with pos < hi and end > lo) */
+typedef struct svt_fetch_unit {
+    int32_t tid_a, lo_a, hi_a;
+    int32_t tid_b, lo_b, hi_b;
+} svt_fetch_unit;
+
+typedef struct svt_summarise_args {
+    uint64_t n_units;
+    const svt_fetch_unit* windows;      /* n_units */
+    const svt_breakpoint* breakpoints;  /* n_units: only pos_a / pos_b are read (interval choice) */
+    uint32_t n_read_groups;
+    const char* const* read_groups;     /* RG ids */
+    const int32_t* read_group_lib;      /* library index of each RG; -1 = library not active
+                                           (prevalence below the cut, classic.py:85-87)          */
+    int64_t max_reads;                  /* < 0: unlimited                                         */
+    int32_t count_mode;                 /* 0: classic.py:79-93 (position of the read in the fetch of
+                                           one side > max_reads); 1: singlesample.py:158-185
+                                           (bam.count() of either region > max_reads)            */
+    int32_t n_threads;                  /* <= 0: all hardware threads                             */
+} svt_summarise_args;
+
+typedef struct svt_summaries {
+    uint64_t* frag_offset;    /* n_units + 1, malloc'ed */
+    svt_fragment* fragments;  /* frag_offset[n_units], malloc'ed */
+    uint8_t* skipped;         /* n_units: 1 = too many reads (unit has no fragments) */
+} svt_summaries;
+
+/* Summarise all units (multi-threaded over units; every thread has its own file handle).
+ * On success the three arrays of `out` are owned by the caller: release with svt_summaries_free. */
+int svt_bam_summarise(const svt_bam* bam, const svt_summarise_args* args, svt_summaries* out);
+void svt_summaries_free(svt_summaries* s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SVTYPER_READS_H */

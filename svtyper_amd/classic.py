@@ -21,7 +21,8 @@ from . import __version__
 from . import evidence as ev
 from .bam import open_alignment_file
 from .library import Sample, setup_sample, write_sample_json
-from .pipeline import (MIN_LIB_PREVALENCE, UnitCollector, add_read_to, default_engine, fetch_window)
+from .pipeline import (MIN_LIB_PREVALENCE, NativeUnitCollector, UnitCollector, add_read_to, default_engine,
+                       fetch_window)
 from .results import result_from_record
 from .vcf import VALID_SVTYPES, Variant, Vcf
 
@@ -64,7 +65,8 @@ def apply_result(var: Variant, sample_name: str, rec) -> None:
 
 
 def sv_genotype(bam_string, vcf_in, vcf_out, min_aligned, split_weight, disc_weight, num_samp, lib_info_path,
-                debug, alignment_outpath, ref_fasta, sum_quals, max_reads, max_ci_dist, *, engine=None, geometry="host"):
+                debug, alignment_outpath, ref_fasta, sum_quals, max_reads, max_ci_dist, *, engine=None, geometry="host",
+                reader="python"):
     if alignment_outpath is not None:
         raise NotImplementedError("-w/--write_alignment (evidence BAM dump) is outside the MI355X hot path build")
     bams = []
@@ -90,7 +92,15 @@ def sv_genotype(bam_string, vcf_in, vcf_out, min_aligned, split_weight, disc_wei
     if engine is None:
         engine = default_engine()
     vcf = Vcf()
-    collector = UnitCollector(samples, split_weight, disc_weight, min_aligned, geometry)
+    if reader == "native":      # C++ fetch + summariser, geometry and likelihood on the device
+        from .native_reads import COUNT_CLASSIC, NativeBam
+        native = [NativeBam(p) for p in bam_string.split(",")]
+        collector = NativeUnitCollector(samples, native, split_weight, disc_weight, min_aligned, COUNT_CLASSIC,
+                                        max_reads)
+    elif reader == "python":
+        collector = UnitCollector(samples, split_weight, disc_weight, min_aligned, geometry)
+    else:
+        raise ValueError("reader must be 'python' or 'native'")
     pending: list = []      # ordered output actions of the current chunk
     header_lines: list = []
     in_header = True
@@ -146,10 +156,13 @@ def sv_genotype(bam_string, vcf_in, vcf_out, min_aligned, split_weight, disc_wei
             var2 = var
             var = _take_first_mate(vcf, bp, var2)
 
-        first_unit = len(collector)
-        for k, sample in enumerate(samples):
-            fragments, many = gather_all_reads(sample, bp, max_reads)
-            collector.add(bp, k, fragments, skip=many)
+        if reader == "native":
+            first_unit = collector.add_site(bp)
+        else:
+            first_unit = len(collector)
+            for k, sample in enumerate(samples):
+                fragments, many = gather_all_reads(sample, bp, max_reads)
+                collector.add(bp, k, fragments, skip=many)
         pending.append(("gt", var, var2, first_unit))
         if len(collector) >= CHUNK_UNITS:
             flush()

@@ -3,6 +3,8 @@
 #ifndef SVT_COMMON_H
 #define SVT_COMMON_H
 
+#include "svt_error.h"
+
 namespace svt {
 
 
@@ -18,13 +20,6 @@ constexpr uint32_t kMaxLdsTableBytes = 64 * 1024;  // hist+thr budget before fal
 constexpr uint32_t kMaxL10Lds = 4096;              // log10 table entries kept in LDS (32 KiB)
 constexpr uint32_t kTailPadRows = 16;   // look-ahead loads may run this far past a tile (>= 2 * group)
 
-inline thread_local std::string g_err;
-
-inline int fail(int code, const std::string& msg)
-{
-    g_err = msg;
-    return code;
-}
 
 #define HIP_TRY(expr)                                                                       \
     do {                                                                                    \

@@ -1,0 +1,810 @@
+// svt_reads.cpp -- native BAM access + fragment summariser (include/svtyper_reads.h).
+//
+// Host-only C++ (no HIP): BGZF/BAM/BAI reader with the fetch()/count() semantics the SVTyper path
+// relies on (pysam's, as restated in svtyper_amd/bam.py), read-fragment assembly and split-read QC
+// (svtyper/parsers.py:729-768, 891-1058 as restated in svtyper_amd/fragments.py) and the emission of
+// svt_fragment summaries (svtyper_amd/geometry.py).  The Python modules are the portable
+// implementation and the checker of this file (tests/test_native_reads.py compares the summaries
+// byte for byte); this file exists because per-read Python objects, not the GPU, bound a real run.
+
+#include <zlib.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <set>
+#include <string>
+#include <thread>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/svtyper_reads.h"
+#include "svt_error.h"
+
+namespace {
+
+using svt::fail;
+
+// ------------------------------------------------------------------------------------------
+// BGZF: random access through (compressed offset << 16 | in-block offset) addresses
+// ------------------------------------------------------------------------------------------
+class Bgzf {
+public:
+    explicit Bgzf(const std::string& path) { f_ = std::fopen(path.c_str(), "rb"); }
+    ~Bgzf() { if (f_) std::fclose(f_); }
+    bool ok() const { return f_ != nullptr; }
+    bool failed() const { return bad_; }
+
+    void seek(uint64_t voff)
+    {
+        load(voff >> 16);
+        uoff_ = (size_t)(voff & 0xFFFF);
+    }
+    uint64_t tell() const
+    {
+        if (uoff_ >= block_->data.size() && !block_->data.empty()) return block_->next << 16;
+        return (coff_ << 16) | uoff_;
+    }
+    // returns the number of bytes actually read
+    size_t read(void* dst, size_t n)
+    {
+        size_t got = 0;
+        uint8_t* out = static_cast<uint8_t*>(dst);
+        while (got < n) {
+            const size_t avail = block_ ? block_->data.size() - std::min(uoff_, block_->data.size()) : 0;
+            if (avail == 0) {
+                const uint64_t next = block_ ? block_->next : 0;
+                if (block_ && next == coff_) break;
+                if (!load(next)) break;
+                uoff_ = 0;
+                continue;
+            }
+            const size_t take = std::min(avail, n - got);
+            std::memcpy(out + got, block_->data.data() + uoff_, take);
+            uoff_ += take;
+            got += take;
+        }
+        return got;
+    }
+
+private:
+    struct Block { std::vector<uint8_t> data; uint64_t next = 0; };
+    bool load(uint64_t coff)
+    {
+        auto it = cache_.find(coff);
+        if (it != cache_.end()) {
+            block_ = &it->second;
+            coff_ = coff;
+            return !block_->data.empty() || block_->next > coff;
+        }
+        if (cache_.size() >= 64) cache_.clear();   // regions are walked forward: a simple bound is enough
+        Block b;
+        b.next = coff;
+        uint8_t hdr[18];
+        if (fseeko(f_, (off_t)coff, SEEK_SET) != 0 || std::fread(hdr, 1, 18, f_) != 18) {
+            block_ = &(cache_[coff] = b);
+            coff_ = coff;
+            return false;
+        }
+        if (hdr[0] != 31 || hdr[1] != 139) { bad_ = true; block_ = &(cache_[coff] = b); coff_ = coff; return false; }
+        const unsigned xlen = hdr[10] | (hdr[11] << 8);
+        std::vector<uint8_t> extra(xlen);
+        std::memcpy(extra.data(), hdr + 12, std::min<size_t>(6, xlen));
+        if (xlen > 6 && std::fread(extra.data() + 6, 1, xlen - 6, f_) != xlen - 6) bad_ = true;
+        int bsize = -1;
+        for (size_t i = 0; i + 4 <= extra.size();) {
+            const unsigned slen = extra[i + 2] | (extra[i + 3] << 8);
+            if (extra[i] == 66 && extra[i + 1] == 67 && i + 6 <= extra.size()) bsize = extra[i + 4] | (extra[i + 5] << 8);
+            i += 4 + slen;
+        }
+        if (bsize < 0) { bad_ = true; block_ = &(cache_[coff] = b); coff_ = coff; return false; }
+        const int clen = bsize - (int)xlen - 19;
+        std::vector<uint8_t> cdata((size_t)std::max(clen, 0));
+        uint8_t tail[8];
+        if ((clen > 0 && std::fread(cdata.data(), 1, (size_t)clen, f_) != (size_t)clen) || std::fread(tail, 1, 8, f_) != 8) bad_ = true;
+        const uint32_t isize = tail[4] | (tail[5] << 8) | (tail[6] << 16) | ((uint32_t)tail[7] << 24);
+        b.data.resize(isize);
+        if (isize) {
+            z_stream zs;
+            std::memset(&zs, 0, sizeof zs);
+            if (inflateInit2(&zs, -15) != Z_OK) bad_ = true;
+            zs.next_in = cdata.data();
+            zs.avail_in = (uInt)cdata.size();
+            zs.next_out = b.data.data();
+            zs.avail_out = (uInt)b.data.size();
+            if (inflate(&zs, Z_FINISH) != Z_STREAM_END) bad_ = true;
+            inflateEnd(&zs);
+        }
+        b.next = coff + (uint64_t)bsize + 1;
+        block_ = &(cache_[coff] = std::move(b));
+        coff_ = coff;
+        return true;
+    }
+
+    FILE* f_ = nullptr;
+    std::unordered_map<uint64_t, Block> cache_;
+    Block empty_;
+    Block* block_ = &empty_;
+    uint64_t coff_ = 0;
+    size_t uoff_ = 0;
+    bool bad_ = false;
+};
+
+// ------------------------------------------------------------------------------------------
+// CIGAR helpers (svtyper_amd/fragments.py, svtyper/parsers.py:922-947,1062-1101,1242-1253)
+// ------------------------------------------------------------------------------------------
+typedef std::vector<std::pair<int, int64_t>> Cigar;   // (op, len)
+inline bool is_clip(int op) { return op == 4 || op == 5; }
+inline bool consumes_ref(int op) { return op == 0 || op == 2 || op == 3 || op == 7 || op == 8; }
+inline bool consumes_query(int op) { return op == 0 || op == 1 || op == 7 || op == 8; }
+inline bool is_aligned(int op) { return op == 0 || op == 7 || op == 8; }
+
+struct QueryPos { int64_t start = 0, end = 0, length = 0; };
+
+QueryPos query_pos_from_cigar(const Cigar& cigar, bool reverse)
+{
+    QueryPos q;
+    const size_t n = cigar.size();
+    for (size_t i = 0; i < n; ++i) {
+        const auto& c = reverse ? cigar[n - 1 - i] : cigar[i];
+        if (is_clip(c.first)) {
+            if (i == 0) { q.start += c.second; q.end += c.second; }
+            q.length += c.second;
+        } else if (consumes_query(c.first)) {
+            q.end += c.second;
+            q.length += c.second;
+        }
+    }
+    return q;
+}
+
+bool left_clipped(const Cigar& c)
+{
+    const bool lc = is_clip(c.front().first), rc = is_clip(c.back().first);
+    return (lc && !rc) || (lc && rc && c.front().second > c.back().second);
+}
+
+bool parse_cigar_string(const std::string& s, Cigar& out)
+{
+    static const char* ops = "MIDNSHP=X";
+    int64_t num = 0;
+    bool have = false;
+    for (char ch : s) {
+        if (ch >= '0' && ch <= '9') { num = num * 10 + (ch - '0'); have = true; continue; }
+        const char* p = std::strchr(ops, ch);
+        if (!p || !have) return false;
+        out.emplace_back((int)(p - ops), num);
+        num = 0;
+        have = false;
+    }
+    return !have;
+}
+
+// ------------------------------------------------------------------------------------------
+// reads, pieces, fragments
+// ------------------------------------------------------------------------------------------
+struct Piece {
+    int32_t tid = 0;          // -2: dummy piece (chrom None); -3: chromosome not in the header
+    int64_t start = 0, end = 0;
+    bool reverse = false;
+    int64_t mapq = 0;
+    Cigar cigar;
+    QueryPos qp;
+};
+
+struct ReadInfo {
+    int32_t tid = -1;
+    int64_t start = 0, end = 0;
+    bool reverse = false;
+    int mapq = 0;
+    std::vector<std::pair<int64_t, int64_t>> intervals;   // maximal gap-free aligned reference intervals
+};
+
+struct Split {
+    bool soft = false;
+    Piece left, right;
+};
+
+struct Fragment {
+    int lib = 0;
+    int num_primary = 0;
+    std::set<uint16_t> seen;          // flags already added under this query name (parsers.py:748-754)
+    std::vector<ReadInfo> primaries;
+    std::vector<Split> splits;
+};
+
+struct Record {               // one BAM alignment, decoded as far as the path needs
+    int32_t tid = -1;
+    int64_t pos = 0, end = 0;
+    uint16_t flag = 0;
+    int mapq = 0;
+    int64_t l_seq = 0;
+    std::string name;
+    Cigar cigar;
+    const uint8_t* tags = nullptr;
+    size_t tags_len = 0;
+};
+
+// Z-typed tag value or nullptr; walks the tag area like svtyper_amd/bam.py::_parse_tags
+const char* find_z_tag(const Record& r, char k0, char k1, bool* malformed)
+{
+    const uint8_t* b = r.tags;
+    size_t i = 0, n = r.tags_len;
+    while (i + 3 <= n) {
+        const char a0 = (char)b[i], a1 = (char)b[i + 1], t = (char)b[i + 2];
+        i += 3;
+        size_t skip = 0;
+        switch (t) {
+        case 'A': case 'c': case 'C': skip = 1; break;
+        case 's': case 'S': skip = 2; break;
+        case 'i': case 'I': case 'f': skip = 4; break;
+        case 'Z': case 'H': {
+            const void* z = std::memchr(b + i, 0, n - i);
+            if (!z) { *malformed = true; return nullptr; }
+            if (a0 == k0 && a1 == k1 && t == 'Z') return reinterpret_cast<const char*>(b + i);
+            skip = (size_t)(static_cast<const uint8_t*>(z) - (b + i)) + 1;
+            break;
+        }
+        case 'B': {
+            if (i + 5 > n) { *malformed = true; return nullptr; }
+            const char sub = (char)b[i];
+            const uint32_t cnt = b[i + 1] | (b[i + 2] << 8) | (b[i + 3] << 16) | ((uint32_t)b[i + 4] << 24);
+            const size_t sz = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : 4;
+            skip = 5 + (size_t)cnt * sz;
+            break;
+        }
+        default: *malformed = true; return nullptr;
+        }
+        i += skip;
+    }
+    return nullptr;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+// the BAM handle: header + index (shared, read-only); file handles are per thread
+// ------------------------------------------------------------------------------------------
+struct svt_bam {
+    std::string path;
+    std::string text;
+    std::vector<std::string> ref_names;
+    std::vector<int64_t> ref_lengths;
+    std::unordered_map<std::string, int32_t> tid_of;
+    uint64_t first_record = 0;
+    struct RefIndex {
+        std::unordered_map<uint32_t, std::vector<std::pair<uint64_t, uint64_t>>> bins;
+        std::vector<uint64_t> linear;
+    };
+    std::vector<RefIndex> index;
+    bool has_index = false;
+};
+
+namespace {
+
+void reg2bins(int64_t beg, int64_t end, std::vector<uint32_t>& bins)
+{
+    --end;
+    bins.clear();
+    bins.push_back(0);
+    const int shifts[5] = {26, 23, 20, 17, 14};
+    const uint32_t offs[5] = {1, 9, 73, 585, 4681};
+    for (int l = 0; l < 5; ++l)
+        for (int64_t k = offs[l] + (beg >> shifts[l]); k <= (int64_t)offs[l] + (end >> shifts[l]); ++k) bins.push_back((uint32_t)k);
+}
+
+bool read_record(Bgzf& z, std::vector<uint8_t>& buf, Record& r)
+{
+    uint8_t szb[4];
+    if (z.read(szb, 4) != 4) return false;
+    const uint32_t size = szb[0] | (szb[1] << 8) | (szb[2] << 16) | ((uint32_t)szb[3] << 24);
+    if (size < 32) return false;
+    buf.resize(size);
+    if (z.read(buf.data(), size) != size) return false;
+    const uint8_t* d = buf.data();
+    auto u32 = [&](size_t o) { return (uint32_t)d[o] | (d[o + 1] << 8) | (d[o + 2] << 16) | ((uint32_t)d[o + 3] << 24); };
+    r.tid = (int32_t)u32(0);
+    r.pos = (int32_t)u32(4);
+    const unsigned l_name = d[8];
+    r.mapq = d[9];
+    const unsigned n_cigar = d[12] | (d[13] << 8);
+    r.flag = (uint16_t)(d[14] | (d[15] << 8));
+    r.l_seq = (int32_t)u32(16);
+    size_t off = 32;
+    if (off + l_name + 4ull * n_cigar > size) return false;
+    r.name.assign(reinterpret_cast<const char*>(d + off), l_name ? l_name - 1 : 0);
+    off += l_name;
+    r.cigar.clear();
+    r.end = r.pos;
+    for (unsigned k = 0; k < n_cigar; ++k) {
+        const uint32_t c = u32(off + 4 * k);
+        const int op = (int)(c & 0xF);
+        const int64_t len = c >> 4;
+        r.cigar.emplace_back(op, len);
+        if (consumes_ref(op)) r.end += len;
+    }
+    off += 4ull * n_cigar;
+    off += (size_t)((r.l_seq + 1) / 2 + r.l_seq);
+    if (off > size) return false;
+    r.tags = d + off;
+    r.tags_len = size - off;
+    return true;
+}
+
+// pysam-style fetch: records with pos < end and reference end > beg, in file order; `fn` returns
+// false to stop.  Mirrors svtyper_amd/bam.py::AlignmentFile.fetch.
+template <typename Fn>
+bool fetch(const svt_bam& bam, Bgzf& z, int32_t tid, int64_t beg, int64_t end, std::vector<uint8_t>& buf, Fn&& fn)
+{
+    if (tid < 0 || tid >= (int32_t)bam.ref_names.size()) return false;
+    beg = std::max<int64_t>(beg, 0);
+    if (end <= beg) return true;
+    const auto& ri = bam.index[tid];
+    uint64_t min_off = 0;
+    const size_t li = (size_t)(beg >> 14);
+    if (!ri.linear.empty()) min_off = li < ri.linear.size() ? ri.linear[li] : ri.linear.back();
+    std::vector<uint32_t> bins;
+    reg2bins(beg, end, bins);
+    std::vector<std::pair<uint64_t, uint64_t>> chunks;
+    for (uint32_t b : bins) {
+        auto it = ri.bins.find(b);
+        if (it == ri.bins.end()) continue;
+        for (const auto& c : it->second)
+            if (c.second > min_off) chunks.push_back(c);
+    }
+    if (chunks.empty()) return true;
+    std::sort(chunks.begin(), chunks.end());
+    std::vector<std::pair<uint64_t, uint64_t>> merged;
+    merged.push_back(chunks[0]);
+    for (size_t i = 1; i < chunks.size(); ++i) {
+        if (chunks[i].first <= merged.back().second) merged.back().second = std::max(merged.back().second, chunks[i].second);
+        else merged.push_back(chunks[i]);
+    }
+    Record r;
+    for (const auto& c : merged) {
+        z.seek(c.first);
+        while (z.tell() < c.second) {
+            if (!read_record(z, buf, r)) break;
+            if (r.tid != tid || r.pos >= end) return true;
+            int64_t rend = r.end;
+            if (r.cigar.empty() || rend <= r.pos) rend = r.pos + 1;
+            if (rend > beg)
+                if (!fn(r)) return true;
+        }
+    }
+    return !z.failed();
+}
+
+// SplitRead.is_valid (parsers.py:959-1058 / fragments.py) -> fills `out` when the candidate is valid
+// returns 1 valid, 0 invalid, -1 malformed input
+int split_candidate(const svt_bam& bam, const Record& r, Split& out)
+{
+    bool malformed = false;
+    const char* sa = find_z_tag(r, 'S', 'A', &malformed);
+    if (malformed) return -1;
+    Piece a;
+    a.tid = r.tid;
+    a.start = r.pos;
+    a.end = r.end;
+    a.reverse = (r.flag & 0x10) != 0;
+    a.mapq = r.mapq;
+    a.cigar = r.cigar;
+    a.qp = query_pos_from_cigar(a.cigar, a.reverse);
+    if (!sa) {
+        if (r.cigar.empty()) return -1;
+        const bool fc = is_clip(r.cigar.front().first), lc = is_clip(r.cigar.back().first);
+        if (!(fc || lc)) return 0;
+        const int64_t clip_length = std::max(r.cigar.front().second * (fc ? 1 : 0), r.cigar.back().second * (lc ? 1 : 0));
+        int64_t q_aln = 0;
+        for (const auto& c : r.cigar) if (consumes_query(c.first)) q_aln += c.second;
+        if (clip_length > 0 && (r.l_seq - q_aln) <= 50) {
+            Piece dummy;
+            dummy.tid = -2;
+            dummy.start = 1;
+            dummy.end = 1;
+            dummy.reverse = a.reverse;
+            dummy.mapq = 0;
+            dummy.cigar = r.cigar;
+            dummy.qp = query_pos_from_cigar(dummy.cigar, dummy.reverse);
+            out.soft = true;
+            if (left_clipped(a.cigar)) { out.left = dummy; out.right = a; }
+            else { out.left = a; out.right = dummy; }
+            return 1;
+        }
+        return 0;
+    }
+    // SA:Z:chrom,pos,strand,CIGAR,mapQ,NM;...   more than one entry -> discarded (:992-993)
+    std::string s(sa);
+    while (!s.empty() && s.back() == ';') s.pop_back();
+    if (s.find(';') != std::string::npos) return 0;
+    std::vector<std::string> fld;
+    size_t p0 = 0;
+    for (;;) {
+        const size_t p1 = s.find(',', p0);
+        fld.push_back(s.substr(p0, p1 == std::string::npos ? std::string::npos : p1 - p0));
+        if (p1 == std::string::npos) break;
+        p0 = p1 + 1;
+    }
+    if (fld.size() < 5) return -1;
+    char* endp = nullptr;
+    const long long mate_pos1 = std::strtoll(fld[1].c_str(), &endp, 10);
+    if (*endp || fld[1].empty()) return -1;
+    const long long mate_mapq = std::strtoll(fld[4].c_str(), &endp, 10);
+    if (*endp || fld[4].empty()) return -1;
+    Piece b;
+    auto it = bam.tid_of.find(fld[0]);
+    b.tid = it == bam.tid_of.end() ? -3 : it->second;
+    b.start = mate_pos1 - 1;
+    b.reverse = fld[2] == "-";
+    if (!parse_cigar_string(fld[3], b.cigar)) return -1;
+    b.mapq = mate_mapq;
+    b.end = b.start;
+    for (const auto& c : b.cigar) if (consumes_ref(c.first)) b.end += c.second;
+    b.qp = query_pos_from_cigar(b.cigar, b.reverse);
+    const bool same_chrom = r.tid >= 0 && bam.ref_names[r.tid] == fld[0];
+    out.soft = false;
+    if (same_chrom) {
+        if (r.pos > b.start) { out.left = b; out.right = a; }
+        else { out.left = a; out.right = b; }
+    } else if (a.cigar.empty()) {
+        return -1;
+    } else if (left_clipped(a.cigar)) {
+        out.left = b; out.right = a;
+    } else {
+        out.left = a; out.right = b;
+    }
+    const QueryPos &l = out.left.qp, &rq = out.right.qp;
+    const int64_t shared = std::max<int64_t>(0, 1 + std::min(l.end, rq.end) - std::max(l.start, rq.start));
+    const int64_t non_overlap = std::min(1 + l.end - l.start - shared, 1 + rq.end - rq.start - shared);
+    if (non_overlap < 20) return 0;
+    if (out.left.tid == out.right.tid && out.left.reverse == out.right.reverse) {
+        auto start_diag = [](const Piece& p) { return p.start - (p.reverse ? p.qp.length - p.qp.end : p.qp.start); };
+        auto end_diag = [](const Piece& p) { return p.end - (p.reverse ? p.qp.length - p.qp.start : p.qp.end); };
+        const int64_t ins = out.left.reverse ? end_diag(out.right) - start_diag(out.left)
+                                             : end_diag(out.left) - start_diag(out.right);
+        if (std::llabs(ins) < 50) return 0;
+        const int64_t desert = rq.start - l.end - 1;
+        if (desert > 0 && desert - std::max<int64_t>(0, ins) > 50) return 0;
+    }
+    return 1;
+}
+
+void aligned_intervals(const Record& r, std::vector<std::pair<int64_t, int64_t>>& out)
+{
+    out.clear();
+    int64_t p = r.pos;
+    bool open = false;
+    for (const auto& c : r.cigar) {
+        if (is_aligned(c.first)) {
+            if (!open) { out.emplace_back(p, p + c.second); open = true; }
+            else out.back().second = p + c.second;
+            p += c.second;
+        } else if (c.first == 2 || c.first == 3) {
+            open = false;
+            p += c.second;
+        }
+    }
+}
+
+inline int32_t clip32(int64_t x) { return (int32_t)std::max<int64_t>(INT32_MIN, std::min<int64_t>(INT32_MAX, x)); }
+
+void fill_read(svt_read_summary& d, const ReadInfo& r, int64_t near_a, int64_t near_b)
+{
+    d.tid = r.tid;
+    d.start = clip32(r.start);
+    d.end = clip32(r.end);
+    std::vector<std::pair<int64_t, int64_t>> ivs = r.intervals;
+    if (ivs.size() > 2) {
+        auto dist = [&](const std::pair<int64_t, int64_t>& iv) {
+            auto one = [&](int64_t q) { return (iv.first <= q && q <= iv.second) ? (int64_t)0 : std::min(std::llabs(iv.first - q), std::llabs(iv.second - q)); };
+            return std::min(one(near_a), one(near_b));
+        };
+        std::stable_sort(ivs.begin(), ivs.end(), [&](const auto& x, const auto& y) { return dist(x) < dist(y); });
+        ivs.resize(2);
+    }
+    for (size_t k = 0; k < ivs.size(); ++k) {
+        d.iv_start[k] = clip32(ivs[k].first);
+        d.iv_end[k] = clip32(ivs[k].second);
+    }
+    d.mapq = (uint8_t)r.mapq;
+    d.flags = (uint8_t)(SVT_READ_PRESENT | (r.reverse ? SVT_READ_REVERSE : 0));
+}
+
+bool fill_piece(svt_piece_summary& d, const Piece& p)
+{
+    if (p.mapq < 0 || p.mapq > 255) return false;
+    d.tid = p.tid;
+    d.start = clip32(p.start);
+    d.end = clip32(p.end);
+    d.mapq = (uint8_t)p.mapq;
+    d.flags = (uint8_t)(SVT_READ_PRESENT | (p.reverse ? SVT_READ_REVERSE : 0));
+    return true;
+}
+
+struct UnitOut {
+    std::vector<svt_fragment> frags;
+    bool skipped = false;
+};
+
+// one unit: gather reads of both windows, assemble fragments, emit summaries
+int process_unit(const svt_bam& bam, Bgzf& z, std::vector<uint8_t>& buf, const svt_summarise_args& A,
+                 const std::unordered_map<std::string, int32_t>& rg_lib, uint64_t u, UnitOut& out, std::string& err)
+{
+    const svt_fetch_unit& w = A.windows[u];
+    const int32_t tids[2] = {w.tid_a, w.tid_b};
+    const int64_t los[2] = {w.lo_a, w.lo_b}, his[2] = {w.hi_a, w.hi_b};
+    std::map<std::string, Fragment> frags;   // ordered by name == Python's sorted() for ASCII names
+    int rc = SVT_OK;
+
+    if (A.count_mode == 1 && A.max_reads >= 0) {   // singlesample.py:158-185
+        for (int s = 0; s < 2; ++s) {
+            int64_t n = 0;
+            if (!fetch(bam, z, tids[s], los[s], his[s], buf, [&](const Record& r) {
+                    if (!(r.flag & (0x4 | 0x100 | 0x200 | 0x400))) ++n;
+                    return true;
+                })) { err = "BAM read error"; return SVT_ERR_INVALID; }
+            if (n > A.max_reads) { out.skipped = true; return SVT_OK; }
+        }
+    }
+    for (int s = 0; s < 2 && !out.skipped; ++s) {
+        int64_t i = -1;
+        const bool ok = fetch(bam, z, tids[s], los[s], his[s], buf, [&](const Record& r) {
+            ++i;                                                        // enumerate() index of classic.py:79
+            if (r.flag & (0x4 | 0x400)) return true;                   // unmapped / duplicate
+            bool malformed = false;
+            const char* rg = find_z_tag(r, 'R', 'G', &malformed);
+            if (malformed || !rg) { err = "read without a usable RG tag: " + r.name; rc = SVT_ERR_INVALID; return false; }
+            auto it = rg_lib.find(rg);
+            if (it == rg_lib.end()) { err = std::string("read group not in the library table: ") + rg; rc = SVT_ERR_INVALID; return false; }
+            if (it->second < 0) return true;                            // library below the prevalence cut
+            if (A.count_mode == 0 && A.max_reads >= 0 && i > A.max_reads) { out.skipped = true; return false; }
+            auto fit = frags.find(r.name);
+            if (fit == frags.end()) {
+                fit = frags.emplace(r.name, Fragment()).first;
+                fit->second.lib = it->second;                           // SamFragment(read, lib)
+            }
+            Fragment& f = fit->second;
+            if (!f.seen.insert(r.flag).second) return true;             // same (name, flag) again
+            if (r.flag & (0x100 | 0x800)) return true;                  // secondary / supplementary
+            ReadInfo ri;
+            ri.tid = r.tid;
+            ri.start = r.pos;
+            ri.end = r.end;
+            ri.reverse = (r.flag & 0x10) != 0;
+            ri.mapq = r.mapq;
+            aligned_intervals(r, ri.intervals);
+            f.primaries.push_back(std::move(ri));
+            f.num_primary += 1;
+            Split sp;
+            const int v = split_candidate(bam, r, sp);
+            if (v < 0) { err = "malformed SA tag / CIGAR at read " + r.name; rc = SVT_ERR_INVALID; return false; }
+            if (v > 0) f.splits.push_back(std::move(sp));
+            return true;
+        });
+        if (rc != SVT_OK) return rc;
+        if (!ok) { err = "BAM read error"; return SVT_ERR_INVALID; }
+    }
+    if (out.skipped) { out.frags.clear(); return SVT_OK; }
+
+    const int64_t near_a = A.breakpoints[u].pos_a, near_b = A.breakpoints[u].pos_b;
+    for (const auto& kv : frags) {
+        const Fragment& f = kv.second;
+        std::vector<const Split*> seq, clip;
+        for (const Split& s : f.splits) (s.soft ? clip : seq).push_back(&s);
+        const size_t n_rec = std::max<size_t>({(size_t)1, (f.primaries.size() + 1) / 2, seq.size(), clip.size()});
+        for (size_t k = 0; k < n_rec; ++k) {
+            svt_fragment fr;
+            std::memset(&fr, 0, sizeof fr);
+            fr.read[0].tid = fr.read[1].tid = -1;
+            for (int j = 0; j < 2; ++j)
+                if (2 * k + j < f.primaries.size()) fill_read(fr.read[j], f.primaries[2 * k + j], near_a, near_b);
+            fr.read[0].reserved = (uint16_t)f.lib;
+            fr.read[1].reserved = (uint16_t)(((k == 0 && f.num_primary == 2) ? SVT_FRAG_PAIR : 0) | (k > 0 ? SVT_FRAG_CONTINUATION : 0));
+            bool ok = true;
+            if (k < seq.size()) ok = fill_piece(fr.seq[0], seq[k]->left) && fill_piece(fr.seq[1], seq[k]->right);
+            if (ok && k < clip.size()) ok = fill_piece(fr.clip[0], clip[k]->left) && fill_piece(fr.clip[1], clip[k]->right);
+            if (!ok) { err = "MAPQ outside 0..255 in an SA tag of fragment " + kv.first; return SVT_ERR_INVALID; }
+            out.frags.push_back(fr);
+        }
+    }
+    return SVT_OK;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------
+extern "C" {
+
+int svt_bam_open(const char* path, svt_bam** out)
+{
+    if (!path || !out) return fail(SVT_ERR_INVALID, "null argument");
+    *out = nullptr;
+    Bgzf z(path);
+    if (!z.ok()) return fail(SVT_ERR_INVALID, std::string("cannot open ") + path);
+    std::unique_ptr<svt_bam> b(new svt_bam());
+    b->path = path;
+    uint8_t magic[4];
+    z.seek(0);
+    auto rd32 = [&](int32_t& v) {
+        uint8_t t[4];
+        if (z.read(t, 4) != 4) return false;
+        v = (int32_t)((uint32_t)t[0] | (t[1] << 8) | (t[2] << 16) | ((uint32_t)t[3] << 24));
+        return true;
+    };
+    int32_t l_text = 0, n_ref = 0;
+    if (z.read(magic, 4) != 4 || std::memcmp(magic, "BAM\1", 4) != 0 || !rd32(l_text) || l_text < 0)
+        return fail(SVT_ERR_INVALID, std::string(path) + " is not a BAM file");
+    b->text.resize((size_t)l_text);
+    if (l_text && z.read(&b->text[0], (size_t)l_text) != (size_t)l_text) return fail(SVT_ERR_INVALID, "truncated BAM header");
+    b->text = b->text.c_str();   // cut at the first NUL
+    if (!rd32(n_ref) || n_ref < 0) return fail(SVT_ERR_INVALID, "truncated BAM header");
+    for (int32_t i = 0; i < n_ref; ++i) {
+        int32_t l_name = 0, l_ref = 0;
+        if (!rd32(l_name) || l_name <= 0) return fail(SVT_ERR_INVALID, "truncated BAM header");
+        std::string name((size_t)l_name, '\0');
+        if (z.read(&name[0], (size_t)l_name) != (size_t)l_name || !rd32(l_ref)) return fail(SVT_ERR_INVALID, "truncated BAM header");
+        name.resize((size_t)l_name - 1);
+        b->tid_of[name] = i;
+        b->ref_names.push_back(name);
+        b->ref_lengths.push_back(l_ref);
+    }
+    b->first_record = z.tell();
+    // index: <path>.bai, else the .bai next to the file
+    std::string cand[2] = {b->path + ".bai", b->path};
+    const size_t dot = cand[1].rfind('.');
+    if (dot != std::string::npos) cand[1] = cand[1].substr(0, dot) + ".bai";
+    for (const std::string& p : cand) {
+        FILE* f = std::fopen(p.c_str(), "rb");
+        if (!f) continue;
+        std::vector<uint8_t> data;
+        uint8_t tmp[65536];
+        size_t n;
+        while ((n = std::fread(tmp, 1, sizeof tmp, f)) > 0) data.insert(data.end(), tmp, tmp + n);
+        std::fclose(f);
+        if (data.size() < 8 || std::memcmp(data.data(), "BAI\1", 4) != 0) return fail(SVT_ERR_INVALID, p + " is not a BAI index");
+        size_t off = 4;
+        auto u32 = [&](size_t o) { return (uint32_t)data[o] | (data[o + 1] << 8) | (data[o + 2] << 16) | ((uint32_t)data[o + 3] << 24); };
+        auto u64 = [&](size_t o) { return (uint64_t)u32(o) | ((uint64_t)u32(o + 4) << 32); };
+        const uint32_t nr = u32(off);
+        off += 4;
+        b->index.resize(nr);
+        for (uint32_t r = 0; r < nr; ++r) {
+            if (off + 4 > data.size()) return fail(SVT_ERR_INVALID, "truncated BAI");
+            const uint32_t n_bin = u32(off);
+            off += 4;
+            for (uint32_t k = 0; k < n_bin; ++k) {
+                if (off + 8 > data.size()) return fail(SVT_ERR_INVALID, "truncated BAI");
+                const uint32_t bin = u32(off), n_chunk = u32(off + 4);
+                off += 8;
+                if (off + 16ull * n_chunk > data.size()) return fail(SVT_ERR_INVALID, "truncated BAI");
+                if (bin != 37450) {
+                    auto& v = b->index[r].bins[bin];
+                    for (uint32_t c = 0; c < n_chunk; ++c) v.emplace_back(u64(off + 16 * c), u64(off + 16 * c + 8));
+                }
+                off += 16ull * n_chunk;
+            }
+            if (off + 4 > data.size()) return fail(SVT_ERR_INVALID, "truncated BAI");
+            const uint32_t n_intv = u32(off);
+            off += 4;
+            if (off + 8ull * n_intv > data.size()) return fail(SVT_ERR_INVALID, "truncated BAI");
+            for (uint32_t k = 0; k < n_intv; ++k) b->index[r].linear.push_back(u64(off + 8 * k));
+            off += 8ull * n_intv;
+        }
+        b->has_index = true;
+        break;
+    }
+    if (!b->has_index) return fail(SVT_ERR_INVALID, std::string("no .bai index found for ") + path);
+    if (b->index.size() < b->ref_names.size()) b->index.resize(b->ref_names.size());
+    *out = b.release();
+    return SVT_OK;
+}
+
+void svt_bam_close(svt_bam* bam) { delete bam; }
+
+int32_t svt_bam_n_references(const svt_bam* bam) { return bam ? (int32_t)bam->ref_names.size() : 0; }
+
+const char* svt_bam_reference_name(const svt_bam* bam, int32_t tid)
+{
+    return (bam && tid >= 0 && tid < (int32_t)bam->ref_names.size()) ? bam->ref_names[tid].c_str() : nullptr;
+}
+
+int64_t svt_bam_reference_length(const svt_bam* bam, int32_t tid)
+{
+    return (bam && tid >= 0 && tid < (int32_t)bam->ref_lengths.size()) ? bam->ref_lengths[tid] : -1;
+}
+
+int32_t svt_bam_tid(const svt_bam* bam, const char* name)
+{
+    if (!bam || !name) return -1;
+    auto it = bam->tid_of.find(name);
+    return it == bam->tid_of.end() ? -1 : it->second;
+}
+
+const char* svt_bam_header_text(const svt_bam* bam) { return bam ? bam->text.c_str() : nullptr; }
+
+int svt_bam_summarise(const svt_bam* bam, const svt_summarise_args* args, svt_summaries* out)
+{
+    if (!bam || !args || !out) return fail(SVT_ERR_INVALID, "null argument");
+    out->frag_offset = nullptr;
+    out->fragments = nullptr;
+    out->skipped = nullptr;
+    const uint64_t n = args->n_units;
+    if (n && (!args->windows || !args->breakpoints)) return fail(SVT_ERR_INVALID, "null unit arrays");
+    std::unordered_map<std::string, int32_t> rg_lib;
+    for (uint32_t i = 0; i < args->n_read_groups; ++i) rg_lib[args->read_groups[i]] = args->read_group_lib[i];
+
+    std::vector<UnitOut> outs(n);
+    unsigned nt = args->n_threads > 0 ? (unsigned)args->n_threads : std::thread::hardware_concurrency();
+    nt = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(nt ? nt : 1, n ? n : 1));
+    std::atomic<uint64_t> next(0);
+    std::atomic<int> first_rc(SVT_OK);
+    std::mutex err_lock;
+    std::string first_err;
+    auto worker = [&]() {
+        Bgzf z(bam->path);
+        std::vector<uint8_t> buf;
+        if (!z.ok()) {
+            std::lock_guard<std::mutex> g(err_lock);
+            if (first_rc.exchange(SVT_ERR_INVALID) == SVT_OK) first_err = "cannot reopen " + bam->path;
+            return;
+        }
+        for (;;) {
+            const uint64_t u = next.fetch_add(1);
+            if (u >= n || first_rc.load() != SVT_OK) return;
+            std::string err;
+            const int rc = process_unit(*bam, z, buf, *args, rg_lib, u, outs[u], err);
+            if (rc != SVT_OK) {
+                std::lock_guard<std::mutex> g(err_lock);
+                if (first_rc.exchange(rc) == SVT_OK) first_err = err;
+                return;
+            }
+        }
+    };
+    if (nt <= 1) worker();
+    else {
+        std::vector<std::thread> pool;
+        for (unsigned t = 0; t < nt; ++t) pool.emplace_back(worker);
+        for (auto& th : pool) th.join();
+    }
+    if (first_rc.load() != SVT_OK) return fail(first_rc.load(), first_err);
+
+    uint64_t total = 0;
+    for (const auto& o : outs) total += o.frags.size();
+    out->frag_offset = static_cast<uint64_t*>(std::malloc((n + 1) * sizeof(uint64_t)));
+    out->fragments = static_cast<svt_fragment*>(std::malloc(std::max<uint64_t>(total, 1) * sizeof(svt_fragment)));
+    out->skipped = static_cast<uint8_t*>(std::malloc(std::max<uint64_t>(n, 1)));
+    if (!out->frag_offset || !out->fragments || !out->skipped) {
+        svt_summaries_free(out);
+        return fail(SVT_ERR_NOMEM, "out of host memory");
+    }
+    uint64_t off = 0;
+    for (uint64_t u = 0; u < n; ++u) {
+        out->frag_offset[u] = off;
+        if (!outs[u].frags.empty()) std::memcpy(out->fragments + off, outs[u].frags.data(), outs[u].frags.size() * sizeof(svt_fragment));
+        off += outs[u].frags.size();
+        out->skipped[u] = outs[u].skipped ? 1 : 0;
+    }
+    out->frag_offset[n] = off;
+    return SVT_OK;
+}
+
+void svt_summaries_free(svt_summaries* s)
+{
+    if (!s) return;
+    std::free(s->frag_offset);
+    std::free(s->fragments);
+    std::free(s->skipped);
+    s->frag_offset = nullptr;
+    s->fragments = nullptr;
+    s->skipped = nullptr;
+}
+
+}  // extern "C"

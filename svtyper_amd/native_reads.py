@@ -1,0 +1,126 @@
+"""ctypes binding of the native BAM reader + fragment summariser (include/svtyper_reads.h).
+
+`NativeBam` offers the handful of `pysam.AlignmentFile` attributes the library / sample layer needs
+(header['RG'], references, lengths, gettid) and `summarise()`, which fetches, assembles and
+condenses the read-fragments of many (breakpoint, sample) units in C++ threads.  The summaries feed
+the device geometry stage directly (`geometry="device"`), so with `reader="native"` no per-read
+Python object is created at all.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import hip
+from .geometry import BREAKPOINT_DTYPE, FRAGMENT_DTYPE
+
+FETCH_DTYPE = np.dtype([("tid_a", "<i4"), ("lo_a", "<i4"), ("hi_a", "<i4"),
+                        ("tid_b", "<i4"), ("lo_b", "<i4"), ("hi_b", "<i4")])
+assert FETCH_DTYPE.itemsize == 24
+
+COUNT_CLASSIC, COUNT_SSO = 0, 1
+
+
+class _Args(C.Structure):
+    _fields_ = [("n_units", C.c_uint64), ("windows", C.c_void_p), ("breakpoints", C.c_void_p),
+                ("n_read_groups", C.c_uint32), ("read_groups", C.POINTER(C.c_char_p)),
+                ("read_group_lib", C.POINTER(C.c_int32)), ("max_reads", C.c_int64), ("count_mode", C.c_int32),
+                ("n_threads", C.c_int32)]
+
+
+class _Summaries(C.Structure):
+    _fields_ = [("frag_offset", C.POINTER(C.c_uint64)), ("fragments", C.c_void_p), ("skipped", C.POINTER(C.c_uint8))]
+
+
+_declared = False
+
+
+def _lib():
+    global _declared
+    L = hip.load()
+    if not _declared:
+        L.svt_bam_open.restype = C.c_int
+        L.svt_bam_open.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
+        L.svt_bam_close.restype = None
+        L.svt_bam_close.argtypes = [C.c_void_p]
+        L.svt_bam_n_references.restype = C.c_int32
+        L.svt_bam_n_references.argtypes = [C.c_void_p]
+        L.svt_bam_reference_name.restype = C.c_char_p
+        L.svt_bam_reference_name.argtypes = [C.c_void_p, C.c_int32]
+        L.svt_bam_reference_length.restype = C.c_int64
+        L.svt_bam_reference_length.argtypes = [C.c_void_p, C.c_int32]
+        L.svt_bam_tid.restype = C.c_int32
+        L.svt_bam_tid.argtypes = [C.c_void_p, C.c_char_p]
+        L.svt_bam_header_text.restype = C.c_char_p
+        L.svt_bam_header_text.argtypes = [C.c_void_p]
+        L.svt_bam_summarise.restype = C.c_int
+        L.svt_bam_summarise.argtypes = [C.c_void_p, C.POINTER(_Args), C.POINTER(_Summaries)]
+        L.svt_summaries_free.restype = None
+        L.svt_summaries_free.argtypes = [C.POINTER(_Summaries)]
+        _declared = True
+    return L
+
+
+class NativeBam:
+    """An indexed BAM opened by the C++ reader."""
+
+    def __init__(self, path: str):
+        L = _lib()
+        self._L = L
+        self._h = C.c_void_p()
+        hip._check(L.svt_bam_open(path.encode(), C.byref(self._h)))
+        self.filename = path
+        n = L.svt_bam_n_references(self._h)
+        self.references = tuple(L.svt_bam_reference_name(self._h, i).decode() for i in range(n))
+        self.lengths = tuple(int(L.svt_bam_reference_length(self._h, i)) for i in range(n))
+        self._tid = {r: i for i, r in enumerate(self.references)}
+        text = (L.svt_bam_header_text(self._h) or b"").decode("ascii", "replace")
+        self.header: Dict[str, list] = {}
+        for line in text.splitlines():
+            if not line.startswith("@") or line.startswith("@CO"):
+                continue
+            parts = line.split("\t")
+            rec = {f[:2]: f[3:] for f in parts[1:] if len(f) >= 3 and f[2] == ":"}
+            self.header.setdefault(parts[0][1:], []).append(rec)
+
+    def gettid(self, name: str) -> int:
+        return self._tid.get(name, -1)
+
+    def close(self):
+        if self._h:
+            self._L.svt_bam_close(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def summarise(self, windows: np.ndarray, breakpoints: np.ndarray, read_groups: Sequence[str],
+                  read_group_lib: Sequence[int], max_reads: Optional[int], count_mode: int,
+                  n_threads: int = 0) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+        """(frag_offset uint64 [n+1], fragments FRAGMENT_DTYPE, skipped uint8 [n])"""
+        windows = np.ascontiguousarray(windows, dtype=FETCH_DTYPE)
+        breakpoints = np.ascontiguousarray(breakpoints, dtype=BREAKPOINT_DTYPE)
+        n = int(windows.shape[0])
+        if breakpoints.shape[0] != n:
+            raise ValueError("windows and breakpoints must have the same length")
+        names = (C.c_char_p * max(1, len(read_groups)))(*[rg.encode() for rg in read_groups])
+        libs = (C.c_int32 * max(1, len(read_groups)))(*[int(x) for x in read_group_lib])
+        a = _Args(n, windows.ctypes.data, breakpoints.ctypes.data, len(read_groups), names, libs,
+                  -1 if max_reads is None else int(max_reads), int(count_mode), int(n_threads))
+        out = _Summaries()
+        hip._check(self._L.svt_bam_summarise(self._h, C.byref(a), C.byref(out)))
+        try:
+            off = np.ctypeslib.as_array(out.frag_offset, shape=(n + 1,)).copy()
+            total = int(off[-1])
+            frags = np.zeros(total, FRAGMENT_DTYPE)
+            if total:
+                C.memmove(frags.ctypes.data, out.fragments, total * FRAGMENT_DTYPE.itemsize)
+            skipped = np.ctypeslib.as_array(out.skipped, shape=(max(n, 1),))[:n].copy()
+        finally:
+            self._L.svt_summaries_free(C.byref(out))
+        return off, frags, skipped

@@ -118,6 +118,82 @@ class UnitCollector:
         return res
 
 
+class NativeUnitCollector:
+    """reader="native": no per-read Python objects.  Sites are only recorded here; at run() the C++
+    reader (svt_bam_summarise, one pool of threads per sample) fetches and condenses the fragments of
+    every (site, sample) unit and the summaries go straight to the device geometry + likelihood stages."""
+
+    def __init__(self, samples: List[Sample], native_bams, split_weight: float, disc_weight: float,
+                 min_aligned: int, count_mode: int, max_reads, n_threads: int = 0):
+        self.samples = samples
+        self.bams = native_bams
+        self.min_aligned = min_aligned
+        self.count_mode = count_mode
+        self.max_reads = max_reads
+        self.n_threads = n_threads
+        self.split_weight = split_weight
+        self.disc_weight = disc_weight
+        self.lib_tables = []
+        self.rg_tables = []          # per sample: (read group ids, library index or -1)
+        for s in samples:
+            base = len(self.lib_tables)
+            libs = list(s.lib_dict.values())
+            self.lib_tables.extend(lib.table() for lib in libs)
+            rgs = list(s.rg_to_lib.keys())
+            idx = [base + libs.index(s.rg_to_lib[rg]) if s.rg_to_lib[rg].name in s.active_libs else -1 for rg in rgs]
+            self.rg_tables.append((rgs, idx))
+        if len(self.lib_tables) > 256:
+            raise ValueError("more than 256 libraries in one run are not supported by the evidence record")
+        self.sites: List[dict] = []
+
+    def add_site(self, breakpoint: dict) -> int:
+        """Returns the index of the site's first unit (its samples follow in order)."""
+        self.sites.append(breakpoint)
+        return (len(self.sites) - 1) * len(self.samples)
+
+    def __len__(self):
+        return len(self.sites) * len(self.samples)
+
+    def run(self, engine: Engine, flags: int) -> Results:
+        import numpy as np
+        from .geometry import FragmentBatch, breakpoint_record
+        from .native_reads import COUNT_SSO, FETCH_DTYPE
+        n_sites, n_samp = len(self.sites), len(self.samples)
+        if n_sites == 0:
+            return Results.empty(0)
+        if not hasattr(engine, "genotype_fragments"):
+            raise TypeError("reader='native' needs an engine with genotype_fragments (the HIP engine)")
+        per_sample = []
+        for k, (sample, nbam) in enumerate(zip(self.samples, self.bams)):
+            tid_of = nbam.gettid
+            bps = np.concatenate([breakpoint_record(bp, tid_of, k) for bp in self.sites])
+            win = np.zeros(n_sites, FETCH_DTYPE)
+            for i, bp in enumerate(self.sites):
+                for side, (t, lo, hi) in (("A", ("tid_a", "lo_a", "hi_a")), ("B", ("tid_b", "lo_b", "hi_b"))):
+                    chrom, a, b = fetch_window(sample, bp[side]["chrom"], bp[side]["pos"], bp[side]["ci"],
+                                               as_int=(self.count_mode == COUNT_SSO))
+                    win[t][i], win[lo][i], win[hi][i] = tid_of(chrom), int(a), int(b)
+            rgs, idx = self.rg_tables[k]
+            off, frags, skipped = nbam.summarise(win, bps, rgs, idx, self.max_reads, self.count_mode, self.n_threads)
+            bps["flags"] |= np.where(skipped != 0, 4, 0).astype(np.uint8)   # SVT_BP_SKIP
+            per_sample.append((bps, off, frags))
+        if n_samp == 1:
+            bps, off, frags = per_sample[0]
+        else:   # interleave: units are site-major, sample-minor
+            bps = np.stack([p[0] for p in per_sample], axis=1).reshape(-1)
+            counts = np.stack([np.diff(p[1].astype(np.int64)) for p in per_sample], axis=1).reshape(-1)
+            off = np.concatenate([[0], np.cumsum(counts)]).astype(np.uint64)
+            parts = []
+            for i in range(n_sites):
+                for _, o, f in per_sample:
+                    parts.append(f[int(o[i]):int(o[i + 1])])
+            frags = np.concatenate(parts) if parts else per_sample[0][2][:0]
+        fb = FragmentBatch(off, bps, frags, self.lib_tables, self.split_weight, self.disc_weight, self.min_aligned,
+                           SPLIT_SLOP)
+        self.sites = []
+        return engine.genotype_fragments(fb, flags)
+
+
 def add_read_to(fragments: Dict[str, SamFragment], read, lib):
     frag = fragments.get(read.query_name)
     if frag is None:

@@ -20,7 +20,8 @@ from . import __version__
 from . import evidence as ev
 from .bam import open_alignment_file
 from .library import Sample, setup_sample, write_sample_json
-from .pipeline import (MIN_LIB_PREVALENCE, UnitCollector, add_read_to, default_engine, fetch_window)
+from .pipeline import (MIN_LIB_PREVALENCE, NativeUnitCollector, UnitCollector, add_read_to, default_engine,
+                       fetch_window)
 from .results import blank_result, result_from_record
 from .vcf import Variant, Vcf
 
@@ -67,7 +68,8 @@ def assign_genotype(variant: Variant, sample_name: str, rec) -> None:
 
 
 def sso_genotype(bam_string, vcf_in, vcf_out, min_aligned, split_weight, disc_weight, num_samp, lib_info_path,
-                 debug, ref_fasta, sum_quals, max_reads, max_ci_dist, cores, batch_size, *, engine=None, geometry="host"):
+                 debug, ref_fasta, sum_quals, max_reads, max_ci_dist, cores, batch_size, *, engine=None, geometry="host",
+                 reader="python"):
     if vcf_in is None:
         return
     full_bam_path = os.path.abspath(bam_string)
@@ -112,7 +114,14 @@ def sso_genotype(bam_string, vcf_in, vcf_out, min_aligned, split_weight, disc_we
     vcf.write_header(vcf_out)
 
     logit("Genotyping Input VCF (%s Mode)" % ("Serial" if cores is None else "Parallel"))
-    collector = UnitCollector([sample], split_weight, disc_weight, min_aligned, geometry)
+    if reader == "native":      # C++ fetch + summariser (cores = its thread count), device geometry
+        from .native_reads import COUNT_SSO, NativeBam
+        collector = NativeUnitCollector([sample], [NativeBam(full_bam_path)], split_weight, disc_weight, min_aligned,
+                                        COUNT_SSO, max_reads, n_threads=cores or 0)
+    elif reader == "python":
+        collector = UnitCollector([sample], split_weight, disc_weight, min_aligned, geometry)
+    else:
+        raise ValueError("reader must be 'python' or 'native'")
     pending: list = []
 
     def flush():
@@ -150,8 +159,11 @@ def sso_genotype(bam_string, vcf_in, vcf_out, min_aligned, split_weight, disc_we
         if variant.get_svtype() == "BND":
             variant2 = variant
             variant = vcf._bnd_first.pop(bp["id"])
-        fragments, many = gather_reads(sample, bp, max_reads)
-        unit = collector.add(bp, 0, fragments, skip=many)
+        if reader == "native":
+            unit = collector.add_site(bp)
+        else:
+            fragments, many = gather_reads(sample, bp, max_reads)
+            unit = collector.add(bp, 0, fragments, skip=many)
         pending.append(("gt", variant, variant2, unit))
         if len(collector) >= CHUNK_UNITS:
             flush()

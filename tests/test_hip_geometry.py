@@ -91,16 +91,32 @@ def test_fixture_sites_device_geometry(hip_device):
             assert np.array_equal(d.records[name], want[name]), name
 
 
+@pytest.mark.parametrize("reader", ["python", "native"])
 @pytest.mark.parametrize("driver", ["classic", "sso"])
-def test_drivers_with_device_geometry(tmp_path, hip_device, driver):
+def test_drivers_with_device_geometry(tmp_path, hip_device, driver, reader):
+    """example.gt.vcf byte for byte with the predicates on the device, fragments from the Python reader
+    or from the native C++ reader + summariser."""
     import test_host_pipeline as T
     out = str(tmp_path / "out.vcf")
     if driver == "classic":
         with open(T.IN_VCF) as inf, open(out, "w") as outf:
             T.classic.sv_genotype(T.IN_BAM, inf, outf, 20, 1, 1, 1000000, T.LIB_JSON, False, None, None, False, None,
-                                  1e10, geometry="device")
+                                  1e10, geometry="device", reader=reader)
     else:
         with open(T.IN_VCF) as inf, open(out, "w") as outf:
             T.singlesample.sso_genotype(T.IN_BAM, inf, outf, 20, 1, 1, 1000000, T.LIB_JSON, False, None, False, 1000,
-                                        1e10, None, 1000, geometry="device")
+                                        1e10, None, 1000, geometry="device", reader=reader)
     T.same_vcf(T.EXPECTED, out)
+
+
+def test_native_reader_two_bams_sum_quals(tmp_path, hip_device):
+    """Multi-sample interleave of the native collector + QUAL accumulation, against the reference's output."""
+    import gzip
+    import test_host_pipeline as T
+    out = str(tmp_path / "out.vcf")
+    with open(T.IN_VCF) as inf, open(out, "w") as outf:
+        T.classic.sv_genotype(T.IN_BAM + "," + T.IN_BAM, inf, outf, 20, 1, 1, 1000000, T.LIB_JSON, False, None, None,
+                              True, None, 1e10, reader="native")
+    want = gzip.open(os.path.join(HERE, "golden", "example.twice.sumquals.gt.vcf.gz"), "rt").read().split("\n")
+    got = [l for l in open(out).read().split("\n") if not l.startswith("##fileDate=")]
+    assert got == want
