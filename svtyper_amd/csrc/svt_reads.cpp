@@ -36,8 +36,19 @@ using svt::fail;
 // ------------------------------------------------------------------------------------------
 class Bgzf {
 public:
-    explicit Bgzf(const std::string& path) { f_ = std::fopen(path.c_str(), "rb"); }
-    ~Bgzf() { if (f_) std::fclose(f_); }
+    explicit Bgzf(const std::string& path)
+    {
+        f_ = std::fopen(path.c_str(), "rb");
+        std::memset(&zs_, 0, sizeof zs_);
+        zs_ok_ = inflateInit2(&zs_, -15) == Z_OK;   // one inflate state per handle, reset per block
+    }
+    ~Bgzf()
+    {
+        if (zs_ok_) inflateEnd(&zs_);
+        if (f_) std::fclose(f_);
+    }
+    Bgzf(const Bgzf&) = delete;
+    Bgzf& operator=(const Bgzf&) = delete;
     bool ok() const { return f_ != nullptr; }
     bool failed() const { return bad_; }
 
@@ -111,15 +122,14 @@ private:
         const uint32_t isize = tail[4] | (tail[5] << 8) | (tail[6] << 16) | ((uint32_t)tail[7] << 24);
         b.data.resize(isize);
         if (isize) {
-            z_stream zs;
-            std::memset(&zs, 0, sizeof zs);
-            if (inflateInit2(&zs, -15) != Z_OK) bad_ = true;
-            zs.next_in = cdata.data();
-            zs.avail_in = (uInt)cdata.size();
-            zs.next_out = b.data.data();
-            zs.avail_out = (uInt)b.data.size();
-            if (inflate(&zs, Z_FINISH) != Z_STREAM_END) bad_ = true;
-            inflateEnd(&zs);
+            if (!zs_ok_ || inflateReset(&zs_) != Z_OK) bad_ = true;
+            else {
+                zs_.next_in = cdata.data();
+                zs_.avail_in = (uInt)cdata.size();
+                zs_.next_out = b.data.data();
+                zs_.avail_out = (uInt)b.data.size();
+                if (inflate(&zs_, Z_FINISH) != Z_STREAM_END) bad_ = true;
+            }
         }
         b.next = coff + (uint64_t)bsize + 1;
         block_ = &(cache_[coff] = std::move(b));
@@ -128,6 +138,8 @@ private:
     }
 
     FILE* f_ = nullptr;
+    z_stream zs_;
+    bool zs_ok_ = false;
     std::unordered_map<uint64_t, Block> cache_;
     Block empty_;
     Block* block_ = &empty_;
@@ -788,11 +800,27 @@ int svt_bam_summarise(const svt_bam* bam, const svt_summarise_args* args, svt_su
     uint64_t off = 0;
     for (uint64_t u = 0; u < n; ++u) {
         out->frag_offset[u] = off;
-        if (!outs[u].frags.empty()) std::memcpy(out->fragments + off, outs[u].frags.data(), outs[u].frags.size() * sizeof(svt_fragment));
         off += outs[u].frags.size();
         out->skipped[u] = outs[u].skipped ? 1 : 0;
     }
     out->frag_offset[n] = off;
+    {   // gather the per-unit vectors into the flat array on the same threads
+        std::atomic<uint64_t> nextu(0);
+        auto copier = [&]() {
+            for (;;) {
+                const uint64_t u0 = nextu.fetch_add(256);
+                if (u0 >= n) return;
+                for (uint64_t u = u0; u < std::min(n, u0 + 256); ++u)
+                    if (!outs[u].frags.empty())
+                        std::memcpy(out->fragments + out->frag_offset[u], outs[u].frags.data(),
+                                    outs[u].frags.size() * sizeof(svt_fragment));
+            }
+        };
+        std::vector<std::thread> pool;
+        for (unsigned t = 1; t < std::min(nt, 16u); ++t) pool.emplace_back(copier);
+        copier();
+        for (auto& th : pool) th.join();
+    }
     return SVT_OK;
 }
 

@@ -114,13 +114,25 @@ class NativeBam:
                   -1 if max_reads is None else int(max_reads), int(count_mode), int(n_threads))
         out = _Summaries()
         hip._check(self._L.svt_bam_summarise(self._h, C.byref(a), C.byref(out)))
-        try:
-            off = np.ctypeslib.as_array(out.frag_offset, shape=(n + 1,)).copy()
-            total = int(off[-1])
-            frags = np.zeros(total, FRAGMENT_DTYPE)
-            if total:
-                C.memmove(frags.ctypes.data, out.fragments, total * FRAGMENT_DTYPE.itemsize)
-            skipped = np.ctypeslib.as_array(out.skipped, shape=(max(n, 1),))[:n].copy()
-        finally:
-            self._L.svt_summaries_free(C.byref(out))
+        owner = _SummariesOwner(self._L, out)   # frees the C buffers when the arrays below are gone
+        off = np.ctypeslib.as_array(out.frag_offset, shape=(n + 1,)).copy()
+        total = int(off[-1])
+        skipped = np.ctypeslib.as_array(out.skipped, shape=(max(n, 1),))[:n].copy()
+        if total:   # zero-copy view of the C array (1.4 GB for 10 M fragments)
+            raw = (C.c_uint8 * (total * FRAGMENT_DTYPE.itemsize)).from_address(out.fragments)
+            raw._svt_owner = owner   # every numpy view keeps `raw` alive through .base, and raw keeps the owner
+            frags = np.frombuffer(raw, dtype=FRAGMENT_DTYPE)
+        else:
+            frags = np.zeros(0, FRAGMENT_DTYPE)
         return off, frags, skipped
+
+
+class _SummariesOwner:
+    def __init__(self, lib, summaries):
+        self._lib, self._s = lib, summaries
+
+    def __del__(self):
+        try:
+            self._lib.svt_summaries_free(C.byref(self._s))
+        except Exception:
+            pass
