@@ -7,8 +7,8 @@ import re
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_symbols():
-    src = open(os.path.join(ROOT, "include", "svtyper_hip.h")).read()
+def declared_symbols(header="svtyper_hip.h"):
+    src = open(os.path.join(ROOT, "include", header)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(svt_[a-z_]+)\s*\(", src)))
 
@@ -22,6 +22,10 @@ def test_header_symbols_exported():
     for s in syms:
         assert hasattr(lib, s), "missing export %s" % s
     assert sorted(hip.EXPORTS) == syms
+    reads = declared_symbols("svtyper_reads.h")
+    assert len(reads) >= 9
+    for s in reads:
+        assert hasattr(lib, s), "missing export %s" % s
 
 
 def test_version_and_loud_failure_without_gpu():
