@@ -191,3 +191,55 @@ def test_multisample_per_sample_libraries(hip_device):
     for flags in ALL_FLAGS:
         got, want = run_both(batch, flags)
         assert_parity(got, want)
+
+
+def _fuzz_batch(seed, libs, wide):
+    """Uniformly random bytes inside the record contract: any MAPQ 0..255 anywhere, any combination of the
+    defined flag bits, spans around (and far from) the histogram, arbitrary svtype / lengths / weights."""
+    rng = np.random.default_rng(seed)
+    n = 3000
+    F = rng.integers(0, 220, n)
+    F[rng.random(n) < 0.05] = 0
+    off = np.zeros(n + 1, np.uint64)
+    np.cumsum(F, out=off[1:])
+    R = int(off[-1])
+    rec = np.zeros(R, ev.RECORD_DTYPE)
+    for fld in ("mapq_a", "mapq_b", "rs_a", "rs_b", "seq_l", "seq_r", "clip_l", "clip_r"):
+        common = rng.choice([0, 60, 255, 10, 20, 3], R)
+        rec[fld] = np.where(rng.random(R) < 0.4, 0, np.where(rng.random(R) < 0.5, common, rng.integers(0, 256, R)))
+    pair = rng.random(R) < 0.8
+    bits = rng.integers(0, 8, R) * pair                      # straddle bits only with HAS_PAIR
+    cont = (rng.random(R) < 0.1).astype(np.uint32) * ev.REC_CONTINUATION
+    lib = rng.integers(0, len(libs), R).astype(np.uint32)
+    rec["flags"] = bits.astype(np.uint32) | cont | (pair.astype(np.uint32) * ev.REC_HAS_PAIR) | (lib << ev.REC_LIB_SHIFT)
+    span = rng.integers(0, 1500, R)
+    span = np.where(rng.random(R) < 0.1, rng.integers(0, 2**31 - 1, R), span)
+    rec["ospan_len"] = span
+    units = np.zeros(n, ev.UNIT_DTYPE)
+    units["svtype"] = rng.integers(0, 4, n)
+    vl = rng.integers(-50, 1500, n)
+    if wide:
+        vl = np.where(rng.random(n) < 0.2, rng.integers(-2**31, 2**31 - 1, n), vl)
+    units["var_length"] = vl
+    units["pos_delta"] = np.where(rng.random(n) < 0.5, rng.integers(-10, 400, n), rng.integers(-2**31, 2**31 - 1, n))
+    units["sample"] = rng.integers(0, 65536, n)
+    units["flags"] = (rng.random(n) < 0.02) * ev.UNIT_SKIP
+    sw, dw = rng.choice([1.0, 0.5, 2.0, 0.0, 1.3]), rng.choice([1.0, 0.25, 3.0, 0.0, 0.9])
+    return ev.EvidenceBatch(off, units, rec, libs, float(sw), float(dw))
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_fuzz_random_records(hip_device, fixture_library, seed):
+    libs_sets = {
+        1: [fixture_library],
+        2: [fixture_library, synth.normal_library(420.0, 95.0, n=50000, seed=3)],
+        3: [synth.normal_library(300.0, 50.0, n=30000, seed=9)],
+        4: [synth.normal_library(250.0 + 30 * k, 40.0 + 5 * k, n=20000, seed=20 + k) for k in range(40)],
+    }
+    libs = libs_sets[seed]
+    if seed == 3:
+        libs[0].mean, libs[0].sd = 300.0, 50.0          # integral mean + 3 sd -> exact float-key kernel
+    batch = _fuzz_batch(100 + seed, libs, wide=(seed % 2 == 0))
+    for flags in ALL_FLAGS:
+        got, want = run_both(batch, flags)
+        assert_parity(got, want)
