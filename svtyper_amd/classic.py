@@ -23,7 +23,7 @@ from .bam import open_alignment_file
 from .library import Sample, setup_sample, write_sample_json
 from .pipeline import (MIN_LIB_PREVALENCE, NativeUnitCollector, UnitCollector, add_read_to, default_engine,
                        fetch_window)
-from .results import result_from_record
+from .results import results_to_dicts
 from .vcf import VALID_SVTYPES, Variant, Vcf
 
 CHUNK_UNITS = 200_000   # (breakpoint, sample) units per device batch
@@ -47,14 +47,12 @@ def gather_all_reads(sample: Sample, bp: dict, max_reads):
     return fragments, False
 
 
-def apply_result(var: Variant, sample_name: str, rec) -> None:
-    """Result record -> FORMAT fields and QUAL of one sample (classic.py:454-513)."""
+def apply_result(var: Variant, sample_name: str, gt: int, res: dict) -> None:
+    """Result of one unit -> FORMAT fields and QUAL of one sample (classic.py:454-513)."""
     g = var.genotype(sample_name)
-    gt = int(rec["gt"])
     if gt == ev.GT_SKIPPED:                       # classic.py:282-284
         g.set_format("GT", "./.")
         return
-    res = result_from_record(rec)
     f = res["formats"]
     if gt == ev.GT_BLANK:                         # classic.py:496-513 (QUAL is reset, not kept)
         var.qual = 0
@@ -107,16 +105,17 @@ def sv_genotype(bam_string, vcf_in, vcf_out, min_aligned, split_weight, disc_wei
 
     def flush():
         results = collector.run(engine, 0)
+        dicts = results_to_dicts(results)
+        gts = results.gt.tolist()
         for action in pending:
             if action[0] == "raw":
                 vcf_out.write(action[1].get_var_string() + "\n")
                 continue
             _, var, var2, first_unit = action
             for k, sample in enumerate(samples):
-                rec = results.rec[first_unit + k]
                 if debug:
-                    _debug_print(rec)
-                apply_result(var, sample.name, rec)
+                    _debug_print(results.rec[first_unit + k])
+                apply_result(var, sample.name, gts[first_unit + k], dicts[first_unit + k])
             vcf_out.write(var.get_var_string() + "\n")
             if var2 is not None:                   # BND: second mate carries the same genotypes
                 var.share_genotypes_with(var2)

@@ -158,21 +158,45 @@ class NativeUnitCollector:
         import numpy as np
         from .geometry import FragmentBatch, breakpoint_record
         from .native_reads import COUNT_SSO, FETCH_DTYPE
-        n_sites, n_samp = len(self.sites), len(self.samples)
+        n_samp = len(self.samples)
+        n_sites = len(self.sites)
         if n_sites == 0:
             return Results.empty(0)
         if not hasattr(engine, "genotype_fragments"):
             raise TypeError("reader='native' needs an engine with genotype_fragments (the HIP engine)")
         per_sample = []
+        n_sites = len(self.sites)
+        A = [bp["A"] for bp in self.sites]
+        B = [bp["B"] for bp in self.sites]
+        pos = np.array([[a["pos"], b["pos"]] for a, b in zip(A, B)], dtype=np.int64)
+        ci = np.array([[a["ci"][0], a["ci"][1], b["ci"][0], b["ci"][1]] for a, b in zip(A, B)], dtype=np.int64)
+        rev = np.array([(1 if a["is_reverse"] else 0) | (2 if b["is_reverse"] else 0) for a, b in zip(A, B)], np.uint8)
+        svt = np.array([ev.SVTYPE_CODE[bp["svtype"]] for bp in self.sites], np.uint8)
+        vlen = np.array([bp.get("var_length", 0) if bp["svtype"] == "DEL" else 0 for bp in self.sites], np.int64)
+        clip = lambda x: np.clip(x, -2**31, 2**31 - 1)
         for k, (sample, nbam) in enumerate(zip(self.samples, self.bams)):
             tid_of = nbam.gettid
-            bps = np.concatenate([breakpoint_record(bp, tid_of, k) for bp in self.sites])
+            tid = np.array([[tid_of(a["chrom"]), tid_of(b["chrom"])] for a, b in zip(A, B)], dtype=np.int64)
+            if (tid < 0).any():
+                bad = self.sites[int(np.nonzero((tid < 0).any(axis=1))[0][0])]
+                raise KeyError("chromosome of variant %s is not in %s" % (bad.get("id"), nbam.filename))
+            from .geometry import BREAKPOINT_DTYPE
+            bps = np.zeros(n_sites, BREAKPOINT_DTYPE)
+            bps["tid_a"], bps["tid_b"] = tid[:, 0], tid[:, 1]
+            bps["pos_a"], bps["pos_b"] = clip(pos[:, 0]), clip(pos[:, 1])
+            bps["ci_a"], bps["ci_b"] = clip(ci[:, 0:2]), clip(ci[:, 2:4])
+            bps["var_length"] = clip(vlen)
+            bps["svtype"], bps["flags"], bps["sample"] = svt, rev, k
+            # fetch windows: pos + ci -+ (mean + 3 sd), clamped to the chromosome (classic.py:73-81;
+            # singlesample.py:139-156 truncates to int, pysam truncates classic's float bounds the same way)
+            flank = sample.get_fetch_flank(Z)
+            length = np.array(nbam.lengths, dtype=np.float64)[tid]
+            lo = np.maximum(pos + ci[:, [0, 2]] - flank, 0.0)
+            hi = np.minimum(pos + ci[:, [1, 3]] + flank, length)
             win = np.zeros(n_sites, FETCH_DTYPE)
-            for i, bp in enumerate(self.sites):
-                for side, (t, lo, hi) in (("A", ("tid_a", "lo_a", "hi_a")), ("B", ("tid_b", "lo_b", "hi_b"))):
-                    chrom, a, b = fetch_window(sample, bp[side]["chrom"], bp[side]["pos"], bp[side]["ci"],
-                                               as_int=(self.count_mode == COUNT_SSO))
-                    win[t][i], win[lo][i], win[hi][i] = tid_of(chrom), int(a), int(b)
+            win["tid_a"], win["tid_b"] = tid[:, 0], tid[:, 1]
+            win["lo_a"], win["lo_b"] = lo[:, 0].astype(np.int64), lo[:, 1].astype(np.int64)
+            win["hi_a"], win["hi_b"] = hi[:, 0].astype(np.int64), hi[:, 1].astype(np.int64)
             rgs, idx = self.rg_tables[k]
             off, frags, skipped = nbam.summarise(win, bps, rgs, idx, self.max_reads, self.count_mode, self.n_threads)
             bps["flags"] |= np.where(skipped != 0, 4, 0).astype(np.uint8)   # SVT_BP_SKIP

@@ -39,3 +39,27 @@ def result_from_record(rec) -> dict:
         f["GT"] = ev.GT_STRING[gt]
         out["qual"] = sq
     return out
+
+
+def results_to_dicts(results) -> list:
+    """All records of a Results at once (same dicts as result_from_record, one bulk conversion to
+    Python objects instead of one numpy scalar access per field)."""
+    rec = results.rec
+    gts = rec["gt"].tolist()
+    gls = rec["gl"].tolist()
+    sqs = rec["sq"].tolist()
+    cnts = rec["counts"].tolist()
+    out = []
+    for gt, gl, sq, c in zip(gts, gls, sqs, cnts):
+        res = blank_result()
+        if gt not in (ev.GT_BLANK, ev.GT_SKIPPED):
+            f = res["formats"]
+            f["GL"] = "%.0f,%.0f,%.0f" % (gl[0], gl[1], gl[2])
+            (f["QR"], f["QA"], gq, f["DP"], f["RO"], f["AO"], f["RS"], f["AS"], f["ASC"], f["RP"], f["AP"]) = c
+            tot = f["QR"] + f["QA"]
+            f["AB"] = "%.2g" % (f["QA"] / float(tot)) if tot != 0 else "."
+            if gt >= 0:
+                f["GQ"], f["SQ"], f["GT"] = gq, sq, ev.GT_STRING[gt]
+                res["qual"] = sq
+        out.append(res)
+    return out

@@ -22,7 +22,7 @@ from .bam import open_alignment_file
 from .library import Sample, setup_sample, write_sample_json
 from .pipeline import (MIN_LIB_PREVALENCE, NativeUnitCollector, UnitCollector, add_read_to, default_engine,
                        fetch_window)
-from .results import blank_result, result_from_record
+from .results import results_to_dicts
 from .vcf import Variant, Vcf
 
 CHUNK_UNITS = 200_000
@@ -58,9 +58,8 @@ def gather_reads(sample: Sample, bp: dict, max_reads):
     return fragments, False
 
 
-def assign_genotype(variant: Variant, sample_name: str, rec) -> None:
+def assign_genotype(variant: Variant, sample_name: str, res: dict) -> None:
     """singlesample.py:544-575: every FORMAT field is always written; QUAL accumulates."""
-    res = blank_result() if int(rec["gt"]) in (ev.GT_BLANK, ev.GT_SKIPPED) else result_from_record(rec)
     variant.qual += res["qual"]
     g = variant.genotype(sample_name)
     for key in _ASSIGN_ORDER:
@@ -126,12 +125,13 @@ def sso_genotype(bam_string, vcf_in, vcf_out, min_aligned, split_weight, disc_we
 
     def flush():
         results = collector.run(engine, ev.FLAG_SSO_ASSOCIATION)
+        dicts = results_to_dicts(results)   # blank for "no evidence" and "too many reads" alike
         for action in pending:
             if action[0] == "raw":
                 action[1].write(vcf_out)
                 continue
             _, variant, variant2, unit = action
-            assign_genotype(variant, sample.name, results.rec[unit])
+            assign_genotype(variant, sample.name, dicts[unit])
             variant.write(vcf_out)
             if variant2 is not None:
                 variant.share_genotypes_with(variant2)

@@ -87,6 +87,7 @@ class Vcf:
         self.alt_list: List[HeaderLine] = []
         self.header_misc: List[str] = []
         self.filename: Optional[str] = None
+        self.format_rank: Dict[str, int] = {}
         self._bnd_pending: Dict[str, "Variant"] = {}   # first mates waiting for their partner
         self._bnd_first: Dict[str, "Variant"] = {}     # first mates of completed pairs, by breakpoint id
         self.add_format("GT", 1, "String", "Genotype")
@@ -103,6 +104,7 @@ class Vcf:
     def add_format(self, id, number, type, desc):
         if str(id) not in [h.id for h in self.format_list]:
             self.format_list.append(HeaderLine("FORMAT", id, number, type, desc))
+            self.format_rank = {h.id: i for i, h in enumerate(self.format_list)}   # header order of FORMAT keys
 
     def add_sample(self, name):
         self.sample_list.append(name)
@@ -204,6 +206,7 @@ class Variant:
         self.sample_list = vcf.sample_list
         self.info_list = vcf.info_list
         self.format_list = vcf.format_list
+        self.format_rank = vcf.format_rank
         self.active_formats: List[str] = []
         self.gts: Dict[str, Genotype] = {}
         if len(var_list) < 9:
@@ -280,14 +283,15 @@ class Genotype:
         self.set_format("GT", gt)
 
     def set_format(self, field, value):
-        order = [h.id for h in self.variant.format_list]
-        if field not in order:
+        rank = self.variant.format_rank
+        if field not in rank:
             sys.stderr.write('Error: invalid FORMAT field, "' + field + '"\n')
             sys.exit(1)
         self.format[field] = value
-        if field not in self.variant.active_formats:
-            self.variant.active_formats.append(field)
-            self.variant.active_formats.sort(key=order.index)
+        active = self.variant.active_formats
+        if field not in active:
+            active.append(field)
+            active.sort(key=rank.__getitem__)   # header declaration order (parsers.py:375-381)
 
     def get_format(self, field):
         return self.format[field]
