@@ -754,6 +754,7 @@ int svt_bam_summarise(const svt_bam* bam, const svt_summarise_args* args, svt_su
     for (uint32_t i = 0; i < args->n_read_groups; ++i) rg_lib[args->read_groups[i]] = args->read_group_lib[i];
 
     std::vector<UnitOut> outs(n);
+    constexpr uint64_t kUnitsPerGrab = 16;
     unsigned nt = args->n_threads > 0 ? (unsigned)args->n_threads : std::thread::hardware_concurrency();
     nt = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(nt ? nt : 1, n ? n : 1));
     std::atomic<uint64_t> next(0);
@@ -768,15 +769,18 @@ int svt_bam_summarise(const svt_bam* bam, const svt_summarise_args* args, svt_su
             if (first_rc.exchange(SVT_ERR_INVALID) == SVT_OK) first_err = "cannot reopen " + bam->path;
             return;
         }
-        for (;;) {
-            const uint64_t u = next.fetch_add(1);
-            if (u >= n || first_rc.load() != SVT_OK) return;
-            std::string err;
-            const int rc = process_unit(*bam, z, buf, *args, rg_lib, u, outs[u], err);
-            if (rc != SVT_OK) {
-                std::lock_guard<std::mutex> g(err_lock);
-                if (first_rc.exchange(rc) == SVT_OK) first_err = err;
-                return;
+        for (;;) {   // consecutive units stay on one thread: neighbouring sites share BGZF blocks (and its cache)
+            const uint64_t u0 = next.fetch_add(kUnitsPerGrab);
+            if (u0 >= n) return;
+            for (uint64_t u = u0; u < std::min(n, u0 + kUnitsPerGrab); ++u) {
+                if (first_rc.load(std::memory_order_relaxed) != SVT_OK) return;
+                std::string err;
+                const int rc = process_unit(*bam, z, buf, *args, rg_lib, u, outs[u], err);
+                if (rc != SVT_OK) {
+                    std::lock_guard<std::mutex> g(err_lock);
+                    if (first_rc.exchange(rc) == SVT_OK) first_err = err;
+                    return;
+                }
             }
         }
     };
