@@ -33,6 +33,26 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
 
+def usable_cpus() -> int:
+    """Host threads this process can actually keep busy: the affinity mask capped by the cgroup CPU
+    quota (a container with `cpu.max = 1600000 100000` schedules 16 CPUs however many it can see)."""
+    n = len(os.sched_getaffinity(0))
+    quota, period = -1, 0
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, p = f.read().split()[:2]
+            quota, period = (-1 if q == "max" else int(q)), int(p)
+    except (OSError, ValueError):
+        try:
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        except (OSError, ValueError):
+            pass
+    if quota > 0 and period > 0:
+        n = min(n, max(1, -(-quota // period)))
+    return max(1, n)
+
+
 def fixture_library():
     from svtyper_amd.evidence import LibraryTable
     with open(os.path.join(ROOT, "tests", "data", "NA12878.bam.json")) as f:
@@ -94,7 +114,7 @@ def main():
         args.gpus = world
 
     # generate on the host BEFORE importing torch (fork-safe, and no GPU context in the workers)
-    n_cpu = len(os.sched_getaffinity(0))
+    n_cpu = usable_cpus()
     t0 = time.time()
     batch = generate(args.workload, args.units, rank, max(1, n_cpu // max(1, min(world, 8))))
     gen_s = time.time() - t0
@@ -238,12 +258,12 @@ def main():
             from oracle import c_oracle
             sample_n = n
             sample = batch.slice(0, sample_n)
-            threads = c_oracle.max_threads()
-            want = c_oracle.genotype_batch(sample, flags=flags & ev.FLAG_SSO_ASSOCIATION)   # warm-up + parity reference
+            threads = min(c_oracle.max_threads(), n_cpu)   # more threads than the CPU quota only get throttled
+            want = c_oracle.genotype_batch(sample, flags=flags & ev.FLAG_SSO_ASSOCIATION, n_threads=threads)   # warm-up + parity reference
             t0 = time.perf_counter()
             reps = 0
             while True:
-                c_oracle.genotype_batch(sample, flags=flags & ev.FLAG_SSO_ASSOCIATION, out=want)
+                c_oracle.genotype_batch(sample, flags=flags & ev.FLAG_SSO_ASSOCIATION, n_threads=threads, out=want)
                 reps += 1
                 if time.perf_counter() - t0 >= args.cpu_seconds or reps >= 50:
                     break
@@ -254,7 +274,8 @@ def main():
                 "cores": threads,
                 "kind": "port",
                 "sample": "the workload's %d units x %d repetitions, oracle/svt_oracle.c "
-                          "(OpenMP, %d threads)" % (sample_n, reps, threads),
+                          "(OpenMP, %d threads = the host CPUs this process may use: %d visible, cgroup quota %d)"
+                          % (sample_n, reps, threads, len(os.sched_getaffinity(0)), n_cpu),
             }
             # the closest stand-in for "the reference's own CPU path" that can run here: the pure-Python
             # restatement, 1 process and a multiprocessing.Pool over all cores with 1000-unit batches

@@ -4,6 +4,7 @@
 #define SVT_HOST_TILING_H
 
 #include "svt_device_types.h"
+#include "svt_host_cpus.h"
 
 namespace svt {
 
@@ -21,8 +22,7 @@ struct Tiling {
 
 inline unsigned host_threads()
 {
-    const unsigned hc = std::thread::hardware_concurrency();
-    return std::max(1u, std::min(hc ? hc : 1u, 16u));
+    return std::max(1u, std::min(usable_cpus(), 16u));
 }
 
 // run fn(i) for i in [0, n) on up to host_threads() threads

@@ -7,10 +7,15 @@
 // implementation and the checker of this file (tests/test_native_reads.py compares the summaries
 // byte for byte); this file exists because per-read Python objects, not the GPU, bound a real run.
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -26,6 +31,7 @@
 
 #include "../../include/svtyper_reads.h"
 #include "svt_error.h"
+#include "svt_host_cpus.h"
 
 namespace {
 
@@ -34,22 +40,45 @@ using svt::fail;
 // ------------------------------------------------------------------------------------------
 // BGZF: random access through (compressed offset << 16 | in-block offset) addresses
 // ------------------------------------------------------------------------------------------
+// the whole file, mapped read-only once per handle and shared by all worker threads: no read()
+// syscalls or stdio buffers on the fetch path, the inflate input is the mapping itself
+struct FileMap {
+    const uint8_t* data = nullptr;
+    size_t size = 0;
+    FileMap() = default;
+    FileMap(const FileMap&) = delete;
+    FileMap& operator=(const FileMap&) = delete;
+    ~FileMap() { if (data) munmap(const_cast<uint8_t*>(data), size); }
+    bool open(const std::string& path)
+    {
+        const int fd = ::open(path.c_str(), O_RDONLY);
+        if (fd < 0) return false;
+        struct stat st;
+        if (fstat(fd, &st) != 0 || st.st_size <= 0) { ::close(fd); return false; }
+        void* p = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_SHARED, fd, 0);
+        ::close(fd);
+        if (p == MAP_FAILED) return false;
+        madvise(p, (size_t)st.st_size, MADV_RANDOM);   // region fetches, not a scan
+        data = static_cast<const uint8_t*>(p);
+        size = (size_t)st.st_size;
+        return true;
+    }
+};
+
 class Bgzf {
 public:
-    explicit Bgzf(const std::string& path)
+    explicit Bgzf(const FileMap& file) : file_(file)
     {
-        f_ = std::fopen(path.c_str(), "rb");
         std::memset(&zs_, 0, sizeof zs_);
-        zs_ok_ = inflateInit2(&zs_, -15) == Z_OK;   // one inflate state per handle, reset per block
+        zs_ok_ = inflateInit2(&zs_, -15) == Z_OK;   // one inflate state per reader, reset per block
     }
     ~Bgzf()
     {
         if (zs_ok_) inflateEnd(&zs_);
-        if (f_) std::fclose(f_);
     }
     Bgzf(const Bgzf&) = delete;
     Bgzf& operator=(const Bgzf&) = delete;
-    bool ok() const { return f_ != nullptr; }
+    bool ok() const { return file_.data != nullptr && zs_ok_; }
     bool failed() const { return bad_; }
 
     void seek(uint64_t voff)
@@ -68,10 +97,10 @@ public:
         size_t got = 0;
         uint8_t* out = static_cast<uint8_t*>(dst);
         while (got < n) {
-            const size_t avail = block_ ? block_->data.size() - std::min(uoff_, block_->data.size()) : 0;
+            const size_t avail = block_->data.size() - std::min(uoff_, block_->data.size());
             if (avail == 0) {
-                const uint64_t next = block_ ? block_->next : 0;
-                if (block_ && next == coff_) break;
+                const uint64_t next = block_->next;
+                if (block_ != &empty_ && next == coff_) break;
                 if (!load(next)) break;
                 uoff_ = 0;
                 continue;
@@ -85,62 +114,81 @@ public:
     }
 
 private:
-    struct Block { std::vector<uint8_t> data; uint64_t next = 0; };
+    struct Block { std::vector<uint8_t> data; uint64_t next = 0; uint64_t coff = ~0ull; };
+    // a few recently inflated blocks: the two windows of a unit and its neighbours walk forward through
+    // the same blocks.  Fixed slots whose buffers are reused -- no allocation once they are warm.
+    static constexpr int kSlots = 8;
+    Block* slot_for(uint64_t coff)
+    {
+        for (int i = 0; i < kSlots; ++i)
+            if (slots_[i].coff == coff) return &slots_[i];
+        return nullptr;
+    }
+    Block* victim()
+    {
+        Block* b = &slots_[clock_];
+        clock_ = (clock_ + 1) % kSlots;
+        b->data.clear();
+        return b;
+    }
+    bool park(Block* b, uint64_t coff, bool is_bad)
+    {
+        if (is_bad) bad_ = true;
+        b->coff = coff;
+        b->next = coff;
+        block_ = b;
+        coff_ = coff;
+        return false;
+    }
     bool load(uint64_t coff)
     {
-        auto it = cache_.find(coff);
-        if (it != cache_.end()) {
-            block_ = &it->second;
+        if (Block* hit = slot_for(coff)) {
+            block_ = hit;
             coff_ = coff;
             return !block_->data.empty() || block_->next > coff;
         }
-        if (cache_.size() >= 64) cache_.clear();   // regions are walked forward: a simple bound is enough
-        Block b;
-        b.next = coff;
-        uint8_t hdr[18];
-        if (fseeko(f_, (off_t)coff, SEEK_SET) != 0 || std::fread(hdr, 1, 18, f_) != 18) {
-            block_ = &(cache_[coff] = b);
-            coff_ = coff;
-            return false;
-        }
-        if (hdr[0] != 31 || hdr[1] != 139) { bad_ = true; block_ = &(cache_[coff] = b); coff_ = coff; return false; }
-        const unsigned xlen = hdr[10] | (hdr[11] << 8);
-        std::vector<uint8_t> extra(xlen);
-        std::memcpy(extra.data(), hdr + 12, std::min<size_t>(6, xlen));
-        if (xlen > 6 && std::fread(extra.data() + 6, 1, xlen - 6, f_) != xlen - 6) bad_ = true;
+        Block* b = victim();
+        if (coff + 18 > file_.size) return park(b, coff, false);          // end of file
+        const uint8_t* hdr = file_.data + coff;
+        if (hdr[0] != 31 || hdr[1] != 139) return park(b, coff, true);
+        const size_t xlen = hdr[10] | (hdr[11] << 8);
+        if (coff + 12 + xlen > file_.size) return park(b, coff, true);
         int bsize = -1;
-        for (size_t i = 0; i + 4 <= extra.size();) {
-            const unsigned slen = extra[i + 2] | (extra[i + 3] << 8);
-            if (extra[i] == 66 && extra[i + 1] == 67 && i + 6 <= extra.size()) bsize = extra[i + 4] | (extra[i + 5] << 8);
+        for (size_t i = 0; i + 4 <= xlen;) {
+            const uint8_t* x = hdr + 12 + i;
+            const size_t slen = x[2] | (x[3] << 8);
+            if (x[0] == 66 && x[1] == 67 && i + 6 <= xlen) bsize = x[4] | (x[5] << 8);
             i += 4 + slen;
         }
-        if (bsize < 0) { bad_ = true; block_ = &(cache_[coff] = b); coff_ = coff; return false; }
+        if (bsize < 0 || coff + (uint64_t)bsize + 1 > file_.size) return park(b, coff, true);
         const int clen = bsize - (int)xlen - 19;
-        std::vector<uint8_t> cdata((size_t)std::max(clen, 0));
-        uint8_t tail[8];
-        if ((clen > 0 && std::fread(cdata.data(), 1, (size_t)clen, f_) != (size_t)clen) || std::fread(tail, 1, 8, f_) != 8) bad_ = true;
+        if (clen < 0) return park(b, coff, true);
+        const uint8_t* cdata = hdr + 12 + xlen;
+        const uint8_t* tail = cdata + clen;
         const uint32_t isize = tail[4] | (tail[5] << 8) | (tail[6] << 16) | ((uint32_t)tail[7] << 24);
-        b.data.resize(isize);
+        b->data.resize(isize);
         if (isize) {
-            if (!zs_ok_ || inflateReset(&zs_) != Z_OK) bad_ = true;
+            if (inflateReset(&zs_) != Z_OK) bad_ = true;
             else {
-                zs_.next_in = cdata.data();
-                zs_.avail_in = (uInt)cdata.size();
-                zs_.next_out = b.data.data();
-                zs_.avail_out = (uInt)b.data.size();
+                zs_.next_in = const_cast<Bytef*>(cdata);
+                zs_.avail_in = (uInt)clen;
+                zs_.next_out = b->data.data();
+                zs_.avail_out = (uInt)b->data.size();
                 if (inflate(&zs_, Z_FINISH) != Z_STREAM_END) bad_ = true;
             }
         }
-        b.next = coff + (uint64_t)bsize + 1;
-        block_ = &(cache_[coff] = std::move(b));
+        b->coff = coff;
+        b->next = coff + (uint64_t)bsize + 1;
+        block_ = b;
         coff_ = coff;
         return true;
     }
 
-    FILE* f_ = nullptr;
+    const FileMap& file_;
     z_stream zs_;
     bool zs_ok_ = false;
-    std::unordered_map<uint64_t, Block> cache_;
+    Block slots_[kSlots];
+    int clock_ = 0;
     Block empty_;
     Block* block_ = &empty_;
     uint64_t coff_ = 0;
@@ -285,6 +333,7 @@ const char* find_z_tag(const Record& r, char k0, char k1, bool* malformed)
 // ------------------------------------------------------------------------------------------
 struct svt_bam {
     std::string path;
+    FileMap file;
     std::string text;
     std::vector<std::string> ref_names;
     std::vector<int64_t> ref_lengths;
@@ -539,15 +588,66 @@ bool fill_piece(svt_piece_summary& d, const Piece& p)
     return true;
 }
 
-struct UnitOut {
+struct UnitOut {                       // per worker, reused for every unit it processes
     std::vector<svt_fragment> frags;
     bool skipped = false;
+};
+
+struct UnitSpan {                      // where a finished unit's summaries wait for the gather
+    const svt_fragment* frags = nullptr;
+    uint64_t count = 0;
+    bool skipped = false;
+};
+
+// Anonymous mapping advised for transparent huge pages: the summaries are written once and read
+// once, so what they cost is page faults -- with 4 KB pages and a few hundred threads those contend
+// in the kernel long before the cores are busy.
+void* map_buffer(size_t bytes)
+{
+    void* p = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    if (p == MAP_FAILED) return nullptr;
+    madvise(p, bytes, MADV_HUGEPAGE);
+    return p;
+}
+
+// append-only store of one worker: units are copied in whole, never split across chunks
+class SummaryArena {
+public:
+    SummaryArena() = default;
+    SummaryArena(const SummaryArena&) = delete;
+    SummaryArena& operator=(const SummaryArena&) = delete;
+    ~SummaryArena() { for (auto& c : chunks_) munmap(c.first, c.second); }
+    const svt_fragment* append(const std::vector<svt_fragment>& v)
+    {
+        const size_t bytes = v.size() * sizeof(svt_fragment);
+        if (bytes == 0) return nullptr;
+        if (used_ + bytes > cap_) {
+            const size_t want = std::max(bytes, kChunkBytes);
+            const size_t size = (want + kHuge - 1) / kHuge * kHuge;
+            void* p = map_buffer(size);
+            if (!p) return nullptr;
+            chunks_.emplace_back(p, size);
+            cap_ = size;
+            used_ = 0;
+        }
+        uint8_t* dst = static_cast<uint8_t*>(chunks_.back().first) + used_;
+        std::memcpy(dst, v.data(), bytes);
+        used_ += bytes;
+        return reinterpret_cast<const svt_fragment*>(dst);
+    }
+
+private:
+    static constexpr size_t kHuge = 2u << 20, kChunkBytes = 16u << 20;
+    std::vector<std::pair<void*, size_t>> chunks_;
+    size_t cap_ = 0, used_ = 0;
 };
 
 // one unit: gather reads of both windows, assemble fragments, emit summaries
 int process_unit(const svt_bam& bam, Bgzf& z, std::vector<uint8_t>& buf, const svt_summarise_args& A,
                  const std::unordered_map<std::string, int32_t>& rg_lib, uint64_t u, UnitOut& out, std::string& err)
 {
+    out.frags.clear();
+    out.skipped = false;
     const svt_fetch_unit& w = A.windows[u];
     const int32_t tids[2] = {w.tid_a, w.tid_b};
     const int64_t los[2] = {w.lo_a, w.lo_b}, his[2] = {w.hi_a, w.hi_b};
@@ -639,10 +739,11 @@ int svt_bam_open(const char* path, svt_bam** out)
 {
     if (!path || !out) return fail(SVT_ERR_INVALID, "null argument");
     *out = nullptr;
-    Bgzf z(path);
-    if (!z.ok()) return fail(SVT_ERR_INVALID, std::string("cannot open ") + path);
     std::unique_ptr<svt_bam> b(new svt_bam());
     b->path = path;
+    if (!b->file.open(b->path)) return fail(SVT_ERR_INVALID, std::string("cannot open ") + path);
+    Bgzf z(b->file);
+    if (!z.ok()) return fail(SVT_ERR_NOMEM, "cannot set up the inflate state");
     uint8_t magic[4];
     z.seek(0);
     auto rd32 = [&](int32_t& v) {
@@ -753,20 +854,30 @@ int svt_bam_summarise(const svt_bam* bam, const svt_summarise_args* args, svt_su
     std::unordered_map<std::string, int32_t> rg_lib;
     for (uint32_t i = 0; i < args->n_read_groups; ++i) rg_lib[args->read_groups[i]] = args->read_group_lib[i];
 
-    std::vector<UnitOut> outs(n);
+    const bool trace = std::getenv("SVT_TRACE") != nullptr;
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (trace)
+            std::fprintf(stderr, "[svt_bam_summarise] %-10s %8.1f ms\n", what,
+                         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
+    };
+    std::vector<UnitSpan> outs(n);
     constexpr uint64_t kUnitsPerGrab = 16;
-    unsigned nt = args->n_threads > 0 ? (unsigned)args->n_threads : std::thread::hardware_concurrency();
+    unsigned nt = args->n_threads > 0 ? (unsigned)args->n_threads : svt::usable_cpus();
     nt = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(nt ? nt : 1, n ? n : 1));
     std::atomic<uint64_t> next(0);
     std::atomic<int> first_rc(SVT_OK);
     std::mutex err_lock;
     std::string first_err;
-    auto worker = [&]() {
-        Bgzf z(bam->path);
+    std::vector<std::unique_ptr<SummaryArena>> arenas(nt);
+    auto worker = [&](unsigned t) {
+        Bgzf z(bam->file);
         std::vector<uint8_t> buf;
+        UnitOut unit;
+        arenas[t].reset(new SummaryArena());
         if (!z.ok()) {
             std::lock_guard<std::mutex> g(err_lock);
-            if (first_rc.exchange(SVT_ERR_INVALID) == SVT_OK) first_err = "cannot reopen " + bam->path;
+            if (first_rc.exchange(SVT_ERR_NOMEM) == SVT_OK) first_err = "cannot set up the inflate state";
             return;
         }
         for (;;) {   // consecutive units stay on one thread: neighbouring sites share BGZF blocks (and its cache)
@@ -775,7 +886,13 @@ int svt_bam_summarise(const svt_bam* bam, const svt_summarise_args* args, svt_su
             for (uint64_t u = u0; u < std::min(n, u0 + kUnitsPerGrab); ++u) {
                 if (first_rc.load(std::memory_order_relaxed) != SVT_OK) return;
                 std::string err;
-                const int rc = process_unit(*bam, z, buf, *args, rg_lib, u, outs[u], err);
+                int rc = process_unit(*bam, z, buf, *args, rg_lib, u, unit, err);
+                if (rc == SVT_OK) {
+                    outs[u].count = unit.frags.size();
+                    outs[u].skipped = unit.skipped;
+                    outs[u].frags = arenas[t]->append(unit.frags);
+                    if (outs[u].count && !outs[u].frags) { rc = SVT_ERR_NOMEM; err = "out of host memory"; }
+                }
                 if (rc != SVT_OK) {
                     std::lock_guard<std::mutex> g(err_lock);
                     if (first_rc.exchange(rc) == SVT_OK) first_err = err;
@@ -784,18 +901,25 @@ int svt_bam_summarise(const svt_bam* bam, const svt_summarise_args* args, svt_su
             }
         }
     };
-    if (nt <= 1) worker();
+    if (nt <= 1) worker(0);
     else {
         std::vector<std::thread> pool;
-        for (unsigned t = 0; t < nt; ++t) pool.emplace_back(worker);
+        for (unsigned t = 0; t < nt; ++t) pool.emplace_back(worker, t);
         for (auto& th : pool) th.join();
     }
     if (first_rc.load() != SVT_OK) return fail(first_rc.load(), first_err);
+    lap("units");
 
     uint64_t total = 0;
-    for (const auto& o : outs) total += o.frags.size();
+    for (const auto& o : outs) total += o.count;
     out->frag_offset = static_cast<uint64_t*>(std::malloc((n + 1) * sizeof(uint64_t)));
-    out->fragments = static_cast<svt_fragment*>(std::malloc(std::max<uint64_t>(total, 1) * sizeof(svt_fragment)));
+    {   // 2 MB aligned + huge-page advice (still free()-able): 1.4 GB for 10 M summaries
+        const size_t bytes = std::max<uint64_t>(total, 1) * sizeof(svt_fragment);
+        void* p = nullptr;
+        if (bytes >= (4u << 20) && posix_memalign(&p, 2u << 20, bytes) == 0) madvise(p, bytes, MADV_HUGEPAGE);
+        else p = std::malloc(bytes);
+        out->fragments = static_cast<svt_fragment*>(p);
+    }
     out->skipped = static_cast<uint8_t*>(std::malloc(std::max<uint64_t>(n, 1)));
     if (!out->frag_offset || !out->fragments || !out->skipped) {
         svt_summaries_free(out);
@@ -804,7 +928,7 @@ int svt_bam_summarise(const svt_bam* bam, const svt_summarise_args* args, svt_su
     uint64_t off = 0;
     for (uint64_t u = 0; u < n; ++u) {
         out->frag_offset[u] = off;
-        off += outs[u].frags.size();
+        off += outs[u].count;
         out->skipped[u] = outs[u].skipped ? 1 : 0;
     }
     out->frag_offset[n] = off;
@@ -815,16 +939,19 @@ int svt_bam_summarise(const svt_bam* bam, const svt_summarise_args* args, svt_su
                 const uint64_t u0 = nextu.fetch_add(256);
                 if (u0 >= n) return;
                 for (uint64_t u = u0; u < std::min(n, u0 + 256); ++u)
-                    if (!outs[u].frags.empty())
-                        std::memcpy(out->fragments + out->frag_offset[u], outs[u].frags.data(),
-                                    outs[u].frags.size() * sizeof(svt_fragment));
+                    if (outs[u].count)
+                        std::memcpy(out->fragments + out->frag_offset[u], outs[u].frags,
+                                    outs[u].count * sizeof(svt_fragment));
             }
         };
         std::vector<std::thread> pool;
-        for (unsigned t = 1; t < std::min(nt, 16u); ++t) pool.emplace_back(copier);
+        for (unsigned t = 1; t < std::min(nt, 32u); ++t) pool.emplace_back(copier);
         copier();
         for (auto& th : pool) th.join();
     }
+    lap("gather");
+    arenas.clear();
+    lap("release");
     return SVT_OK;
 }
 
