@@ -243,3 +243,79 @@ def test_fuzz_random_records(hip_device, fixture_library, seed):
     for flags in ALL_FLAGS:
         got, want = run_both(batch, flags)
         assert_parity(got, want)
+
+
+# ------------------------------------------------------------------------------------------
+# BASELINE.json's full size (configs[2]: 1 M units, ~100 M records) through size-independent
+# properties -- the oracle only sees a bounded random sample of it
+# ------------------------------------------------------------------------------------------
+def _digest(res: ev.Results) -> np.ndarray:
+    """per-unit checksum over the whole 128-byte result record"""
+    words = np.ascontiguousarray(res.rec).view(np.uint64).reshape(len(res.rec), -1)
+    mult = (np.arange(words.shape[1], dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15) + np.uint64(1))
+    with np.errstate(over="ignore"):
+        return (words * mult).sum(axis=1, dtype=np.uint64)
+
+
+@pytest.fixture(scope="module")
+def full_c3(fixture_library):
+    import multiprocessing as mp
+    n, chunk = synth.CONFIGS["c3_mixed_1m"]["n_units"], 62_500
+    jobs = [(chunk, synth.BASE_SEED + 3 + 1000 * i, [fixture_library], synth.CONFIGS["c3_mixed_1m"]["svtype_mix"])
+            for i in range(n // chunk)]
+    with mp.get_context("fork").Pool(min(16, len(jobs))) as pool:
+        parts = pool.starmap(_c3_chunk, jobs)
+    return ev.concat_batches(parts)
+
+
+def _c3_chunk(n, seed, libs, mix):
+    return synth.make_units(n, seed, libs, svtype_mix=mix)
+
+
+def test_full_size_properties(hip_device, full_c3):
+    from oracle import c_oracle
+    from svtyper_amd import hip
+    batch = full_c3
+    n = batch.n_units
+    assert n == 1_000_000 and batch.n_records > 90_000_000
+    with hip.DeviceBatch(batch, device=hip_device) as d:
+        d.genotype(sync=True)
+        first = d.results()
+        d.genotype(sync=True)                       # idempotence: a second pass over the resident batch
+        again = d.results()
+    assert np.array_equal(first.rec, again.rec)
+    base = _digest(first)
+    # every result record is fully written and the padding stays zero
+    assert not first.rec["pad"].any()
+    assert np.isin(first.gt, (0, 1, 2, ev.GT_MISSING, ev.GT_BLANK)).all()
+
+    # split invariance: a unit's result does not depend on which other units share its batch / tile
+    cut = 333_337
+    lo = hip.genotype_batch(batch.slice(0, cut), device=hip_device)
+    hi = hip.genotype_batch(batch.slice(cut, n), device=hip_device)
+    assert np.array_equal(np.concatenate([_digest(lo), _digest(hi)]), base)
+
+    # permutation invariance (the library re-sorts units by length; results come back in input order)
+    rng = np.random.default_rng(99)
+    order = rng.permutation(n)
+    perm = hip.genotype_batch(synth.permute_units(batch, order), device=hip_device)
+    assert np.array_equal(_digest(perm), base[order])
+
+    # both device layouts agree on everything
+    dense = hip.genotype_batch(batch, device=hip_device, flags=ev.FLAG_DENSE_LAYOUT)
+    assert np.array_equal(dense.rec, first.rec)
+
+    # the oracle on a bounded random sample of the same units
+    pick = np.sort(rng.choice(n, 20_000, replace=False))
+    sample = synth.permute_units(batch, pick)
+    want = c_oracle.genotype_batch(sample, flags=0)
+    assert_parity(ev.Results(first.rec[pick].copy()), want)
+
+    # counts are truncations of the tallies they summarise (classic.py:455-465): int(a)+int(b) <= int(a+b)
+    c = first.counts
+    col = {name: c[:, i].astype(np.int64) for i, name in enumerate(ev.COUNT_NAMES)}
+    called = first.gt != ev.GT_BLANK
+    slack = (col["DP"] - col["RO"] - col["AO"])[called]
+    assert slack.min() >= 0 and slack.max() <= 1
+    t = first.tallies[called]
+    assert np.array_equal(col["DP"][called], np.trunc(t[:, 0] + t[:, 1] + t[:, 2] + t[:, 3] + t[:, 4]).astype(np.int64))
