@@ -40,9 +40,11 @@ inline void parallel_for(uint64_t n, Fn&& fn)
     for (auto& th : pool) th.join();
 }
 
-// Sort units by library and stream length inside chunks, cut into 64-unit tiles.  len_a/len_b are
-// the per-unit row counts of the two streams (dense layout: len_a = F, len_b = 0).  Chunks are
-// independent and are processed by several host threads.
+// Bucket units by their first library (one sample's units end up together, whatever the input
+// order: site-major batches interleave the samples), sort by stream length inside 16384-unit
+// chunks of that sequence, cut into 64-unit tiles.  len_a/len_b are the per-unit row counts of the
+// two streams (dense layout: len_a = F, len_b = 0).  Chunks are independent and are processed by
+// several host threads.
 inline void build_tiling(const svt_evidence_batch* in, const std::vector<uint32_t>& nrec,
                   const std::vector<uint32_t>& len_a, const std::vector<uint32_t>& len_b,
                   const std::vector<uint4>& scan, Tiling& G)
@@ -58,18 +60,29 @@ inline void build_tiling(const svt_evidence_batch* in, const std::vector<uint32_
     G.hdr.assign(n_tiles * kWave, LaneHdr{});
     G.lane_src.assign(n_tiles * kWave, 0);
     G.lane_nrec.assign(n_tiles * kWave, 0);
+    // stable counting sort by first library: a workgroup's library window (LDS) then covers one
+    // sample, and the length sort below runs over a whole chunk of that sample's units
+    std::vector<uint32_t> by_lib;
+    if (in->n_libs > 1) {
+        uint64_t start[257] = {0};
+        for (uint64_t u = 0; u < n; ++u) ++start[(scan[u].z & 0xffu) + 1];
+        for (int l = 0; l < 256; ++l) start[l + 1] += start[l];
+        by_lib.resize(n);
+        for (uint64_t u = 0; u < n; ++u) by_lib[start[scan[u].z & 0xffu]++] = (uint32_t)u;
+    }
+    auto unit_at = [&](uint64_t i) -> uint64_t { return by_lib.empty() ? i : by_lib[i]; };
     parallel_for(n_chunks, [&](uint64_t c) {
         const uint64_t c0 = c * kChunkUnits;
         const uint32_t cn = (uint32_t)std::min<uint64_t>(kChunkUnits, n - c0);
         std::vector<uint32_t> order(cn);
         for (uint32_t i = 0; i < cn; ++i) order[i] = i;
-        // by first library (keeps the units of one sample together so a workgroup's library window
-        // stays small), then longest first
+        // by first library, then longest first
         std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
-            const uint32_t lx = scan[c0 + x].z, ly = scan[c0 + y].z;
+            const uint64_t ux = unit_at(c0 + x), uy = unit_at(c0 + y);
+            const uint32_t lx = scan[ux].z, ly = scan[uy].z;
             if (lx != ly) return lx < ly;
-            const uint64_t kx = ((uint64_t)len_a[c0 + x] << 32) | len_b[c0 + x];
-            const uint64_t ky = ((uint64_t)len_a[c0 + y] << 32) | len_b[c0 + y];
+            const uint64_t kx = ((uint64_t)len_a[ux] << 32) | len_b[ux];
+            const uint64_t ky = ((uint64_t)len_a[uy] << 32) | len_b[uy];
             return kx > ky;
         });
         for (uint32_t t0 = 0; t0 < cn; t0 += kWave) {
@@ -83,7 +96,7 @@ inline void build_tiling(const svt_evidence_batch* in, const std::vector<uint32_
                 uint64_t src = 0;
                 uint32_t f = 0;
                 if (t0 + l < cn) {
-                    const uint64_t u = c0 + order[t0 + l];
+                    const uint64_t u = unit_at(c0 + order[t0 + l]);
                     const svt_unit& U = in->units[u];
                     h.var_length = U.var_length;
                     h.pos_delta = U.pos_delta;

@@ -16,7 +16,7 @@
 //     truncated integer counts are bit-exact.  No FMA contraction (-ffp-contract=off).
 //   * records are re-tiled once per batch into lane-interleaved tiles: row j of a tile holds
 //     the j-th 16 bytes of its 64 units back to back, so every wave-level load is one contiguous
-//     1 KiB global_load_dwordx4.  Units are sorted by length inside 4096-unit chunks so that the
+//     1 KiB global_load_dwordx4.  Units are sorted by length inside 16384-unit chunks so that the
 //     zero-padding of a tile stays small.  Two device layouts:
 //       - split (default): a unit's evidence becomes two sparse 8-byte streams -- pair entries
 //         (only fragments with a straddle bit) and weight entries (only fragments with a non-zero
