@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SVT_ABI_VERSION 3
+#define SVT_ABI_VERSION 4
 
 /* ---- error codes (0 = ok, <0 = error; text via svt_last_error()) ---------- */
 #define SVT_OK 0
@@ -59,10 +59,15 @@ extern "C" {
  *                then added to the site total (singlesample.py:246-276,367-372) */
 #define SVT_FLAG_SSO_ASSOCIATION 0x1u
 /* device layout of the resident batch:
- *   0 (default, "split"): the records are re-encoded once, on the device, into two sparse
- *       8-byte streams per unit -- pair entries (ospan, mapq_a, mapq_b, straddle bits, library)
- *       for fragments with a straddle bit, weight entries (the six gated MAPQs) for fragments
- *       with a non-zero gated MAPQ.  Dropped entries could only have added +0.0.
+ *   0 (default, "compact"): the records are re-encoded once, on the device, into two sparse
+ *       streams of 4-byte entries per unit -- pair entries (straddle bits, mapq_a, mapq_b and
+ *       ospan_len translated into the index space of the library's histogram tables) for
+ *       fragments with a straddle bit and two non-zero MAPQs, weight entries (one gated MAPQ
+ *       pair + its kind) for every non-zero reference / split / clip pair.  Dropped entries
+ *       could only have added +0.0.  The encoding needs histograms of at most 4095 bins, DEL
+ *       lengths >= 0 and, with several libraries, units whose libraries span at most 4
+ *       consecutive indices and MAPQs <= 127 on the kept pair entries; a batch that does not
+ *       qualify silently uses the dense layout (svt_batch_layout tells which one it got).
  *   SVT_FLAG_DENSE_LAYOUT: the 16-byte records are streamed as they are.
  * Results are bit-identical between the two.                                              */
 #define SVT_FLAG_DENSE_LAYOUT 0x2u
@@ -304,6 +309,11 @@ int svt_batch_bind_device_results(svt_batch* b, svt_result* dev_ptr);
  * section 8(d): sum_u (16*F(u) + 16 + 96); and what the tiled layout really
  * holds (padding included).                                                     */
 int svt_batch_bytes(const svt_batch* b, uint64_t* algorithmic, uint64_t* resident);
+
+/* Which device layout / kernel flavour the batch got: *compact = 1 for the compact entry streams,
+ * 0 for the dense records; *table_mode = 0 one library, tables in LDS; 1 several libraries,
+ * per-workgroup library windows in LDS; 2 general geometry, tables read through L2.          */
+int svt_batch_layout(const svt_batch* b, int* compact, int* table_mode);
 
 /* The HIP stream (hipStream_t) the batch launches on, as an opaque pointer.    */
 void* svt_batch_stream(svt_batch* b);

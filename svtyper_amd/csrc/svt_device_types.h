@@ -24,12 +24,12 @@ struct LaneHdr {          // 16 B, one per tile lane
     int32_t var_length;
     int32_t pos_delta;
     uint32_t unit;        // original unit index, kPadUnit for padding lanes
-    uint32_t packed;      // svtype | flags << 8 | sample << 16
+    uint32_t packed;      // svtype | flags << 8 | first library of the unit << 16
 };
 
 // One 64-unit tile.  Dense layout: rows_a rows of 16-byte records at base_a (rows_b == 0).
-// Split layout: rows_a rows of pair entries at base_a, rows_b rows of weight entries at base_b
-// (each 16-byte row slot of a lane holds two consecutive 8-byte entries).
+// Compact layout: rows_a rows of pair entries at base_a, rows_b rows of weight entries at base_b
+// (each 16-byte row slot of a lane holds four consecutive 4-byte entries).
 struct TileDesc {         // 32 B, stored in dispatch (longest-first) order
     uint64_t base_a;
     uint64_t base_b;

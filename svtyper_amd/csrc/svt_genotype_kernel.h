@@ -30,6 +30,8 @@ struct LaneCtx {
     uint32_t kmin;        // kSingleLds: (uint32) key_min
     uint32_t nb;          // kSingleLds: n_bins (== sentinel index)
     uint32_t sub2;        // kSingleLds: DEL ? var_length + key_min : 0x80000000 (never in range)
+    uint32_t off2;        // compact layout, kSingleLds: DEL ? min(var_length, n_bins) : 0x80000000
+    uint32_t lib_min;     // compact layout, kMultiLds: first library of the lane's unit
     uint32_t lib_lo;      // kMultiLds: first library / first bin staged by this workgroup
     uint32_t bin_lo;
     int32_t var_length;
@@ -131,6 +133,66 @@ __device__ __forceinline__ void pair_evidence(const uint32_t o, const uint32_t m
     a.ref_span += pp * pw.w_ref;
 }
 
+// ---- compact layout (svt_prepare_kernels.h describes the entries) -------------------------------
+// Pair entry: the two table indices come from `code` by clamping; the look-ups, the p_concordant
+// decision and the sums are the ones of pair_evidence above.
+template <int MODE>
+__device__ __forceinline__ void pair_entry(const uint32_t e, const Tables& t, const LaneCtx& c, Acc& a)
+{
+    const uint32_t code = e & ((1u << kCodeBits) - 1u);
+    const uint32_t f3 = (e >> kCodeBits) & 7u;
+    double pm_a, pm_b;
+    int32_t thr1;
+    uint32_t h2;
+    if (MODE == kSingleLds) {
+        pm_a = t.pm[(e >> 16) & 0xffu];
+        pm_b = t.pm[e >> 24];
+        thr1 = t.thr[min(code, c.nb)];
+        h2 = t.hist[min(code - c.off2, c.nb)];
+    } else {
+        pm_a = t.pm[(e >> 16) & 0x7fu];
+        pm_b = t.pm[(e >> 23) & 0x7fu];
+        const LibDesc lib = t.libs[c.lib_min + (e >> 30) - c.lib_lo];
+        const uint32_t off2 = c.is_del ? min((uint32_t)c.var_length, lib.n_bins) : 0x80000000u;
+        const uint32_t base = lib.tab_off - c.bin_lo;
+        thr1 = t.thr[base + min(code, lib.n_bins)];
+        h2 = t.hist[base + min(code - off2, lib.n_bins)];
+    }
+    const bool p_conc = (int32_t)h2 <= thr1;
+    const PairWeights pw = t.wtab[f3 | (p_conc ? 8u : 0u) | c.del16];
+    const double pp = pm_a * pm_b;
+    a.alt_span += pp * pw.w_alt;
+    a.ref_span += pp * pw.w_ref;
+}
+
+// Weight entry of one kind (classic.py:306-328): the other two sums receive +0.0.
+template <bool SSO>
+__device__ __forceinline__ void weight_entry(const uint32_t e, const Tables& t, Acc& a)
+{
+    const double x = t.pm[e & 0xffu];
+    const double y = t.pm[(e >> 8) & 0xffu];
+    const uint32_t kind = (e >> 16) & 3u;
+    const double xr = kind == 0u ? x : 0.0, yr = kind == 0u ? y : 0.0;
+    const double p = (x + y) * 0.5;                       // (pm(left) * L + pm(right) * R) / 2.0
+    const double ps = kind == 1u ? p : 0.0, pc = kind == 2u ? p : 0.0;
+    if (SSO) {
+        // singlesample.py:246-276,367-372: fragment-local sums, added to the site totals when the
+        // next fragment (with evidence of this kind) starts
+        const bool first = (e & (1u << 18)) != 0u;
+        const bool f0 = first && kind == 0u, f1 = first && kind == 1u, f2 = first && kind == 2u;
+        a.ref_seq += f0 ? a.l_ref_seq : 0.0;
+        a.alt_seq += f1 ? a.l_alt_seq : 0.0;
+        a.alt_clip += f2 ? a.l_alt_clip : 0.0;
+        a.l_ref_seq = ((f0 ? 0.0 : a.l_ref_seq) + xr) + yr;
+        a.l_alt_seq = (f1 ? 0.0 : a.l_alt_seq) + ps;
+        a.l_alt_clip = (f2 ? 0.0 : a.l_alt_clip) + pc;
+    } else {
+        a.ref_seq = (a.ref_seq + xr) + yr;
+        a.alt_seq += ps;
+        a.alt_clip += pc;
+    }
+}
+
 __device__ __forceinline__ double log_choose_dev(const double* __restrict__ l10, int32_t n, int32_t k)
 {
     // statistics.py:9-20 -- same loop, log(i)/log(10) from the host-built table
@@ -187,7 +249,7 @@ __device__ __forceinline__ void stream_rows(const uint4* __restrict__ p, const u
 // ------------------------------------------------------------------------------------------
 // genotype kernel
 // ------------------------------------------------------------------------------------------
-template <bool SSO, int MODE, bool SPLIT>
+template <bool SSO, int MODE, bool COMPACT>
 __global__ __launch_bounds__(kBlock, SVT_MIN_WAVES) void svt_genotype_kernel(const KernelArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -250,21 +312,25 @@ __global__ __launch_bounds__(kBlock, SVT_MIN_WAVES) void svt_genotype_kernel(con
         c.kmin = (uint32_t)a.lib0.key_min;
         c.nb = a.lib0.n_bins;
         c.sub2 = c.is_del ? (uint32_t)h.var_length + (uint32_t)a.lib0.key_min : 0x80000000u;
+        c.off2 = c.is_del ? min((uint32_t)h.var_length, a.lib0.n_bins) : 0x80000000u;
+        c.lib_min = (h.packed >> 16) & 0xffu;
     }
 
     Acc acc = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
 
     // ---- stream the tile: row j is one contiguous 1 KiB line for the wave
-    if (SPLIT) {
-        // pair entries: x = ospan_len, y = mapq_a | mapq_b << 8 | f3 << 16 | lib << 24
+    if (COMPACT) {
         stream_rows<SVT_GROUP_A>(a.tiled + td.base_a + lane, td.rows_a, [&](const uint4 w) {
-            pair_evidence<MODE>(w.x, w.y & 0xffffu, (w.y >> 16) & 7u, w.y >> 24, t, c, acc);
-            pair_evidence<MODE>(w.z, w.w & 0xffffu, (w.w >> 16) & 7u, w.w >> 24, t, c, acc);
+            pair_entry<MODE>(w.x, t, c, acc);
+            pair_entry<MODE>(w.y, t, c, acc);
+            pair_entry<MODE>(w.z, t, c, acc);
+            pair_entry<MODE>(w.w, t, c, acc);
         });
-        // weight entries: x = rs_a | rs_b << 8 | seq_l << 16 | seq_r << 24, y = clip_l | clip_r << 8 | cont << 16
         stream_rows<SVT_GROUP_B>(a.tiled + td.base_b + lane, td.rows_b, [&](const uint4 w) {
-            weight_evidence<SSO>(w.x, w.y, (w.y & 0x10000u) != 0, t, acc);
-            weight_evidence<SSO>(w.z, w.w, (w.w & 0x10000u) != 0, t, acc);
+            weight_entry<SSO>(w.x, t, acc);
+            weight_entry<SSO>(w.y, t, acc);
+            weight_entry<SSO>(w.z, t, acc);
+            weight_entry<SSO>(w.w, t, acc);
         });
     } else {
         // canonical 16-byte records (include/svtyper_hip.h: svt_record)

@@ -65,7 +65,7 @@ inline void build_tiling(const svt_evidence_batch* in, const std::vector<uint32_
     std::vector<uint32_t> by_lib;
     if (in->n_libs > 1) {
         uint64_t start[257] = {0};
-        for (uint64_t u = 0; u < n; ++u) ++start[(scan[u].z & 0xffu) + 1];
+        for (uint64_t u = 0; u < n; ++u) ++start[(scan[u].z & 0xffu) + 1];   // z = lib_min | lib_max << 8
         for (int l = 0; l < 256; ++l) start[l + 1] += start[l];
         by_lib.resize(n);
         for (uint64_t u = 0; u < n; ++u) by_lib[start[scan[u].z & 0xffu]++] = (uint32_t)u;
@@ -79,7 +79,7 @@ inline void build_tiling(const svt_evidence_batch* in, const std::vector<uint32_
         // by first library, then longest first
         std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
             const uint64_t ux = unit_at(c0 + x), uy = unit_at(c0 + y);
-            const uint32_t lx = scan[ux].z, ly = scan[uy].z;
+            const uint32_t lx = scan[ux].z & 0xffu, ly = scan[uy].z & 0xffu;
             if (lx != ly) return lx < ly;
             const uint64_t kx = ((uint64_t)len_a[ux] << 32) | len_b[ux];
             const uint64_t ky = ((uint64_t)len_a[uy] << 32) | len_b[uy];
@@ -101,14 +101,14 @@ inline void build_tiling(const svt_evidence_batch* in, const std::vector<uint32_
                     h.var_length = U.var_length;
                     h.pos_delta = U.pos_delta;
                     h.unit = (uint32_t)u;
-                    h.packed = (uint32_t)U.svtype | ((uint32_t)U.flags << 8) | ((uint32_t)U.sample << 16);
+                    h.packed = (uint32_t)U.svtype | ((uint32_t)U.flags << 8) | ((scan[u].z & 0xffu) << 16);
                     src = in->rec_offset[u];
                     f = nrec[u];
                     td.rows_a = std::max(td.rows_a, len_a[u]);
                     td.rows_b = std::max(td.rows_b, len_b[u]);
                     if (f) {
-                        lib_lo = std::min(lib_lo, scan[u].z);
-                        lib_hi = std::max(lib_hi, scan[u].w);
+                        lib_lo = std::min(lib_lo, scan[u].z & 0xffu);
+                        lib_hi = std::max(lib_hi, (scan[u].z >> 8) & 0xffu);
                     }
                 }
                 G.hdr[td.lane_base + l] = h;

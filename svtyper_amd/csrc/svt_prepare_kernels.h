@@ -11,37 +11,118 @@ namespace svt {
 // batch preparation kernels (run once per batch, outside the genotyping pass)
 // ------------------------------------------------------------------------------------------
 
-// which sparse streams a canonical record feeds
-__device__ __forceinline__ bool has_pair_entry(const uint4 w) { return (w.w & 7u) != 0u; }
-__device__ __forceinline__ bool has_weight_entry(const uint4 w) { return ((w.y >> 16) | w.z) != 0u; }
+// ---- compact layout --------------------------------------------------------------------------
+// A unit's evidence becomes two sparse streams of 4-byte entries (four per 16-byte row slot):
+//
+//   pair entry    code | f3 << 13 | mapq_a << 16 | mapq_b << 24                      (one library)
+//                 code | f3 << 13 | mapq_a << 16 | mapq_b << 23 | (lib - lib_min) << 30   (several)
+//     f3   = alt | refA << 1 | refB << 2 straddle bits
+//     code = ospan_len translated into the index space of the library's histogram tables: with
+//            r = ospan_len - key_min, the kernel needs hist/thr[r] (parsers.py:870-872) and, for a
+//            DEL, hist[r - var_length] (parsers.py:874-878), each replaced by the sentinel bin
+//            n_bins when out of range.  With off2 = min(var_length, n_bins):
+//                var_length <  n_bins:  code = r            for 0 <= r < var_length + n_bins
+//                var_length >= n_bins:  code = r            for 0 <= r < n_bins
+//                                       code = n_bins + (r - var_length)   for 0 <= r - var_length < n_bins
+//                anything else / not a DEL window:  code = 2 * n_bins
+//            so that i1 = min(code, n_bins) and i2 = min(code - off2, n_bins) (unsigned) are exactly the
+//            two table indices.  Only the addressing is precomputed; the look-ups, the p_concordant
+//            decision and every sum stay in the genotype kernel.
+//   weight entry  mapq0 | mapq1 << 8 | kind << 16 | first_of_fragment << 18
+//     kind 0: reference reads (rs_a, rs_b), 1: split candidate (seq_l, seq_r), 2: clip candidate
+//     first_of_fragment: first kept entry of this kind in its read-fragment (sso association)
+//
+// Entries that can only add +0.0 to a sum are not stored: pair entries without a straddle bit, with a
+// zero MAPQ on either read, or of a DEL smaller than 2 sd of the entry's library (classic.py:339,383);
+// weight kinds whose two gated MAPQs are 0.  x + 0.0 == x bit-for-bit for these non-negative sums.
 
-// one thread per unit: validate the record contract of include/svtyper_hip.h and count the entries
-// of the two sparse streams and the range of libraries the unit references
-__global__ __launch_bounds__(kBlock) void svt_scan_kernel(const uint4* __restrict__ csr,
-                                                          const uint64_t* __restrict__ rec_offset,
-                                                          uint64_t n_units, uint32_t n_libs,
-                                                          uint4* __restrict__ counts, uint32_t* err)
+struct UnitGeom {
+    bool is_del;
+    int32_t var_length;
+    double pos_delta_d;
+};
+
+__device__ __forceinline__ UnitGeom unit_geom(const svt_unit& U)
+{
+    UnitGeom g;
+    g.is_del = U.svtype == SVT_SVTYPE_DEL;
+    g.var_length = U.var_length;
+    g.pos_delta_d = (double)U.pos_delta;
+    return g;
+}
+
+__device__ __forceinline__ bool keeps_pair_entry(const uint4 w, const UnitGeom& g, const LibDesc& lib)
+{
+    if ((w.w & 7u) == 0u) return false;
+    if ((w.y & 0xffu) == 0u || (w.y & 0xff00u) == 0u) return false;      // prob_mapq(0) == 0.0
+    if (g.is_del && g.pos_delta_d < lib.sd2) return false;                // classic.py:339,383
+    return true;
+}
+
+__device__ __forceinline__ uint32_t pair_code(const uint32_t ospan_len, const UnitGeom& g, const LibDesc& lib)
+{
+    const int64_t nb = lib.n_bins;
+    const int64_t r = (int64_t)(int32_t)ospan_len - (int64_t)lib.key_min;
+    const bool in1 = r >= 0 && r < nb;
+    if (!g.is_del) return in1 ? (uint32_t)r : (uint32_t)(2 * nb);
+    const int64_t vl = g.var_length;            // >= 0 (checked on the host before this layout is chosen)
+    const int64_t r2 = r - vl;
+    const bool in2 = r2 >= 0 && r2 < nb;
+    if (vl < nb) return (r >= 0 && r < vl + nb) ? (uint32_t)r : (uint32_t)(2 * nb);
+    return in1 ? (uint32_t)r : in2 ? (uint32_t)(nb + r2) : (uint32_t)(2 * nb);
+}
+
+// the three weight kinds of a canonical record: gated MAPQ pairs (lo byte, hi byte), 0 = nothing to add
+__device__ __forceinline__ void weight_kinds(const uint4 w, uint32_t k[3])
+{
+    k[0] = w.y >> 16;            // rs_a | rs_b << 8
+    k[1] = w.z & 0xffffu;        // seq_l | seq_r << 8
+    k[2] = w.z >> 16;            // clip_l | clip_r << 8
+}
+
+struct ScanArgs {
+    const uint4* csr;
+    const uint64_t* rec_offset;
+    const svt_unit* units;
+    const LibDesc* libs;
+    uint64_t n_units;
+    uint32_t n_libs;
+    uint4* counts;      // per unit: pair entries, weight entries, lib_min | lib_max << 8, kScan* flags
+    uint32_t* err;
+};
+constexpr uint32_t kScanWideMapq = 1u;   // a kept pair entry has a MAPQ > 127
+
+// one thread per unit: validate the record contract of include/svtyper_hip.h, count the entries of the
+// two sparse streams and find the range of libraries the unit references
+__global__ __launch_bounds__(kBlock) void svt_scan_kernel(const ScanArgs a)
 {
     const uint64_t u = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (u >= n_units) return;
-    const uint64_t lo = rec_offset[u], hi = rec_offset[u + 1];
-    uint32_t np = 0, nq = 0, bad = 0, lib_min = 0xffu, lib_max = 0u;
+    if (u >= a.n_units) return;
+    const uint64_t lo = a.rec_offset[u], hi = a.rec_offset[u + 1];
+    const UnitGeom g = unit_geom(a.units[u]);
+    uint32_t np = 0, nq = 0, bad = 0, lib_min = 0xffu, lib_max = 0u, flags = 0u;
     for (uint64_t j = lo; j < hi; ++j) {
-        const uint4 w = csr[j];
+        const uint4 w = a.csr[j];
         const uint32_t f = w.w;
-        lib_min = min(lib_min, SVT_REC_LIB(f));
-        lib_max = max(lib_max, SVT_REC_LIB(f));
+        const uint32_t lib = SVT_REC_LIB(f);
+        lib_min = min(lib_min, lib);
+        lib_max = max(lib_max, lib);
         if (!(f & SVT_REC_HAS_PAIR) &&
             (f & (SVT_REC_ALT_STRADDLE | SVT_REC_REF_STRADDLE_A | SVT_REC_REF_STRADDLE_B))) bad |= 2u;
-        if (SVT_REC_LIB(f) >= n_libs) bad |= 4u;
+        if (lib >= a.n_libs) { bad |= 4u; continue; }
         if (f & ~SVT_REC_FLAG_MASK) bad |= 8u;
         if ((int32_t)w.x < 0) bad |= 16u;
-        np += has_pair_entry(w) ? 1u : 0u;
-        nq += has_weight_entry(w) ? 1u : 0u;
+        if (keeps_pair_entry(w, g, a.libs[lib])) {
+            ++np;
+            if ((w.y & 0x8080u) != 0u) flags |= kScanWideMapq;
+        }
+        uint32_t k[3];
+        weight_kinds(w, k);
+        nq += (k[0] ? 1u : 0u) + (k[1] ? 1u : 0u) + (k[2] ? 1u : 0u);
     }
     if (lo == hi) lib_min = 0u;
-    counts[u] = make_uint4(np, nq, lib_min, lib_max);
-    if (bad) atomicOr(err, bad);
+    a.counts[u] = make_uint4(np, nq, lib_min | (lib_max << 8), flags);
+    if (bad) atomicOr(a.err, bad);
 }
 
 struct RepackArgs {
@@ -49,8 +130,12 @@ struct RepackArgs {
     const uint64_t* lane_src;   // per tile lane: first CSR record of the unit
     const uint32_t* lane_nrec;  // per tile lane: F (0 for padding lanes)
     const TileDesc* tiles;      // in storage order
+    const LaneHdr* hdr;         // per tile lane (compact layout: unit geometry + first library)
+    const svt_unit* units;
+    const LibDesc* libs;
     uint4* tiled;
     uint32_t n_tiles;
+    uint32_t multi_lib;         // pair entries carry (lib - lib_min) and 7-bit MAPQs
 };
 
 // dense layout: CSR records -> lane-interleaved rows of 16-byte records
@@ -69,10 +154,35 @@ __global__ __launch_bounds__(kBlock) void svt_repack_dense_kernel(const RepackAr
     }
 }
 
-// split layout: CSR records -> pair-entry rows + weight-entry rows.  Entries keep the order of the
-// records they come from; a record that cannot change a sum (no straddle bit / all gated MAPQs 0)
-// produces no entry in that stream.
-__global__ __launch_bounds__(kBlock) void svt_repack_split_kernel(const RepackArgs a)
+// four 4-byte entries per 16-byte row slot of the lane
+struct RowWriter {
+    uint4* out;       // row 0 of this lane
+    uint32_t n = 0;   // entries so far
+    uint4 hold = make_uint4(0, 0, 0, 0);
+    __device__ __forceinline__ void put(const uint32_t e)
+    {
+        switch (n & 3u) {
+        case 0: hold.x = e; break;
+        case 1: hold.y = e; break;
+        case 2: hold.z = e; break;
+        default:
+            hold.w = e;
+            out[(uint64_t)(n >> 2) * kWave] = hold;
+            hold = make_uint4(0, 0, 0, 0);
+        }
+        ++n;
+    }
+    // flush the open row and zero the rest of the tile's rows (zero entries add +0.0)
+    __device__ __forceinline__ void finish(const uint32_t rows)
+    {
+        uint32_t r = n >> 2;
+        if (n & 3u) out[(uint64_t)r++ * kWave] = hold;
+        for (; r < rows; ++r) out[(uint64_t)r * kWave] = make_uint4(0, 0, 0, 0);
+    }
+};
+
+// compact layout: CSR records -> pair-entry rows + weight-entry rows, in record order
+__global__ __launch_bounds__(kBlock) void svt_repack_compact_kernel(const RepackArgs a)
 {
     const uint32_t wave = threadIdx.x / kWave;
     const uint32_t lane = threadIdx.x % kWave;
@@ -81,35 +191,34 @@ __global__ __launch_bounds__(kBlock) void svt_repack_split_kernel(const RepackAr
     const TileDesc td = a.tiles[tile_idx];
     const uint64_t src = a.lane_src[td.lane_base + lane];
     const uint32_t nrec = a.lane_nrec[td.lane_base + lane];
-    uint4* __restrict__ outp = a.tiled + td.base_a + lane;
-    uint4* __restrict__ outq = a.tiled + td.base_b + lane;
-    uint32_t np = 0, nq = 0;
-    uint2 hold_p = make_uint2(0, 0), hold_q = make_uint2(0, 0);
-    bool frag_has_q = false;  // did the current fragment already emit a weight entry?
+    const LaneHdr h = a.hdr[td.lane_base + lane];
+    UnitGeom g{false, 0, 0.0};
+    if (h.unit != kPadUnit) g = unit_geom(a.units[h.unit]);
+    const uint32_t lib_min = (h.packed >> 16) & 0xffu;
+    RowWriter P{a.tiled + td.base_a + lane}, Q{a.tiled + td.base_b + lane};
+    bool frag_has[3] = {false, false, false};  // did the current fragment already emit an entry of this kind?
     for (uint32_t j = 0; j < nrec; ++j) {
         const uint4 w = a.csr[src + j];
-        if (!(w.w & SVT_REC_CONTINUATION)) frag_has_q = false;
-        if (has_pair_entry(w)) {
-            const uint2 e = make_uint2(w.x, (w.y & 0xffffu) | ((w.w & 7u) << 16) | (SVT_REC_LIB(w.w) << 24));
-            if (np & 1u) outp[(uint64_t)(np >> 1) * kWave] = make_uint4(hold_p.x, hold_p.y, e.x, e.y);
-            else hold_p = e;
-            ++np;
+        if (!(w.w & SVT_REC_CONTINUATION)) frag_has[0] = frag_has[1] = frag_has[2] = false;
+        const uint32_t lib_idx = SVT_REC_LIB(w.w);
+        const LibDesc lib = a.libs[lib_idx];
+        if (keeps_pair_entry(w, g, lib)) {
+            const uint32_t code = pair_code(w.x, g, lib) | ((w.w & 7u) << kCodeBits);
+            const uint32_t mq_a = w.y & 0xffu, mq_b = (w.y >> 8) & 0xffu;
+            P.put(a.multi_lib ? (code | (mq_a << 16) | (mq_b << 23) | ((lib_idx - lib_min) << 30))
+                              : (code | (mq_a << 16) | (mq_b << 24)));
         }
-        if (has_weight_entry(w)) {
-            // the continuation bit only survives if the entry it continues was emitted too; a
-            // dropped predecessor contributed exactly +0.0 to the fragment-local sums
-            const uint2 e = make_uint2((w.y >> 16) | (w.z << 16), (w.z >> 16) | (frag_has_q ? 0x10000u : 0u));
-            if (nq & 1u) outq[(uint64_t)(nq >> 1) * kWave] = make_uint4(hold_q.x, hold_q.y, e.x, e.y);
-            else hold_q = e;
-            ++nq;
-            frag_has_q = true;
-        }
+        uint32_t k[3];
+        weight_kinds(w, k);
+#pragma unroll
+        for (uint32_t kind = 0; kind < 3; ++kind)
+            if (k[kind]) {
+                Q.put(k[kind] | (kind << 16) | (frag_has[kind] ? 0u : (1u << 18)));
+                frag_has[kind] = true;
+            }
     }
-    uint32_t rp = np >> 1, rq = nq >> 1;
-    if (np & 1u) outp[(uint64_t)rp++ * kWave] = make_uint4(hold_p.x, hold_p.y, 0, 0);
-    if (nq & 1u) outq[(uint64_t)rq++ * kWave] = make_uint4(hold_q.x, hold_q.y, 0, 0);
-    for (; rp < td.rows_a; ++rp) outp[(uint64_t)rp * kWave] = make_uint4(0, 0, 0, 0);
-    for (; rq < td.rows_b; ++rq) outq[(uint64_t)rq * kWave] = make_uint4(0, 0, 0, 0);
+    P.finish(td.rows_a);
+    Q.finish(td.rows_b);
 }
 
 

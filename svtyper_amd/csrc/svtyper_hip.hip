@@ -18,10 +18,11 @@
 //     the j-th 16 bytes of its 64 units back to back, so every wave-level load is one contiguous
 //     1 KiB global_load_dwordx4.  Units are sorted by length inside 16384-unit chunks so that the
 //     zero-padding of a tile stays small.  Two device layouts:
-//       - split (default): a unit's evidence becomes two sparse 8-byte streams -- pair entries
-//         (only fragments with a straddle bit) and weight entries (only fragments with a non-zero
-//         gated MAPQ); entries that could only add +0.0 are dropped, which the reference's sums
-//         cannot observe;
+//       - compact (default): a unit's evidence becomes two sparse streams of 4-byte entries --
+//         pair entries (straddle bits, both MAPQs, ospan_len translated into the histogram's index
+//         space) and weight entries (one per non-zero reference / split / clip MAPQ pair); entries
+//         that could only add +0.0 are dropped, which the reference's sums cannot observe
+//         (svt_prepare_kernels.h has the format);
 //       - dense (SVT_FLAG_DENSE_LAYOUT): the canonical 16-byte records as they are.
 //   * all look-up tables (prob_mapq, insert-size histogram + p_concordant thresholds, log10,
 //     paired-end decision weights) are built on the host with the same libm CPython uses and
@@ -50,10 +51,10 @@
 #define SVT_GROUP 4   // rows fetched per look-ahead group (dense layout)
 #endif
 #ifndef SVT_GROUP_A
-#define SVT_GROUP_A 2 // split layout, pair-entry rows
+#define SVT_GROUP_A 2 // compact layout, pair-entry rows
 #endif
 #ifndef SVT_GROUP_B
-#define SVT_GROUP_B 2 // split layout, weight-entry rows
+#define SVT_GROUP_B 2 // compact layout, weight-entry rows
 #endif
 #ifndef SVT_MIN_WAVES
 #define SVT_MIN_WAVES 1
@@ -84,7 +85,7 @@ struct svt_batch {
     uint64_t n_units = 0, n_records = 0, slots = 0;
     uint32_t n_tiles = 0;
     int mode = kSingleLds;
-    bool split = true;
+    bool compact = true;   // sparse 4-byte entry streams (default) vs the canonical 16-byte records
     size_t lds_bytes = 0;
     bool have_results = false;
     // device buffers
@@ -146,21 +147,23 @@ int upload(DevScratch& d, const std::vector<T>& v, hipStream_t s)
     return SVT_OK;
 }
 
-template <bool SSO, bool SPLIT>
-const void* kernel_for(int mode)
+template <bool SSO>
+const void* kernel_for(int mode, bool compact)
 {
+    if (compact)   // only chosen together with one of the LDS modes (create_on_device)
+        return mode == kSingleLds ? reinterpret_cast<const void*>(&svt_genotype_kernel<SSO, kSingleLds, true>)
+                                  : reinterpret_cast<const void*>(&svt_genotype_kernel<SSO, kMultiLds, true>);
     switch (mode) {
-    case kSingleLds: return reinterpret_cast<const void*>(&svt_genotype_kernel<SSO, kSingleLds, SPLIT>);
-    case kMultiLds:  return reinterpret_cast<const void*>(&svt_genotype_kernel<SSO, kMultiLds, SPLIT>);
-    default:         return reinterpret_cast<const void*>(&svt_genotype_kernel<SSO, kGeneral, SPLIT>);
+    case kSingleLds: return reinterpret_cast<const void*>(&svt_genotype_kernel<SSO, kSingleLds, false>);
+    case kMultiLds:  return reinterpret_cast<const void*>(&svt_genotype_kernel<SSO, kMultiLds, false>);
+    default:         return reinterpret_cast<const void*>(&svt_genotype_kernel<SSO, kGeneral, false>);
     }
 }
 
 const void* kernel_of(const svt_batch* b)
 {
-    const bool sso = (b->flags & SVT_FLAG_SSO_ASSOCIATION) != 0;
-    if (b->split) return sso ? kernel_for<true, true>(b->mode) : kernel_for<false, true>(b->mode);
-    return sso ? kernel_for<true, false>(b->mode) : kernel_for<false, false>(b->mode);
+    return (b->flags & SVT_FLAG_SSO_ASSOCIATION) ? kernel_for<true>(b->mode, b->compact)
+                                                 : kernel_for<false>(b->mode, b->compact);
 }
 
 int launch_genotype(svt_batch* b)
@@ -195,7 +198,7 @@ int create_on_device(const svt_evidence_batch* in, svt_batch* b, const uint4* d_
     // ---- per-unit record counts + validation of the CSR
     std::vector<uint32_t> nrec(n);
     uint64_t max_f = 0;
-    bool wide_var_length = false;
+    bool wide_var_length = false, negative_del = false;
     for (uint64_t u = 0; u < n; ++u) {
         if (in->rec_offset[u + 1] < in->rec_offset[u]) return fail(SVT_ERR_INVALID, "rec_offset not monotone");
         const uint64_t f = in->rec_offset[u + 1] - in->rec_offset[u];
@@ -204,6 +207,7 @@ int create_on_device(const svt_evidence_batch* in, svt_batch* b, const uint4* d_
         if (U.svtype > SVT_SVTYPE_BND) return fail(SVT_ERR_INVALID, "bad svtype");
         if (U.reserved != 0 || (U.flags & ~SVT_UNIT_SKIP)) return fail(SVT_ERR_INVALID, "unit reserved/flags bits must be 0");
         if (U.var_length < -(1 << 30) || U.var_length > (1 << 30)) wide_var_length = true;
+        if (U.svtype == SVT_SVTYPE_DEL && U.var_length < 0) negative_del = true;
         nrec[u] = (uint32_t)f;
         max_f = std::max(max_f, f);
     }
@@ -233,15 +237,26 @@ int create_on_device(const svt_evidence_batch* in, svt_batch* b, const uint4* d_
     }
     SVT_TRY(d_off.alloc((n + 1) * sizeof(uint64_t)));
     if (n) HIP_TRY(hipMemcpyAsync(d_off.p, in->rec_offset, (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, b->stream));
+    DevScratch d_units;
+    SVT_TRY(d_units.alloc(n * sizeof(svt_unit)));
+    if (n) HIP_TRY(hipMemcpyAsync(d_units.p, in->units, n * sizeof(svt_unit), hipMemcpyHostToDevice, b->stream));
+    SVT_TRY(upload(&b->d_libs, T.libs, b->stream));
     SVT_TRY(d_counts.alloc(n * sizeof(uint4)));
     SVT_TRY(d_err.alloc(sizeof(uint32_t)));
     HIP_TRY(hipMemsetAsync(d_err.p, 0, sizeof(uint32_t), b->stream));
     std::vector<uint4> counts(n);
     uint32_t err_bits = 0;
     if (n) {
-        hipLaunchKernelGGL(svt_scan_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, b->stream,
-                           d_csr, d_off.as<uint64_t>(), n, in->n_libs, d_counts.as<uint4>(),
-                           d_err.as<uint32_t>());
+        ScanArgs sa{};
+        sa.csr = d_csr;
+        sa.rec_offset = d_off.as<uint64_t>();
+        sa.units = d_units.as<svt_unit>();
+        sa.libs = b->d_libs;
+        sa.n_units = n;
+        sa.n_libs = in->n_libs;
+        sa.counts = d_counts.as<uint4>();
+        sa.err = d_err.as<uint32_t>();
+        hipLaunchKernelGGL(svt_scan_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, b->stream, sa);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(counts.data(), d_counts.p, n * sizeof(uint4), hipMemcpyDeviceToHost, b->stream));
     }
@@ -257,60 +272,87 @@ int create_on_device(const svt_evidence_batch* in, svt_batch* b, const uint4* d_
         return fail(SVT_ERR_INVALID, m);
     }
 
+    // ---- layout: the compact entries need the 32-bit table geometry, histograms narrow enough for
+    // the 13-bit code, DEL lengths >= 0 and, with several libraries, at most 4 consecutive libraries
+    // per unit and 7-bit MAPQs on the kept pair entries; anything else keeps the canonical records
+    if (b->compact) {
+        bool ok = T.fast_geometry && !negative_del;
+        for (const LibDesc& L : T.libs) ok = ok && L.n_bins <= kMaxCompactBins;
+        if (ok && in->n_libs > 1)
+            for (uint64_t u = 0; u < n && ok; ++u)
+                ok = ((counts[u].z >> 8) & 0xffu) - (counts[u].z & 0xffu) < kMaxCompactLibSpan &&
+                     !(counts[u].w & kScanWideMapq);
+        b->compact = ok;
+    }
+
     // ---- tiling
-    std::vector<uint32_t> len_a(n), len_b(n);
-    for (uint64_t u = 0; u < n; ++u) {
-        if (b->split) {
-            len_a[u] = (counts[u].x + 1) / 2;   // two 8-byte entries per 16-byte row slot
-            len_b[u] = (counts[u].y + 1) / 2;
-        } else {
-            len_a[u] = nrec[u];
-            len_b[u] = 0;
-        }
-    }
     Tiling G;
-    build_tiling(in, nrec, len_a, len_b, counts, G);
-    if (G.tiles.size() > 0xFFFFFFF0ull / kWave) return fail(SVT_ERR_INVALID, "too many tiles");
-    b->n_tiles = (uint32_t)G.tiles.size();
-    b->slots = G.slots;
-    // dispatch order: tiles stay in groups of 4 consecutive (= one workgroup, similar length, same
-    // libraries); the groups go longest first (LPT) so the tail of the grid is made of short tiles
-    const uint32_t n_groups = (b->n_tiles + kWavesPerBlock - 1) / kWavesPerBlock;
-    std::vector<uint32_t> group_order(n_groups);
-    std::vector<uint64_t> group_cost(n_groups, 0);
-    for (uint32_t g = 0; g < n_groups; ++g) {
-        group_order[g] = g;
-        for (uint32_t t = g * kWavesPerBlock; t < std::min(b->n_tiles, (g + 1) * kWavesPerBlock); ++t)
-            group_cost[g] += G.tiles[t].rows_a + G.tiles[t].rows_b;
-    }
-    std::stable_sort(group_order.begin(), group_order.end(),
-                     [&](uint32_t x, uint32_t y) { return group_cost[x] > group_cost[y]; });
     std::vector<TileDesc> dispatch;
     std::vector<WgDesc> windows;
-    dispatch.reserve((size_t)n_groups * kWavesPerBlock);
-    uint32_t max_win_libs = 1, max_win_bins = 1;
-    for (uint32_t g : group_order) {
-        uint32_t lo = 0xffffffffu, hi = 0;
-        for (uint32_t k = 0; k < (uint32_t)kWavesPerBlock; ++k) {
-            const uint32_t t = g * kWavesPerBlock + k;
-            if (t < b->n_tiles) {
-                dispatch.push_back(G.tiles[t]);
-                lo = std::min(lo, G.tile_lib_lo[t]);
-                hi = std::max(hi, G.tile_lib_hi[t]);
+    uint32_t n_groups = 0, max_win_libs = 1, max_win_bins = 1;
+    auto plan = [&]() -> int {
+        std::vector<uint32_t> len_a(n), len_b(n);
+        for (uint64_t u = 0; u < n; ++u) {
+            if (b->compact) {
+                len_a[u] = (counts[u].x + 3) / 4;   // four 4-byte entries per 16-byte row slot
+                len_b[u] = (counts[u].y + 3) / 4;
             } else {
-                TileDesc pad{};
-                pad.lane_base = kPadUnit;          // marks a tile that does not exist
-                dispatch.push_back(pad);
+                len_a[u] = nrec[u];
+                len_b[u] = 0;
             }
         }
-        WgDesc w{};
-        w.lib_lo = lo;
-        w.lib_cnt = hi - lo + 1;
-        w.bin_lo = T.libs[lo].tab_off;
-        w.bin_cnt = T.libs[hi].tab_off + T.libs[hi].n_bins + 1 - w.bin_lo;
-        windows.push_back(w);
-        max_win_libs = std::max(max_win_libs, w.lib_cnt);
-        max_win_bins = std::max(max_win_bins, w.bin_cnt);
+        G = Tiling();
+        build_tiling(in, nrec, len_a, len_b, counts, G);
+        if (G.tiles.size() > 0xFFFFFFF0ull / kWave) return fail(SVT_ERR_INVALID, "too many tiles");
+        b->n_tiles = (uint32_t)G.tiles.size();
+        b->slots = G.slots;
+        // dispatch order: tiles stay in groups of 4 consecutive (= one workgroup, similar length, same
+        // libraries); the groups go longest first (LPT) so the tail of the grid is made of short tiles
+        n_groups = (b->n_tiles + kWavesPerBlock - 1) / kWavesPerBlock;
+        std::vector<uint32_t> group_order(n_groups);
+        std::vector<uint64_t> group_cost(n_groups, 0);
+        for (uint32_t g = 0; g < n_groups; ++g) {
+            group_order[g] = g;
+            for (uint32_t t = g * kWavesPerBlock; t < std::min(b->n_tiles, (g + 1) * kWavesPerBlock); ++t)
+                group_cost[g] += G.tiles[t].rows_a + G.tiles[t].rows_b;
+        }
+        std::stable_sort(group_order.begin(), group_order.end(),
+                         [&](uint32_t x, uint32_t y) { return group_cost[x] > group_cost[y]; });
+        dispatch.clear();
+        windows.clear();
+        dispatch.reserve((size_t)n_groups * kWavesPerBlock);
+        max_win_libs = 1;
+        max_win_bins = 1;
+        for (uint32_t g : group_order) {
+            uint32_t lo = 0xffffffffu, hi = 0;
+            for (uint32_t k = 0; k < (uint32_t)kWavesPerBlock; ++k) {
+                const uint32_t t = g * kWavesPerBlock + k;
+                if (t < b->n_tiles) {
+                    dispatch.push_back(G.tiles[t]);
+                    lo = std::min(lo, G.tile_lib_lo[t]);
+                    hi = std::max(hi, G.tile_lib_hi[t]);
+                } else {
+                    TileDesc pad{};
+                    pad.lane_base = kPadUnit;          // marks a tile that does not exist
+                    dispatch.push_back(pad);
+                }
+            }
+            WgDesc w{};
+            w.lib_lo = lo;
+            w.lib_cnt = hi - lo + 1;
+            w.bin_lo = T.libs[lo].tab_off;
+            w.bin_cnt = T.libs[hi].tab_off + T.libs[hi].n_bins + 1 - w.bin_lo;
+            windows.push_back(w);
+            max_win_libs = std::max(max_win_libs, w.lib_cnt);
+            max_win_bins = std::max(max_win_bins, w.bin_cnt);
+        }
+        return SVT_OK;
+    };
+    SVT_TRY(plan());
+    const bool lds_tables = T.fast_geometry && (size_t)max_win_bins * 8 <= kMaxLdsTableBytes;
+    if (b->compact && !lds_tables) {   // the compact entries only exist for the LDS modes
+        b->compact = false;
+        SVT_TRY(plan());
     }
 
     tm.mark("tiling (host sort)");
@@ -323,7 +365,6 @@ int create_on_device(const svt_evidence_batch* in, svt_batch* b, const uint4* d_
     SVT_TRY(upload(d_lane_nrec, G.lane_nrec, b->stream));
     SVT_TRY(upload(&b->d_pm, T.pm, b->stream));
     SVT_TRY(upload(&b->d_l10, T.l10, b->stream));
-    SVT_TRY(upload(&b->d_libs, T.libs, b->stream));
     SVT_TRY(upload(&b->d_hist, T.hist, b->stream));
     SVT_TRY(upload(&b->d_thr, T.thr, b->stream));
     SVT_TRY(upload(&b->d_wtab, T.wtab, b->stream));
@@ -339,10 +380,14 @@ int create_on_device(const svt_evidence_batch* in, svt_batch* b, const uint4* d_
         ra.lane_src = d_lane_src.as<uint64_t>();
         ra.lane_nrec = d_lane_nrec.as<uint32_t>();
         ra.tiles = d_tiles_store.as<TileDesc>();
+        ra.hdr = b->d_hdr;
+        ra.units = d_units.as<svt_unit>();
+        ra.libs = b->d_libs;
         ra.tiled = b->d_tiled;
         ra.n_tiles = b->n_tiles;
+        ra.multi_lib = in->n_libs > 1 ? 1u : 0u;
         const dim3 grid((b->n_tiles + kWavesPerBlock - 1) / kWavesPerBlock), block(kBlock);
-        if (b->split) hipLaunchKernelGGL(svt_repack_split_kernel, grid, block, 0, b->stream, ra);
+        if (b->compact) hipLaunchKernelGGL(svt_repack_compact_kernel, grid, block, 0, b->stream, ra);
         else hipLaunchKernelGGL(svt_repack_dense_kernel, grid, block, 0, b->stream, ra);
         HIP_TRY(hipGetLastError());
     }
@@ -373,7 +418,7 @@ int create_on_device(const svt_evidence_batch* in, svt_batch* b, const uint4* d_
     a.wg = b->d_wg;
     // kernel flavour: tables in LDS when the 32-bit geometry holds and the largest per-workgroup
     // library window fits the LDS budget; otherwise the general kernel reads them through L2
-    if (T.fast_geometry && (size_t)max_win_bins * 8 <= kMaxLdsTableBytes) {
+    if (lds_tables) {
         b->mode = in->n_libs == 1 ? kSingleLds : kMultiLds;
         a.lds_libs = in->n_libs == 1 ? 1u : max_win_libs;
         a.lds_bins = in->n_libs == 1 ? a.total_bins : max_win_bins;
@@ -434,7 +479,7 @@ int svt_batch_create(const svt_evidence_batch* in, int device, unsigned flags, s
     if (!b) return fail(SVT_ERR_NOMEM, "out of host memory");
     b->device = device;
     b->flags = flags;
-    b->split = (flags & SVT_FLAG_DENSE_LAYOUT) == 0;
+    b->compact = (flags & SVT_FLAG_DENSE_LAYOUT) == 0;
     b->n_units = n;
     b->n_records = n ? in->rec_offset[n] : 0;
     const int rc = create_on_device(in, b);
@@ -546,7 +591,7 @@ int svt_batch_create_from_fragments(const svt_fragment_batch* in, int device, un
     if (!b) return fail(SVT_ERR_NOMEM, "out of host memory");
     b->device = device;
     b->flags = flags;
-    b->split = (flags & SVT_FLAG_DENSE_LAYOUT) == 0;
+    b->compact = (flags & SVT_FLAG_DENSE_LAYOUT) == 0;
     b->n_units = n;
     b->n_records = n_frag;
     const int rc = create_on_device(&eb, b, d_records.as<uint4>());
@@ -623,6 +668,14 @@ int svt_batch_bytes(const svt_batch* b, uint64_t* algorithmic, uint64_t* residen
     if (!b) return fail(SVT_ERR_INVALID, "null batch");
     if (algorithmic) *algorithmic = 16 * b->n_records + (16 + 96) * b->n_units;
     if (resident) *resident = 16 * b->slots + (uint64_t)b->n_tiles * kWave * sizeof(LaneHdr);
+    return SVT_OK;
+}
+
+int svt_batch_layout(const svt_batch* b, int* compact, int* table_mode)
+{
+    if (!b) return fail(SVT_ERR_INVALID, "null batch");
+    if (compact) *compact = b->compact ? 1 : 0;
+    if (table_mode) *table_mode = b->mode;
     return SVT_OK;
 }
 

@@ -14,13 +14,13 @@ from .evidence import CEvidenceBatch, EvidenceBatch, RESULT_DTYPE, Results
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SVTYPER_HIP_LIB") or os.path.join(_HERE, "csrc", "libsvtyper_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 EXPORTS = (
     "svt_version", "svt_device_count", "svt_last_error", "svt_batch_create", "svt_batch_create_from_fragments",
     "svt_batch_genotype",
     "svt_batch_genotype_n", "svt_batch_genotype_timed", "svt_batch_results", "svt_batch_device_results",
-    "svt_batch_bind_device_results", "svt_batch_bytes",
+    "svt_batch_bind_device_results", "svt_batch_bytes", "svt_batch_layout",
     "svt_batch_stream", "svt_batch_destroy", "svt_trim", "svt_bayes_gt", "svt_genotype",
 )
 
@@ -71,6 +71,8 @@ def load() -> C.CDLL:
     L.svt_batch_device_results.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
     L.svt_batch_bind_device_results.restype = C.c_int
     L.svt_batch_bind_device_results.argtypes = [C.c_void_p, C.c_void_p]
+    L.svt_batch_layout.restype = C.c_int
+    L.svt_batch_layout.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.svt_batch_bytes.restype = C.c_int
     L.svt_batch_bytes.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.svt_batch_stream.restype = C.c_void_p
@@ -168,6 +170,12 @@ class DeviceBatch:
         a, r = C.c_uint64(), C.c_uint64()
         _check(self._lib.svt_batch_bytes(self._h, C.byref(a), C.byref(r)))
         return int(a.value), int(r.value)
+
+    def layout(self):
+        """(compact: bool, table_mode: 0 one library in LDS / 1 library windows in LDS / 2 general)"""
+        c, m = C.c_int(), C.c_int()
+        _check(self._lib.svt_batch_layout(self._h, C.byref(c), C.byref(m)))
+        return bool(c.value), int(m.value)
 
     def stream(self) -> int:
         return int(self._lib.svt_batch_stream(self._h) or 0)

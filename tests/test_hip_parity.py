@@ -319,3 +319,105 @@ def test_full_size_properties(hip_device, full_c3):
     assert slack.min() >= 0 and slack.max() <= 1
     t = first.tallies[called]
     assert np.array_equal(col["DP"][called], np.trunc(t[:, 0] + t[:, 1] + t[:, 2] + t[:, 3] + t[:, 4]).astype(np.int64))
+
+
+# ------------------------------------------------------------------------------------------
+# compact layout: the ospan_len -> table-code translation and the fallbacks to the dense records
+# ------------------------------------------------------------------------------------------
+def _layout_of(batch, flags=0, device=0):
+    from svtyper_amd import hip
+    with hip.DeviceBatch(batch, device, flags) as d:
+        return d.layout()
+
+
+def _sweep_batch(lib, var_lengths, svtype, extra_libs=()):
+    """One unit per var_length whose records sweep ospan_len across both histogram windows
+    (key_min .. key_min + n_bins and the same shifted by var_length), every straddle-bit combination."""
+    kmin, nb = int(lib.key_min), int(len(lib.hist))
+    units, recs, off = [], [], [0]
+    for vl in var_lengths:
+        spans = set()
+        for base in (kmin, kmin + vl):
+            spans.update(range(base - 3, base + 4))
+            spans.update(range(base + nb - 4, base + nb + 4))
+            spans.update(range(base + nb // 2 - 8, base + nb // 2 + 8))
+        spans = sorted(s for s in spans if 0 <= s < 2**31)
+        n = len(spans) * 7
+        r = np.zeros(n, ev.RECORD_DTYPE)
+        r["ospan_len"] = np.repeat(spans, 7)
+        r["flags"] = np.tile(np.arange(1, 8), len(spans)).astype(np.uint32) | np.uint32(ev.REC_HAS_PAIR)
+        r["mapq_a"], r["mapq_b"] = 60, 37
+        r["rs_a"] = 20
+        u = np.zeros(1, ev.UNIT_DTYPE)
+        u["svtype"] = svtype
+        u["var_length"] = vl if svtype == 0 else 0
+        u["pos_delta"] = max(vl, 10_000)          # well past the small-DEL gate
+        units.append(u)
+        recs.append(r)
+        off.append(off[-1] + n)
+    return ev.EvidenceBatch(np.asarray(off, np.uint64), np.concatenate(units), np.concatenate(recs),
+                            [lib, *extra_libs], 1.0, 1.0)
+
+
+@pytest.mark.parametrize("svtype", [0, 1, 2])
+def test_compact_code_windows(hip_device, fixture_library, svtype):
+    nb = len(fixture_library.hist)
+    vls = [0, 1, 37, nb - 1, nb, nb + 1, 3 * nb, 100_000, 2**29]
+    batch = _sweep_batch(fixture_library, vls, svtype)
+    assert _layout_of(batch) == (True, 0)
+    for flags in ALL_FLAGS:
+        got, want = run_both(batch, flags)
+        assert_parity(got, want)
+
+
+def test_compact_code_windows_multi_library(hip_device, fixture_library):
+    other = synth.normal_library(420.0, 95.0, seed=3)
+    nb = len(other.hist)
+    batch = _sweep_batch(other, [0, 5, nb - 1, nb, nb + 7, 50_000], 0, extra_libs=(fixture_library,))
+    batch.records["flags"][1::2] |= np.uint32(1 << ev.REC_LIB_SHIFT)   # alternate the two libraries
+    assert _layout_of(batch) == (True, 1)
+    for flags in ALL_FLAGS:
+        got, want = run_both(batch, flags)
+        assert_parity(got, want)
+
+
+def test_small_deletion_gate_per_library(hip_device, fixture_library):
+    """pos_delta < 2 sd of the *entry's* library switches its pair evidence off (classic.py:339,383)."""
+    tight = synth.normal_library(300.0, 20.0, seed=11)      # 2 sd = 40
+    wide = synth.normal_library(500.0, 120.0, seed=12)      # 2 sd = 240
+    batch = synth.make_units(3000, 21, [tight, wide], svtype_mix=(1.0, 0, 0, 0))
+    batch.units["pos_delta"] = np.resize([10, 39, 40, 41, 100, 239, 240, 241, 1000], batch.n_units)
+    batch.units["var_length"] = batch.units["pos_delta"]
+    assert _layout_of(batch)[0]
+    for flags in ALL_FLAGS:
+        got, want = run_both(batch, flags)
+        assert_parity(got, want)
+
+
+def test_compact_fallbacks_stay_exact(hip_device, fixture_library):
+    """Batches the compact encoding cannot express take the dense layout, silently and exactly."""
+    # (a) a histogram wider than the 13-bit code allows
+    broad = synth.normal_library(3000.0, 900.0, seed=5)
+    assert len(broad.hist) > 4095
+    a = synth.make_units(1500, 31, [broad], svtype_mix=(0.6, 0.2, 0.2, 0.0))
+    # (b) several libraries and a MAPQ above 127 on a pair entry
+    libs = [fixture_library, synth.normal_library(420.0, 95.0, seed=3)]
+    b = synth.make_units(1500, 32, libs, svtype_mix=(0.6, 0.2, 0.2, 0.0))
+    b.records["mapq_a"][::11] = 200
+    # (c) a unit whose records reference libraries more than 4 apart
+    many = [synth.normal_library(300.0 + 10 * i, 40.0 + i, seed=40 + i) for i in range(7)]
+    c = synth.make_units(1500, 33, many, svtype_mix=(0.6, 0.2, 0.2, 0.0))
+    fl = c.records["flags"] & ~np.uint32(0xff << ev.REC_LIB_SHIFT)
+    c.records["flags"] = fl | (np.resize([0, 6, 3], c.n_records).astype(np.uint32) << ev.REC_LIB_SHIFT)
+    # (d) a negative DEL length
+    d = synth.make_units(1500, 34, [fixture_library], svtype_mix=(1.0, 0, 0, 0))
+    d.units["var_length"][::9] = -250
+    for batch in (a, b, c, d):
+        assert _layout_of(batch)[0] is False
+        for flags in (0, ev.FLAG_SSO_ASSOCIATION):
+            got, want = run_both(batch, flags)
+            assert_parity(got, want)
+    # the same shapes without the offending feature do take the compact layout
+    b.records["mapq_a"][::11] = 60
+    d.units["var_length"][::9] = 250
+    assert _layout_of(b)[0] and _layout_of(d)[0]
