@@ -99,8 +99,6 @@ def main():
     ap.add_argument("--workload", default="c3_mixed_1m", choices=["c3_mixed_1m", "c2_del_100k", "c5_multisample"])
     ap.add_argument("--sso", action="store_true", help="singlesample.py floating-point association")
     ap.add_argument("--dense", action="store_true", help="stream the canonical 16-byte records (no sparse re-encoding)")
-    ap.add_argument("--no-dense-leg", action="store_true",
-                    help="skip the extra timing of the dense-record layout (N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dense-leg", action="store_true",
                     help="skip the extra timing of the dense-record layout (N=1 only)")

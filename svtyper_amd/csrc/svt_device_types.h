@@ -11,8 +11,8 @@ namespace svt {
 // device-side structures
 // ------------------------------------------------------------------------------------------
 struct LibDesc {          // 32 B, one per library
-    uint32_t tab_off;     // offset of this library's bins inside hist[] / thr[] (each library
-                          // owns n_bins + 1 entries; the last one is the out-of-range sentinel)
+    uint32_t tab_off;     // offset of this library's bins inside bins[] (each library owns
+                          // n_bins + 1 entries; the last one is the out-of-range sentinel)
     int32_t key_min;
     uint32_t n_bins;
     uint32_t pad;
@@ -27,17 +27,34 @@ struct LaneHdr {          // 16 B, one per tile lane
     uint32_t packed;      // svtype | flags << 8 | first library of the unit << 16
 };
 
-// One 64-unit tile.  Dense layout: rows_a rows of 16-byte records at base_a (rows_b == 0).
-// Compact layout: rows_a rows of pair entries at base_a, rows_b rows of weight entries at base_b
-// (each 16-byte row slot of a lane holds four consecutive 4-byte entries).
+// One 64-unit tile: `rows[k]` rows of stream k, stored back to back from `base` (in 16-byte row
+// slots; row j holds the j-th 16 bytes of each of the 64 lanes).  Dense layout: one stream of
+// canonical 16-byte records (rows[0] = longest unit).  Compact layout: three streams of 4-byte
+// entries, four per row slot -- pair entries, reference-read weight entries and split/clip
+// candidate weight entries (svt_prepare_kernels.h has the formats).
+constexpr int kStreams = 3;
+enum Stream : int { kPairs = 0, kRefReads = 1, kCandidates = 2 };
 struct TileDesc {         // 32 B, stored in dispatch (longest-first) order
-    uint64_t base_a;
-    uint64_t base_b;
-    uint32_t rows_a;
-    uint32_t rows_b;
+    uint64_t base;
+    uint32_t rows[kStreams];
     uint32_t lane_base;   // first LaneHdr of the tile
-    uint32_t pad;
+    uint32_t pad[2];
 };
+
+// one bin of a library's insert-size tables: thr = largest h2 for which p_concordant still holds
+// (svt_host_tables.h), hist = the Counter value.  Every library owns n_bins + 1 of them; the last one
+// is the out-of-range sentinel {-1, 0}.
+struct Bin {
+    int32_t thr;
+    uint32_t hist;
+};
+
+// LDS layout of the genotype kernel, in bytes from the start of the workgroup's LDS (the kernel has
+// no static LDS, so the dynamic segment starts at 0 -- checked at run time).  The first three
+// regions have fixed addresses; the compact entries are consumed with these as immediates.
+constexpr uint32_t kLdsPm = 0;                       // double[256]      prob_mapq
+constexpr uint32_t kLdsWtab = kLdsPm + 256 * 8;      // PairWeights[32]  paired-end decision table
+constexpr uint32_t kLdsBins = kLdsWtab + 32 * 16;    // Bin[lds_bins], then LibDesc[lds_libs], then log10
 
 struct GtConsts {
     double lgp[2][3];     // [is_dup][genotype] log(p)/log(10)      (statistics.py:33-35)
@@ -78,8 +95,7 @@ struct KernelArgs {
     const double* pm;          // 256
     const double* l10;         // n_l10
     const LibDesc* libs;       // n_libs
-    const uint32_t* hist;      // total_bins (sentinels included)
-    const int32_t* thr;        // total_bins
+    const Bin* bins;           // total_bins (sentinels included)
     const PairWeights* wtab;   // 32
     uint32_t n_l10;
     uint32_t n_libs;

@@ -8,14 +8,42 @@
 namespace svt {
 
 // ------------------------------------------------------------------------------------------
-// evidence arithmetic shared by both layouts
+// LDS access by byte address.  The tables live at fixed byte offsets of the workgroup's LDS
+// (svt_device_types.h: kLds*), so an entry field that is already a byte offset becomes the operand
+// of a ds_read with the table base as the instruction's immediate offset.
 // ------------------------------------------------------------------------------------------
-struct Tables {
+typedef __attribute__((address_space(3))) const double lds_cf64;
+typedef __attribute__((address_space(3))) const uint32_t lds_cu32;
+typedef __attribute__((address_space(3))) const int32_t lds_ci32;
+
+__device__ __forceinline__ double lds_f64(const uint32_t addr) { return *reinterpret_cast<lds_cf64*>((size_t)addr); }
+__device__ __forceinline__ uint32_t lds_u32(const uint32_t addr) { return *reinterpret_cast<lds_cu32*>((size_t)addr); }
+__device__ __forceinline__ int32_t lds_i32(const uint32_t addr) { return *reinterpret_cast<lds_ci32*>((size_t)addr); }
+
+// (byte N of e) * 8 in one VALU instruction (SDWA source select + shift): the LDS byte offset of
+// prob_mapq[byte] in the double[256] table
+#define SVT_BYTE_X8(N)                                                                                       \
+    __device__ __forceinline__ uint32_t byte##N##_x8(const uint32_t e)                                      \
+    {                                                                                                        \
+        uint32_t r;                                                                                          \
+        asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_" #N \
+            : "=v"(r) : "v"(3u), "v"(e));                                                                    \
+        return r;                                                                                            \
+    }
+SVT_BYTE_X8(0)
+SVT_BYTE_X8(1)
+SVT_BYTE_X8(2)
+SVT_BYTE_X8(3)
+#undef SVT_BYTE_X8
+
+// ------------------------------------------------------------------------------------------
+// evidence arithmetic
+// ------------------------------------------------------------------------------------------
+struct Tables {               // dense layout: tables through ordinary pointers
     const double* pm;          // LDS
     const PairWeights* wtab;   // LDS
     const LibDesc* libs;       // LDS
-    const uint32_t* hist;      // LDS (kGeneral: global)
-    const int32_t* thr;
+    const Bin* bins;           // LDS (kGeneral: global)
 };
 
 struct Acc {
@@ -26,19 +54,26 @@ struct Acc {
 // per-lane constants of the unit, hoisted out of the record loop
 struct LaneCtx {
     uint32_t del16;       // is_DEL ? 16 : 0 (decision-table index bit)
-    uint32_t fmask;       // kSingleLds: straddle-bit mask with the small-DEL gate applied
-    uint32_t kmin;        // kSingleLds: (uint32) key_min
-    uint32_t nb;          // kSingleLds: n_bins (== sentinel index)
-    uint32_t sub2;        // kSingleLds: DEL ? var_length + key_min : 0x80000000 (never in range)
-    uint32_t off2;        // compact layout, kSingleLds: DEL ? min(var_length, n_bins) : 0x80000000
-    uint32_t lib_min;     // compact layout, kMultiLds: first library of the lane's unit
+    uint32_t fmask;       // dense kSingleLds: straddle-bit mask with the small-DEL gate applied
+    uint32_t kmin;        // dense kSingleLds: (uint32) key_min
+    uint32_t nb;          // dense kSingleLds: n_bins (== sentinel index)
+    uint32_t sub2;        // dense kSingleLds: DEL ? var_length + key_min : 0x80000000 (never in range)
+    uint32_t nb8;         // compact kSingleLds: n_bins * 8 (byte offset of the sentinel bin)
+    uint32_t off2_8;      // compact kSingleLds: DEL ? min(var_length, n_bins) * 8 : 0x80000000
+    uint32_t wt0, wt1;    // compact: LDS address of the decision-table rows for p_concordant = 0 / 1
+    uint32_t lib_min;     // compact kMultiLds: first library of the lane's unit
     uint32_t lib_lo;      // kMultiLds: first library / first bin staged by this workgroup
     uint32_t bin_lo;
+    uint32_t libx_lane;   // compact kMultiLds: LDS address of the {bins address, n_bins * 8} pair of the
+                          // lane's first library (svt_genotype_kernel stages one pair per window library)
+    uint32_t vl8;         // compact kMultiLds: min(var_length, 8191) * 8
+    uint32_t nodel;       // compact kMultiLds: DEL ? 0 : 0x80000000
     int32_t var_length;
     double pos_delta_d;
     bool is_del;
 };
 
+// ---- dense layout: one canonical 16-byte record -------------------------------------------------
 // Split-read / reference-read weights of one fragment record (classic.py:306-328).  Every add is
 // unconditional: gated-off evidence arrives as MAPQ 0, whose weight prob_mapq(0) is exactly +0.0,
 // and x + 0.0 == x bit-for-bit for these non-negative sums.
@@ -83,16 +118,16 @@ __device__ __forceinline__ void pair_evidence(const uint32_t o, const uint32_t m
 
     // p_concordant (parsers.py:861-882) as an integer test: with d1 = hist[o]/N fixed, the
     // reference's binary64 expression d1*0.95/(0.95*d1 + 0.05*d2) > 0.5 is monotone in
-    // h2 = hist[o - v]; thr[o] is the largest h2 for which it still holds (found on the host with
-    // the reference's own expression), -1 where hist[o] == 0 (p == 0 or ZeroDivisionError).
+    // h2 = hist[o - v]; bins[o].thr is the largest h2 for which it still holds (found on the host
+    // with the reference's own expression), -1 where hist[o] == 0 (p == 0 or ZeroDivisionError).
     int32_t thr1;
     uint32_t h2;
     if (MODE == kSingleLds) {
         f3 &= c.fmask;                                  // small-DEL gate (classic.py:339,383)
         const uint32_t i1 = min(o - c.kmin, c.nb);      // out of range -> sentinel (thr -1)
         const uint32_t i2 = min(o - c.sub2, c.nb);      // out of range -> sentinel (hist 0)
-        thr1 = t.thr[i1];
-        h2 = t.hist[i2];
+        thr1 = t.bins[i1].thr;
+        h2 = t.bins[i2].hist;
     } else if (MODE == kMultiLds) {
         const LibDesc lib = t.libs[lib_idx - c.lib_lo];
         const bool small_del = c.is_del && (c.pos_delta_d < lib.sd2);
@@ -102,15 +137,15 @@ __device__ __forceinline__ void pair_evidence(const uint32_t o, const uint32_t m
         const uint32_t i1 = min(o - kmin, lib.n_bins);
         const uint32_t i2 = min(o - sub2, lib.n_bins);
         const uint32_t base = lib.tab_off - c.bin_lo;
-        thr1 = t.thr[base + i1];
-        h2 = t.hist[base + i2];
+        thr1 = t.bins[base + i1].thr;
+        h2 = t.bins[base + i2].hist;
     } else {
         const LibDesc lib = t.libs[lib_idx];
         const bool small_del = c.is_del && (c.pos_delta_d < lib.sd2);
         f3 = small_del ? 0u : f3;
         const int64_t i1 = (int64_t)(int32_t)o - (int64_t)lib.key_min;
         const bool in1 = (uint64_t)i1 < (uint64_t)lib.n_bins;
-        thr1 = t.thr[lib.tab_off + (in1 ? (uint32_t)i1 : lib.n_bins)];
+        thr1 = t.bins[lib.tab_off + (in1 ? (uint32_t)i1 : lib.n_bins)].thr;
         int64_t key2;
         bool ok2 = true;
         if (c.is_del) {
@@ -124,7 +159,7 @@ __device__ __forceinline__ void pair_evidence(const uint32_t o, const uint32_t m
         }
         const int64_t i2 = key2 - (int64_t)lib.key_min;
         const bool in2 = ok2 && ((uint64_t)i2 < (uint64_t)lib.n_bins);
-        h2 = t.hist[lib.tab_off + (in2 ? (uint32_t)i2 : lib.n_bins)];
+        h2 = t.bins[lib.tab_off + (in2 ? (uint32_t)i2 : lib.n_bins)].hist;
     }
     const bool p_conc = (int32_t)h2 <= thr1;
     const PairWeights pw = t.wtab[f3 | (p_conc ? 8u : 0u) | c.del16];
@@ -134,60 +169,67 @@ __device__ __forceinline__ void pair_evidence(const uint32_t o, const uint32_t m
 }
 
 // ---- compact layout (svt_prepare_kernels.h describes the entries) -------------------------------
-// Pair entry: the two table indices come from `code` by clamping; the look-ups, the p_concordant
-// decision and the sums are the ones of pair_evidence above.
+// Pair entry: the two bin addresses come from the entry's table code by clamping; the look-ups, the
+// p_concordant decision and the sums are the ones of pair_evidence above.
 template <int MODE>
-__device__ __forceinline__ void pair_entry(const uint32_t e, const Tables& t, const LaneCtx& c, Acc& a)
+__device__ __forceinline__ void pair_entry(const uint32_t e, const LaneCtx& c, Acc& a)
 {
-    const uint32_t code = e & ((1u << kCodeBits) - 1u);
-    const uint32_t f3 = (e >> kCodeBits) & 7u;
+    const uint32_t code8 = e & 0xfff8u;          // byte offset of bins[code] inside the library's table
     double pm_a, pm_b;
     int32_t thr1;
     uint32_t h2;
     if (MODE == kSingleLds) {
-        pm_a = t.pm[(e >> 16) & 0xffu];
-        pm_b = t.pm[e >> 24];
-        thr1 = t.thr[min(code, c.nb)];
-        h2 = t.hist[min(code - c.off2, c.nb)];
+        pm_a = lds_f64(kLdsPm + byte2_x8(e));
+        pm_b = lds_f64(kLdsPm + byte3_x8(e));
+        thr1 = lds_i32(kLdsBins + min(code8, c.nb8));
+        h2 = lds_u32(kLdsBins + 4u + min(code8 - c.off2_8, c.nb8));
     } else {
-        pm_a = t.pm[(e >> 16) & 0x7fu];
-        pm_b = t.pm[(e >> 23) & 0x7fu];
-        const LibDesc lib = t.libs[c.lib_min + (e >> 30) - c.lib_lo];
-        const uint32_t off2 = c.is_del ? min((uint32_t)c.var_length, lib.n_bins) : 0x80000000u;
-        const uint32_t base = lib.tab_off - c.bin_lo;
-        thr1 = t.thr[base + min(code, lib.n_bins)];
-        h2 = t.hist[base + min(code - off2, lib.n_bins)];
+        pm_a = lds_f64(kLdsPm + ((e >> 15) & 0x3f8u));
+        pm_b = lds_f64(kLdsPm + ((e >> 22) & 0x3f8u));
+        const uint32_t xa = c.libx_lane + ((e >> 13) & 0x18u);               // + (lib - lib_min) * 8
+        const uint32_t base = lds_u32(xa), nb8 = lds_u32(xa + 4u);           // &bins[tab_off], n_bins * 8
+        const uint32_t off2_8 = min(c.vl8, nb8) | c.nodel;                   // DEL ? min(var_length, n_bins) * 8 : never
+        thr1 = lds_i32(base + min(code8, nb8));
+        h2 = lds_u32(base + 4u + min(code8 - off2_8, nb8));
     }
     const bool p_conc = (int32_t)h2 <= thr1;
-    const PairWeights pw = t.wtab[f3 | (p_conc ? 8u : 0u) | c.del16];
+    const uint32_t wa = (p_conc ? c.wt1 : c.wt0) | ((e << 4) & 0x70u);   // &wtab[f3 | p_conc << 3 | del16]
+    const double w_alt = lds_f64(wa), w_ref = lds_f64(wa + 8u);
     const double pp = pm_a * pm_b;
-    a.alt_span += pp * pw.w_alt;
-    a.ref_span += pp * pw.w_ref;
+    a.alt_span += pp * w_alt;
+    a.ref_span += pp * w_ref;
 }
 
-// Weight entry of one kind (classic.py:306-328): the other two sums receive +0.0.
+// Weight entries (classic.py:306-328), one stream per tally.  e = mapq0 | mapq1 << 8 | first << 16.
 template <bool SSO>
-__device__ __forceinline__ void weight_entry(const uint32_t e, const Tables& t, Acc& a)
+__device__ __forceinline__ void ref_read_entry(const uint32_t e, Acc& a)
 {
-    const double x = t.pm[e & 0xffu];
-    const double y = t.pm[(e >> 8) & 0xffu];
-    const uint32_t kind = (e >> 16) & 3u;
-    const double xr = kind == 0u ? x : 0.0, yr = kind == 0u ? y : 0.0;
-    const double p = (x + y) * 0.5;                       // (pm(left) * L + pm(right) * R) / 2.0
-    const double ps = kind == 1u ? p : 0.0, pc = kind == 2u ? p : 0.0;
-    if (SSO) {
-        // singlesample.py:246-276,367-372: fragment-local sums, added to the site totals when the
-        // next fragment (with evidence of this kind) starts
-        const bool first = (e & (1u << 18)) != 0u;
-        const bool f0 = first && kind == 0u, f1 = first && kind == 1u, f2 = first && kind == 2u;
-        a.ref_seq += f0 ? a.l_ref_seq : 0.0;
-        a.alt_seq += f1 ? a.l_alt_seq : 0.0;
-        a.alt_clip += f2 ? a.l_alt_clip : 0.0;
-        a.l_ref_seq = ((f0 ? 0.0 : a.l_ref_seq) + xr) + yr;
-        a.l_alt_seq = (f1 ? 0.0 : a.l_alt_seq) + ps;
-        a.l_alt_clip = (f2 ? 0.0 : a.l_alt_clip) + pc;
+    const double x = lds_f64(kLdsPm + byte0_x8(e)), y = lds_f64(kLdsPm + byte1_x8(e));
+    if (SSO) {   // singlesample.py:246-276,367-372: fragment-local sum, flushed when the next fragment starts
+        const bool first = (e & 0x10000u) != 0u;
+        a.ref_seq += first ? a.l_ref_seq : 0.0;
+        a.l_ref_seq = ((first ? 0.0 : a.l_ref_seq) + x) + y;
     } else {
-        a.ref_seq = (a.ref_seq + xr) + yr;
+        a.ref_seq = (a.ref_seq + x) + y;
+    }
+}
+
+// split (alt_seq) or clip (alt_clip) candidate: the other tally receives +0.0
+template <bool SSO>
+__device__ __forceinline__ void candidate_entry(const uint32_t e, Acc& a)
+{
+    const double x = lds_f64(kLdsPm + byte0_x8(e)), y = lds_f64(kLdsPm + byte1_x8(e));
+    const double p = (x + y) * 0.5;              // (pm(left) * L + pm(right) * R) / 2.0   (classic.py:324)
+    const bool clip = (e & 0x20000u) != 0u;
+    const double ps = clip ? 0.0 : p, pc = clip ? p : 0.0;
+    if (SSO) {
+        const bool first = (e & 0x10000u) != 0u;
+        const bool fs = first && !clip, fc = first && clip;
+        a.alt_seq += fs ? a.l_alt_seq : 0.0;
+        a.alt_clip += fc ? a.l_alt_clip : 0.0;
+        a.l_alt_seq = (fs ? 0.0 : a.l_alt_seq) + ps;
+        a.l_alt_clip = (fc ? 0.0 : a.l_alt_clip) + pc;
+    } else {
         a.alt_seq += ps;
         a.alt_clip += pc;
     }
@@ -215,36 +257,49 @@ __device__ __forceinline__ uint4 ld_stream(const uint4* __restrict__ p)
     return make_uint4(v.x, v.y, v.z, v.w);
 }
 
+// 16 bytes of a result record (written once, not read again by this pass)
+__device__ __forceinline__ void st_result(uint4* __restrict__ p, const uint4 v)
+{
+    *p = v;   // plain store: the eight 16-byte pieces of a record merge into one line in L2 (non-temporal
+              // stores reach HBM piecewise and are 4x slower here)
+}
+
 __device__ __forceinline__ uint4 pack2d(double x, double y)
 {
     const uint64_t a = (uint64_t)__double_as_longlong(x), b = (uint64_t)__double_as_longlong(y);
     return make_uint4((uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32));
 }
 
-// Stream `rows` row slots of one lane, SVT_GROUP at a time, one group ahead of the group being
-// consumed (the tiled buffer carries kTailPadRows rows of slack, so the look-ahead never leaves
-// the allocation).
-template <int G, typename F>
-__device__ __forceinline__ void stream_rows(const uint4* __restrict__ p, const uint32_t rows, F&& consume)
-{
-    uint4 cur[G], nxt[G];
-#pragma unroll
-    for (int k = 0; k < G; ++k) cur[k] = ld_stream(p + k * kWave);
-    uint32_t j = 0;
-    for (; j + G <= rows; j += G) {
-        const uint4* __restrict__ q = p + (uint64_t)(j + G) * kWave;
-#pragma unroll
-        for (int k = 0; k < G; ++k) nxt[k] = ld_stream(q + k * kWave);
-#pragma unroll
-        for (int k = 0; k < G; ++k) consume(cur[k]);
-#pragma unroll
-        for (int k = 0; k < G; ++k) cur[k] = nxt[k];
+// The rows of a tile, read once, in order, two rows ahead of the row being consumed.  The streams of a
+// tile follow each other in memory, so one reader serves all of them: run(n, f) consumes the next n
+// rows with f and the look-ahead simply continues into the next stream (the tiled buffer carries
+// kTailPadRows rows of slack, so it never leaves the allocation).
+struct RowReader {
+    const uint4* __restrict__ next;   // row after the two held ones (this lane's slot)
+    uint4 r0, r1;                     // the next two rows to consume
+    __device__ __forceinline__ explicit RowReader(const uint4* __restrict__ p)
+        : next(p + 2 * kWave), r0(ld_stream(p)), r1(ld_stream(p + kWave)) {}
+    template <typename F>
+    __device__ __forceinline__ void run(const uint32_t n, F&& consume)
+    {
+        uint32_t j = 0;
+        for (; j + 2 <= n; j += 2) {
+            const uint4 w0 = r0, w1 = r1;
+            r0 = ld_stream(next);
+            r1 = ld_stream(next + kWave);
+            next += 2 * kWave;
+            consume(w0);
+            consume(w1);
+        }
+        if (j < n) {                  // odd row count (wave-uniform): rotate by one
+            const uint4 w0 = r0;
+            r0 = r1;
+            r1 = ld_stream(next);
+            next += kWave;
+            consume(w0);
+        }
     }
-    const uint32_t rem = rows - j;  // wave-uniform
-#pragma unroll
-    for (int k = 0; k < G - 1; ++k)
-        if ((uint32_t)k < rem) consume(cur[k]);
-}
+};
 
 // ------------------------------------------------------------------------------------------
 // genotype kernel
@@ -253,14 +308,15 @@ template <bool SSO, int MODE, bool COMPACT>
 __global__ __launch_bounds__(kBlock, SVT_MIN_WAVES) void svt_genotype_kernel(const KernelArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // LDS layout: pm[256] | wtab[32] | l10[n_l10 (even)] | libs[n_libs] | hist[total_bins] | thr[total_bins]
-    double* s_pm = reinterpret_cast<double*>(smem);
-    PairWeights* s_wtab = reinterpret_cast<PairWeights*>(s_pm + 256);
-    double* s_l10 = reinterpret_cast<double*>(s_wtab + 32);
-    const uint32_t n_l10_lds = a.l10_in_lds ? ((a.n_l10 + 1u) & ~1u) : 0u;
-    LibDesc* s_lib = reinterpret_cast<LibDesc*>(s_l10 + n_l10_lds);
-    uint32_t* s_hist = reinterpret_cast<uint32_t*>(s_lib + a.lds_libs);
-    int32_t* s_thr = reinterpret_cast<int32_t*>(s_hist + a.lds_bins);
+    // LDS layout (svt_device_types.h): pm[256] | wtab[32] | bins[lds_bins] | libs[lds_libs] | libx[lds_libs] | l10[n_l10]
+    double* s_pm = reinterpret_cast<double*>(smem + kLdsPm);
+    PairWeights* s_wtab = reinterpret_cast<PairWeights*>(smem + kLdsWtab);
+    Bin* s_bins = reinterpret_cast<Bin*>(smem + kLdsBins);
+    LibDesc* s_lib = reinterpret_cast<LibDesc*>(s_bins + a.lds_bins);
+    uint2* s_libx = reinterpret_cast<uint2*>(s_lib + a.lds_libs);   // compact kMultiLds: {LDS address of the library's bins, n_bins * 8}
+    double* s_l10 = reinterpret_cast<double*>(s_libx + a.lds_libs);
+    // the compact entries address the tables by absolute LDS byte offsets
+    if (COMPACT && (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)smem != 0u) __builtin_trap();
     // library window of this workgroup (everything when the tables of the whole batch fit)
     WgDesc wd = {0u, a.n_libs, 0u, MODE != kGeneral ? a.total_bins : 0u};
     if (MODE == kMultiLds) wd = a.wg[blockIdx.x];
@@ -273,12 +329,14 @@ __global__ __launch_bounds__(kBlock, SVT_MIN_WAVES) void svt_genotype_kernel(con
     for (uint32_t i = threadIdx.x; i < wd.lib_cnt * (uint32_t)(sizeof(LibDesc) / 8); i += kBlock)
         reinterpret_cast<uint64_t*>(s_lib)[i] =
             reinterpret_cast<const uint64_t*>(a.libs + wd.lib_lo)[i];
-    if (MODE != kGeneral) {
-        for (uint32_t i = threadIdx.x; i < wd.bin_cnt; i += kBlock) {
-            s_hist[i] = a.hist[wd.bin_lo + i];
-            s_thr[i] = a.thr[wd.bin_lo + i];
+    if (MODE != kGeneral)
+        for (uint32_t i = threadIdx.x; i < wd.bin_cnt; i += kBlock)
+            reinterpret_cast<uint64_t*>(s_bins)[i] = reinterpret_cast<const uint64_t*>(a.bins + wd.bin_lo)[i];
+    if (COMPACT && MODE == kMultiLds)
+        for (uint32_t i = threadIdx.x; i < wd.lib_cnt; i += kBlock) {
+            const LibDesc L = a.libs[wd.lib_lo + i];
+            s_libx[i] = make_uint2(kLdsBins + (L.tab_off - wd.bin_lo) * (uint32_t)sizeof(Bin), L.n_bins * (uint32_t)sizeof(Bin));
         }
-    }
     __syncthreads();
 
     const uint32_t wave = threadIdx.x / kWave;
@@ -296,8 +354,7 @@ __global__ __launch_bounds__(kBlock, SVT_MIN_WAVES) void svt_genotype_kernel(con
     t.pm = s_pm;
     t.wtab = s_wtab;
     t.libs = s_lib;
-    t.hist = MODE != kGeneral ? s_hist : a.hist;
-    t.thr = MODE != kGeneral ? s_thr : a.thr;
+    t.bins = MODE != kGeneral ? s_bins : a.bins;
 
     LaneCtx c;
     c.is_del = svtype == SVT_SVTYPE_DEL;
@@ -306,35 +363,49 @@ __global__ __launch_bounds__(kBlock, SVT_MIN_WAVES) void svt_genotype_kernel(con
     c.pos_delta_d = (double)h.pos_delta;
     c.lib_lo = wd.lib_lo;
     c.bin_lo = wd.bin_lo;
+    c.lib_min = (h.packed >> 16) & 0xffu;
+    c.libx_lane = kLdsBins + a.lds_bins * (uint32_t)sizeof(Bin) + a.lds_libs * (uint32_t)sizeof(LibDesc) +
+                  (c.lib_min - wd.lib_lo) * (uint32_t)sizeof(uint2);
+    c.vl8 = (uint32_t)min(max(h.var_length, 0), 8191) * 8u;
+    c.nodel = c.is_del ? 0u : 0x80000000u;
+    c.wt0 = kLdsWtab + c.del16 * (uint32_t)sizeof(PairWeights);
+    c.wt1 = c.wt0 + 8u * (uint32_t)sizeof(PairWeights);
     {
         const bool small_del = c.is_del && (c.pos_delta_d < a.lib0.sd2);  // classic.py:339,383
         c.fmask = small_del ? 0u : 7u;
         c.kmin = (uint32_t)a.lib0.key_min;
         c.nb = a.lib0.n_bins;
         c.sub2 = c.is_del ? (uint32_t)h.var_length + (uint32_t)a.lib0.key_min : 0x80000000u;
-        c.off2 = c.is_del ? min((uint32_t)h.var_length, a.lib0.n_bins) : 0x80000000u;
-        c.lib_min = (h.packed >> 16) & 0xffu;
+        c.nb8 = a.lib0.n_bins * 8u;
+        c.off2_8 = c.is_del ? min((uint32_t)h.var_length, a.lib0.n_bins) * 8u : 0x80000000u;
     }
 
     Acc acc = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
 
     // ---- stream the tile: row j is one contiguous 1 KiB line for the wave
+    RowReader rows(a.tiled + td.base + lane);
     if (COMPACT) {
-        stream_rows<SVT_GROUP_A>(a.tiled + td.base_a + lane, td.rows_a, [&](const uint4 w) {
-            pair_entry<MODE>(w.x, t, c, acc);
-            pair_entry<MODE>(w.y, t, c, acc);
-            pair_entry<MODE>(w.z, t, c, acc);
-            pair_entry<MODE>(w.w, t, c, acc);
+        rows.run(td.rows[kPairs], [&](const uint4 w) {
+            pair_entry<MODE>(w.x, c, acc);
+            pair_entry<MODE>(w.y, c, acc);
+            pair_entry<MODE>(w.z, c, acc);
+            pair_entry<MODE>(w.w, c, acc);
         });
-        stream_rows<SVT_GROUP_B>(a.tiled + td.base_b + lane, td.rows_b, [&](const uint4 w) {
-            weight_entry<SSO>(w.x, t, acc);
-            weight_entry<SSO>(w.y, t, acc);
-            weight_entry<SSO>(w.z, t, acc);
-            weight_entry<SSO>(w.w, t, acc);
+        rows.run(td.rows[kRefReads], [&](const uint4 w) {
+            ref_read_entry<SSO>(w.x, acc);
+            ref_read_entry<SSO>(w.y, acc);
+            ref_read_entry<SSO>(w.z, acc);
+            ref_read_entry<SSO>(w.w, acc);
+        });
+        rows.run(td.rows[kCandidates], [&](const uint4 w) {
+            candidate_entry<SSO>(w.x, acc);
+            candidate_entry<SSO>(w.y, acc);
+            candidate_entry<SSO>(w.z, acc);
+            candidate_entry<SSO>(w.w, acc);
         });
     } else {
         // canonical 16-byte records (include/svtyper_hip.h: svt_record)
-        stream_rows<SVT_GROUP>(a.tiled + td.base_a + lane, td.rows_a, [&](const uint4 w) {
+        rows.run(td.rows[0], [&](const uint4 w) {
             weight_evidence<SSO>(w.y >> 16 | (w.z << 16), w.z >> 16, (w.w & SVT_REC_CONTINUATION) != 0, t, acc);
             pair_evidence<MODE>(w.x, w.y & 0xffffu, w.w & 7u, SVT_REC_LIB(w.w), t, c, acc);
         });
@@ -426,17 +497,15 @@ __global__ __launch_bounds__(kBlock, SVT_MIN_WAVES) void svt_genotype_kernel(con
     // ---- one 128-byte result record per unit = one full L2 line written by one lane: the
     // scatter back to the unit's original position costs no partial-line traffic
     uint4* __restrict__ dst = reinterpret_cast<uint4*>(a.out + h.unit);
-    dst[0] = pack2d(gl[0], gl[1]);
-    dst[1] = pack2d(gl[2], sq);
-    dst[2] = pack2d(ref_seq, alt_seq);
-    dst[3] = pack2d(alt_clip, ref_span);
-    {
-        const uint64_t t4 = (uint64_t)__double_as_longlong(alt_span);
-        dst[4] = make_uint4((uint32_t)t4, (uint32_t)(t4 >> 32), (uint32_t)cnt[0], (uint32_t)cnt[1]);
-    }
-    dst[5] = make_uint4((uint32_t)cnt[2], (uint32_t)cnt[3], (uint32_t)cnt[4], (uint32_t)cnt[5]);
-    dst[6] = make_uint4((uint32_t)cnt[6], (uint32_t)cnt[7], (uint32_t)cnt[8], (uint32_t)cnt[9]);
-    dst[7] = make_uint4((uint32_t)cnt[10], (uint32_t)gt & 0xffu, 0u, 0u);
+    const uint64_t t4 = (uint64_t)__double_as_longlong(alt_span);
+    st_result(dst + 0, pack2d(gl[0], gl[1]));
+    st_result(dst + 1, pack2d(gl[2], sq));
+    st_result(dst + 2, pack2d(ref_seq, alt_seq));
+    st_result(dst + 3, pack2d(alt_clip, ref_span));
+    st_result(dst + 4, make_uint4((uint32_t)t4, (uint32_t)(t4 >> 32), (uint32_t)cnt[0], (uint32_t)cnt[1]));
+    st_result(dst + 5, make_uint4((uint32_t)cnt[2], (uint32_t)cnt[3], (uint32_t)cnt[4], (uint32_t)cnt[5]));
+    st_result(dst + 6, make_uint4((uint32_t)cnt[6], (uint32_t)cnt[7], (uint32_t)cnt[8], (uint32_t)cnt[9]));
+    st_result(dst + 7, make_uint4((uint32_t)cnt[10], (uint32_t)gt & 0xffu, 0u, 0u));
 }
 
 

@@ -56,8 +56,7 @@ inline void fill_gt_consts(GtConsts& c, double split_weight, double disc_weight)
 
 struct HostTables {
     std::vector<LibDesc> libs;
-    std::vector<uint32_t> hist;      // per library: n_bins counts + sentinel 0
-    std::vector<int32_t> thr;        // per library: n_bins thresholds + sentinel -1
+    std::vector<Bin> bins;           // per library: n_bins {threshold, count} + sentinel {-1, 0}
     std::vector<PairWeights> wtab;   // 32
     std::vector<double> pm;          // 256
     std::vector<double> l10;
@@ -80,7 +79,7 @@ inline int build_tables(const svt_evidence_batch* in, uint64_t max_records_per_u
             hmax = std::max(hmax, L.hist[i]);
         }
         LibDesc d{};
-        d.tab_off = (uint32_t)T.hist.size();
+        d.tab_off = (uint32_t)T.bins.size();
         d.key_min = L.key_min;
         d.n_bins = L.n_bins;
         d.v_nondel = L.mean + L.sd * 3;  // parsers.py:873-875
@@ -93,7 +92,6 @@ inline int build_tables(const svt_evidence_batch* in, uint64_t max_records_per_u
             T.fast_geometry = false;
         for (uint32_t i = 0; i < L.n_bins; ++i) {
             const uint32_t h1 = L.hist[i];
-            T.hist.push_back(h1);
             int32_t t = -1;
             if (h1 > 0 && total > 0 && p_concordant_expr(h1, 0, total)) {
                 // largest h2 in [0, hmax] with p > 0.5 (the expression is monotone non-increasing in h2)
@@ -106,10 +104,10 @@ inline int build_tables(const svt_evidence_batch* in, uint64_t max_records_per_u
                     }
                 t = (int32_t)lo;
             }
-            T.thr.push_back(t);
+            T.bins.push_back(Bin{t, h1});
         }
-        T.hist.push_back(0);   // out-of-range sentinel: Counter miss -> 0
-        T.thr.push_back(-1);   //                        hist[o] == 0 -> never concordant
+        // out-of-range sentinel: Counter miss -> count 0; hist[o] == 0 -> never concordant
+        T.bins.push_back(Bin{-1, 0u});
     }
     // paired-end decision table (see PairWeights)
     T.wtab.resize(32);

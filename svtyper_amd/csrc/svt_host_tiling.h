@@ -5,6 +5,7 @@
 
 #include "svt_device_types.h"
 #include "svt_host_cpus.h"
+#include "svt_prepare_kernels.h"
 
 namespace svt {
 
@@ -40,14 +41,19 @@ inline void parallel_for(uint64_t n, Fn&& fn)
     for (auto& th : pool) th.join();
 }
 
+// rows of 16-byte slots unit `u` needs in stream `k`
+inline uint32_t stream_rows_of(const ScanOut& sc, uint32_t nrec, bool compact, int k)
+{
+    if (compact) return (sc.n[k] + 3) / 4;   // four 4-byte entries per row slot
+    return k == 0 ? nrec : 0u;
+}
+
 // Bucket units by their first library (one sample's units end up together, whatever the input
 // order: site-major batches interleave the samples), sort by stream length inside 16384-unit
-// chunks of that sequence, cut into 64-unit tiles.  len_a/len_b are the per-unit row counts of the
-// two streams (dense layout: len_a = F, len_b = 0).  Chunks are independent and are processed by
+// chunks of that sequence, cut into 64-unit tiles.  Chunks are independent and are processed by
 // several host threads.
 inline void build_tiling(const svt_evidence_batch* in, const std::vector<uint32_t>& nrec,
-                  const std::vector<uint32_t>& len_a, const std::vector<uint32_t>& len_b,
-                  const std::vector<uint4>& scan, Tiling& G)
+                  const std::vector<ScanOut>& scan, bool compact, Tiling& G)
 {
     const uint64_t n = in->n_units;
     const uint64_t n_chunks = (n + kChunkUnits - 1) / kChunkUnits;
@@ -65,10 +71,10 @@ inline void build_tiling(const svt_evidence_batch* in, const std::vector<uint32_
     std::vector<uint32_t> by_lib;
     if (in->n_libs > 1) {
         uint64_t start[257] = {0};
-        for (uint64_t u = 0; u < n; ++u) ++start[(scan[u].z & 0xffu) + 1];   // z = lib_min | lib_max << 8
+        for (uint64_t u = 0; u < n; ++u) ++start[(scan[u].libs & 0xffu) + 1];
         for (int l = 0; l < 256; ++l) start[l + 1] += start[l];
         by_lib.resize(n);
-        for (uint64_t u = 0; u < n; ++u) by_lib[start[scan[u].z & 0xffu]++] = (uint32_t)u;
+        for (uint64_t u = 0; u < n; ++u) by_lib[start[scan[u].libs & 0xffu]++] = (uint32_t)u;
     }
     auto unit_at = [&](uint64_t i) -> uint64_t { return by_lib.empty() ? i : by_lib[i]; };
     parallel_for(n_chunks, [&](uint64_t c) {
@@ -79,10 +85,12 @@ inline void build_tiling(const svt_evidence_batch* in, const std::vector<uint32_
         // by first library, then longest first
         std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
             const uint64_t ux = unit_at(c0 + x), uy = unit_at(c0 + y);
-            const uint32_t lx = scan[ux].z & 0xffu, ly = scan[uy].z & 0xffu;
+            const uint32_t lx = scan[ux].libs & 0xffu, ly = scan[uy].libs & 0xffu;
             if (lx != ly) return lx < ly;
-            const uint64_t kx = ((uint64_t)len_a[ux] << 32) | len_b[ux];
-            const uint64_t ky = ((uint64_t)len_a[uy] << 32) | len_b[uy];
+            const uint64_t kx = ((uint64_t)stream_rows_of(scan[ux], nrec[ux], compact, 0) << 32) |
+                                stream_rows_of(scan[ux], nrec[ux], compact, 1);
+            const uint64_t ky = ((uint64_t)stream_rows_of(scan[uy], nrec[uy], compact, 0) << 32) |
+                                stream_rows_of(scan[uy], nrec[uy], compact, 1);
             return kx > ky;
         });
         for (uint32_t t0 = 0; t0 < cn; t0 += kWave) {
@@ -101,14 +109,14 @@ inline void build_tiling(const svt_evidence_batch* in, const std::vector<uint32_
                     h.var_length = U.var_length;
                     h.pos_delta = U.pos_delta;
                     h.unit = (uint32_t)u;
-                    h.packed = (uint32_t)U.svtype | ((uint32_t)U.flags << 8) | ((scan[u].z & 0xffu) << 16);
+                    h.packed = (uint32_t)U.svtype | ((uint32_t)U.flags << 8) | ((scan[u].libs & 0xffu) << 16);
                     src = in->rec_offset[u];
                     f = nrec[u];
-                    td.rows_a = std::max(td.rows_a, len_a[u]);
-                    td.rows_b = std::max(td.rows_b, len_b[u]);
+                    for (int k = 0; k < kStreams; ++k)
+                        td.rows[k] = std::max(td.rows[k], stream_rows_of(scan[u], f, compact, k));
                     if (f) {
-                        lib_lo = std::min(lib_lo, scan[u].z & 0xffu);
-                        lib_hi = std::max(lib_hi, (scan[u].z >> 8) & 0xffu);
+                        lib_lo = std::min(lib_lo, scan[u].libs & 0xffu);
+                        lib_hi = std::max(lib_hi, (scan[u].libs >> 8) & 0xffu);
                     }
                 }
                 G.hdr[td.lane_base + l] = h;
@@ -120,11 +128,10 @@ inline void build_tiling(const svt_evidence_batch* in, const std::vector<uint32_
             G.tile_lib_hi[ti] = lib_lo == 0xffffffffu ? 0u : lib_hi;
         }
     });
-    // slot offsets: a tile's pair rows, then its weight rows
+    // slot offsets: the streams of a tile follow each other
     for (TileDesc& td : G.tiles) {
-        td.base_a = G.slots;
-        td.base_b = G.slots + (uint64_t)td.rows_a * kWave;
-        G.slots += (uint64_t)(td.rows_a + td.rows_b) * kWave;
+        td.base = G.slots;
+        for (int k = 0; k < kStreams; ++k) G.slots += (uint64_t)td.rows[k] * kWave;
     }
 }
 

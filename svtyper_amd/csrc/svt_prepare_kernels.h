@@ -12,14 +12,17 @@ namespace svt {
 // ------------------------------------------------------------------------------------------
 
 // ---- compact layout --------------------------------------------------------------------------
-// A unit's evidence becomes two sparse streams of 4-byte entries (four per 16-byte row slot):
+// A unit's evidence becomes three sparse streams of 4-byte entries (four per 16-byte row slot), each in
+// record order.  The five tallies are independent sums, so evidence for different tallies can live
+// in different streams without changing any of them.
 //
-//   pair entry    code | f3 << 13 | mapq_a << 16 | mapq_b << 24                      (one library)
-//                 code | f3 << 13 | mapq_a << 16 | mapq_b << 23 | (lib - lib_min) << 30   (several)
+//   pair entry (alt_span, ref_span)
+//       one library:  f3 | code << 3 | mapq_a << 16 | mapq_b << 24
+//       several:      f3 | code << 3 | (lib - lib_min) << 16 | mapq_a << 18 | mapq_b << 25
 //     f3   = alt | refA << 1 | refB << 2 straddle bits
 //     code = ospan_len translated into the index space of the library's histogram tables: with
-//            r = ospan_len - key_min, the kernel needs hist/thr[r] (parsers.py:870-872) and, for a
-//            DEL, hist[r - var_length] (parsers.py:874-878), each replaced by the sentinel bin
+//            r = ospan_len - key_min, the kernel needs bins[r].thr (parsers.py:870-872) and, for a
+//            DEL, bins[r - var_length].hist (parsers.py:874-878), each replaced by the sentinel bin
 //            n_bins when out of range.  With off2 = min(var_length, n_bins):
 //                var_length <  n_bins:  code = r            for 0 <= r < var_length + n_bins
 //                var_length >= n_bins:  code = r            for 0 <= r < n_bins
@@ -27,14 +30,18 @@ namespace svt {
 //                anything else / not a DEL window:  code = 2 * n_bins
 //            so that i1 = min(code, n_bins) and i2 = min(code - off2, n_bins) (unsigned) are exactly the
 //            two table indices.  Only the addressing is precomputed; the look-ups, the p_concordant
-//            decision and every sum stay in the genotype kernel.
-//   weight entry  mapq0 | mapq1 << 8 | kind << 16 | first_of_fragment << 18
-//     kind 0: reference reads (rs_a, rs_b), 1: split candidate (seq_l, seq_r), 2: clip candidate
-//     first_of_fragment: first kept entry of this kind in its read-fragment (sso association)
+//            decision and every sum stay in the genotype kernel.  `code << 3` is the byte offset of
+//            the bin, and the MAPQs sit on byte boundaries, so the kernel turns every field into an LDS
+//            address with one instruction.
+//   reference-read entries (ref_seq)         mapq0 | mapq1 << 8 | first_of_fragment << 16
+//   candidate entries (alt_seq / alt_clip)   mapq0 | mapq1 << 8 | first_of_fragment << 16 | is_clip << 17
+//     the two gated MAPQs of the reference reads (rs_a, rs_b), of the split candidate (seq_l, seq_r)
+//     or of the clip candidate (clip_l, clip_r); first_of_fragment marks the first kept entry for its
+//     tally in a read-fragment (sso association: fragment-local sums).
 //
 // Entries that can only add +0.0 to a sum are not stored: pair entries without a straddle bit, with a
 // zero MAPQ on either read, or of a DEL smaller than 2 sd of the entry's library (classic.py:339,383);
-// weight kinds whose two gated MAPQs are 0.  x + 0.0 == x bit-for-bit for these non-negative sums.
+// weight entries whose two gated MAPQs are 0.  x + 0.0 == x bit-for-bit for these non-negative sums.
 
 struct UnitGeom {
     bool is_del;
@@ -72,13 +79,21 @@ __device__ __forceinline__ uint32_t pair_code(const uint32_t ospan_len, const Un
     return in1 ? (uint32_t)r : in2 ? (uint32_t)(nb + r2) : (uint32_t)(2 * nb);
 }
 
-// the three weight kinds of a canonical record: gated MAPQ pairs (lo byte, hi byte), 0 = nothing to add
-__device__ __forceinline__ void weight_kinds(const uint4 w, uint32_t k[3])
+// the gated MAPQ pairs (lo byte, hi byte) of a canonical record that feed ref_seq / alt_seq / alt_clip;
+// 0 = nothing to add
+__device__ __forceinline__ void weight_pairs(const uint4 w, uint32_t k[3])
 {
     k[0] = w.y >> 16;            // rs_a | rs_b << 8
     k[1] = w.z & 0xffffu;        // seq_l | seq_r << 8
     k[2] = w.z >> 16;            // clip_l | clip_r << 8
 }
+
+struct ScanOut {          // per unit
+    uint32_t n[kStreams]; // entries per compact stream
+    uint32_t libs;        // lib_min | lib_max << 8
+    uint32_t flags;       // kScan*
+};
+constexpr uint32_t kScanWideMapq = 1u;   // a kept pair entry has a MAPQ > 127
 
 struct ScanArgs {
     const uint4* csr;
@@ -87,20 +102,20 @@ struct ScanArgs {
     const LibDesc* libs;
     uint64_t n_units;
     uint32_t n_libs;
-    uint4* counts;      // per unit: pair entries, weight entries, lib_min | lib_max << 8, kScan* flags
+    ScanOut* out;
     uint32_t* err;
 };
-constexpr uint32_t kScanWideMapq = 1u;   // a kept pair entry has a MAPQ > 127
 
 // one thread per unit: validate the record contract of include/svtyper_hip.h, count the entries of the
-// two sparse streams and find the range of libraries the unit references
+// compact streams and find the range of libraries the unit references
 __global__ __launch_bounds__(kBlock) void svt_scan_kernel(const ScanArgs a)
 {
     const uint64_t u = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
     if (u >= a.n_units) return;
     const uint64_t lo = a.rec_offset[u], hi = a.rec_offset[u + 1];
     const UnitGeom g = unit_geom(a.units[u]);
-    uint32_t np = 0, nq = 0, bad = 0, lib_min = 0xffu, lib_max = 0u, flags = 0u;
+    ScanOut o{};
+    uint32_t bad = 0, lib_min = 0xffu, lib_max = 0u;
     for (uint64_t j = lo; j < hi; ++j) {
         const uint4 w = a.csr[j];
         const uint32_t f = w.w;
@@ -113,15 +128,17 @@ __global__ __launch_bounds__(kBlock) void svt_scan_kernel(const ScanArgs a)
         if (f & ~SVT_REC_FLAG_MASK) bad |= 8u;
         if ((int32_t)w.x < 0) bad |= 16u;
         if (keeps_pair_entry(w, g, a.libs[lib])) {
-            ++np;
-            if ((w.y & 0x8080u) != 0u) flags |= kScanWideMapq;
+            ++o.n[kPairs];
+            if ((w.y & 0x8080u) != 0u) o.flags |= kScanWideMapq;
         }
         uint32_t k[3];
-        weight_kinds(w, k);
-        nq += (k[0] ? 1u : 0u) + (k[1] ? 1u : 0u) + (k[2] ? 1u : 0u);
+        weight_pairs(w, k);
+        o.n[kRefReads] += k[0] ? 1u : 0u;
+        o.n[kCandidates] += (k[1] ? 1u : 0u) + (k[2] ? 1u : 0u);
     }
     if (lo == hi) lib_min = 0u;
-    a.counts[u] = make_uint4(np, nq, lib_min | (lib_max << 8), flags);
+    o.libs = lib_min | (lib_max << 8);
+    a.out[u] = o;
     if (bad) atomicOr(a.err, bad);
 }
 
@@ -148,9 +165,9 @@ __global__ __launch_bounds__(kBlock) void svt_repack_dense_kernel(const RepackAr
     const TileDesc td = a.tiles[tile_idx];
     const uint64_t src = a.lane_src[td.lane_base + lane];
     const uint32_t nrec = a.lane_nrec[td.lane_base + lane];
-    for (uint32_t j = 0; j < td.rows_a; ++j) {
+    for (uint32_t j = 0; j < td.rows[0]; ++j) {
         const uint4 w = j < nrec ? a.csr[src + j] : make_uint4(0, 0, 0, 0);
-        a.tiled[td.base_a + (uint64_t)j * kWave + lane] = w;
+        a.tiled[td.base + (uint64_t)j * kWave + lane] = w;
     }
 }
 
@@ -181,7 +198,7 @@ struct RowWriter {
     }
 };
 
-// compact layout: CSR records -> pair-entry rows + weight-entry rows, in record order
+// compact layout: CSR records -> the four entry streams of the tile, in record order
 __global__ __launch_bounds__(kBlock) void svt_repack_compact_kernel(const RepackArgs a)
 {
     const uint32_t wave = threadIdx.x / kWave;
@@ -195,30 +212,38 @@ __global__ __launch_bounds__(kBlock) void svt_repack_compact_kernel(const Repack
     UnitGeom g{false, 0, 0.0};
     if (h.unit != kPadUnit) g = unit_geom(a.units[h.unit]);
     const uint32_t lib_min = (h.packed >> 16) & 0xffu;
-    RowWriter P{a.tiled + td.base_a + lane}, Q{a.tiled + td.base_b + lane};
-    bool frag_has[3] = {false, false, false};  // did the current fragment already emit an entry of this kind?
+    uint4* row0 = a.tiled + td.base + lane;
+    RowWriter P{row0};
+    RowWriter R{row0 + (uint64_t)td.rows[kPairs] * kWave};
+    RowWriter X{row0 + (uint64_t)(td.rows[kPairs] + td.rows[kRefReads]) * kWave};
+    bool frag_has[3] = {false, false, false};  // did the current fragment already emit an entry for this tally?
     for (uint32_t j = 0; j < nrec; ++j) {
         const uint4 w = a.csr[src + j];
         if (!(w.w & SVT_REC_CONTINUATION)) frag_has[0] = frag_has[1] = frag_has[2] = false;
         const uint32_t lib_idx = SVT_REC_LIB(w.w);
         const LibDesc lib = a.libs[lib_idx];
         if (keeps_pair_entry(w, g, lib)) {
-            const uint32_t code = pair_code(w.x, g, lib) | ((w.w & 7u) << kCodeBits);
+            const uint32_t lo16 = (w.w & 7u) | (pair_code(w.x, g, lib) << 3);
             const uint32_t mq_a = w.y & 0xffu, mq_b = (w.y >> 8) & 0xffu;
-            P.put(a.multi_lib ? (code | (mq_a << 16) | (mq_b << 23) | ((lib_idx - lib_min) << 30))
-                              : (code | (mq_a << 16) | (mq_b << 24)));
+            P.put(a.multi_lib ? (lo16 | ((lib_idx - lib_min) << 16) | (mq_a << 18) | (mq_b << 25))
+                              : (lo16 | (mq_a << 16) | (mq_b << 24)));
         }
         uint32_t k[3];
-        weight_kinds(w, k);
+        weight_pairs(w, k);
+        if (k[0]) {
+            R.put(k[0] | (frag_has[0] ? 0u : (1u << 16)));
+            frag_has[0] = true;
+        }
 #pragma unroll
-        for (uint32_t kind = 0; kind < 3; ++kind)
-            if (k[kind]) {
-                Q.put(k[kind] | (kind << 16) | (frag_has[kind] ? 0u : (1u << 18)));
-                frag_has[kind] = true;
+        for (int s = 1; s < 3; ++s)
+            if (k[s]) {
+                X.put(k[s] | (frag_has[s] ? 0u : (1u << 16)) | ((uint32_t)(s - 1) << 17));
+                frag_has[s] = true;
             }
     }
-    P.finish(td.rows_a);
-    Q.finish(td.rows_b);
+    P.finish(td.rows[kPairs]);
+    R.finish(td.rows[kRefReads]);
+    X.finish(td.rows[kCandidates]);
 }
 
 

@@ -95,8 +95,7 @@ struct svt_batch {
     double* d_pm = nullptr;
     double* d_l10 = nullptr;
     LibDesc* d_libs = nullptr;
-    uint32_t* d_hist = nullptr;
-    int32_t* d_thr = nullptr;
+    Bin* d_bins = nullptr;
     PairWeights* d_wtab = nullptr;
     WgDesc* d_wg = nullptr;
     svt_result* d_out = nullptr;
@@ -112,7 +111,7 @@ void free_batch(svt_batch* b)
     (void)hipSetDevice(b->device);
     auto F = [](void* p) { if (p) (void)hipFree(p); };
     F(b->d_tiled); F(b->d_tiles); F(b->d_hdr); F(b->d_pm); F(b->d_l10); F(b->d_libs);
-    F(b->d_hist); F(b->d_thr); F(b->d_wtab); F(b->d_wg); F(b->d_out);
+    F(b->d_bins); F(b->d_wtab); F(b->d_wg); F(b->d_out);
     if (b->ev0) (void)hipEventDestroy(b->ev0);
     if (b->ev1) (void)hipEventDestroy(b->ev1);
     if (b->stream) (void)hipStreamDestroy(b->stream);
@@ -241,10 +240,10 @@ int create_on_device(const svt_evidence_batch* in, svt_batch* b, const uint4* d_
     SVT_TRY(d_units.alloc(n * sizeof(svt_unit)));
     if (n) HIP_TRY(hipMemcpyAsync(d_units.p, in->units, n * sizeof(svt_unit), hipMemcpyHostToDevice, b->stream));
     SVT_TRY(upload(&b->d_libs, T.libs, b->stream));
-    SVT_TRY(d_counts.alloc(n * sizeof(uint4)));
+    SVT_TRY(d_counts.alloc(n * sizeof(ScanOut)));
     SVT_TRY(d_err.alloc(sizeof(uint32_t)));
     HIP_TRY(hipMemsetAsync(d_err.p, 0, sizeof(uint32_t), b->stream));
-    std::vector<uint4> counts(n);
+    std::vector<ScanOut> counts(n);
     uint32_t err_bits = 0;
     if (n) {
         ScanArgs sa{};
@@ -254,11 +253,11 @@ int create_on_device(const svt_evidence_batch* in, svt_batch* b, const uint4* d_
         sa.libs = b->d_libs;
         sa.n_units = n;
         sa.n_libs = in->n_libs;
-        sa.counts = d_counts.as<uint4>();
+        sa.out = d_counts.as<ScanOut>();
         sa.err = d_err.as<uint32_t>();
         hipLaunchKernelGGL(svt_scan_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, b->stream, sa);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(counts.data(), d_counts.p, n * sizeof(uint4), hipMemcpyDeviceToHost, b->stream));
+        HIP_TRY(hipMemcpyAsync(counts.data(), d_counts.p, n * sizeof(ScanOut), hipMemcpyDeviceToHost, b->stream));
     }
     HIP_TRY(hipMemcpyAsync(&err_bits, d_err.p, sizeof(uint32_t), hipMemcpyDeviceToHost, b->stream));
     HIP_TRY(hipStreamSynchronize(b->stream));
@@ -280,8 +279,8 @@ int create_on_device(const svt_evidence_batch* in, svt_batch* b, const uint4* d_
         for (const LibDesc& L : T.libs) ok = ok && L.n_bins <= kMaxCompactBins;
         if (ok && in->n_libs > 1)
             for (uint64_t u = 0; u < n && ok; ++u)
-                ok = ((counts[u].z >> 8) & 0xffu) - (counts[u].z & 0xffu) < kMaxCompactLibSpan &&
-                     !(counts[u].w & kScanWideMapq);
+                ok = ((counts[u].libs >> 8) & 0xffu) - (counts[u].libs & 0xffu) < kMaxCompactLibSpan &&
+                     !(counts[u].flags & kScanWideMapq);
         b->compact = ok;
     }
 
@@ -291,18 +290,8 @@ int create_on_device(const svt_evidence_batch* in, svt_batch* b, const uint4* d_
     std::vector<WgDesc> windows;
     uint32_t n_groups = 0, max_win_libs = 1, max_win_bins = 1;
     auto plan = [&]() -> int {
-        std::vector<uint32_t> len_a(n), len_b(n);
-        for (uint64_t u = 0; u < n; ++u) {
-            if (b->compact) {
-                len_a[u] = (counts[u].x + 3) / 4;   // four 4-byte entries per 16-byte row slot
-                len_b[u] = (counts[u].y + 3) / 4;
-            } else {
-                len_a[u] = nrec[u];
-                len_b[u] = 0;
-            }
-        }
         G = Tiling();
-        build_tiling(in, nrec, len_a, len_b, counts, G);
+        build_tiling(in, nrec, counts, b->compact, G);
         if (G.tiles.size() > 0xFFFFFFF0ull / kWave) return fail(SVT_ERR_INVALID, "too many tiles");
         b->n_tiles = (uint32_t)G.tiles.size();
         b->slots = G.slots;
@@ -314,7 +303,7 @@ int create_on_device(const svt_evidence_batch* in, svt_batch* b, const uint4* d_
         for (uint32_t g = 0; g < n_groups; ++g) {
             group_order[g] = g;
             for (uint32_t t = g * kWavesPerBlock; t < std::min(b->n_tiles, (g + 1) * kWavesPerBlock); ++t)
-                group_cost[g] += G.tiles[t].rows_a + G.tiles[t].rows_b;
+                for (int k = 0; k < kStreams; ++k) group_cost[g] += G.tiles[t].rows[k];
         }
         std::stable_sort(group_order.begin(), group_order.end(),
                          [&](uint32_t x, uint32_t y) { return group_cost[x] > group_cost[y]; });
@@ -349,7 +338,7 @@ int create_on_device(const svt_evidence_batch* in, svt_batch* b, const uint4* d_
         return SVT_OK;
     };
     SVT_TRY(plan());
-    const bool lds_tables = T.fast_geometry && (size_t)max_win_bins * 8 <= kMaxLdsTableBytes;
+    const bool lds_tables = T.fast_geometry && (size_t)max_win_bins * sizeof(Bin) <= kMaxLdsTableBytes;
     if (b->compact && !lds_tables) {   // the compact entries only exist for the LDS modes
         b->compact = false;
         SVT_TRY(plan());
@@ -365,8 +354,7 @@ int create_on_device(const svt_evidence_batch* in, svt_batch* b, const uint4* d_
     SVT_TRY(upload(d_lane_nrec, G.lane_nrec, b->stream));
     SVT_TRY(upload(&b->d_pm, T.pm, b->stream));
     SVT_TRY(upload(&b->d_l10, T.l10, b->stream));
-    SVT_TRY(upload(&b->d_hist, T.hist, b->stream));
-    SVT_TRY(upload(&b->d_thr, T.thr, b->stream));
+    SVT_TRY(upload(&b->d_bins, T.bins, b->stream));
     SVT_TRY(upload(&b->d_wtab, T.wtab, b->stream));
     SVT_TRY(upload(&b->d_wg, windows, b->stream));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&b->d_tiled), (G.slots + kTailPadRows * kWave) * sizeof(uint4)));
@@ -402,12 +390,11 @@ int create_on_device(const svt_evidence_batch* in, svt_batch* b, const uint4* d_
     a.pm = b->d_pm;
     a.l10 = b->d_l10;
     a.libs = b->d_libs;
-    a.hist = b->d_hist;
-    a.thr = b->d_thr;
+    a.bins = b->d_bins;
     a.wtab = b->d_wtab;
     a.n_l10 = (uint32_t)T.l10.size();
     a.n_libs = in->n_libs;
-    a.total_bins = (uint32_t)T.hist.size();
+    a.total_bins = (uint32_t)T.bins.size();
     a.n_tiles = n_groups * kWavesPerBlock;   // the dispatch list is padded to whole workgroups
     a.l10_in_lds = a.n_l10 <= kMaxL10Lds ? 1u : 0u;
     a.n_units = n;
@@ -428,8 +415,8 @@ int create_on_device(const svt_evidence_batch* in, svt_batch* b, const uint4* d_
         a.lds_bins = 0;
     }
     const uint32_t n_l10_lds = a.l10_in_lds ? ((a.n_l10 + 1u) & ~1u) : 0u;
-    b->lds_bytes = 256 * 8 + 32 * sizeof(PairWeights) + (size_t)n_l10_lds * 8 +
-                   (size_t)a.lds_libs * sizeof(LibDesc) + (size_t)a.lds_bins * 8;
+    b->lds_bytes = kLdsBins + (size_t)a.lds_bins * sizeof(Bin) + (size_t)a.lds_libs * (sizeof(LibDesc) + sizeof(uint2)) +
+                   (size_t)n_l10_lds * 8;
     b->lds_bytes = (b->lds_bytes + 15) & ~size_t(15);
     if (b->lds_bytes > 160 * 1024) return fail(SVT_ERR_INVALID, "LDS budget exceeded");
     if (b->lds_bytes > 64 * 1024)
@@ -660,6 +647,7 @@ int svt_batch_bind_device_results(svt_batch* b, svt_result* dev)
     if (dev && (reinterpret_cast<uintptr_t>(dev) & 127u)) return fail(SVT_ERR_INVALID, "result buffer must be 128-byte aligned");
     b->args.out = dev ? dev : b->d_out;
     b->have_results = false;
+
     return SVT_OK;
 }
 
