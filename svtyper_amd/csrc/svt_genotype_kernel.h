@@ -237,10 +237,22 @@ __device__ __forceinline__ void candidate_entry(const uint32_t e, Acc& a)
 
 __device__ __forceinline__ double log_choose_dev(const double* __restrict__ l10, int32_t n, int32_t k)
 {
-    // statistics.py:9-20 -- same loop, log(i)/log(10) from the host-built table
+    // statistics.py:9-20 -- same loop and the same order of additions, log(i)/log(10) from the host-built
+    // table; the table reads of four iterations are issued together so the chain of dependent adds
+    // does not wait for one LDS round trip per term
     double r = 0.0;
     if (k * 2 > n) k = n - k;
-    for (int32_t d = 1; d <= k; ++d) {
+    int32_t d = 1;
+    for (; d + 3 <= k; d += 4) {
+        const double a0 = l10[n], a1 = l10[n - 1], a2 = l10[n - 2], a3 = l10[n - 3];
+        const double b0 = l10[d], b1 = l10[d + 1], b2 = l10[d + 2], b3 = l10[d + 3];
+        r += a0; r -= b0;
+        r += a1; r -= b1;
+        r += a2; r -= b2;
+        r += a3; r -= b3;
+        n -= 4;
+    }
+    for (; d <= k; ++d) {
         r += l10[n];
         r -= l10[d];
         n -= 1;
@@ -317,6 +329,18 @@ __global__ __launch_bounds__(kBlock, SVT_MIN_WAVES) void svt_genotype_kernel(con
     double* s_l10 = reinterpret_cast<double*>(s_libx + a.lds_libs);
     // the compact entries address the tables by absolute LDS byte offsets
     if (COMPACT && (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)smem != 0u) __builtin_trap();
+    // this wave's tile and this lane's unit: requested before the tables are staged so that the two
+    // dependent loads overlap the staging instead of following the barrier
+    const uint32_t wave = threadIdx.x / kWave;
+    const uint32_t lane = threadIdx.x % kWave;
+    const uint32_t tile_idx = blockIdx.x * kWavesPerBlock + wave;
+    TileDesc td{};
+    td.lane_base = kPadUnit;
+    if (tile_idx < a.n_tiles) td = a.tiles[tile_idx];
+    const bool live = td.lane_base != kPadUnit;    // not the padding of the last workgroup
+    LaneHdr h{};
+    if (live) h = a.hdr[td.lane_base + lane];
+
     // library window of this workgroup (everything when the tables of the whole batch fit)
     WgDesc wd = {0u, a.n_libs, 0u, MODE != kGeneral ? a.total_bins : 0u};
     if (MODE == kMultiLds) wd = a.wg[blockIdx.x];
@@ -339,14 +363,7 @@ __global__ __launch_bounds__(kBlock, SVT_MIN_WAVES) void svt_genotype_kernel(con
         }
     __syncthreads();
 
-    const uint32_t wave = threadIdx.x / kWave;
-    const uint32_t lane = threadIdx.x % kWave;
-    const uint32_t tile_idx = blockIdx.x * kWavesPerBlock + wave;
-    if (tile_idx >= a.n_tiles) return;
-
-    const TileDesc td = a.tiles[tile_idx];
-    if (td.lane_base == kPadUnit) return;   // padding of the last workgroup
-    const LaneHdr h = a.hdr[td.lane_base + lane];
+    if (!live) return;
     const uint32_t svtype = h.packed & 0xffu;
     const uint32_t uflags = (h.packed >> 8) & 0xffu;
 
