@@ -42,6 +42,69 @@ struct CsrScratchCache {
 };
 inline CsrScratchCache g_csr_cache;
 
+// Pool of the large resident device buffers (tiled image, result records, lane headers): a fresh
+// hipMalloc is not only slow by itself, the first kernel that touches the new memory also waits ~10-20 ms
+// for the driver's asynchronous clear of it (measured: tools/first_pass_probe.py), so a pipeline that
+// creates one batch per chunk would pay that on every chunk.  svt_batch_destroy returns the buffers
+// here; svt_trim() releases them.
+struct DevicePool {
+    struct Item { void* p; uint64_t cap; int device; };
+    static constexpr size_t kMaxItems = 8;
+    std::mutex lock;
+    std::vector<Item> items;
+    // a buffer of at least `bytes` (best fit, at most 2x + 1 MiB oversized), else a new allocation
+    int get(int device, uint64_t bytes, void** out, uint64_t* cap)
+    {
+        bytes = std::max<uint64_t>(bytes, 256);
+        {
+            std::lock_guard<std::mutex> g(lock);
+            size_t best = items.size();
+            for (size_t i = 0; i < items.size(); ++i)
+                if (items[i].device == device && items[i].cap >= bytes && items[i].cap <= 2 * bytes + (1u << 20) &&
+                    (best == items.size() || items[i].cap < items[best].cap))
+                    best = i;
+            if (best != items.size()) {
+                *out = items[best].p;
+                *cap = items[best].cap;
+                items.erase(items.begin() + (long)best);
+                return SVT_OK;
+            }
+        }
+        const uint64_t want = bytes + bytes / 8;   // room for the next, slightly larger batch
+        HIP_TRY(hipMalloc(out, want));
+        *cap = want;
+        return SVT_OK;
+    }
+    void put(int device, void* p, uint64_t cap)
+    {
+        if (!p) return;
+        void* drop = nullptr;
+        {
+            std::lock_guard<std::mutex> g(lock);
+            items.push_back(Item{p, cap, device});
+            if (items.size() > kMaxItems) {   // keep the largest ones
+                size_t smallest = 0;
+                for (size_t i = 1; i < items.size(); ++i)
+                    if (items[i].cap < items[smallest].cap) smallest = i;
+                drop = items[smallest].p;
+                if (items[smallest].device != device) (void)hipSetDevice(items[smallest].device);
+                items.erase(items.begin() + (long)smallest);
+            }
+        }
+        if (drop) (void)hipFree(drop);
+    }
+    void trim()
+    {
+        std::lock_guard<std::mutex> g(lock);
+        for (const Item& it : items) {
+            (void)hipSetDevice(it.device);
+            (void)hipFree(it.p);
+        }
+        items.clear();
+    }
+};
+inline DevicePool g_pool;
+
 // Pinned staging ring shared by all batches of the process (allocated on first use, per device
 // context of the first caller; pinned host memory is usable from every device).
 struct StagingRing {
@@ -59,47 +122,82 @@ struct StagingRing {
 };
 inline StagingRing g_ring;
 
-// Host -> device copy of a large pageable buffer through the pinned ring: a few host threads fill
-// one piece while the previous piece is on the wire (a first hipMemcpy of pageable memory stages at
-// ~13 GB/s on this platform; pinned pieces move at ~56 GB/s, tools/h2d_probe.hip).
-inline int h2d_staged(void* dst, const void* src, uint64_t bytes, hipStream_t stream)
-{
-    if (bytes < (16ull << 20)) {
-        if (bytes) HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream));
+// Host -> device copies of pageable memory through the pinned ring: a few host threads fill one piece
+// while the previous piece is on the wire (pinned pieces move at ~56 GB/s; a first hipMemcpy of
+// pageable memory stages at ~13 GB/s, tools/h2d_probe.hip).  It also keeps the runtime from pinning the
+// caller's (or our own std::vector's) pages for a direct DMA: when such pages are unmapped later, the
+// driver's MMU notifier evicts the process's GPU queues and the next kernel starts 10-20 ms late
+// (tools/first_pass_probe.py).  One Stager holds the ring for its lifetime; copies are asynchronous on
+// `stream`, finish() waits for them.
+constexpr uint64_t kDirectCopyMax = 256u << 10;   // below this the runtime's own bounce buffer is used anyway
+
+class Stager {
+public:
+    explicit Stager(hipStream_t stream) : stream_(stream), guard_(g_ring.lock) {}
+    Stager(const Stager&) = delete;
+    Stager& operator=(const Stager&) = delete;
+    ~Stager()
+    {
+        (void)hipStreamSynchronize(stream_);   // the ring is reusable once the last piece has left
+        for (int i = 0; i < StagingRing::kSlots; ++i)
+            if (done_[i]) (void)hipEventDestroy(done_[i]);
+    }
+    int copy(void* dst, const void* src, uint64_t bytes)
+    {
+        if (bytes == 0) return SVT_OK;
+        if (bytes <= kDirectCopyMax) {
+            HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream_));
+            return SVT_OK;
+        }
+        SVT_TRY(g_ring.ensure());
+        for (int i = 0; i < StagingRing::kSlots; ++i)
+            if (!done_[i] && hipEventCreateWithFlags(&done_[i], hipEventDisableTiming) != hipSuccess)
+                return fail(SVT_ERR_HIP, "hipEventCreate");
+        const unsigned nt = std::min(host_threads(), 6u);   // 4-8 threads saturate the host copy
+        for (uint64_t off = 0; off < bytes; slot_ = (slot_ + 1) % StagingRing::kSlots) {
+            const uint64_t len = std::min(StagingRing::kPiece, bytes - off);
+            if (hipEventSynchronize(done_[slot_]) != hipSuccess) return fail(SVT_ERR_HIP, "staging event");
+            const char* s0 = static_cast<const char*>(src) + off;
+            char* p0 = static_cast<char*>(g_ring.buf[slot_]);
+            if (len < (4u << 20)) std::memcpy(p0, s0, len);
+            else {
+                const uint64_t part = ((len + nt - 1) / nt + 4095) & ~uint64_t(4095);
+                parallel_for(nt, [&](uint64_t t) {
+                    const uint64_t lo = t * part, hi = std::min(len, lo + part);
+                    if (lo < hi) std::memcpy(p0 + lo, s0 + lo, hi - lo);
+                });
+            }
+            if (hipMemcpyAsync(static_cast<char*>(dst) + off, p0, len, hipMemcpyHostToDevice, stream_) != hipSuccess ||
+                hipEventRecord(done_[slot_], stream_) != hipSuccess)
+                return fail(SVT_ERR_HIP, "staged hipMemcpyAsync");
+            off += len;
+        }
         return SVT_OK;
     }
-    std::lock_guard<std::mutex> guard(g_ring.lock);
-    SVT_TRY(g_ring.ensure());
-    hipEvent_t done[StagingRing::kSlots] = {nullptr, nullptr, nullptr};
-    int rc = SVT_OK;
-    for (int i = 0; i < StagingRing::kSlots && rc == SVT_OK; ++i)
-        if (hipEventCreateWithFlags(&done[i], hipEventDisableTiming) != hipSuccess) rc = fail(SVT_ERR_HIP, "hipEventCreate");
-    const unsigned nt = std::min(host_threads(), 6u);   // 4-8 threads saturate the host copy
-    uint64_t off = 0;
-    for (int slot = 0; rc == SVT_OK && off < bytes; slot = (slot + 1) % StagingRing::kSlots) {
-        const uint64_t len = std::min(StagingRing::kPiece, bytes - off);
-        if (hipEventSynchronize(done[slot]) != hipSuccess) { rc = fail(SVT_ERR_HIP, "staging event"); break; }
-        const char* s0 = static_cast<const char*>(src) + off;
-        char* p0 = static_cast<char*>(g_ring.buf[slot]);
-        const uint64_t part = ((len + nt - 1) / nt + 4095) & ~uint64_t(4095);
-        parallel_for(nt, [&](uint64_t t) {
-            const uint64_t lo = t * part, hi = std::min(len, lo + part);
-            if (lo < hi) std::memcpy(p0 + lo, s0 + lo, hi - lo);
-        });
-        if (hipMemcpyAsync(static_cast<char*>(dst) + off, p0, len, hipMemcpyHostToDevice, stream) != hipSuccess ||
-            hipEventRecord(done[slot], stream) != hipSuccess) { rc = fail(SVT_ERR_HIP, "staged hipMemcpyAsync"); break; }
-        off += len;
+    int finish()
+    {
+        HIP_TRY(hipStreamSynchronize(stream_));
+        return SVT_OK;
     }
-    (void)hipStreamSynchronize(stream);   // the ring is reusable once the last piece has left
-    for (int i = 0; i < StagingRing::kSlots; ++i)
-        if (done[i]) (void)hipEventDestroy(done[i]);
-    return rc;
+
+private:
+    hipStream_t stream_;
+    std::lock_guard<std::mutex> guard_;
+    hipEvent_t done_[StagingRing::kSlots] = {nullptr, nullptr, nullptr};
+    int slot_ = 0;
+};
+
+inline int h2d_staged(void* dst, const void* src, uint64_t bytes, hipStream_t stream)
+{
+    Stager st(stream);
+    SVT_TRY(st.copy(dst, src, bytes));
+    return st.finish();
 }
 
 // Device -> host through the same pinned ring (results: 128 B per unit).
 inline int d2h_staged(void* dst, const void* src, uint64_t bytes, hipStream_t stream)
 {
-    if (bytes < (16ull << 20)) {
+    if (bytes <= kDirectCopyMax) {
         if (bytes) HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         return SVT_OK;

@@ -89,7 +89,8 @@ struct svt_batch {
     size_t lds_bytes = 0;
     bool have_results = false;
     // device buffers
-    uint4* d_tiled = nullptr;
+    uint4* d_tiled = nullptr;     // d_tiled, d_hdr and d_out come from (and go back to) g_pool
+    uint64_t cap_tiled = 0, cap_hdr = 0, cap_out = 0;
     TileDesc* d_tiles = nullptr;  // dispatch order
     LaneHdr* d_hdr = nullptr;
     double* d_pm = nullptr;
@@ -110,8 +111,11 @@ void free_batch(svt_batch* b)
     if (!b) return;
     (void)hipSetDevice(b->device);
     auto F = [](void* p) { if (p) (void)hipFree(p); };
-    F(b->d_tiled); F(b->d_tiles); F(b->d_hdr); F(b->d_pm); F(b->d_l10); F(b->d_libs);
-    F(b->d_bins); F(b->d_wtab); F(b->d_wg); F(b->d_out);
+    g_pool.put(b->device, b->d_tiled, b->cap_tiled);
+    g_pool.put(b->device, b->d_hdr, b->cap_hdr);
+    g_pool.put(b->device, b->d_out, b->cap_out);
+    F(b->d_tiles); F(b->d_pm); F(b->d_l10); F(b->d_libs);
+    F(b->d_bins); F(b->d_wtab); F(b->d_wg);
     if (b->ev0) (void)hipEventDestroy(b->ev0);
     if (b->ev1) (void)hipEventDestroy(b->ev1);
     if (b->stream) (void)hipStreamDestroy(b->stream);
@@ -131,19 +135,17 @@ struct DevScratch {
 };
 
 template <typename T>
-int upload(T** dptr, const std::vector<T>& v, hipStream_t s)
+int upload(T** dptr, const std::vector<T>& v, Stager& st)
 {
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(dptr), std::max<size_t>(v.size(), 1) * sizeof(T)));
-    if (!v.empty()) HIP_TRY(hipMemcpyAsync(*dptr, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s));
-    return SVT_OK;
+    return st.copy(*dptr, v.data(), v.size() * sizeof(T));
 }
 
 template <typename T>
-int upload(DevScratch& d, const std::vector<T>& v, hipStream_t s)
+int upload(DevScratch& d, const std::vector<T>& v, Stager& st)
 {
     SVT_TRY(d.alloc(v.size() * sizeof(T)));
-    if (!v.empty()) HIP_TRY(hipMemcpyAsync(d.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s));
-    return SVT_OK;
+    return st.copy(d.p, v.data(), v.size() * sizeof(T));
 }
 
 template <bool SSO>
@@ -187,6 +189,28 @@ struct StageTimer {
     }
 };
 
+// Host-side work arrays of svt_batch_create (per-unit counts, the tiling, the dispatch list): ~100 MB
+// for a 1 M-unit batch.  Kept between calls -- allocating and releasing them per batch costs ~10 ms of
+// page faults and munmap -- and handed to one svt_batch_create at a time; svt_trim() releases them.
+struct HostScratch {
+    std::mutex lock;
+    std::vector<uint32_t> nrec;
+    std::vector<ScanOut> counts;
+    Tiling G;
+    std::vector<TileDesc> dispatch;
+    std::vector<WgDesc> windows;
+    void trim()
+    {
+        std::lock_guard<std::mutex> g(lock);
+        std::vector<uint32_t>().swap(nrec);
+        std::vector<ScanOut>().swap(counts);
+        G.slots = 0;
+        std::vector<TileDesc>().swap(dispatch);
+        std::vector<WgDesc>().swap(windows);
+    }
+};
+HostScratch g_host;
+
 // everything of svt_batch_create that needs the device; `b` is freed by the caller on failure
 int create_on_device(const svt_evidence_batch* in, svt_batch* b, const uint4* d_records_resident = nullptr)
 {
@@ -195,7 +219,9 @@ int create_on_device(const svt_evidence_batch* in, svt_batch* b, const uint4* d_
     StageTimer tm;
 
     // ---- per-unit record counts + validation of the CSR
-    std::vector<uint32_t> nrec(n);
+    std::lock_guard<std::mutex> host_guard(g_host.lock);
+    std::vector<uint32_t>& nrec = g_host.nrec;
+    nrec.assign(n, 0u);
     uint64_t max_f = 0;
     bool wide_var_length = false, negative_del = false;
     for (uint64_t u = 0; u < n; ++u) {
@@ -222,28 +248,32 @@ int create_on_device(const svt_evidence_batch* in, svt_batch* b, const uint4* d_
     HIP_TRY(hipEventCreate(&b->ev1));
 
     // ---- canonical records to the device; validate them and count the sparse-stream entries
-    DevScratch d_off, d_counts, d_err;
+    DevScratch d_off, d_counts, d_err, d_units;
     std::unique_lock<std::mutex> csr_guard(g_csr_cache.lock, std::defer_lock);
     const uint4* d_csr = d_records_resident;
-    if (!d_csr) {
-        csr_guard.lock();   // the cached scratch is ours until we return
-        void* d_csr_p = nullptr;
-        SVT_TRY(g_csr_cache.acquire(b->device, std::max<uint64_t>(n_rec, 1) * sizeof(uint4), &d_csr_p));
-        d_csr = static_cast<const uint4*>(d_csr_p);
-        tm.mark("stream/event/alloc");
-        SVT_TRY(h2d_staged(d_csr_p, in->records, n_rec * sizeof(uint4), b->stream));
-        tm.mark("H2D records (staged)");
+    {   // every host -> device copy goes through the pinned ring (svt_host_transfer.h: Stager)
+        Stager st(b->stream);
+        if (!d_csr) {
+            csr_guard.lock();   // the cached scratch is ours until we return
+            void* d_csr_p = nullptr;
+            SVT_TRY(g_csr_cache.acquire(b->device, std::max<uint64_t>(n_rec, 1) * sizeof(uint4), &d_csr_p));
+            d_csr = static_cast<const uint4*>(d_csr_p);
+            tm.mark("stream/event/alloc");
+            SVT_TRY(st.copy(d_csr_p, in->records, n_rec * sizeof(uint4)));
+        }
+        SVT_TRY(d_off.alloc((n + 1) * sizeof(uint64_t)));
+        if (n) SVT_TRY(st.copy(d_off.p, in->rec_offset, (n + 1) * sizeof(uint64_t)));
+        SVT_TRY(d_units.alloc(n * sizeof(svt_unit)));
+        SVT_TRY(st.copy(d_units.p, in->units, n * sizeof(svt_unit)));
+        SVT_TRY(upload(&b->d_libs, T.libs, st));
+        SVT_TRY(st.finish());
+        tm.mark("H2D records + unit arrays (staged)");
     }
-    SVT_TRY(d_off.alloc((n + 1) * sizeof(uint64_t)));
-    if (n) HIP_TRY(hipMemcpyAsync(d_off.p, in->rec_offset, (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, b->stream));
-    DevScratch d_units;
-    SVT_TRY(d_units.alloc(n * sizeof(svt_unit)));
-    if (n) HIP_TRY(hipMemcpyAsync(d_units.p, in->units, n * sizeof(svt_unit), hipMemcpyHostToDevice, b->stream));
-    SVT_TRY(upload(&b->d_libs, T.libs, b->stream));
     SVT_TRY(d_counts.alloc(n * sizeof(ScanOut)));
     SVT_TRY(d_err.alloc(sizeof(uint32_t)));
     HIP_TRY(hipMemsetAsync(d_err.p, 0, sizeof(uint32_t), b->stream));
-    std::vector<ScanOut> counts(n);
+    std::vector<ScanOut>& counts = g_host.counts;
+    counts.assign(n, ScanOut{});
     uint32_t err_bits = 0;
     if (n) {
         ScanArgs sa{};
@@ -257,9 +287,9 @@ int create_on_device(const svt_evidence_batch* in, svt_batch* b, const uint4* d_
         sa.err = d_err.as<uint32_t>();
         hipLaunchKernelGGL(svt_scan_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, b->stream, sa);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(counts.data(), d_counts.p, n * sizeof(ScanOut), hipMemcpyDeviceToHost, b->stream));
     }
     HIP_TRY(hipMemcpyAsync(&err_bits, d_err.p, sizeof(uint32_t), hipMemcpyDeviceToHost, b->stream));
+    if (n) SVT_TRY(d2h_staged(counts.data(), d_counts.p, n * sizeof(ScanOut), b->stream));
     HIP_TRY(hipStreamSynchronize(b->stream));
     tm.mark("scan kernel + counts D2H");
     if (err_bits) {
@@ -285,12 +315,12 @@ int create_on_device(const svt_evidence_batch* in, svt_batch* b, const uint4* d_
     }
 
     // ---- tiling
-    Tiling G;
-    std::vector<TileDesc> dispatch;
-    std::vector<WgDesc> windows;
+    Tiling& G = g_host.G;
+    std::vector<TileDesc>& dispatch = g_host.dispatch;
+    std::vector<WgDesc>& windows = g_host.windows;
     uint32_t n_groups = 0, max_win_libs = 1, max_win_bins = 1;
     auto plan = [&]() -> int {
-        G = Tiling();
+        G.slots = 0;
         build_tiling(in, nrec, counts, b->compact, G);
         if (G.tiles.size() > 0xFFFFFFF0ull / kWave) return fail(SVT_ERR_INVALID, "too many tiles");
         b->n_tiles = (uint32_t)G.tiles.size();
@@ -347,19 +377,31 @@ int create_on_device(const svt_evidence_batch* in, svt_batch* b, const uint4* d_
     tm.mark("tiling (host sort)");
     // ---- resident device objects
     DevScratch d_tiles_store, d_lane_src, d_lane_nrec;
-    SVT_TRY(upload(&b->d_tiles, dispatch, b->stream));
-    SVT_TRY(upload(d_tiles_store, G.tiles, b->stream));
-    SVT_TRY(upload(&b->d_hdr, G.hdr, b->stream));
-    SVT_TRY(upload(d_lane_src, G.lane_src, b->stream));
-    SVT_TRY(upload(d_lane_nrec, G.lane_nrec, b->stream));
-    SVT_TRY(upload(&b->d_pm, T.pm, b->stream));
-    SVT_TRY(upload(&b->d_l10, T.l10, b->stream));
-    SVT_TRY(upload(&b->d_bins, T.bins, b->stream));
-    SVT_TRY(upload(&b->d_wtab, T.wtab, b->stream));
-    SVT_TRY(upload(&b->d_wg, windows, b->stream));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&b->d_tiled), (G.slots + kTailPadRows * kWave) * sizeof(uint4)));
-    HIP_TRY(hipMemsetAsync(b->d_tiled + G.slots, 0, kTailPadRows * kWave * sizeof(uint4), b->stream));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&b->d_out), std::max<uint64_t>(n, 1) * sizeof(svt_result)));
+    {
+        Stager st(b->stream);
+        SVT_TRY(upload(&b->d_tiles, dispatch, st));
+        SVT_TRY(upload(d_tiles_store, G.tiles, st));
+        void* p = nullptr;
+        SVT_TRY(g_pool.get(b->device, G.hdr.size() * sizeof(LaneHdr), &p, &b->cap_hdr));
+        b->d_hdr = static_cast<LaneHdr*>(p);
+        SVT_TRY(st.copy(b->d_hdr, G.hdr.data(), G.hdr.size() * sizeof(LaneHdr)));
+        SVT_TRY(upload(d_lane_src, G.lane_src, st));
+        SVT_TRY(upload(d_lane_nrec, G.lane_nrec, st));
+        SVT_TRY(upload(&b->d_pm, T.pm, st));
+        SVT_TRY(upload(&b->d_l10, T.l10, st));
+        SVT_TRY(upload(&b->d_bins, T.bins, st));
+        SVT_TRY(upload(&b->d_wtab, T.wtab, st));
+        SVT_TRY(upload(&b->d_wg, windows, st));
+        SVT_TRY(st.finish());
+    }
+    {
+        void* p = nullptr;
+        SVT_TRY(g_pool.get(b->device, (G.slots + kTailPadRows * kWave) * sizeof(uint4), &p, &b->cap_tiled));
+        b->d_tiled = static_cast<uint4*>(p);
+        HIP_TRY(hipMemsetAsync(b->d_tiled + G.slots, 0, kTailPadRows * kWave * sizeof(uint4), b->stream));
+        SVT_TRY(g_pool.get(b->device, std::max<uint64_t>(n, 1) * sizeof(svt_result), &p, &b->cap_out));
+        b->d_out = static_cast<svt_result*>(p);
+    }
 
     // ---- re-tile on the device
     if (b->n_tiles) {
@@ -528,13 +570,17 @@ int svt_batch_create_from_fragments(const svt_fragment_batch* in, int device, un
     struct StreamGuard { hipStream_t s; ~StreamGuard() { (void)hipStreamDestroy(s); } } sg{s};
     StageTimer tm;
     DevScratch d_frags, d_frag_unit, d_bps, d_libs, d_records, d_err;
-    SVT_TRY(d_frags.alloc(n_frag * sizeof(svt_fragment)));
-    SVT_TRY(h2d_staged(d_frags.p, in->fragments, n_frag * sizeof(svt_fragment), s));
-    tm.mark("H2D fragment summaries");
-    SVT_TRY(upload(d_frag_unit, frag_unit, s));
-    SVT_TRY(d_bps.alloc(n * sizeof(svt_breakpoint)));
-    if (n) HIP_TRY(hipMemcpyAsync(d_bps.p, in->breakpoints, n * sizeof(svt_breakpoint), hipMemcpyHostToDevice, s));
-    SVT_TRY(upload(d_libs, libs, s));
+    {
+        Stager st(s);
+        SVT_TRY(d_frags.alloc(n_frag * sizeof(svt_fragment)));
+        SVT_TRY(st.copy(d_frags.p, in->fragments, n_frag * sizeof(svt_fragment)));
+        SVT_TRY(upload(d_frag_unit, frag_unit, st));
+        SVT_TRY(d_bps.alloc(n * sizeof(svt_breakpoint)));
+        SVT_TRY(st.copy(d_bps.p, in->breakpoints, n * sizeof(svt_breakpoint)));
+        SVT_TRY(upload(d_libs, libs, st));
+        SVT_TRY(st.finish());
+        tm.mark("H2D fragment summaries + unit arrays (staged)");
+    }
     SVT_TRY(d_records.alloc(n_frag * sizeof(uint4)));
     SVT_TRY(d_err.alloc(sizeof(uint32_t)));
     HIP_TRY(hipMemsetAsync(d_err.p, 0, sizeof(uint32_t), s));
@@ -555,8 +601,7 @@ int svt_batch_create_from_fragments(const svt_fragment_batch* in, int device, un
     }
     uint32_t err_bits = 0;
     HIP_TRY(hipMemcpyAsync(&err_bits, d_err.p, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    if (records_out && n_frag)
-        HIP_TRY(hipMemcpyAsync(records_out, d_records.p, n_frag * sizeof(uint4), hipMemcpyDeviceToHost, s));
+    if (records_out && n_frag) SVT_TRY(d2h_staged(records_out, d_records.p, n_frag * sizeof(uint4), s));
     HIP_TRY(hipStreamSynchronize(s));
     tm.mark("geometry kernel (+ copies)");
     if (err_bits) return fail(SVT_ERR_INVALID, "invalid fragment summaries: library index >= n_libs");
@@ -709,7 +754,12 @@ void* svt_batch_stream(svt_batch* b) { return b ? (void*)b->stream : nullptr; }
 
 void svt_batch_destroy(svt_batch* b) { free_batch(b); }
 
-void svt_trim(void) { g_csr_cache.trim(); }
+void svt_trim(void)
+{
+    g_csr_cache.trim();
+    g_pool.trim();
+    g_host.trim();
+}
 
 int svt_genotype(const svt_evidence_batch* in, svt_result* out, int device, unsigned flags)
 {
