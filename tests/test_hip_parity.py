@@ -421,3 +421,19 @@ def test_compact_fallbacks_stay_exact(hip_device, fixture_library):
     b.records["mapq_a"][::11] = 60
     d.units["var_length"][::9] = 250
     assert _layout_of(b)[0] and _layout_of(d)[0]
+
+
+def test_pooled_buffers_do_not_leak_state(hip_device, fixture_library):
+    """svt_batch_destroy hands the big device buffers to a pool and the next create reuses them
+    (larger than needed, full of the previous batch's bytes): results must not depend on that."""
+    from svtyper_amd import hip
+    big = synth.make_units(30_000, 71, [fixture_library], svtype_mix=(0.5, 0.2, 0.2, 0.1))
+    small = synth.make_units(17_000, 72, [fixture_library], svtype_mix=(0.5, 0.2, 0.2, 0.1), mean_frags=40, sd_frags=30,
+                             min_frags=0, max_frags=120)
+    want_small = run_both(small)[1]
+    for flags in (0, ev.FLAG_DENSE_LAYOUT, 0):
+        got_big, want_big = run_both(big, flags)
+        assert_parity(got_big, want_big)
+        assert_parity(hip.genotype_batch(small, device=hip_device, flags=flags), want_small)
+    hip.trim()
+    assert_parity(hip.genotype_batch(small, device=hip_device), want_small)
