@@ -47,6 +47,9 @@ def gather_all_reads(sample: Sample, bp: dict, max_reads):
     return fragments, False
 
 
+_FORMAT_KEYS = ("GL", "DP", "RO", "AO", "QR", "QA", "RS", "AS", "ASC", "RP", "AP", "AB", "GQ", "SQ", "GT")
+
+
 def apply_result(var: Variant, sample_name: str, gt: int, res: dict) -> None:
     """Result of one unit -> FORMAT fields and QUAL of one sample (classic.py:454-513)."""
     g = var.genotype(sample_name)
@@ -56,8 +59,7 @@ def apply_result(var: Variant, sample_name: str, gt: int, res: dict) -> None:
     f = res["formats"]
     if gt == ev.GT_BLANK:                         # classic.py:496-513 (QUAL is reset, not kept)
         var.qual = 0
-    for key in ("GL", "DP", "RO", "AO", "QR", "QA", "RS", "AS", "ASC", "RP", "AP", "AB", "GQ", "SQ", "GT"):
-        g.set_format(key, f[key])
+    g.set_formats([(key, f[key]) for key in _FORMAT_KEYS])
     if gt >= 0:
         var.qual += res["qual"]                   # classic.py:485
 

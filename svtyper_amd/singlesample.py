@@ -61,9 +61,8 @@ def gather_reads(sample: Sample, bp: dict, max_reads):
 def assign_genotype(variant: Variant, sample_name: str, res: dict) -> None:
     """singlesample.py:544-575: every FORMAT field is always written; QUAL accumulates."""
     variant.qual += res["qual"]
-    g = variant.genotype(sample_name)
-    for key in _ASSIGN_ORDER:
-        g.set_format(key, res["formats"][key])
+    f = res["formats"]
+    variant.genotype(sample_name).set_formats([(key, f[key]) for key in _ASSIGN_ORDER])
 
 
 def sso_genotype(bam_string, vcf_in, vcf_out, min_aligned, split_weight, disc_weight, num_samp, lib_info_path,

@@ -257,7 +257,8 @@ class Variant:
         return ";".join(out)
 
     def get_format_string(self) -> str:
-        return ":".join(h.id for h in self.format_list if h.id in self.active_formats)
+        # active_formats is kept in header declaration order by Genotype.set_format / set_formats
+        return ":".join(self.active_formats)
 
     def get_var_string(self) -> str:
         return "\t".join(str(x) for x in (
@@ -292,6 +293,23 @@ class Genotype:
         if field not in active:
             active.append(field)
             active.sort(key=rank.__getitem__)   # header declaration order (parsers.py:375-381)
+
+    def set_formats(self, items):
+        """set_format for several (field, value) pairs with one re-ordering of the active list"""
+        rank = self.variant.format_rank
+        fmt = self.format
+        active = self.variant.active_formats
+        grew = False
+        for field, value in items:
+            if field not in rank:
+                sys.stderr.write('Error: invalid FORMAT field, "' + field + '"\n')
+                sys.exit(1)
+            fmt[field] = value
+            if field not in active:
+                active.append(field)
+                grew = True
+        if grew:
+            active.sort(key=rank.__getitem__)
 
     def get_format(self, field):
         return self.format[field]
