@@ -49,44 +49,58 @@ inline uint32_t stream_rows_of(const ScanOut& sc, uint32_t nrec, bool compact, i
 }
 
 // Bucket units by their first library (one sample's units end up together, whatever the input
-// order: site-major batches interleave the samples), sort by stream length inside 16384-unit
-// chunks of that sequence, cut into 64-unit tiles.  Chunks are independent and are processed by
-// several host threads.
+// order: site-major batches interleave the samples), sort by stream length inside chunks of at
+// most 16384 units of one bucket, cut into 64-unit tiles.  A chunk never crosses a bucket and its
+// tile count is padded to whole workgroups, so the library window a workgroup stages in LDS is the
+// one of a single sample.  Chunks are independent and are processed by several host threads.
 inline void build_tiling(const svt_evidence_batch* in, const std::vector<uint32_t>& nrec,
                   const std::vector<ScanOut>& scan, bool compact, Tiling& G)
 {
     const uint64_t n = in->n_units;
-    const uint64_t n_chunks = (n + kChunkUnits - 1) / kChunkUnits;
-    const uint64_t tiles_per_chunk = kChunkUnits / kWave;
-    const uint64_t n_tiles = n ? (n_chunks - 1) * tiles_per_chunk +
-                                     ((n - (n_chunks - 1) * kChunkUnits) + kWave - 1) / kWave : 0;
-    G.tiles.assign(n_tiles, TileDesc{});
-    G.tile_lib_lo.assign(n_tiles, 0);
-    G.tile_lib_hi.assign(n_tiles, 0);
-    G.hdr.assign(n_tiles * kWave, LaneHdr{});
-    G.lane_src.assign(n_tiles * kWave, 0);
-    G.lane_nrec.assign(n_tiles * kWave, 0);
-    // stable counting sort by first library: a workgroup's library window (LDS) then covers one
-    // sample, and the length sort below runs over a whole chunk of that sample's units
+    // stable counting sort by first library
     std::vector<uint32_t> by_lib;
+    uint64_t bucket_end[256];
+    int n_buckets = 1;
+    bucket_end[0] = n;
     if (in->n_libs > 1) {
         uint64_t start[257] = {0};
         for (uint64_t u = 0; u < n; ++u) ++start[(scan[u].libs & 0xffu) + 1];
         for (int l = 0; l < 256; ++l) start[l + 1] += start[l];
+        for (int l = 0; l < 256; ++l) bucket_end[l] = start[l + 1];
+        n_buckets = 256;
         by_lib.resize(n);
         for (uint64_t u = 0; u < n; ++u) by_lib[start[scan[u].libs & 0xffu]++] = (uint32_t)u;
     }
     auto unit_at = [&](uint64_t i) -> uint64_t { return by_lib.empty() ? i : by_lib[i]; };
-    parallel_for(n_chunks, [&](uint64_t c) {
-        const uint64_t c0 = c * kChunkUnits;
-        const uint32_t cn = (uint32_t)std::min<uint64_t>(kChunkUnits, n - c0);
+    struct Chunk { uint64_t begin; uint32_t len; uint64_t tile_base; };
+    std::vector<Chunk> chunks;
+    uint64_t n_tiles = 0;
+    for (int bkt = 0; bkt < n_buckets; ++bkt) {
+        const uint64_t lo = bkt ? bucket_end[bkt - 1] : 0, hi = bucket_end[bkt];
+        for (uint64_t c0 = lo; c0 < hi; c0 += kChunkUnits) {
+            const uint32_t len = (uint32_t)std::min<uint64_t>(kChunkUnits, hi - c0);
+            chunks.push_back(Chunk{c0, len, n_tiles});
+            const uint64_t t = (len + kWave - 1) / kWave;
+            n_tiles += (t + kWavesPerBlock - 1) / kWavesPerBlock * kWavesPerBlock;   // whole workgroups
+        }
+    }
+    // the last chunk of the batch needs no padding tiles (the dispatch list pads the last group itself)
+    if (!chunks.empty()) n_tiles = chunks.back().tile_base + (chunks.back().len + kWave - 1) / kWave;
+    G.tiles.assign(n_tiles, TileDesc{});
+    G.tile_lib_lo.assign(n_tiles, 0xffffffffu);   // 0xffffffff: the tile references no library
+    G.tile_lib_hi.assign(n_tiles, 0);
+    G.hdr.assign(n_tiles * kWave, LaneHdr{0, 0, kPadUnit, 0});
+    G.lane_src.assign(n_tiles * kWave, 0);
+    G.lane_nrec.assign(n_tiles * kWave, 0);
+    for (uint64_t ti = 0; ti < n_tiles; ++ti) G.tiles[ti].lane_base = (uint32_t)(ti * kWave);   // padding tiles too
+    parallel_for(chunks.size(), [&](uint64_t c) {
+        const uint64_t c0 = chunks[c].begin;
+        const uint32_t cn = chunks[c].len;
         std::vector<uint32_t> order(cn);
         for (uint32_t i = 0; i < cn; ++i) order[i] = i;
-        // by first library, then longest first
+        // longest first
         std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
             const uint64_t ux = unit_at(c0 + x), uy = unit_at(c0 + y);
-            const uint32_t lx = scan[ux].libs & 0xffu, ly = scan[uy].libs & 0xffu;
-            if (lx != ly) return lx < ly;
             const uint64_t kx = ((uint64_t)stream_rows_of(scan[ux], nrec[ux], compact, 0) << 32) |
                                 stream_rows_of(scan[ux], nrec[ux], compact, 1);
             const uint64_t ky = ((uint64_t)stream_rows_of(scan[uy], nrec[uy], compact, 0) << 32) |
@@ -94,7 +108,7 @@ inline void build_tiling(const svt_evidence_batch* in, const std::vector<uint32_
             return kx > ky;
         });
         for (uint32_t t0 = 0; t0 < cn; t0 += kWave) {
-            const uint64_t ti = c * tiles_per_chunk + t0 / kWave;
+            const uint64_t ti = chunks[c].tile_base + t0 / kWave;
             TileDesc td{};
             td.lane_base = (uint32_t)(ti * kWave);
             uint32_t lib_lo = 0xffffffffu, lib_hi = 0;
@@ -124,8 +138,8 @@ inline void build_tiling(const svt_evidence_batch* in, const std::vector<uint32_
                 G.lane_nrec[td.lane_base + l] = f;
             }
             G.tiles[ti] = td;
-            G.tile_lib_lo[ti] = lib_lo == 0xffffffffu ? 0u : lib_lo;
-            G.tile_lib_hi[ti] = lib_lo == 0xffffffffu ? 0u : lib_hi;
+            G.tile_lib_lo[ti] = lib_lo;
+            G.tile_lib_hi[ti] = lib_hi;
         }
     });
     // slot offsets: the streams of a tile follow each other

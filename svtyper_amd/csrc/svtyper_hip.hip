@@ -348,14 +348,17 @@ int create_on_device(const svt_evidence_batch* in, svt_batch* b, const uint4* d_
                 const uint32_t t = g * kWavesPerBlock + k;
                 if (t < b->n_tiles) {
                     dispatch.push_back(G.tiles[t]);
-                    lo = std::min(lo, G.tile_lib_lo[t]);
-                    hi = std::max(hi, G.tile_lib_hi[t]);
+                    if (G.tile_lib_lo[t] != 0xffffffffu) {   // the tile references a library at all
+                        lo = std::min(lo, G.tile_lib_lo[t]);
+                        hi = std::max(hi, G.tile_lib_hi[t]);
+                    }
                 } else {
                     TileDesc pad{};
                     pad.lane_base = kPadUnit;          // marks a tile that does not exist
                     dispatch.push_back(pad);
                 }
             }
+            if (lo == 0xffffffffu) lo = hi = 0;        // a group of empty units: any window will do
             WgDesc w{};
             w.lib_lo = lo;
             w.lib_cnt = hi - lo + 1;
