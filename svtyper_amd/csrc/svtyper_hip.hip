@@ -741,16 +741,19 @@ int svt_bayes_gt(const int32_t* ref, const int32_t* alt, const uint8_t* is_dup, 
     SVT_TRY(d_dup.alloc(n));
     SVT_TRY(d_l10.alloc(l10.size() * sizeof(double)));
     SVT_TRY(d_out.alloc(n * 4 * sizeof(double)));
-    HIP_TRY(hipMemcpy(d_ref.p, ref, n * sizeof(int32_t), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(d_alt.p, alt, n * sizeof(int32_t), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(d_dup.p, is_dup, n, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(d_l10.p, l10.data(), l10.size() * sizeof(double), hipMemcpyHostToDevice));
+    {
+        Stager st(nullptr);
+        SVT_TRY(st.copy(d_ref.p, ref, n * sizeof(int32_t)));
+        SVT_TRY(st.copy(d_alt.p, alt, n * sizeof(int32_t)));
+        SVT_TRY(st.copy(d_dup.p, is_dup, n));
+        SVT_TRY(st.copy(d_l10.p, l10.data(), l10.size() * sizeof(double)));
+        SVT_TRY(st.finish());
+    }
     hipLaunchKernelGGL(svt_bayes_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, 0,
                        d_ref.as<int32_t>(), d_alt.as<int32_t>(), d_dup.as<uint8_t>(), n, d_l10.as<double>(), c,
                        d_out.as<double>());
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpy(out, d_out.p, n * 4 * sizeof(double), hipMemcpyDeviceToHost));
-    return SVT_OK;
+    return d2h_staged(out, d_out.p, n * 4 * sizeof(double), nullptr);
 }
 
 void* svt_batch_stream(svt_batch* b) { return b ? (void*)b->stream : nullptr; }
