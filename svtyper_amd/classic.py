@@ -224,6 +224,12 @@ def get_args():
                    help="write relevant reads to BAM file")
     p.add_argument("--debug", action="store_true", help=argparse.SUPPRESS)
     p.add_argument("--verbose", action="store_true", default=False, help="Report status updates")
+    # not in the reference: where the host work runs (same output bytes either way)
+    p.add_argument("--reader", choices=("python", "native"), default="python",
+                   help="BAM access + fragment assembly: portable Python reader, or the C++ threads of "
+                        "libsvtyper_hip.so feeding the device geometry stage [python]")
+    p.add_argument("--geometry", choices=("host", "device"), default="host",
+                   help="with --reader python: breakpoint-dependent read predicates on the host or on the GPU [host]")
     args = p.parse_args()
     if args.input_vcf is None and not sys.stdin.isatty():
         args.input_vcf = sys.stdin
@@ -237,7 +243,7 @@ def main():
         sys.stderr.write("Warning: --split_bam (-S) is deprecated. Ignoring %s.\n" % args.split_bam)
     sv_genotype(args.bam, args.input_vcf, args.output_vcf, args.min_aligned, args.split_weight, args.disc_weight,
                 args.num_samp, args.lib_info_path, args.debug, args.alignment_outpath, args.ref_fasta,
-                args.sum_quals, args.max_reads, args.max_ci_dist)
+                args.sum_quals, args.max_reads, args.max_ci_dist, geometry=args.geometry, reader=args.reader)
 
 
 def cli():
