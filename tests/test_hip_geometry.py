@@ -120,3 +120,20 @@ def test_native_reader_two_bams_sum_quals(tmp_path, hip_device):
     want = gzip.open(os.path.join(HERE, "golden", "example.twice.sumquals.gt.vcf.gz"), "rt").read().split("\n")
     got = [l for l in open(out).read().split("\n") if not l.startswith("##fileDate=")]
     assert got == want
+
+
+@pytest.mark.parametrize("module,extra", [("svtyper_amd.classic", []),
+                                          ("svtyper_amd.singlesample", ["--max_reads", "1000"]),
+                                          ("svtyper_amd.singlesample", ["--max_reads", "1000", "--reader", "native"]),
+                                          ("svtyper_amd.classic", ["--reader", "python", "--geometry", "device"])])
+def test_command_line(tmp_path, hip_device, module, extra):
+    """the two console entry points, as a user runs them (svtyper / svtyper-sso argument surface)"""
+    import subprocess
+    import sys
+    import test_host_pipeline as T
+    out = str(tmp_path / "cli.vcf")
+    cmd = [sys.executable, "-m", module, "-B", T.IN_BAM, "-i", T.IN_VCF, "-l", T.LIB_JSON, "-o", out] + extra
+    r = subprocess.run(cmd, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    T.same_vcf(T.EXPECTED, out)
