@@ -87,7 +87,6 @@ struct DevicePool {
                 for (size_t i = 1; i < items.size(); ++i)
                     if (items[i].cap < items[smallest].cap) smallest = i;
                 drop = items[smallest].p;
-                if (items[smallest].device != device) (void)hipSetDevice(items[smallest].device);
                 items.erase(items.begin() + (long)smallest);
             }
         }
