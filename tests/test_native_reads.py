@@ -78,3 +78,98 @@ def test_summaries_equal_python(setup, mode, max_reads, threads):
     if max_reads is not None and max_reads < 1000:
         assert want[2].any() and not want[2].all()   # the threshold really splits the sites
     assert len(want[1]) > 5000 or want[2].any()
+
+
+# ------------------------------------------------------------------------------------------
+# a synthetic BAM with the record shapes the fixture does not have: records spanning BGZF blocks,
+# hard clips, insertions, deletions, N gaps, several SA entries, secondary / supplementary /
+# duplicate / unmapped flags, MAPQ 255, B-typed tags in front of the ones that matter
+# ------------------------------------------------------------------------------------------
+def _synthetic_bam(path, seed=11, n_pairs=700):
+    import bamwriter as bw
+    rng = np.random.default_rng(seed)
+    refs = [("1", 200_000), ("2", 100_000)]
+    header = ("@HD\\tVN:1.5\\tSO:coordinate\\n@SQ\\tSN:1\\tLN:200000\\n@SQ\\tSN:2\\tLN:100000\\n"
+              "@RG\\tID:rgA\\tSM:syn\\tLB:libA\\n@RG\\tID:rgB\\tSM:syn\\tLB:libB\\n@CO\\tsynthetic\\n").replace("\\t", "\t").replace("\\n", "\n")
+    sites = [
+        {"id": "d1", "svtype": "DEL", "var_length": 800, "A": {"chrom": "1", "pos": 50_000, "ci": [-5, 5], "is_reverse": False},
+         "B": {"chrom": "1", "pos": 50_800, "ci": [-5, 5], "is_reverse": True}},
+        {"id": "u1", "svtype": "DUP", "A": {"chrom": "1", "pos": 90_000, "ci": [0, 0], "is_reverse": True},
+         "B": {"chrom": "1", "pos": 91_500, "ci": [0, 0], "is_reverse": False}},
+        {"id": "i1", "svtype": "INV", "A": {"chrom": "1", "pos": 120_000, "ci": [-10, 10], "is_reverse": False},
+         "B": {"chrom": "1", "pos": 123_000, "ci": [-10, 10], "is_reverse": False}},
+        {"id": "b1", "svtype": "BND", "A": {"chrom": "1", "pos": 150_000, "ci": [-2, 2], "is_reverse": False},
+         "B": {"chrom": "2", "pos": 40_000, "ci": [-2, 2], "is_reverse": True}},
+    ]
+    for bp in sites:   # the drivers move reverse-strand breakends by one (vcf.get_variant_breakpoints)
+        for side in ("A", "B"):
+            if bp[side]["is_reverse"]:
+                bp[side]["pos"] += 1
+    cigars = ["100M", "100M", "100M", "60M40S", "40S60M", "30M2D70M", "50M10I40M", "20H80M", "80M20H", "35M1000N65M",
+              "25S50M25S", "10S90M", "70M30S", "45M3D20M5I30M", "15H15S70M"]
+    tid_of = {"1": 0, "2": 1}
+    recs = []
+    for k in range(n_pairs):
+        bp = sites[k % len(sites)]
+        side = ("A", "B")[int(rng.integers(2))]
+        tid = tid_of[bp[side]["chrom"]]
+        pos1 = int(bp[side]["pos"] + rng.integers(-450, 150))
+        other = "B" if side == "A" else "A"
+        far = rng.random() < 0.45                      # mate near the other breakend (discordant) or nearby
+        mtid = tid_of[bp[other]["chrom"]] if far else tid
+        pos2 = int(bp[other]["pos"] + rng.integers(-150, 450)) if far else pos1 + int(rng.integers(150, 520))
+        rev1, rev2 = bool(rng.integers(2)), bool(rng.integers(2))
+        mq = [0, 1, 20, 37, 60, 60, 60, 255]
+        rg = ("rgA", "rgB")[int(rng.integers(2))]
+        name = "q%05d" % int(rng.integers(0, 10 ** 5)) + ("" if rng.random() < 0.9 else "x")
+        extra = 0x400 if rng.random() < 0.03 else 0
+        for mate, (t, p, r, mt, mp, mr) in enumerate(((tid, pos1, rev1, mtid, pos2, rev2), (mtid, pos2, rev2, tid, pos1, rev1))):
+            cigar = cigars[int(rng.integers(len(cigars)))]
+            flag = 0x1 | (0x40 if mate == 0 else 0x80) | (0x10 if r else 0) | (0x20 if mr else 0) | extra
+            if rng.random() < 0.02:
+                flag |= 0x4                             # unmapped but placed
+            if rng.random() < 0.02:
+                flag |= 0x8
+            tags = [("XB", "B", ("s", [1, -2, 3])), ("NM", "C", int(rng.integers(5))), ("RG", "Z", rg)]
+            clipped = cigar[-1] in "SH" or cigar.split("M")[0][-1:] in "SH" or "S" in cigar or "H" in cigar
+            if clipped and rng.random() < 0.7:          # split alignment near the other breakend
+                sa_pos = int(bp[other]["pos"] + rng.integers(-60, 10))
+                sa_cig = ["40S60M", "60M40S", "60H40M", "30M70S", "20S60M20S"][int(rng.integers(5))]
+                sa = "%s,%d,%s,%s,%d,%d;" % (bp[other]["chrom"], sa_pos + 1, "+-"[int(rng.integers(2))], sa_cig,
+                                              mq[int(rng.integers(len(mq)))] % 256, int(rng.integers(4)))
+                if rng.random() < 0.2:
+                    sa += "2,777,+,50M50S,10,1;"
+                tags.append(("SA", "Z", sa))
+            recs.append(dict(name=name, flag=flag, tid=t, pos=max(0, p), mapq=mq[int(rng.integers(len(mq)))], cigar=cigar,
+                             mtid=mt, mpos=max(0, mp), tlen=(mp - p) if t == mt else 0, tags=tags))
+            if rng.random() < 0.06:                    # an extra secondary / supplementary record of the same read
+                recs.append(dict(recs[-1], flag=flag | (0x100 if rng.random() < 0.5 else 0x800),
+                                 pos=max(0, p + int(rng.integers(-30, 30))), cigar=cigars[int(rng.integers(len(cigars)))]))
+    recs.sort(key=lambda r: (r["tid"], r["pos"]))
+    bw.write_bam(path, header, refs, recs, block_bytes=int(rng.integers(700, 5000)))
+    hist = {str(k): int(1000 * np.exp(-((k - 330) / 70.0) ** 2)) + 1 for k in range(100, 600)}
+    lib = lambda nm, rgs: {"library_name": nm, "readgroups": rgs, "read_length": 100, "histogram": hist, "mean": 330.0,
+                           "sd": 50.0, "prevalence": 0.5}
+    info = {"syn": {"mapped": len(recs), "unmapped": 0, "bam": path, "sample_name": "syn",
+                    "libraryArray": [lib("libA", ["rgA"]), lib("libB", ["rgB"])]}}
+    return [{"breakpoint": bp} for bp in sites], info
+
+
+@pytest.mark.parametrize("seed,mode,max_reads", [(11, nr.COUNT_CLASSIC, None), (12, nr.COUNT_SSO, 1000),
+                                                 (13, nr.COUNT_CLASSIC, 90), (14, nr.COUNT_SSO, 200),
+                                                 (15, nr.COUNT_CLASSIC, 345), (16, nr.COUNT_SSO, 352)])
+def test_synthetic_bam_native_equals_python(tmp_path, seed, mode, max_reads):
+    path = str(tmp_path / "syn.bam")
+    sites, info = _synthetic_bam(path, seed)
+    pybam = bam.AlignmentFile(path)
+    sample = library.Sample.from_lib_info(pybam, info, 1e-3)
+    nbam = nr.NativeBam(path)
+    assert nbam.references == pybam.references and nbam.header["RG"] == pybam.header["RG"]
+    want = _python_summaries(sites, sample, mode, max_reads)
+    got = _native_summaries(sites, sample, nbam, mode, max_reads, 2)
+    assert np.array_equal(got[2], want[2]), "skip flags differ"
+    assert np.array_equal(got[0], want[0]), "fragment counts differ: %s vs %s" % (got[0], want[0])
+    assert got[1].tobytes() == want[1].tobytes()
+    assert len(want[1]) > 100 or want[2].any()
+    # the synthetic reads really exercise the split-read path
+    assert (want[1]["seq"]["flags"] & 1).any() or (want[1]["clip"]["flags"] & 1).any() or want[2].all()
