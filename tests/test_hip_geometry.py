@@ -137,3 +137,53 @@ def test_command_line(tmp_path, hip_device, module, extra):
                        text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     T.same_vcf(T.EXPECTED, out)
+
+
+def _synthetic_case(tmp_path):
+    """BAM from tests/test_native_reads.py::_synthetic_bam + a VCF with its four sites (DEL, DUP, INV, BND pair)"""
+    import json
+    import test_host_pipeline as T
+    import test_native_reads as N
+    bam_path = str(tmp_path / "syn.bam")
+    _, info = N._synthetic_bam(bam_path, seed=21, n_pairs=900)
+    lib_json = str(tmp_path / "syn.json")
+    with open(lib_json, "w") as f:
+        json.dump(info, f)
+    header = [l for l in open(T.IN_VCF) if l.startswith("##")]
+    cols = "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\n"
+    body = [
+        "1\t50000\td1\tN\t<DEL>\t0\t.\tSVTYPE=DEL;SVLEN=-800;END=50800;STR=+-:10;CIPOS=-5,5;CIEND=-5,5\n",
+        "1\t90000\tu1\tN\t<DUP>\t0\t.\tSVTYPE=DUP;SVLEN=1500;END=91500;STR=-+:10;CIPOS=0,0;CIEND=0,0\n",
+        "1\t120000\ti1\tN\t<INV>\t0\t.\tSVTYPE=INV;SVLEN=3000;END=123000;STR=++:5,--:5;CIPOS=-10,10;CIEND=-10,10\n",
+        "1\t150000\tb1_1\tN\tN]2:40000]\t0\t.\tSVTYPE=BND;STR=++:7;CIPOS=-2,2;CIEND=-2,2;MATEID=b1_2;EVENT=b1\n",
+        "2\t40000\tb1_2\tN\tN]1:150000]\t0\t.\tSVTYPE=BND;STR=++:7;CIPOS=-2,2;CIEND=-2,2;MATEID=b1_1;EVENT=b1;SECONDARY\n",
+    ]
+    vcf_path = str(tmp_path / "syn.vcf")
+    with open(vcf_path, "w") as f:
+        f.write("".join(header) + cols + "".join(body))
+    return bam_path, vcf_path, lib_json
+
+
+@pytest.mark.parametrize("driver", ["classic", "sso"])
+def test_synthetic_bam_all_paths_agree(tmp_path, hip_device, driver):
+    """Unusual records (hard clips, N gaps, several SA entries, flags) through every host configuration:
+    the CPU oracle engine behind the Python reader is the expectation; the HIP paths (host geometry, device
+    geometry, native reader) must write the same bytes."""
+    import test_host_pipeline as T
+    bam_path, vcf_path, lib_json = _synthetic_case(tmp_path)
+
+    def run(out, **kw):
+        with open(vcf_path) as inf, open(out, "w") as outf:
+            if driver == "classic":
+                T.classic.sv_genotype(bam_path, inf, outf, 20, 1, 1, 1000000, lib_json, False, None, None, False, None,
+                                      1e10, **kw)
+            else:
+                T.singlesample.sso_genotype(bam_path, inf, outf, 20, 1, 1, 1000000, lib_json, False, None, False, 1000,
+                                            1e10, None, 1000, **kw)
+        return open(out).read()
+
+    want = run(str(tmp_path / "oracle.vcf"), engine=T.oracle_engine)
+    assert want.count("\n") > 40 and "\t0/1:" in want or "\t1/1:" in want or "\t0/0:" in want
+    for name, kw in (("host", {}), ("device", dict(geometry="device")), ("native", dict(geometry="device", reader="native"))):
+        got = run(str(tmp_path / (name + ".vcf")), **kw)
+        assert got == want, "%s path differs from the oracle-engine output" % name
