@@ -7,14 +7,14 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 B="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-dense-leg"
 timeout 240 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS -d $OUT/p1 -o pmc -- $B > /dev/null 2> $OUT/p1.err
-timeout 240 rocprofv3 --pmc TCP_TCC_READ_REQ_LATENCY_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_HIT_sum TCP_UTCL1_REQUEST_sum -d $OUT/p2 -o pmc -- $B > /dev/null 2> $OUT/p2.err
+# (a pass with the TCP_* latency / UTCL1 counters hung rocprofv3 on this pool until the outer timeout -- left out)
 timeout 240 rocprofv3 --pmc MeanOccupancyPerCU OccupancyPercent MemUnitStalled LDSBankConflict -d $OUT/p3 -o pmc -- $B > /dev/null 2> $OUT/p3.err
 timeout 240 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_IFETCH -d $OUT/p4 -o pmc -- $B > /dev/null 2> $OUT/p4.err
 timeout 240 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_TAG_STALL_sum TCC_BUSY_sum GRBM_GUI_ACTIVE -d $OUT/p5 -o pmc -- $B > /dev/null 2> $OUT/p5.err
 python - "$OUT" <<'PY'
 import glob, os, sqlite3, sys
 out = sys.argv[1]
-for sub in ("p1", "p2", "p3", "p4", "p5"):
+for sub in ("p1", "p3", "p4", "p5"):
     for f in sorted(glob.glob(os.path.join(out, sub, "**", "*.db"), recursive=True)):
         c = sqlite3.connect(f)
         q = ("select kernel_name, counter_name, avg(value), count(*) from counters_collection "
