@@ -34,8 +34,8 @@ class SvtyperHipError(RuntimeError):
 def build(force: bool = False) -> str:
     """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
     import glob
-    srcs = glob.glob(os.path.join(_HERE, "csrc", "*.hip")) + glob.glob(os.path.join(_HERE, "csrc", "*.h"))
-    srcs.append(os.path.join(_HERE, "..", "include", "svtyper_hip.h"))
+    srcs = [f for pat in ("*.hip", "*.cpp", "*.h") for f in glob.glob(os.path.join(_HERE, "csrc", pat))]
+    srcs += glob.glob(os.path.join(_HERE, "..", "include", "*.h"))
     stale = not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(s) for s in srcs)
     if force or stale:
         subprocess.check_call(["make", "-C", os.path.join(_HERE, "csrc"), "-B", "libsvtyper_hip.so"])

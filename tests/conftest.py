@@ -12,6 +12,14 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """Whatever test runs first finds the in-tree library: compile it if it has never been built
+    (hipcc cross-compiles gfx950 without a GPU; on the GPU box the prebuilt .so travels with the tree)."""
+    from svtyper_amd import hip
+    if not os.path.exists(hip.LIB_PATH):
+        hip.build()
+
+
 @pytest.fixture(scope="session")
 def fixture_library():
     """The reference fixture's single library (tests/data/NA12878.bam.json)."""
