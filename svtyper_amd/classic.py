@@ -21,8 +21,8 @@ from . import __version__
 from . import evidence as ev
 from .bam import open_alignment_file
 from .library import Sample, setup_sample, write_sample_json
-from .pipeline import (MIN_LIB_PREVALENCE, NativeUnitCollector, UnitCollector, add_read_to, default_engine,
-                       fetch_window)
+from .pipeline import (MIN_LIB_PREVALENCE, ChunkPipeline, NativeUnitCollector, UnitCollector, add_read_to,
+                       default_engine, fetch_window)
 from .results import results_to_dicts
 from .vcf import VALID_SVTYPES, Variant, Vcf
 
@@ -105,11 +105,17 @@ def sv_genotype(bam_string, vcf_in, vcf_out, min_aligned, split_weight, disc_wei
     header_lines: list = []
     in_header = True
 
+    pipe = ChunkPipeline()
+
     def flush():
-        results = collector.run(engine, 0)
+        actions = list(pending)
+        pending.clear()
+        pipe.submit(collector.take(engine, 0), lambda results: write_out(results, actions))
+
+    def write_out(results, actions):
         dicts = results_to_dicts(results)
         gts = results.gt.tolist()
-        for action in pending:
+        for action in actions:
             if action[0] == "raw":
                 vcf_out.write(action[1].get_var_string() + "\n")
                 continue
@@ -122,7 +128,6 @@ def sv_genotype(bam_string, vcf_in, vcf_out, min_aligned, split_weight, disc_wei
             if var2 is not None:                   # BND: second mate carries the same genotypes
                 var.share_genotypes_with(var2)
                 vcf_out.write(var2.get_var_string() + "\n")
-        pending.clear()
 
     for line in vcf_in:
         if in_header:
@@ -171,6 +176,7 @@ def sv_genotype(bam_string, vcf_in, vcf_out, min_aligned, split_weight, disc_wei
     if in_header and header_lines:   # header-only VCF: the reference writes nothing
         pass
     flush()
+    pipe.close()
     if vcf._bnd_pending:
         logging.warning("Unpaired breakends found in file. These will not be present in output.")
     vcf_in.close()

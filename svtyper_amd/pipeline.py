@@ -104,18 +104,25 @@ class UnitCollector:
     def __len__(self):
         return len(self.builder)
 
+    def take(self, engine: Engine, flags: int):
+        """Detach the units collected so far as a job (a callable returning their Results); the collector is
+        empty again and can be filled while the job runs on another thread (ChunkPipeline)."""
+        builder, self.builder = self.builder, self._new_builder()
+        geometry = self.geometry
+
+        def job() -> Results:
+            batch = builder.build()
+            if batch.n_units == 0:
+                return Results.empty(0)
+            if geometry == "device":
+                if not hasattr(engine, "genotype_fragments"):
+                    raise TypeError("geometry='device' needs an engine with genotype_fragments (the HIP engine)")
+                return engine.genotype_fragments(batch, flags)
+            return engine(batch, flags)
+        return job
+
     def run(self, engine: Engine, flags: int) -> Results:
-        batch = self.builder.build()
-        if batch.n_units == 0:
-            return Results.empty(0)
-        if self.geometry == "device":
-            if not hasattr(engine, "genotype_fragments"):
-                raise TypeError("geometry='device' needs an engine with genotype_fragments (the HIP engine)")
-            res = engine.genotype_fragments(batch, flags)
-        else:
-            res = engine(batch, flags)
-        self.builder = self._new_builder()
-        return res
+        return self.take(engine, flags)()
 
 
 class NativeUnitCollector:
@@ -154,31 +161,38 @@ class NativeUnitCollector:
     def __len__(self):
         return len(self.sites) * len(self.samples)
 
+    def take(self, engine: Engine, flags: int):
+        """Detach the sites recorded so far as a job (see UnitCollector.take)."""
+        sites, self.sites = self.sites, []
+        return lambda: self._run_sites(sites, engine, flags)
+
     def run(self, engine: Engine, flags: int) -> Results:
+        return self.take(engine, flags)()
+
+    def _run_sites(self, sites: List[dict], engine: Engine, flags: int) -> Results:
         import numpy as np
         from .geometry import FragmentBatch, breakpoint_record
         from .native_reads import COUNT_SSO, FETCH_DTYPE
         n_samp = len(self.samples)
-        n_sites = len(self.sites)
+        n_sites = len(sites)
         if n_sites == 0:
             return Results.empty(0)
         if not hasattr(engine, "genotype_fragments"):
             raise TypeError("reader='native' needs an engine with genotype_fragments (the HIP engine)")
         per_sample = []
-        n_sites = len(self.sites)
-        A = [bp["A"] for bp in self.sites]
-        B = [bp["B"] for bp in self.sites]
+        A = [bp["A"] for bp in sites]
+        B = [bp["B"] for bp in sites]
         pos = np.array([[a["pos"], b["pos"]] for a, b in zip(A, B)], dtype=np.int64)
         ci = np.array([[a["ci"][0], a["ci"][1], b["ci"][0], b["ci"][1]] for a, b in zip(A, B)], dtype=np.int64)
         rev = np.array([(1 if a["is_reverse"] else 0) | (2 if b["is_reverse"] else 0) for a, b in zip(A, B)], np.uint8)
-        svt = np.array([ev.SVTYPE_CODE[bp["svtype"]] for bp in self.sites], np.uint8)
-        vlen = np.array([bp.get("var_length", 0) if bp["svtype"] == "DEL" else 0 for bp in self.sites], np.int64)
+        svt = np.array([ev.SVTYPE_CODE[bp["svtype"]] for bp in sites], np.uint8)
+        vlen = np.array([bp.get("var_length", 0) if bp["svtype"] == "DEL" else 0 for bp in sites], np.int64)
         clip = lambda x: np.clip(x, -2**31, 2**31 - 1)
         for k, (sample, nbam) in enumerate(zip(self.samples, self.bams)):
             tid_of = nbam.gettid
             tid = np.array([[tid_of(a["chrom"]), tid_of(b["chrom"])] for a, b in zip(A, B)], dtype=np.int64)
             if (tid < 0).any():
-                bad = self.sites[int(np.nonzero((tid < 0).any(axis=1))[0][0])]
+                bad = sites[int(np.nonzero((tid < 0).any(axis=1))[0][0])]
                 raise KeyError("chromosome of variant %s is not in %s" % (bad.get("id"), nbam.filename))
             from .geometry import BREAKPOINT_DTYPE
             bps = np.zeros(n_sites, BREAKPOINT_DTYPE)
@@ -214,8 +228,39 @@ class NativeUnitCollector:
             frags = np.concatenate(parts) if parts else per_sample[0][2][:0]
         fb = FragmentBatch(off, bps, frags, self.lib_tables, self.split_weight, self.disc_weight, self.min_aligned,
                            SPLIT_SLOP)
-        self.sites = []
         return engine.genotype_fragments(fb, flags)
+
+
+class ChunkPipeline:
+    """Chunk-level double buffering of the drivers (svtyper/singlesample.py:710-762 re-cast): the job of
+    chunk k -- C++ fetch/summarise or packing, H2D, kernels, D2H, all outside the GIL -- runs on a worker
+    thread while the host parses the VCF lines of chunk k+1; `on_done(results)` is called on the caller's
+    thread, in submission order (chunk k-1's when chunk k is submitted, the last one at close())."""
+
+    def __init__(self, overlap: bool = True):
+        from concurrent.futures import ThreadPoolExecutor
+        self._pool = ThreadPoolExecutor(1) if overlap else None
+        self._prev = None
+
+    def submit(self, job, on_done) -> None:
+        if self._pool is None:
+            on_done(job())
+            return
+        fut = self._pool.submit(job)
+        self._drain()
+        self._prev = (fut, on_done)
+
+    def _drain(self) -> None:
+        if self._prev is not None:
+            (fut, on_done), self._prev = self._prev, None
+            on_done(fut.result())
+
+    def close(self) -> None:
+        try:
+            self._drain()
+        finally:
+            if self._pool is not None:
+                self._pool.shutdown(wait=True)
 
 
 def add_read_to(fragments: Dict[str, SamFragment], read, lib):

@@ -20,8 +20,8 @@ from . import __version__
 from . import evidence as ev
 from .bam import open_alignment_file
 from .library import Sample, setup_sample, write_sample_json
-from .pipeline import (MIN_LIB_PREVALENCE, NativeUnitCollector, UnitCollector, add_read_to, default_engine,
-                       fetch_window)
+from .pipeline import (MIN_LIB_PREVALENCE, ChunkPipeline, NativeUnitCollector, UnitCollector, add_read_to,
+                       default_engine, fetch_window)
 from .results import results_to_dicts
 from .vcf import Variant, Vcf
 
@@ -121,11 +121,16 @@ def sso_genotype(bam_string, vcf_in, vcf_out, min_aligned, split_weight, disc_we
     else:
         raise ValueError("reader must be 'python' or 'native'")
     pending: list = []
+    pipe = ChunkPipeline()
 
     def flush():
-        results = collector.run(engine, ev.FLAG_SSO_ASSOCIATION)
+        actions = list(pending)
+        pending.clear()
+        pipe.submit(collector.take(engine, ev.FLAG_SSO_ASSOCIATION), lambda results: write_out(results, actions))
+
+    def write_out(results, actions):
         dicts = results_to_dicts(results)   # blank for "no evidence" and "too many reads" alike
-        for action in pending:
+        for action in actions:
             if action[0] == "raw":
                 action[1].write(vcf_out)
                 continue
@@ -135,7 +140,6 @@ def sso_genotype(bam_string, vcf_in, vcf_out, min_aligned, split_weight, disc_we
             if variant2 is not None:
                 variant.share_genotypes_with(variant2)
                 variant2.write(vcf_out)
-        pending.clear()
 
     for line in lines:
         if line.startswith("#"):
@@ -167,6 +171,7 @@ def sso_genotype(bam_string, vcf_in, vcf_out, min_aligned, split_weight, disc_we
         if len(collector) >= CHUNK_UNITS:
             flush()
     flush()
+    pipe.close()
     sample.close()
 
 

@@ -63,6 +63,42 @@ def test_sso_integration_oracle_engine(tmp_path, cores):
     same_vcf(EXPECTED, out)
 
 
+@pytest.mark.parametrize("driver", ["classic", "sso"])
+def test_small_chunks_through_the_chunk_pipeline(tmp_path, monkeypatch, driver):
+    """Many device batches per run: chunk k is genotyped on the worker thread while chunk k+1 is parsed,
+    the output order and bytes stay those of the single-batch run (BND mates straddle chunk borders)."""
+    calls = []
+
+    def counting_engine(batch, flags=0):
+        calls.append(batch.n_units)
+        return oracle_engine(batch, flags)
+
+    out = str(tmp_path / "out.vcf")
+    if driver == "classic":
+        monkeypatch.setattr(classic, "CHUNK_UNITS", 17)
+        run_classic(out, counting_engine)
+    else:
+        monkeypatch.setattr(singlesample, "CHUNK_UNITS", 17)
+        run_sso(out, counting_engine, None)
+    same_vcf(EXPECTED, out)
+    assert len(calls) >= 12 and max(calls) <= 17
+
+
+def test_chunk_pipeline_orders_results_and_surfaces_errors():
+    from svtyper_amd.pipeline import ChunkPipeline
+    import time
+    seen = []
+    pipe = ChunkPipeline()
+    for k in range(5):
+        pipe.submit(lambda k=k: (time.sleep(0.02 * (5 - k)), k)[1], seen.append)
+    pipe.close()
+    assert seen == [0, 1, 2, 3, 4]
+    pipe = ChunkPipeline()
+    pipe.submit(lambda: 1 / 0, seen.append)
+    with pytest.raises(ZeroDivisionError):
+        pipe.close()
+
+
 def test_default_engine_fails_loudly_without_gpu(tmp_path):
     from svtyper_amd import hip
     hip.load()
