@@ -274,6 +274,9 @@ def main():
         }
         if gather:
             out["gather"] = gather
+        if args.workload == "c5_multisample":   # one breakpoint = one VCF site; a unit = (site, sample)
+            out["sites_per_s"] = value / 32.0
+            out["units_per_s"] = value
         if world == 1 and compact and not args.no_dense_leg:
             # the same pass over the canonical 16-byte records (SVT_FLAG_DENSE_LAYOUT), for reference
             try:
@@ -313,10 +316,17 @@ def main():
                 if time.perf_counter() - t0 >= args.cpu_seconds or reps >= 50:
                     break
             cpu_s = time.perf_counter() - t0
+            n1 = min(sample_n, 200_000)               # the same restatement on one thread, bounded slice
+            one = batch.slice(0, n1)
+            c_oracle.genotype_batch(one, flags=flags & ev.FLAG_SSO_ASSOCIATION, n_threads=1)
+            t0 = time.perf_counter()
+            c_oracle.genotype_batch(one, flags=flags & ev.FLAG_SSO_ASSOCIATION, n_threads=1)
+            one_thread = n1 / (time.perf_counter() - t0)
             out["cpu_baseline"] = {
                 "value": sample_n * reps / cpu_s,
                 "unit": "breakpoints/s",
                 "cores": threads,
+                "one_thread": one_thread,
                 "kind": "port",
                 "sample": "the workload's %d units x %d repetitions, oracle/svt_oracle.c "
                           "(OpenMP, %d threads = the host CPUs this process may use: %d visible, cgroup quota %d)"
