@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SVT_ABI_VERSION 4
+#define SVT_ABI_VERSION 5
 
 /* ---- error codes (0 = ok, <0 = error; text via svt_last_error()) ---------- */
 #define SVT_OK 0
@@ -331,6 +331,15 @@ void svt_trim(void);
  * (frag_offset[n_units] entries) are also copied back to it (used by the parity tests).        */
 int svt_batch_create_from_fragments(const svt_fragment_batch* in, int device, unsigned flags,
                                     svt_record* records_out, svt_batch** out);
+
+/* QUAL of every site of a multi-sample batch (svtyper/classic.py:216-217,485,498): the running
+ * binary64 sum of SQ over the site's samples in -B order, reset to 0 by a sample without evidence
+ * (GT code SVT_GT_BLANK), untouched by skipped and './.' samples.  The batch's units must be
+ * site-major (unit = site * n_samples + sample; n_units = n_sites * n_samples) and genotyped.
+ * `initial` (host, n_sites doubles: the incoming QUAL under --sum_quals) may be NULL = all 0;
+ * `qual_out` (host) receives n_sites doubles.                                                  */
+int svt_batch_site_qual(svt_batch* b, uint32_t n_samples, const double* initial, double* qual_out,
+                        uint64_t n_sites);
 
 /* Array form of the reference's inner operator seam statistics.bayes_gt(ref, alt, is_dup)
  * (svtyper/statistics.py:23-37) and log_choose(ref + alt, alt) (statistics.py:9-20):

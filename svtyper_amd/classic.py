@@ -110,11 +110,13 @@ def sv_genotype(bam_string, vcf_in, vcf_out, min_aligned, split_weight, disc_wei
     def flush():
         actions = list(pending)
         pending.clear()
-        pipe.submit(collector.take(engine, 0), lambda results: write_out(results, actions))
+        quals = [float(a[1].qual) for a in actions if a[0] == "gt"]      # incoming QUAL (0 unless --sum_quals)
+        pipe.submit(collector.take(engine, 0, site_quals=quals), lambda results: write_out(results, actions))
 
     def write_out(results, actions):
         dicts = results_to_dicts(results)
         gts = results.gt.tolist()
+        site_qual = None if results.site_qual is None else results.site_qual.tolist()
         for action in actions:
             if action[0] == "raw":
                 vcf_out.write(action[1].get_var_string() + "\n")
@@ -124,6 +126,8 @@ def sv_genotype(bam_string, vcf_in, vcf_out, min_aligned, split_weight, disc_wei
                 if debug:
                     _debug_print(results.rec[first_unit + k])
                 apply_result(var, sample.name, gts[first_unit + k], dicts[first_unit + k])
+            if site_qual is not None:      # the same running sum, accumulated on the device (svt_batch_site_qual)
+                var.qual = site_qual[first_unit // len(samples)]
             vcf_out.write(var.get_var_string() + "\n")
             if var2 is not None:                   # BND: second mate carries the same genotypes
                 var.share_genotypes_with(var2)

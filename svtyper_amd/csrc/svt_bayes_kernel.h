@@ -29,6 +29,27 @@ __global__ __launch_bounds__(kBlock) void svt_bayes_kernel(const int32_t* __rest
     reinterpret_cast<double4*>(out)[i] = o;
 }
 
+// ------------------------------------------------------------------------------------------
+// QUAL of a site over its samples (classic.py:216-217,485,498): a running binary64 sum of SQ in -B
+// order, reset to 0 by a sample without evidence, untouched by a skipped or './.' sample.  One site
+// per thread, samples in order; units are site-major (unit = site * n_samples + sample).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void svt_site_qual_kernel(const svt_result* __restrict__ res, uint32_t n_samples,
+                                                               const double* __restrict__ initial,
+                                                               double* __restrict__ qual, uint64_t n_sites)
+{
+    const uint64_t site = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (site >= n_sites) return;
+    double q = initial ? initial[site] : 0.0;
+    const svt_result* r = res + site * n_samples;
+    for (uint32_t s = 0; s < n_samples; ++s) {
+        const int gt = r[s].gt;
+        if (gt >= 0) q += r[s].sq;                   // classic.py:485
+        else if (gt == SVT_GT_BLANK) q = 0.0;        // classic.py:498
+    }
+    qual[site] = q;
+}
+
 
 }  // namespace svt
 

@@ -718,6 +718,27 @@ int svt_batch_layout(const svt_batch* b, int* compact, int* table_mode)
     return SVT_OK;
 }
 
+int svt_batch_site_qual(svt_batch* b, uint32_t n_samples, const double* initial, double* qual_out, uint64_t n_sites)
+{
+    if (!b || (!qual_out && n_sites)) return fail(SVT_ERR_INVALID, "null argument");
+    if (!b->have_results) return fail(SVT_ERR_STATE, "svt_batch_genotype has not run");
+    if (n_samples == 0 || n_sites * n_samples != b->n_units) return fail(SVT_ERR_INVALID, "n_sites * n_samples != n_units");
+    if (n_sites == 0) return SVT_OK;
+    HIP_TRY(hipSetDevice(b->device));
+    DevScratch d_init, d_qual;
+    SVT_TRY(d_qual.alloc(n_sites * sizeof(double)));
+    if (initial) {
+        SVT_TRY(d_init.alloc(n_sites * sizeof(double)));
+        Stager st(b->stream);
+        SVT_TRY(st.copy(d_init.p, initial, n_sites * sizeof(double)));
+        SVT_TRY(st.finish());
+    }
+    hipLaunchKernelGGL(svt_site_qual_kernel, dim3((unsigned)((n_sites + kBlock - 1) / kBlock)), dim3(kBlock), 0, b->stream,
+                       b->args.out, n_samples, initial ? d_init.as<double>() : nullptr, d_qual.as<double>(), n_sites);
+    HIP_TRY(hipGetLastError());
+    return d2h_staged(qual_out, d_qual.p, n_sites * sizeof(double), b->stream);
+}
+
 int svt_bayes_gt(const int32_t* ref, const int32_t* alt, const uint8_t* is_dup, uint64_t n, double* out,
                  int device)
 {

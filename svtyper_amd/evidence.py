@@ -216,6 +216,7 @@ class Results:
 
     def __init__(self, rec: np.ndarray):
         self.rec = np.ascontiguousarray(rec, dtype=RESULT_DTYPE)
+        self.site_qual = None   # float64 [n_sites] when the engine also accumulated QUAL over the samples
 
     @classmethod
     def empty(cls, n: int) -> "Results":

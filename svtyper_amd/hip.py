@@ -10,17 +10,19 @@ import os
 import subprocess
 from typing import Optional
 
+import numpy as np
+
 from .evidence import CEvidenceBatch, EvidenceBatch, RESULT_DTYPE, Results
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SVTYPER_HIP_LIB") or os.path.join(_HERE, "csrc", "libsvtyper_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 EXPORTS = (
     "svt_version", "svt_device_count", "svt_last_error", "svt_batch_create", "svt_batch_create_from_fragments",
     "svt_batch_genotype",
     "svt_batch_genotype_n", "svt_batch_genotype_timed", "svt_batch_results", "svt_batch_device_results",
-    "svt_batch_bind_device_results", "svt_batch_bytes", "svt_batch_layout",
+    "svt_batch_bind_device_results", "svt_batch_bytes", "svt_batch_layout", "svt_batch_site_qual",
     "svt_batch_stream", "svt_batch_destroy", "svt_trim", "svt_bayes_gt", "svt_genotype",
 )
 
@@ -71,6 +73,8 @@ def load() -> C.CDLL:
     L.svt_batch_device_results.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
     L.svt_batch_bind_device_results.restype = C.c_int
     L.svt_batch_bind_device_results.argtypes = [C.c_void_p, C.c_void_p]
+    L.svt_batch_site_qual.restype = C.c_int
+    L.svt_batch_site_qual.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64]
     L.svt_batch_layout.restype = C.c_int
     L.svt_batch_layout.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.svt_batch_bytes.restype = C.c_int
@@ -171,6 +175,18 @@ class DeviceBatch:
         _check(self._lib.svt_batch_bytes(self._h, C.byref(a), C.byref(r)))
         return int(a.value), int(r.value)
 
+    def site_qual(self, n_samples: int, initial=None) -> np.ndarray:
+        """QUAL of every site (classic.py:485,498) from the result records on the device; units must be
+        site-major.  `initial`: incoming QUAL per site (--sum_quals), None = 0."""
+        n_sites = self.n_units // max(1, int(n_samples))
+        out = np.zeros(n_sites, np.float64)
+        init = None if initial is None else np.ascontiguousarray(initial, dtype=np.float64)
+        if init is not None and init.shape[0] != n_sites:
+            raise ValueError("initial must have one value per site")
+        _check(self._lib.svt_batch_site_qual(self._h, int(n_samples), None if init is None else init.ctypes.data,
+                                             out.ctypes.data, n_sites))
+        return out
+
     def layout(self):
         """(compact: bool, table_mode: 0 one library in LDS / 1 library windows in LDS / 2 general)"""
         c, m = C.c_int(), C.c_int()
@@ -198,15 +214,25 @@ class DeviceBatch:
         self.close()
 
 
-def genotype_fragments(fbatch, device: int = 0, flags: int = 0) -> Results:
+def _finish(d: "DeviceBatch", site_qual) -> Results:
+    d.genotype(sync=True)
+    res = d.results()
+    if site_qual is not None:      # (n_samples, initial QUAL per site or None): classic.py:485,498 on the device
+        res.site_qual = d.site_qual(site_qual[0], site_qual[1])
+    return res
+
+
+def genotype_fragments(fbatch, device: int = 0, flags: int = 0, site_qual=None) -> Results:
     """Fragment summaries -> results with both the geometry and the likelihood stage on the device."""
     with DeviceBatch.from_fragments(fbatch, device, flags) as d:
-        d.genotype(sync=True)
-        return d.results()
+        return _finish(d, site_qual)
 
 
-def genotype_batch(batch: EvidenceBatch, device: int = 0, flags: int = 0) -> Results:
+def genotype_batch(batch: EvidenceBatch, device: int = 0, flags: int = 0, site_qual=None) -> Results:
     """create + genotype + results + destroy (svt_genotype)."""
+    if site_qual is not None:
+        with DeviceBatch(batch, device, flags) as d:
+            return _finish(d, site_qual)
     L = load()
     out = Results.empty(batch.n_units)
     cb = batch.as_c()

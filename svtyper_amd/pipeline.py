@@ -41,12 +41,21 @@ class HipEngine:
         self._hip = hip
         self.device = device
 
-    def __call__(self, batch: EvidenceBatch, flags: int = 0) -> Results:
-        return self._hip.genotype_batch(batch, device=self.device, flags=flags)
+    supports_site_qual = True   # QUAL over a site's samples (classic.py:485,498) can stay on the device
 
-    def genotype_fragments(self, fbatch, flags: int = 0) -> Results:
+    def __call__(self, batch: EvidenceBatch, flags: int = 0, site_qual=None) -> Results:
+        return self._hip.genotype_batch(batch, device=self.device, flags=flags, site_qual=site_qual)
+
+    def genotype_fragments(self, fbatch, flags: int = 0, site_qual=None) -> Results:
         """geometry="device": fragment summaries in, both stages on the GPU."""
-        return self._hip.genotype_fragments(fbatch, device=self.device, flags=flags)
+        return self._hip.genotype_fragments(fbatch, device=self.device, flags=flags, site_qual=site_qual)
+
+
+def _site_qual_kw(engine, n_samples: int, site_quals) -> dict:
+    if site_quals is None or not getattr(engine, "supports_site_qual", False):
+        return {}
+    import numpy as np
+    return {"site_qual": (n_samples, np.asarray(site_quals, dtype=np.float64))}
 
 
 def default_engine() -> Engine:
@@ -104,11 +113,14 @@ class UnitCollector:
     def __len__(self):
         return len(self.builder)
 
-    def take(self, engine: Engine, flags: int):
+    def take(self, engine: Engine, flags: int, site_quals=None):
         """Detach the units collected so far as a job (a callable returning their Results); the collector is
-        empty again and can be filled while the job runs on another thread (ChunkPipeline)."""
+        empty again and can be filled while the job runs on another thread (ChunkPipeline).  `site_quals`
+        (incoming QUAL of every site, units site-major over self.samples) asks an engine that can for
+        Results.site_qual."""
         builder, self.builder = self.builder, self._new_builder()
         geometry = self.geometry
+        kw = _site_qual_kw(engine, len(self.samples), site_quals)
 
         def job() -> Results:
             batch = builder.build()
@@ -117,8 +129,8 @@ class UnitCollector:
             if geometry == "device":
                 if not hasattr(engine, "genotype_fragments"):
                     raise TypeError("geometry='device' needs an engine with genotype_fragments (the HIP engine)")
-                return engine.genotype_fragments(batch, flags)
-            return engine(batch, flags)
+                return engine.genotype_fragments(batch, flags, **kw)
+            return engine(batch, flags, **kw)
         return job
 
     def run(self, engine: Engine, flags: int) -> Results:
@@ -161,15 +173,16 @@ class NativeUnitCollector:
     def __len__(self):
         return len(self.sites) * len(self.samples)
 
-    def take(self, engine: Engine, flags: int):
+    def take(self, engine: Engine, flags: int, site_quals=None):
         """Detach the sites recorded so far as a job (see UnitCollector.take)."""
         sites, self.sites = self.sites, []
-        return lambda: self._run_sites(sites, engine, flags)
+        kw = _site_qual_kw(engine, len(self.samples), site_quals)
+        return lambda: self._run_sites(sites, engine, flags, kw)
 
     def run(self, engine: Engine, flags: int) -> Results:
         return self.take(engine, flags)()
 
-    def _run_sites(self, sites: List[dict], engine: Engine, flags: int) -> Results:
+    def _run_sites(self, sites: List[dict], engine: Engine, flags: int, kw: dict) -> Results:
         import numpy as np
         from .geometry import FragmentBatch, breakpoint_record
         from .native_reads import COUNT_SSO, FETCH_DTYPE
@@ -228,7 +241,7 @@ class NativeUnitCollector:
             frags = np.concatenate(parts) if parts else per_sample[0][2][:0]
         fb = FragmentBatch(off, bps, frags, self.lib_tables, self.split_weight, self.disc_weight, self.min_aligned,
                            SPLIT_SLOP)
-        return engine.genotype_fragments(fb, flags)
+        return engine.genotype_fragments(fb, flags, **kw)
 
 
 class ChunkPipeline:

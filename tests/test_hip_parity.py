@@ -437,3 +437,36 @@ def test_pooled_buffers_do_not_leak_state(hip_device, fixture_library):
         assert_parity(hip.genotype_batch(small, device=hip_device, flags=flags), want_small)
     hip.trim()
     assert_parity(hip.genotype_batch(small, device=hip_device), want_small)
+
+
+@pytest.mark.parametrize("n_samples", [1, 3, 32])
+def test_site_qual_on_device(hip_device, fixture_library, n_samples):
+    """svt_batch_site_qual == the reference's running QUAL (classic.py:216-217,485,498), bit for bit"""
+    from svtyper_amd import hip
+    batch = synth.make_edge_cases([fixture_library], seed=5)
+    n_sites = batch.n_units // n_samples
+    batch = batch.slice(0, n_sites * n_samples)
+    rng = np.random.default_rng(n_samples)
+    initial = np.where(rng.random(n_sites) < 0.5, 0.0, rng.random(n_sites) * 1000.0)
+    with hip.DeviceBatch(batch, hip_device) as d:
+        d.genotype(sync=True)
+        res = d.results()
+        got0 = d.site_qual(n_samples)
+        got1 = d.site_qual(n_samples, initial)
+    codes = set(np.unique(res.gt).tolist())
+    assert {ev.GT_BLANK, ev.GT_SKIPPED, ev.GT_MISSING} <= codes and codes & {0, 1, 2}
+    for init, got in ((np.zeros(n_sites), got0), (initial, got1)):
+        want = np.zeros(n_sites)
+        for s in range(n_sites):
+            q = float(init[s])
+            for k in range(n_samples):
+                r = res.rec[s * n_samples + k]
+                if r["gt"] >= 0:
+                    q += float(r["sq"])
+                elif r["gt"] == ev.GT_BLANK:
+                    q = 0.0
+            want[s] = q
+        assert np.array_equal(got.view(np.uint64), want.view(np.uint64))
+    with pytest.raises(hip.SvtyperHipError):
+        with hip.DeviceBatch(batch, hip_device) as d:
+            d.site_qual(n_samples)          # no pass has run yet
