@@ -72,6 +72,28 @@ typedef struct svt_summaries {
 int svt_bam_summarise(const svt_bam* bam, const svt_summarise_args* args, svt_summaries* out);
 void svt_summaries_free(svt_summaries* s);
 
+/* Library statistics straight from the BAM (svtyper/parsers.py:501-576): what Library.from_bam scans
+ * for, for ONE library given as its read-group ids, in three passes from the first record each --
+ *   read_length : max query length (M/I/S/=/X) over the library's reads until 10 001 of them were seen
+ *                 (calc_read_length, :516-528)
+ *   hist        : Counter of template_length over the library's forward-strand, mate-reverse, mapped,
+ *                 mate-mapped, primary reads with template_length > 0, until num_samp of them
+ *                 (calc_insert_hist, :534-576; trimming and moments stay with the caller)
+ *   in_lib/total: reads of the library among the first 100 000 records (calc_lib_prevalence, :501-513)
+ * A read that has to be attributed but carries no RG tag is an error, as it is for the reference.   */
+typedef struct svt_library_scan {
+    int64_t read_length;
+    uint64_t in_lib, total;
+    uint64_t n_hist;          /* distinct template lengths                      */
+    int64_t* hist_keys;       /* n_hist, in order of first occurrence (the order the
+                                 reference's Counter sums in), malloc'ed        */
+    uint64_t* hist_counts;    /* n_hist, malloc'ed                              */
+} svt_library_scan;
+
+int svt_bam_scan_library(const svt_bam* bam, uint32_t n_read_groups, const char* const* read_groups,
+                         int64_t num_samp, svt_library_scan* out);
+void svt_library_scan_free(svt_library_scan* s);
+
 #ifdef __cplusplus
 }
 #endif

@@ -82,7 +82,12 @@ def sv_genotype(bam_string, vcf_in, vcf_out, min_aligned, split_weight, disc_wei
             lib_info = json.load(f)
     if vcf_in is None:
         sys.stderr.write("Warning: VCF not found.\n")
-    samples: List[Sample] = [setup_sample(b, lib_info, num_samp, MIN_LIB_PREVALENCE) for b in bams]
+    native = None
+    if reader == "native":      # C++ reader: library scans now, fetch + fragment summaries later
+        from .native_reads import COUNT_CLASSIC, NativeBam
+        native = [NativeBam(p) for p in bam_string.split(",")]
+    samples: List[Sample] = [setup_sample(b, lib_info, num_samp, MIN_LIB_PREVALENCE, nb)
+                             for b, nb in zip(bams, native or [None] * len(bams))]
     if lib_info_path is not None and not os.path.isfile(lib_info_path):
         logging.info("Writing library metrics to %s..." % lib_info_path)
         write_sample_json(samples, open(lib_info_path, "w"))
@@ -93,8 +98,6 @@ def sv_genotype(bam_string, vcf_in, vcf_out, min_aligned, split_weight, disc_wei
         engine = default_engine()
     vcf = Vcf()
     if reader == "native":      # C++ fetch + summariser, geometry and likelihood on the device
-        from .native_reads import COUNT_CLASSIC, NativeBam
-        native = [NativeBam(p) for p in bam_string.split(",")]
         collector = NativeUnitCollector(samples, native, split_weight, disc_weight, min_aligned, COUNT_CLASSIC,
                                         max_reads)
     elif reader == "python":

@@ -285,6 +285,7 @@ struct Record {               // one BAM alignment, decoded as far as the path n
     uint16_t flag = 0;
     int mapq = 0;
     int64_t l_seq = 0;
+    int64_t tlen = 0;         // template_length
     std::string name;
     Cigar cigar;
     const uint8_t* tags = nullptr;
@@ -377,6 +378,7 @@ bool read_record(Bgzf& z, std::vector<uint8_t>& buf, Record& r)
     const unsigned n_cigar = d[12] | (d[13] << 8);
     r.flag = (uint16_t)(d[14] | (d[15] << 8));
     r.l_seq = (int32_t)u32(16);
+    r.tlen = (int32_t)u32(28);
     size_t off = 32;
     if (off + l_name + 4ull * n_cigar > size) return false;
     r.name.assign(reinterpret_cast<const char*>(d + off), l_name ? l_name - 1 : 0);
@@ -964,6 +966,96 @@ void svt_summaries_free(svt_summaries* s)
     s->frag_offset = nullptr;
     s->fragments = nullptr;
     s->skipped = nullptr;
+}
+
+int svt_bam_scan_library(const svt_bam* bam, uint32_t n_read_groups, const char* const* read_groups, int64_t num_samp,
+                         svt_library_scan* out)
+{
+    if (!bam || !out || (n_read_groups && !read_groups)) return fail(SVT_ERR_INVALID, "null argument");
+    *out = svt_library_scan{};
+    std::set<std::string> rgset;
+    for (uint32_t i = 0; i < n_read_groups; ++i) rgset.insert(read_groups[i]);
+    Bgzf z(bam->file);
+    if (!z.ok()) return fail(SVT_ERR_NOMEM, "cannot set up the inflate state");
+    std::vector<uint8_t> buf;
+    Record r;
+    // 1 in the set, 0 not in the set, -1 no usable RG tag (an error where the reference calls get_tag)
+    auto in_library = [&](const Record& rec) -> int {
+        bool malformed = false;
+        const char* rg = find_z_tag(rec, 'R', 'G', &malformed);
+        if (malformed || !rg) return -1;
+        return rgset.count(rg) ? 1 : 0;
+    };
+    auto no_rg = [&](const Record& rec) { return fail(SVT_ERR_INVALID, "read without a usable RG tag: " + rec.name); };
+    auto query_length = [](const Record& rec) {
+        int64_t n = 0;
+        for (const auto& c : rec.cigar) if (c.first == 0 || c.first == 1 || c.first == 4 || c.first == 7 || c.first == 8) n += c.second;
+        return n;
+    };
+
+    // calc_read_length (parsers.py:516-528)
+    z.seek(bam->first_record);
+    for (int64_t seen = 0; read_record(z, buf, r);) {
+        const int in = in_library(r);
+        if (in < 0) return no_rg(r);
+        if (!in) continue;
+        out->read_length = std::max(out->read_length, query_length(r));
+        if (seen == 10000) break;
+        ++seen;
+    }
+    // calc_insert_hist (parsers.py:534-576)
+    // keys in order of first occurrence, like the reference's Counter: its mean / sd are sums in that order
+    std::vector<int64_t> hist_keys;
+    std::vector<uint64_t> hist_counts;
+    std::unordered_map<int64_t, size_t> hist_slot;
+    z.seek(bam->first_record);
+    for (int64_t n = 0; n != num_samp && read_record(z, buf, r);) {
+        if ((r.flag & 0x10) || !(r.flag & 0x20) || (r.flag & (0x4 | 0x8)) || (r.flag & (0x100 | 0x800))) continue;
+        if (r.tlen <= 0) continue;
+        const int in = in_library(r);
+        if (in < 0) return no_rg(r);
+        if (!in) continue;
+        auto slot = hist_slot.find(r.tlen);
+        if (slot == hist_slot.end()) {
+            hist_slot.emplace(r.tlen, hist_keys.size());
+            hist_keys.push_back(r.tlen);
+            hist_counts.push_back(1);
+        } else {
+            ++hist_counts[slot->second];
+        }
+        ++n;
+    }
+    // calc_lib_prevalence (parsers.py:501-513)
+    z.seek(bam->first_record);
+    while (out->total != 100000 && read_record(z, buf, r)) {
+        const int in = in_library(r);
+        if (in < 0) return no_rg(r);
+        out->in_lib += (uint64_t)in;
+        ++out->total;
+    }
+    if (z.failed()) return fail(SVT_ERR_INVALID, "corrupt BGZF block in " + bam->path);
+    out->n_hist = hist_keys.size();
+    out->hist_keys = static_cast<int64_t*>(std::malloc(std::max<size_t>(hist_keys.size(), 1) * sizeof(int64_t)));
+    out->hist_counts = static_cast<uint64_t*>(std::malloc(std::max<size_t>(hist_keys.size(), 1) * sizeof(uint64_t)));
+    if (!out->hist_keys || !out->hist_counts) {
+        svt_library_scan_free(out);
+        return fail(SVT_ERR_NOMEM, "out of host memory");
+    }
+    if (!hist_keys.empty()) {
+        std::memcpy(out->hist_keys, hist_keys.data(), hist_keys.size() * sizeof(int64_t));
+        std::memcpy(out->hist_counts, hist_counts.data(), hist_counts.size() * sizeof(uint64_t));
+    }
+    return SVT_OK;
+}
+
+void svt_library_scan_free(svt_library_scan* s)
+{
+    if (!s) return;
+    std::free(s->hist_keys);
+    std::free(s->hist_counts);
+    s->hist_keys = nullptr;
+    s->hist_counts = nullptr;
+    s->n_hist = 0;
 }
 
 }  // extern "C"

@@ -78,8 +78,11 @@ class Library:
 
     # ---- empirically from a BAM (parsers.py:472-583)
     @classmethod
-    def from_bam(cls, lib_name, bam, num_samp) -> "Library":
+    def from_bam(cls, lib_name, bam, num_samp, native=None) -> "Library":
         readgroups = [rg["ID"] for rg in bam.header["RG"] if rg.get("LB", "") == lib_name]
+        if native is not None:       # the same three scans in the C++ reader (native_reads.NativeBam.scan_library)
+            read_length, counts, in_lib, total = native.scan_library(readgroups, num_samp)
+            return cls._from_scan(lib_name, readgroups, read_length, Counter(counts), in_lib, total, bam)
         rgset = set(readgroups)
         primary = lambda r: not r.is_supplementary and not r.is_secondary
 
@@ -102,6 +105,19 @@ class Library:
             n += 1
             if n == num_samp:
                 break
+        in_lib = total = 0                               # calc_lib_prevalence (:501-513)
+        for read in bam.fetch():
+            if total == 100000:
+                break
+            if read.get_tag("RG") in rgset:
+                in_lib += 1
+            total += 1
+        return cls._from_scan(lib_name, readgroups, read_length, hist, in_lib, total, bam)
+
+    @classmethod
+    def _from_scan(cls, lib_name, readgroups, read_length, hist, in_lib, total, bam) -> "Library":
+        """The arithmetic after the three BAM scans (parsers.py:549-576,512): outlier trimming, moments,
+        prevalence.  `hist` keeps the order in which the template lengths first occurred."""
         if not hist:
             sys.stderr.write("Error: failed to build insert size histogram for paired-end reads.\n"
                              "Please ensure BAM file (%s) has inward facing, paired-end reads.\n" % bam.filename)
@@ -111,14 +127,6 @@ class Library:
         for x in [x for x in list(hist) if x > cut]:
             del hist[x]
         mean, sd = hist_mean(hist), hist_stdev(hist)
-
-        in_lib = total = 0                               # calc_lib_prevalence (:501-513)
-        for read in bam.fetch():
-            if total == 100000:
-                break
-            if read.get_tag("RG") in rgset:
-                in_lib += 1
-            total += 1
         return cls(lib_name, readgroups, read_length, hist, mean, sd, float(in_lib) / total)
 
     def table(self) -> LibraryTable:
@@ -153,13 +161,13 @@ class Sample:
                    lib_info[name]["mapped"], lib_info[name]["unmapped"])
 
     @classmethod
-    def from_bam(cls, bam, num_samp, min_lib_prevalence) -> "Sample":
+    def from_bam(cls, bam, num_samp, min_lib_prevalence, native=None) -> "Sample":
         name = bam.header["RG"][0]["SM"]
         lib_dict, rg_to_lib = {}, {}
         for rg in bam.header["RG"]:
             lib_name = rg.get("LB", "")
             if lib_name not in lib_dict:
-                lib_dict[lib_name] = Library.from_bam(lib_name, bam, num_samp)
+                lib_dict[lib_name] = Library.from_bam(lib_name, bam, num_samp, native)
             rg_to_lib[rg["ID"]] = lib_dict[lib_name]
         return cls(name, bam, lib_dict, rg_to_lib, min_lib_prevalence, bam.mapped, bam.unmapped)
 
@@ -192,7 +200,8 @@ def write_sample_json(sample_list: List[Sample], lib_info_file):
     lib_info_file.close()
 
 
-def setup_sample(bam, lib_info: Optional[dict], num_samp: int, min_lib_prevalence: float = 1e-3) -> Sample:
+def setup_sample(bam, lib_info: Optional[dict], num_samp: int, min_lib_prevalence: float = 1e-3, native=None) -> Sample:
+    """`native`: a native_reads.NativeBam of the same file; the library scans then run in the C++ reader."""
     if lib_info is not None:
         return Sample.from_lib_info(bam, lib_info, min_lib_prevalence)
-    return Sample.from_bam(bam, num_samp, min_lib_prevalence)
+    return Sample.from_bam(bam, num_samp, min_lib_prevalence, native)

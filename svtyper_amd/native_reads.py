@@ -34,6 +34,11 @@ class _Summaries(C.Structure):
     _fields_ = [("frag_offset", C.POINTER(C.c_uint64)), ("fragments", C.c_void_p), ("skipped", C.POINTER(C.c_uint8))]
 
 
+class _LibraryScan(C.Structure):
+    _fields_ = [("read_length", C.c_int64), ("in_lib", C.c_uint64), ("total", C.c_uint64), ("n_hist", C.c_uint64),
+                ("hist_keys", C.POINTER(C.c_int64)), ("hist_counts", C.POINTER(C.c_uint64))]
+
+
 _declared = False
 
 
@@ -59,6 +64,10 @@ def _lib():
         L.svt_bam_summarise.argtypes = [C.c_void_p, C.POINTER(_Args), C.POINTER(_Summaries)]
         L.svt_summaries_free.restype = None
         L.svt_summaries_free.argtypes = [C.POINTER(_Summaries)]
+        L.svt_bam_scan_library.restype = C.c_int
+        L.svt_bam_scan_library.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_char_p), C.c_int64, C.POINTER(_LibraryScan)]
+        L.svt_library_scan_free.restype = None
+        L.svt_library_scan_free.argtypes = [C.POINTER(_LibraryScan)]
         _declared = True
     return L
 
@@ -98,6 +107,20 @@ class NativeBam:
             self.close()
         except Exception:
             pass
+
+    def scan_library(self, read_groups: Sequence[str], num_samp: int):
+        """(read_length, {template_length: count}, reads of the library among the first 100 000, that total):
+        the three scans of Library.from_bam (svtyper/parsers.py:501-576) in C++."""
+        names = (C.c_char_p * max(1, len(read_groups)))(*[rg.encode() for rg in read_groups])
+        out = _LibraryScan()
+        hip._check(self._L.svt_bam_scan_library(self._h, len(read_groups), names, int(num_samp), C.byref(out)))
+        try:
+            n = int(out.n_hist)
+            keys = np.ctypeslib.as_array(out.hist_keys, shape=(max(n, 1),))[:n].tolist()
+            counts = np.ctypeslib.as_array(out.hist_counts, shape=(max(n, 1),))[:n].tolist()
+            return int(out.read_length), dict(zip(keys, counts)), int(out.in_lib), int(out.total)
+        finally:
+            self._L.svt_library_scan_free(C.byref(out))
 
     def summarise(self, windows: np.ndarray, breakpoints: np.ndarray, read_groups: Sequence[str],
                   read_group_lib: Sequence[int], max_reads: Optional[int], count_mode: int,

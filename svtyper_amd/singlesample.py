@@ -80,7 +80,11 @@ def sso_genotype(bam_string, vcf_in, vcf_out, min_aligned, split_weight, disc_we
         logit("Reading library metrics from %s..." % lib_info_path)
         with open(lib_info_path) as f:
             lib_info = json.load(f)
-    sample = setup_sample(bam, lib_info, num_samp, MIN_LIB_PREVALENCE)
+    native = None
+    if reader == "native":      # C++ reader: library scans now, fetch + fragment summaries later
+        from .native_reads import COUNT_SSO, NativeBam
+        native = NativeBam(full_bam_path)
+    sample = setup_sample(bam, lib_info, num_samp, MIN_LIB_PREVALENCE, native)
     if lib_info_path is not None and not os.path.exists(lib_info_path):
         logit("Writing library metrics to %s..." % lib_info_path)
         write_sample_json([sample], open(lib_info_path, "w"))
@@ -113,8 +117,7 @@ def sso_genotype(bam_string, vcf_in, vcf_out, min_aligned, split_weight, disc_we
 
     logit("Genotyping Input VCF (%s Mode)" % ("Serial" if cores is None else "Parallel"))
     if reader == "native":      # C++ fetch + summariser (cores = its thread count), device geometry
-        from .native_reads import COUNT_SSO, NativeBam
-        collector = NativeUnitCollector([sample], [NativeBam(full_bam_path)], split_weight, disc_weight, min_aligned,
+        collector = NativeUnitCollector([sample], [native], split_weight, disc_weight, min_aligned,
                                         COUNT_SSO, max_reads, n_threads=cores or 0)
     elif reader == "python":
         collector = UnitCollector([sample], split_weight, disc_weight, min_aligned, geometry)

@@ -173,3 +173,31 @@ def test_synthetic_bam_native_equals_python(tmp_path, seed, mode, max_reads):
     assert len(want[1]) > 100 or want[2].any()
     # the synthetic reads really exercise the split-read path
     assert (want[1]["seq"]["flags"] & 1).any() or (want[1]["clip"]["flags"] & 1).any() or want[2].all()
+
+
+def test_library_statistics_native_equals_python_and_reference(tmp_path):
+    """Library.from_bam through the C++ scans == through the Python reader, field for field, including the
+    order-sensitive mean / sd."""
+    pybam = bam.AlignmentFile(BAM)
+    py = library.Sample.from_bam(pybam, 1000000, 1e-3)
+    nat = library.Sample.from_bam(pybam, 1000000, 1e-3, native=nr.NativeBam(BAM))
+    assert list(py.lib_dict) == list(nat.lib_dict)
+    for name in py.lib_dict:
+        a, b = py.lib_dict[name], nat.lib_dict[name]
+        assert (a.read_length, a.mean, a.sd, a.prevalence, a.readgroups) == (b.read_length, b.mean, b.sd, b.prevalence, b.readgroups)
+        assert list(a.hist.items()) == list(b.hist.items())        # same counts in the same (first-seen) order
+    # a small num_samp stops the histogram scan early in both readers alike
+    for n in (50, 777):
+        a = library.Library.from_bam("", pybam, n)
+        b = library.Library.from_bam("", pybam, n, native=nr.NativeBam(BAM))
+        assert list(a.hist.items()) == list(b.hist.items()) and (a.mean, a.sd) == (b.mean, b.sd)
+    # and on the synthetic BAM with two libraries
+    path = str(tmp_path / "syn.bam")
+    _synthetic_bam(path, seed=31)
+    sb = bam.AlignmentFile(path)
+    for lib_name in ("libA", "libB"):
+        a = library.Library.from_bam(lib_name, sb, 5000)
+        b = library.Library.from_bam(lib_name, sb, 5000, native=nr.NativeBam(path))
+        assert (a.read_length, a.mean, a.sd, a.prevalence) == (b.read_length, b.mean, b.sd, b.prevalence)
+        assert list(a.hist.items()) == list(b.hist.items())
+    # (the Python reader's numbers are pinned to the reference's by tests/test_host_pipeline.py)
