@@ -187,3 +187,19 @@ def test_synthetic_bam_all_paths_agree(tmp_path, hip_device, driver):
     for name, kw in (("host", {}), ("device", dict(geometry="device")), ("native", dict(geometry="device", reader="native"))):
         got = run(str(tmp_path / (name + ".vcf")), **kw)
         assert got == want, "%s path differs from the oracle-engine output" % name
+
+
+def test_library_statistics_from_bam_native_reader(tmp_path, hip_device):
+    """No library JSON: both readers derive the libraries from the BAM itself (Library.from_bam; the native
+    one through svt_bam_scan_library), write the same JSON and the same genotypes."""
+    import test_host_pipeline as T
+    outs, jsons = [], []
+    for name, kw in (("python", {}), ("native", dict(geometry="device", reader="native"))):
+        out, lib_json = str(tmp_path / (name + ".vcf")), str(tmp_path / (name + ".json"))
+        with open(T.IN_VCF) as inf, open(out, "w") as outf:
+            T.classic.sv_genotype(T.IN_BAM, inf, outf, 20, 1, 1, 1000000, lib_json, False, None, None, False, None,
+                                  1e10, **kw)
+        outs.append(open(out).read())
+        jsons.append(open(lib_json).read())
+    assert jsons[0] == jsons[1] and '"histogram"' in jsons[0]
+    assert outs[0] == outs[1] and outs[0].count("\n") > 200
