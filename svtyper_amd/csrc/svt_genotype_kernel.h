@@ -200,18 +200,30 @@ __device__ __forceinline__ void pair_entry(const uint32_t e, const LaneCtx& c, A
     a.ref_span += pp * w_ref;
 }
 
-// Weight entries (classic.py:306-328), one stream per tally.  e = mapq0 | mapq1 << 8 | first << 16.
+// Reference-read entries (classic.py:306-315): seven MAPQ pairs per row slot, byte 14 of the slot holds their
+// first-of-fragment bits.  x, y = the two prob_mapq look-ups of one pair.
 template <bool SSO>
-__device__ __forceinline__ void ref_read_entry(const uint32_t e, Acc& a)
+__device__ __forceinline__ void ref_read_pair(const double x, const double y, const bool first, Acc& a)
 {
-    const double x = lds_f64(kLdsPm + byte0_x8(e)), y = lds_f64(kLdsPm + byte1_x8(e));
     if (SSO) {   // singlesample.py:246-276,367-372: fragment-local sum, flushed when the next fragment starts
-        const bool first = (e & 0x10000u) != 0u;
         a.ref_seq += first ? a.l_ref_seq : 0.0;
         a.l_ref_seq = ((first ? 0.0 : a.l_ref_seq) + x) + y;
     } else {
         a.ref_seq = (a.ref_seq + x) + y;
     }
+}
+
+template <bool SSO>
+__device__ __forceinline__ void ref_read_row(const uint4 w, Acc& a)
+{
+    const uint32_t f = w.w >> 16;     // bit k: entry k is the first kept one of its fragment
+    ref_read_pair<SSO>(lds_f64(kLdsPm + byte0_x8(w.x)), lds_f64(kLdsPm + byte1_x8(w.x)), (f & 1u) != 0u, a);
+    ref_read_pair<SSO>(lds_f64(kLdsPm + byte2_x8(w.x)), lds_f64(kLdsPm + byte3_x8(w.x)), (f & 2u) != 0u, a);
+    ref_read_pair<SSO>(lds_f64(kLdsPm + byte0_x8(w.y)), lds_f64(kLdsPm + byte1_x8(w.y)), (f & 4u) != 0u, a);
+    ref_read_pair<SSO>(lds_f64(kLdsPm + byte2_x8(w.y)), lds_f64(kLdsPm + byte3_x8(w.y)), (f & 8u) != 0u, a);
+    ref_read_pair<SSO>(lds_f64(kLdsPm + byte0_x8(w.z)), lds_f64(kLdsPm + byte1_x8(w.z)), (f & 16u) != 0u, a);
+    ref_read_pair<SSO>(lds_f64(kLdsPm + byte2_x8(w.z)), lds_f64(kLdsPm + byte3_x8(w.z)), (f & 32u) != 0u, a);
+    ref_read_pair<SSO>(lds_f64(kLdsPm + byte0_x8(w.w)), lds_f64(kLdsPm + byte1_x8(w.w)), (f & 64u) != 0u, a);
 }
 
 // split (alt_seq) or clip (alt_clip) candidate: the other tally receives +0.0
@@ -408,12 +420,7 @@ __global__ __launch_bounds__(kBlock, SVT_MIN_WAVES) void svt_genotype_kernel(con
             pair_entry<MODE>(w.z, c, acc);
             pair_entry<MODE>(w.w, c, acc);
         });
-        rows.run(td.rows[kRefReads], [&](const uint4 w) {
-            ref_read_entry<SSO>(w.x, acc);
-            ref_read_entry<SSO>(w.y, acc);
-            ref_read_entry<SSO>(w.z, acc);
-            ref_read_entry<SSO>(w.w, acc);
-        });
+        rows.run(td.rows[kRefReads], [&](const uint4 w) { ref_read_row<SSO>(w, acc); });
         rows.run(td.rows[kCandidates], [&](const uint4 w) {
             candidate_entry<SSO>(w.x, acc);
             candidate_entry<SSO>(w.y, acc);

@@ -44,7 +44,7 @@ inline void parallel_for(uint64_t n, Fn&& fn)
 // rows of 16-byte slots unit `u` needs in stream `k`
 inline uint32_t stream_rows_of(const ScanOut& sc, uint32_t nrec, bool compact, int k)
 {
-    if (compact) return (sc.n[k] + 3) / 4;   // four 4-byte entries per row slot
+    if (compact) return (sc.n[k] + kEntriesPerRow[k] - 1) / kEntriesPerRow[k];
     return k == 0 ? nrec : 0u;
 }
 

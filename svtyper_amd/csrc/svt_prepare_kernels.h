@@ -12,7 +12,7 @@ namespace svt {
 // ------------------------------------------------------------------------------------------
 
 // ---- compact layout --------------------------------------------------------------------------
-// A unit's evidence becomes three sparse streams of 4-byte entries (four per 16-byte row slot), each in
+// A unit's evidence becomes three sparse streams of entries packed into 16-byte row slots, each in
 // record order.  The five tallies are independent sums, so evidence for different tallies can live
 // in different streams without changing any of them.
 //
@@ -33,7 +33,8 @@ namespace svt {
 //            decision and every sum stay in the genotype kernel.  `code << 3` is the byte offset of
 //            the bin, and the MAPQs sit on byte boundaries, so the kernel turns every field into an LDS
 //            address with one instruction.
-//   reference-read entries (ref_seq)         mapq0 | mapq1 << 8 | first_of_fragment << 16
+//   reference-read entries (ref_seq)         2 bytes: mapq0, mapq1 -- seven per row slot (bytes 0..13), byte 14
+//                                            of the slot holds their seven first_of_fragment bits
 //   candidate entries (alt_seq / alt_clip)   mapq0 | mapq1 << 8 | first_of_fragment << 16 | is_clip << 17
 //     the two gated MAPQs of the reference reads (rs_a, rs_b), of the split candidate (seq_l, seq_r)
 //     or of the clip candidate (clip_l, clip_r); first_of_fragment marks the first kept entry for its
@@ -171,6 +172,36 @@ __global__ __launch_bounds__(kBlock) void svt_repack_dense_kernel(const RepackAr
     }
 }
 
+// seven 2-byte reference-read entries + their first-of-fragment bits per 16-byte row slot of the lane
+struct RefRowWriter {
+    uint4* out;       // row 0 of this lane
+    uint32_t n = 0;   // entries so far
+    uint32_t w[4] = {0u, 0u, 0u, 0u};
+    __device__ __forceinline__ void put(const uint32_t mapq_pair, const bool first)
+    {
+        const uint32_t k = n % 7u;
+        const uint32_t half = mapq_pair << ((k & 1u) * 16u);
+        switch (k >> 1) {
+        case 0: w[0] |= half; break;
+        case 1: w[1] |= half; break;
+        case 2: w[2] |= half; break;
+        default: w[3] |= half;        // k == 6: low half of the last dword
+        }
+        if (first) w[3] |= 1u << (16u + k);
+        if (k == 6u) {
+            out[(uint64_t)(n / 7u) * kWave] = make_uint4(w[0], w[1], w[2], w[3]);
+            w[0] = w[1] = w[2] = w[3] = 0u;
+        }
+        ++n;
+    }
+    __device__ __forceinline__ void finish(const uint32_t rows)
+    {
+        uint32_t r = n / 7u;
+        if (n % 7u) out[(uint64_t)r++ * kWave] = make_uint4(w[0], w[1], w[2], w[3]);
+        for (; r < rows; ++r) out[(uint64_t)r * kWave] = make_uint4(0, 0, 0, 0);
+    }
+};
+
 // four 4-byte entries per 16-byte row slot of the lane
 struct RowWriter {
     uint4* out;       // row 0 of this lane
@@ -214,7 +245,7 @@ __global__ __launch_bounds__(kBlock) void svt_repack_compact_kernel(const Repack
     const uint32_t lib_min = (h.packed >> 16) & 0xffu;
     uint4* row0 = a.tiled + td.base + lane;
     RowWriter P{row0};
-    RowWriter R{row0 + (uint64_t)td.rows[kPairs] * kWave};
+    RefRowWriter R{row0 + (uint64_t)td.rows[kPairs] * kWave};
     RowWriter X{row0 + (uint64_t)(td.rows[kPairs] + td.rows[kRefReads]) * kWave};
     bool frag_has[3] = {false, false, false};  // did the current fragment already emit an entry for this tally?
     for (uint32_t j = 0; j < nrec; ++j) {
@@ -231,7 +262,7 @@ __global__ __launch_bounds__(kBlock) void svt_repack_compact_kernel(const Repack
         uint32_t k[3];
         weight_pairs(w, k);
         if (k[0]) {
-            R.put(k[0] | (frag_has[0] ? 0u : (1u << 16)));
+            R.put(k[0], !frag_has[0]);
             frag_has[0] = true;
         }
 #pragma unroll
