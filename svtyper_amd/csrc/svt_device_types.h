@@ -30,13 +30,13 @@ struct LaneHdr {          // 16 B, one per tile lane
 // One 64-unit tile: `rows[k]` rows of stream k, stored back to back from `base` (in 16-byte row
 // slots; row j holds the j-th 16 bytes of each of the 64 lanes).  Dense layout: one stream of
 // canonical 16-byte records (rows[0] = longest unit).  Compact layout: three streams of entries --
-// pair entries (4 bytes, four per row slot), reference-read weight entries (2 bytes, seven per row
-// slot) and split/clip candidate weight entries (4 bytes) (svt_prepare_kernels.h has the formats).
+// pair entries (4 bytes, four per row slot), reference-read weight entries and split/clip candidate
+// weight entries (2 bytes, seven per row slot) (svt_prepare_kernels.h has the formats).
 constexpr int kStreams = 3;
 enum Stream : int { kPairs = 0, kRefReads = 1, kCandidates = 2 };
-// entries per 16-byte row slot: 4-byte pair and candidate entries, 2-byte reference-read entries
-// (seven MAPQ pairs + one byte with their seven first-of-fragment bits)
-constexpr uint32_t kEntriesPerRow[kStreams] = {4u, 7u, 4u};
+// entries per 16-byte row slot: 4-byte pair entries; 2-byte reference-read and candidate entries
+// (seven MAPQ pairs in bytes 0..13, their flag bits in bytes 14..15)
+constexpr uint32_t kEntriesPerRow[kStreams] = {4u, 7u, 7u};
 struct TileDesc {         // 32 B, stored in dispatch (longest-first) order
     uint64_t base;
     uint32_t rows[kStreams];

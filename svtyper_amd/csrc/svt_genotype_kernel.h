@@ -201,7 +201,7 @@ __device__ __forceinline__ void pair_entry(const uint32_t e, const LaneCtx& c, A
 }
 
 // Reference-read entries (classic.py:306-315): seven MAPQ pairs per row slot, byte 14 of the slot holds their
-// first-of-fragment bits.  x, y = the two prob_mapq look-ups of one pair.
+// first-of-fragment bits (bits 0..6 of f below; bit 7 is unused).  x, y = the two prob_mapq look-ups of one pair.
 template <bool SSO>
 __device__ __forceinline__ void ref_read_pair(const double x, const double y, const bool first, Acc& a)
 {
@@ -228,14 +228,11 @@ __device__ __forceinline__ void ref_read_row(const uint4 w, Acc& a)
 
 // split (alt_seq) or clip (alt_clip) candidate: the other tally receives +0.0
 template <bool SSO>
-__device__ __forceinline__ void candidate_entry(const uint32_t e, Acc& a)
+__device__ __forceinline__ void candidate_pair(const double x, const double y, const bool first, const bool clip, Acc& a)
 {
-    const double x = lds_f64(kLdsPm + byte0_x8(e)), y = lds_f64(kLdsPm + byte1_x8(e));
     const double p = (x + y) * 0.5;              // (pm(left) * L + pm(right) * R) / 2.0   (classic.py:324)
-    const bool clip = (e & 0x20000u) != 0u;
     const double ps = clip ? 0.0 : p, pc = clip ? p : 0.0;
     if (SSO) {
-        const bool first = (e & 0x10000u) != 0u;
         const bool fs = first && !clip, fc = first && clip;
         a.alt_seq += fs ? a.l_alt_seq : 0.0;
         a.alt_clip += fc ? a.l_alt_clip : 0.0;
@@ -245,6 +242,19 @@ __device__ __forceinline__ void candidate_entry(const uint32_t e, Acc& a)
         a.alt_seq += ps;
         a.alt_clip += pc;
     }
+}
+
+template <bool SSO>
+__device__ __forceinline__ void candidate_row(const uint4 w, Acc& a)
+{
+    const uint32_t f = w.w >> 16, c = w.w >> 24;   // bit k: first of its fragment / clip candidate
+    candidate_pair<SSO>(lds_f64(kLdsPm + byte0_x8(w.x)), lds_f64(kLdsPm + byte1_x8(w.x)), (f & 1u) != 0u, (c & 1u) != 0u, a);
+    candidate_pair<SSO>(lds_f64(kLdsPm + byte2_x8(w.x)), lds_f64(kLdsPm + byte3_x8(w.x)), (f & 2u) != 0u, (c & 2u) != 0u, a);
+    candidate_pair<SSO>(lds_f64(kLdsPm + byte0_x8(w.y)), lds_f64(kLdsPm + byte1_x8(w.y)), (f & 4u) != 0u, (c & 4u) != 0u, a);
+    candidate_pair<SSO>(lds_f64(kLdsPm + byte2_x8(w.y)), lds_f64(kLdsPm + byte3_x8(w.y)), (f & 8u) != 0u, (c & 8u) != 0u, a);
+    candidate_pair<SSO>(lds_f64(kLdsPm + byte0_x8(w.z)), lds_f64(kLdsPm + byte1_x8(w.z)), (f & 16u) != 0u, (c & 16u) != 0u, a);
+    candidate_pair<SSO>(lds_f64(kLdsPm + byte2_x8(w.z)), lds_f64(kLdsPm + byte3_x8(w.z)), (f & 32u) != 0u, (c & 32u) != 0u, a);
+    candidate_pair<SSO>(lds_f64(kLdsPm + byte0_x8(w.w)), lds_f64(kLdsPm + byte1_x8(w.w)), (f & 64u) != 0u, (c & 64u) != 0u, a);
 }
 
 __device__ __forceinline__ double log_choose_dev(const double* __restrict__ l10, int32_t n, int32_t k)
@@ -421,12 +431,7 @@ __global__ __launch_bounds__(kBlock, SVT_MIN_WAVES) void svt_genotype_kernel(con
             pair_entry<MODE>(w.w, c, acc);
         });
         rows.run(td.rows[kRefReads], [&](const uint4 w) { ref_read_row<SSO>(w, acc); });
-        rows.run(td.rows[kCandidates], [&](const uint4 w) {
-            candidate_entry<SSO>(w.x, acc);
-            candidate_entry<SSO>(w.y, acc);
-            candidate_entry<SSO>(w.z, acc);
-            candidate_entry<SSO>(w.w, acc);
-        });
+        rows.run(td.rows[kCandidates], [&](const uint4 w) { candidate_row<SSO>(w, acc); });
     } else {
         // canonical 16-byte records (include/svtyper_hip.h: svt_record)
         rows.run(td.rows[0], [&](const uint4 w) {

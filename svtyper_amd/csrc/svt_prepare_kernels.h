@@ -33,9 +33,9 @@ namespace svt {
 //            decision and every sum stay in the genotype kernel.  `code << 3` is the byte offset of
 //            the bin, and the MAPQs sit on byte boundaries, so the kernel turns every field into an LDS
 //            address with one instruction.
-//   reference-read entries (ref_seq)         2 bytes: mapq0, mapq1 -- seven per row slot (bytes 0..13), byte 14
+//   reference-read entries (ref_seq)         2 bytes: mapq0, mapq1 -- seven per row slot (bytes 0..13); byte 14
 //                                            of the slot holds their seven first_of_fragment bits
-//   candidate entries (alt_seq / alt_clip)   mapq0 | mapq1 << 8 | first_of_fragment << 16 | is_clip << 17
+//   candidate entries (alt_seq / alt_clip)   the same, plus their seven is_clip bits in byte 15
 //     the two gated MAPQs of the reference reads (rs_a, rs_b), of the split candidate (seq_l, seq_r)
 //     or of the clip candidate (clip_l, clip_r); first_of_fragment marks the first kept entry for its
 //     tally in a read-fragment (sso association: fragment-local sums).
@@ -172,12 +172,13 @@ __global__ __launch_bounds__(kBlock) void svt_repack_dense_kernel(const RepackAr
     }
 }
 
-// seven 2-byte reference-read entries + their first-of-fragment bits per 16-byte row slot of the lane
-struct RefRowWriter {
+// seven 2-byte MAPQ-pair entries per 16-byte row slot of the lane: bytes 0..13; bit k of byte 14 = entry k
+// is the first kept one of its fragment; bit k of byte 15 = entry k is a clip candidate (candidate stream)
+struct WeightRowWriter {
     uint4* out;       // row 0 of this lane
     uint32_t n = 0;   // entries so far
     uint32_t w[4] = {0u, 0u, 0u, 0u};
-    __device__ __forceinline__ void put(const uint32_t mapq_pair, const bool first)
+    __device__ __forceinline__ void put(const uint32_t mapq_pair, const bool first, const bool clip = false)
     {
         const uint32_t k = n % 7u;
         const uint32_t half = mapq_pair << ((k & 1u) * 16u);
@@ -188,6 +189,7 @@ struct RefRowWriter {
         default: w[3] |= half;        // k == 6: low half of the last dword
         }
         if (first) w[3] |= 1u << (16u + k);
+        if (clip) w[3] |= 1u << (24u + k);
         if (k == 6u) {
             out[(uint64_t)(n / 7u) * kWave] = make_uint4(w[0], w[1], w[2], w[3]);
             w[0] = w[1] = w[2] = w[3] = 0u;
@@ -245,8 +247,8 @@ __global__ __launch_bounds__(kBlock) void svt_repack_compact_kernel(const Repack
     const uint32_t lib_min = (h.packed >> 16) & 0xffu;
     uint4* row0 = a.tiled + td.base + lane;
     RowWriter P{row0};
-    RefRowWriter R{row0 + (uint64_t)td.rows[kPairs] * kWave};
-    RowWriter X{row0 + (uint64_t)(td.rows[kPairs] + td.rows[kRefReads]) * kWave};
+    WeightRowWriter R{row0 + (uint64_t)td.rows[kPairs] * kWave};
+    WeightRowWriter X{row0 + (uint64_t)(td.rows[kPairs] + td.rows[kRefReads]) * kWave};
     bool frag_has[3] = {false, false, false};  // did the current fragment already emit an entry for this tally?
     for (uint32_t j = 0; j < nrec; ++j) {
         const uint4 w = a.csr[src + j];
@@ -268,7 +270,7 @@ __global__ __launch_bounds__(kBlock) void svt_repack_compact_kernel(const Repack
 #pragma unroll
         for (int s = 1; s < 3; ++s)
             if (k[s]) {
-                X.put(k[s] | (frag_has[s] ? 0u : (1u << 16)) | ((uint32_t)(s - 1) << 17));
+                X.put(k[s], !frag_has[s], s == 2);
                 frag_has[s] = true;
             }
     }
