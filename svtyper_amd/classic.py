@@ -15,7 +15,7 @@ import json
 import logging
 import os
 import sys
-from typing import List, Optional
+from typing import List
 
 from . import __version__
 from . import evidence as ev

@@ -11,7 +11,7 @@ One process per GPU, `torch.distributed` for the rendezvous and the collective o
 """
 from __future__ import annotations
 
-from typing import List, Optional, Tuple
+from typing import List, Tuple
 
 import numpy as np
 

@@ -12,7 +12,7 @@ from typing import Optional
 
 import numpy as np
 
-from .evidence import CEvidenceBatch, EvidenceBatch, RESULT_DTYPE, Results
+from .evidence import CEvidenceBatch, EvidenceBatch, Results
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SVTYPER_HIP_LIB") or os.path.join(_HERE, "csrc", "libsvtyper_hip.so")

@@ -9,7 +9,7 @@ Python object is created at all.
 from __future__ import annotations
 
 import ctypes as C
-from typing import Dict, List, Optional, Sequence, Tuple
+from typing import Dict, Optional, Sequence, Tuple
 
 import numpy as np
 

@@ -13,7 +13,6 @@ through the same seam.
 """
 from __future__ import annotations
 
-import sys
 from typing import Callable, Dict, List, Optional, Tuple
 
 from . import evidence as ev
@@ -185,7 +184,7 @@ class NativeUnitCollector:
     def _run_sites(self, sites: List[dict], engine: Engine, flags: int, kw: dict) -> Results:
         import numpy as np
         from .geometry import FragmentBatch, breakpoint_record
-        from .native_reads import COUNT_SSO, FETCH_DTYPE
+        from .native_reads import FETCH_DTYPE
         n_samp = len(self.samples)
         n_sites = len(sites)
         if n_sites == 0:
