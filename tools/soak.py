@@ -1,0 +1,57 @@
+#!/usr/bin/env python
+"""Differential soak: many random batches (random libraries, weights, flags, layouts) through the HIP path
+and the C oracle; stops at the first difference.  Usage: tools/soak.py [seconds]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import test_hip_parity as P
+from oracle import c_oracle
+from svtyper_amd import evidence as ev, hip, synth
+import bench
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+t0, it, units = time.time(), 0, 0
+fixture = bench.fixture_library()
+while time.time() - t0 < budget:
+    rng = np.random.default_rng(1000 + it)
+    n_libs = int(rng.choice([1, 1, 2, 3, 5, 12]))
+    libs = [fixture if (k == 0 and rng.random() < 0.5) else
+            synth.normal_library(float(rng.uniform(150, 900)), float(rng.uniform(15, 260)), n=int(rng.integers(3000, 60000)),
+                                 seed=int(rng.integers(1 << 30))) for k in range(n_libs)]
+    kind = it % 4
+    if kind == 0:
+        b = P._fuzz_batch(5000 + it, libs, wide=bool(rng.integers(2)))
+    elif kind == 1:
+        b = synth.make_units(int(rng.integers(1, 30000)), 7000 + it, libs, svtype_mix=tuple(rng.dirichlet([2, 1, 1, 1])),
+                             mean_frags=float(rng.uniform(5, 180)), sd_frags=float(rng.uniform(1, 60)), min_frags=0,
+                             max_frags=int(rng.integers(60, 600)), frac_empty=0.02, frac_skip=0.01,
+                             split_weight=float(rng.choice([1.0, 1.0, 0.5, 2.3])), disc_weight=float(rng.choice([1.0, 1.0, 0.25, 3.0])))
+    elif kind == 2:
+        b = synth.make_edge_cases(libs, seed=it)
+    else:   # random bytes again, but inside what the compact layout can express: it must not fall back
+        b = P._fuzz_batch(9000 + it, libs, wide=False)
+        b.units["var_length"] = np.abs(b.units["var_length"])
+        off = b.rec_offset.astype(np.int64)
+        unit_of = np.repeat(np.arange(b.n_units), np.diff(off))
+        base = rng.integers(0, max(1, n_libs - 3), b.n_units)
+        lib = base[unit_of] + rng.integers(0, min(4, n_libs), b.n_records)
+        fl = b.records["flags"] & ~np.uint32(0xff << ev.REC_LIB_SHIFT)
+        b.records["flags"] = fl | (lib.astype(np.uint32) << ev.REC_LIB_SHIFT)
+        if n_libs > 1:
+            b.records["mapq_a"] &= 0x7f
+            b.records["mapq_b"] &= 0x7f
+        if all(len(l.hist) <= 4095 for l in libs):
+            with hip.DeviceBatch(b, 0, 0) as d:
+                assert d.layout()[0], "expected the compact layout"
+    for flags in P.ALL_FLAGS:
+        got = hip.genotype_batch(b, 0, flags)
+        want = c_oracle.genotype_batch(b, flags & ev.FLAG_SSO_ASSOCIATION)
+        try:
+            P.assert_parity(got, want)
+        except AssertionError as e:
+            print("MISMATCH at iteration %d (kind %d, %d libs, flags %d): %s" % (it, kind, n_libs, flags, e))
+            sys.exit(1)
+    it += 1
+    units += b.n_units
+print("soak ok: %d batches, %d units, 4 flag combinations each, %.0f s" % (it, units, time.time() - t0))
