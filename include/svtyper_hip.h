@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SVT_ABI_VERSION 5
+#define SVT_ABI_VERSION 6
 
 /* ---- error codes (0 = ok, <0 = error; text via svt_last_error()) ---------- */
 #define SVT_OK 0
@@ -340,6 +340,24 @@ int svt_batch_create_from_fragments(const svt_fragment_batch* in, int device, un
  * `qual_out` (host) receives n_sites doubles.                                                  */
 int svt_batch_site_qual(svt_batch* b, uint32_t n_samples, const double* initial, double* qual_out,
                         uint64_t n_sites);
+
+/* ---- host-side helper: result records -> text of VCF sample columns ---------------------------
+ * The values the reference writes per sample (svtyper/classic.py:454-513, singlesample.py:207-227,
+ * 430-471) joined with ':' in the order `fields` gives (the FORMAT order of the VCF header), for every
+ * unit: GT "0/0|0/1|1/1|./.", GQ int or ".", SQ "%0.2f" or ".", GL "%.0f,%.0f,%.0f" or ".", the ten
+ * integer counts, AB "%.2g" or ".".  SVT_FMT_ABSENT prints "." (a FORMAT key this sample has no value
+ * for).  skipped_as_dots != 0: a unit with GT code SVT_GT_SKIPPED prints "./." and "." for everything
+ * else (classic.py:282-284); 0: it prints the blank result like SVT_GT_BLANK (singlesample.py:207-227).
+ * text_out / offsets_out (n_units + 1 offsets into the text, no terminators) are malloc'ed: release
+ * with svt_format_free.  No GPU is involved.                                                        */
+enum svt_format_field {
+    SVT_FMT_GT = 0, SVT_FMT_GQ, SVT_FMT_SQ, SVT_FMT_GL, SVT_FMT_DP, SVT_FMT_RO, SVT_FMT_AO, SVT_FMT_QR,
+    SVT_FMT_QA, SVT_FMT_RS, SVT_FMT_AS, SVT_FMT_ASC, SVT_FMT_RP, SVT_FMT_AP, SVT_FMT_AB,
+    SVT_N_FORMAT_FIELDS, SVT_FMT_ABSENT = 255
+};
+int svt_format_results(const svt_result* res, uint64_t n_units, const uint8_t* fields, uint32_t n_fields,
+                       int skipped_as_dots, char** text_out, uint64_t** offsets_out);
+void svt_format_free(char* text, uint64_t* offsets);
 
 /* Array form of the reference's inner operator seam statistics.bayes_gt(ref, alt, is_dup)
  * (svtyper/statistics.py:23-37) and log_choose(ref + alt, alt) (statistics.py:9-20):

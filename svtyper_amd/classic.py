@@ -21,7 +21,7 @@ from . import __version__
 from . import evidence as ev
 from .bam import open_alignment_file
 from .library import Sample, setup_sample, write_sample_json
-from .pipeline import (MIN_LIB_PREVALENCE, ChunkPipeline, NativeUnitCollector, UnitCollector, add_read_to,
+from .pipeline import (MIN_LIB_PREVALENCE, ChunkPipeline, NativeUnitCollector, SampleColumnWriter, UnitCollector, add_read_to,
                        default_engine, fetch_window)
 from .results import results_to_dicts
 from .vcf import VALID_SVTYPES, Variant, Vcf
@@ -116,15 +116,41 @@ def sv_genotype(bam_string, vcf_in, vcf_out, min_aligned, split_weight, disc_wei
         quals = [float(a[1].qual) for a in actions if a[0] == "gt"]      # incoming QUAL (0 unless --sum_quals)
         pipe.submit(collector.take(engine, 0, site_quals=quals), lambda results: write_out(results, actions))
 
+    fast: list = []     # SampleColumnWriter, made once the header is known
+
     def write_out(results, actions):
-        dicts = results_to_dicts(results)
         gts = results.gt.tolist()
         site_qual = None if results.site_qual is None else results.site_qual.tolist()
+        n_samp = len(samples)
+        columns = sqs = dicts = None
         for action in actions:
             if action[0] == "raw":
                 vcf_out.write(action[1].get_var_string() + "\n")
                 continue
             _, var, var2, first_unit = action
+            unit_gts = gts[first_unit:first_unit + n_samp]
+            if (not debug and fast and fast[0].eligible(var)
+                    and any(g != ev.GT_SKIPPED for g in unit_gts)):
+                # bulk path: the sample columns of the whole chunk were formatted in one native call
+                if columns is None:
+                    columns = fast[0].columns(results)
+                    sqs = results.sq.tolist()
+                if site_qual is not None:
+                    var.qual = site_qual[first_unit // n_samp]
+                else:
+                    for k, g in enumerate(unit_gts):           # classic.py:485,498
+                        if g >= 0:
+                            var.qual += sqs[first_unit + k]
+                        elif g == ev.GT_BLANK:
+                            var.qual = 0
+                cols = columns[first_unit:first_unit + n_samp]
+                vcf_out.write(var.get_var_string_with(fast[0].format_string, cols) + "\n")
+                if var2 is not None:               # BND: second mate carries the same QUAL and genotypes
+                    var2.qual = var.qual
+                    vcf_out.write(var2.get_var_string_with(fast[0].format_string, cols) + "\n")
+                continue
+            if dicts is None:
+                dicts = results_to_dicts(results)
             for k, sample in enumerate(samples):
                 if debug:
                     _debug_print(results.rec[first_unit + k])
@@ -148,6 +174,7 @@ def sv_genotype(bam_string, vcf_in, vcf_out, min_aligned, split_weight, disc_wei
                 if sample.name not in vcf.sample_list:
                     vcf.add_sample(sample.name)
             vcf_out.write(vcf.get_header() + "\n")
+            fast.append(SampleColumnWriter(vcf, [s.name for s in samples], skipped_as_dots=True))
 
         var = Variant(line.rstrip().split("\t"), vcf)
         if not sum_quals:

@@ -16,7 +16,7 @@ from .evidence import CEvidenceBatch, EvidenceBatch, Results
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SVTYPER_HIP_LIB") or os.path.join(_HERE, "csrc", "libsvtyper_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 EXPORTS = (
     "svt_version", "svt_device_count", "svt_last_error", "svt_batch_create", "svt_batch_create_from_fragments",
@@ -24,6 +24,7 @@ EXPORTS = (
     "svt_batch_genotype_n", "svt_batch_genotype_timed", "svt_batch_results", "svt_batch_device_results",
     "svt_batch_bind_device_results", "svt_batch_bytes", "svt_batch_layout", "svt_batch_site_qual",
     "svt_batch_stream", "svt_batch_destroy", "svt_trim", "svt_bayes_gt", "svt_genotype",
+    "svt_format_results", "svt_format_free",
 )
 
 _lib: Optional[C.CDLL] = None
@@ -73,6 +74,11 @@ def load() -> C.CDLL:
     L.svt_batch_device_results.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
     L.svt_batch_bind_device_results.restype = C.c_int
     L.svt_batch_bind_device_results.argtypes = [C.c_void_p, C.c_void_p]
+    L.svt_format_results.restype = C.c_int
+    L.svt_format_results.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_int, C.POINTER(C.c_void_p),
+                                     C.POINTER(C.c_void_p)]
+    L.svt_format_free.restype = None
+    L.svt_format_free.argtypes = [C.c_void_p, C.c_void_p]
     L.svt_batch_site_qual.restype = C.c_int
     L.svt_batch_site_qual.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64]
     L.svt_batch_layout.restype = C.c_int
@@ -238,6 +244,28 @@ def genotype_batch(batch: EvidenceBatch, device: int = 0, flags: int = 0, site_q
     cb = batch.as_c()
     _check(L.svt_genotype(C.byref(cb), C.c_void_p(out.ptr()), int(device), int(flags)))
     return out
+
+
+FORMAT_CODES = {name: i for i, name in enumerate(
+    ("GT", "GQ", "SQ", "GL", "DP", "RO", "AO", "QR", "QA", "RS", "AS", "ASC", "RP", "AP", "AB"))}
+FORMAT_ABSENT = 255
+
+
+def format_results(results: Results, fields, skipped_as_dots: bool):
+    """svt_format_results: the text of every unit's VCF sample column for the FORMAT keys `fields` (names; a
+    key outside the fifteen svtyper ones prints '.'), as a list of str.  Host-only (no GPU needed)."""
+    L = load()
+    codes = np.array([FORMAT_CODES.get(f, FORMAT_ABSENT) for f in fields], dtype=np.uint8)
+    n = results.n_units
+    text, off = C.c_void_p(), C.c_void_p()
+    _check(L.svt_format_results(C.c_void_p(results.ptr()), n, codes.ctypes.data, len(codes), 1 if skipped_as_dots else 0,
+                                C.byref(text), C.byref(off)))
+    try:
+        o = np.ctypeslib.as_array(C.cast(off, C.POINTER(C.c_uint64)), shape=(n + 1,)).tolist()
+        blob = C.string_at(text, o[-1]).decode("ascii")
+        return [blob[o[i]:o[i + 1]] for i in range(n)]
+    finally:
+        L.svt_format_free(text, off)
 
 
 def bayes_gt_array(ref, alt, is_dup, device: int = 0):

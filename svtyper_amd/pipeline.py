@@ -243,6 +243,42 @@ class NativeUnitCollector:
         return engine.genotype_fragments(fb, flags, **kw)
 
 
+SVTYPER_FORMAT_KEYS = ("GT", "GQ", "SQ", "GL", "DP", "RO", "AO", "QR", "QA", "RS", "AS", "ASC", "RP", "AP", "AB")
+
+
+class SampleColumnWriter:
+    """Sample columns of a whole chunk as text in one native call (svt_format_results) instead of one dict,
+    fifteen set_format calls and a join per sample.  It applies to a variant when every sample column of the
+    VCF is written by this run, in this order, and carries nothing but a GT so far (sites-only input, the
+    svtools workflow); anything else -- other samples' columns, FORMAT keys of other tools with values --
+    keeps the general Genotype path, which prints the same bytes."""
+
+    def __init__(self, vcf, sample_names, skipped_as_dots: bool):
+        self._skipped_as_dots = skipped_as_dots
+        self._ours = frozenset(SVTYPER_FORMAT_KEYS)
+        self.enabled = (list(vcf.sample_list) == list(sample_names)
+                        and all(k in vcf.format_rank for k in SVTYPER_FORMAT_KEYS))
+        self.fields = sorted(SVTYPER_FORMAT_KEYS, key=lambda k: vcf.format_rank.get(k, 0))
+        self.format_string = ":".join(self.fields)
+
+    def eligible(self, variant) -> bool:
+        if not self.enabled:
+            return False
+        ours = self._ours
+        for f in variant.active_formats:
+            if f not in ours:
+                return False
+        for g in variant.gts.values():
+            if len(g.format) != 1:
+                return False
+        return True
+
+    def columns(self, results) -> list:
+        """one string per unit of `results`"""
+        from . import hip
+        return hip.format_results(results, self.fields, self._skipped_as_dots)
+
+
 class ChunkPipeline:
     """Chunk-level double buffering of the drivers (svtyper/singlesample.py:710-762 re-cast): the job of
     chunk k -- C++ fetch/summarise or packing, H2D, kernels, D2H, all outside the GIL -- runs on a worker

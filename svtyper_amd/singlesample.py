@@ -20,7 +20,7 @@ from . import __version__
 from . import evidence as ev
 from .bam import open_alignment_file
 from .library import Sample, setup_sample, write_sample_json
-from .pipeline import (MIN_LIB_PREVALENCE, ChunkPipeline, NativeUnitCollector, UnitCollector, add_read_to,
+from .pipeline import (MIN_LIB_PREVALENCE, ChunkPipeline, NativeUnitCollector, SampleColumnWriter, UnitCollector, add_read_to,
                        default_engine, fetch_window)
 from .results import results_to_dicts
 from .vcf import Variant, Vcf
@@ -131,13 +131,29 @@ def sso_genotype(bam_string, vcf_in, vcf_out, min_aligned, split_weight, disc_we
         pending.clear()
         pipe.submit(collector.take(engine, ev.FLAG_SSO_ASSOCIATION), lambda results: write_out(results, actions))
 
+    fast = SampleColumnWriter(vcf, [sample.name], skipped_as_dots=False)
+
     def write_out(results, actions):
-        dicts = results_to_dicts(results)   # blank for "no evidence" and "too many reads" alike
+        columns = gts = sqs = dicts = None
         for action in actions:
             if action[0] == "raw":
                 action[1].write(vcf_out)
                 continue
             _, variant, variant2, unit = action
+            if fast.eligible(variant):
+                # bulk path: the sample column of every unit of the chunk was formatted in one native call
+                if columns is None:
+                    columns, gts, sqs = fast.columns(results), results.gt.tolist(), results.sq.tolist()
+                if gts[unit] >= 0:
+                    variant.qual += sqs[unit]          # singlesample.py:544-546
+                cols = columns[unit:unit + 1]
+                print(variant.get_var_string_with(fast.format_string, cols), file=vcf_out)
+                if variant2 is not None:
+                    variant2.qual = variant.qual
+                    print(variant2.get_var_string_with(fast.format_string, cols), file=vcf_out)
+                continue
+            if dicts is None:
+                dicts = results_to_dicts(results)   # blank for "no evidence" and "too many reads" alike
             assign_genotype(variant, sample.name, dicts[unit])
             variant.write(vcf_out)
             if variant2 is not None:

@@ -266,6 +266,12 @@ class Variant:
             self.get_info_string(), self.get_format_string(),
             "\t".join(self.genotype(s).get_gt_string() for s in self.sample_list)))
 
+    def get_var_string_with(self, format_string: str, sample_columns) -> str:
+        """get_var_string() with the FORMAT column and the sample columns supplied as ready text (the bulk
+        formatter of pipeline.SampleColumnWriter); the eight fixed columns are printed as always."""
+        return "\t".join((self.chrom, str(self.pos), self.var_id, self.ref, self.alt, "%0.2f" % self.qual, self.filter,
+                          self.get_info_string(), format_string, "\t".join(sample_columns)))
+
     def write(self, fd=None):
         print(self.get_var_string(), file=fd if fd is not None else sys.stdout)
 

@@ -84,6 +84,27 @@ def test_small_chunks_through_the_chunk_pipeline(tmp_path, monkeypatch, driver):
     assert len(calls) >= 12 and max(calls) <= 17
 
 
+@pytest.mark.parametrize("driver", ["classic", "sso"])
+def test_bulk_sample_columns_and_general_path_write_the_same_bytes(tmp_path, monkeypatch, driver):
+    """The fixture is a sites-only VCF, so the drivers take the bulk formatter (svt_format_results); with it
+    switched off the per-sample Genotype path must produce the same file (== the reference's output)."""
+    from svtyper_amd import pipeline
+    calls = []
+    orig = pipeline.SampleColumnWriter.columns
+    monkeypatch.setattr(pipeline.SampleColumnWriter, "columns", lambda self, r: (calls.append(r.n_units), orig(self, r))[1])
+    run = (lambda out: run_classic(out, oracle_engine)) if driver == "classic" else (lambda out: run_sso(out, oracle_engine, None))
+    bulk = str(tmp_path / "bulk.vcf")
+    run(bulk)
+    assert calls, "the bulk formatter was not used"
+    same_vcf(EXPECTED, bulk)
+    monkeypatch.setattr(pipeline.SampleColumnWriter, "eligible", lambda self, v: False)
+    n = len(calls)
+    general = str(tmp_path / "general.vcf")
+    run(general)
+    assert len(calls) == n
+    same_vcf(EXPECTED, general)
+
+
 def test_chunk_pipeline_orders_results_and_surfaces_errors():
     from svtyper_amd.pipeline import ChunkPipeline
     import time

@@ -85,12 +85,12 @@ def test_summaries_equal_python(setup, mode, max_reads, threads):
 # hard clips, insertions, deletions, N gaps, several SA entries, secondary / supplementary /
 # duplicate / unmapped flags, MAPQ 255, B-typed tags in front of the ones that matter
 # ------------------------------------------------------------------------------------------
-def _synthetic_bam(path, seed=11, n_pairs=700):
+def _synthetic_bam(path, seed=11, n_pairs=700, sample="syn"):
     import bamwriter as bw
     rng = np.random.default_rng(seed)
     refs = [("1", 200_000), ("2", 100_000)]
     header = ("@HD\\tVN:1.5\\tSO:coordinate\\n@SQ\\tSN:1\\tLN:200000\\n@SQ\\tSN:2\\tLN:100000\\n"
-              "@RG\\tID:rgA\\tSM:syn\\tLB:libA\\n@RG\\tID:rgB\\tSM:syn\\tLB:libB\\n@CO\\tsynthetic\\n").replace("\\t", "\t").replace("\\n", "\n")
+              "@RG\\tID:rgA\\tSM:%s\\tLB:libA\\n@RG\\tID:rgB\\tSM:%s\\tLB:libB\\n@CO\\tsynthetic\\n" % (sample, sample)).replace("\\t", "\t").replace("\\n", "\n")
     sites = [
         {"id": "d1", "svtype": "DEL", "var_length": 800, "A": {"chrom": "1", "pos": 50_000, "ci": [-5, 5], "is_reverse": False},
          "B": {"chrom": "1", "pos": 50_800, "ci": [-5, 5], "is_reverse": True}},
@@ -150,7 +150,7 @@ def _synthetic_bam(path, seed=11, n_pairs=700):
     hist = {str(k): int(1000 * np.exp(-((k - 330) / 70.0) ** 2)) + 1 for k in range(100, 600)}
     lib = lambda nm, rgs: {"library_name": nm, "readgroups": rgs, "read_length": 100, "histogram": hist, "mean": 330.0,
                            "sd": 50.0, "prevalence": 0.5}
-    info = {"syn": {"mapped": len(recs), "unmapped": 0, "bam": path, "sample_name": "syn",
+    info = {sample: {"mapped": len(recs), "unmapped": 0, "bam": path, "sample_name": sample,
                     "libraryArray": [lib("libA", ["rgA"]), lib("libB", ["rgB"])]}}
     return [{"breakpoint": bp} for bp in sites], info
 
