@@ -26,7 +26,7 @@ from .pipeline import (MIN_LIB_PREVALENCE, ChunkPipeline, NativeUnitCollector, S
 from .results import results_to_dicts
 from .vcf import VALID_SVTYPES, Variant, Vcf
 
-CHUNK_UNITS = 200_000   # (breakpoint, sample) units per device batch
+CHUNK_UNITS = 50_000    # (breakpoint, sample) units per device batch: small enough to overlap chunks (ChunkPipeline)
 
 
 def gather_all_reads(sample: Sample, bp: dict, max_reads):

@@ -865,7 +865,9 @@ int svt_bam_summarise(const svt_bam* bam, const svt_summarise_args* args, svt_su
     };
     std::vector<UnitSpan> outs(n);
     constexpr uint64_t kUnitsPerGrab = 16;
-    unsigned nt = args->n_threads > 0 ? (unsigned)args->n_threads : svt::usable_cpus();
+    // by default one usable CPU is left to the caller's other thread (the drivers parse the next chunk of the
+    // VCF while this runs: pipeline.ChunkPipeline)
+    unsigned nt = args->n_threads > 0 ? (unsigned)args->n_threads : std::max(1u, svt::usable_cpus() - 1u);
     nt = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(nt ? nt : 1, n ? n : 1));
     std::atomic<uint64_t> next(0);
     std::atomic<int> first_rc(SVT_OK);

@@ -226,21 +226,22 @@ class NativeUnitCollector:
             rgs, idx = self.rg_tables[k]
             off, frags, skipped = nbam.summarise(win, bps, rgs, idx, self.max_reads, self.count_mode, self.n_threads)
             bps["flags"] |= np.where(skipped != 0, 4, 0).astype(np.uint8)   # SVT_BP_SKIP
-            per_sample.append((bps, off, frags))
-        if n_samp == 1:
-            bps, off, frags = per_sample[0]
-        else:   # interleave: units are site-major, sample-minor
-            bps = np.stack([p[0] for p in per_sample], axis=1).reshape(-1)
-            counts = np.stack([np.diff(p[1].astype(np.int64)) for p in per_sample], axis=1).reshape(-1)
-            off = np.concatenate([[0], np.cumsum(counts)]).astype(np.uint64)
-            parts = []
-            for i in range(n_sites):
-                for _, o, f in per_sample:
-                    parts.append(f[int(o[i]):int(o[i + 1])])
-            frags = np.concatenate(parts) if parts else per_sample[0][2][:0]
-        fb = FragmentBatch(off, bps, frags, self.lib_tables, self.split_weight, self.disc_weight, self.min_aligned,
-                           SPLIT_SLOP)
-        return engine.genotype_fragments(fb, flags, **kw)
+            fb = FragmentBatch(off, bps, frags, self.lib_tables, self.split_weight, self.disc_weight, self.min_aligned,
+                               SPLIT_SLOP)
+            if n_samp == 1:
+                return engine.genotype_fragments(fb, flags, **kw)
+            # one device batch per sample: the summaries go to the GPU as the reader produced them (no
+            # re-interleaving of ~13 KB per unit on the host)
+            per_sample.append(engine.genotype_fragments(fb, flags).rec)
+        # units are site-major, sample-minor for the caller: interleave the 128-byte result records
+        res = Results(np.stack(per_sample, axis=1).reshape(-1))
+        if "site_qual" in kw:      # QUAL over the samples of a site, in -B order (classic.py:216-217,485,498):
+            q = np.array(kw["site_qual"][1], dtype=np.float64, copy=True)   # the same adds, vectorised over the sites
+            for rec in per_sample:
+                gt = rec["gt"]
+                q = np.where(gt >= 0, q + rec["sq"], np.where(gt == ev.GT_BLANK, 0.0, q))
+            res.site_qual = q
+        return res
 
 
 SVTYPER_FORMAT_KEYS = ("GT", "GQ", "SQ", "GL", "DP", "RO", "AO", "QR", "QA", "RS", "AS", "ASC", "RP", "AP", "AB")

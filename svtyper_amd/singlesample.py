@@ -25,7 +25,7 @@ from .pipeline import (MIN_LIB_PREVALENCE, ChunkPipeline, NativeUnitCollector, S
 from .results import results_to_dicts
 from .vcf import Variant, Vcf
 
-CHUNK_UNITS = 200_000
+CHUNK_UNITS = 50_000    # (breakpoint, sample) units per device batch: small enough to overlap chunks (ChunkPipeline)
 _ASSIGN_ORDER = ("GT", "GQ", "SQ", "GL", "DP", "AO", "RO", "AS", "ASC", "RS", "AP", "RP", "QR", "QA", "AB")
 
 
