@@ -258,12 +258,24 @@ struct Piece {
     QueryPos qp;
 };
 
-struct ReadInfo {
+struct ReadInfo {                // what a primary read contributes to a summary (svt_read_summary)
     int32_t tid = -1;
     int64_t start = 0, end = 0;
     bool reverse = false;
     int mapq = 0;
-    std::vector<std::pair<int64_t, int64_t>> intervals;   // maximal gap-free aligned reference intervals
+    int n_iv = 0;                // the (at most two) gap-free aligned intervals closest to the unit's breakends
+    int64_t iv_start[2] = {0, 0}, iv_end[2] = {0, 0};
+};
+
+struct PieceOut {                // what a split piece contributes to a summary (svt_piece_summary)
+    int32_t tid = 0;
+    int64_t start = 0, end = 0, mapq = 0;
+    bool reverse = false;
+};
+
+struct SplitOut {
+    bool soft = false;
+    PieceOut left, right;
 };
 
 struct Split {
@@ -271,12 +283,23 @@ struct Split {
     Piece left, right;
 };
 
-struct Fragment {
+struct Fragment {                // reused from unit to unit (its vectors keep their capacity)
     int lib = 0;
     int num_primary = 0;
-    std::set<uint16_t> seen;          // flags already added under this query name (parsers.py:748-754)
+    uint32_t name_off = 0, name_len = 0;   // query name in the workspace's name arena
+    std::vector<uint16_t> seen;            // flags already added under this query name (parsers.py:748-754)
     std::vector<ReadInfo> primaries;
-    std::vector<Split> splits;
+    std::vector<SplitOut> splits;
+    void reset(int library, uint32_t off, uint32_t len)
+    {
+        lib = library;
+        num_primary = 0;
+        name_off = off;
+        name_len = len;
+        seen.clear();
+        primaries.clear();
+        splits.clear();
+    }
 };
 
 struct Record {               // one BAM alignment, decoded as far as the path needs
@@ -451,6 +474,10 @@ int split_candidate(const svt_bam& bam, const Record& r, Split& out)
     bool malformed = false;
     const char* sa = find_z_tag(r, 'S', 'A', &malformed);
     if (malformed) return -1;
+    if (!sa) {   // the common read: no SA tag and no clipped end -> not a candidate, nothing to build
+        if (r.cigar.empty()) return -1;
+        if (!is_clip(r.cigar.front().first) && !is_clip(r.cigar.back().first)) return 0;
+    }
     Piece a;
     a.tid = r.tid;
     a.start = r.pos;
@@ -538,48 +565,66 @@ int split_candidate(const svt_bam& bam, const Record& r, Split& out)
     return 1;
 }
 
-void aligned_intervals(const Record& r, std::vector<std::pair<int64_t, int64_t>>& out)
+// Maximal gap-free aligned reference intervals of a read (geometry.aligned_intervals), reduced to what a
+// summary keeps: all of them when there are at most two, else the two closest to the unit's breakends in
+// the order of a stable sort by distance (geometry._read_words).
+void aligned_intervals(const Record& r, int64_t near_a, int64_t near_b, std::vector<std::pair<int64_t, int64_t>>& scratch, ReadInfo& out)
 {
-    out.clear();
+    scratch.clear();
     int64_t p = r.pos;
     bool open = false;
     for (const auto& c : r.cigar) {
         if (is_aligned(c.first)) {
-            if (!open) { out.emplace_back(p, p + c.second); open = true; }
-            else out.back().second = p + c.second;
+            if (!open) { scratch.emplace_back(p, p + c.second); open = true; }
+            else scratch.back().second = p + c.second;
             p += c.second;
         } else if (c.first == 2 || c.first == 3) {
             open = false;
             p += c.second;
         }
     }
-}
-
-inline int32_t clip32(int64_t x) { return (int32_t)std::max<int64_t>(INT32_MIN, std::min<int64_t>(INT32_MAX, x)); }
-
-void fill_read(svt_read_summary& d, const ReadInfo& r, int64_t near_a, int64_t near_b)
-{
-    d.tid = r.tid;
-    d.start = clip32(r.start);
-    d.end = clip32(r.end);
-    std::vector<std::pair<int64_t, int64_t>> ivs = r.intervals;
-    if (ivs.size() > 2) {
+    if (scratch.size() > 2) {
         auto dist = [&](const std::pair<int64_t, int64_t>& iv) {
             auto one = [&](int64_t q) { return (iv.first <= q && q <= iv.second) ? (int64_t)0 : std::min(std::llabs(iv.first - q), std::llabs(iv.second - q)); };
             return std::min(one(near_a), one(near_b));
         };
-        std::stable_sort(ivs.begin(), ivs.end(), [&](const auto& x, const auto& y) { return dist(x) < dist(y); });
-        ivs.resize(2);
+        std::stable_sort(scratch.begin(), scratch.end(), [&](const auto& x, const auto& y) { return dist(x) < dist(y); });
+        scratch.resize(2);
     }
-    for (size_t k = 0; k < ivs.size(); ++k) {
-        d.iv_start[k] = clip32(ivs[k].first);
-        d.iv_end[k] = clip32(ivs[k].second);
+    out.n_iv = (int)scratch.size();
+    for (int k = 0; k < out.n_iv; ++k) {
+        out.iv_start[k] = scratch[(size_t)k].first;
+        out.iv_end[k] = scratch[(size_t)k].second;
+    }
+}
+
+inline int32_t clip32(int64_t x) { return (int32_t)std::max<int64_t>(INT32_MIN, std::min<int64_t>(INT32_MAX, x)); }
+
+void fill_read(svt_read_summary& d, const ReadInfo& r)
+{
+    d.tid = r.tid;
+    d.start = clip32(r.start);
+    d.end = clip32(r.end);
+    for (int k = 0; k < r.n_iv; ++k) {
+        d.iv_start[k] = clip32(r.iv_start[k]);
+        d.iv_end[k] = clip32(r.iv_end[k]);
     }
     d.mapq = (uint8_t)r.mapq;
     d.flags = (uint8_t)(SVT_READ_PRESENT | (r.reverse ? SVT_READ_REVERSE : 0));
 }
 
-bool fill_piece(svt_piece_summary& d, const Piece& p)
+inline PieceOut piece_out(const Piece& p)
+{
+    PieceOut o;
+    o.tid = p.tid;
+    o.start = p.start;
+    o.end = p.end;
+    o.mapq = p.mapq;
+    o.reverse = p.reverse;
+    return o;
+}
+
+bool fill_piece(svt_piece_summary& d, const PieceOut& p)
 {
     if (p.mapq < 0 || p.mapq > 255) return false;
     d.tid = p.tid;
@@ -593,6 +638,78 @@ bool fill_piece(svt_piece_summary& d, const Piece& p)
 struct UnitOut {                       // per worker, reused for every unit it processes
     std::vector<svt_fragment> frags;
     bool skipped = false;
+};
+
+// Per-worker scratch of process_unit, reused from unit to unit so that a read costs no allocation: the
+// read-fragments of the unit (query name -> Fragment) live in a vector indexed through an open-addressing
+// hash table over a name arena, and are emitted in sorted(query_name) order at the end.
+struct Workspace {
+    std::vector<Fragment> frags;       // [0, n_frags) are live
+    size_t n_frags = 0;
+    std::vector<char> names;
+    std::vector<uint32_t> table;       // fragment index + 1, 0 = empty; size is a power of two
+    std::vector<uint32_t> order;
+    std::vector<std::pair<int64_t, int64_t>> intervals;
+    std::vector<const SplitOut*> seq, clip;
+    std::string last_rg;               // most reads of a unit share their read group
+    int32_t last_lib = 0;
+    bool have_last_rg = false;
+
+    void begin_unit()
+    {
+        n_frags = 0;
+        names.clear();
+        if (table.size() < 1024) table.assign(1024, 0u);
+        else std::fill(table.begin(), table.end(), 0u);
+    }
+    static uint64_t hash_name(const char* p, size_t n)
+    {
+        uint64_t h = 1469598103934665603ull;                  // FNV-1a
+        for (size_t i = 0; i < n; ++i) h = (h ^ (unsigned char)p[i]) * 1099511628211ull;
+        return h;
+    }
+    const char* name_of(const Fragment& f) const { return names.data() + f.name_off; }
+    // the fragment of this query name; created (with `lib`) when the name is new
+    Fragment& fragment(const std::string& name, int lib)
+    {
+        if ((n_frags + 1) * 2 > table.size()) grow();
+        const size_t mask = table.size() - 1;
+        for (size_t i = hash_name(name.data(), name.size()) & mask;; i = (i + 1) & mask) {
+            const uint32_t slot = table[i];
+            if (slot == 0u) {
+                if (n_frags == frags.size()) frags.emplace_back();
+                Fragment& f = frags[n_frags];
+                f.reset(lib, (uint32_t)names.size(), (uint32_t)name.size());
+                names.insert(names.end(), name.begin(), name.end());
+                table[i] = (uint32_t)++n_frags;
+                return f;
+            }
+            Fragment& f = frags[slot - 1];
+            if (f.name_len == name.size() && std::memcmp(name_of(f), name.data(), name.size()) == 0) return f;
+        }
+    }
+    void grow()
+    {
+        table.assign(table.size() * 2, 0u);
+        const size_t mask = table.size() - 1;
+        for (size_t k = 0; k < n_frags; ++k) {
+            size_t i = hash_name(name_of(frags[k]), frags[k].name_len) & mask;
+            while (table[i]) i = (i + 1) & mask;
+            table[i] = (uint32_t)(k + 1);
+        }
+    }
+    // live fragments in the order of Python's sorted() over their (ASCII) names
+    const std::vector<uint32_t>& sorted_order()
+    {
+        order.resize(n_frags);
+        for (size_t k = 0; k < n_frags; ++k) order[k] = (uint32_t)k;
+        std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
+            const Fragment &a = frags[x], &b = frags[y];
+            const int c = std::memcmp(name_of(a), name_of(b), std::min(a.name_len, b.name_len));
+            return c != 0 ? c < 0 : a.name_len < b.name_len;
+        });
+        return order;
+    }
 };
 
 struct UnitSpan {                      // where a finished unit's summaries wait for the gather
@@ -646,45 +763,48 @@ private:
 
 // one unit: gather reads of both windows, assemble fragments, emit summaries
 int process_unit(const svt_bam& bam, Bgzf& z, std::vector<uint8_t>& buf, const svt_summarise_args& A,
-                 const std::unordered_map<std::string, int32_t>& rg_lib, uint64_t u, UnitOut& out, std::string& err)
+                 const std::unordered_map<std::string, int32_t>& rg_lib, uint64_t u, Workspace& ws, UnitOut& out,
+                 std::string& err)
 {
     out.frags.clear();
     out.skipped = false;
     const svt_fetch_unit& w = A.windows[u];
     const int32_t tids[2] = {w.tid_a, w.tid_b};
     const int64_t los[2] = {w.lo_a, w.lo_b}, his[2] = {w.hi_a, w.hi_b};
-    std::map<std::string, Fragment> frags;   // ordered by name == Python's sorted() for ASCII names
+    const int64_t near_a = A.breakpoints[u].pos_a, near_b = A.breakpoints[u].pos_b;
+    ws.begin_unit();
     int rc = SVT_OK;
 
-    if (A.count_mode == 1 && A.max_reads >= 0) {   // singlesample.py:158-185
-        for (int s = 0; s < 2; ++s) {
-            int64_t n = 0;
-            if (!fetch(bam, z, tids[s], los[s], his[s], buf, [&](const Record& r) {
-                    if (!(r.flag & (0x4 | 0x100 | 0x200 | 0x400))) ++n;
-                    return true;
-                })) { err = "BAM read error"; return SVT_ERR_INVALID; }
-            if (n > A.max_reads) { out.skipped = true; return SVT_OK; }
-        }
-    }
+    // count_mode 1 (singlesample.py:158-185): a unit is skipped when bam.count() of either window exceeds
+    // max_reads.  count() looks at the same records the gather pass walks, so the two are one pass here: the
+    // reads of a window are counted (pysam's filter: not unmapped / secondary / QC-fail / duplicate) while
+    // they are gathered, and the unit is dropped when a window turns out to be over the limit.
+    const bool count_windows = A.count_mode == 1 && A.max_reads >= 0;
     for (int s = 0; s < 2 && !out.skipped; ++s) {
-        int64_t i = -1;
+        int64_t i = -1, n_counted = 0;
         const bool ok = fetch(bam, z, tids[s], los[s], his[s], buf, [&](const Record& r) {
             ++i;                                                        // enumerate() index of classic.py:79
+            if (count_windows && !(r.flag & (0x4 | 0x100 | 0x200 | 0x400)) && ++n_counted > A.max_reads) {
+                out.skipped = true;
+                return false;
+            }
             if (r.flag & (0x4 | 0x400)) return true;                   // unmapped / duplicate
             bool malformed = false;
             const char* rg = find_z_tag(r, 'R', 'G', &malformed);
+
             if (malformed || !rg) { err = "read without a usable RG tag: " + r.name; rc = SVT_ERR_INVALID; return false; }
-            auto it = rg_lib.find(rg);
-            if (it == rg_lib.end()) { err = std::string("read group not in the library table: ") + rg; rc = SVT_ERR_INVALID; return false; }
-            if (it->second < 0) return true;                            // library below the prevalence cut
-            if (A.count_mode == 0 && A.max_reads >= 0 && i > A.max_reads) { out.skipped = true; return false; }
-            auto fit = frags.find(r.name);
-            if (fit == frags.end()) {
-                fit = frags.emplace(r.name, Fragment()).first;
-                fit->second.lib = it->second;                           // SamFragment(read, lib)
+            if (!ws.have_last_rg || ws.last_rg != rg) {
+                auto it = rg_lib.find(rg);
+                if (it == rg_lib.end()) { err = std::string("read group not in the library table: ") + rg; rc = SVT_ERR_INVALID; return false; }
+                ws.last_rg = rg;
+                ws.last_lib = it->second;
+                ws.have_last_rg = true;
             }
-            Fragment& f = fit->second;
-            if (!f.seen.insert(r.flag).second) return true;             // same (name, flag) again
+            if (ws.last_lib < 0) return true;                           // library below the prevalence cut
+            if (A.count_mode == 0 && A.max_reads >= 0 && i > A.max_reads) { out.skipped = true; return false; }
+            Fragment& f = ws.fragment(r.name, ws.last_lib);             // SamFragment(read, lib) when new
+            if (std::find(f.seen.begin(), f.seen.end(), r.flag) != f.seen.end()) return true;   // same (name, flag) again
+            f.seen.push_back(r.flag);
             if (r.flag & (0x100 | 0x800)) return true;                  // secondary / supplementary
             ReadInfo ri;
             ri.tid = r.tid;
@@ -692,13 +812,13 @@ int process_unit(const svt_bam& bam, Bgzf& z, std::vector<uint8_t>& buf, const s
             ri.end = r.end;
             ri.reverse = (r.flag & 0x10) != 0;
             ri.mapq = r.mapq;
-            aligned_intervals(r, ri.intervals);
-            f.primaries.push_back(std::move(ri));
+            aligned_intervals(r, near_a, near_b, ws.intervals, ri);
+            f.primaries.push_back(ri);
             f.num_primary += 1;
             Split sp;
             const int v = split_candidate(bam, r, sp);
             if (v < 0) { err = "malformed SA tag / CIGAR at read " + r.name; rc = SVT_ERR_INVALID; return false; }
-            if (v > 0) f.splits.push_back(std::move(sp));
+            if (v > 0) f.splits.push_back(SplitOut{sp.soft, piece_out(sp.left), piece_out(sp.right)});
             return true;
         });
         if (rc != SVT_OK) return rc;
@@ -706,24 +826,27 @@ int process_unit(const svt_bam& bam, Bgzf& z, std::vector<uint8_t>& buf, const s
     }
     if (out.skipped) { out.frags.clear(); return SVT_OK; }
 
-    const int64_t near_a = A.breakpoints[u].pos_a, near_b = A.breakpoints[u].pos_b;
-    for (const auto& kv : frags) {
-        const Fragment& f = kv.second;
-        std::vector<const Split*> seq, clip;
-        for (const Split& s : f.splits) (s.soft ? clip : seq).push_back(&s);
-        const size_t n_rec = std::max<size_t>({(size_t)1, (f.primaries.size() + 1) / 2, seq.size(), clip.size()});
+    for (const uint32_t fi : ws.sorted_order()) {
+        const Fragment& f = ws.frags[fi];
+        ws.seq.clear();
+        ws.clip.clear();
+        for (const SplitOut& sp : f.splits) (sp.soft ? ws.clip : ws.seq).push_back(&sp);
+        const size_t n_rec = std::max<size_t>({(size_t)1, (f.primaries.size() + 1) / 2, ws.seq.size(), ws.clip.size()});
         for (size_t k = 0; k < n_rec; ++k) {
             svt_fragment fr;
             std::memset(&fr, 0, sizeof fr);
             fr.read[0].tid = fr.read[1].tid = -1;
             for (int j = 0; j < 2; ++j)
-                if (2 * k + j < f.primaries.size()) fill_read(fr.read[j], f.primaries[2 * k + j], near_a, near_b);
+                if (2 * k + j < f.primaries.size()) fill_read(fr.read[j], f.primaries[2 * k + j]);
             fr.read[0].reserved = (uint16_t)f.lib;
             fr.read[1].reserved = (uint16_t)(((k == 0 && f.num_primary == 2) ? SVT_FRAG_PAIR : 0) | (k > 0 ? SVT_FRAG_CONTINUATION : 0));
             bool ok = true;
-            if (k < seq.size()) ok = fill_piece(fr.seq[0], seq[k]->left) && fill_piece(fr.seq[1], seq[k]->right);
-            if (ok && k < clip.size()) ok = fill_piece(fr.clip[0], clip[k]->left) && fill_piece(fr.clip[1], clip[k]->right);
-            if (!ok) { err = "MAPQ outside 0..255 in an SA tag of fragment " + kv.first; return SVT_ERR_INVALID; }
+            if (k < ws.seq.size()) ok = fill_piece(fr.seq[0], ws.seq[k]->left) && fill_piece(fr.seq[1], ws.seq[k]->right);
+            if (ok && k < ws.clip.size()) ok = fill_piece(fr.clip[0], ws.clip[k]->left) && fill_piece(fr.clip[1], ws.clip[k]->right);
+            if (!ok) {
+                err = "MAPQ outside 0..255 in an SA tag of fragment " + std::string(ws.name_of(f), f.name_len);
+                return SVT_ERR_INVALID;
+            }
             out.frags.push_back(fr);
         }
     }
@@ -878,6 +1001,7 @@ int svt_bam_summarise(const svt_bam* bam, const svt_summarise_args* args, svt_su
         Bgzf z(bam->file);
         std::vector<uint8_t> buf;
         UnitOut unit;
+        Workspace ws;
         arenas[t].reset(new SummaryArena());
         if (!z.ok()) {
             std::lock_guard<std::mutex> g(err_lock);
@@ -890,7 +1014,7 @@ int svt_bam_summarise(const svt_bam* bam, const svt_summarise_args* args, svt_su
             for (uint64_t u = u0; u < std::min(n, u0 + kUnitsPerGrab); ++u) {
                 if (first_rc.load(std::memory_order_relaxed) != SVT_OK) return;
                 std::string err;
-                int rc = process_unit(*bam, z, buf, *args, rg_lib, u, unit, err);
+                int rc = process_unit(*bam, z, buf, *args, rg_lib, u, ws, unit, err);
                 if (rc == SVT_OK) {
                     outs[u].count = unit.frags.size();
                     outs[u].skipped = unit.skipped;
