@@ -13,7 +13,8 @@ namespace svt {
 // ------------------------------------------------------------------------------------------
 struct GeomArgs {
     const uint4* frags;          // svt_fragment[n_frags] viewed as 8 x uint4
-    const uint32_t* frag_unit;   // unit of every fragment summary
+    const uint64_t* frag_offset; // [n_units + 1]: the unit of fragment i is found by binary search
+    uint64_t n_units;
     const svt_breakpoint* bps;
     const LibDesc* libs;         // v_nondel = lib.mean + lib.sd * 3 is also is_pair_straddle's flank
     uint64_t n_frags;
@@ -119,7 +120,12 @@ __global__ __launch_bounds__(kBlock) void svt_geometry_kernel(const GeomArgs g)
     const ReadS rb = unpack_read(f[2], f[3]);
     const PieceS sl = unpack_piece(f[4]), sr = unpack_piece(f[5]);
     const PieceS cl = unpack_piece(f[6]), cr = unpack_piece(f[7]);
-    const svt_breakpoint bp = g.bps[g.frag_unit[i]];
+    uint64_t lo = 0, hi = g.n_units;               // largest u with frag_offset[u] <= i (units may be empty)
+    while (hi - lo > 1) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if (g.frag_offset[mid] <= i) lo = mid; else hi = mid;
+    }
+    const svt_breakpoint bp = g.bps[lo];
     const uint32_t lib = ra.extra & 0xffu;
     const bool pair_ok = (rb.extra & SVT_FRAG_PAIR) != 0;
     const bool cont = (rb.extra & SVT_FRAG_CONTINUATION) != 0;

@@ -546,9 +546,8 @@ int svt_batch_create_from_fragments(const svt_fragment_batch* in, int device, un
     if (device < 0 || device >= ndev) return fail(SVT_ERR_NO_DEVICE, "device index out of range");
     HIP_TRY(hipSetDevice(device));
 
-    // unit headers and the fragment -> unit map
+    // unit headers
     std::vector<svt_unit> units(n);
-    std::vector<uint32_t> frag_unit(n_frag);
     for (uint64_t u = 0; u < n; ++u) {
         const svt_breakpoint& bp = in->breakpoints[u];
         if (in->frag_offset[u + 1] < in->frag_offset[u]) return fail(SVT_ERR_INVALID, "frag_offset not monotone");
@@ -561,7 +560,6 @@ int svt_batch_create_from_fragments(const svt_fragment_batch* in, int device, un
         U.svtype = bp.svtype;
         U.flags = (bp.flags & SVT_BP_SKIP) ? SVT_UNIT_SKIP : 0;
         units[u] = U;
-        for (uint64_t j = in->frag_offset[u]; j < in->frag_offset[u + 1]; ++j) frag_unit[j] = (uint32_t)u;
     }
     // library descriptors (the flank of is_pair_straddle is lib.mean + lib.sd * 3)
     std::vector<LibDesc> libs(in->n_libs);
@@ -575,32 +573,42 @@ int svt_batch_create_from_fragments(const svt_fragment_batch* in, int device, un
     HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
     struct StreamGuard { hipStream_t s; ~StreamGuard() { (void)hipStreamDestroy(s); } } sg{s};
     StageTimer tm;
-    DevScratch d_frags, d_frag_unit, d_bps, d_libs, d_records, d_err;
+    // the two big buffers of this stage come from the pool svt_batch_destroy refills (svt_host_transfer.h)
+    struct Pooled {
+        int device;
+        void* p = nullptr;
+        uint64_t cap = 0;
+        ~Pooled() { g_pool.put(device, p, cap); }
+        int get(uint64_t bytes) { return g_pool.get(device, bytes, &p, &cap); }
+    } d_frags{device}, d_records{device};
+    DevScratch d_frag_off, d_bps, d_libs, d_err;
     {
         Stager st(s);
-        SVT_TRY(d_frags.alloc(n_frag * sizeof(svt_fragment)));
+        SVT_TRY(d_frags.get(n_frag * sizeof(svt_fragment)));
         SVT_TRY(st.copy(d_frags.p, in->fragments, n_frag * sizeof(svt_fragment)));
-        SVT_TRY(upload(d_frag_unit, frag_unit, st));
+        SVT_TRY(d_frag_off.alloc((n + 1) * sizeof(uint64_t)));
+        if (n) SVT_TRY(st.copy(d_frag_off.p, in->frag_offset, (n + 1) * sizeof(uint64_t)));
         SVT_TRY(d_bps.alloc(n * sizeof(svt_breakpoint)));
         SVT_TRY(st.copy(d_bps.p, in->breakpoints, n * sizeof(svt_breakpoint)));
         SVT_TRY(upload(d_libs, libs, st));
         SVT_TRY(st.finish());
         tm.mark("H2D fragment summaries + unit arrays (staged)");
     }
-    SVT_TRY(d_records.alloc(n_frag * sizeof(uint4)));
+    SVT_TRY(d_records.get(n_frag * sizeof(uint4)));
     SVT_TRY(d_err.alloc(sizeof(uint32_t)));
     HIP_TRY(hipMemsetAsync(d_err.p, 0, sizeof(uint32_t), s));
     if (n_frag) {
         GeomArgs g{};
-        g.frags = d_frags.as<uint4>();
-        g.frag_unit = d_frag_unit.as<uint32_t>();
+        g.frags = static_cast<const uint4*>(d_frags.p);
+        g.frag_offset = d_frag_off.as<uint64_t>();
+        g.n_units = n;
         g.bps = d_bps.as<svt_breakpoint>();
         g.libs = d_libs.as<LibDesc>();
         g.n_frags = n_frag;
         g.n_libs = in->n_libs;
         g.min_aligned = in->min_aligned;
         g.split_slop = in->split_slop;
-        g.records = d_records.as<uint4>();
+        g.records = static_cast<uint4*>(d_records.p);
         g.err = d_err.as<uint32_t>();
         hipLaunchKernelGGL(svt_geometry_kernel, dim3((unsigned)((n_frag + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, g);
         HIP_TRY(hipGetLastError());
@@ -632,7 +640,7 @@ int svt_batch_create_from_fragments(const svt_fragment_batch* in, int device, un
     b->compact = (flags & SVT_FLAG_DENSE_LAYOUT) == 0;
     b->n_units = n;
     b->n_records = n_frag;
-    const int rc = create_on_device(&eb, b, d_records.as<uint4>());
+    const int rc = create_on_device(&eb, b, static_cast<const uint4*>(d_records.p));
     if (rc != SVT_OK) {
         const std::string keep = g_err;
         free_batch(b);
