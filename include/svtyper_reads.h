@@ -57,7 +57,8 @@ typedef struct svt_summarise_args {
     int64_t max_reads;                  /* < 0: unlimited                                         */
     int32_t count_mode;                 /* 0: classic.py:79-93 (position of the read in the fetch of
                                            one side > max_reads); 1: singlesample.py:158-185
-                                           (bam.count() of either region > max_reads)            */
+                                           (bam.count() of either region > max_reads; counted
+                                           while the reads are gathered, same outcome)           */
     int32_t n_threads;                  /* <= 0: all hardware threads                             */
 } svt_summarise_args;
 
