@@ -88,6 +88,7 @@ class Vcf:
         self.header_misc: List[str] = []
         self.filename: Optional[str] = None
         self.format_rank: Dict[str, int] = {}
+        self.info_plans: Dict[tuple, tuple] = {}      # see Variant.get_info_string
         self._bnd_pending: Dict[str, "Variant"] = {}   # first mates waiting for their partner
         self._bnd_first: Dict[str, "Variant"] = {}     # first mates of completed pairs, by breakpoint id
         self.add_format("GT", 1, "String", "Genotype")
@@ -96,6 +97,7 @@ class Vcf:
     def add_info(self, id, number, type, desc):
         if str(id) not in [h.id for h in self.info_list]:
             self.info_list.append(HeaderLine("INFO", id, number, type, desc))
+            self.info_plans.clear()
 
     def add_alt(self, id, desc):
         if str(id) not in [h.id for h in self.alt_list]:
@@ -207,6 +209,7 @@ class Variant:
         self.info_list = vcf.info_list
         self.format_list = vcf.format_list
         self.format_rank = vcf.format_rank
+        self._info_plans = vcf.info_plans          # {tuple of INFO keys: ((key, is_flag), ...) in header order}
         self.active_formats: List[str] = []
         self.gts: Dict[str, Genotype] = {}
         if len(var_list) < 9:
@@ -250,11 +253,13 @@ class Variant:
         sys.stderr.write('Error: invalid sample name, "' + sample_name + '"\n')
 
     def get_info_string(self) -> str:
-        out = []
-        for h in self.info_list:
-            if h.id in self.info:
-                out.append(h.id if h.type == "Flag" else "%s=%s" % (h.id, self.info[h.id]))
-        return ";".join(out)
+        # header declaration order (parsers.py:346-355); the order for a given set of keys is worked out once
+        keys = tuple(self.info)
+        plan = self._info_plans.get(keys)
+        if plan is None:     # (Vcf.add_info clears the plans when a declaration is added)
+            plan = self._info_plans[keys] = tuple((h.id, h.type == "Flag") for h in self.info_list if h.id in self.info)
+        info = self.info
+        return ";".join([k if flag else "%s=%s" % (k, info[k]) for k, flag in plan])
 
     def get_format_string(self) -> str:
         # active_formats is kept in header declaration order by Genotype.set_format / set_formats
