@@ -231,7 +231,7 @@ struct RowWriter {
     }
 };
 
-// compact layout: CSR records -> the four entry streams of the tile, in record order
+// compact layout: CSR records -> the three entry streams of the tile, in record order
 __global__ __launch_bounds__(kBlock) void svt_repack_compact_kernel(const RepackArgs a)
 {
     const uint32_t wave = threadIdx.x / kWave;
