@@ -402,7 +402,7 @@ __global__ __launch_bounds__(kBlock, SVT_MIN_WAVES) void svt_genotype_kernel(con
     c.pos_delta_d = (double)h.pos_delta;
     c.lib_lo = wd.lib_lo;
     c.bin_lo = wd.bin_lo;
-    c.lib_min = (h.packed >> 16) & 0xffu;
+    c.lib_min = h.unit == kPadUnit ? wd.lib_lo : (h.packed >> 16) & 0xffu;   // padding lanes stream zero entries: keep their look-ups inside the window
     c.libx_lane = kLdsBins + a.lds_bins * (uint32_t)sizeof(Bin) + a.lds_libs * (uint32_t)sizeof(LibDesc) +
                   (c.lib_min - wd.lib_lo) * (uint32_t)sizeof(uint2);
     c.vl8 = (uint32_t)min(max(h.var_length, 0), 8191) * 8u;
