@@ -63,6 +63,7 @@ struct LaneCtx {
     uint32_t wt0, wt1;    // compact: LDS address of the decision-table rows for p_concordant = 0 / 1
     uint32_t lib_min;     // compact kMultiLds: first library of the lane's unit
     uint32_t lib_lo;      // kMultiLds: first library / first bin staged by this workgroup
+    uint32_t lib_last;    // kMultiLds: index of the last staged library inside the window
     uint32_t bin_lo;
     uint32_t libx_lane;   // compact kMultiLds: LDS address of the {bins address, n_bins * 8} pair of the
                           // lane's first library (svt_genotype_kernel stages one pair per window library)
@@ -129,7 +130,9 @@ __device__ __forceinline__ void pair_evidence(const uint32_t o, const uint32_t m
         thr1 = t.bins[i1].thr;
         h2 = t.bins[i2].hist;
     } else if (MODE == kMultiLds) {
-        const LibDesc lib = t.libs[lib_idx - c.lib_lo];
+        // (an all-zero padding record names library 0, which may lie below the window: any staged library
+        // will do for it, its MAPQ-0 weights make the contribution exactly +0.0)
+        const LibDesc lib = t.libs[min(lib_idx - c.lib_lo, c.lib_last)];
         const bool small_del = c.is_del && (c.pos_delta_d < lib.sd2);
         f3 = small_del ? 0u : f3;
         const uint32_t kmin = (uint32_t)lib.key_min;
@@ -401,6 +404,7 @@ __global__ __launch_bounds__(kBlock, SVT_MIN_WAVES) void svt_genotype_kernel(con
     c.var_length = h.var_length;
     c.pos_delta_d = (double)h.pos_delta;
     c.lib_lo = wd.lib_lo;
+    c.lib_last = wd.lib_cnt - 1u;
     c.bin_lo = wd.bin_lo;
     c.lib_min = h.unit == kPadUnit ? wd.lib_lo : (h.packed >> 16) & 0xffu;   // padding lanes stream zero entries: keep their look-ups inside the window
     c.libx_lane = kLdsBins + a.lds_bins * (uint32_t)sizeof(Bin) + a.lds_libs * (uint32_t)sizeof(LibDesc) +
