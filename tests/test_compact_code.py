@@ -1,0 +1,62 @@
+"""The algebra behind the compact pair entries (svtyper_amd/csrc/svt_prepare_kernels.h: pair_code; consumed by
+pair_entry in svt_genotype_kernel.h): one table code per entry from which the kernel gets BOTH histogram indices
+by clamping.  Exhaustive over small geometries, against the direct definition of the two look-ups
+(svtyper/parsers.py:870-878).  Pure arithmetic -- the device code itself is covered by the gpu tests
+(tests/test_hip_parity.py::test_compact_code_windows)."""
+import itertools
+
+M32 = (1 << 32) - 1
+
+
+def pair_code(ospan_len, key_min, n_bins, is_del, var_length):
+    """mirror of the device function"""
+    r = ospan_len - key_min
+    in1 = 0 <= r < n_bins
+    far = 2 * n_bins
+    if not is_del:
+        return r if in1 else far
+    r2 = r - var_length
+    in2 = 0 <= r2 < n_bins
+    if var_length < n_bins:
+        return r if 0 <= r < var_length + n_bins else far
+    return r if in1 else (n_bins + r2 if in2 else far)
+
+
+def kernel_indices(code, n_bins, is_del, var_length):
+    """what pair_entry computes (in bins; the kernel works in bytes = bins * 8, unsigned 32-bit)"""
+    off2 = min(var_length, n_bins) if is_del else 0x80000000 // 8
+    i1 = min(code, n_bins)
+    i2 = min((code - off2) & M32, n_bins)
+    return i1, i2
+
+
+def direct_indices(ospan_len, key_min, n_bins, is_del, var_length):
+    """hist[o] and hist[o - var_length] of parsers.py:870-878, out-of-range -> the sentinel bin n_bins"""
+    r = ospan_len - key_min
+    i1 = r if 0 <= r < n_bins else n_bins
+    r2 = r - var_length
+    i2 = r2 if (is_del and 0 <= r2 < n_bins) else n_bins
+    return i1, i2
+
+
+def test_code_gives_both_table_indices():
+    checked = 0
+    for n_bins, key_min in itertools.product((1, 2, 3, 7, 16, 33), (0, 2, 5)):
+        for is_del in (False, True):
+            for var_length in ((0,) if not is_del else (0, 1, 2, n_bins - 1, n_bins, n_bins + 1, 2 * n_bins, 5 * n_bins + 3, 1000)):
+                if var_length < 0:
+                    continue
+                for ospan_len in range(0, key_min + max(var_length, 0) + 2 * n_bins + 8):
+                    code = pair_code(ospan_len, key_min, n_bins, is_del, var_length)
+                    assert 0 <= code <= 2 * n_bins                      # fits the 13-bit field for n_bins <= 4095
+                    got = kernel_indices(code, n_bins, is_del, var_length)
+                    want = direct_indices(ospan_len, key_min, n_bins, is_del, var_length)
+                    assert got == want, (n_bins, key_min, is_del, var_length, ospan_len, code)
+                    checked += 1
+    assert checked > 10000
+
+
+def test_far_spans_take_the_sentinel():
+    for ospan_len in (0, 1, 10**6, 2**31 - 1):
+        code = pair_code(ospan_len, 100, 50, True, 10**5)
+        assert kernel_indices(code, 50, True, 10**5) == direct_indices(ospan_len, 100, 50, True, 10**5)
