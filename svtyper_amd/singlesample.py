@@ -229,9 +229,9 @@ def get_args():
     p.add_argument("--batch_size", type=int, metavar="INT", default=1000,
                    help="accepted for compatibility with the reference's worker batches")
     # not in the reference: where the host work runs (same output bytes either way)
-    p.add_argument("--reader", choices=("python", "native"), default="python",
-                   help="BAM access + fragment assembly: portable Python reader, or the C++ threads of "
-                        "libsvtyper_hip.so feeding the device geometry stage [python]")
+    p.add_argument("--reader", choices=("python", "native"), default="native",
+                   help="BAM access + fragment assembly: the C++ threads of libsvtyper_hip.so feeding the device "
+                        "geometry stage, or the portable Python reader (same output bytes) [native]")
     p.add_argument("--geometry", choices=("host", "device"), default="host",
                    help="with --reader python: breakpoint-dependent read predicates on the host or on the GPU [host]")
     args = p.parse_args()
