@@ -1,0 +1,35 @@
+"""bench.py prints ONE JSON line with the keys the driver and the judge read (gpu: it runs the real path)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+def test_bench_line_has_the_contract_keys(hip_device):
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--steps", "3", "--warmup", "1", "--units", "30000",
+                        "--cpu-seconds", "1"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, "exactly one line on stdout"
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["higher_is_better"] is True
+    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic" and d["dtype"] == "f64"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    roof = d["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in roof, key
+    assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9
+    cpu = d["cpu_baseline"]
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in cpu, key
+    assert cpu["kind"] == "port" and cpu["cores"] >= 1
+    assert d["value"] > 0 and abs(d["value"] - 30000 * 3 / (d["ms_per_step"] * 3 * 1e-3)) / d["value"] < 1e-6
+    assert d["parity"]["integer_mismatches"] == 0 and d["parity"]["max_abs_dGL"] <= 1e-6 and d["parity"]["max_abs_dSQ"] <= 1e-6
