@@ -269,10 +269,7 @@ class SampleColumnWriter:
         for f in variant.active_formats:
             if f not in ours:
                 return False
-        for g in variant.gts.values():
-            if len(g.format) != 1:
-                return False
-        return True
+        return variant.only_default_genotypes()
 
     def columns(self, results) -> list:
         """one string per unit of `results`"""

@@ -211,18 +211,24 @@ class Variant:
         self.format_rank = vcf.format_rank
         self._info_plans = vcf.info_plans          # {tuple of INFO keys: ((key, is_flag), ...) in header order}
         self.active_formats: List[str] = []
-        self.gts: Dict[str, Genotype] = {}
-        if len(var_list) < 9:
-            var_list.append("GT")
-        for s in self.sample_list:
-            try:
-                col = var_list[vcf.sample_to_col(s)]
-                g = Genotype(self, s, col.split(":")[0])
-                self.gts[s] = g
-                for key, value in zip(var_list[8].split(":"), col.split(":")):
-                    g.set_format(key, value)
-            except IndexError:
-                self.gts[s] = Genotype(self, s, "./.")
+        if len(var_list) <= 9:
+            # no sample column on the line (a sites-only VCF): every sample starts as GT './.'
+            # (parsers.py:296-307 via the IndexError branch); the Genotype objects are only made when
+            # somebody asks for one -- the bulk writer of pipeline.SampleColumnWriter never does
+            self._gts: Optional[Dict[str, Genotype]] = None
+            if self.sample_list:
+                self.active_formats.append("GT")
+        else:
+            self._gts = {}
+            for s in self.sample_list:
+                try:
+                    col = var_list[vcf.sample_to_col(s)]
+                    g = Genotype(self, s, col.split(":")[0])
+                    self._gts[s] = g
+                    for key, value in zip(var_list[8].split(":"), col.split(":")):
+                        g.set_format(key, value)
+                except IndexError:
+                    self._gts[s] = Genotype(self, s, "./.")
         self.info: Dict[str, object] = {}
         for item in var_list[7].split(";"):
             kv = item.split("=")
@@ -246,6 +252,21 @@ class Variant:
 
     def is_valid_svtype(self) -> bool:
         return self.get_svtype() in VALID_SVTYPES
+
+    @property
+    def gts(self) -> Dict[str, "Genotype"]:
+        if self._gts is None:
+            self._gts = {s: Genotype(self, s, "./.") for s in self.sample_list}
+        return self._gts
+
+    def only_default_genotypes(self) -> bool:
+        """no sample of this variant carries anything but its initial GT"""
+        if self._gts is None:
+            return True
+        for g in self._gts.values():
+            if len(g.format) != 1:
+                return False
+        return True
 
     def genotype(self, sample_name) -> "Genotype":
         if sample_name in self.sample_list:
