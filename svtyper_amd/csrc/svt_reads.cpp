@@ -166,6 +166,7 @@ private:
         const uint8_t* cdata = hdr + 12 + xlen;
         const uint8_t* tail = cdata + clen;
         const uint32_t isize = tail[4] | (tail[5] << 8) | (tail[6] << 16) | ((uint32_t)tail[7] << 24);
+        if (isize > 65536u) return park(b, coff, true);     // a BGZF block inflates to at most 64 KiB
         b->data.resize(isize);
         if (isize) {
             if (inflateReset(&zs_) != Z_OK) bad_ = true;
