@@ -103,7 +103,7 @@ def load() -> C.CDLL:
 def _check(rc: int):
     if rc != 0:
         msg = load().svt_last_error()
-        raise SvtyperHipError("svtyper_hip error %d: %s" % (rc, msg.decode() if msg else ""))
+        raise SvtyperHipError("svtyper_hip error %d: %s" % (rc, msg.decode("utf-8", "replace") if msg else ""))
 
 
 def trim():
