@@ -4,8 +4,8 @@ reader must answer with an error (or a result), never crash."""
 import os, sys, subprocess, tempfile, random
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 child = r'''
-import sys, json
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import sys, json, os
+ROOT = os.environ["SVT_ROOT"]; sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import test_native_reads as N
 from svtyper_amd import bam, library, native_reads as nr, hip
