@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Open-ended check of the stages in front of the likelihood path: random synthetic BAMs (tests/bamwriter.py) through
 sso_genotype / sv_genotype with (Python reader, host geometry) and with (native reader, device geometry); the two VCFs
-must be identical.  Usage: tools/soak_geometry.py [seconds]"""
+must be identical.  Usage: tests/soak_geometry.py [seconds]"""
 import io, json, os, pathlib, sys, tempfile, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -1,8 +1,8 @@
 #!/usr/bin/env python
 """Differential soak: many random batches (random libraries, weights, flags, layouts) through the HIP path
-and the C oracle; stops at the first difference.  Usage: tools/soak.py [seconds]"""
+and the C oracle; stops at the first difference.  Usage: tests/soak_likelihood.py [seconds]"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))   # repo root (this file lives in tests/)
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import test_hip_parity as P
