@@ -281,9 +281,19 @@ def main():
     logging.basicConfig(format="%(message)s", level=logging.INFO if args.verbose else logging.WARNING)
     if args.split_bam is not None:
         sys.stderr.write("Warning: --split_bam (-S) is deprecated. Ignoring %s.\n" % args.split_bam)
-    sv_genotype(args.bam, args.input_vcf, args.output_vcf, args.min_aligned, args.split_weight, args.disc_weight,
-                args.num_samp, args.lib_info_path, args.debug, args.alignment_outpath, args.ref_fasta,
-                args.sum_quals, args.max_reads, args.max_ci_dist, geometry=args.geometry, reader=args.reader)
+    call = (args.bam, args.input_vcf, args.output_vcf, args.min_aligned, args.split_weight, args.disc_weight,
+            args.num_samp, args.lib_info_path, args.debug, args.alignment_outpath, args.ref_fasta,
+            args.sum_quals, args.max_reads, args.max_ci_dist)
+    from . import sharded
+    job = sharded.job()
+    if job is None:
+        return sv_genotype(*call, geometry=args.geometry, reader=args.reader)
+    # launched by torch.distributed.run with several ranks: one GPU each, variants sharded, one gather
+    rank, world, local_rank = job
+    engine = sharded.init(local_rank)
+    sharded.sv_genotype_sharded(*call, rank=rank, world=world, engine=engine, geometry=args.geometry,
+                                reader=args.reader)
+    sharded.finish()
 
 
 def cli():

@@ -43,17 +43,16 @@ def local_shard(batch: EvidenceBatch, rank: int, world: int, group: int = 1) -> 
     return batch.slice(lo, hi), (lo, hi)
 
 
-def gather_result_records(local, counts: List[int], dst: int = 0):
-    """Gather every rank's result records (a uint8 torch tensor of n_local * 128 bytes, on the
-    backend's device) onto `dst` with one collective.  Shards may differ in size, so the payload
-    is padded to the largest shard.  Returns the concatenated uint8 tensor on `dst`, None elsewhere."""
+def gather_bytes(local, sizes: List[int], dst: int = 0):
+    """Gather every rank's uint8 tensor (sizes[r] bytes on rank r, on the backend's device) onto `dst`
+    with one collective.  Shards may differ in size, so the payload is padded to the largest one.
+    Returns the concatenated uint8 tensor on `dst`, None elsewhere."""
     import torch
     import torch.distributed as dist
 
     world = dist.get_world_size()
     rank = dist.get_rank()
-    rec = ev.RESULT_DTYPE.itemsize
-    width = max(counts) * rec
+    width = max(max(sizes), 1)
     buf = local
     if local.numel() != width:
         buf = torch.zeros(width, dtype=torch.uint8, device=local.device)
@@ -62,7 +61,14 @@ def gather_result_records(local, counts: List[int], dst: int = 0):
     dist.gather(buf, out, dst=dst)
     if rank != dst:
         return None
-    return torch.cat([o[: c * rec] for o, c in zip(out, counts)])
+    return torch.cat([o[:c] for o, c in zip(out, sizes)])
+
+
+def gather_result_records(local, counts: List[int], dst: int = 0):
+    """Gather every rank's result records (a uint8 torch tensor of n_local * 128 bytes, on the
+    backend's device) onto `dst`; `counts` are records per rank."""
+    rec = ev.RESULT_DTYPE.itemsize
+    return gather_bytes(local, [c * rec for c in counts], dst)
 
 
 def results_from_bytes(t) -> Results:

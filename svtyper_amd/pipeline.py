@@ -13,6 +13,8 @@ through the same seam.
 """
 from __future__ import annotations
 
+import os
+
 from typing import Callable, Dict, List, Optional, Tuple
 
 from . import evidence as ev
@@ -148,7 +150,7 @@ class NativeUnitCollector:
         self.min_aligned = min_aligned
         self.count_mode = count_mode
         self.max_reads = max_reads
-        self.n_threads = n_threads
+        self.n_threads = n_threads or int(os.environ.get("SVT_READER_THREADS", "0"))   # 0 = the library's default
         self.split_weight = split_weight
         self.disc_weight = disc_weight
         self.lib_tables = []
