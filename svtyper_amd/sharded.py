@@ -133,6 +133,10 @@ def run_sharded(driver: Callable, bam_string, vcf_in, vcf_out, *rest, rank: int,
     writes everything to `vcf_out`.  Needs an initialised process group."""
     if vcf_in is None:
         return driver(bam_string, None, vcf_out, *rest, **kw)
+    import sys
+    import time
+    trace = bool(os.environ.get("SVT_TRACE"))
+    t0 = time.perf_counter()
     lines = vcf_in.readlines()
     n_head = 0
     while n_head < len(lines) and lines[n_head].startswith("#"):
@@ -145,7 +149,9 @@ def run_sharded(driver: Callable, bam_string, vcf_in, vcf_out, *rest, rank: int,
         rest[lib_info_index] = None        # only rank 0 writes the library JSON; the others just scan
     sink = _Sink()
     share = _Lines(lines[:n_head] + [body[i] for i in mine], getattr(vcf_in, "name", "<stdin>"))
+    t1 = time.perf_counter()
     driver(bam_string, share, sink, *rest, **kw)
+    t2 = time.perf_counter()
     text = sink.getvalue()
     if rank != 0:                           # header comes from rank 0 only (body lines never start with '#')
         kept = [l for l in text.splitlines(True) if not l.startswith("#")]
@@ -155,6 +161,9 @@ def run_sharded(driver: Callable, bam_string, vcf_in, vcf_out, *rest, rank: int,
         for part in parts:
             vcf_out.write(part)
         vcf_out.flush()
+    if trace:
+        sys.stderr.write("[sharded] rank %d/%d: %d of %d lines | read+plan %.2f s, driver %.2f s, gather+write %.2f s\n"
+                         % (rank, world, len(mine), len(body), t1 - t0, t2 - t1, time.perf_counter() - t2))
 
 
 def usable_cpus() -> int:
