@@ -10,7 +10,8 @@ import test_hip_geometry as G
 import test_host_pipeline as T
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
-t0, it = time.time(), 0
+first = int(sys.argv[2]) if len(sys.argv) > 2 else 0      # seeds derive from the iteration number
+t0, it = time.time(), first
 devnull = open(os.devnull, "w")
 while time.time() - t0 < budget:
     tmp = pathlib.Path(tempfile.mkdtemp())
@@ -38,4 +39,4 @@ while time.time() - t0 < budget:
         print("MISMATCH at iteration %d (files under %s)" % (it, tmp))
         sys.exit(1)
     it += 1
-print("geometry soak ok: %d synthetic BAMs x 2 drivers, %.0f s" % (it, time.time() - t0))
+print("geometry soak ok: iterations %d..%d (synthetic BAMs) x 2 drivers, %.0f s" % (first, it - 1, time.time() - t0))

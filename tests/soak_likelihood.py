@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Differential soak: many random batches (random libraries, weights, flags, layouts) through the HIP path
-and the C oracle; stops at the first difference.  Usage: tests/soak_likelihood.py [seconds]"""
+and the C oracle; stops at the first difference.  Usage: tests/soak_likelihood.py [seconds [first_iteration]]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))   # repo root (this file lives in tests/)
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -11,7 +11,8 @@ from svtyper_amd import evidence as ev, hip, synth
 import bench
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
-t0, it, units = time.time(), 0, 0
+first = int(sys.argv[2]) if len(sys.argv) > 2 else 0      # seeds derive from the iteration number
+t0, it, units = time.time(), first, 0
 fixture = bench.fixture_library()
 while time.time() - t0 < budget:
     rng = np.random.default_rng(1000 + it)
@@ -54,4 +55,4 @@ while time.time() - t0 < budget:
             sys.exit(1)
     it += 1
     units += b.n_units
-print("soak ok: %d batches, %d units, 4 flag combinations each, %.0f s" % (it, units, time.time() - t0))
+print("soak ok: iterations %d..%d, %d units, 4 flag combinations each, %.0f s" % (first, it - 1, units, time.time() - t0))
