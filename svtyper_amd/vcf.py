@@ -229,10 +229,18 @@ class Variant:
                         g.set_format(key, value)
                 except IndexError:
                     self._gts[s] = Genotype(self, s, "./.")
-        self.info: Dict[str, object] = {}
+        # key=value items keep what lies between the first and the second '=' (parsers.py:260-268 takes
+        # item.split('=')[1]); a bare key is a flag
+        info: Dict[str, object] = {}
         for item in var_list[7].split(";"):
-            kv = item.split("=")
-            self.info[kv[0]] = kv[1] if len(kv) > 1 else True
+            key, eq, value = item.partition("=")
+            if not eq:
+                info[key] = True
+            elif "=" in value:
+                info[key] = value[:value.index("=")]
+            else:
+                info[key] = value
+        self.info = info
 
     def set_info(self, field, value):
         if field in [h.id for h in self.info_list]:
