@@ -7,6 +7,7 @@
 // implementation and the checker of this file (tests/test_native_reads.py compares the summaries
 // byte for byte); this file exists because per-read Python objects, not the GPU, bound a real run.
 
+#include <dlfcn.h>
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -65,20 +66,50 @@ struct FileMap {
     }
 };
 
+// Raw-deflate decoding of BGZF blocks is where a region fetch spends its time on real data (a window is reached by
+// inflating every block from the start of its 16-kb bin).  libdeflate's whole-buffer decoder is 2-3x faster
+// than zlib's streaming one; the image ships its runtime (libdeflate.so.0) without headers, so it is bound by
+// name at first use and zlib stays as the decoder when it is absent (or SVT_INFLATE=zlib asks for it).
+struct FastInflate {
+    void* (*alloc)() = nullptr;
+    int (*decompress)(void*, const void*, size_t, void*, size_t, size_t*) = nullptr;
+    void (*release)(void*) = nullptr;
+    FastInflate()
+    {
+        const char* want = std::getenv("SVT_INFLATE");
+        if (want && std::strcmp(want, "zlib") == 0) return;
+        void* h = dlopen("libdeflate.so.0", RTLD_NOW | RTLD_LOCAL);
+        if (!h) return;
+        alloc = reinterpret_cast<void* (*)()>(dlsym(h, "libdeflate_alloc_decompressor"));
+        decompress = reinterpret_cast<int (*)(void*, const void*, size_t, void*, size_t, size_t*)>(
+            dlsym(h, "libdeflate_deflate_decompress"));
+        release = reinterpret_cast<void (*)(void*)>(dlsym(h, "libdeflate_free_decompressor"));
+        if (!alloc || !decompress || !release) alloc = nullptr;
+    }
+    bool usable() const { return alloc != nullptr; }
+};
+static const FastInflate& fast_inflate()
+{
+    static const FastInflate f;
+    return f;
+}
+
 class Bgzf {
 public:
     explicit Bgzf(const FileMap& file) : file_(file)
     {
         std::memset(&zs_, 0, sizeof zs_);
-        zs_ok_ = inflateInit2(&zs_, -15) == Z_OK;   // one inflate state per reader, reset per block
+        if (fast_inflate().usable()) fast_ = fast_inflate().alloc();
+        if (!fast_) zs_ok_ = inflateInit2(&zs_, -15) == Z_OK;   // one inflate state per reader, reset per block
     }
     ~Bgzf()
     {
+        if (fast_) fast_inflate().release(fast_);
         if (zs_ok_) inflateEnd(&zs_);
     }
     Bgzf(const Bgzf&) = delete;
     Bgzf& operator=(const Bgzf&) = delete;
-    bool ok() const { return file_.data != nullptr && zs_ok_; }
+    bool ok() const { return file_.data != nullptr && (zs_ok_ || fast_); }
     bool failed() const { return bad_; }
 
     void seek(uint64_t voff)
@@ -113,11 +144,26 @@ public:
         return got;
     }
 
+    // n bytes at the read position as one span inside the current inflated block, or nullptr when they
+    // straddle a block boundary / the file ends (the caller then falls back to read()).  The pointer stays
+    // valid until the next call that may load a block.
+    const uint8_t* contiguous(size_t n)
+    {
+        if (uoff_ >= block_->data.size()) {
+            const uint64_t next = block_->next;
+            if (block_ != &empty_ && next == coff_) return nullptr;
+            if (!load(next)) return nullptr;
+            uoff_ = 0;
+        }
+        return block_->data.size() - uoff_ >= n ? block_->data.data() + uoff_ : nullptr;
+    }
+    void advance(size_t n) { uoff_ += n; }   // over bytes contiguous() has just vouched for
+
 private:
     struct Block { std::vector<uint8_t> data; uint64_t next = 0; uint64_t coff = ~0ull; };
     // a few recently inflated blocks: the two windows of a unit and its neighbours walk forward through
     // the same blocks.  Fixed slots whose buffers are reused -- no allocation once they are warm.
-    static constexpr int kSlots = 8;
+    static constexpr int kSlots = 32;
     Block* slot_for(uint64_t coff)
     {
         for (int i = 0; i < kSlots; ++i)
@@ -168,7 +214,10 @@ private:
         const uint32_t isize = tail[4] | (tail[5] << 8) | (tail[6] << 16) | ((uint32_t)tail[7] << 24);
         if (isize > 65536u) return park(b, coff, true);     // a BGZF block inflates to at most 64 KiB
         b->data.resize(isize);
-        if (isize) {
+        if (isize && fast_) {
+            // exactly isize bytes or an error (a null "actual size" pointer makes a short stream a failure)
+            if (fast_inflate().decompress(fast_, cdata, (size_t)clen, b->data.data(), b->data.size(), nullptr) != 0) bad_ = true;
+        } else if (isize) {
             if (inflateReset(&zs_) != Z_OK) bad_ = true;
             else {
                 zs_.next_in = const_cast<Bytef*>(cdata);
@@ -188,6 +237,7 @@ private:
     const FileMap& file_;
     z_stream zs_;
     bool zs_ok_ = false;
+    void* fast_ = nullptr;   // libdeflate decompressor of this reader
     Block slots_[kSlots];
     int clock_ = 0;
     Block empty_;
@@ -385,42 +435,79 @@ void reg2bins(int64_t beg, int64_t end, std::vector<uint32_t>& bins)
         for (int64_t k = offs[l] + (beg >> shifts[l]); k <= (int64_t)offs[l] + (end >> shifts[l]); ++k) bins.push_back((uint32_t)k);
 }
 
-bool read_record(Bgzf& z, std::vector<uint8_t>& buf, Record& r)
+inline uint32_t le32(const uint8_t* d) { return (uint32_t)d[0] | (d[1] << 8) | (d[2] << 16) | ((uint32_t)d[3] << 24); }
+
+// The bytes of the next alignment (after its length word): in place inside the inflated block when the
+// record does not straddle a block boundary -- no copy, which is what makes walking up to a window cheap
+// -- otherwise gathered into `buf`.  nullptr at the end of the data / on a bad length.
+const uint8_t* next_record(Bgzf& z, std::vector<uint8_t>& buf, uint32_t& size)
 {
-    uint8_t szb[4];
-    if (z.read(szb, 4) != 4) return false;
-    const uint32_t size = szb[0] | (szb[1] << 8) | (szb[2] << 16) | ((uint32_t)szb[3] << 24);
-    if (size < 32) return false;
-    buf.resize(size);
-    if (z.read(buf.data(), size) != size) return false;
-    const uint8_t* d = buf.data();
-    auto u32 = [&](size_t o) { return (uint32_t)d[o] | (d[o + 1] << 8) | (d[o + 2] << 16) | ((uint32_t)d[o + 3] << 24); };
-    r.tid = (int32_t)u32(0);
-    r.pos = (int32_t)u32(4);
-    const unsigned l_name = d[8];
-    r.mapq = d[9];
-    const unsigned n_cigar = d[12] | (d[13] << 8);
-    r.flag = (uint16_t)(d[14] | (d[15] << 8));
-    r.l_seq = (int32_t)u32(16);
-    r.tlen = (int32_t)u32(28);
-    size_t off = 32;
-    if (off + l_name + 4ull * n_cigar > size) return false;
-    r.name.assign(reinterpret_cast<const char*>(d + off), l_name ? l_name - 1 : 0);
-    off += l_name;
-    r.cigar.clear();
-    r.end = r.pos;
-    for (unsigned k = 0; k < n_cigar; ++k) {
-        const uint32_t c = u32(off + 4 * k);
-        const int op = (int)(c & 0xF);
-        const int64_t len = c >> 4;
-        r.cigar.emplace_back(op, len);
-        if (consumes_ref(op)) r.end += len;
+    if (const uint8_t* h = z.contiguous(4)) {
+        size = le32(h);
+        if (size < 32) return nullptr;
+        if (const uint8_t* d = z.contiguous(4 + (size_t)size)) {
+            z.advance(4 + (size_t)size);
+            return d + 4;
+        }
     }
-    off += 4ull * n_cigar;
+    uint8_t szb[4];
+    if (z.read(szb, 4) != 4) return nullptr;
+    size = le32(szb);
+    if (size < 32) return nullptr;
+    buf.resize(size);
+    if (z.read(buf.data(), size) != size) return nullptr;
+    return buf.data();
+}
+
+struct RecordLayout { unsigned l_name = 0, n_cigar = 0; size_t tags_off = 0; };
+
+// fixed fields + reference end: all a fetch needs to decide whether the record overlaps its window
+bool decode_core(const uint8_t* d, uint32_t size, Record& r, RecordLayout& lay)
+{
+    r.tid = (int32_t)le32(d);
+    r.pos = (int32_t)le32(d + 4);
+    lay.l_name = d[8];
+    r.mapq = d[9];
+    lay.n_cigar = d[12] | (d[13] << 8);
+    r.flag = (uint16_t)(d[14] | (d[15] << 8));
+    r.l_seq = (int32_t)le32(d + 16);
+    r.tlen = (int32_t)le32(d + 28);
+    size_t off = 32;
+    if (off + lay.l_name + 4ull * lay.n_cigar > size) return false;
+    off += lay.l_name;
+    r.end = r.pos;
+    for (unsigned k = 0; k < lay.n_cigar; ++k) {
+        const uint32_t c = le32(d + off + 4 * k);
+        if (consumes_ref((int)(c & 0xF))) r.end += (int64_t)(c >> 4);
+    }
+    off += 4ull * lay.n_cigar;
     off += (size_t)((r.l_seq + 1) / 2 + r.l_seq);
     if (off > size) return false;
-    r.tags = d + off;
-    r.tags_len = size - off;
+    lay.tags_off = off;
+    return true;
+}
+
+// the variable-length parts a kept record is asked for: query name, CIGAR operations, tag area
+void decode_rest(const uint8_t* d, uint32_t size, const RecordLayout& lay, Record& r)
+{
+    r.name.assign(reinterpret_cast<const char*>(d + 32), lay.l_name ? lay.l_name - 1 : 0);
+    r.cigar.clear();
+    const uint8_t* c0 = d + 32 + lay.l_name;
+    for (unsigned k = 0; k < lay.n_cigar; ++k) {
+        const uint32_t c = le32(c0 + 4 * k);
+        r.cigar.emplace_back((int)(c & 0xF), (int64_t)(c >> 4));
+    }
+    r.tags = d + lay.tags_off;
+    r.tags_len = size - lay.tags_off;
+}
+
+bool read_record(Bgzf& z, std::vector<uint8_t>& buf, Record& r)
+{
+    uint32_t size = 0;
+    const uint8_t* d = next_record(z, buf, size);
+    RecordLayout lay;
+    if (!d || !decode_core(d, size, r, lay)) return false;
+    decode_rest(d, size, lay, r);
     return true;
 }
 
@@ -457,12 +544,17 @@ bool fetch(const svt_bam& bam, Bgzf& z, int32_t tid, int64_t beg, int64_t end, s
     for (const auto& c : merged) {
         z.seek(c.first);
         while (z.tell() < c.second) {
-            if (!read_record(z, buf, r)) break;
+            uint32_t size = 0;
+            const uint8_t* d = next_record(z, buf, size);
+            RecordLayout lay;
+            if (!d || !decode_core(d, size, r, lay)) break;
             if (r.tid != tid || r.pos >= end) return true;
             int64_t rend = r.end;
-            if (r.cigar.empty() || rend <= r.pos) rend = r.pos + 1;
-            if (rend > beg)
+            if (lay.n_cigar == 0 || rend <= r.pos) rend = r.pos + 1;
+            if (rend > beg) {      // most records walked on the way to the window stop here, undecoded
+                decode_rest(d, size, lay, r);
                 if (!fn(r)) return true;
+            }
         }
     }
     return !z.failed();

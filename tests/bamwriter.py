@@ -46,7 +46,11 @@ def encode_record(r):
                        r["flag"], l_seq, r["mtid"], r["mpos"], r["tlen"])
     body += name
     body += b"".join(struct.pack("<I", (n << 4) | op) for op, n in cigar)
-    body += b"\x00" * ((l_seq + 1) // 2) + b"\xff" * l_seq
+    if "seq4" in r:     # optional real content: packed 4-bit bases + qualities (realistic inflate cost)
+        assert len(r["seq4"]) == (l_seq + 1) // 2 and len(r["qual"]) == l_seq
+        body += r["seq4"] + r["qual"]
+    else:
+        body += b"\x00" * ((l_seq + 1) // 2) + b"\xff" * l_seq
     for key, typ, val in r.get("tags", ()):
         body += key.encode() + typ.encode()
         if typ == "Z":

@@ -201,3 +201,32 @@ def test_library_statistics_native_equals_python_and_reference(tmp_path):
         assert (a.read_length, a.mean, a.sd, a.prevalence) == (b.read_length, b.mean, b.sd, b.prevalence)
         assert list(a.hist.items()) == list(b.hist.items())
     # (the Python reader's numbers are pinned to the reference's by tests/test_host_pipeline.py)
+
+
+_DIGEST_CHILD = r'''
+import hashlib, os, sys
+sys.path.insert(0, os.environ["SVT_ROOT"]); sys.path.insert(0, os.path.join(os.environ["SVT_ROOT"], "tests"))
+import test_native_reads as N
+from svtyper_amd import bam, library, native_reads as nr
+path = sys.argv[1]
+sites, info = N._synthetic_bam(path, 21, n_pairs=1500)       # small BGZF blocks: many records straddle them
+sample = library.Sample.from_lib_info(bam.AlignmentFile(path), info, 1e-3)
+off, frags, skipped = N._native_summaries(sites, sample, nr.NativeBam(path), nr.COUNT_CLASSIC, None, 2)
+scan = nr.NativeBam(path).scan_library(["rgA"], 1000000)
+print(hashlib.sha256(off.tobytes() + frags.tobytes() + skipped.tobytes()).hexdigest(), repr(scan)[:300])
+'''
+
+
+def test_both_inflate_decoders_give_the_same_summaries(tmp_path):
+    """BGZF blocks go through libdeflate when the image has its runtime and through zlib otherwise
+    (SVT_INFLATE=zlib forces it); the decoder is chosen once per process, hence the two children."""
+    import subprocess
+    import sys
+    outs = []
+    for mode in ("zlib", "default"):
+        env = dict(os.environ, SVT_ROOT=os.path.dirname(HERE), SVT_INFLATE=mode)
+        r = subprocess.run([sys.executable, "-c", _DIGEST_CHILD, str(tmp_path / ("%s.bam" % mode))], env=env,
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-500:]
+        outs.append(r.stdout.strip())
+    assert outs[0] == outs[1] and len(outs[0]) > 64
