@@ -1080,11 +1080,12 @@ int svt_bam_summarise(const svt_bam* bam, const svt_summarise_args* args, svt_su
                          std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
     };
     std::vector<UnitSpan> outs(n);
-    constexpr uint64_t kUnitsPerGrab = 16;
     // by default one usable CPU is left to the caller's other thread (the drivers parse the next chunk of the
     // VCF while this runs: pipeline.ChunkPipeline)
     unsigned nt = args->n_threads > 0 ? (unsigned)args->n_threads : std::max(1u, svt::usable_cpus() - 1u);
     nt = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(nt ? nt : 1, n ? n : 1));
+    // units per grab: 16 keeps neighbours on one worker, fewer when the batch is too small to feed every worker that way
+    const uint64_t kUnitsPerGrab = std::max<uint64_t>(1, std::min<uint64_t>(16, n / (4ull * nt)));
     std::atomic<uint64_t> next(0);
     std::atomic<int> first_rc(SVT_OK);
     std::mutex err_lock;
