@@ -109,7 +109,7 @@ def _gather_text(text: str, rank: int, world: int) -> Optional[List[str]]:
     import torch.distributed as dist
     from . import distributed as D
 
-    device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    device = _backend_device()
     raw = np.frombuffer(text.encode("utf-8"), np.uint8)
     sizes = torch.zeros(world, dtype=torch.int64, device=device)
     sizes[rank] = raw.size
@@ -127,6 +127,31 @@ def _gather_text(text: str, rank: int, world: int) -> Optional[List[str]]:
     return out
 
 
+def _backend_device():
+    import torch
+    import torch.distributed as dist
+    return torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+
+
+def _require_same_input(lines: List[str], rank: int, world: int) -> None:
+    """Every rank plans the split from its own copy of the VCF, so the copies must be the same text (a rank
+    reading an empty stdin would otherwise drop its share silently)."""
+    import zlib
+    import torch
+    import torch.distributed as dist
+
+    crc = 0
+    for line in lines:
+        crc = zlib.crc32(line.encode("utf-8", "surrogateescape"), crc)
+    mine = torch.tensor([len(lines), crc], dtype=torch.int64, device=_backend_device())
+    lo, hi = mine.clone(), mine.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    if lo.tolist() != hi.tolist():
+        raise RuntimeError("rank %d of %d: the ranks did not read the same VCF (%d lines here); give the input "
+                           "as a file (-i), not on stdin, when running under torch.distributed.run" % (rank, world, len(lines)))
+
+
 def run_sharded(driver: Callable, bam_string, vcf_in, vcf_out, *rest, rank: int, world: int,
                 lib_info_index: int, **kw) -> None:
     """`driver(bam_string, vcf_in, vcf_out, *rest, **kw)` over this rank's share of `vcf_in`; rank 0
@@ -142,6 +167,7 @@ def run_sharded(driver: Callable, bam_string, vcf_in, vcf_out, *rest, rank: int,
     while n_head < len(lines) and lines[n_head].startswith("#"):
         n_head += 1
     body = lines[n_head:]
+    _require_same_input(lines, rank, world)
     mine = plan_shards(body, world)[rank]
     rest = list(rest)
     lib_info_path = rest[lib_info_index]

@@ -166,3 +166,26 @@ def test_cli_under_torch_distributed_run(tmp_path, hip_device, module):
                     "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), "-m", module]
                    + common + ["-o", multi], check=True, env=env, cwd=ROOT, timeout=900)
     assert open(multi).read() == open(single).read()
+
+
+def _mismatch_worker(rank, world, port, in_path, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    text = open(in_path).read() if rank == 0 else ""          # rank 1 sees an empty stdin
+    try:
+        sharded.sv_genotype_sharded(H.IN_BAM, sharded._Lines(text.splitlines(True), "<stdin>"), io.StringIO(),
+                                    *_classic_args(), rank=rank, world=world, engine=H.oracle_engine)
+        verdict = "ran"
+    except RuntimeError as e:
+        verdict = "refused" if "same VCF" in str(e) else "other: %s" % e
+    open(os.path.join(out_dir, "rank%d" % rank), "w").write(verdict)
+    dist.destroy_process_group()
+
+
+def test_ranks_with_different_inputs_are_refused(tmp_path):
+    import torch.multiprocessing as mp
+    mp.spawn(_mismatch_worker, args=(2, _free_port(), H.IN_VCF, str(tmp_path)), nprocs=2, join=True)
+    assert [open(str(tmp_path / ("rank%d" % r))).read() for r in (0, 1)] == ["refused", "refused"]
