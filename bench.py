@@ -90,7 +90,18 @@ def generate(name: str, n_units: int, rank: int, workers: int):
     return parts[0] if len(parts) == 1 else ev.concat_batches(parts)
 
 
+def claim_stdout():
+    """The contract is ONE JSON line on stdout, but libraries below us write there too (RCCL prints its version
+    banner on stdout through C stdio, flushed at exit).  Keep the real stdout for the JSON line and point file
+    descriptor 1 at stderr for everybody else."""
+    sys.stdout.flush()
+    real = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+    return real
+
+
 def main():
+    json_out = claim_stdout()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -359,7 +370,7 @@ def main():
                 "max_abs_dGL": float(np.max(np.abs(got.gl[:sample_n] - want.gl))),
                 "max_abs_dSQ": float(np.max(np.abs(got.sq[:sample_n] - want.sq))),
             }
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=json_out, flush=True)
 
     dbatch.close()
     if use_dist:

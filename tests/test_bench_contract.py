@@ -33,3 +33,16 @@ def test_bench_line_has_the_contract_keys(hip_device):
     assert cpu["kind"] == "port" and cpu["cores"] >= 1
     assert d["value"] > 0 and abs(d["value"] - 30000 * 3 / (d["ms_per_step"] * 3 * 1e-3)) / d["value"] < 1e-6
     assert d["parity"]["integer_mismatches"] == 0 and d["parity"]["max_abs_dGL"] <= 1e-6 and d["parity"]["max_abs_dSQ"] <= 1e-6
+
+
+@pytest.mark.gpu
+def test_one_line_on_stdout_with_the_process_group_up(hip_device):
+    """--force-dist: RCCL initialised and the gather run on one rank; RCCL's banner must not reach stdout."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29671", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--units", "20000", "--force-dist",
+                        "--no-cpu-baseline", "--no-dense-leg"], cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout[-1000:]
+    d = json.loads(lines[0])
+    assert d["gather"]["collective"] == "rccl gather" and d["value"] > 0
