@@ -237,6 +237,18 @@ def init(local_rank: int, backend: Optional[str] = None):
     return HipEngine(device)
 
 
+def private_stdout(vcf_out):
+    """When the VCF goes to stdout: keep the real stdout for it and point file descriptor 1 at stderr, because
+    RCCL writes its version banner to stdout (C stdio, flushed at exit) and would end up inside the VCF."""
+    import sys
+    if vcf_out is not sys.stdout:
+        return vcf_out
+    sys.stdout.flush()
+    real = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+    return real
+
+
 def finish() -> None:
     import torch.distributed as dist
     if dist.is_initialized():

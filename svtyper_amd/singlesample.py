@@ -253,6 +253,7 @@ def main():
         return sso_genotype(*call, geometry=args.geometry, reader=args.reader)
     # launched by torch.distributed.run with several ranks: one GPU each, variants sharded, one gather
     rank, world, local_rank = job
+    call = call[:2] + (sharded.private_stdout(call[2]),) + call[3:]
     engine = sharded.init(local_rank)
     sharded.sso_genotype_sharded(*call, rank=rank, world=world, engine=engine, geometry=args.geometry,
                                  reader=args.reader)
