@@ -189,3 +189,44 @@ def test_ranks_with_different_inputs_are_refused(tmp_path):
     import torch.multiprocessing as mp
     mp.spawn(_mismatch_worker, args=(2, _free_port(), H.IN_VCF, str(tmp_path)), nprocs=2, join=True)
     assert [open(str(tmp_path / ("rank%d" % r))).read() for r in (0, 1)] == ["refused", "refused"]
+
+
+def test_pairing_replay_matches_the_vcf_model_on_random_bodies():
+    """bnd_pairs() replays parsers.py:155-178 on raw lines; the Vcf model is the same logic on parsed
+    variants.  Random bodies: mates in either order, missing partners, several pairs interleaved."""
+    import random
+    from svtyper_amd.vcf import Variant, Vcf
+    rng = random.Random(7)
+    for trial in range(200):
+        n_pairs = rng.randint(0, 6)
+        lines = []
+        for k in range(n_pairs):
+            a, b = "p%d_1" % k, "p%d_2" % k
+            mates = [_bnd("1", 1000 + k, a, b, "N[1:5000["), _bnd("1", 5000 + k, b, a, "]1:1000]N")]
+            if rng.random() < 0.25:
+                mates.pop(rng.randrange(2))                      # a mate whose partner never shows up
+            lines += mates
+        lines += ["1\t%d\tv%d\tN\t<DEL>\t0\t.\tSVTYPE=DEL;END=%d;CIPOS=0,0;CIEND=0,0\n" % (100 + i, i, 900 + i)
+                  for i in range(rng.randint(0, 12))]
+        rng.shuffle(lines)
+        vcf = Vcf()
+        want = {}
+        first_index = {}
+        for idx, line in enumerate(lines):
+            var = Variant(line.rstrip().split("\t"), vcf)
+            if var.get_svtype() != "BND":
+                continue
+            first_index[var.var_id] = idx
+            bp = vcf.get_variant_breakpoints(var, 1e10)
+            if bp is not None:
+                want[idx] = first_index[bp["id"]]
+                vcf._bnd_first.pop(bp["id"])
+        assert sharded.bnd_pairs(lines) == want
+        for world in (1, 2, 3, 7):
+            plan = sharded.plan_shards(lines, world)
+            assert sorted(i for p in plan for i in p) == list(range(len(lines)))
+            owner = {i: r for r, p in enumerate(plan) for i in p}
+            assert all(owner[s] == owner[f] for s, f in want.items())
+            # apart from first mates that moved to their partner's rank, ranks hold file-order ranges
+            stay = [i for i in range(len(lines)) if i not in set(want.values())]
+            assert [owner[i] for i in stay] == sorted(owner[i] for i in stay)
