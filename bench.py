@@ -111,6 +111,7 @@ def main():
     ap.add_argument("--workload", default="c3_mixed_1m", choices=["c3_mixed_1m", "c2_del_100k", "c5_multisample"])
     ap.add_argument("--sso", action="store_true", help="singlesample.py floating-point association")
     ap.add_argument("--dense", action="store_true", help="stream the canonical 16-byte records (no sparse re-encoding)")
+    ap.add_argument("--fixed-pair-entries", action="store_true", help="compact layout with 4-byte pair entries only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dense-leg", action="store_true",
                     help="skip the extra timing of the dense-record layout (N=1 only)")
@@ -151,7 +152,8 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))
 
-    flags = (ev.FLAG_SSO_ASSOCIATION if args.sso else 0) | (ev.FLAG_DENSE_LAYOUT if args.dense else 0)
+    flags = ((ev.FLAG_SSO_ASSOCIATION if args.sso else 0) | (ev.FLAG_DENSE_LAYOUT if args.dense else 0)
+             | (ev.FLAG_FIXED_PAIR_ENTRIES if args.fixed_pair_entries else 0))
     t0 = time.time()
     dbatch = hip.DeviceBatch(batch, device=local_rank, flags=flags)
     upload_s = time.time() - t0
@@ -167,6 +169,7 @@ def main():
     n = batch.n_units
     alg_bytes, resident_bytes = dbatch.bytes()
     compact, table_mode = dbatch.layout()
+    layout_name = dbatch.layout_name()
 
     # result records straight into a torch buffer (so the final RCCL gather needs no extra copy)
     res_buf = torch.zeros(max(n, 1) * ev.RESULT_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
@@ -225,7 +228,7 @@ def main():
         try:
             with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as f:
                 tj = json.load(f)
-            tj = tj["compact" if compact else "dense"]
+            tj = tj[layout_name]
             if tj.get("units") == n and tj.get("records") == batch.n_records:
                 traffic = tj["traffic_bytes_per_launch"]
                 traffic_note = "rocprofv3 PMC (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), profiles/hbm_traffic.json"
@@ -254,7 +257,8 @@ def main():
                 "units_per_gpu": n,
                 "records_per_gpu": batch.n_records,
                 "association": "sso" if args.sso else "classic",
-                "device_layout": "compact sparse 4-byte entry streams" if compact else "dense 16-byte records",
+                "device_layout": {"dense": "dense 16-byte records", "compact": "compact sparse 4-byte entry streams",
+                                  "short": "compact sparse entry streams, 2-byte pair entries for the common MAPQ pair"}[layout_name],
                 "parallelism": "units sharded over %d GPU(s), no data-path collective per step" % world,
             },
             "roofline": {

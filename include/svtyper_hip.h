@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SVT_ABI_VERSION 6
+#define SVT_ABI_VERSION 7
 
 /* ---- error codes (0 = ok, <0 = error; text via svt_last_error()) ---------- */
 #define SVT_OK 0
@@ -68,9 +68,14 @@ extern "C" {
  *       lengths >= 0 and, with several libraries, units whose libraries span at most 4
  *       consecutive indices and MAPQs <= 127 on the kept pair entries; a batch that does not
  *       qualify silently uses the dense layout (svt_batch_layout tells which one it got).
+ *       With one library of at most 2047 bins the pair entries are written in half-words
+ *       ("short" layout): an entry whose two MAPQs are the batch's most common pair (60, 60
+ *       for bwa alignments) takes 2 bytes, any other one 4; same order, same sums.
  *   SVT_FLAG_DENSE_LAYOUT: the 16-byte records are streamed as they are.
- * Results are bit-identical between the two.                                              */
+ *   SVT_FLAG_FIXED_PAIR_ENTRIES: compact layout, but every pair entry keeps its 4 bytes.
+ * Results are bit-identical between all of them.                                          */
 #define SVT_FLAG_DENSE_LAYOUT 0x2u
+#define SVT_FLAG_FIXED_PAIR_ENTRIES 0x4u
 
 /* ---- evidence record: one per read-fragment (query name) of a unit, 16 B --
  * Records of a unit are stored in the order the reference walks them:
@@ -310,8 +315,8 @@ int svt_batch_bind_device_results(svt_batch* b, svt_result* dev_ptr);
  * holds (padding included).                                                     */
 int svt_batch_bytes(const svt_batch* b, uint64_t* algorithmic, uint64_t* resident);
 
-/* Which device layout / kernel flavour the batch got: *compact = 1 for the compact entry streams,
- * 0 for the dense records; *table_mode = 0 one library, tables in LDS; 1 several libraries,
+/* Which device layout / kernel flavour the batch got: *compact = 0 for the dense records, 1 for the
+ * compact entry streams with 4-byte pair entries, 2 for the short pair entries; *table_mode = 0 one library, tables in LDS; 1 several libraries,
  * per-workgroup library windows in LDS; 2 general geometry, tables read through L2.          */
 int svt_batch_layout(const svt_batch* b, int* compact, int* table_mode);
 

@@ -37,6 +37,15 @@ enum Stream : int { kPairs = 0, kRefReads = 1, kCandidates = 2 };
 // entries per 16-byte row slot: 4-byte pair entries; 2-byte reference-read and candidate entries
 // (seven MAPQ pairs in bytes 0..13, their flag bits in bytes 14..15)
 constexpr uint32_t kEntriesPerRow[kStreams] = {4u, 7u, 7u};
+// kLayoutShort: the pair stream is counted in half-words (2-byte short entries, 4-byte wide ones), eight per slot
+constexpr uint32_t kHalfwordsPerRow = 8u;
+
+// device layout of a batch's evidence
+enum Layout : int {
+    kLayoutDense = 0,    // canonical 16-byte records
+    kLayoutCompact = 1,  // three entry streams, 4-byte pair entries
+    kLayoutShort = 2     // three entry streams, 2-byte pair entries for the batch's most common MAPQ pair
+};
 struct TileDesc {         // 32 B, stored in dispatch (longest-first) order
     uint64_t base;
     uint32_t rows[kStreams];
@@ -107,7 +116,7 @@ struct KernelArgs {
     uint32_t l10_in_lds;
     uint32_t lds_libs;         // LDS capacity in library descriptors (largest window)
     uint32_t lds_bins;         // LDS capacity in histogram bins (largest window)
-    uint32_t pad0;
+    uint32_t common_mq;        // kLayoutShort: mapq_a | mapq_b << 8 of the short pair entries
     uint64_t n_units;
     svt_result* out;           // [n_units]
     LibDesc lib0;              // copy of libs[0] (kSingleLds)

@@ -72,6 +72,8 @@ struct LaneCtx {
     int32_t var_length;
     double pos_delta_d;
     bool is_del;
+    uint32_t common_mq;   // short layout: mapq_a | mapq_b << 8 of the one-half-word pair entries
+    double pp_common;     // short layout: prob_mapq(mapq_a) * prob_mapq(mapq_b) of that pair
 };
 
 // ---- dense layout: one canonical 16-byte record -------------------------------------------------
@@ -201,6 +203,33 @@ __device__ __forceinline__ void pair_entry(const uint32_t e, const LaneCtx& c, A
     const double pp = pm_a * pm_b;
     a.alt_span += pp * w_alt;
     a.ref_span += pp * w_ref;
+}
+
+// Short layout (one library): a 16-byte row slot is four dwords, each either two one-half-word entries that carry
+// the batch's common MAPQ pair, or one wide entry (low half f3 | code << 3 | 0x8000, high half its two MAPQs).
+// code8 = byte offset of bins[code], f3x16 = f3 << 4 (byte offset inside the decision table), pp = pmA * pmB.
+__device__ __forceinline__ void pair_eval_single(const uint32_t code8, const uint32_t f3x16, const double pp,
+                                                 const LaneCtx& c, Acc& a)
+{
+    const int32_t thr1 = lds_i32(kLdsBins + min(code8, c.nb8));
+    const uint32_t h2 = lds_u32(kLdsBins + 4u + min(code8 - c.off2_8, c.nb8));
+    const bool p_conc = (int32_t)h2 <= thr1;
+    const uint32_t wa = (p_conc ? c.wt1 : c.wt0) | f3x16;
+    const double w_alt = lds_f64(wa), w_ref = lds_f64(wa + 8u);
+    a.alt_span += pp * w_alt;
+    a.ref_span += pp * w_ref;
+}
+
+__device__ __forceinline__ void short_pair_dword(const uint32_t e, const LaneCtx& c, Acc& a)
+{
+    const bool wide = (e & 0x8000u) != 0u;
+    const uint32_t hi = e >> 16;
+    const uint32_t mq = wide ? hi : c.common_mq;
+    const double pm_a = lds_f64(kLdsPm + byte0_x8(mq)), pm_b = lds_f64(kLdsPm + byte1_x8(mq));
+    pair_eval_single(e & 0x7ff8u, (e << 4) & 0x70u, pm_a * pm_b, c, a);
+    // the high half: a second entry with the common MAPQs, or the MAPQ bytes of the wide entry just added --
+    // then its straddle bits read as 0, both weights are 0 and the sums receive +0.0
+    pair_eval_single(hi & 0x7ff8u, wide ? 0u : (hi << 4) & 0x70u, c.pp_common, c, a);
 }
 
 // Reference-read entries (classic.py:306-315): seven MAPQ pairs per row slot, byte 14 of the slot holds their
@@ -341,9 +370,10 @@ struct RowReader {
 // ------------------------------------------------------------------------------------------
 // genotype kernel
 // ------------------------------------------------------------------------------------------
-template <bool SSO, int MODE, bool COMPACT>
+template <bool SSO, int MODE, int LAYOUT>
 __global__ __launch_bounds__(kBlock, SVT_MIN_WAVES) void svt_genotype_kernel(const KernelArgs a)
 {
+    constexpr bool COMPACT = LAYOUT != kLayoutDense;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // LDS layout (svt_device_types.h): pm[256] | wtab[32] | bins[lds_bins] | libs[lds_libs] | libx[lds_libs] | l10[n_l10]
     double* s_pm = reinterpret_cast<double*>(smem + kLdsPm);
@@ -423,17 +453,29 @@ __global__ __launch_bounds__(kBlock, SVT_MIN_WAVES) void svt_genotype_kernel(con
         c.off2_8 = c.is_del ? min((uint32_t)h.var_length, a.lib0.n_bins) * 8u : 0x80000000u;
     }
 
+    c.common_mq = a.common_mq;
+    c.pp_common = s_pm[a.common_mq & 0xffu] * s_pm[(a.common_mq >> 8) & 0xffu];
+
     Acc acc = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
 
     // ---- stream the tile: row j is one contiguous 1 KiB line for the wave
     RowReader rows(a.tiled + td.base + lane);
     if (COMPACT) {
-        rows.run(td.rows[kPairs], [&](const uint4 w) {
-            pair_entry<MODE>(w.x, c, acc);
-            pair_entry<MODE>(w.y, c, acc);
-            pair_entry<MODE>(w.z, c, acc);
-            pair_entry<MODE>(w.w, c, acc);
-        });
+        if (LAYOUT == kLayoutShort) {
+            rows.run(td.rows[kPairs], [&](const uint4 w) {
+                short_pair_dword(w.x, c, acc);
+                short_pair_dword(w.y, c, acc);
+                short_pair_dword(w.z, c, acc);
+                short_pair_dword(w.w, c, acc);
+            });
+        } else {
+            rows.run(td.rows[kPairs], [&](const uint4 w) {
+                pair_entry<MODE>(w.x, c, acc);
+                pair_entry<MODE>(w.y, c, acc);
+                pair_entry<MODE>(w.z, c, acc);
+                pair_entry<MODE>(w.w, c, acc);
+            });
+        }
         rows.run(td.rows[kRefReads], [&](const uint4 w) { ref_read_row<SSO>(w, acc); });
         rows.run(td.rows[kCandidates], [&](const uint4 w) { candidate_row<SSO>(w, acc); });
     } else {

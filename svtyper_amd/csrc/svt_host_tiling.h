@@ -42,9 +42,10 @@ inline void parallel_for(uint64_t n, Fn&& fn)
 }
 
 // rows of 16-byte slots unit `u` needs in stream `k`
-inline uint32_t stream_rows_of(const ScanOut& sc, uint32_t nrec, bool compact, int k)
+inline uint32_t stream_rows_of(const ScanOut& sc, uint32_t nrec, int layout, int k)
 {
-    if (compact) return (sc.n[k] + kEntriesPerRow[k] - 1) / kEntriesPerRow[k];
+    if (layout == kLayoutShort && k == kPairs) return (sc.n_short + kHalfwordsPerRow - 1) / kHalfwordsPerRow;
+    if (layout != kLayoutDense) return (sc.n[k] + kEntriesPerRow[k] - 1) / kEntriesPerRow[k];
     return k == 0 ? nrec : 0u;
 }
 
@@ -54,7 +55,7 @@ inline uint32_t stream_rows_of(const ScanOut& sc, uint32_t nrec, bool compact, i
 // tile count is padded to whole workgroups, so the library window a workgroup stages in LDS is the
 // one of a single sample.  Chunks are independent and are processed by several host threads.
 inline void build_tiling(const svt_evidence_batch* in, const std::vector<uint32_t>& nrec,
-                  const std::vector<ScanOut>& scan, bool compact, Tiling& G)
+                  const std::vector<ScanOut>& scan, int layout, Tiling& G)
 {
     const uint64_t n = in->n_units;
     // stable counting sort by first library
@@ -101,10 +102,10 @@ inline void build_tiling(const svt_evidence_batch* in, const std::vector<uint32_
         // longest first
         std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
             const uint64_t ux = unit_at(c0 + x), uy = unit_at(c0 + y);
-            const uint64_t kx = ((uint64_t)stream_rows_of(scan[ux], nrec[ux], compact, 0) << 32) |
-                                stream_rows_of(scan[ux], nrec[ux], compact, 1);
-            const uint64_t ky = ((uint64_t)stream_rows_of(scan[uy], nrec[uy], compact, 0) << 32) |
-                                stream_rows_of(scan[uy], nrec[uy], compact, 1);
+            const uint64_t kx = ((uint64_t)stream_rows_of(scan[ux], nrec[ux], layout, 0) << 32) |
+                                stream_rows_of(scan[ux], nrec[ux], layout, 1);
+            const uint64_t ky = ((uint64_t)stream_rows_of(scan[uy], nrec[uy], layout, 0) << 32) |
+                                stream_rows_of(scan[uy], nrec[uy], layout, 1);
             return kx > ky;
         });
         for (uint32_t t0 = 0; t0 < cn; t0 += kWave) {
@@ -127,7 +128,7 @@ inline void build_tiling(const svt_evidence_batch* in, const std::vector<uint32_
                     src = in->rec_offset[u];
                     f = nrec[u];
                     for (int k = 0; k < kStreams; ++k)
-                        td.rows[k] = std::max(td.rows[k], stream_rows_of(scan[u], f, compact, k));
+                        td.rows[k] = std::max(td.rows[k], stream_rows_of(scan[u], f, layout, k));
                     if (f) {
                         lib_lo = std::min(lib_lo, scan[u].libs & 0xffu);
                         lib_hi = std::max(lib_hi, (scan[u].libs >> 8) & 0xffu);

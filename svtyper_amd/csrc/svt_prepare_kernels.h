@@ -40,6 +40,13 @@ namespace svt {
 //     or of the clip candidate (clip_l, clip_r); first_of_fragment marks the first kept entry for its
 //     tally in a read-fragment (sso association: fragment-local sums).
 //
+//   short layout (one library, n_bins <= 2047, so `code` needs 12 bits and bit 15 of the low half is free):
+//     most pair entries of a real batch carry the same two MAPQs (60, 60 for bwa), so the pair stream is
+//     written in half-words.  An entry with the batch's most common MAPQ pair is ONE half-word
+//     f3 | code << 3; any other entry is a 4-byte-aligned pair of half-words, f3 | code << 3 | 0x8000 then
+//     mapq_a | mapq_b << 8.  A zero half-word is a no-op (f3 = 0: both weights 0) and pads a wide entry to
+//     its alignment.  Order is untouched, so every sum sees the same additions in the same order.
+//
 // Entries that can only add +0.0 to a sum are not stored: pair entries without a straddle bit, with a
 // zero MAPQ on either read, or of a DEL smaller than 2 sd of the entry's library (classic.py:339,383);
 // weight entries whose two gated MAPQs are 0.  x + 0.0 == x bit-for-bit for these non-negative sums.
@@ -93,8 +100,39 @@ struct ScanOut {          // per unit
     uint32_t n[kStreams]; // entries per compact stream
     uint32_t libs;        // lib_min | lib_max << 8
     uint32_t flags;       // kScan*
+    uint32_t n_short;     // half-words of the pair stream in the short layout
 };
 constexpr uint32_t kScanWideMapq = 1u;   // a kept pair entry has a MAPQ > 127
+constexpr uint32_t kWideEntry = 0x8000u; // short layout: the next half-word holds this entry's MAPQs
+constexpr uint32_t kDefaultCommonMapq = 60u | (60u << 8);
+constexpr uint32_t kVoteRecords = 1u << 18;   // records the MAPQ vote looks at
+
+// The most common (mapq_a, mapq_b) of the first kVoteRecords pair records: votes[mapq_a | mapq_b << 8]++,
+// then votes[65536] = the winner.  Any answer is correct, a good one makes the short layout shorter.
+__global__ __launch_bounds__(kBlock) void svt_mapq_vote_kernel(const uint4* __restrict__ csr, const uint32_t n, uint32_t* votes)
+{
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const uint4 w = csr[i];
+    if ((w.w & 7u) == 0u || (w.y & 0xffu) == 0u || (w.y & 0xff00u) == 0u) return;
+    atomicAdd(&votes[w.y & 0xffffu], 1u);
+}
+
+__global__ __launch_bounds__(kBlock) void svt_mapq_pick_kernel(uint32_t* votes)
+{
+    __shared__ uint32_t best_n[kBlock], best_k[kBlock];
+    uint32_t bn = 0, bk = kDefaultCommonMapq;
+    for (uint32_t k = threadIdx.x; k < 65536u; k += kBlock)
+        if (votes[k] > bn) { bn = votes[k]; bk = k; }      // ties: the lowest key of this thread's stride
+    best_n[threadIdx.x] = bn;
+    best_k[threadIdx.x] = bk;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (uint32_t t = 1; t < kBlock; ++t)
+            if (best_n[t] > bn || (best_n[t] == bn && bn && best_k[t] < bk)) { bn = best_n[t]; bk = best_k[t]; }
+        votes[65536] = bk;
+    }
+}
 
 struct ScanArgs {
     const uint4* csr;
@@ -105,6 +143,7 @@ struct ScanArgs {
     uint32_t n_libs;
     ScanOut* out;
     uint32_t* err;
+    const uint32_t* common_mq;   // device word written by svt_mapq_pick_kernel
 };
 
 // one thread per unit: validate the record contract of include/svtyper_hip.h, count the entries of the
@@ -116,6 +155,7 @@ __global__ __launch_bounds__(kBlock) void svt_scan_kernel(const ScanArgs a)
     const uint64_t lo = a.rec_offset[u], hi = a.rec_offset[u + 1];
     const UnitGeom g = unit_geom(a.units[u]);
     ScanOut o{};
+    const uint32_t common = *a.common_mq;
     uint32_t bad = 0, lib_min = 0xffu, lib_max = 0u;
     for (uint64_t j = lo; j < hi; ++j) {
         const uint4 w = a.csr[j];
@@ -131,6 +171,8 @@ __global__ __launch_bounds__(kBlock) void svt_scan_kernel(const ScanArgs a)
         if (keeps_pair_entry(w, g, a.libs[lib])) {
             ++o.n[kPairs];
             if ((w.y & 0x8080u) != 0u) o.flags |= kScanWideMapq;
+            // half-words of the short layout: one, or an aligned pair (ShortRowWriter below)
+            o.n_short += (w.y & 0xffffu) == common ? 1u : (o.n_short & 1u) + 2u;
         }
         uint32_t k[3];
         weight_pairs(w, k);
@@ -154,6 +196,8 @@ struct RepackArgs {
     uint4* tiled;
     uint32_t n_tiles;
     uint32_t multi_lib;         // pair entries carry (lib - lib_min) and 7-bit MAPQs
+    uint32_t short_pairs;       // kLayoutShort
+    uint32_t common_mq;         // kLayoutShort: the MAPQ pair of the one-half-word entries
 };
 
 // dense layout: CSR records -> lane-interleaved rows of 16-byte records
@@ -231,6 +275,45 @@ struct RowWriter {
     }
 };
 
+// short layout: eight half-words per 16-byte row slot of the lane
+struct ShortRowWriter {
+    uint4* out;       // row 0 of this lane
+    uint32_t n = 0;   // half-words so far
+    uint32_t w[4] = {0u, 0u, 0u, 0u};
+    __device__ __forceinline__ void put_half(const uint32_t hw)
+    {
+        const uint32_t k = n & 7u;
+        const uint32_t v = hw << ((k & 1u) * 16u);
+        switch (k >> 1) {
+        case 0: w[0] |= v; break;
+        case 1: w[1] |= v; break;
+        case 2: w[2] |= v; break;
+        default: w[3] |= v;
+        }
+        if (k == 7u) {
+            out[(uint64_t)(n >> 3) * kWave] = make_uint4(w[0], w[1], w[2], w[3]);
+            w[0] = w[1] = w[2] = w[3] = 0u;
+        }
+        ++n;
+    }
+    __device__ __forceinline__ void put(const uint32_t lo16, const uint32_t mq, const uint32_t common)
+    {
+        if (mq == common) {
+            put_half(lo16);
+        } else {
+            if (n & 1u) put_half(0u);          // no-op: wide entries start on a 4-byte boundary
+            put_half(lo16 | kWideEntry);
+            put_half(mq);
+        }
+    }
+    __device__ __forceinline__ void finish(const uint32_t rows)
+    {
+        uint32_t r = n >> 3;
+        if (n & 7u) out[(uint64_t)r++ * kWave] = make_uint4(w[0], w[1], w[2], w[3]);
+        for (; r < rows; ++r) out[(uint64_t)r * kWave] = make_uint4(0, 0, 0, 0);
+    }
+};
+
 // compact layout: CSR records -> the three entry streams of the tile, in record order
 __global__ __launch_bounds__(kBlock) void svt_repack_compact_kernel(const RepackArgs a)
 {
@@ -247,6 +330,7 @@ __global__ __launch_bounds__(kBlock) void svt_repack_compact_kernel(const Repack
     const uint32_t lib_min = (h.packed >> 16) & 0xffu;
     uint4* row0 = a.tiled + td.base + lane;
     RowWriter P{row0};
+    ShortRowWriter S{row0};
     WeightRowWriter R{row0 + (uint64_t)td.rows[kPairs] * kWave};
     WeightRowWriter X{row0 + (uint64_t)(td.rows[kPairs] + td.rows[kRefReads]) * kWave};
     bool frag_has[3] = {false, false, false};  // did the current fragment already emit an entry for this tally?
@@ -258,8 +342,9 @@ __global__ __launch_bounds__(kBlock) void svt_repack_compact_kernel(const Repack
         if (keeps_pair_entry(w, g, lib)) {
             const uint32_t lo16 = (w.w & 7u) | (pair_code(w.x, g, lib) << 3);
             const uint32_t mq_a = w.y & 0xffu, mq_b = (w.y >> 8) & 0xffu;
-            P.put(a.multi_lib ? (lo16 | ((lib_idx - lib_min) << 16) | (mq_a << 18) | (mq_b << 25))
-                              : (lo16 | (mq_a << 16) | (mq_b << 24)));
+            if (a.short_pairs) S.put(lo16, w.y & 0xffffu, a.common_mq);
+            else P.put(a.multi_lib ? (lo16 | ((lib_idx - lib_min) << 16) | (mq_a << 18) | (mq_b << 25))
+                                   : (lo16 | (mq_a << 16) | (mq_b << 24)));
         }
         uint32_t k[3];
         weight_pairs(w, k);
@@ -274,7 +359,8 @@ __global__ __launch_bounds__(kBlock) void svt_repack_compact_kernel(const Repack
                 frag_has[s] = true;
             }
     }
-    P.finish(td.rows[kPairs]);
+    if (a.short_pairs) S.finish(td.rows[kPairs]);
+    else P.finish(td.rows[kPairs]);
     R.finish(td.rows[kRefReads]);
     X.finish(td.rows[kCandidates]);
 }

@@ -85,7 +85,8 @@ struct svt_batch {
     uint64_t n_units = 0, n_records = 0, slots = 0;
     uint32_t n_tiles = 0;
     int mode = kSingleLds;
-    bool compact = true;   // sparse 4-byte entry streams (default) vs the canonical 16-byte records
+    int layout = kLayoutCompact;   // svt_device_types.h: Layout
+    uint32_t common_mq = kDefaultCommonMapq;   // kLayoutShort: the MAPQ pair of the one-half-word entries
     size_t lds_bytes = 0;
     bool have_results = false;
     // device buffers
@@ -149,22 +150,24 @@ int upload(DevScratch& d, const std::vector<T>& v, Stager& st)
 }
 
 template <bool SSO>
-const void* kernel_for(int mode, bool compact)
+const void* kernel_for(int mode, int layout)
 {
-    if (compact)   // only chosen together with one of the LDS modes (create_on_device)
-        return mode == kSingleLds ? reinterpret_cast<const void*>(&svt_genotype_kernel<SSO, kSingleLds, true>)
-                                  : reinterpret_cast<const void*>(&svt_genotype_kernel<SSO, kMultiLds, true>);
+    if (layout == kLayoutShort)     // one library, tables in LDS (create_on_device)
+        return reinterpret_cast<const void*>(&svt_genotype_kernel<SSO, kSingleLds, kLayoutShort>);
+    if (layout == kLayoutCompact)   // only chosen together with one of the LDS modes (create_on_device)
+        return mode == kSingleLds ? reinterpret_cast<const void*>(&svt_genotype_kernel<SSO, kSingleLds, kLayoutCompact>)
+                                  : reinterpret_cast<const void*>(&svt_genotype_kernel<SSO, kMultiLds, kLayoutCompact>);
     switch (mode) {
-    case kSingleLds: return reinterpret_cast<const void*>(&svt_genotype_kernel<SSO, kSingleLds, false>);
-    case kMultiLds:  return reinterpret_cast<const void*>(&svt_genotype_kernel<SSO, kMultiLds, false>);
-    default:         return reinterpret_cast<const void*>(&svt_genotype_kernel<SSO, kGeneral, false>);
+    case kSingleLds: return reinterpret_cast<const void*>(&svt_genotype_kernel<SSO, kSingleLds, kLayoutDense>);
+    case kMultiLds:  return reinterpret_cast<const void*>(&svt_genotype_kernel<SSO, kMultiLds, kLayoutDense>);
+    default:         return reinterpret_cast<const void*>(&svt_genotype_kernel<SSO, kGeneral, kLayoutDense>);
     }
 }
 
 const void* kernel_of(const svt_batch* b)
 {
-    return (b->flags & SVT_FLAG_SSO_ASSOCIATION) ? kernel_for<true>(b->mode, b->compact)
-                                                 : kernel_for<false>(b->mode, b->compact);
+    return (b->flags & SVT_FLAG_SSO_ASSOCIATION) ? kernel_for<true>(b->mode, b->layout)
+                                                 : kernel_for<false>(b->mode, b->layout);
 }
 
 int launch_genotype(svt_batch* b)
@@ -272,6 +275,18 @@ int create_on_device(const svt_evidence_batch* in, svt_batch* b, const uint4* d_
     SVT_TRY(d_counts.alloc(n * sizeof(ScanOut)));
     SVT_TRY(d_err.alloc(sizeof(uint32_t)));
     HIP_TRY(hipMemsetAsync(d_err.p, 0, sizeof(uint32_t), b->stream));
+    // the batch's most common MAPQ pair (short layout), voted by the first records
+    DevScratch d_votes;
+    SVT_TRY(d_votes.alloc((65536 + 1) * sizeof(uint32_t)));
+    HIP_TRY(hipMemsetAsync(d_votes.p, 0, (65536 + 1) * sizeof(uint32_t), b->stream));
+    {
+        const uint32_t n_vote = (uint32_t)std::min<uint64_t>(n_rec, kVoteRecords);
+        if (n_vote)
+            hipLaunchKernelGGL(svt_mapq_vote_kernel, dim3((n_vote + kBlock - 1) / kBlock), dim3(kBlock), 0, b->stream,
+                               d_csr, n_vote, d_votes.as<uint32_t>());
+        hipLaunchKernelGGL(svt_mapq_pick_kernel, dim3(1), dim3(kBlock), 0, b->stream, d_votes.as<uint32_t>());
+        HIP_TRY(hipGetLastError());
+    }
     std::vector<ScanOut>& counts = g_host.counts;
     counts.assign(n, ScanOut{});
     uint32_t err_bits = 0;
@@ -285,10 +300,12 @@ int create_on_device(const svt_evidence_batch* in, svt_batch* b, const uint4* d_
         sa.n_libs = in->n_libs;
         sa.out = d_counts.as<ScanOut>();
         sa.err = d_err.as<uint32_t>();
+        sa.common_mq = d_votes.as<uint32_t>() + 65536;
         hipLaunchKernelGGL(svt_scan_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, b->stream, sa);
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipMemcpyAsync(&err_bits, d_err.p, sizeof(uint32_t), hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipMemcpyAsync(&b->common_mq, d_votes.as<uint32_t>() + 65536, sizeof(uint32_t), hipMemcpyDeviceToHost, b->stream));
     if (n) SVT_TRY(d2h_staged(counts.data(), d_counts.p, n * sizeof(ScanOut), b->stream));
     HIP_TRY(hipStreamSynchronize(b->stream));
     tm.mark("scan kernel + counts D2H");
@@ -304,14 +321,16 @@ int create_on_device(const svt_evidence_batch* in, svt_batch* b, const uint4* d_
     // ---- layout: the compact entries need the 32-bit table geometry, histograms narrow enough for
     // the 13-bit code, DEL lengths >= 0 and, with several libraries, at most 4 consecutive libraries
     // per unit and 7-bit MAPQs on the kept pair entries; anything else keeps the canonical records
-    if (b->compact) {
+    if (b->layout != kLayoutDense) {
         bool ok = T.fast_geometry && !negative_del;
         for (const LibDesc& L : T.libs) ok = ok && L.n_bins <= kMaxCompactBins;
         if (ok && in->n_libs > 1)
             for (uint64_t u = 0; u < n && ok; ++u)
                 ok = ((counts[u].libs >> 8) & 0xffu) - (counts[u].libs & 0xffu) < kMaxCompactLibSpan &&
                      !(counts[u].flags & kScanWideMapq);
-        b->compact = ok;
+        // short pair entries: one library whose table code fits 12 bits (bit 15 of the half-word marks a wide entry)
+        const bool can_short = in->n_libs == 1 && T.libs[0].n_bins <= kMaxShortBins && !(b->flags & SVT_FLAG_FIXED_PAIR_ENTRIES);
+        b->layout = !ok ? kLayoutDense : can_short ? kLayoutShort : kLayoutCompact;
     }
 
     // ---- tiling
@@ -321,7 +340,7 @@ int create_on_device(const svt_evidence_batch* in, svt_batch* b, const uint4* d_
     uint32_t n_groups = 0, max_win_libs = 1, max_win_bins = 1;
     auto plan = [&]() -> int {
         G.slots = 0;
-        build_tiling(in, nrec, counts, b->compact, G);
+        build_tiling(in, nrec, counts, b->layout, G);
         if (G.tiles.size() > 0xFFFFFFF0ull / kWave) return fail(SVT_ERR_INVALID, "too many tiles");
         b->n_tiles = (uint32_t)G.tiles.size();
         b->slots = G.slots;
@@ -372,8 +391,8 @@ int create_on_device(const svt_evidence_batch* in, svt_batch* b, const uint4* d_
     };
     SVT_TRY(plan());
     const bool lds_tables = T.fast_geometry && (size_t)max_win_bins * sizeof(Bin) <= kMaxLdsTableBytes;
-    if (b->compact && !lds_tables) {   // the compact entries only exist for the LDS modes
-        b->compact = false;
+    if (b->layout != kLayoutDense && !lds_tables) {   // the compact entries only exist for the LDS modes
+        b->layout = kLayoutDense;
         SVT_TRY(plan());
     }
 
@@ -419,8 +438,10 @@ int create_on_device(const svt_evidence_batch* in, svt_batch* b, const uint4* d_
         ra.tiled = b->d_tiled;
         ra.n_tiles = b->n_tiles;
         ra.multi_lib = in->n_libs > 1 ? 1u : 0u;
+        ra.short_pairs = b->layout == kLayoutShort ? 1u : 0u;
+        ra.common_mq = b->common_mq;
         const dim3 grid((b->n_tiles + kWavesPerBlock - 1) / kWavesPerBlock), block(kBlock);
-        if (b->compact) hipLaunchKernelGGL(svt_repack_compact_kernel, grid, block, 0, b->stream, ra);
+        if (b->layout != kLayoutDense) hipLaunchKernelGGL(svt_repack_compact_kernel, grid, block, 0, b->stream, ra);
         else hipLaunchKernelGGL(svt_repack_dense_kernel, grid, block, 0, b->stream, ra);
         HIP_TRY(hipGetLastError());
     }
@@ -444,6 +465,7 @@ int create_on_device(const svt_evidence_batch* in, svt_batch* b, const uint4* d_
     a.n_units = n;
     a.out = b->d_out;
     a.lib0 = T.libs[0];
+    a.common_mq = b->common_mq;
     fill_gt_consts(a.c, in->split_weight, in->disc_weight);
 
     a.wg = b->d_wg;
@@ -495,7 +517,7 @@ int svt_batch_create(const svt_evidence_batch* in, int device, unsigned flags, s
     if (!in || !out) return fail(SVT_ERR_INVALID, "null argument");
     *out = nullptr;
     const uint64_t n = in->n_units;
-    if (flags & ~(SVT_FLAG_SSO_ASSOCIATION | SVT_FLAG_DENSE_LAYOUT)) return fail(SVT_ERR_INVALID, "unknown flag bits");
+    if (flags & ~(SVT_FLAG_SSO_ASSOCIATION | SVT_FLAG_DENSE_LAYOUT | SVT_FLAG_FIXED_PAIR_ENTRIES)) return fail(SVT_ERR_INVALID, "unknown flag bits");
     if (n >= 0xFFFFFFF0ull) return fail(SVT_ERR_INVALID, "too many units in one batch (< 2^32)");
     if (in->n_libs == 0 || in->n_libs > 256 || !in->libs) return fail(SVT_ERR_INVALID, "n_libs must be 1..256");
     if (n && (!in->rec_offset || !in->units)) return fail(SVT_ERR_INVALID, "null unit arrays");
@@ -514,7 +536,7 @@ int svt_batch_create(const svt_evidence_batch* in, int device, unsigned flags, s
     if (!b) return fail(SVT_ERR_NOMEM, "out of host memory");
     b->device = device;
     b->flags = flags;
-    b->compact = (flags & SVT_FLAG_DENSE_LAYOUT) == 0;
+    b->layout = (flags & SVT_FLAG_DENSE_LAYOUT) ? kLayoutDense : kLayoutCompact;
     b->n_units = n;
     b->n_records = n ? in->rec_offset[n] : 0;
     const int rc = create_on_device(in, b);
@@ -534,7 +556,7 @@ int svt_batch_create_from_fragments(const svt_fragment_batch* in, int device, un
     if (!in || !out) return fail(SVT_ERR_INVALID, "null argument");
     *out = nullptr;
     const uint64_t n = in->n_units;
-    if (flags & ~(SVT_FLAG_SSO_ASSOCIATION | SVT_FLAG_DENSE_LAYOUT)) return fail(SVT_ERR_INVALID, "unknown flag bits");
+    if (flags & ~(SVT_FLAG_SSO_ASSOCIATION | SVT_FLAG_DENSE_LAYOUT | SVT_FLAG_FIXED_PAIR_ENTRIES)) return fail(SVT_ERR_INVALID, "unknown flag bits");
     if (n >= 0xFFFFFFF0ull) return fail(SVT_ERR_INVALID, "too many units in one batch (< 2^32)");
     if (in->n_libs == 0 || in->n_libs > 256 || !in->libs) return fail(SVT_ERR_INVALID, "n_libs must be 1..256");
     if (n && (!in->frag_offset || !in->breakpoints)) return fail(SVT_ERR_INVALID, "null unit arrays");
@@ -637,7 +659,7 @@ int svt_batch_create_from_fragments(const svt_fragment_batch* in, int device, un
     if (!b) return fail(SVT_ERR_NOMEM, "out of host memory");
     b->device = device;
     b->flags = flags;
-    b->compact = (flags & SVT_FLAG_DENSE_LAYOUT) == 0;
+    b->layout = (flags & SVT_FLAG_DENSE_LAYOUT) ? kLayoutDense : kLayoutCompact;
     b->n_units = n;
     b->n_records = n_frag;
     const int rc = create_on_device(&eb, b, static_cast<const uint4*>(d_records.p));
@@ -721,7 +743,7 @@ int svt_batch_bytes(const svt_batch* b, uint64_t* algorithmic, uint64_t* residen
 int svt_batch_layout(const svt_batch* b, int* compact, int* table_mode)
 {
     if (!b) return fail(SVT_ERR_INVALID, "null batch");
-    if (compact) *compact = b->compact ? 1 : 0;
+    if (compact) *compact = b->layout;
     if (table_mode) *table_mode = b->mode;
     return SVT_OK;
 }

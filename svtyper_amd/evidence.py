@@ -20,6 +20,7 @@ SVTYPE_NAME = {v: k for k, v in SVTYPE_CODE.items()}
 
 FLAG_SSO_ASSOCIATION = 0x1
 FLAG_DENSE_LAYOUT = 0x2
+FLAG_FIXED_PAIR_ENTRIES = 0x4   # compact layout with 4-byte pair entries only (no 2-byte short entries)
 
 REC_ALT_STRADDLE = 1 << 0
 REC_REF_STRADDLE_A = 1 << 1

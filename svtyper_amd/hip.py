@@ -16,7 +16,7 @@ from .evidence import CEvidenceBatch, EvidenceBatch, Results
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SVTYPER_HIP_LIB") or os.path.join(_HERE, "csrc", "libsvtyper_hip.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 EXPORTS = (
     "svt_version", "svt_device_count", "svt_last_error", "svt_batch_create", "svt_batch_create_from_fragments",
@@ -198,6 +198,13 @@ class DeviceBatch:
         c, m = C.c_int(), C.c_int()
         _check(self._lib.svt_batch_layout(self._h, C.byref(c), C.byref(m)))
         return bool(c.value), int(m.value)
+
+    def layout_name(self) -> str:
+        """"dense" (16-byte records), "compact" (entry streams, 4-byte pair entries) or "short" (entry streams,
+        2-byte pair entries for the batch's most common MAPQ pair)"""
+        c, m = C.c_int(), C.c_int()
+        _check(self._lib.svt_batch_layout(self._h, C.byref(c), C.byref(m)))
+        return ("dense", "compact", "short")[c.value]
 
     def stream(self) -> int:
         return int(self._lib.svt_batch_stream(self._h) or 0)

@@ -41,7 +41,8 @@ def run_both(batch, flags=0, device=0):
     return got, want
 
 
-ALL_FLAGS = [0, ev.FLAG_SSO_ASSOCIATION, ev.FLAG_DENSE_LAYOUT, ev.FLAG_DENSE_LAYOUT | ev.FLAG_SSO_ASSOCIATION]
+ALL_FLAGS = [0, ev.FLAG_SSO_ASSOCIATION, ev.FLAG_DENSE_LAYOUT, ev.FLAG_DENSE_LAYOUT | ev.FLAG_SSO_ASSOCIATION,
+             ev.FLAG_FIXED_PAIR_ENTRIES, ev.FLAG_FIXED_PAIR_ENTRIES | ev.FLAG_SSO_ASSOCIATION]
 
 
 def oracle_flags(flags):
@@ -470,3 +471,75 @@ def test_site_qual_on_device(hip_device, fixture_library, n_samples):
     with pytest.raises(hip.SvtyperHipError):
         with hip.DeviceBatch(batch, hip_device) as d:
             d.site_qual(n_samples)          # no pass has run yet
+
+
+# ------------------------------------------------------------------------------------------
+# short layout: 2-byte pair entries for the batch's most common MAPQ pair, 4-byte-aligned wide entries otherwise
+# ------------------------------------------------------------------------------------------
+def _name_of(batch, flags=0, device=0):
+    from svtyper_amd import hip
+    with hip.DeviceBatch(batch, device, flags) as d:
+        return d.layout_name()
+
+
+def test_short_layout_is_the_default_for_one_narrow_library(hip_device, fixture_library):
+    assert len(fixture_library.hist) <= 2047
+    batch = synth.make_units(4000, 51, [fixture_library], svtype_mix=(0.6, 0.2, 0.1, 0.1))
+    assert _name_of(batch) == "short"
+    assert _name_of(batch, ev.FLAG_FIXED_PAIR_ENTRIES) == "compact"
+    assert _name_of(batch, ev.FLAG_DENSE_LAYOUT) == "dense"
+    # a library between 2048 and 4095 bins keeps the 4-byte entries; several libraries as well
+    mid = synth.normal_library(1500.0, 420.0, seed=9)
+    assert 2047 < len(mid.hist) <= 4095
+    assert _name_of(synth.make_units(500, 52, [mid])) == "compact"
+    assert _name_of(synth.make_units(500, 53, [fixture_library, synth.normal_library(420.0, 95.0, seed=3)])) == "compact"
+
+
+@pytest.mark.parametrize("pattern", ["all_common", "all_wide", "alternate", "runs", "random", "mapq255", "vote_other"])
+def test_short_layout_mapq_patterns(hip_device, fixture_library, pattern):
+    """Every mix of one-half-word and wide entries (and the no-op half-words that align the wide ones), with the
+    common pair found by the vote -- which need not be (60, 60)."""
+    import zlib
+    rng = np.random.default_rng(zlib.crc32(pattern.encode()))
+    batch = synth.make_units(3000, 61, [fixture_library], svtype_mix=(0.5, 0.2, 0.2, 0.1), mean_frags=40, sd_frags=25,
+                             min_frags=0)
+    n = batch.n_records
+    a, b = batch.records["mapq_a"], batch.records["mapq_b"]
+    if pattern == "all_common":
+        a[:], b[:] = 60, 60
+    elif pattern == "all_wide":
+        a[:] = rng.integers(1, 60, n); b[:] = 60 - a // 2           # never (60, 60), all different
+    elif pattern == "alternate":
+        a[:], b[:] = 60, 60
+        a[::2] = 37
+    elif pattern == "runs":
+        a[:], b[:] = 60, 60
+        k = np.arange(n)
+        wide = (k % 11) < 3                                          # 3 wide, 8 common, ...: every alignment case
+        a[wide], b[wide] = 23, 59
+    elif pattern == "random":
+        a[:] = rng.choice([60, 60, 60, 0, 1, 40, 255], n); b[:] = rng.choice([60, 60, 60, 0, 13, 255], n)
+    elif pattern == "mapq255":
+        a[:], b[:] = 255, 255
+        a[::5] = 128
+    else:   # the vote picks (40, 13); (60, 60) entries are then the wide ones
+        a[:], b[:] = 40, 13
+        a[::4], b[::4] = 60, 60
+    assert _name_of(batch) == "short"
+    for flags in ALL_FLAGS:
+        got, want = run_both(batch, flags)
+        assert_parity(got, want)
+
+
+def test_short_layout_is_smaller_and_equal_on_the_headline_shape(hip_device, fixture_library):
+    from svtyper_amd import hip
+    batch = synth.make_config("c3_mixed_1m", [fixture_library], n_units=30_000)
+    sizes, results = {}, {}
+    for name, flags in (("short", 0), ("compact", ev.FLAG_FIXED_PAIR_ENTRIES), ("dense", ev.FLAG_DENSE_LAYOUT)):
+        with hip.DeviceBatch(batch, hip_device, flags) as d:
+            assert d.layout_name() == name
+            sizes[name] = d.bytes()[1]
+            d.genotype(sync=True)
+            results[name] = d.results().rec.tobytes()
+    assert results["short"] == results["compact"] == results["dense"]
+    assert sizes["short"] < 0.8 * sizes["compact"] < sizes["dense"]
