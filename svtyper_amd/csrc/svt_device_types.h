@@ -66,7 +66,8 @@ struct Bin {
 // regions have fixed addresses; the compact entries are consumed with these as immediates.
 constexpr uint32_t kLdsPm = 0;                       // double[256]      prob_mapq
 constexpr uint32_t kLdsWtab = kLdsPm + 256 * 8;      // PairWeights[32]  paired-end decision table
-constexpr uint32_t kLdsBins = kLdsWtab + 32 * 16;    // Bin[lds_bins], then LibDesc[lds_libs], then log10
+constexpr uint32_t kLdsWtabC = kLdsWtab + 32 * 16;   // PairWeights[32]  the same table times pmA * pmB of the batch's common MAPQ pair (short layout)
+constexpr uint32_t kLdsBins = kLdsWtabC + 32 * 16;   // Bin[lds_bins], then LibDesc[lds_libs], then log10
 
 struct GtConsts {
     double lgp[2][3];     // [is_dup][genotype] log(p)/log(10)      (statistics.py:33-35)

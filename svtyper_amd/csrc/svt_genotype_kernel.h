@@ -73,7 +73,6 @@ struct LaneCtx {
     double pos_delta_d;
     bool is_del;
     uint32_t common_mq;   // short layout: mapq_a | mapq_b << 8 of the one-half-word pair entries
-    double pp_common;     // short layout: prob_mapq(mapq_a) * prob_mapq(mapq_b) of that pair
 };
 
 // ---- dense layout: one canonical 16-byte record -------------------------------------------------
@@ -227,9 +226,18 @@ __device__ __forceinline__ void short_pair_dword(const uint32_t e, const LaneCtx
     const uint32_t mq = wide ? hi : c.common_mq;
     const double pm_a = lds_f64(kLdsPm + byte0_x8(mq)), pm_b = lds_f64(kLdsPm + byte1_x8(mq));
     pair_eval_single(e & 0x7ff8u, (e << 4) & 0x70u, pm_a * pm_b, c, a);
-    // the high half: a second entry with the common MAPQs, or the MAPQ bytes of the wide entry just added --
-    // then its straddle bits read as 0, both weights are 0 and the sums receive +0.0
-    pair_eval_single(hi & 0x7ff8u, wide ? 0u : (hi << 4) & 0x70u, c.pp_common, c, a);
+    // the high half: a second entry with the common MAPQs -- its products pmA * pmB * {w_alt, w_ref} come ready from the
+    // second decision table -- or the MAPQ bytes of the wide entry just added: then the straddle bits read as 0,
+    // both table values are 0 and the sums receive +0.0
+    {
+        const uint32_t code8 = hi & 0x7ff8u;
+        const int32_t thr1 = lds_i32(kLdsBins + min(code8, c.nb8));
+        const uint32_t h2 = lds_u32(kLdsBins + 4u + min(code8 - c.off2_8, c.nb8));
+        const bool p_conc = (int32_t)h2 <= thr1;
+        const uint32_t wa = ((p_conc ? c.wt1 : c.wt0) + (kLdsWtabC - kLdsWtab)) | (wide ? 0u : (hi << 4) & 0x70u);
+        a.alt_span += lds_f64(wa);
+        a.ref_span += lds_f64(wa + 8u);
+    }
 }
 
 // Reference-read entries (classic.py:306-315): seven MAPQ pairs per row slot, byte 14 of the slot holds their
@@ -375,7 +383,7 @@ __global__ __launch_bounds__(kBlock, SVT_MIN_WAVES) void svt_genotype_kernel(con
 {
     constexpr bool COMPACT = LAYOUT != kLayoutDense;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // LDS layout (svt_device_types.h): pm[256] | wtab[32] | bins[lds_bins] | libs[lds_libs] | libx[lds_libs] | l10[n_l10]
+    // LDS layout (svt_device_types.h): pm[256] | wtab[32] | wtab x common pair[32] | bins[lds_bins] | libs[lds_libs] | libx[lds_libs] | l10[n_l10]
     double* s_pm = reinterpret_cast<double*>(smem + kLdsPm);
     PairWeights* s_wtab = reinterpret_cast<PairWeights*>(smem + kLdsWtab);
     Bin* s_bins = reinterpret_cast<Bin*>(smem + kLdsBins);
@@ -403,6 +411,11 @@ __global__ __launch_bounds__(kBlock, SVT_MIN_WAVES) void svt_genotype_kernel(con
     // ---- stage the tables in LDS (they are L2-resident after the first workgroups)
     for (uint32_t i = threadIdx.x; i < 256; i += kBlock) s_pm[i] = a.pm[i];
     if (threadIdx.x < 32) s_wtab[threadIdx.x] = a.wtab[threadIdx.x];
+    if (LAYOUT == kLayoutShort && threadIdx.x < 32) {   // the decision table times the common pair's pmA * pmB (the very product an entry would form)
+        const double pp0 = a.pm[a.common_mq & 0xffu] * a.pm[(a.common_mq >> 8) & 0xffu];
+        const PairWeights w = a.wtab[threadIdx.x];
+        reinterpret_cast<PairWeights*>(smem + kLdsWtabC)[threadIdx.x] = PairWeights{pp0 * w.w_alt, pp0 * w.w_ref};
+    }
     if (a.l10_in_lds)
         for (uint32_t i = threadIdx.x; i < a.n_l10; i += kBlock) s_l10[i] = a.l10[i];
     for (uint32_t i = threadIdx.x; i < wd.lib_cnt * (uint32_t)(sizeof(LibDesc) / 8); i += kBlock)
@@ -454,7 +467,6 @@ __global__ __launch_bounds__(kBlock, SVT_MIN_WAVES) void svt_genotype_kernel(con
     }
 
     c.common_mq = a.common_mq;
-    c.pp_common = s_pm[a.common_mq & 0xffu] * s_pm[(a.common_mq >> 8) & 0xffu];
 
     Acc acc = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
 
