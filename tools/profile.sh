@@ -11,7 +11,7 @@ BENCH_SHORT="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-dense-l
 timeout 240 rocprofv3 --kernel-trace --stats -d $OUT/stats -o stats -- $BENCH > $OUT/stats_bench.json 2> $OUT/stats.err
 timeout 240 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS -d $OUT/pmc_sq1 -o pmc -- $BENCH_SHORT > /dev/null 2> $OUT/pmc_sq1.err
 timeout 240 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_VMEM_RD -d $OUT/pmc_sq2 -o pmc -- $BENCH_SHORT > /dev/null 2> $OUT/pmc_sq2.err
-timeout 240 rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE -d $OUT/pmc_fetch -o pmc -- $BENCH_SHORT > /dev/null 2> $OUT/pmc_fetch.err
+timeout 240 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o pmc -- $BENCH_SHORT > /dev/null 2> $OUT/pmc_fetch.err
 timeout 240 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o pmc -- $BENCH_SHORT > /dev/null 2> $OUT/pmc_write.err
 python tools/summarize_prof.py $OUT > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt
