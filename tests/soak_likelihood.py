@@ -55,4 +55,4 @@ while time.time() - t0 < budget:
             sys.exit(1)
     it += 1
     units += b.n_units
-print("soak ok: iterations %d..%d, %d units, 4 flag combinations each, %.0f s" % (first, it - 1, units, time.time() - t0))
+print("soak ok: iterations %d..%d, %d units, %d flag combinations each, %.0f s" % (first, it - 1, units, len(P.ALL_FLAGS), time.time() - t0))
