@@ -566,9 +566,18 @@ __global__ __launch_bounds__(kBlock, SVT_MIN_WAVES) void svt_genotype_kernel(con
         // host libm's own underflow point of pow(10, x), so GT './.' agrees with CPython.
         const double gl_best = gl[best];
         if (gl_best >= a.c.x_uflow) {
+            // 10**gl: exp10 (no logarithm inside, a third of pow's instructions) wherever its last-place error
+            // cannot show -- with the largest term far above the subnormal range every term is either accurate
+            // to an ulp or negligible beside it.  Sums near the underflow point keep pow, whose rounding of
+            // subnormal results is the one the parity tests pinned against the host libm.
             double gt_sum = 0.0;
+            if (gl_best >= -290.0) {
 #pragma unroll
-            for (int g = 0; g < 3; ++g) gt_sum += pow(10.0, gl[g]);
+                for (int g = 0; g < 3; ++g) gt_sum += exp10(gl[g]);
+            } else {
+#pragma unroll
+                for (int g = 0; g < 3; ++g) gt_sum += pow(10.0, gl[g]);
+            }
             const double gt_sum_log = log(gt_sum) / a.c.ln10;                       // :480
             sq = fabs(-10.0 * (gl[0] - gt_sum_log));                                // :481
             double phred_gq = -10.0 * (gl[second] - gl_best);                       // :482

@@ -543,3 +543,32 @@ def test_short_layout_is_smaller_and_equal_on_the_headline_shape(hip_device, fix
             results[name] = d.results().rec.tobytes()
     assert results["short"] == results["compact"] == results["dense"]
     assert sizes["short"] < 0.8 * sizes["compact"] < sizes["dense"]
+
+
+def test_sum_of_likelihoods_across_the_underflow_band(hip_device, fixture_library):
+    """gt_sum = sum(10**GL) (classic.py:473-481) from comfortable magnitudes down through the subnormal range to
+    0: the kernel forms 10**x with exp10 while the largest term is far from underflow and with pow below that, SQ
+    must stay within 1e-6 of the reference arithmetic on both sides of the switch and GT './.' must start at the
+    same unit."""
+    # alt-only pair evidence: QA = n (or n - 1), QR = 0; GL of the best genotype = QA * log10(0.9) for a DEL
+    # (-0.046 per read) and QA * log10(1/3) for a DUP (-0.477 per read): both sweep -250 .. -335
+    for svtype, counts in ((0, np.arange(5500, 7320, 3)), (1, np.arange(520, 710))):
+        off = np.concatenate([[0], np.cumsum(counts)]).astype(np.uint64)
+        r = np.zeros(int(off[-1]), ev.RECORD_DTYPE)
+        r["flags"] = np.uint32(ev.REC_ALT_STRADDLE | ev.REC_HAS_PAIR)
+        r["mapq_a"], r["mapq_b"] = 60, 60
+        r["ospan_len"] = 100_000                      # far outside the histogram
+        u = np.zeros(len(counts), ev.UNIT_DTYPE)
+        u["svtype"] = svtype
+        u["var_length"] = 5000 if svtype == 0 else 0
+        u["pos_delta"] = 5000
+        batch = ev.EvidenceBatch(off, u, r, [fixture_library], 1.0, 1.0)
+        for flags in (0, ev.FLAG_DENSE_LAYOUT):
+            got, want = run_both(batch, flags)
+            assert_parity(got, want)
+        best = want.gl.max(axis=1)
+        called = want.gt >= 0
+        assert (best[called] > -280).any() and ((best[called] < -295) & (best[called] > -310)).any()
+        assert (want.gt == ev.GT_MISSING).any() and called.any()
+        # the band where 10**GL is subnormal is covered unit by unit
+        assert ((best < -308) & (best > -324)).sum() >= 5
