@@ -189,7 +189,8 @@ def main():
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    dbatch.genotype_n(args.steps)          # `steps` passes enqueued back to back on the batch stream
+    # `steps` passes enqueued back to back on the batch stream, between two HIP events on that stream
+    kern_ms = dbatch.genotype_timed(args.steps) / args.steps
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -198,8 +199,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # ---- dominant-kernel time by HIP events on the launch stream (for the roofline)
-    kern_ms = dbatch.genotype_timed(args.steps) / args.steps
+    # (kern_ms: the dominant kernel's average launch duration over the timed region itself, by HIP events on
+    # the launch stream -- torch.cuda.Event would only see torch's current stream)
 
     # ---- the single RCCL gather of the result records onto rank 0
     gather = None
