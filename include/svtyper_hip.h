@@ -45,6 +45,7 @@ extern "C" {
 #define SVT_ERR_HIP (-3)       /* a HIP runtime call failed                   */
 #define SVT_ERR_NOMEM (-4)
 #define SVT_ERR_STATE (-5)     /* results requested before genotype, ...      */
+#define SVT_ERR_INTERNAL (-6)  /* an unexpected failure inside the library     */
 
 /* ---- SV types (classic.py:228 accepts exactly these four) ----------------- */
 #define SVT_SVTYPE_DEL 0

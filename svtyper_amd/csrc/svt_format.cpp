@@ -22,6 +22,8 @@
 namespace {
 
 using svt::fail;
+using svt::guarded;
+using svt::run_threads;
 
 inline void put_int(std::string& s, int32_t v)
 {
@@ -82,7 +84,7 @@ void put_field(std::string& s, const svt_result& r, uint8_t field, bool skipped_
 
 extern "C" {
 
-int svt_format_results(const svt_result* res, uint64_t n_units, const uint8_t* fields, uint32_t n_fields,
+static int svt_format_results_impl(const svt_result* res, uint64_t n_units, const uint8_t* fields, uint32_t n_fields,
                        int skipped_as_dots, char** text_out, uint64_t** offsets_out)
 {
     if (!text_out || !offsets_out || (n_units && !res) || (n_fields && !fields)) return fail(SVT_ERR_INVALID, "null argument");
@@ -108,12 +110,7 @@ int svt_format_results(const svt_result* res, uint64_t n_units, const uint8_t* f
             len[t].push_back((uint32_t)(s.size() - at));
         }
     };
-    if (nt == 1) work(0);
-    else {
-        std::vector<std::thread> pool;
-        for (unsigned t = 0; t < nt; ++t) pool.emplace_back(work, t);
-        for (auto& th : pool) th.join();
-    }
+    run_threads(nt, work);
     uint64_t total = 0;
     for (const auto& s : part) total += s.size();
     char* text = static_cast<char*>(std::malloc(std::max<uint64_t>(total, 1)));
@@ -135,6 +132,11 @@ int svt_format_results(const svt_result* res, uint64_t n_units, const uint8_t* f
     *text_out = text;
     *offsets_out = off;
     return SVT_OK;
+}
+
+int svt_format_results(const svt_result* res, uint64_t n_units, const uint8_t* fields, uint32_t n_fields, int skipped_as_dots, char** text_out, uint64_t** offsets_out)
+{
+    return guarded([&] { return svt_format_results_impl(res, n_units, fields, n_fields, skipped_as_dots, text_out, offsets_out); });
 }
 
 void svt_format_free(char* text, uint64_t* offsets)

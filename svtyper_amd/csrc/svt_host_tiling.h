@@ -4,6 +4,7 @@
 #define SVT_HOST_TILING_H
 
 #include "svt_device_types.h"
+#include "svt_error.h"
 #include "svt_host_cpus.h"
 #include "svt_prepare_kernels.h"
 
@@ -31,14 +32,8 @@ template <typename Fn>
 inline void parallel_for(uint64_t n, Fn&& fn)
 {
     const unsigned nt = (unsigned)std::min<uint64_t>(host_threads(), n);
-    if (nt <= 1) {
-        for (uint64_t i = 0; i < n; ++i) fn(i);
-        return;
-    }
-    std::vector<std::thread> pool;
-    for (unsigned t = 0; t < nt; ++t)
-        pool.emplace_back([&, t]() { for (uint64_t i = t; i < n; i += nt) fn(i); });
-    for (auto& th : pool) th.join();
+    if (nt == 0) return;
+    run_threads(nt, [&](unsigned t) { for (uint64_t i = t; i < n; i += nt) fn(i); });
 }
 
 // rows of 16-byte slots unit `u` needs in stream `k`

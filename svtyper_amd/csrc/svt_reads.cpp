@@ -37,6 +37,8 @@
 namespace {
 
 using svt::fail;
+using svt::guarded;
+using svt::run_threads;
 
 // ------------------------------------------------------------------------------------------
 // BGZF: random access through (compressed offset << 16 | in-block offset) addresses
@@ -111,6 +113,7 @@ public:
     Bgzf& operator=(const Bgzf&) = delete;
     bool ok() const { return file_.data != nullptr && (zs_ok_ || fast_); }
     bool failed() const { return bad_; }
+    void mark_bad() { bad_ = true; }   // the record stream inside the blocks is corrupt
 
     void seek(uint64_t voff)
     {
@@ -442,9 +445,10 @@ inline uint32_t le32(const uint8_t* d) { return (uint32_t)d[0] | (d[1] << 8) | (
 // -- otherwise gathered into `buf`.  nullptr at the end of the data / on a bad length.
 const uint8_t* next_record(Bgzf& z, std::vector<uint8_t>& buf, uint32_t& size)
 {
+    constexpr uint32_t kMaxRecord = 1u << 28;   // no alignment record is a quarter of a gigabyte: a corrupt length
     if (const uint8_t* h = z.contiguous(4)) {
         size = le32(h);
-        if (size < 32) return nullptr;
+        if (size < 32 || size > kMaxRecord) { z.mark_bad(); return nullptr; }
         if (const uint8_t* d = z.contiguous(4 + (size_t)size)) {
             z.advance(4 + (size_t)size);
             return d + 4;
@@ -453,7 +457,7 @@ const uint8_t* next_record(Bgzf& z, std::vector<uint8_t>& buf, uint32_t& size)
     uint8_t szb[4];
     if (z.read(szb, 4) != 4) return nullptr;
     size = le32(szb);
-    if (size < 32) return nullptr;
+    if (size < 32 || size > kMaxRecord) { z.mark_bad(); return nullptr; }
     buf.resize(size);
     if (z.read(buf.data(), size) != size) return nullptr;
     return buf.data();
@@ -953,7 +957,7 @@ int process_unit(const svt_bam& bam, Bgzf& z, std::vector<uint8_t>& buf, const s
 // ------------------------------------------------------------------------------------------
 extern "C" {
 
-int svt_bam_open(const char* path, svt_bam** out)
+static int svt_bam_open_impl(const char* path, svt_bam** out)
 {
     if (!path || !out) return fail(SVT_ERR_INVALID, "null argument");
     *out = nullptr;
@@ -1038,6 +1042,11 @@ int svt_bam_open(const char* path, svt_bam** out)
     return SVT_OK;
 }
 
+int svt_bam_open(const char* path, svt_bam** out)
+{
+    return guarded([&] { return svt_bam_open_impl(path, out); });
+}
+
 void svt_bam_close(svt_bam* bam) { delete bam; }
 
 int32_t svt_bam_n_references(const svt_bam* bam) { return bam ? (int32_t)bam->ref_names.size() : 0; }
@@ -1061,7 +1070,7 @@ int32_t svt_bam_tid(const svt_bam* bam, const char* name)
 
 const char* svt_bam_header_text(const svt_bam* bam) { return bam ? bam->text.c_str() : nullptr; }
 
-int svt_bam_summarise(const svt_bam* bam, const svt_summarise_args* args, svt_summaries* out)
+static int svt_bam_summarise_impl(const svt_bam* bam, const svt_summarise_args* args, svt_summaries* out)
 {
     if (!bam || !args || !out) return fail(SVT_ERR_INVALID, "null argument");
     out->frag_offset = nullptr;
@@ -1123,12 +1132,7 @@ int svt_bam_summarise(const svt_bam* bam, const svt_summarise_args* args, svt_su
             }
         }
     };
-    if (nt <= 1) worker(0);
-    else {
-        std::vector<std::thread> pool;
-        for (unsigned t = 0; t < nt; ++t) pool.emplace_back(worker, t);
-        for (auto& th : pool) th.join();
-    }
+    run_threads(nt, worker);
     if (first_rc.load() != SVT_OK) return fail(first_rc.load(), first_err);
     lap("units");
 
@@ -1166,15 +1170,17 @@ int svt_bam_summarise(const svt_bam* bam, const svt_summarise_args* args, svt_su
                                     outs[u].count * sizeof(svt_fragment));
             }
         };
-        std::vector<std::thread> pool;
-        for (unsigned t = 1; t < std::min(nt, 32u); ++t) pool.emplace_back(copier);
-        copier();
-        for (auto& th : pool) th.join();
+        run_threads(std::min(nt, 32u), [&](unsigned) { copier(); });
     }
     lap("gather");
     arenas.clear();
     lap("release");
     return SVT_OK;
+}
+
+int svt_bam_summarise(const svt_bam* bam, const svt_summarise_args* args, svt_summaries* out)
+{
+    return guarded([&] { return svt_bam_summarise_impl(bam, args, out); });
 }
 
 void svt_summaries_free(svt_summaries* s)
@@ -1188,7 +1194,7 @@ void svt_summaries_free(svt_summaries* s)
     s->skipped = nullptr;
 }
 
-int svt_bam_scan_library(const svt_bam* bam, uint32_t n_read_groups, const char* const* read_groups, int64_t num_samp,
+static int svt_bam_scan_library_impl(const svt_bam* bam, uint32_t n_read_groups, const char* const* read_groups, int64_t num_samp,
                          svt_library_scan* out)
 {
     if (!bam || !out || (n_read_groups && !read_groups)) return fail(SVT_ERR_INVALID, "null argument");
@@ -1266,6 +1272,11 @@ int svt_bam_scan_library(const svt_bam* bam, uint32_t n_read_groups, const char*
         std::memcpy(out->hist_counts, hist_counts.data(), hist_counts.size() * sizeof(uint64_t));
     }
     return SVT_OK;
+}
+
+int svt_bam_scan_library(const svt_bam* bam, uint32_t n_read_groups, const char* const* read_groups, int64_t num_samp, svt_library_scan* out)
+{
+    return guarded([&] { return svt_bam_scan_library_impl(bam, n_read_groups, read_groups, num_samp, out); });
 }
 
 void svt_library_scan_free(svt_library_scan* s)

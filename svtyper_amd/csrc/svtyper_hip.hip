@@ -512,7 +512,7 @@ int svt_device_count(void)
 
 const char* svt_last_error(void) { return g_err.c_str(); }
 
-int svt_batch_create(const svt_evidence_batch* in, int device, unsigned flags, svt_batch** out)
+static int svt_batch_create_impl(const svt_evidence_batch* in, int device, unsigned flags, svt_batch** out)
 {
     if (!in || !out) return fail(SVT_ERR_INVALID, "null argument");
     *out = nullptr;
@@ -550,7 +550,12 @@ int svt_batch_create(const svt_evidence_batch* in, int device, unsigned flags, s
     return SVT_OK;
 }
 
-int svt_batch_create_from_fragments(const svt_fragment_batch* in, int device, unsigned flags,
+int svt_batch_create(const svt_evidence_batch* in, int device, unsigned flags, svt_batch** out)
+{
+    return guarded([&] { return svt_batch_create_impl(in, device, flags, out); });
+}
+
+static int svt_batch_create_from_fragments_impl(const svt_fragment_batch* in, int device, unsigned flags,
                                     svt_record* records_out, svt_batch** out)
 {
     if (!in || !out) return fail(SVT_ERR_INVALID, "null argument");
@@ -673,7 +678,12 @@ int svt_batch_create_from_fragments(const svt_fragment_batch* in, int device, un
     return SVT_OK;
 }
 
-int svt_batch_genotype(svt_batch* b, int sync)
+int svt_batch_create_from_fragments(const svt_fragment_batch* in, int device, unsigned flags, svt_record* records_out, svt_batch** out)
+{
+    return guarded([&] { return svt_batch_create_from_fragments_impl(in, device, flags, records_out, out); });
+}
+
+static int svt_batch_genotype_impl(svt_batch* b, int sync)
 {
     if (!b) return fail(SVT_ERR_INVALID, "null batch");
     HIP_TRY(hipSetDevice(b->device));
@@ -683,7 +693,12 @@ int svt_batch_genotype(svt_batch* b, int sync)
     return SVT_OK;
 }
 
-int svt_batch_genotype_n(svt_batch* b, int iters)
+int svt_batch_genotype(svt_batch* b, int sync)
+{
+    return guarded([&] { return svt_batch_genotype_impl(b, sync); });
+}
+
+static int svt_batch_genotype_n_impl(svt_batch* b, int iters)
 {
     if (!b || iters <= 0) return fail(SVT_ERR_INVALID, "bad arguments");
     HIP_TRY(hipSetDevice(b->device));
@@ -692,7 +707,12 @@ int svt_batch_genotype_n(svt_batch* b, int iters)
     return SVT_OK;
 }
 
-int svt_batch_genotype_timed(svt_batch* b, int iters, float* ms_total)
+int svt_batch_genotype_n(svt_batch* b, int iters)
+{
+    return guarded([&] { return svt_batch_genotype_n_impl(b, iters); });
+}
+
+static int svt_batch_genotype_timed_impl(svt_batch* b, int iters, float* ms_total)
 {
     if (!b || !ms_total || iters <= 0) return fail(SVT_ERR_INVALID, "bad arguments");
     HIP_TRY(hipSetDevice(b->device));
@@ -705,7 +725,12 @@ int svt_batch_genotype_timed(svt_batch* b, int iters, float* ms_total)
     return SVT_OK;
 }
 
-int svt_batch_results(svt_batch* b, svt_result* out, uint64_t n_units)
+int svt_batch_genotype_timed(svt_batch* b, int iters, float* ms_total)
+{
+    return guarded([&] { return svt_batch_genotype_timed_impl(b, iters, ms_total); });
+}
+
+static int svt_batch_results_impl(svt_batch* b, svt_result* out, uint64_t n_units)
 {
     if (!b || (!out && n_units)) return fail(SVT_ERR_INVALID, "null argument");
     if (!b->have_results) return fail(SVT_ERR_STATE, "svt_batch_genotype has not run");
@@ -715,6 +740,11 @@ int svt_batch_results(svt_batch* b, svt_result* out, uint64_t n_units)
     return d2h_staged(out, b->args.out, b->n_units * sizeof(svt_result), b->stream);
 }
 
+int svt_batch_results(svt_batch* b, svt_result* out, uint64_t n_units)
+{
+    return guarded([&] { return svt_batch_results_impl(b, out, n_units); });
+}
+
 int svt_batch_device_results(svt_batch* b, svt_result** dev)
 {
     if (!b || !dev) return fail(SVT_ERR_INVALID, "null argument");
@@ -722,7 +752,7 @@ int svt_batch_device_results(svt_batch* b, svt_result** dev)
     return SVT_OK;
 }
 
-int svt_batch_bind_device_results(svt_batch* b, svt_result* dev)
+static int svt_batch_bind_device_results_impl(svt_batch* b, svt_result* dev)
 {
     if (!b) return fail(SVT_ERR_INVALID, "null batch");
     if (dev && (reinterpret_cast<uintptr_t>(dev) & 127u)) return fail(SVT_ERR_INVALID, "result buffer must be 128-byte aligned");
@@ -730,6 +760,11 @@ int svt_batch_bind_device_results(svt_batch* b, svt_result* dev)
     b->have_results = false;
 
     return SVT_OK;
+}
+
+int svt_batch_bind_device_results(svt_batch* b, svt_result* dev)
+{
+    return guarded([&] { return svt_batch_bind_device_results_impl(b, dev); });
 }
 
 int svt_batch_bytes(const svt_batch* b, uint64_t* algorithmic, uint64_t* resident)
@@ -748,7 +783,7 @@ int svt_batch_layout(const svt_batch* b, int* compact, int* table_mode)
     return SVT_OK;
 }
 
-int svt_batch_site_qual(svt_batch* b, uint32_t n_samples, const double* initial, double* qual_out, uint64_t n_sites)
+static int svt_batch_site_qual_impl(svt_batch* b, uint32_t n_samples, const double* initial, double* qual_out, uint64_t n_sites)
 {
     if (!b || (!qual_out && n_sites)) return fail(SVT_ERR_INVALID, "null argument");
     if (!b->have_results) return fail(SVT_ERR_STATE, "svt_batch_genotype has not run");
@@ -769,7 +804,12 @@ int svt_batch_site_qual(svt_batch* b, uint32_t n_samples, const double* initial,
     return d2h_staged(qual_out, d_qual.p, n_sites * sizeof(double), b->stream);
 }
 
-int svt_bayes_gt(const int32_t* ref, const int32_t* alt, const uint8_t* is_dup, uint64_t n, double* out,
+int svt_batch_site_qual(svt_batch* b, uint32_t n_samples, const double* initial, double* qual_out, uint64_t n_sites)
+{
+    return guarded([&] { return svt_batch_site_qual_impl(b, n_samples, initial, qual_out, n_sites); });
+}
+
+static int svt_bayes_gt_impl(const int32_t* ref, const int32_t* alt, const uint8_t* is_dup, uint64_t n, double* out,
                  int device)
 {
     if (n == 0) return SVT_OK;
@@ -810,6 +850,11 @@ int svt_bayes_gt(const int32_t* ref, const int32_t* alt, const uint8_t* is_dup, 
     return d2h_staged(out, d_out.p, n * 4 * sizeof(double), nullptr);
 }
 
+int svt_bayes_gt(const int32_t* ref, const int32_t* alt, const uint8_t* is_dup, uint64_t n, double* out, int device)
+{
+    return guarded([&] { return svt_bayes_gt_impl(ref, alt, is_dup, n, out, device); });
+}
+
 void* svt_batch_stream(svt_batch* b) { return b ? (void*)b->stream : nullptr; }
 
 void svt_batch_destroy(svt_batch* b) { free_batch(b); }
@@ -821,7 +866,7 @@ void svt_trim(void)
     g_host.trim();
 }
 
-int svt_genotype(const svt_evidence_batch* in, svt_result* out, int device, unsigned flags)
+static int svt_genotype_impl(const svt_evidence_batch* in, svt_result* out, int device, unsigned flags)
 {
     svt_batch* b = nullptr;
     SVT_TRY(svt_batch_create(in, device, flags, &b));
@@ -831,6 +876,11 @@ int svt_genotype(const svt_evidence_batch* in, svt_result* out, int device, unsi
     svt_batch_destroy(b);
     g_err = keep;
     return rc;
+}
+
+int svt_genotype(const svt_evidence_batch* in, svt_result* out, int device, unsigned flags)
+{
+    return guarded([&] { return svt_genotype_impl(in, out, device, flags); });
 }
 
 }  // extern "C"
