@@ -73,6 +73,8 @@ struct LaneCtx {
     double pos_delta_d;
     bool is_del;
     uint32_t common_mq;   // short layout: mapq_a | mapq_b << 8 of the one-half-word pair entries
+    uint32_t nb4, off2_4; // short layout: nb8 / 2, off2_8 / 2 (thr[] and hist[] are separate 4-byte arrays there)
+    uint32_t hist_at;     // short layout: LDS address of hist[0]
 };
 
 // ---- dense layout: one canonical 16-byte record -------------------------------------------------
@@ -207,11 +209,11 @@ __device__ __forceinline__ void pair_entry(const uint32_t e, const LaneCtx& c, A
 // Short layout (one library): a 16-byte row slot is four dwords, each either two one-half-word entries that carry
 // the batch's common MAPQ pair, or one wide entry (low half f3 | code << 3 | 0x8000, high half its two MAPQs).
 // code8 = byte offset of bins[code], f3x16 = f3 << 4 (byte offset inside the decision table), pp = pmA * pmB.
-__device__ __forceinline__ void pair_eval_single(const uint32_t code8, const uint32_t f3x16, const double pp,
+__device__ __forceinline__ void pair_eval_single(const uint32_t code4, const uint32_t f3x16, const double pp,
                                                  const LaneCtx& c, Acc& a)
 {
-    const int32_t thr1 = lds_i32(kLdsBins + min(code8, c.nb8));
-    const uint32_t h2 = lds_u32(kLdsBins + 4u + min(code8 - c.off2_8, c.nb8));
+    const int32_t thr1 = lds_i32(kLdsBins + min(code4, c.nb4));
+    const uint32_t h2 = lds_u32(c.hist_at + min(code4 - c.off2_4, c.nb4));
     const bool p_conc = (int32_t)h2 <= thr1;
     const uint32_t wa = (p_conc ? c.wt1 : c.wt0) | f3x16;
     const double w_alt = lds_f64(wa), w_ref = lds_f64(wa + 8u);
@@ -225,14 +227,14 @@ __device__ __forceinline__ void short_pair_dword(const uint32_t e, const LaneCtx
     const uint32_t hi = e >> 16;
     const uint32_t mq = wide ? hi : c.common_mq;
     const double pm_a = lds_f64(kLdsPm + byte0_x8(mq)), pm_b = lds_f64(kLdsPm + byte1_x8(mq));
-    pair_eval_single(e & 0x7ff8u, (e << 4) & 0x70u, pm_a * pm_b, c, a);
+    pair_eval_single((e >> 1) & 0x3ffcu, (e << 4) & 0x70u, pm_a * pm_b, c, a);
     // the high half: a second entry with the common MAPQs -- its products pmA * pmB * {w_alt, w_ref} come ready from the
     // second decision table -- or the MAPQ bytes of the wide entry just added: then the straddle bits read as 0,
     // both table values are 0 and the sums receive +0.0
     {
-        const uint32_t code8 = hi & 0x7ff8u;
-        const int32_t thr1 = lds_i32(kLdsBins + min(code8, c.nb8));
-        const uint32_t h2 = lds_u32(kLdsBins + 4u + min(code8 - c.off2_8, c.nb8));
+        const uint32_t code4 = (e >> 17) & 0x3ffcu;
+        const int32_t thr1 = lds_i32(kLdsBins + min(code4, c.nb4));
+        const uint32_t h2 = lds_u32(c.hist_at + min(code4 - c.off2_4, c.nb4));
         const bool p_conc = (int32_t)h2 <= thr1;
         const uint32_t wa = ((p_conc ? c.wt1 : c.wt0) + (kLdsWtabC - kLdsWtab)) | (wide ? 0u : (hi << 4) & 0x70u);
         a.alt_span += lds_f64(wa);
@@ -421,7 +423,17 @@ __global__ __launch_bounds__(kBlock, SVT_MIN_WAVES) void svt_genotype_kernel(con
     for (uint32_t i = threadIdx.x; i < wd.lib_cnt * (uint32_t)(sizeof(LibDesc) / 8); i += kBlock)
         reinterpret_cast<uint64_t*>(s_lib)[i] =
             reinterpret_cast<const uint64_t*>(a.libs + wd.lib_lo)[i];
-    if (MODE != kGeneral)
+    if (LAYOUT == kLayoutShort) {
+        // thr[] and hist[] as two 4-byte arrays: the random look-ups of a wave then spread over every LDS bank
+        // (interleaved {thr, hist} pairs would put all thr reads on the even banks and all hist reads on the odd ones)
+        int32_t* s_thr = reinterpret_cast<int32_t*>(s_bins);
+        uint32_t* s_hist = reinterpret_cast<uint32_t*>(s_bins) + wd.bin_cnt;
+        for (uint32_t i = threadIdx.x; i < wd.bin_cnt; i += kBlock) {
+            const Bin bn = a.bins[wd.bin_lo + i];
+            s_thr[i] = bn.thr;
+            s_hist[i] = bn.hist;
+        }
+    } else if (MODE != kGeneral)
         for (uint32_t i = threadIdx.x; i < wd.bin_cnt; i += kBlock)
             reinterpret_cast<uint64_t*>(s_bins)[i] = reinterpret_cast<const uint64_t*>(a.bins + wd.bin_lo)[i];
     if (COMPACT && MODE == kMultiLds)
@@ -464,6 +476,9 @@ __global__ __launch_bounds__(kBlock, SVT_MIN_WAVES) void svt_genotype_kernel(con
         c.sub2 = c.is_del ? (uint32_t)h.var_length + (uint32_t)a.lib0.key_min : 0x80000000u;
         c.nb8 = a.lib0.n_bins * 8u;
         c.off2_8 = c.is_del ? min((uint32_t)h.var_length, a.lib0.n_bins) * 8u : 0x80000000u;
+        c.nb4 = a.lib0.n_bins * 4u;
+        c.off2_4 = c.is_del ? min((uint32_t)h.var_length, a.lib0.n_bins) * 4u : 0x80000000u;
+        c.hist_at = kLdsBins + a.total_bins * 4u;   // kSingleLds: the window is the whole table (n_bins + 1 entries)
     }
 
     c.common_mq = a.common_mq;
