@@ -66,8 +66,13 @@ struct Bin {
 // regions have fixed addresses; the compact entries are consumed with these as immediates.
 constexpr uint32_t kLdsPm = 0;                       // double[256]      prob_mapq
 constexpr uint32_t kLdsWtab = kLdsPm + 256 * 8;      // PairWeights[32]  paired-end decision table
-constexpr uint32_t kLdsWtabC = kLdsWtab + 32 * 16;   // PairWeights[32]  the same table times pmA * pmB of the batch's common MAPQ pair (short layout)
-constexpr uint32_t kLdsBins = kLdsWtabC + 32 * 16;   // Bin[lds_bins], then LibDesc[lds_libs], then log10
+// the compact layouts read the decision table column-wise: w_alt[32] then w_ref[32], 8-byte rows.  Rows that differ
+// only in p_concordant then sit in different LDS banks (with 16-byte {w_alt, w_ref} rows every (p_concordant, is_DEL)
+// variant of a straddle pattern shares its four banks and the lanes of a wave serialise on them)
+constexpr uint32_t kLdsWcol = kLdsWtab + 32 * 16;    // double[32] w_alt, double[32] w_ref
+constexpr uint32_t kLdsWcolC = kLdsWcol + 2 * 32 * 8;   // the same two columns times pmA * pmB of the batch's common MAPQ pair (short layout)
+constexpr uint32_t kWcolRef = 32 * 8;                // byte distance from a w_alt entry to its w_ref entry
+constexpr uint32_t kLdsBins = kLdsWcolC + 2 * 32 * 8;   // Bin[lds_bins], then LibDesc[lds_libs], then log10
 
 struct GtConsts {
     double lgp[2][3];     // [is_dup][genotype] log(p)/log(10)      (statistics.py:33-35)

@@ -60,7 +60,7 @@ struct LaneCtx {
     uint32_t sub2;        // dense kSingleLds: DEL ? var_length + key_min : 0x80000000 (never in range)
     uint32_t nb8;         // compact kSingleLds: n_bins * 8 (byte offset of the sentinel bin)
     uint32_t off2_8;      // compact kSingleLds: DEL ? min(var_length, n_bins) * 8 : 0x80000000
-    uint32_t wt0, wt1;    // compact: LDS address of the decision-table rows for p_concordant = 0 / 1
+    uint32_t wt0, wt1;    // compact: LDS address of w_alt[del16] / w_alt[del16 + 8] (p_concordant = 0 / 1) in the column-wise table
     uint32_t lib_min;     // compact kMultiLds: first library of the lane's unit
     uint32_t lib_lo;      // kMultiLds: first library / first bin staged by this workgroup
     uint32_t lib_last;    // kMultiLds: index of the last staged library inside the window
@@ -199,8 +199,8 @@ __device__ __forceinline__ void pair_entry(const uint32_t e, const LaneCtx& c, A
         h2 = lds_u32(base + 4u + min(code8 - off2_8, nb8));
     }
     const bool p_conc = (int32_t)h2 <= thr1;
-    const uint32_t wa = (p_conc ? c.wt1 : c.wt0) | ((e << 4) & 0x70u);   // &wtab[f3 | p_conc << 3 | del16]
-    const double w_alt = lds_f64(wa), w_ref = lds_f64(wa + 8u);
+    const uint32_t wa = (p_conc ? c.wt1 : c.wt0) | ((e << 3) & 0x38u);   // &w_alt[f3 | p_conc << 3 | del16]
+    const double w_alt = lds_f64(wa), w_ref = lds_f64(wa + kWcolRef);
     const double pp = pm_a * pm_b;
     a.alt_span += pp * w_alt;
     a.ref_span += pp * w_ref;
@@ -208,15 +208,15 @@ __device__ __forceinline__ void pair_entry(const uint32_t e, const LaneCtx& c, A
 
 // Short layout (one library): a 16-byte row slot is four dwords, each either two one-half-word entries that carry
 // the batch's common MAPQ pair, or one wide entry (low half f3 | code << 3 | 0x8000, high half its two MAPQs).
-// code8 = byte offset of bins[code], f3x16 = f3 << 4 (byte offset inside the decision table), pp = pmA * pmB.
-__device__ __forceinline__ void pair_eval_single(const uint32_t code4, const uint32_t f3x16, const double pp,
+// code4 = byte offset of thr[code] / hist[code], f3x8 = f3 << 3 (byte offset inside a decision-table column), pp = pmA * pmB.
+__device__ __forceinline__ void pair_eval_single(const uint32_t code4, const uint32_t f3x8, const double pp,
                                                  const LaneCtx& c, Acc& a)
 {
     const int32_t thr1 = lds_i32(kLdsBins + min(code4, c.nb4));
     const uint32_t h2 = lds_u32(c.hist_at + min(code4 - c.off2_4, c.nb4));
     const bool p_conc = (int32_t)h2 <= thr1;
-    const uint32_t wa = (p_conc ? c.wt1 : c.wt0) | f3x16;
-    const double w_alt = lds_f64(wa), w_ref = lds_f64(wa + 8u);
+    const uint32_t wa = (p_conc ? c.wt1 : c.wt0) | f3x8;
+    const double w_alt = lds_f64(wa), w_ref = lds_f64(wa + kWcolRef);
     a.alt_span += pp * w_alt;
     a.ref_span += pp * w_ref;
 }
@@ -227,7 +227,7 @@ __device__ __forceinline__ void short_pair_dword(const uint32_t e, const LaneCtx
     const uint32_t hi = e >> 16;
     const uint32_t mq = wide ? hi : c.common_mq;
     const double pm_a = lds_f64(kLdsPm + byte0_x8(mq)), pm_b = lds_f64(kLdsPm + byte1_x8(mq));
-    pair_eval_single((e >> 1) & 0x3ffcu, (e << 4) & 0x70u, pm_a * pm_b, c, a);
+    pair_eval_single((e >> 1) & 0x3ffcu, (e << 3) & 0x38u, pm_a * pm_b, c, a);
     // the high half: a second entry with the common MAPQs -- its products pmA * pmB * {w_alt, w_ref} come ready from the
     // second decision table -- or the MAPQ bytes of the wide entry just added: then the straddle bits read as 0,
     // both table values are 0 and the sums receive +0.0
@@ -236,9 +236,9 @@ __device__ __forceinline__ void short_pair_dword(const uint32_t e, const LaneCtx
         const int32_t thr1 = lds_i32(kLdsBins + min(code4, c.nb4));
         const uint32_t h2 = lds_u32(c.hist_at + min(code4 - c.off2_4, c.nb4));
         const bool p_conc = (int32_t)h2 <= thr1;
-        const uint32_t wa = ((p_conc ? c.wt1 : c.wt0) + (kLdsWtabC - kLdsWtab)) | (wide ? 0u : (hi << 4) & 0x70u);
+        const uint32_t wa = ((p_conc ? c.wt1 : c.wt0) + (kLdsWcolC - kLdsWcol)) | (wide ? 0u : (e >> 13) & 0x38u);
         a.alt_span += lds_f64(wa);
-        a.ref_span += lds_f64(wa + 8u);
+        a.ref_span += lds_f64(wa + kWcolRef);
     }
 }
 
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(kBlock, SVT_MIN_WAVES) void svt_genotype_kernel(con
 {
     constexpr bool COMPACT = LAYOUT != kLayoutDense;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // LDS layout (svt_device_types.h): pm[256] | wtab[32] | wtab x common pair[32] | bins[lds_bins] | libs[lds_libs] | libx[lds_libs] | l10[n_l10]
+    // LDS layout (svt_device_types.h): pm[256] | wtab[32] | w_alt[32], w_ref[32] | the same x common pair | bins[lds_bins] | libs[lds_libs] | libx[lds_libs] | l10[n_l10]
     double* s_pm = reinterpret_cast<double*>(smem + kLdsPm);
     PairWeights* s_wtab = reinterpret_cast<PairWeights*>(smem + kLdsWtab);
     Bin* s_bins = reinterpret_cast<Bin*>(smem + kLdsBins);
@@ -412,11 +412,19 @@ __global__ __launch_bounds__(kBlock, SVT_MIN_WAVES) void svt_genotype_kernel(con
 
     // ---- stage the tables in LDS (they are L2-resident after the first workgroups)
     for (uint32_t i = threadIdx.x; i < 256; i += kBlock) s_pm[i] = a.pm[i];
-    if (threadIdx.x < 32) s_wtab[threadIdx.x] = a.wtab[threadIdx.x];
+    if (threadIdx.x < 32) {
+        const PairWeights w = a.wtab[threadIdx.x];
+        s_wtab[threadIdx.x] = w;
+        if (COMPACT) {
+            reinterpret_cast<double*>(smem + kLdsWcol)[threadIdx.x] = w.w_alt;
+            reinterpret_cast<double*>(smem + kLdsWcol + kWcolRef)[threadIdx.x] = w.w_ref;
+        }
+    }
     if (LAYOUT == kLayoutShort && threadIdx.x < 32) {   // the decision table times the common pair's pmA * pmB (the very product an entry would form)
         const double pp0 = a.pm[a.common_mq & 0xffu] * a.pm[(a.common_mq >> 8) & 0xffu];
         const PairWeights w = a.wtab[threadIdx.x];
-        reinterpret_cast<PairWeights*>(smem + kLdsWtabC)[threadIdx.x] = PairWeights{pp0 * w.w_alt, pp0 * w.w_ref};
+        reinterpret_cast<double*>(smem + kLdsWcolC)[threadIdx.x] = pp0 * w.w_alt;
+        reinterpret_cast<double*>(smem + kLdsWcolC + kWcolRef)[threadIdx.x] = pp0 * w.w_ref;
     }
     if (a.l10_in_lds)
         for (uint32_t i = threadIdx.x; i < a.n_l10; i += kBlock) s_l10[i] = a.l10[i];
@@ -466,8 +474,8 @@ __global__ __launch_bounds__(kBlock, SVT_MIN_WAVES) void svt_genotype_kernel(con
                   (c.lib_min - wd.lib_lo) * (uint32_t)sizeof(uint2);
     c.vl8 = (uint32_t)min(max(h.var_length, 0), 8191) * 8u;
     c.nodel = c.is_del ? 0u : 0x80000000u;
-    c.wt0 = kLdsWtab + c.del16 * (uint32_t)sizeof(PairWeights);
-    c.wt1 = c.wt0 + 8u * (uint32_t)sizeof(PairWeights);
+    c.wt0 = kLdsWcol + c.del16 * 8u;
+    c.wt1 = c.wt0 + 8u * 8u;
     {
         const bool small_del = c.is_del && (c.pos_delta_d < a.lib0.sd2);  // classic.py:339,383
         c.fmask = small_del ? 0u : 7u;
