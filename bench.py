@@ -276,6 +276,8 @@ def main():
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "resident_bytes_per_launch": resident_bytes,
                 "kernel_ms": kern_ms,
+                "kernel_ms_note": "HIP events around the `steps` back-to-back launches of the timed region, divided by `steps`: "
+                                  "includes the ~5-10 us between consecutive dispatches that rocprofv3's per-kernel duration leaves out",
                 "note": ("`achieved` is ALGORITHMIC bytes (16 B per fragment record + 112 B per unit) over the "
                          "kernel time; the compact layout keeps only the entries that can change a sum "
                          "(resident_bytes_per_launch) so it can exceed the HBM peak -- `traffic` / "
