@@ -17,12 +17,14 @@
 //   * records are re-tiled once per batch into lane-interleaved tiles: row j of a tile holds
 //     the j-th 16 bytes of its 64 units back to back, so every wave-level load is one contiguous
 //     1 KiB global_load_dwordx4.  Units are sorted by length inside 16384-unit chunks so that the
-//     zero-padding of a tile stays small.  Two device layouts:
-//       - compact (default): a unit's evidence becomes two sparse streams of 4-byte entries --
+//     zero-padding of a tile stays small.  Three device layouts:
+//       - compact (default): a unit's evidence becomes three sparse streams of small entries --
 //         pair entries (straddle bits, both MAPQs, ospan_len translated into the histogram's index
-//         space) and weight entries (one per non-zero reference / split / clip MAPQ pair); entries
-//         that could only add +0.0 are dropped, which the reference's sums cannot observe
-//         (svt_prepare_kernels.h has the format);
+//         space; 4 bytes), reference-read and split / clip candidate entries (one gated MAPQ pair,
+//         2 bytes); entries that could only add +0.0 are dropped, which the reference's sums cannot
+//         observe (svt_prepare_kernels.h has the formats);
+//       - short (what a one-library batch of <= 2047 bins gets): the same with 2-byte pair entries
+//         for the batch's most common MAPQ pair;
 //       - dense (SVT_FLAG_DENSE_LAYOUT): the canonical 16-byte records as they are.
 //   * all look-up tables (prob_mapq, insert-size histogram + p_concordant thresholds, log10,
 //     paired-end decision weights) are built on the host with the same libm CPython uses and
