@@ -77,6 +77,12 @@ extern "C" {
  * Results are bit-identical between all of them.                                          */
 #define SVT_FLAG_DENSE_LAYOUT 0x2u
 #define SVT_FLAG_FIXED_PAIR_ENTRIES 0x4u
+/*   SVT_FLAG_STREAM_LAYOUT: nothing is re-tiled or re-encoded at all -- the CSR arrays go to HBM as the
+ *       caller packed them and ONE kernel streams them through per-wave LDS rings (each record is read
+ *       from HBM exactly once, by the pass itself).  svt_batch_create is then upload only; the record
+ *       contract is checked by the pass, so a malformed record is reported by svt_batch_genotype(sync)
+ *       / svt_batch_results instead of svt_batch_create.                                             */
+#define SVT_FLAG_STREAM_LAYOUT 0x8u
 
 /* ---- evidence record: one per read-fragment (query name) of a unit, 16 B --
  * Records of a unit are stored in the order the reference walks them:

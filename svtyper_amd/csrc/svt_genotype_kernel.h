@@ -349,6 +349,116 @@ __device__ __forceinline__ uint4 pair_swap(const uint4 v)
     return make_uint4(pair_swap(v.x), pair_swap(v.y), pair_swap(v.z), pair_swap(v.w));
 }
 
+// ------------------------------------------------------------------------------------------
+// per-unit epilogue: zeroing rules -> QR/QA -> bayes_gt -> GT/GQ/SQ -> the eight 16-byte pieces of the
+// 128-byte result record (classic.py:425-513).  Shared by every genotype kernel, so all device layouts
+// produce the same bits.  The host-built log(i)/log(10) table is read from LDS (l10_lds) or through L2 (l10_global).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void unit_epilogue(const Acc& acc, const uint32_t svtype, const uint32_t uflags, const GtConsts& c,
+                                              const double* l10_lds, const double* __restrict__ l10_global, const bool l10_in_lds,
+                                              uint4 (&piece)[8])
+{
+    double ref_seq = acc.ref_seq, alt_seq = acc.alt_seq, alt_clip = acc.alt_clip,
+           ref_span = acc.ref_span, alt_span = acc.alt_span;
+
+    // ---- zeroing rules (classic.py:425-435)
+    if ((alt_seq + alt_clip) < 0.5 && alt_span >= 1.0) { alt_seq = 0.0; alt_clip = 0.0; ref_seq = 0.0; }
+    if (alt_span < 0.5 && (alt_seq + alt_clip) >= 1.0) { alt_span = 0.0; ref_span = 0.0; }
+    if (alt_span + alt_seq == 0.0 && alt_clip > 0.0) alt_clip = 0.0;
+
+    int32_t cnt[SVT_N_COUNTS];
+#pragma unroll
+    for (int i = 0; i < SVT_N_COUNTS; ++i) cnt[i] = 0;
+    double gl[3] = {0.0, 0.0, 0.0};
+    double sq = 0.0;
+    int32_t gt;
+
+    const bool skipped = (uflags & SVT_UNIT_SKIP) != 0;
+    const bool evidence = (ref_seq + alt_seq + ref_span + alt_span + alt_clip) > 0.0;  // classic.py:437
+    if (skipped) {
+        ref_seq = alt_seq = alt_clip = ref_span = alt_span = 0.0;
+        gt = SVT_GT_SKIPPED;
+        cnt[SVT_CNT_GQ] = -1;
+    } else if (!evidence) {
+        gt = SVT_GT_BLANK;  // classic.py:496-513
+        cnt[SVT_CNT_GQ] = -1;
+    } else {
+        const int is_dup = svtype == SVT_SVTYPE_DUP;                                  // :439
+        const double alt_splitters = alt_seq + alt_clip;                              // :442
+        const int32_t QR = (int32_t)(c.split_weight * ref_seq) + (int32_t)(c.disc_weight * ref_span);      // :443
+        const int32_t QA = (int32_t)(c.split_weight * alt_splitters) + (int32_t)(c.disc_weight * alt_span); // :444
+        // bayes_gt (statistics.py:23-37)
+        const int32_t total = QR + QA;
+        double log_combo;
+        if (l10_in_lds) log_combo = log_choose_dev(l10_lds, total, QA);   // two call sites: ds_read vs global_load
+        else log_combo = log_choose_dev(l10_global, total, QA);
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+            gl[g] = (log_combo + (double)QA * c.lgp[is_dup][g]) + (double)QR * c.lg1p[is_dup][g];
+
+        // stable descending order of (index, value): ties keep the lower index (classic.py:446)
+        int best = 0;
+        if (gl[1] > gl[best]) best = 1;
+        if (gl[2] > gl[best]) best = 2;
+        const int r0 = best == 0 ? 1 : 0;
+        const int r1 = best == 2 ? 1 : 2;
+        const int second = (gl[r1] > gl[r0]) ? r1 : r0;
+
+        cnt[SVT_CNT_QR] = QR;
+        cnt[SVT_CNT_QA] = QA;
+        cnt[SVT_CNT_DP] = (int32_t)(ref_seq + alt_seq + alt_clip + ref_span + alt_span);  // :455
+        cnt[SVT_CNT_RO] = (int32_t)(ref_seq + ref_span);                                  // :456
+        cnt[SVT_CNT_AO] = (int32_t)(alt_seq + alt_clip + alt_span);                       // :457
+        cnt[SVT_CNT_RS] = (int32_t)ref_seq;
+        cnt[SVT_CNT_AS] = (int32_t)alt_seq;
+        cnt[SVT_CNT_ASC] = (int32_t)alt_clip;
+        cnt[SVT_CNT_RP] = (int32_t)ref_span;
+        cnt[SVT_CNT_AP] = (int32_t)alt_span;
+
+        // gt_sum = sum(10**gl) (classic.py:473-478).  Whether it is > 0 is decided against the
+        // host libm's own underflow point of pow(10, x), so GT './.' agrees with CPython.
+        const double gl_best = gl[best];
+        if (gl_best >= c.x_uflow) {
+            // 10**gl: exp10 (no logarithm inside, a third of pow's instructions) wherever its last-place error
+            // cannot show -- with the largest term far above the subnormal range every term is either accurate
+            // to an ulp or negligible beside it.  Sums near the underflow point keep pow, whose rounding of
+            // subnormal results is the one the parity tests pinned against the host libm.
+            double gt_sum = 0.0;
+            if (gl_best >= -290.0) {
+#pragma unroll
+                for (int g = 0; g < 3; ++g) gt_sum += exp10(gl[g]);
+            } else {
+#pragma unroll
+                for (int g = 0; g < 3; ++g) gt_sum += pow(10.0, gl[g]);
+            }
+            const double gt_sum_log = log(gt_sum) / c.ln10;                       // :480
+            sq = fabs(-10.0 * (gl[0] - gt_sum_log));                                // :481
+            double phred_gq = -10.0 * (gl[second] - gl_best);                       // :482
+            if (phred_gq > 200.0) phred_gq = 200.0;
+            cnt[SVT_CNT_GQ] = (int32_t)phred_gq;                                    // :483
+            gt = best;
+        } else {
+            cnt[SVT_CNT_GQ] = -1;                                                   // :493-495
+            gt = SVT_GT_MISSING;
+        }
+    }
+
+    // ---- one 128-byte result record per unit, scattered back to the unit's original position
+    const uint64_t t4 = (uint64_t)__double_as_longlong(alt_span);
+    const uint4 out_piece[8] = {
+        pack2d(gl[0], gl[1]),
+        pack2d(gl[2], sq),
+        pack2d(ref_seq, alt_seq),
+        pack2d(alt_clip, ref_span),
+        make_uint4((uint32_t)t4, (uint32_t)(t4 >> 32), (uint32_t)cnt[0], (uint32_t)cnt[1]),
+        make_uint4((uint32_t)cnt[2], (uint32_t)cnt[3], (uint32_t)cnt[4], (uint32_t)cnt[5]),
+        make_uint4((uint32_t)cnt[6], (uint32_t)cnt[7], (uint32_t)cnt[8], (uint32_t)cnt[9]),
+        make_uint4((uint32_t)cnt[10], (uint32_t)gt & 0xffu, 0u, 0u),
+    };
+#pragma unroll
+    for (int i = 0; i < 8; ++i) piece[i] = out_piece[i];
+}
+
 // The result records of a lane pair, written 32 contiguous bytes at a time.  Stored directly, the eight 16-byte
 // pieces of a record reach the L2 as eight partial-line transactions, and the write path is paced by transactions
 // (a timing build writing the same bytes with this pattern ran 8 % faster).  So the two lanes of a pair exchange
@@ -553,106 +663,8 @@ __global__ __launch_bounds__(kBlock, SVT_MIN_WAVES) void svt_genotype_kernel(con
         acc.alt_clip += acc.l_alt_clip;
     }
 
-    // (padding lanes carry on: they hold no evidence, fall through the blank branch below and take part in the
-    // exchange of st_results_by_pairs, which skips their records)
-
-    double ref_seq = acc.ref_seq, alt_seq = acc.alt_seq, alt_clip = acc.alt_clip,
-           ref_span = acc.ref_span, alt_span = acc.alt_span;
-
-    // ---- zeroing rules (classic.py:425-435)
-    if ((alt_seq + alt_clip) < 0.5 && alt_span >= 1.0) { alt_seq = 0.0; alt_clip = 0.0; ref_seq = 0.0; }
-    if (alt_span < 0.5 && (alt_seq + alt_clip) >= 1.0) { alt_span = 0.0; ref_span = 0.0; }
-    if (alt_span + alt_seq == 0.0 && alt_clip > 0.0) alt_clip = 0.0;
-
-    int32_t cnt[SVT_N_COUNTS];
-#pragma unroll
-    for (int i = 0; i < SVT_N_COUNTS; ++i) cnt[i] = 0;
-    double gl[3] = {0.0, 0.0, 0.0};
-    double sq = 0.0;
-    int32_t gt;
-
-    const bool skipped = (uflags & SVT_UNIT_SKIP) != 0;
-    const bool evidence = (ref_seq + alt_seq + ref_span + alt_span + alt_clip) > 0.0;  // classic.py:437
-    if (skipped) {
-        ref_seq = alt_seq = alt_clip = ref_span = alt_span = 0.0;
-        gt = SVT_GT_SKIPPED;
-        cnt[SVT_CNT_GQ] = -1;
-    } else if (!evidence) {
-        gt = SVT_GT_BLANK;  // classic.py:496-513
-        cnt[SVT_CNT_GQ] = -1;
-    } else {
-        const int is_dup = svtype == SVT_SVTYPE_DUP;                                  // :439
-        const double alt_splitters = alt_seq + alt_clip;                              // :442
-        const int32_t QR = (int32_t)(a.c.split_weight * ref_seq) + (int32_t)(a.c.disc_weight * ref_span);      // :443
-        const int32_t QA = (int32_t)(a.c.split_weight * alt_splitters) + (int32_t)(a.c.disc_weight * alt_span); // :444
-        // bayes_gt (statistics.py:23-37)
-        const int32_t total = QR + QA;
-        double log_combo;
-        if (a.l10_in_lds) log_combo = log_choose_dev(s_l10, total, QA);
-        else log_combo = log_choose_dev(a.l10, total, QA);
-#pragma unroll
-        for (int g = 0; g < 3; ++g)
-            gl[g] = (log_combo + (double)QA * a.c.lgp[is_dup][g]) + (double)QR * a.c.lg1p[is_dup][g];
-
-        // stable descending order of (index, value): ties keep the lower index (classic.py:446)
-        int best = 0;
-        if (gl[1] > gl[best]) best = 1;
-        if (gl[2] > gl[best]) best = 2;
-        const int r0 = best == 0 ? 1 : 0;
-        const int r1 = best == 2 ? 1 : 2;
-        const int second = (gl[r1] > gl[r0]) ? r1 : r0;
-
-        cnt[SVT_CNT_QR] = QR;
-        cnt[SVT_CNT_QA] = QA;
-        cnt[SVT_CNT_DP] = (int32_t)(ref_seq + alt_seq + alt_clip + ref_span + alt_span);  // :455
-        cnt[SVT_CNT_RO] = (int32_t)(ref_seq + ref_span);                                  // :456
-        cnt[SVT_CNT_AO] = (int32_t)(alt_seq + alt_clip + alt_span);                       // :457
-        cnt[SVT_CNT_RS] = (int32_t)ref_seq;
-        cnt[SVT_CNT_AS] = (int32_t)alt_seq;
-        cnt[SVT_CNT_ASC] = (int32_t)alt_clip;
-        cnt[SVT_CNT_RP] = (int32_t)ref_span;
-        cnt[SVT_CNT_AP] = (int32_t)alt_span;
-
-        // gt_sum = sum(10**gl) (classic.py:473-478).  Whether it is > 0 is decided against the
-        // host libm's own underflow point of pow(10, x), so GT './.' agrees with CPython.
-        const double gl_best = gl[best];
-        if (gl_best >= a.c.x_uflow) {
-            // 10**gl: exp10 (no logarithm inside, a third of pow's instructions) wherever its last-place error
-            // cannot show -- with the largest term far above the subnormal range every term is either accurate
-            // to an ulp or negligible beside it.  Sums near the underflow point keep pow, whose rounding of
-            // subnormal results is the one the parity tests pinned against the host libm.
-            double gt_sum = 0.0;
-            if (gl_best >= -290.0) {
-#pragma unroll
-                for (int g = 0; g < 3; ++g) gt_sum += exp10(gl[g]);
-            } else {
-#pragma unroll
-                for (int g = 0; g < 3; ++g) gt_sum += pow(10.0, gl[g]);
-            }
-            const double gt_sum_log = log(gt_sum) / a.c.ln10;                       // :480
-            sq = fabs(-10.0 * (gl[0] - gt_sum_log));                                // :481
-            double phred_gq = -10.0 * (gl[second] - gl_best);                       // :482
-            if (phred_gq > 200.0) phred_gq = 200.0;
-            cnt[SVT_CNT_GQ] = (int32_t)phred_gq;                                    // :483
-            gt = best;
-        } else {
-            cnt[SVT_CNT_GQ] = -1;                                                   // :493-495
-            gt = SVT_GT_MISSING;
-        }
-    }
-
-    // ---- one 128-byte result record per unit, scattered back to the unit's original position
-    const uint64_t t4 = (uint64_t)__double_as_longlong(alt_span);
-    const uint4 piece[8] = {
-        pack2d(gl[0], gl[1]),
-        pack2d(gl[2], sq),
-        pack2d(ref_seq, alt_seq),
-        pack2d(alt_clip, ref_span),
-        make_uint4((uint32_t)t4, (uint32_t)(t4 >> 32), (uint32_t)cnt[0], (uint32_t)cnt[1]),
-        make_uint4((uint32_t)cnt[2], (uint32_t)cnt[3], (uint32_t)cnt[4], (uint32_t)cnt[5]),
-        make_uint4((uint32_t)cnt[6], (uint32_t)cnt[7], (uint32_t)cnt[8], (uint32_t)cnt[9]),
-        make_uint4((uint32_t)cnt[10], (uint32_t)gt & 0xffu, 0u, 0u),
-    };
+    uint4 piece[8];
+    unit_epilogue(acc, svtype, uflags, a.c, s_l10, a.l10, a.l10_in_lds != 0u, piece);
     st_results_by_pairs(piece, h.unit, a.out, lane);
 }
 

@@ -64,11 +64,15 @@
 #ifndef SVT_CHUNK
 #define SVT_CHUNK 16384
 #endif
+#ifndef SVT_STREAM_R
+#define SVT_STREAM_R 2   // streaming kernel: 64-unit tiles per wave (a workgroup sorts 256 * R consecutive units)
+#endif
 
 #include "svt_common.h"
 #include "svt_device_types.h"
 #include "svt_genotype_kernel.h"
 #include "svt_prepare_kernels.h"
+#include "svt_stream_kernel.h"
 #include "svt_geometry_kernel.h"
 #include "svt_bayes_kernel.h"
 #include "svt_host_tables.h"
@@ -80,6 +84,13 @@ using namespace svt;
 // ------------------------------------------------------------------------------------------
 // batch object
 // ------------------------------------------------------------------------------------------
+constexpr unsigned kKnownFlags = SVT_FLAG_SSO_ASSOCIATION | SVT_FLAG_DENSE_LAYOUT | SVT_FLAG_FIXED_PAIR_ENTRIES | SVT_FLAG_STREAM_LAYOUT;
+
+inline int layout_of_flags(unsigned flags)
+{
+    return (flags & SVT_FLAG_STREAM_LAYOUT) ? svt::kLayoutStream : (flags & SVT_FLAG_DENSE_LAYOUT) ? svt::kLayoutDense : svt::kLayoutCompact;
+}
+
 struct svt_batch {
     int device = 0;
     unsigned flags = 0;
@@ -104,6 +115,13 @@ struct svt_batch {
     WgDesc* d_wg = nullptr;
     svt_result* d_out = nullptr;
     KernelArgs args{};
+    // kLayoutStream: the canonical CSR as it is (svt_stream_kernel.h); d_records / d_off / d_units come from g_pool
+    void* d_records = nullptr;
+    uint64_t* d_off = nullptr;
+    svt_unit* d_units = nullptr;
+    uint64_t cap_records = 0, cap_off = 0, cap_units = 0;
+    uint32_t* d_err = nullptr;
+    StreamArgs sargs{};
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
 
@@ -117,6 +135,10 @@ void free_batch(svt_batch* b)
     g_pool.put(b->device, b->d_tiled, b->cap_tiled);
     g_pool.put(b->device, b->d_hdr, b->cap_hdr);
     g_pool.put(b->device, b->d_out, b->cap_out);
+    g_pool.put(b->device, b->d_records, b->cap_records);
+    g_pool.put(b->device, b->d_off, b->cap_off);
+    g_pool.put(b->device, b->d_units, b->cap_units);
+    F(b->d_err);
     F(b->d_tiles); F(b->d_pm); F(b->d_l10); F(b->d_libs);
     F(b->d_bins); F(b->d_wtab); F(b->d_wg);
     if (b->ev0) (void)hipEventDestroy(b->ev0);
@@ -172,8 +194,28 @@ const void* kernel_of(const svt_batch* b)
                                                  : kernel_for<false>(b->mode, b->layout);
 }
 
+template <bool SSO>
+const void* stream_kernel_for(int mode)
+{
+    return mode == kSingleLds ? reinterpret_cast<const void*>(&svt_stream_kernel<SSO, kSingleLds, SVT_STREAM_R>)
+                              : reinterpret_cast<const void*>(&svt_stream_kernel<SSO, kGeneral, SVT_STREAM_R>);
+}
+
+const void* stream_kernel_of(const svt_batch* b)
+{
+    return (b->flags & SVT_FLAG_SSO_ASSOCIATION) ? stream_kernel_for<true>(b->mode) : stream_kernel_for<false>(b->mode);
+}
+
 int launch_genotype(svt_batch* b)
 {
+    if (b->layout == kLayoutStream) {
+        if (b->n_units == 0) return SVT_OK;
+        constexpr uint64_t per_wg = (uint64_t)kBlock * SVT_STREAM_R;
+        const dim3 grid((unsigned)((b->n_units + per_wg - 1) / per_wg)), block(kBlock);
+        void* params[] = {&b->sargs};
+        HIP_TRY(hipLaunchKernel(stream_kernel_of(b), grid, block, params, b->lds_bytes, b->stream));
+        return SVT_OK;
+    }
     if (b->n_tiles == 0) return SVT_OK;
     const dim3 grid((b->n_tiles + kWavesPerBlock - 1) / kWavesPerBlock), block(kBlock);
     void* params[] = {&b->args};
@@ -215,6 +257,132 @@ struct HostScratch {
     }
 };
 HostScratch g_host;
+
+// the record-contract violations the kernels report (svt_scan_kernel / svt_stream_kernel)
+int record_error(uint32_t err_bits)
+{
+    std::string m = "invalid evidence records:";
+    if (err_bits & kErrStraddleNoPair) m += " straddle bits without HAS_PAIR;";
+    if (err_bits & kErrLibIndex) m += " lib index >= n_libs;";
+    if (err_bits & kErrReservedBits) m += " reserved/undefined bits set;";
+    if (err_bits & kErrNegativeSpan) m += " negative ospan_len;";
+    return fail(SVT_ERR_INVALID, m);
+}
+
+// kLayoutStream: has the last pass seen a record that breaks the contract?  (blocking)
+int check_stream_errors(svt_batch* b)
+{
+    if (b->layout != kLayoutStream || !b->d_err) return SVT_OK;
+    uint32_t bits = 0;
+    HIP_TRY(hipMemcpyAsync(&bits, b->d_err, sizeof(uint32_t), hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    return bits ? record_error(bits) : SVT_OK;
+}
+
+// svt_batch_create for the streaming layout: validate the unit arrays, build the tables, put the canonical
+// CSR in HBM as it is.  No scan, no tiling, no re-encoding: the pass reads the records where they lie.
+// `d_records_resident` (from the geometry stage) is adopted: the batch then owns that pool buffer.
+int create_stream(const svt_evidence_batch* in, svt_batch* b, void* d_records_resident = nullptr, uint64_t resident_cap = 0)
+{
+    const uint64_t n = in->n_units;
+    const uint64_t n_rec = n ? in->rec_offset[n] : 0;
+    StageTimer tm;
+    if (n_rec >= 0xFFFFFFF0ull) return fail(SVT_ERR_INVALID, "too many records in one batch (< 2^32)");
+    uint64_t max_f = 0;
+    bool wide_var_length = false;
+    for (uint64_t u = 0; u < n; ++u) {
+        if (in->rec_offset[u + 1] < in->rec_offset[u]) return fail(SVT_ERR_INVALID, "rec_offset not monotone");
+        const uint64_t f = in->rec_offset[u + 1] - in->rec_offset[u];
+        if (f > 0x3FFFFFFFull) return fail(SVT_ERR_INVALID, "unit with too many records");
+        const svt_unit& U = in->units[u];
+        if (U.svtype > SVT_SVTYPE_BND) return fail(SVT_ERR_INVALID, "bad svtype");
+        if (U.reserved != 0 || (U.flags & ~SVT_UNIT_SKIP)) return fail(SVT_ERR_INVALID, "unit reserved/flags bits must be 0");
+        if (U.var_length < -(1 << 30) || U.var_length > (1 << 30)) wide_var_length = true;
+        max_f = std::max(max_f, f);
+    }
+    tm.mark("validate units");
+    HostTables T;
+    SVT_TRY(build_tables(in, max_f, T));
+    if (wide_var_length) T.fast_geometry = false;
+    const uint32_t n_l10 = (uint32_t)T.l10.size();
+    T.l10.resize(((size_t)n_l10 + 127) / 128 * 128, 0.0);   // the ring copy of the table moves whole KiB
+    tm.mark("build tables");
+
+    HIP_TRY(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreate(&b->ev0));
+    HIP_TRY(hipEventCreate(&b->ev1));
+
+    const uint64_t n_blk = std::max<uint64_t>((n_rec + kBlockRecords - 1) / kBlockRecords, 1);
+    {
+        Stager st(b->stream);
+        void* p = nullptr;
+        if (d_records_resident) {
+            if (resident_cap < n_blk * 128) return fail(SVT_ERR_INTERNAL, "resident record buffer too small");
+            b->d_records = d_records_resident;
+            b->cap_records = resident_cap;
+        } else {
+            SVT_TRY(g_pool.get(b->device, n_blk * 128, &p, &b->cap_records));
+            b->d_records = p;
+        }
+        // the tail of the last 128-byte block is read (and contract-checked) like any record: zero it
+        if (n_blk * 128 > n_rec * 16)
+            HIP_TRY(hipMemsetAsync(static_cast<char*>(b->d_records) + n_rec * 16, 0, n_blk * 128 - n_rec * 16, b->stream));
+        if (!d_records_resident) SVT_TRY(st.copy(b->d_records, in->records, n_rec * sizeof(uint4)));
+        SVT_TRY(g_pool.get(b->device, (n + 1) * sizeof(uint64_t), &p, &b->cap_off));
+        b->d_off = static_cast<uint64_t*>(p);
+        if (n) SVT_TRY(st.copy(b->d_off, in->rec_offset, (n + 1) * sizeof(uint64_t)));
+        SVT_TRY(g_pool.get(b->device, std::max<uint64_t>(n, 1) * sizeof(svt_unit), &p, &b->cap_units));
+        b->d_units = static_cast<svt_unit*>(p);
+        SVT_TRY(st.copy(b->d_units, in->units, n * sizeof(svt_unit)));
+        SVT_TRY(upload(&b->d_libs, T.libs, st));
+        SVT_TRY(upload(&b->d_pm, T.pm, st));
+        SVT_TRY(upload(&b->d_l10, T.l10, st));
+        SVT_TRY(upload(&b->d_bins, T.bins, st));
+        SVT_TRY(upload(&b->d_wtab, T.wtab, st));
+        SVT_TRY(g_pool.get(b->device, std::max<uint64_t>(n, 1) * sizeof(svt_result), &p, &b->cap_out));
+        b->d_out = static_cast<svt_result*>(p);
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&b->d_err), sizeof(uint32_t)));
+        HIP_TRY(hipMemsetAsync(b->d_err, 0, sizeof(uint32_t), b->stream));
+        SVT_TRY(st.finish());
+    }
+    tm.mark("H2D CSR + tables (staged)");
+
+    // one library whose tables fit beside the rings: tables in LDS, 32-bit index math; anything else reads
+    // the tables through L2 with exact 64-bit geometry
+    const size_t single_lds = kLdsStreamBins + T.bins.size() * sizeof(Bin);
+    const bool single = in->n_libs == 1 && T.fast_geometry && single_lds + kWavesPerBlock * kRingBytes <= 96 * 1024;
+    b->mode = single ? kSingleLds : kGeneral;
+    StreamArgs& a = b->sargs;
+    a.records = static_cast<const uint4*>(b->d_records);
+    a.rec_offset = b->d_off;
+    a.units = b->d_units;
+    a.pm = b->d_pm;
+    a.l10 = b->d_l10;
+    a.libs = b->d_libs;
+    a.bins = b->d_bins;
+    a.wtab = b->d_wtab;
+    a.n_l10 = n_l10;
+    a.n_libs = in->n_libs;
+    a.total_bins = (uint32_t)T.bins.size();
+    a.last_blk = (uint32_t)(n_blk - 1);
+    a.lds_bins = single ? a.total_bins : 0u;
+    a.lds_libs = single ? 0u : in->n_libs;
+    size_t tables = kLdsStreamBins + (size_t)a.lds_bins * sizeof(Bin) + (size_t)a.lds_libs * sizeof(LibDesc);
+    tables = (tables + 127) & ~size_t(127);
+    a.lds_rings = (uint32_t)tables;
+    a.l10_in_ring = (uint64_t)n_l10 * 8 <= kRingBytes ? 1u : 0u;
+    a.n_units = n;
+    a.out = b->d_out;
+    a.err = b->d_err;
+    a.lib0 = T.libs[0];
+    fill_gt_consts(a.c, in->split_weight, in->disc_weight);
+    b->args.out = b->d_out;   // svt_batch_device_results / svt_batch_bind_device_results / svt_batch_site_qual
+    b->lds_bytes = tables + kWavesPerBlock * kRingBytes;
+    if (b->lds_bytes > 160 * 1024) return fail(SVT_ERR_INVALID, "LDS budget exceeded");
+    if (b->lds_bytes > 64 * 1024)
+        HIP_TRY(hipFuncSetAttribute(stream_kernel_of(b), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_bytes));
+    return SVT_OK;
+}
 
 // everything of svt_batch_create that needs the device; `b` is freed by the caller on failure
 int create_on_device(const svt_evidence_batch* in, svt_batch* b, const uint4* d_records_resident = nullptr)
@@ -311,14 +479,7 @@ int create_on_device(const svt_evidence_batch* in, svt_batch* b, const uint4* d_
     if (n) SVT_TRY(d2h_staged(counts.data(), d_counts.p, n * sizeof(ScanOut), b->stream));
     HIP_TRY(hipStreamSynchronize(b->stream));
     tm.mark("scan kernel + counts D2H");
-    if (err_bits) {
-        std::string m = "invalid evidence records:";
-        if (err_bits & 2u) m += " straddle bits without HAS_PAIR;";
-        if (err_bits & 4u) m += " lib index >= n_libs;";
-        if (err_bits & 8u) m += " reserved/undefined bits set;";
-        if (err_bits & 16u) m += " negative ospan_len;";
-        return fail(SVT_ERR_INVALID, m);
-    }
+    if (err_bits) return record_error(err_bits);
 
     // ---- layout: the compact entries need the 32-bit table geometry, histograms narrow enough for
     // the 13-bit code, DEL lengths >= 0 and, with several libraries, at most 4 consecutive libraries
@@ -519,7 +680,7 @@ static int svt_batch_create_impl(const svt_evidence_batch* in, int device, unsig
     if (!in || !out) return fail(SVT_ERR_INVALID, "null argument");
     *out = nullptr;
     const uint64_t n = in->n_units;
-    if (flags & ~(SVT_FLAG_SSO_ASSOCIATION | SVT_FLAG_DENSE_LAYOUT | SVT_FLAG_FIXED_PAIR_ENTRIES)) return fail(SVT_ERR_INVALID, "unknown flag bits");
+    if (flags & ~kKnownFlags) return fail(SVT_ERR_INVALID, "unknown flag bits");
     if (n >= 0xFFFFFFF0ull) return fail(SVT_ERR_INVALID, "too many units in one batch (< 2^32)");
     if (in->n_libs == 0 || in->n_libs > 256 || !in->libs) return fail(SVT_ERR_INVALID, "n_libs must be 1..256");
     if (n && (!in->rec_offset || !in->units)) return fail(SVT_ERR_INVALID, "null unit arrays");
@@ -538,10 +699,10 @@ static int svt_batch_create_impl(const svt_evidence_batch* in, int device, unsig
     if (!b) return fail(SVT_ERR_NOMEM, "out of host memory");
     b->device = device;
     b->flags = flags;
-    b->layout = (flags & SVT_FLAG_DENSE_LAYOUT) ? kLayoutDense : kLayoutCompact;
+    b->layout = layout_of_flags(flags);
     b->n_units = n;
     b->n_records = n ? in->rec_offset[n] : 0;
-    const int rc = create_on_device(in, b);
+    const int rc = b->layout == kLayoutStream ? create_stream(in, b) : create_on_device(in, b);
     if (rc != SVT_OK) {
         const std::string keep = g_err;
         free_batch(b);
@@ -563,7 +724,7 @@ static int svt_batch_create_from_fragments_impl(const svt_fragment_batch* in, in
     if (!in || !out) return fail(SVT_ERR_INVALID, "null argument");
     *out = nullptr;
     const uint64_t n = in->n_units;
-    if (flags & ~(SVT_FLAG_SSO_ASSOCIATION | SVT_FLAG_DENSE_LAYOUT | SVT_FLAG_FIXED_PAIR_ENTRIES)) return fail(SVT_ERR_INVALID, "unknown flag bits");
+    if (flags & ~kKnownFlags) return fail(SVT_ERR_INVALID, "unknown flag bits");
     if (n >= 0xFFFFFFF0ull) return fail(SVT_ERR_INVALID, "too many units in one batch (< 2^32)");
     if (in->n_libs == 0 || in->n_libs > 256 || !in->libs) return fail(SVT_ERR_INVALID, "n_libs must be 1..256");
     if (n && (!in->frag_offset || !in->breakpoints)) return fail(SVT_ERR_INVALID, "null unit arrays");
@@ -609,6 +770,7 @@ static int svt_batch_create_from_fragments_impl(const svt_fragment_batch* in, in
         uint64_t cap = 0;
         ~Pooled() { g_pool.put(device, p, cap); }
         int get(uint64_t bytes) { return g_pool.get(device, bytes, &p, &cap); }
+        void* release() { void* q = p; p = nullptr; return q; }
     } d_frags{device}, d_records{device};
     DevScratch d_frag_off, d_bps, d_libs, d_err;
     {
@@ -623,7 +785,7 @@ static int svt_batch_create_from_fragments_impl(const svt_fragment_batch* in, in
         SVT_TRY(st.finish());
         tm.mark("H2D fragment summaries + unit arrays (staged)");
     }
-    SVT_TRY(d_records.get(n_frag * sizeof(uint4)));
+    SVT_TRY(d_records.get((n_frag + kBlockRecords) * sizeof(uint4)));   // whole 128-byte blocks (kLayoutStream)
     SVT_TRY(d_err.alloc(sizeof(uint32_t)));
     HIP_TRY(hipMemsetAsync(d_err.p, 0, sizeof(uint32_t), s));
     if (n_frag) {
@@ -666,10 +828,17 @@ static int svt_batch_create_from_fragments_impl(const svt_fragment_batch* in, in
     if (!b) return fail(SVT_ERR_NOMEM, "out of host memory");
     b->device = device;
     b->flags = flags;
-    b->layout = (flags & SVT_FLAG_DENSE_LAYOUT) ? kLayoutDense : kLayoutCompact;
+    b->layout = layout_of_flags(flags);
     b->n_units = n;
     b->n_records = n_frag;
-    const int rc = create_on_device(&eb, b, static_cast<const uint4*>(d_records.p));
+    int rc;
+    if (b->layout == kLayoutStream) {
+        const uint64_t cap = d_records.cap;
+        rc = create_stream(&eb, b, d_records.p, cap);
+        if (b->d_records == d_records.p) d_records.release();   // the batch owns the records now
+    } else {
+        rc = create_on_device(&eb, b, static_cast<const uint4*>(d_records.p));
+    }
     if (rc != SVT_OK) {
         const std::string keep = g_err;
         free_batch(b);
@@ -691,7 +860,10 @@ static int svt_batch_genotype_impl(svt_batch* b, int sync)
     HIP_TRY(hipSetDevice(b->device));
     SVT_TRY(launch_genotype(b));
     b->have_results = true;
-    if (sync) HIP_TRY(hipStreamSynchronize(b->stream));
+    if (sync) {
+        HIP_TRY(hipStreamSynchronize(b->stream));
+        SVT_TRY(check_stream_errors(b));
+    }
     return SVT_OK;
 }
 
@@ -724,7 +896,7 @@ static int svt_batch_genotype_timed_impl(svt_batch* b, int iters, float* ms_tota
     HIP_TRY(hipEventSynchronize(b->ev1));
     HIP_TRY(hipEventElapsedTime(ms_total, b->ev0, b->ev1));
     b->have_results = true;
-    return SVT_OK;
+    return check_stream_errors(b);
 }
 
 int svt_batch_genotype_timed(svt_batch* b, int iters, float* ms_total)
@@ -739,6 +911,7 @@ static int svt_batch_results_impl(svt_batch* b, svt_result* out, uint64_t n_unit
     if (n_units != b->n_units) return fail(SVT_ERR_INVALID, "results n_units mismatch");
     HIP_TRY(hipSetDevice(b->device));
     HIP_TRY(hipStreamSynchronize(b->stream));   // the pass that produced the records
+    SVT_TRY(check_stream_errors(b));
     return d2h_staged(out, b->args.out, b->n_units * sizeof(svt_result), b->stream);
 }
 
@@ -759,6 +932,7 @@ static int svt_batch_bind_device_results_impl(svt_batch* b, svt_result* dev)
     if (!b) return fail(SVT_ERR_INVALID, "null batch");
     if (dev && (reinterpret_cast<uintptr_t>(dev) & 127u)) return fail(SVT_ERR_INVALID, "result buffer must be 128-byte aligned");
     b->args.out = dev ? dev : b->d_out;
+    b->sargs.out = b->args.out;
     b->have_results = false;
 
     return SVT_OK;
@@ -773,7 +947,8 @@ int svt_batch_bytes(const svt_batch* b, uint64_t* algorithmic, uint64_t* residen
 {
     if (!b) return fail(SVT_ERR_INVALID, "null batch");
     if (algorithmic) *algorithmic = 16 * b->n_records + (16 + 96) * b->n_units;
-    if (resident) *resident = 16 * b->slots + (uint64_t)b->n_tiles * kWave * sizeof(LaneHdr);
+    if (resident) *resident = b->layout == kLayoutStream ? 16 * b->n_records + (8 + 16) * b->n_units
+                                                         : 16 * b->slots + (uint64_t)b->n_tiles * kWave * sizeof(LaneHdr);
     return SVT_OK;
 }
 

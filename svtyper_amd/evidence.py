@@ -21,6 +21,7 @@ SVTYPE_NAME = {v: k for k, v in SVTYPE_CODE.items()}
 FLAG_SSO_ASSOCIATION = 0x1
 FLAG_DENSE_LAYOUT = 0x2
 FLAG_FIXED_PAIR_ENTRIES = 0x4   # compact layout with 4-byte pair entries only (no 2-byte short entries)
+FLAG_STREAM_LAYOUT = 0x8        # the CSR as it is, streamed through per-wave LDS rings by the pass itself
 
 REC_ALT_STRADDLE = 1 << 0
 REC_REF_STRADDLE_A = 1 << 1

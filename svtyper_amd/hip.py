@@ -204,7 +204,7 @@ class DeviceBatch:
         2-byte pair entries for the batch's most common MAPQ pair)"""
         c, m = C.c_int(), C.c_int()
         _check(self._lib.svt_batch_layout(self._h, C.byref(c), C.byref(m)))
-        return ("dense", "compact", "short")[c.value]
+        return ("dense", "compact", "short", "stream")[c.value]
 
     def stream(self) -> int:
         return int(self._lib.svt_batch_stream(self._h) or 0)

@@ -42,7 +42,8 @@ def run_both(batch, flags=0, device=0):
 
 
 ALL_FLAGS = [0, ev.FLAG_SSO_ASSOCIATION, ev.FLAG_DENSE_LAYOUT, ev.FLAG_DENSE_LAYOUT | ev.FLAG_SSO_ASSOCIATION,
-             ev.FLAG_FIXED_PAIR_ENTRIES, ev.FLAG_FIXED_PAIR_ENTRIES | ev.FLAG_SSO_ASSOCIATION]
+             ev.FLAG_FIXED_PAIR_ENTRIES, ev.FLAG_FIXED_PAIR_ENTRIES | ev.FLAG_SSO_ASSOCIATION,
+             ev.FLAG_STREAM_LAYOUT, ev.FLAG_STREAM_LAYOUT | ev.FLAG_SSO_ASSOCIATION]
 
 
 def oracle_flags(flags):
