@@ -110,8 +110,11 @@ def main():
                     help="breakpoints per GPU [the workload's own size: 1 000 000; c2_del_100k: 100 000]")
     ap.add_argument("--workload", default="c3_mixed_1m", choices=["c3_mixed_1m", "c2_del_100k", "c5_multisample"])
     ap.add_argument("--sso", action="store_true", help="singlesample.py floating-point association")
-    ap.add_argument("--dense", action="store_true", help="stream the canonical 16-byte records (no sparse re-encoding)")
-    ap.add_argument("--fixed-pair-entries", action="store_true", help="compact layout with 4-byte pair entries only")
+    ap.add_argument("--layout", default="stream", choices=["stream", "short", "compact", "dense"],
+                    help="stream (default): ONE kernel over the canonical CSR records as they lie in HBM; "
+                         "short / compact / dense: the tiled layouts svt_batch_create builds once (re-run figures)")
+    ap.add_argument("--dense", action="store_true", help="= --layout dense")
+    ap.add_argument("--fixed-pair-entries", action="store_true", help="= --layout compact")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dense-leg", action="store_true",
                     help="skip the extra timing of the dense-record layout (N=1 only)")
@@ -120,6 +123,10 @@ def main():
                     help="initialise torch.distributed (RCCL) and run the gather even with one rank")
     args = ap.parse_args()
 
+    if args.dense:
+        args.layout = "dense"
+    if args.fixed_pair_entries:
+        args.layout = "compact"
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.units is None:
@@ -152,8 +159,9 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))
 
-    flags = ((ev.FLAG_SSO_ASSOCIATION if args.sso else 0) | (ev.FLAG_DENSE_LAYOUT if args.dense else 0)
-             | (ev.FLAG_FIXED_PAIR_ENTRIES if args.fixed_pair_entries else 0))
+    flags = ((ev.FLAG_SSO_ASSOCIATION if args.sso else 0)
+             | {"stream": ev.FLAG_STREAM_LAYOUT, "short": 0, "compact": ev.FLAG_FIXED_PAIR_ENTRIES,
+                "dense": ev.FLAG_DENSE_LAYOUT}[args.layout])
     t0 = time.time()
     dbatch = hip.DeviceBatch(batch, device=local_rank, flags=flags)
     upload_s = time.time() - t0
@@ -258,13 +266,16 @@ def main():
                 "units_per_gpu": n,
                 "records_per_gpu": batch.n_records,
                 "association": "sso" if args.sso else "classic",
-                "device_layout": {"dense": "dense 16-byte records", "compact": "compact sparse 4-byte entry streams",
-                                  "short": "compact sparse entry streams, 2-byte pair entries for the common MAPQ pair"}[layout_name],
+                "device_layout": {"dense": "dense 16-byte records, tiled once at svt_batch_create",
+                                  "compact": "compact sparse 4-byte entry streams, re-encoded once at svt_batch_create",
+                                  "short": "compact sparse entry streams, 2-byte pair entries for the common MAPQ pair, "
+                                           "re-encoded once at svt_batch_create",
+                                  "stream": "the canonical CSR records as uploaded, streamed by the pass itself"}[layout_name],
                 "parallelism": "units sharded over %d GPU(s), no data-path collective per step" % world,
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "svt_genotype_kernel",
+                "kernel": "svt_stream_kernel" if layout_name == "stream" else "svt_genotype_kernel",
                 "achieved": ach,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
@@ -283,7 +294,7 @@ def main():
                          "(resident_bytes_per_launch) so it can exceed the HBM peak -- `traffic` / "
                          "`traffic_frac_of_peak` are the physical HBM bytes (PMC) of the same kernel, and "
                          "`roofline_dense_layout` is the same pass streaming the canonical records")
-                        if compact else "canonical 16-byte records streamed as they are",
+                        if layout_name in ("short", "compact") else "canonical 16-byte records streamed as they are",
             },
             "host": {"generate_s": gen_s, "first_create_s": upload_s, "steady_create_s": upload_steady_s,
                      "pcie_inclusive_breakpoints_per_s": n / (upload_steady_s + kern_ms * 1e-3),
@@ -295,7 +306,7 @@ def main():
         if args.workload == "c5_multisample":   # one breakpoint = one VCF site; a unit = (site, sample)
             out["sites_per_s"] = value / 32.0
             out["units_per_s"] = value
-        if world == 1 and compact and not args.no_dense_leg:
+        if world == 1 and layout_name in ("short", "compact") and not args.no_dense_leg:
             # the same pass over the canonical 16-byte records (SVT_FLAG_DENSE_LAYOUT), for reference
             try:
                 with hip.DeviceBatch(batch, device=local_rank, flags=flags | ev.FLAG_DENSE_LAYOUT) as dd:

@@ -19,10 +19,13 @@
 //   * the block of unit u lands at ring + u * 128 with its eight 16-byte slots XOR-swizzled by
 //     (u >> 1) & 7 -- the lane that owns unit u then reads its records with ds_read_b128 and the 16
 //     lanes the LDS serves per cycle hit 16 different bank quads (conflict-free, MI355X_MICROARCH LDS table);
-//   * two stages per wave (2 x 8 KB): block k + 2 is in flight while block k is consumed;
-//   * records of a block that lie outside the unit (the neighbours' records in its first and last
-//     block) are consumed with their weight bytes zeroed: prob_mapq(0) == +0.0 exactly, and x + 0.0 == x
-//     for these non-negative sums (the argument of include/svtyper_hip.h for gated-off reads);
+//   * one 8 KB stage per wave: a block leaves the stage for VGPRs in one burst of eight ds_read_b128, the
+//     fetch of block k + 1 is issued right behind it and lands while block k is being consumed -- 12 waves
+//     per CU fit beside the tables instead of 8 with a second stage;
+//   * slots of a block that lie outside the unit (the neighbours' records in its first and last line,
+//     everything past the end of a shorter unit) are not fetched; the consumer reads them as records with
+//     MAPQ 0 everywhere: prob_mapq(0) == +0.0 exactly, and x + 0.0 == x for these non-negative sums (the
+//     argument of include/svtyper_hip.h for gated-off reads);
 //   * the result records leave through the same ring: each lane stores its eight pieces to LDS, the wave
 //     reads them back unit-major and every group of eight lanes writes one full 128-byte line.
 //
@@ -31,16 +34,50 @@
 #ifndef SVT_STREAM_KERNEL_H
 #define SVT_STREAM_KERNEL_H
 
+#ifndef SVT_STREAM_AUX
+#define SVT_STREAM_AUX 2   // cache policy bits of the record fetches (2 = nt: every line is used once)
+#endif
+#ifndef SVT_STREAM_PROBE
+#define SVT_STREAM_PROBE 0 // timing-only builds (wrong results): 1 = fetch without the record arithmetic, 2 = arithmetic without fetches
+#endif
+#ifndef SVT_STREAM_SPLIT
+#define SVT_STREAM_SPLIT 4 // scheduling barrier before this record of a block (8 = none)
+#endif
+#ifndef SVT_STREAM_EDGE_AUX
+#define SVT_STREAM_EDGE_AUX 2 // cache policy of the blocks that hold a unit's first / last line
+#endif
+#ifndef SVT_STREAM_UNROLL_TILES
+#define SVT_STREAM_UNROLL_TILES 1 // the R tiles of a wave as straight-line code (a loop lets LICM hoist the epilogue's ~40 constants into registers that then spill)
+#endif
+#ifndef SVT_STREAM_WAVES
+#define SVT_STREAM_WAVES 3 // waves per SIMD the register allocation must allow (three workgroups per CU)
+#endif
+
+#include <type_traits>
+
 #include "svt_genotype_kernel.h"
 
 namespace svt {
 
 constexpr uint32_t kBlockRecords = 8;                         // records per 128-byte block
 constexpr uint32_t kStageBytes = kWave * 128;                 // one block per lane
-constexpr uint32_t kRingStages = 2;
-constexpr uint32_t kRingBytes = kStageBytes * kRingStages;    // per wave
-constexpr uint32_t kLdsStreamBins = kLdsWtab + 32 * 16;       // Bin[lds_bins], then LibDesc[lds_libs], then the rings
+constexpr uint32_t kRingBytes = kStageBytes;                  // per wave: one stage
+// LDS layout of the streaming kernel, absolute byte addresses (the kernel has no static LDS, so the dynamic
+// segment starts at 0 -- checked at run time): the one-library record consumer turns every field of a record
+// into an LDS address with one instruction and the table base as the ds_read's immediate offset.
+constexpr uint32_t kSPm = 0;                          // double[256]  prob_mapq(q)                      (utils.py:74-75)
+constexpr uint32_t kSPmHalf = kSPm + 256 * 8;         // double[256]  prob_mapq(q) / 2 (exact: a power-of-two scaling)
+constexpr uint32_t kSWtab = kSPmHalf + 256 * 8;       // kSingleLds: double w_alt[32], w_ref[32] (columns); kGeneral: PairWeights[32]
+constexpr uint32_t kSWref = 32 * 8;                   // byte distance w_alt[i] -> w_ref[i]
+constexpr uint32_t kSBins = kSWtab + 2 * 32 * 8;      // kSingleLds: int32 thr[total_bins], uint32 hist[total_bins]; kGeneral: LibDesc[n_libs]
 constexpr uint32_t kMaxSortKey = 255;                         // units with more blocks share the last sort bucket
+
+// where the epilogue finds the log10 table of log_choose
+enum L10Place : uint32_t {
+    kL10Shared = 0,   // staged once per workgroup beside the other tables (fits with 3 workgroups per CU)
+    kL10Ring = 1,     // copied into the wave's idle ring before each epilogue
+    kL10Global = 2    // read through L2 (units with thousands of records)
+};
 
 // error bits (shared with svt_scan_kernel)
 constexpr uint32_t kErrStraddleNoPair = 2u, kErrLibIndex = 4u, kErrReservedBits = 8u, kErrNegativeSpan = 16u;
@@ -61,7 +98,8 @@ struct StreamArgs {
     uint32_t lds_bins;           // bins staged in LDS (kSingleLds: the whole table)
     uint32_t lds_libs;           // library descriptors staged in LDS
     uint32_t lds_rings;          // byte offset of wave 0's ring (128-byte aligned)
-    uint32_t l10_in_ring;        // the log10 table fits the ring (n_l10 * 8 <= kRingBytes)
+    uint32_t l10_where;          // kL10Shared / kL10Ring / kL10Global
+    uint32_t lds_l10;            // kL10Shared: byte offset of the workgroup's copy of the log10 table
     uint64_t n_units;
     svt_result* out;
     uint32_t* err;
@@ -71,25 +109,27 @@ struct StreamArgs {
 
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
 
-// eight consecutive records of this lane's block from stage STAGE of the ring, once the LDS-DMA group that
-// filled it has landed: all but the youngest PENDING vector-memory operations must have completed.  The
-// compiler cannot see that these reads depend on the LDS-DMA writes, hence the explicit counters.
-template <int STAGE, int PENDING>
-__device__ __forceinline__ void read_block(const uint32_t (&addr)[8], u32x4 (&w)[8])
+// The eight records of this lane's block, once the LDS-DMA group that filled the ring has landed (it is the
+// only vector-memory work the wave has in flight).  The compiler cannot see that these reads depend on the
+// LDS-DMA writes, hence the explicit counters; when this returns the ring is free for the next block.
+__device__ __forceinline__ void read_block(const uint32_t lane_block, const uint32_t sw16, u32x4 (&w)[8])
 {
-    asm volatile("s_waitcnt vmcnt(%[pend])\n\t"
-                 "ds_read_b128 %0, %8 offset:%[off]\n\t"
-                 "ds_read_b128 %1, %9 offset:%[off]\n\t"
-                 "ds_read_b128 %2, %10 offset:%[off]\n\t"
-                 "ds_read_b128 %3, %11 offset:%[off]\n\t"
-                 "ds_read_b128 %4, %12 offset:%[off]\n\t"
-                 "ds_read_b128 %5, %13 offset:%[off]\n\t"
-                 "ds_read_b128 %6, %14 offset:%[off]\n\t"
-                 "ds_read_b128 %7, %15 offset:%[off]\n\t"
+    // logical record j of the lane's block sits in slot j ^ swz: lane_block + ((j << 4) ^ sw16)
+    uint32_t addr[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) addr[j] = lane_block + (((uint32_t)j << 4) ^ sw16);
+    asm volatile("s_waitcnt vmcnt(0)\n\t"
+                 "ds_read_b128 %0, %8\n\t"
+                 "ds_read_b128 %1, %9\n\t"
+                 "ds_read_b128 %2, %10\n\t"
+                 "ds_read_b128 %3, %11\n\t"
+                 "ds_read_b128 %4, %12\n\t"
+                 "ds_read_b128 %5, %13\n\t"
+                 "ds_read_b128 %6, %14\n\t"
+                 "ds_read_b128 %7, %15\n\t"
                  "s_waitcnt lgkmcnt(0)"
                  : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3]), "=&v"(w[4]), "=&v"(w[5]), "=&v"(w[6]), "=&v"(w[7])
-                 : "v"(addr[0]), "v"(addr[1]), "v"(addr[2]), "v"(addr[3]), "v"(addr[4]), "v"(addr[5]), "v"(addr[6]), "v"(addr[7]),
-                   [pend] "n"(PENDING), [off] "n"(STAGE * (int)kStageBytes)
+                 : "v"(addr[0]), "v"(addr[1]), "v"(addr[2]), "v"(addr[3]), "v"(addr[4]), "v"(addr[5]), "v"(addr[6]), "v"(addr[7])
                  : "memory");
 }
 
@@ -103,33 +143,102 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, const uint32
     return v;
 }
 
-struct RecordCheck {      // accumulated over every record a lane sees (neighbours' included: they are part of the batch)
-    uint32_t undefined = 0, span = 0, lone_straddle = 0, max_lib = 0;
+// The record contract of include/svtyper_hip.h, accumulated over the records of a lane's units at 3-4
+// instructions per record.
+template <int MODE>
+struct RecordCheck {
+    uint32_t flags_or = 0, span_or = 0, lone = 0, lib_max = 0;
     __device__ __forceinline__ void see(const u32x4 w)
     {
-        undefined |= w.w & ~SVT_REC_FLAG_MASK;
-        span |= w.x;                                                    // sign bit: a negative ospan_len
-        lone_straddle |= (w.w & 7u) & (((w.w >> 4) & 1u) - 1u);          // straddle bits without HAS_PAIR
-        max_lib = max(max_lib, (w.w >> SVT_REC_LIB_SHIFT) & 0xffu);
+        flags_or |= w.w;                                     // undefined bits; with one library also the library byte
+        span_or |= w.x;                                      // sign bit: a negative ospan_len
+        lone = max(lone, (w.w & 0x17u) ^ 0x10u);             // > 0x10: straddle bits without HAS_PAIR
+        if (MODE != kSingleLds) lib_max = max(lib_max, w.w & 0xff00u);
     }
     __device__ __forceinline__ uint32_t bits(const uint32_t n_libs) const
     {
-        return (lone_straddle ? kErrStraddleNoPair : 0u) | (max_lib >= n_libs ? kErrLibIndex : 0u) |
-               (undefined ? kErrReservedBits : 0u) | ((int32_t)span < 0 ? kErrNegativeSpan : 0u);
+        const bool bad_lib = MODE == kSingleLds ? (flags_or & 0xff00u) != 0u : (lib_max >> SVT_REC_LIB_SHIFT) >= n_libs;
+        return (lone > 0x10u ? kErrStraddleNoPair : 0u) | (bad_lib ? kErrLibIndex : 0u) |
+               ((flags_or & ~SVT_REC_FLAG_MASK) ? kErrReservedBits : 0u) | ((int32_t)span_or < 0 ? kErrNegativeSpan : 0u);
     }
 };
 
+// per-lane constants of the unit for the one-library record consumer
+struct StreamCtx {
+    uint32_t fmask;    // straddle-bit mask with the small-DEL gate applied (classic.py:339,383)
+    uint32_t kmin;     // (uint32) key_min
+    uint32_t nb;       // n_bins == index of the sentinel bin
+    uint32_t sub2;     // DEL ? var_length + key_min : 0x80000000 (never in range)
+    uint32_t hist_at;  // LDS address of hist[0]
+    uint32_t wt0, wt1; // LDS address of w_alt[del16] / w_alt[del16 + 8] (p_concordant = 0 / 1)
+};
+
+// One canonical record, one library, tables at fixed LDS addresses: the arithmetic of weight_evidence +
+// pair_evidence<kSingleLds> (svt_genotype_kernel.h; classic.py:306-408) with every table index formed by one
+// instruction.  (pm(l) * L + pm(r) * R) / 2.0 (classic.py:324) is taken as pm(l)/2 + pm(r)/2 from a second
+// table: halving a binary64 in [0.2, 1] is exact, so the sum rounds identically.  EDGE: the record may belong
+// to a neighbouring unit -- its weight bytes are then read as MAPQ 0, which adds +0.0 to every sum.
+template <bool SSO, bool EDGE>
+__device__ __forceinline__ void record_single(const u32x4 w, const bool mine, const StreamCtx& c, Acc& a)
+{
+    const uint32_t wy = EDGE ? (mine ? w.y : 0u) : w.y;   // mapq_a | mapq_b << 8 | rs_a << 16 | rs_b << 24
+    const uint32_t wz = EDGE ? (mine ? w.z : 0u) : w.z;   // seq_l | seq_r << 8 | clip_l << 16 | clip_r << 24
+    const double pm_a = lds_f64(kSPm + byte0_x8(wy)), pm_b = lds_f64(kSPm + byte1_x8(wy));
+    const double rs_a = lds_f64(kSPm + byte2_x8(wy)), rs_b = lds_f64(kSPm + byte3_x8(wy));
+    const double p_seq = lds_f64(kSPmHalf + byte0_x8(wz)) + lds_f64(kSPmHalf + byte1_x8(wz));
+    const double p_clip = lds_f64(kSPmHalf + byte2_x8(wz)) + lds_f64(kSPmHalf + byte3_x8(wz));
+    if (SSO) {   // singlesample.py:246-276,367-372: per-fragment sums, added to the site totals when the next fragment starts
+        const bool cont = (w.w & SVT_REC_CONTINUATION) != 0u;
+        a.ref_seq += cont ? 0.0 : a.l_ref_seq;
+        a.alt_seq += cont ? 0.0 : a.l_alt_seq;
+        a.alt_clip += cont ? 0.0 : a.l_alt_clip;
+        a.l_ref_seq = ((cont ? a.l_ref_seq : 0.0) + rs_a) + rs_b;
+        a.l_alt_seq = (cont ? a.l_alt_seq : 0.0) + p_seq;
+        a.l_alt_clip = (cont ? a.l_alt_clip : 0.0) + p_clip;
+    } else {
+        a.ref_seq = (a.ref_seq + rs_a) + rs_b;
+        a.alt_seq += p_seq;
+        a.alt_clip += p_clip;
+    }
+    // p_concordant as the integer test hist[o - v] <= thr[o] (svt_host_tables.h), out-of-range -> sentinel bin
+    const uint32_t i1 = min(w.x - c.kmin, c.nb), i2 = min(w.x - c.sub2, c.nb);
+    const int32_t thr1 = lds_i32(kSBins + (i1 << 2));
+    const uint32_t h2 = lds_u32(c.hist_at + (i2 << 2));
+    const bool p_conc = (int32_t)h2 <= thr1;
+    const uint32_t wa = (p_conc ? c.wt1 : c.wt0) | ((w.w & c.fmask) << 3);   // &w_alt[f3 | p_conc << 3 | del16]
+    const double pp = pm_a * pm_b;
+    a.alt_span += pp * lds_f64(wa);
+    a.ref_span += pp * lds_f64(wa + kSWref);
+}
+
+// Block k of every unit of the tile -> ring.  Lane (o, rr) of instruction i serves unit 8 i + o and only asks for
+// a record of that unit: the neighbours' records in a unit's first and last line, and every block past the end
+// of a shorter unit, are not requested at all (the consumer never looks at those slots).
+template <int AUX>
+__device__ __forceinline__ void fetch_block(const uint32_t k, const uint32_t (&src_first)[8], const uint32_t (&src_end)[8],
+                                            const uint32_t col_even, const uint32_t col_odd, const char* __restrict__ rec_bytes,
+                                            unsigned char* ring)
+{
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const uint32_t rec = (src_first[i] & ~7u) + k * kBlockRecords + (((i & 1) ? col_odd : col_even) >> 4);
+        if (rec >= src_first[i] && rec < src_end[i])
+            __builtin_amdgcn_global_load_lds(rec_bytes + ((uint64_t)rec << 4), (lds_void_ptr)(ring + (uint32_t)i * 1024u), 16, 0, AUX);
+    }
+}
+
 template <bool SSO, int MODE, int R>
-__global__ __launch_bounds__(kBlock) void svt_stream_kernel(const StreamArgs a)
+__global__ __launch_bounds__(kBlock, MODE == kSingleLds ? SVT_STREAM_WAVES : 2) void svt_stream_kernel(const StreamArgs a)
 {
     static_assert(MODE == kSingleLds || MODE == kGeneral, "library windows are not used by the streaming kernel");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // (lds_rings is 128-byte aligned)
     constexpr uint32_t kUnitsPerWg = kBlock * R;
     constexpr uint32_t kTilesPerWg = kWavesPerBlock * R;
-    double* s_pm = reinterpret_cast<double*>(smem + kLdsPm);
-    PairWeights* s_wtab = reinterpret_cast<PairWeights*>(smem + kLdsWtab);
-    Bin* s_bins = reinterpret_cast<Bin*>(smem + kLdsStreamBins);
-    LibDesc* s_lib = reinterpret_cast<LibDesc*>(s_bins + a.lds_bins);
+    double* s_pm = reinterpret_cast<double*>(smem + kSPm);
+    PairWeights* s_wtab = reinterpret_cast<PairWeights*>(smem + kSWtab);   // kGeneral
+    LibDesc* s_lib = reinterpret_cast<LibDesc*>(smem + kSBins);            // kGeneral
+    // the one-library consumer addresses the tables by absolute LDS byte offsets
+    if (MODE == kSingleLds && (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)smem != 0u) __builtin_trap();
     unsigned char* rings = smem + a.lds_rings;
     // sort scratch: lives in the rings until the streaming starts
     uint32_t* s_hist = reinterpret_cast<uint32_t*>(rings);      // kMaxSortKey + 1 buckets
@@ -157,12 +266,37 @@ __global__ __launch_bounds__(kBlock) void svt_stream_kernel(const StreamArgs a)
     }
 
     // ---- stage the tables in LDS
-    for (uint32_t i = tid; i < 256; i += kBlock) s_pm[i] = a.pm[i];
-    if (tid < 32) s_wtab[tid] = a.wtab[tid];
-    for (uint32_t i = tid; i < a.lds_libs * (uint32_t)(sizeof(LibDesc) / 8); i += kBlock)
-        reinterpret_cast<uint64_t*>(s_lib)[i] = reinterpret_cast<const uint64_t*>(a.libs)[i];
-    for (uint32_t i = tid; i < a.lds_bins; i += kBlock)
-        reinterpret_cast<uint64_t*>(s_bins)[i] = reinterpret_cast<const uint64_t*>(a.bins)[i];
+    for (uint32_t i = tid; i < 256; i += kBlock) {
+        const double p = a.pm[i];
+        s_pm[i] = p;
+        reinterpret_cast<double*>(smem + kSPmHalf)[i] = p * 0.5;
+    }
+    if (tid < 32) {
+        const PairWeights pw = a.wtab[tid];
+        if (MODE == kSingleLds) {
+            reinterpret_cast<double*>(smem + kSWtab)[tid] = pw.w_alt;
+            reinterpret_cast<double*>(smem + kSWtab + kSWref)[tid] = pw.w_ref;
+        } else {
+            s_wtab[tid] = pw;
+        }
+    }
+    if (MODE == kSingleLds) {
+        // thr[] and hist[] as two 4-byte arrays: the random look-ups of a wave spread over every LDS bank
+        int32_t* s_thr = reinterpret_cast<int32_t*>(smem + kSBins);
+        uint32_t* s_hst = reinterpret_cast<uint32_t*>(smem + kSBins) + a.total_bins;
+        for (uint32_t i = tid; i < a.total_bins; i += kBlock) {
+            const Bin bn = a.bins[i];
+            s_thr[i] = bn.thr;
+            s_hst[i] = bn.hist;
+        }
+    } else {
+        for (uint32_t i = tid; i < a.n_libs * (uint32_t)(sizeof(LibDesc) / 8); i += kBlock)
+            reinterpret_cast<uint64_t*>(s_lib)[i] = reinterpret_cast<const uint64_t*>(a.libs)[i];
+    }
+    if (a.l10_where == kL10Shared) {
+        double* s_l10 = reinterpret_cast<double*>(smem + a.lds_l10);
+        for (uint32_t i = tid; i < a.n_l10; i += kBlock) s_l10[i] = a.l10[i];
+    }
     for (uint32_t i = tid; i <= kMaxSortKey; i += kBlock) s_hist[i] = 0u;
     __syncthreads();
 
@@ -201,11 +335,11 @@ __global__ __launch_bounds__(kBlock) void svt_stream_kernel(const StreamArgs a)
     static_assert(kTilesPerWg * kWave == kUnitsPerWg, "tiles cover the workgroup's units");
     __syncthreads();   // the rings are free from here on
 
-    Tables t;
+    Tables t;   // kGeneral: tables through ordinary pointers, bins through L2
     t.pm = s_pm;
     t.wtab = s_wtab;
     t.libs = s_lib;
-    t.bins = MODE == kSingleLds ? s_bins : a.bins;
+    t.bins = a.bins;
 
     unsigned char* ring = rings + wave * kRingBytes;
     const uint32_t ring_addr = (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)ring;
@@ -216,21 +350,22 @@ __global__ __launch_bounds__(kBlock) void svt_stream_kernel(const StreamArgs a)
     const uint32_t col_even = (rr ^ (o >> 1)) << 4, col_odd = col_even ^ 64u;
     // consumer: logical record j of this lane's block
     const uint32_t sw = (lane >> 1) & 7u;
-    uint32_t rd_addr[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) rd_addr[j] = ring_addr + lane * 128u + (((uint32_t)j ^ sw) << 4);
+    const uint32_t lane_block = ring_addr + lane * 128u, sw16 = sw << 4;
     const char* rec_bytes = reinterpret_cast<const char*>(a.records);
 
-    RecordCheck check;
+    RecordCheck<MODE> check;
 
+#if SVT_STREAM_UNROLL_TILES
+#pragma unroll
+#else
 #pragma unroll 1
+#endif
     for (int r = 0; r < R; ++r) {
         const uint32_t first_rec = info[r].x, n_rec = info[r].y;
         const uint32_t unit = info[r].z == kPadUnit ? kPadUnit : (uint32_t)wg_base + info[r].z;   // n_units < 2^32
         svt_unit U{};
         if (unit != kPadUnit) U = a.units[unit];
         const uint32_t head = first_rec & 7u, last = head + n_rec;
-        const uint32_t blk0 = first_rec >> 3;
         const uint32_t nblk = n_rec ? (last + 7u) >> 3 : 0u;
         // sorted longest first: the tile's first lane has the most blocks -- unless it sits in the last sort
         // bucket, which holds every longer unit in arrival order
@@ -241,60 +376,81 @@ __global__ __launch_bounds__(kBlock) void svt_stream_kernel(const StreamArgs a)
             for (int d = 1; d < kWave; d <<= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d, kWave));
             max_blk = (uint32_t)__builtin_amdgcn_readfirstlane((int)m);
         }
-        uint32_t src_blk[8];
+        uint32_t min_blk = nblk;    // the first block some lane of the tile ends in
 #pragma unroll
-        for (int i = 0; i < 8; ++i) src_blk[i] = (uint32_t)__shfl((int)blk0, 8 * i + (int)o, kWave);
+        for (int d = 1; d < kWave; d <<= 1) min_blk = min(min_blk, (uint32_t)__shfl_xor((int)min_blk, d, kWave));
+        min_blk = (uint32_t)__builtin_amdgcn_readfirstlane((int)min_blk);
+        // fetch side: lane (o, rr) of instruction i serves unit 8 i + o -- it needs that unit's record range
+        uint32_t src_first[8], src_end[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            src_first[i] = (uint32_t)__shfl((int)first_rec, 8 * i + (int)o, kWave);
+            src_end[i] = src_first[i] + (uint32_t)__shfl((int)n_rec, 8 * i + (int)o, kWave);
+        }
 
-        auto fetch = [&](const uint32_t k, const uint32_t stage) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                // lanes past the end of their unit re-read blocks the neighbouring units need anyway
-                const uint32_t blk = min(src_blk[i] + k, a.last_blk);
-                const char* src = rec_bytes + ((uint64_t)blk << 7) + ((i & 1) ? col_odd : col_even);
-                __builtin_amdgcn_global_load_lds(src, (lds_void_ptr)(ring + stage * kStageBytes + (uint32_t)i * 1024u), 16, 0, 0);
-            }
+        // interior blocks are read once and never again (non-temporal); a unit's first and last line are shared
+        // with its neighbours in the CSR, which another wave fetches at another time: they can be given another
+        // policy (SVT_STREAM_EDGE_AUX) so that the second request may be served by L2 / Infinity Cache
+        auto fetch = [&](const uint32_t k) {
+            if (SVT_STREAM_EDGE_AUX != SVT_STREAM_AUX && (k == 0 || k + 1 >= min_blk))
+                fetch_block<SVT_STREAM_EDGE_AUX>(k, src_first, src_end, col_even, col_odd, rec_bytes, ring);
+            else
+                fetch_block<SVT_STREAM_AUX>(k, src_first, src_end, col_even, col_odd, rec_bytes, ring);
         };
 
-        LaneCtx c{};
+        LaneCtx c{};   // kGeneral
         c.is_del = U.svtype == SVT_SVTYPE_DEL;
         c.del16 = c.is_del ? 16u : 0u;
         c.var_length = U.var_length;
         c.pos_delta_d = (double)U.pos_delta;
+        StreamCtx sc;  // kSingleLds
         {
             const bool small_del = c.is_del && (c.pos_delta_d < a.lib0.sd2);  // classic.py:339,383
-            c.fmask = small_del ? 0u : 7u;
-            c.kmin = (uint32_t)a.lib0.key_min;
-            c.nb = a.lib0.n_bins;
-            c.sub2 = c.is_del ? (uint32_t)U.var_length + (uint32_t)a.lib0.key_min : 0x80000000u;
+            sc.fmask = small_del ? 0u : 7u;
+            sc.kmin = (uint32_t)a.lib0.key_min;
+            sc.nb = a.lib0.n_bins;
+            sc.sub2 = c.is_del ? (uint32_t)U.var_length + (uint32_t)a.lib0.key_min : 0x80000000u;
+            sc.hist_at = kSBins + a.total_bins * 4u;
+            sc.wt0 = kSWtab + c.del16 * 8u;
+            sc.wt1 = sc.wt0 + 8u * 8u;
         }
         Acc acc = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
 
-        auto consume = [&](const u32x4 (&w)[8], const uint32_t k) {
+        // EDGE = false: every lane's eight records of this block are its own
+        auto consume = [&](const u32x4 (&w)[8], const uint32_t k, auto edge) {
+            constexpr bool EDGE = decltype(edge)::value;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                check.see(w[j]);
+                // keep the look-ups of the second half of the block from being hoisted over the first half: eight
+                // records' worth of live table values would not fit the register budget of three waves per SIMD
+                if (j == SVT_STREAM_SPLIT) __builtin_amdgcn_sched_barrier(0);
                 const uint32_t idx = k * kBlockRecords + (uint32_t)j;
-                const bool mine = idx >= head && idx < last;
-                const uint32_t wy = mine ? w[j].y : 0u, wz = mine ? w[j].z : 0u;   // MAPQ 0 everywhere: adds +0.0
-                weight_evidence<SSO>(wy >> 16 | (wz << 16), wz >> 16, (w[j].w & SVT_REC_CONTINUATION) != 0, t, acc);
-                pair_evidence<MODE>(w[j].x, wy & 0xffffu, w[j].w & 7u, min(SVT_REC_LIB(w[j].w), a.n_libs - 1u), t, c, acc);   // (a bad index is reported through *err)
+                const bool mine = !EDGE || (idx >= head && idx < last);
+                if (mine) check.see(w[j]);   // (slots that are not this lane's were not fetched)
+                if (MODE == kSingleLds) {
+                    record_single<SSO, EDGE>(w[j], mine, sc, acc);
+                } else {
+                    const uint32_t wy = mine ? w[j].y : 0u, wz = mine ? w[j].z : 0u;   // MAPQ 0 everywhere: adds +0.0
+                    weight_evidence<SSO>(wy >> 16 | (wz << 16), wz >> 16, (w[j].w & SVT_REC_CONTINUATION) != 0, t, acc);
+                    // (a library index beyond the batch's is reported through *err)
+                    pair_evidence<MODE>(w[j].x, wy & 0xffffu, w[j].w & 7u, min(SVT_REC_LIB(w[j].w), a.n_libs - 1u), t, c, acc);
+                }
             }
         };
 
         if (max_blk) {
-            fetch(0, 0);
-            if (max_blk > 1) fetch(1, 1);
+            fetch(0);
             u32x4 w[8];
-            for (uint32_t k = 0; k < max_blk; k += 2) {
-                if (k + 1 < max_blk) read_block<0, 8>(rd_addr, w);
-                else read_block<0, 0>(rd_addr, w);
-                if (k + 2 < max_blk) fetch(k + 2, 0);
-                consume(w, k);
-                if (k + 1 >= max_blk) break;
-                if (k + 2 < max_blk) read_block<1, 8>(rd_addr, w);
-                else read_block<1, 0>(rd_addr, w);
-                if (k + 3 < max_blk) fetch(k + 3, 1);
-                consume(w, k + 1);
+#pragma unroll 1
+            for (uint32_t k = 0; k < max_blk; ++k) {
+                read_block(lane_block, sw16, w);
+                if (SVT_STREAM_PROBE != 2 && k + 1 < max_blk) fetch(k + 1);
+                const uint32_t k8 = k * kBlockRecords;
+                if (SVT_STREAM_PROBE == 1) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc.ref_seq += (double)(w[j].x ^ w[j].y ^ w[j].z ^ w[j].w);
+                } else if (__any(k8 < head || k8 + kBlockRecords > last)) consume(w, k, std::true_type{});
+                else consume(w, k, std::false_type{});
             }
         }
         if (SSO) {  // flush the last fragment (singlesample.py:370-372)
@@ -303,16 +459,16 @@ __global__ __launch_bounds__(kBlock) void svt_stream_kernel(const StreamArgs a)
             acc.alt_clip += acc.l_alt_clip;
         }
 
-        // ---- epilogue: the log10 table of log_choose goes through the (now idle) ring when it fits
-        double* ring_l10 = reinterpret_cast<double*>(ring);
-        if (a.l10_in_ring) {
+        // ---- epilogue: the log10 table of log_choose sits beside the tables, or goes through the (now idle) ring
+        const double* lds_l10 = reinterpret_cast<const double*>(a.l10_where == kL10Shared ? smem + a.lds_l10 : ring);
+        if (a.l10_where == kL10Ring) {
             const char* l10_bytes = reinterpret_cast<const char*>(a.l10);
             for (uint32_t off = 0; off < a.n_l10 * 8u; off += 1024u)
                 __builtin_amdgcn_global_load_lds(l10_bytes + off + lane * 16u, (lds_void_ptr)(ring + off), 16, 0, 0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         uint4 piece[8];
-        unit_epilogue(acc, (uint32_t)U.svtype, (uint32_t)U.flags, a.c, ring_l10, a.l10, a.l10_in_ring != 0u, piece);
+        unit_epilogue(acc, (uint32_t)U.svtype, (uint32_t)U.flags, a.c, lds_l10, a.l10, a.l10_where != kL10Global, piece);
 
         // ---- result records: lane-major into the ring, unit-major out of it, one full line per eight lanes
         uint4* st = reinterpret_cast<uint4*>(ring + lane * 128u);

@@ -65,7 +65,7 @@
 #define SVT_CHUNK 16384
 #endif
 #ifndef SVT_STREAM_R
-#define SVT_STREAM_R 2   // streaming kernel: 64-unit tiles per wave (a workgroup sorts 256 * R consecutive units)
+#define SVT_STREAM_R 1   // streaming kernel: 64-unit tiles per wave (a workgroup sorts 256 * R consecutive units)
 #endif
 
 #include "svt_common.h"
@@ -349,7 +349,8 @@ int create_stream(const svt_evidence_batch* in, svt_batch* b, void* d_records_re
 
     // one library whose tables fit beside the rings: tables in LDS, 32-bit index math; anything else reads
     // the tables through L2 with exact 64-bit geometry
-    const size_t single_lds = kLdsStreamBins + T.bins.size() * sizeof(Bin);
+    constexpr size_t kStreamLdsPerWg = (160 * 1024 / 3) & ~size_t(127);   // three workgroups per CU
+    const size_t single_lds = kSBins + T.bins.size() * sizeof(Bin);
     const bool single = in->n_libs == 1 && T.fast_geometry && single_lds + kWavesPerBlock * kRingBytes <= 96 * 1024;
     b->mode = single ? kSingleLds : kGeneral;
     StreamArgs& a = b->sargs;
@@ -367,10 +368,19 @@ int create_stream(const svt_evidence_batch* in, svt_batch* b, void* d_records_re
     a.last_blk = (uint32_t)(n_blk - 1);
     a.lds_bins = single ? a.total_bins : 0u;
     a.lds_libs = single ? 0u : in->n_libs;
-    size_t tables = kLdsStreamBins + (size_t)a.lds_bins * sizeof(Bin) + (size_t)a.lds_libs * sizeof(LibDesc);
+    size_t tables = kSBins + (size_t)a.lds_bins * sizeof(Bin) + (size_t)a.lds_libs * sizeof(LibDesc);
     tables = (tables + 127) & ~size_t(127);
+    // the log10 table of the epilogue: beside the tables while three workgroups still fit a CU's 160 KB,
+    // else through the wave's ring, else through L2
+    const size_t l10_bytes = ((size_t)n_l10 * 8 + 127) & ~size_t(127);
+    if (tables + l10_bytes + kWavesPerBlock * kRingBytes <= kStreamLdsPerWg) {
+        a.l10_where = kL10Shared;
+        a.lds_l10 = (uint32_t)tables;
+        tables += l10_bytes;
+    } else {
+        a.l10_where = (uint64_t)n_l10 * 8 <= kRingBytes ? kL10Ring : kL10Global;
+    }
     a.lds_rings = (uint32_t)tables;
-    a.l10_in_ring = (uint64_t)n_l10 * 8 <= kRingBytes ? 1u : 0u;
     a.n_units = n;
     a.out = b->d_out;
     a.err = b->d_err;

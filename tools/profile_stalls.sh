@@ -18,7 +18,7 @@ for sub in ("p1", "p3", "p4", "p5"):
     for f in sorted(glob.glob(os.path.join(out, sub, "**", "*.db"), recursive=True)):
         c = sqlite3.connect(f)
         q = ("select kernel_name, counter_name, avg(value), count(*) from counters_collection "
-             "where kernel_name like '%svt_genotype%' group by kernel_name, counter_name")
+             "where kernel_name like '%svt_%' group by kernel_name, counter_name")
         for r in c.execute(q):
             print(sub, r[0][:60], r[1], "%.6g" % r[2], r[3])
 PY
