@@ -60,29 +60,29 @@ extern "C" {
  *                then added to the site total (singlesample.py:246-276,367-372) */
 #define SVT_FLAG_SSO_ASSOCIATION 0x1u
 /* device layout of the resident batch:
- *   0 (default, "compact"): the records are re-encoded once, on the device, into two sparse
- *       streams of 4-byte entries per unit -- pair entries (straddle bits, mapq_a, mapq_b and
- *       ospan_len translated into the index space of the library's histogram tables) for
- *       fragments with a straddle bit and two non-zero MAPQs, weight entries (one gated MAPQ
- *       pair + its kind) for every non-zero reference / split / clip pair.  Dropped entries
- *       could only have added +0.0.  The encoding needs histograms of at most 4095 bins, DEL
- *       lengths >= 0 and, with several libraries, units whose libraries span at most 4
- *       consecutive indices and MAPQs <= 127 on the kept pair entries; a batch that does not
- *       qualify silently uses the dense layout (svt_batch_layout tells which one it got).
- *       With one library of at most 2047 bins the pair entries are written in half-words
- *       ("short" layout): an entry whose two MAPQs are the batch's most common pair (60, 60
- *       for bwa alignments) takes 2 bytes, any other one 4; same order, same sums.
- *   SVT_FLAG_DENSE_LAYOUT: the 16-byte records are streamed as they are.
- *   SVT_FLAG_FIXED_PAIR_ENTRIES: compact layout, but every pair entry keeps its 4 bytes.
- * Results are bit-identical between all of them.                                          */
+ *   0 (default, "stream"): nothing is re-tiled or re-encoded -- the CSR arrays go to HBM as the caller
+ *       packed them and ONE kernel (svt_stream_kernel) takes them to the result records, streaming every
+ *       record from HBM exactly once through per-wave LDS rings.  svt_batch_create is upload only; the
+ *       record contract is checked by the pass itself, so a malformed record is reported by
+ *       svt_batch_genotype(sync) / svt_batch_results / svt_genotype instead of svt_batch_create.
+ *   The other layouts re-tile the batch once at svt_batch_create (scan + host tiling + repack) into
+ *   64-unit lane-interleaved tiles; they only pay for a batch that is genotyped many times while resident:
+ *   SVT_FLAG_COMPACT_LAYOUT: the records are re-encoded into sparse streams of small entries per unit --
+ *       pair entries (straddle bits, mapq_a, mapq_b and ospan_len translated into the index space of the
+ *       library's histogram tables) for fragments with a straddle bit and two non-zero MAPQs, weight
+ *       entries (one gated MAPQ pair + its kind) for every non-zero reference / split / clip pair.
+ *       Dropped entries could only have added +0.0.  The encoding needs histograms of at most 4095 bins,
+ *       DEL lengths >= 0 and, with several libraries, units whose libraries span at most 4 consecutive
+ *       indices and MAPQs <= 127 on the kept pair entries; a batch that does not qualify silently uses
+ *       the dense tiles (svt_batch_layout tells which one it got).  With one library of at most 2047
+ *       bins the pair entries are written in half-words ("short" layout): an entry whose two MAPQs are
+ *       the batch's most common pair (60, 60 for bwa alignments) takes 2 bytes, any other one 4.
+ *   SVT_FLAG_FIXED_PAIR_ENTRIES: the compact layout, but every pair entry keeps its 4 bytes.
+ *   SVT_FLAG_DENSE_LAYOUT: tiles of the 16-byte records as they are.
+ * Results are bit-identical between all of them.                                                    */
 #define SVT_FLAG_DENSE_LAYOUT 0x2u
 #define SVT_FLAG_FIXED_PAIR_ENTRIES 0x4u
-/*   SVT_FLAG_STREAM_LAYOUT: nothing is re-tiled or re-encoded at all -- the CSR arrays go to HBM as the
- *       caller packed them and ONE kernel streams them through per-wave LDS rings (each record is read
- *       from HBM exactly once, by the pass itself).  svt_batch_create is then upload only; the record
- *       contract is checked by the pass, so a malformed record is reported by svt_batch_genotype(sync)
- *       / svt_batch_results instead of svt_batch_create.                                             */
-#define SVT_FLAG_STREAM_LAYOUT 0x8u
+#define SVT_FLAG_COMPACT_LAYOUT 0x8u
 
 /* ---- evidence record: one per read-fragment (query name) of a unit, 16 B --
  * Records of a unit are stored in the order the reference walks them:
@@ -282,10 +282,9 @@ int svt_device_count(void);
 /* Text of the last error raised on the calling thread ("" when none). */
 const char* svt_last_error(void);
 
-/* Pack `in` for the device and make it resident in HBM on `device`:
- * validates the CSR, sorts units by record count inside 4096-unit chunks,
- * uploads records/headers/tables and re-tiles the records on the device into
- * 64-unit lane-interleaved tiles (DESIGN.md "HBM layout").  `flags`: SVT_FLAG_*.
+/* Make `in` resident in HBM on `device`: validates the unit arrays, builds the look-up tables and
+ * uploads the CSR as it is (default); with one of the tiled layouts it also re-tiles / re-encodes the
+ * records on the device (DESIGN.md "HBM layout").  `flags`: SVT_FLAG_*.
  * Replaces the hand-over of `read_batch` to the per-sample block of
  * classic.py:279-296 / the `sam_fragments` argument of singlesample.py:355.     */
 int svt_batch_create(const svt_evidence_batch* in, int device, unsigned flags,
@@ -322,8 +321,8 @@ int svt_batch_bind_device_results(svt_batch* b, svt_result* dev_ptr);
  * holds (padding included).                                                     */
 int svt_batch_bytes(const svt_batch* b, uint64_t* algorithmic, uint64_t* resident);
 
-/* Which device layout / kernel flavour the batch got: *compact = 0 for the dense records, 1 for the
- * compact entry streams with 4-byte pair entries, 2 for the short pair entries; *table_mode = 0 one library, tables in LDS; 1 several libraries,
+/* Which device layout / kernel flavour the batch got: *compact = 0 for the dense tiles, 1 for the
+ * compact entry streams with 4-byte pair entries, 2 for the short pair entries, 3 for the streamed CSR; *table_mode = 0 one library, tables in LDS; 1 several libraries,
  * per-workgroup library windows in LDS; 2 general geometry, tables read through L2.          */
 int svt_batch_layout(const svt_batch* b, int* compact, int* table_mode);
 

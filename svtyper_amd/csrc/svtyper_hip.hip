@@ -84,11 +84,12 @@ using namespace svt;
 // ------------------------------------------------------------------------------------------
 // batch object
 // ------------------------------------------------------------------------------------------
-constexpr unsigned kKnownFlags = SVT_FLAG_SSO_ASSOCIATION | SVT_FLAG_DENSE_LAYOUT | SVT_FLAG_FIXED_PAIR_ENTRIES | SVT_FLAG_STREAM_LAYOUT;
+constexpr unsigned kKnownFlags = SVT_FLAG_SSO_ASSOCIATION | SVT_FLAG_DENSE_LAYOUT | SVT_FLAG_FIXED_PAIR_ENTRIES | SVT_FLAG_COMPACT_LAYOUT;
 
 inline int layout_of_flags(unsigned flags)
 {
-    return (flags & SVT_FLAG_STREAM_LAYOUT) ? svt::kLayoutStream : (flags & SVT_FLAG_DENSE_LAYOUT) ? svt::kLayoutDense : svt::kLayoutCompact;
+    return (flags & SVT_FLAG_DENSE_LAYOUT) ? svt::kLayoutDense
+           : (flags & (SVT_FLAG_COMPACT_LAYOUT | SVT_FLAG_FIXED_PAIR_ENTRIES)) ? svt::kLayoutCompact : svt::kLayoutStream;
 }
 
 struct svt_batch {

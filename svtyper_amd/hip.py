@@ -194,14 +194,15 @@ class DeviceBatch:
         return out
 
     def layout(self):
-        """(compact: bool, table_mode: 0 one library in LDS / 1 library windows in LDS / 2 general)"""
+        """(compact entry streams: bool, table_mode: 0 one library in LDS / 1 library windows in LDS / 2 general)"""
         c, m = C.c_int(), C.c_int()
         _check(self._lib.svt_batch_layout(self._h, C.byref(c), C.byref(m)))
-        return bool(c.value), int(m.value)
+        return c.value in (1, 2), int(m.value)
 
     def layout_name(self) -> str:
-        """"dense" (16-byte records), "compact" (entry streams, 4-byte pair entries) or "short" (entry streams,
-        2-byte pair entries for the batch's most common MAPQ pair)"""
+        """"stream" (default: the CSR as uploaded), or one of the tiled layouts: "dense" (16-byte records), "compact"
+        (entry streams, 4-byte pair entries), "short" (entry streams, 2-byte pair entries for the batch's most
+        common MAPQ pair)"""
         c, m = C.c_int(), C.c_int()
         _check(self._lib.svt_batch_layout(self._h, C.byref(c), C.byref(m)))
         return ("dense", "compact", "short", "stream")[c.value]

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.mark.gpu
 def test_bench_line_has_the_contract_keys(hip_device):
     r = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--steps", "3", "--warmup", "1", "--units", "30000",
-                        "--cpu-seconds", "1"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+                        "--cpu-seconds", "1", "--large-units", "70000"], cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, "exactly one line on stdout"
@@ -33,6 +33,17 @@ def test_bench_line_has_the_contract_keys(hip_device):
     assert cpu["kind"] == "port" and cpu["cores"] >= 1
     assert d["value"] > 0 and abs(d["value"] - 30000 * 3 / (d["ms_per_step"] * 3 * 1e-3)) / d["value"] < 1e-6
     assert d["parity"]["integer_mismatches"] == 0 and d["parity"]["max_abs_dGL"] <= 1e-6 and d["parity"]["max_abs_dSQ"] <= 1e-6
+    # the timed step is the whole path from the canonical input: the algorithmic rate cannot exceed the HBM peak
+    assert roof["kernel"] == "svt_stream_kernel" and 0 < roof["frac"] <= 1.0
+    assert "nothing pre-digested" in d["config"]["step"]
+    # a traffic figure is only reported when it was measured on this very build
+    assert roof["traffic"] is None or "this build" in roof["traffic_source"]
+    # the labelled extra legs
+    assert d["one_shot"]["pcie_inclusive_breakpoints_per_s"] > 0 and d["one_shot"]["wall_ms"] > 0
+    assert d["large_batch"]["units"] == 70000 and d["large_batch"]["first_units_equal_headline"] is True
+    assert 0 < d["large_batch"]["frac"] <= 1.0
+    for name in ("short", "dense"):
+        assert d["resident_rerun"][name]["results_equal_headline"] is True
 
 
 @pytest.mark.gpu
@@ -40,9 +51,10 @@ def test_one_line_on_stdout_with_the_process_group_up(hip_device):
     """--force-dist: RCCL initialised and the gather run on one rank; RCCL's banner must not reach stdout."""
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29671", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--units", "20000", "--force-dist",
-                        "--no-cpu-baseline", "--no-dense-leg"], cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
+                        "--no-cpu-baseline", "--no-extra-legs", "--scaling", "strong"], cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, r.stdout[-1000:]
     d = json.loads(lines[0])
     assert d["gather"]["collective"] == "rccl gather" and d["value"] > 0
+    assert d["scaling"] == "strong" and d["config"]["total_units"] == 20000 and d["gather"]["units_per_rank"] == [20000]

@@ -25,19 +25,19 @@ def _check(sites, libs_json, flags, hip_device):
                                 s["breakpoint"]["id"])
 
 
-@pytest.mark.parametrize("layout", [0, ev.FLAG_DENSE_LAYOUT])
+@pytest.mark.parametrize("layout", [0, ev.FLAG_DENSE_LAYOUT, ev.FLAG_COMPACT_LAYOUT])
 def test_fixture_sites_sso(hip_device, layout):
     g = gio.load("fixture_sites.json.gz")
     _check(g["sites"], g["libraries"], ev.FLAG_SSO_ASSOCIATION | layout, hip_device)
 
 
-@pytest.mark.parametrize("layout", [0, ev.FLAG_DENSE_LAYOUT])
+@pytest.mark.parametrize("layout", [0, ev.FLAG_DENSE_LAYOUT, ev.FLAG_COMPACT_LAYOUT])
 def test_fixture_sites_classic(hip_device, layout):
     g = gio.load("fixture_sites.json.gz")
     _check(g["sites"], g["libraries"], layout, hip_device)
 
 
-@pytest.mark.parametrize("layout", [0, ev.FLAG_DENSE_LAYOUT])
+@pytest.mark.parametrize("layout", [0, ev.FLAG_DENSE_LAYOUT, ev.FLAG_COMPACT_LAYOUT])
 def test_fake_sites(hip_device, layout):
     g = gio.load("fake_sites.json.gz")
     for grp in g["groups"]:

@@ -43,7 +43,7 @@ def run_both(batch, flags=0, device=0):
 
 ALL_FLAGS = [0, ev.FLAG_SSO_ASSOCIATION, ev.FLAG_DENSE_LAYOUT, ev.FLAG_DENSE_LAYOUT | ev.FLAG_SSO_ASSOCIATION,
              ev.FLAG_FIXED_PAIR_ENTRIES, ev.FLAG_FIXED_PAIR_ENTRIES | ev.FLAG_SSO_ASSOCIATION,
-             ev.FLAG_STREAM_LAYOUT, ev.FLAG_STREAM_LAYOUT | ev.FLAG_SSO_ASSOCIATION]
+             ev.FLAG_COMPACT_LAYOUT, ev.FLAG_COMPACT_LAYOUT | ev.FLAG_SSO_ASSOCIATION]
 
 
 def oracle_flags(flags):
@@ -70,7 +70,7 @@ def test_c2_slice(hip_device, fixture_library, flags):
     assert_parity(got, want)
 
 
-@pytest.mark.parametrize("flags", [0, ev.FLAG_DENSE_LAYOUT])
+@pytest.mark.parametrize("flags", [0, ev.FLAG_DENSE_LAYOUT, ev.FLAG_COMPACT_LAYOUT])
 def test_c3_slice_mixed(hip_device, fixture_library, flags):
     """configs[2]: mixed DEL/DUP/INV."""
     batch = synth.make_config("c3_mixed_1m", [fixture_library], n_units=30_000)
@@ -303,9 +303,9 @@ def test_full_size_properties(hip_device, full_c3):
     perm = hip.genotype_batch(synth.permute_units(batch, order), device=hip_device)
     assert np.array_equal(_digest(perm), base[order])
 
-    # both device layouts agree on everything
-    dense = hip.genotype_batch(batch, device=hip_device, flags=ev.FLAG_DENSE_LAYOUT)
-    assert np.array_equal(dense.rec, first.rec)
+    # every device layout agrees on everything
+    for other in (ev.FLAG_DENSE_LAYOUT, ev.FLAG_COMPACT_LAYOUT):
+        assert np.array_equal(hip.genotype_batch(batch, device=hip_device, flags=other).rec, first.rec)
 
     # the oracle on a bounded random sample of the same units
     pick = np.sort(rng.choice(n, 20_000, replace=False))
@@ -326,7 +326,7 @@ def test_full_size_properties(hip_device, full_c3):
 # ------------------------------------------------------------------------------------------
 # compact layout: the ospan_len -> table-code translation and the fallbacks to the dense records
 # ------------------------------------------------------------------------------------------
-def _layout_of(batch, flags=0, device=0):
+def _layout_of(batch, flags=ev.FLAG_COMPACT_LAYOUT, device=0):
     from svtyper_amd import hip
     with hip.DeviceBatch(batch, device, flags) as d:
         return d.layout()
@@ -416,7 +416,7 @@ def test_compact_fallbacks_stay_exact(hip_device, fixture_library):
     d.units["var_length"][::9] = -250
     for batch in (a, b, c, d):
         assert _layout_of(batch)[0] is False
-        for flags in (0, ev.FLAG_SSO_ASSOCIATION):
+        for flags in (ev.FLAG_COMPACT_LAYOUT, ev.FLAG_COMPACT_LAYOUT | ev.FLAG_SSO_ASSOCIATION):
             got, want = run_both(batch, flags)
             assert_parity(got, want)
     # the same shapes without the offending feature do take the compact layout
@@ -433,7 +433,7 @@ def test_pooled_buffers_do_not_leak_state(hip_device, fixture_library):
     small = synth.make_units(17_000, 72, [fixture_library], svtype_mix=(0.5, 0.2, 0.2, 0.1), mean_frags=40, sd_frags=30,
                              min_frags=0, max_frags=120)
     want_small = run_both(small)[1]
-    for flags in (0, ev.FLAG_DENSE_LAYOUT, 0):
+    for flags in (0, ev.FLAG_DENSE_LAYOUT, ev.FLAG_COMPACT_LAYOUT, 0):
         got_big, want_big = run_both(big, flags)
         assert_parity(got_big, want_big)
         assert_parity(hip.genotype_batch(small, device=hip_device, flags=flags), want_small)
@@ -477,15 +477,16 @@ def test_site_qual_on_device(hip_device, fixture_library, n_samples):
 # ------------------------------------------------------------------------------------------
 # short layout: 2-byte pair entries for the batch's most common MAPQ pair, 4-byte-aligned wide entries otherwise
 # ------------------------------------------------------------------------------------------
-def _name_of(batch, flags=0, device=0):
+def _name_of(batch, flags=ev.FLAG_COMPACT_LAYOUT, device=0):
     from svtyper_amd import hip
     with hip.DeviceBatch(batch, device, flags) as d:
         return d.layout_name()
 
 
-def test_short_layout_is_the_default_for_one_narrow_library(hip_device, fixture_library):
+def test_short_layout_is_what_the_compact_flag_gives_one_narrow_library(hip_device, fixture_library):
     assert len(fixture_library.hist) <= 2047
     batch = synth.make_units(4000, 51, [fixture_library], svtype_mix=(0.6, 0.2, 0.1, 0.1))
+    assert _name_of(batch, 0) == "stream"            # the default layout streams the CSR as it is
     assert _name_of(batch) == "short"
     assert _name_of(batch, ev.FLAG_FIXED_PAIR_ENTRIES) == "compact"
     assert _name_of(batch, ev.FLAG_DENSE_LAYOUT) == "dense"
@@ -536,7 +537,7 @@ def test_short_layout_is_smaller_and_equal_on_the_headline_shape(hip_device, fix
     from svtyper_amd import hip
     batch = synth.make_config("c3_mixed_1m", [fixture_library], n_units=30_000)
     sizes, results = {}, {}
-    for name, flags in (("short", 0), ("compact", ev.FLAG_FIXED_PAIR_ENTRIES), ("dense", ev.FLAG_DENSE_LAYOUT)):
+    for name, flags in (("short", ev.FLAG_COMPACT_LAYOUT), ("compact", ev.FLAG_FIXED_PAIR_ENTRIES), ("dense", ev.FLAG_DENSE_LAYOUT)):
         with hip.DeviceBatch(batch, hip_device, flags) as d:
             assert d.layout_name() == name
             sizes[name] = d.bytes()[1]
@@ -564,7 +565,7 @@ def test_sum_of_likelihoods_across_the_underflow_band(hip_device, fixture_librar
         u["var_length"] = 5000 if svtype == 0 else 0
         u["pos_delta"] = 5000
         batch = ev.EvidenceBatch(off, u, r, [fixture_library], 1.0, 1.0)
-        for flags in (0, ev.FLAG_DENSE_LAYOUT):
+        for flags in (0, ev.FLAG_DENSE_LAYOUT, ev.FLAG_COMPACT_LAYOUT):
             got, want = run_both(batch, flags)
             assert_parity(got, want)
         best = want.gl.max(axis=1)

@@ -31,7 +31,7 @@ if __name__ == "__main__":
         sys.exit(0)
     import bench
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
-    flags = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+    flags = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     only = sys.argv[3:]   # variant name filters
     os.makedirs(TMP, exist_ok=True)
     t0 = time.time()

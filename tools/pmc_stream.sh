@@ -6,7 +6,7 @@ TAG=${1:-x}; LIB=${2:-}
 OUT=gpurun_out/pmc_$TAG; mkdir -p $OUT
 export TMPDIR=/tmp
 [ -n "$LIB" ] && export SVTYPER_HIP_LIB=$LIB
-C="python tools/ab_stream.py --child ${FLAGS:-8}"
+C="python tools/ab_stream.py --child ${FLAGS:-0}"
 for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS" \
            "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS" \
            "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum GRBM_GUI_ACTIVE" "MeanOccupancyPerCU"; do

@@ -45,7 +45,7 @@ if "--no-parity" not in sys.argv:
 
 n = int([a for a in sys.argv[1:] if a.isdigit()][0]) if [a for a in sys.argv[1:] if a.isdigit()] else 1_000_000
 batch = bench.generate("c3_mixed_1m", n, 0, bench.usable_cpus())
-for name, flags in (("stream", ev.FLAG_STREAM_LAYOUT), ("dense", ev.FLAG_DENSE_LAYOUT), ("short", 0)):
+for name, flags in (("stream", 0), ("dense", ev.FLAG_DENSE_LAYOUT), ("short", ev.FLAG_COMPACT_LAYOUT)):
     t0 = time.perf_counter()
     with hip.DeviceBatch(batch, 0, flags) as d:
         t1 = time.perf_counter()
