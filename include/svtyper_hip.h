@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SVT_ABI_VERSION 7
+#define SVT_ABI_VERSION 8
 
 /* ---- error codes (0 = ok, <0 = error; text via svt_last_error()) ---------- */
 #define SVT_OK 0
@@ -370,12 +370,29 @@ int svt_format_results(const svt_result* res, uint64_t n_units, const uint8_t* f
                        int skipped_as_dots, char** text_out, uint64_t** offsets_out);
 void svt_format_free(char* text, uint64_t* offsets);
 
+/* SQ of every called unit (gt >= 0) recomputed IN PLACE from its GL with the host libm, i.e. with the very
+ * calls CPython makes for svtyper/classic.py:473-481 (10 ** gl, math.log(gt_sum, 10)).  GL leaves the device
+ * bit-identical to the reference's, so after this call SQ -- and every QUAL summed from it, and their '%0.2f'
+ * renderings -- are bit-identical too (the device's own SQ goes through the GPU's exp10 / log: |dSQ| <= 5e-13).
+ * Host only, multi-threaded; the drivers call it on every batch of results they format.                    */
+int svt_results_host_sq(svt_result* res, uint64_t n_units);
+
 /* Array form of the reference's inner operator seam statistics.bayes_gt(ref, alt, is_dup)
  * (svtyper/statistics.py:23-37) and log_choose(ref + alt, alt) (statistics.py:9-20):
  * out[4*i .. 4*i+3] = { lp_homref, lp_het, lp_homalt, log_choose } for item i.  All pointers
  * are host memory; ref[i], alt[i] >= 0 and ref[i] + alt[i] < 2^24.                           */
 int svt_bayes_gt(const int32_t* ref, const int32_t* alt, const uint8_t* is_dup, uint64_t n,
                  double* out, int device);
+
+/* Array form of the reference's inner operator seam bayesian_genotype(breakpoint, counts, split_weight,
+ * disc_weight, debug) (svtyper/singlesample.py:406-473; the same lines as classic.py:437-495):
+ * counts[5*i .. 5*i+4] = {ref_seq, alt_seq, alt_clip, ref_span, alt_span} of item i (SVT_TAL_* order) exactly as
+ * tally_variant_read_fragments returned them, is_dup[i] = (breakpoint['svtype'] == 'DUP').  Like the reference
+ * function it applies no zeroing rule and genotypes all-zero counts like any others (its callers take the blank
+ * result before calling it), so out[i].gt is never SVT_GT_BLANK / SVT_GT_SKIPPED.  All pointers are host memory;
+ * counts finite, >= 0, weighted totals < 2^24.                                                              */
+int svt_genotype_counts(const double* counts, const uint8_t* is_dup, uint64_t n, double split_weight,
+                        double disc_weight, svt_result* out, int device);
 
 /* Convenience: create + genotype + results + destroy.                          */
 int svt_genotype(const svt_evidence_batch* in, svt_result* out, int device,

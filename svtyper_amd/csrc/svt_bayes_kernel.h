@@ -30,6 +30,25 @@ __global__ __launch_bounds__(kBlock) void svt_bayes_kernel(const int32_t* __rest
 }
 
 // ------------------------------------------------------------------------------------------
+// bayesian_genotype seam kernel (singlesample.py:406-473): the five counts of an item as its caller has them ->
+// the full result record.  One item per thread; no zeroing rule, no blank shortcut (see unit_epilogue).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void svt_counts_kernel(const double* __restrict__ counts, const uint8_t* __restrict__ is_dup,
+                                                            uint64_t n, const double* __restrict__ l10, const GtConsts c,
+                                                            svt_result* __restrict__ out)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const double* t = counts + 5 * i;   // SVT_TAL_* order: ref_seq, alt_seq, alt_clip, ref_span, alt_span
+    const Acc acc = {t[0], t[1], t[2], t[3], t[4], 0.0, 0.0, 0.0};
+    uint4 piece[8];
+    unit_epilogue<false, false>(acc, is_dup[i] ? SVT_SVTYPE_DUP : SVT_SVTYPE_DEL, 0u, c, l10, l10, false, piece);
+    uint4* dst = reinterpret_cast<uint4*>(out + i);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) dst[k] = piece[k];
+}
+
+// ------------------------------------------------------------------------------------------
 // QUAL of a site over its samples (classic.py:216-217,485,498): a running binary64 sum of SQ in -B
 // order, reset to 0 by a sample without evidence, untouched by a skipped or './.' sample.  One site
 // per thread, samples in order; units are site-major (unit = site * n_samples + sample).

@@ -7,6 +7,7 @@
 // and is the checker of this one.
 
 #include <algorithm>
+#include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -40,6 +41,19 @@ inline void put_fmt(std::string& s, const char* fmt, double v)
     char buf[64];
     const int n = std::snprintf(buf, sizeof buf, fmt, v);
     s.append(buf, (size_t)std::max(0, std::min(n, (int)sizeof buf - 1)));
+}
+
+// SQ of a called unit from its three log10 likelihoods with the HOST libm -- the very calls CPython makes for
+// svtyper/classic.py:473-481: gt_sum = sum(10 ** gl), math.log(gt_sum, 10) == log(gt_sum) / log(10).  GL is
+// bit-identical to the reference's, so this SQ is too (the device's own SQ goes through the GPU's exp10 / log and
+// can differ in the last places: 5e-13 measured).
+inline double host_sample_qual(const svt_result& r)
+{
+    double gt_sum = 0.0;
+    for (int g = 0; g < 3; ++g) gt_sum += std::pow(10.0, r.gl[g]);
+    if (!(gt_sum > 0.0)) return r.sq;           // (the device decided GT './.' against the same libm's underflow point)
+    const double gt_sum_log = std::log(gt_sum) / std::log(10.0);
+    return std::fabs(-10.0 * (r.gl[0] - gt_sum_log));
 }
 
 // one FORMAT value of one unit, exactly as the Python layer prints it
@@ -143,6 +157,23 @@ void svt_format_free(char* text, uint64_t* offsets)
 {
     std::free(text);
     std::free(offsets);
+}
+
+static int svt_results_host_sq_impl(svt_result* res, uint64_t n_units)
+{
+    if (n_units && !res) return fail(SVT_ERR_INVALID, "null argument");
+    const unsigned nt = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(svt::usable_cpus(), n_units / 4096 + 1));
+    run_threads(nt, [&](unsigned t) {
+        const uint64_t lo = n_units * t / nt, hi = n_units * (t + 1) / nt;
+        for (uint64_t u = lo; u < hi; ++u)
+            if (res[u].gt >= 0) res[u].sq = host_sample_qual(res[u]);
+    });
+    return SVT_OK;
+}
+
+int svt_results_host_sq(svt_result* res, uint64_t n_units)
+{
+    return guarded([&] { return svt_results_host_sq_impl(res, n_units); });
 }
 
 }  // extern "C"

@@ -353,7 +353,10 @@ __device__ __forceinline__ uint4 pair_swap(const uint4 v)
 // per-unit epilogue: zeroing rules -> QR/QA -> bayes_gt -> GT/GQ/SQ -> the eight 16-byte pieces of the
 // 128-byte result record (classic.py:425-513).  Shared by every genotype kernel, so all device layouts
 // produce the same bits.  The host-built log(i)/log(10) table is read from LDS (l10_lds) or through L2 (l10_global).
+// RULES = false / BLANKS = false: the seam form bayesian_genotype(counts) (singlesample.py:406-473), which takes the
+// counts as they are -- its callers apply the zeroing rules and pick the blank result before calling it.
 // ------------------------------------------------------------------------------------------
+template <bool RULES = true, bool BLANKS = true>
 __device__ __forceinline__ void unit_epilogue(const Acc& acc, const uint32_t svtype, const uint32_t uflags, const GtConsts& c,
                                               const double* l10_lds, const double* __restrict__ l10_global, const bool l10_in_lds,
                                               uint4 (&piece)[8])
@@ -362,9 +365,11 @@ __device__ __forceinline__ void unit_epilogue(const Acc& acc, const uint32_t svt
            ref_span = acc.ref_span, alt_span = acc.alt_span;
 
     // ---- zeroing rules (classic.py:425-435)
-    if ((alt_seq + alt_clip) < 0.5 && alt_span >= 1.0) { alt_seq = 0.0; alt_clip = 0.0; ref_seq = 0.0; }
-    if (alt_span < 0.5 && (alt_seq + alt_clip) >= 1.0) { alt_span = 0.0; ref_span = 0.0; }
-    if (alt_span + alt_seq == 0.0 && alt_clip > 0.0) alt_clip = 0.0;
+    if (RULES) {
+        if ((alt_seq + alt_clip) < 0.5 && alt_span >= 1.0) { alt_seq = 0.0; alt_clip = 0.0; ref_seq = 0.0; }
+        if (alt_span < 0.5 && (alt_seq + alt_clip) >= 1.0) { alt_span = 0.0; ref_span = 0.0; }
+        if (alt_span + alt_seq == 0.0 && alt_clip > 0.0) alt_clip = 0.0;
+    }
 
     int32_t cnt[SVT_N_COUNTS];
 #pragma unroll
@@ -373,8 +378,8 @@ __device__ __forceinline__ void unit_epilogue(const Acc& acc, const uint32_t svt
     double sq = 0.0;
     int32_t gt;
 
-    const bool skipped = (uflags & SVT_UNIT_SKIP) != 0;
-    const bool evidence = (ref_seq + alt_seq + ref_span + alt_span + alt_clip) > 0.0;  // classic.py:437
+    const bool skipped = BLANKS && (uflags & SVT_UNIT_SKIP) != 0;
+    const bool evidence = !BLANKS || (ref_seq + alt_seq + ref_span + alt_span + alt_clip) > 0.0;  // classic.py:437
     if (skipped) {
         ref_seq = alt_seq = alt_clip = ref_span = alt_span = 0.0;
         gt = SVT_GT_SKIPPED;

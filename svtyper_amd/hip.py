@@ -12,19 +12,19 @@ from typing import Optional
 
 import numpy as np
 
-from .evidence import CEvidenceBatch, EvidenceBatch, Results
+from .evidence import GT_BLANK, CEvidenceBatch, EvidenceBatch, Results
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SVTYPER_HIP_LIB") or os.path.join(_HERE, "csrc", "libsvtyper_hip.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 EXPORTS = (
     "svt_version", "svt_device_count", "svt_last_error", "svt_batch_create", "svt_batch_create_from_fragments",
     "svt_batch_genotype",
     "svt_batch_genotype_n", "svt_batch_genotype_timed", "svt_batch_results", "svt_batch_device_results",
     "svt_batch_bind_device_results", "svt_batch_bytes", "svt_batch_layout", "svt_batch_site_qual",
-    "svt_batch_stream", "svt_batch_destroy", "svt_trim", "svt_bayes_gt", "svt_genotype",
-    "svt_format_results", "svt_format_free",
+    "svt_batch_stream", "svt_batch_destroy", "svt_trim", "svt_bayes_gt", "svt_genotype_counts", "svt_genotype",
+    "svt_format_results", "svt_format_free", "svt_results_host_sq",
 )
 
 _lib: Optional[C.CDLL] = None
@@ -92,6 +92,10 @@ def load() -> C.CDLL:
     L.svt_trim.restype = None
     L.svt_bayes_gt.restype = C.c_int
     L.svt_bayes_gt.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int]
+    L.svt_results_host_sq.restype = C.c_int
+    L.svt_results_host_sq.argtypes = [C.c_void_p, C.c_uint64]
+    L.svt_genotype_counts.restype = C.c_int
+    L.svt_genotype_counts.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_double, C.c_double, C.c_void_p, C.c_int]
     L.svt_genotype.restype = C.c_int
     L.svt_genotype.argtypes = [C.POINTER(CEvidenceBatch), C.c_void_p, C.c_int, C.c_uint]
     if L.svt_version() != ABI_VERSION:
@@ -228,11 +232,31 @@ class DeviceBatch:
         self.close()
 
 
+def host_sq(results: Results) -> Results:
+    """svt_results_host_sq: SQ of every called unit recomputed in place from the bit-exact GL with the host libm
+    (the reference's own arithmetic, classic.py:473-481), so formatted SQ / QUAL are byte-identical."""
+    _check(load().svt_results_host_sq(C.c_void_p(results.ptr()), results.n_units))
+    return results
+
+
+def site_qual_host(results: Results, n_samples: int, initial=None):
+    """QUAL of every site (classic.py:216-217,485,498) from the result records on the host: the running binary64
+    sum of SQ over the site's samples in order, reset by a blank sample.  Units site-major."""
+    import numpy as np
+    n_sites = results.n_units // max(1, int(n_samples))
+    q = np.zeros(n_sites) if initial is None else np.array(initial, dtype=np.float64, copy=True)
+    rec = results.rec[: n_sites * n_samples].reshape(n_sites, n_samples)
+    for k in range(n_samples):
+        gt = rec["gt"][:, k]
+        q = np.where(gt >= 0, q + rec["sq"][:, k], np.where(gt == GT_BLANK, 0.0, q))
+    return q
+
+
 def _finish(d: "DeviceBatch", site_qual) -> Results:
     d.genotype(sync=True)
-    res = d.results()
-    if site_qual is not None:      # (n_samples, initial QUAL per site or None): classic.py:485,498 on the device
-        res.site_qual = d.site_qual(site_qual[0], site_qual[1])
+    res = host_sq(d.results())
+    if site_qual is not None:      # (n_samples, initial QUAL per site or None): classic.py:485,498 over the refined SQ
+        res.site_qual = site_qual_host(res, site_qual[0], site_qual[1])
     return res
 
 
@@ -288,4 +312,18 @@ def bayes_gt_array(ref, alt, is_dup, device: int = 0):
         raise ValueError("ref and alt must have the same shape")
     out = np.zeros((r.size, 4), np.float64)
     _check(L.svt_bayes_gt(r.ctypes.data, a.ctypes.data, d.ctypes.data, r.size, out.ctypes.data, int(device)))
+    return out
+
+
+def genotype_counts(counts, is_dup, split_weight: float = 1.0, disc_weight: float = 1.0, device: int = 0) -> Results:
+    """svt_genotype_counts: the array form of the reference's bayesian_genotype(breakpoint, counts, ...)
+    (svtyper/singlesample.py:406-473).  `counts`: float64 [n, 5] = (ref_seq, alt_seq, alt_clip, ref_span, alt_span)
+    as tally_variant_read_fragments returned them; `is_dup`: [n].  No zeroing rule, no blank result."""
+    import numpy as np
+    L = load()
+    c = np.ascontiguousarray(counts, dtype=np.float64).reshape(-1, 5)
+    d = np.ascontiguousarray(np.broadcast_to(np.asarray(is_dup, dtype=np.uint8), (c.shape[0],)))
+    out = Results.empty(c.shape[0])
+    _check(L.svt_genotype_counts(c.ctypes.data, d.ctypes.data, c.shape[0], float(split_weight), float(disc_weight),
+                                 C.c_void_p(out.ptr()), int(device)))
     return out

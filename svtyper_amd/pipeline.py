@@ -45,11 +45,13 @@ class HipEngine:
     supports_site_qual = True   # QUAL over a site's samples (classic.py:485,498) can stay on the device
 
     def __call__(self, batch: EvidenceBatch, flags: int = 0, site_qual=None) -> Results:
-        return self._hip.genotype_batch(batch, device=self.device, flags=flags, site_qual=site_qual)
+        res = self._hip.genotype_batch(batch, device=self.device, flags=flags, site_qual=site_qual)
+        return res if site_qual is not None else self._hip.host_sq(res)   # SQ as the reference's libm gives it from GL
 
     def genotype_fragments(self, fbatch, flags: int = 0, site_qual=None) -> Results:
         """geometry="device": fragment summaries in, both stages on the GPU."""
-        return self._hip.genotype_fragments(fbatch, device=self.device, flags=flags, site_qual=site_qual)
+        res = self._hip.genotype_fragments(fbatch, device=self.device, flags=flags, site_qual=site_qual)
+        return res if site_qual is not None else self._hip.host_sq(res)
 
 
 def _site_qual_kw(engine, n_samples: int, site_quals) -> dict:

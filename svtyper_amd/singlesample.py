@@ -58,6 +58,67 @@ def gather_reads(sample: Sample, bp: dict, max_reads):
     return fragments, False
 
 
+# ------------------------------------------------------------------------------------------
+# the reference's inner operator seams, by name: same arguments, same dict shapes,
+# the arithmetic on the MI355X through the C ABI (no CPU implementation lives here)
+# ------------------------------------------------------------------------------------------
+SPLIT_SLOP = 3   # singlesample.py:792 / classic.py:184
+_TALLY_KEYS = ("ref_seq", "alt_seq", "alt_clip", "ref_span", "alt_span")   # SVT_TAL_* order
+
+
+def blank_genotype_result():
+    """svtyper/singlesample.py:207-227"""
+    from .results import blank_result
+    return blank_result()
+
+
+def _library_table(lib):
+    if hasattr(lib, "table"):
+        return lib.table()
+    return ev.LibraryTable.from_counter(dict(lib.hist), float(lib.mean), float(lib.sd), getattr(lib, "name", "lib"))
+
+
+def tally_variant_read_fragments(split_slop, min_aligned, breakpoint, sam_fragments, debug, *, device=0):
+    """svtyper/singlesample.py:355-404: the five evidence tallies of one breakpoint over its read-fragments
+    (sorted by query name, fragment-local split-read sums, zeroing rules applied) as the reference's `counts`
+    dict.  The fragments' yes/no geometry is asked here (packer.py), every weight, the insert-size test, the
+    sums and the zeroing rules are evaluated by the streaming kernel (svt_genotype, SVT_FLAG_SSO_ASSOCIATION)."""
+    from . import hip
+    from .packer import BatchBuilder, pack_fragments, unit_header
+    libs, lib_index = [], {}
+    for name in sorted(sam_fragments.keys()):
+        lib = sam_fragments[name].lib
+        if id(lib) not in lib_index:
+            lib_index[id(lib)] = len(libs)
+            libs.append(_library_table(lib))
+    if not libs:     # no fragments: the reference's loop body never runs and the initial integer zeros come back
+        counts = {k: 0 for k in _TALLY_KEYS}
+    else:
+        builder = BatchBuilder(libs, 1.0, 1.0)
+        builder.add(unit_header(breakpoint), pack_fragments(sam_fragments, breakpoint, lib_index, min_aligned, split_slop))
+        res = hip.genotype_batch(builder.build(), device=device, flags=ev.FLAG_SSO_ASSOCIATION)
+        counts = {k: float(res.tallies[0, i]) for i, k in enumerate(_TALLY_KEYS)}
+    if debug:
+        items = ("ref_span", "alt_span", "ref_seq", "alt_seq", "alt_clip")
+        logit("{} -- read fragment tally counts:\n{}".format(
+            breakpoint["id"], "\n".join("{}: {}".format(i, counts[i]) for i in items)))
+    return counts
+
+
+def bayesian_genotype(breakpoint, counts, split_weight, disc_weight, debug, *, device=0):
+    """svtyper/singlesample.py:406-473: `counts` (as tally_variant_read_fragments returned them) -> the
+    reference's result dict {'qual', 'formats': {GT, GQ, SQ, GL, DP, AO, RO, AS, ASC, RS, AP, RP, QR, QA, AB}}.
+    QR/QA, bayes_gt, the GT/GQ decision and the counts come from svt_genotype_counts (device); SQ is then taken
+    from the bit-exact GL with the host libm, as the reference does (svt_results_host_sq)."""
+    from . import hip
+    from .results import result_from_record
+    res = hip.host_sq(hip.genotype_counts([[counts[k] for k in _TALLY_KEYS]], [breakpoint["svtype"] == "DUP"],
+                                          split_weight, disc_weight, device))
+    if debug:
+        logit("{} -- log probabilities (homref, het, homalt) : {}".format(breakpoint["id"], [float(x) for x in res.gl[0]]))
+    return result_from_record(res.rec[0])
+
+
 def assign_genotype(variant: Variant, sample_name: str, res: dict) -> None:
     """singlesample.py:544-575: every FORMAT field is always written; QUAL accumulates."""
     variant.qual += res["qual"]
