@@ -398,6 +398,22 @@ int svt_genotype_counts(const double* counts, const uint8_t* is_dup, uint64_t n,
 int svt_genotype(const svt_evidence_batch* in, svt_result* out, int device,
                  unsigned flags);
 
+/* ---- several GPUs of one node from ONE process (no torch, no MPI) -------------------------------------
+ * The multi-device form of svt_genotype: the replacement for the multiprocessing.Pool of
+ * svtyper/singlesample.py:723-751 (`svtyper-sso --cores N`) for a C caller.  The units are cut into
+ * n_devices contiguous shards balanced by the bytes a unit costs (16 F + 112) and cut only at multiples of
+ * `group` units (group = samples per site keeps all samples of a site on one GPU, so QUAL over a site's
+ * samples stays local; 0 / 1 = any unit boundary); one host thread per entry of devices[] runs its shard
+ * (upload, ONE pass of the hot path, download) and the result records land in out[] in unit order -- the
+ * concatenation is the "gather".  The same device may be listed more than once.  Units are independent, so
+ * out[] is byte-identical to what svt_genotype writes for the whole batch on one device.                  */
+int svt_genotype_multi(const svt_evidence_batch* in, svt_result* out, const int* devices, int n_devices,
+                       uint32_t group, unsigned flags);
+
+/* The shard rule of svt_genotype_multi (and of svtyper_amd/distributed.py: shard_bounds, which ranks of a
+ * torch.distributed job use): bounds[0 .. n_shards], shard r = units [bounds[r], bounds[r + 1]).          */
+int svt_shard_bounds(const uint64_t* rec_offset, uint64_t n_units, int n_shards, uint32_t group, uint64_t* bounds);
+
 #ifdef __cplusplus
 }
 #endif

@@ -104,8 +104,8 @@ struct DevicePool {
 };
 inline DevicePool g_pool;
 
-// Pinned staging ring shared by all batches of the process (allocated on first use, per device
-// context of the first caller; pinned host memory is usable from every device).
+// Pinned staging rings, one per device (allocated on first use): the callers of one device take turns on its
+// ring, callers of different devices (svt_genotype_multi: one host thread per GPU) copy concurrently.
 struct StagingRing {
     static constexpr uint64_t kPiece = 64ull << 20;
     static constexpr int kSlots = 3;
@@ -119,7 +119,15 @@ struct StagingRing {
         return SVT_OK;
     }
 };
-inline StagingRing g_ring;
+inline StagingRing g_rings[CsrScratchCache::kMaxDevices];
+
+// the ring of the calling thread's current device (every entry point has called hipSetDevice)
+inline StagingRing& current_ring()
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= CsrScratchCache::kMaxDevices) dev = 0;
+    return g_rings[dev];
+}
 
 // Host -> device copies of pageable memory through the pinned ring: a few host threads fill one piece
 // while the previous piece is on the wire (pinned pieces move at ~56 GB/s; a first hipMemcpy of
@@ -132,7 +140,7 @@ constexpr uint64_t kDirectCopyMax = 256u << 10;   // below this the runtime's ow
 
 class Stager {
 public:
-    explicit Stager(hipStream_t stream) : stream_(stream), guard_(g_ring.lock) {}
+    explicit Stager(hipStream_t stream) : stream_(stream), ring_(current_ring()), guard_(ring_.lock) {}
     Stager(const Stager&) = delete;
     Stager& operator=(const Stager&) = delete;
     ~Stager()
@@ -148,7 +156,7 @@ public:
             HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream_));
             return SVT_OK;
         }
-        SVT_TRY(g_ring.ensure());
+        SVT_TRY(ring_.ensure());
         for (int i = 0; i < StagingRing::kSlots; ++i)
             if (!done_[i] && hipEventCreateWithFlags(&done_[i], hipEventDisableTiming) != hipSuccess)
                 return fail(SVT_ERR_HIP, "hipEventCreate");
@@ -157,7 +165,7 @@ public:
             const uint64_t len = std::min(StagingRing::kPiece, bytes - off);
             if (hipEventSynchronize(done_[slot_]) != hipSuccess) return fail(SVT_ERR_HIP, "staging event");
             const char* s0 = static_cast<const char*>(src) + off;
-            char* p0 = static_cast<char*>(g_ring.buf[slot_]);
+            char* p0 = static_cast<char*>(ring_.buf[slot_]);
             if (len < (4u << 20)) std::memcpy(p0, s0, len);
             else {
                 const uint64_t part = ((len + nt - 1) / nt + 4095) & ~uint64_t(4095);
@@ -181,6 +189,7 @@ public:
 
 private:
     hipStream_t stream_;
+    StagingRing& ring_;
     std::lock_guard<std::mutex> guard_;
     hipEvent_t done_[StagingRing::kSlots] = {nullptr, nullptr, nullptr};
     int slot_ = 0;
@@ -201,8 +210,9 @@ inline int d2h_staged(void* dst, const void* src, uint64_t bytes, hipStream_t st
         HIP_TRY(hipStreamSynchronize(stream));
         return SVT_OK;
     }
-    std::lock_guard<std::mutex> guard(g_ring.lock);
-    SVT_TRY(g_ring.ensure());
+    StagingRing& ring = current_ring();
+    std::lock_guard<std::mutex> guard(ring.lock);
+    SVT_TRY(ring.ensure());
     const unsigned nt = std::min(host_threads(), 6u);
     // piece k is copied out of its slot while piece k + 1 is on the wire
     uint64_t off = 0, prev_off = 0, prev_len = 0;
@@ -211,10 +221,10 @@ inline int d2h_staged(void* dst, const void* src, uint64_t bytes, hipStream_t st
         uint64_t len = 0;
         if (off < bytes) {
             len = std::min(StagingRing::kPiece, bytes - off);
-            HIP_TRY(hipMemcpyAsync(g_ring.buf[slot], static_cast<const char*>(src) + off, len, hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipMemcpyAsync(ring.buf[slot], static_cast<const char*>(src) + off, len, hipMemcpyDeviceToHost, stream));
         }
         if (prev_slot >= 0) {
-            const char* p0 = static_cast<const char*>(g_ring.buf[prev_slot]);
+            const char* p0 = static_cast<const char*>(ring.buf[prev_slot]);
             char* d0 = static_cast<char*>(dst) + prev_off;
             const uint64_t part = ((prev_len + nt - 1) / nt + 4095) & ~uint64_t(4095);
             parallel_for(nt, [&](uint64_t t) {

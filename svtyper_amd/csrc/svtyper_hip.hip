@@ -1119,4 +1119,77 @@ int svt_genotype(const svt_evidence_batch* in, svt_result* out, int device, unsi
     return guarded([&] { return svt_genotype_impl(in, out, device, flags); });
 }
 
+// contiguous shards balanced by the bytes a unit costs (16 F + 112), cut only at multiples of `group` units
+// (svtyper_amd/distributed.py: shard_bounds is the same rule, and tests/test_multi_device.py checks they agree)
+static int svt_shard_bounds_impl(const uint64_t* rec_offset, uint64_t n_units, int n_shards, uint32_t group, uint64_t* bounds)
+{
+    if (!bounds || n_shards <= 0 || (n_units && !rec_offset)) return fail(SVT_ERR_INVALID, "bad arguments");
+    if (group == 0) group = 1;
+    bounds[0] = 0;
+    const double total = n_units ? (double)(rec_offset[n_units] - rec_offset[0]) * 16.0 + 112.0 * (double)n_units : 0.0;
+    for (int r = 1; r < n_shards; ++r) {
+        const double target = total * (double)r / (double)n_shards;
+        // first k with cost(units [0, k)) >= target
+        uint64_t lo = 0, hi = n_units;
+        while (lo < hi) {
+            const uint64_t mid = lo + (hi - lo) / 2;
+            const double c = (double)(rec_offset[mid] - rec_offset[0]) * 16.0 + 112.0 * (double)mid;
+            if (c < target) lo = mid + 1; else hi = mid;
+        }
+        uint64_t k = lo / group * group;
+        k = std::min<uint64_t>(n_units, std::max<uint64_t>(bounds[r - 1], k));
+        bounds[r] = k;
+    }
+    bounds[n_shards] = n_units;
+    return SVT_OK;
+}
+
+int svt_shard_bounds(const uint64_t* rec_offset, uint64_t n_units, int n_shards, uint32_t group, uint64_t* bounds)
+{
+    return guarded([&] { return svt_shard_bounds_impl(rec_offset, n_units, n_shards, group, bounds); });
+}
+
+static int svt_genotype_multi_impl(const svt_evidence_batch* in, svt_result* out, const int* devices, int n_devices,
+                                   uint32_t group, unsigned flags)
+{
+    if (!in || !devices || n_devices <= 0 || n_devices > 64) return fail(SVT_ERR_INVALID, "bad device list");
+    const uint64_t n = in->n_units;
+    if (n && (!out || !in->rec_offset || !in->units)) return fail(SVT_ERR_INVALID, "null argument");
+    const int ndev = svt_device_count();
+    if (ndev <= 0) return fail(SVT_ERR_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
+    for (int d = 0; d < n_devices; ++d)
+        if (devices[d] < 0 || devices[d] >= ndev) return fail(SVT_ERR_NO_DEVICE, "device index out of range");
+    for (uint64_t u = 0; u < n; ++u)
+        if (in->rec_offset[u + 1] < in->rec_offset[u]) return fail(SVT_ERR_INVALID, "rec_offset not monotone");
+    std::vector<uint64_t> bounds((size_t)n_devices + 1);
+    SVT_TRY(svt_shard_bounds_impl(in->rec_offset, n, n_devices, group, bounds.data()));
+    std::vector<int> rc((size_t)n_devices, SVT_OK);
+    std::vector<std::string> msg((size_t)n_devices);
+    // one host thread per device: upload of its shard, ONE pass, download -- the threads only share the
+    // caller's read-only arrays and write disjoint ranges of out[]
+    run_threads((unsigned)n_devices, [&](unsigned t) {
+        const uint64_t lo = bounds[t], hi = bounds[t + 1];
+        if (lo == hi) return;
+        std::vector<uint64_t> off(hi - lo + 1);
+        const uint64_t r0 = in->rec_offset[lo];
+        for (uint64_t u = lo; u <= hi; ++u) off[u - lo] = in->rec_offset[u] - r0;
+        svt_evidence_batch shard = *in;
+        shard.n_units = hi - lo;
+        shard.rec_offset = off.data();
+        shard.units = in->units + lo;
+        shard.records = in->records ? in->records + r0 : nullptr;
+        rc[t] = svt_genotype(&shard, out + lo, devices[t], flags);
+        if (rc[t] != SVT_OK) msg[t] = g_err;     // (g_err is thread-local: hand the text to the calling thread)
+    });
+    for (int d = 0; d < n_devices; ++d)
+        if (rc[d] != SVT_OK) return fail(rc[d], "device " + std::to_string(devices[d]) + ": " + msg[d]);
+    return SVT_OK;
+}
+
+int svt_genotype_multi(const svt_evidence_batch* in, svt_result* out, const int* devices, int n_devices, uint32_t group,
+                       unsigned flags)
+{
+    return guarded([&] { return svt_genotype_multi_impl(in, out, devices, n_devices, group, flags); });
+}
+
 }  // extern "C"

@@ -23,7 +23,7 @@ EXPORTS = (
     "svt_batch_genotype",
     "svt_batch_genotype_n", "svt_batch_genotype_timed", "svt_batch_results", "svt_batch_device_results",
     "svt_batch_bind_device_results", "svt_batch_bytes", "svt_batch_layout", "svt_batch_site_qual",
-    "svt_batch_stream", "svt_batch_destroy", "svt_trim", "svt_bayes_gt", "svt_genotype_counts", "svt_genotype",
+    "svt_batch_stream", "svt_batch_destroy", "svt_trim", "svt_bayes_gt", "svt_genotype_counts", "svt_genotype", "svt_genotype_multi", "svt_shard_bounds",
     "svt_format_results", "svt_format_free", "svt_results_host_sq",
 )
 
@@ -92,6 +92,10 @@ def load() -> C.CDLL:
     L.svt_trim.restype = None
     L.svt_bayes_gt.restype = C.c_int
     L.svt_bayes_gt.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int]
+    L.svt_genotype_multi.restype = C.c_int
+    L.svt_genotype_multi.argtypes = [C.POINTER(CEvidenceBatch), C.c_void_p, C.POINTER(C.c_int), C.c_int, C.c_uint32, C.c_uint]
+    L.svt_shard_bounds.restype = C.c_int
+    L.svt_shard_bounds.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_uint32, C.c_void_p]
     L.svt_results_host_sq.restype = C.c_int
     L.svt_results_host_sq.argtypes = [C.c_void_p, C.c_uint64]
     L.svt_genotype_counts.restype = C.c_int
@@ -327,3 +331,24 @@ def genotype_counts(counts, is_dup, split_weight: float = 1.0, disc_weight: floa
     _check(L.svt_genotype_counts(c.ctypes.data, d.ctypes.data, c.shape[0], float(split_weight), float(disc_weight),
                                  C.c_void_p(out.ptr()), int(device)))
     return out
+
+
+def genotype_multi(batch: EvidenceBatch, devices, group: int = 1, flags: int = 0) -> Results:
+    """svt_genotype_multi: `batch` sharded over the listed devices (one host thread per entry, a device may be
+    listed more than once), result records in unit order."""
+    L = load()
+    out = Results.empty(batch.n_units)
+    cb = batch.as_c()
+    devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+    _check(L.svt_genotype_multi(C.byref(cb), C.c_void_p(out.ptr()), devs, len(devices), int(group), int(flags)))
+    return out
+
+
+def shard_bounds(rec_offset, n_shards: int, group: int = 1):
+    """svt_shard_bounds: [(lo, hi)] unit ranges, one per shard (host only)."""
+    import numpy as np
+    L = load()
+    off = np.ascontiguousarray(rec_offset, dtype=np.uint64)
+    b = np.zeros(n_shards + 1, np.uint64)
+    _check(L.svt_shard_bounds(off.ctypes.data, max(0, off.shape[0] - 1), int(n_shards), int(group), b.ctypes.data))
+    return [(int(b[i]), int(b[i + 1])) for i in range(n_shards)]

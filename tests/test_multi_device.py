@@ -1,0 +1,117 @@
+"""Several GPUs from one process through the C ABI (svt_genotype_multi / svt_shard_bounds), and ranks of a
+torch.distributed job running the HIP path (shard -> HIP -> one gather).  On a one-GPU box the same device is listed
+several times / shared by the ranks: every line of the multi-device code runs, only the devices coincide."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_c_shard_bounds_equal_the_python_rule():
+    """host only: svt_shard_bounds == distributed.shard_bounds (the rule ranks use)"""
+    from svtyper_amd import distributed as D, hip
+    rng = np.random.default_rng(5)
+    for n in (0, 1, 7, 1000, 10_000):
+        F = rng.integers(0, 200, n)
+        off = np.concatenate([[0], np.cumsum(F)]).astype(np.uint64)
+        for world in (1, 2, 3, 8):
+            for group in (1, 4, 32):
+                assert hip.shard_bounds(off, world, group) == D.shard_bounds(off, world, group), (n, world, group)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sso", [0, 1])
+def test_genotype_multi_equals_one_device_and_the_oracle(hip_device, fixture_library, sso):
+    from oracle import c_oracle
+    from svtyper_amd import evidence as ev, hip, synth
+    batch = synth.make_units(20_011, 41, [fixture_library], svtype_mix=(0.6, 0.2, 0.1, 0.1), min_frags=0)
+    one = hip.genotype_batch(batch, device=hip_device, flags=sso)
+    n_dev = hip.device_count()
+    for devices in ([0], [0, 0], [d % n_dev for d in range(5)], list(range(n_dev)) * 2):
+        got = hip.genotype_multi(batch, devices, flags=sso)
+        assert got.rec.tobytes() == one.rec.tobytes(), devices
+    want = c_oracle.genotype_batch(batch, flags=sso)
+    assert np.array_equal(one.gt, want.gt) and np.array_equal(one.counts, want.counts)
+    assert np.array_equal(one.gl.view(np.uint64), want.gl.view(np.uint64))
+    # a site's samples stay together: shards are cut at multiples of `group`
+    ms = synth.make_multisample(60, 32, seed=9, mean_frags=30, sd_frags=10, min_frags=3, max_frags=70)
+    assert hip.genotype_multi(ms, [0, 0, 0], group=32).rec.tobytes() == hip.genotype_batch(ms).rec.tobytes()
+    assert all(lo % 32 == 0 for lo, _ in hip.shard_bounds(ms.rec_offset, 3, 32))
+    # more devices than units, empty batch
+    tiny = synth.make_units(2, 3, [fixture_library])
+    assert hip.genotype_multi(tiny, [0, 0, 0, 0]).rec.tobytes() == hip.genotype_batch(tiny).rec.tobytes()
+    assert hip.genotype_multi(synth.make_units(0, 3, [fixture_library]), [0, 0]).n_units == 0
+
+
+@pytest.mark.gpu
+def test_genotype_multi_reports_the_failing_device(hip_device, fixture_library):
+    from svtyper_amd import evidence as ev, hip, synth
+    b = synth.make_units(3000, 3, [fixture_library])
+    b.records["flags"][b.n_records - 5] |= 1 << 20          # an undefined flag bit in the last shard
+    with pytest.raises(hip.SvtyperHipError) as e:
+        hip.genotype_multi(b, [0, 0])
+    assert "reserved/undefined bits" in str(e.value) and "device 0" in str(e.value)
+    with pytest.raises(hip.SvtyperHipError):
+        hip.genotype_multi(b, [0, 99])
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _rank(rank, world, port, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+    from svtyper_amd import distributed as D, evidence as ev, hip, synth
+
+    n_dev = hip.device_count()
+    rccl = n_dev >= world                       # one GPU per rank: RCCL; otherwise the ranks share device 0 over gloo
+    device = rank if rccl else 0
+    torch.cuda.set_device(device)
+    dist.init_process_group("nccl" if rccl else "gloo", rank=rank, world_size=world,
+                            **({"device_id": torch.device("cuda", device)} if rccl else {}))
+    lib = synth.normal_library(n=50000)
+    batch = synth.make_units(30_001, 77, [lib], svtype_mix=(0.6, 0.2, 0.1, 0.1), mean_frags=40, sd_frags=20, min_frags=0)
+    bounds = D.shard_bounds(batch.rec_offset, world)
+    shard, (lo, hi) = D.local_shard(batch, rank, world)
+    with hip.DeviceBatch(shard, device=device) as d:
+        buf = torch.zeros(max(1, shard.n_units) * 128, dtype=torch.uint8, device="cuda")
+        d.bind_device_results(buf.data_ptr())        # the kernel writes straight into the tensor that is gathered
+        d.genotype(sync=True)
+        local = buf[: shard.n_units * 128] if rccl else buf[: shard.n_units * 128].cpu()
+        gathered = D.gather_result_records(local, [b[1] - b[0] for b in bounds], dst=0)
+    if rank == 0:
+        from oracle import c_oracle
+        got = D.results_from_bytes(gathered)
+        single = hip.genotype_batch(batch, device=device)
+        want = c_oracle.genotype_batch(batch)
+        ok = (got.rec.tobytes() == single.rec.tobytes() and np.array_equal(got.gt, want.gt)
+              and np.array_equal(got.counts, want.counts) and np.array_equal(got.gl.view(np.uint64), want.gl.view(np.uint64))
+              and float(np.max(np.abs(got.sq - want.sq))) <= 1e-6)
+        with open(out_path, "w") as f:
+            f.write("ok %s" % ("rccl" if rccl else "gloo") if ok else "mismatch")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_ranks_shard_hip_gather(hip_device, tmp_path):
+    """world 2: shard_bounds -> the HIP path on every rank -> ONE gather of the 128-byte records; byte-equal to the
+    single-rank result and parity-equal to the oracle (RCCL when two devices are visible, gloo on one)."""
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "result.txt")
+    mp.spawn(_rank, args=(2, _free_port(), out), nprocs=2, join=True)
+    assert open(out).read().startswith("ok")
