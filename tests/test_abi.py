@@ -70,3 +70,57 @@ def test_native_sample_column_text_equals_python_formatting():
                 else:
                     want = ":".join(cell(d["formats"][f]) if f in d["formats"] else "." for f in fields)
                 assert got[i] == want, (i, gt, fields, got[i], want)
+
+
+def test_struct_layouts_match_the_header(tmp_path):
+    """sizeof / offsetof of every struct of include/svtyper_hip.h, as a C compiler lays them out, against the numpy
+    dtypes and ctypes Structures the Python side hands to the library (and the INTEGRATION.md stub copies)."""
+    import subprocess
+    import numpy as np
+    from svtyper_amd import evidence as ev, geometry as geo
+    structs = {
+        "svt_record": ["ospan_len", "mapq_a", "mapq_b", "rs_a", "rs_b", "seq_l", "seq_r", "clip_l", "clip_r", "flags"],
+        "svt_unit": ["var_length", "pos_delta", "sample", "svtype", "flags", "reserved"],
+        "svt_library": ["hist", "key_min", "n_bins", "mean", "sd"],
+        "svt_evidence_batch": ["n_units", "rec_offset", "units", "records", "n_libs", "libs", "split_weight", "disc_weight"],
+        "svt_read_summary": ["tid", "start", "end", "iv_start", "iv_end", "mapq", "flags", "reserved"],
+        "svt_piece_summary": ["tid", "start", "end", "mapq", "flags", "reserved"],
+        "svt_fragment": ["read", "seq", "clip"],
+        "svt_breakpoint": ["tid_a", "pos_a", "ci_a", "tid_b", "pos_b", "ci_b", "var_length", "sample", "svtype", "flags", "reserved"],
+        "svt_fragment_batch": ["n_units", "frag_offset", "breakpoints", "fragments", "n_libs", "libs", "split_weight",
+                               "disc_weight", "min_aligned", "split_slop"],
+        "svt_result": ["gl", "sq", "tallies", "counts", "gt", "pad"],
+    }
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "svtyper_hip.h"', 'int main(void) {']
+    for name, fields in structs.items():
+        lines.append('printf("%s %%zu\\n", sizeof(%s));' % (name, name))
+        for f in fields:
+            lines.append('printf("%s.%s %%zu\\n", offsetof(%s, %s));' % (name, f, name, f))
+    lines += ['printf("SVT_ABI_VERSION %d\\n", SVT_ABI_VERSION);', 'return 0; }']
+    src = tmp_path / "probe.c"
+    src.write_text("\n".join(lines))
+    exe = str(tmp_path / "probe")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", exe])
+    c = dict(l.split() for l in subprocess.check_output([exe], text=True).splitlines())
+    c = {k: int(v) for k, v in c.items()}
+
+    from svtyper_amd import hip
+    assert c["SVT_ABI_VERSION"] == hip.ABI_VERSION
+    dtypes = {"svt_record": ev.RECORD_DTYPE, "svt_unit": ev.UNIT_DTYPE, "svt_result": ev.RESULT_DTYPE,
+              "svt_read_summary": geo.READ_DTYPE, "svt_piece_summary": geo.PIECE_DTYPE, "svt_fragment": geo.FRAGMENT_DTYPE,
+              "svt_breakpoint": geo.BREAKPOINT_DTYPE}
+    for name, dt in dtypes.items():
+        assert dt.itemsize == c[name], (name, dt.itemsize, c[name])
+        assert list(dt.names) == structs[name], (name, dt.names)
+        for f in dt.names:
+            assert dt.fields[f][1] == c["%s.%s" % (name, f)], (name, f, dt.fields[f][1], c["%s.%s" % (name, f)])
+    assert c["svt_record"] == 16 and c["svt_unit"] == 16 and c["svt_result"] == 128 and c["svt_fragment"] == 128
+    ctys = {"svt_library": ev.CLibrary, "svt_evidence_batch": ev.CEvidenceBatch, "svt_fragment_batch": geo.CFragmentBatch}
+    for name, ct in ctys.items():
+        assert ctypes.sizeof(ct) == c[name], (name, ctypes.sizeof(ct), c[name])
+        assert [f[0] for f in ct._fields_] == structs[name], name
+        for f in structs[name]:
+            assert getattr(ct, f).offset == c["%s.%s" % (name, f)], (name, f)
+    # the enumerations the result record is indexed with
+    assert list(ev.COUNT_NAMES) == ["QR", "QA", "GQ", "DP", "RO", "AO", "RS", "AS", "ASC", "RP", "AP"]
+    assert list(ev.TALLY_NAMES) == ["ref_seq", "alt_seq", "alt_clip", "ref_span", "alt_span"]
