@@ -46,6 +46,8 @@ extern "C" {
 #define SVT_ERR_NOMEM (-4)
 #define SVT_ERR_STATE (-5)     /* results requested before genotype, ...      */
 #define SVT_ERR_INTERNAL (-6)  /* an unexpected failure inside the library     */
+#define SVT_ERR_UNSUPPORTED (-7) /* svt_pack_evidence: the batch cannot be expressed as packed evidence
+                                    (use the canonical records)                 */
 
 /* ---- SV types (classic.py:228 accepts exactly these four) ----------------- */
 #define SVT_SVTYPE_DEL 0
@@ -322,7 +324,8 @@ int svt_batch_bind_device_results(svt_batch* b, svt_result* dev_ptr);
 int svt_batch_bytes(const svt_batch* b, uint64_t* algorithmic, uint64_t* resident);
 
 /* Which device layout / kernel flavour the batch got: *compact = 0 for the dense tiles, 1 for the
- * compact entry streams with 4-byte pair entries, 2 for the short pair entries, 3 for the streamed CSR; *table_mode = 0 one library, tables in LDS; 1 several libraries,
+ * compact entry streams with 4-byte pair entries, 2 for the short pair entries, 3 for the streamed CSR, 4 for
+ * streamed packed evidence; *table_mode = 0 one library, tables in LDS; 1 several libraries,
  * per-workgroup library windows in LDS; 2 general geometry, tables read through L2.          */
 int svt_batch_layout(const svt_batch* b, int* compact, int* table_mode);
 
@@ -397,6 +400,55 @@ int svt_genotype_counts(const double* counts, const uint8_t* is_dup, uint64_t n,
 /* Convenience: create + genotype + results + destroy.                          */
 int svt_genotype(const svt_evidence_batch* in, svt_result* out, int device,
                  unsigned flags);
+
+/* ---- packed evidence: what a host producer emits when the bytes have to cross PCIe -------------------------
+ * The canonical record spends 16 bytes on a fragment whose evidence is mostly "two MAPQ-60 reads and an insert
+ * size".  Packed evidence is the same information as three sparse streams of small entries per unit, in 16-byte
+ * slots, unit after unit in caller order:
+ *   stream 0  pair entries (-> alt_span, ref_span): straddle bits + ospan_len translated into the index space of
+ *             the library's histogram table; ONE half-word when the two MAPQs are the batch's most common pair
+ *             (`common_mapq`; 60, 60 for bwa), two half-words otherwise; eight half-words per slot;
+ *   stream 1  reference-read entries (-> ref_seq): the two gated MAPQs rs_a, rs_b; seven per slot + 7 first-of-
+ *             fragment bits;
+ *   stream 2  split / clip candidate entries (-> alt_seq / alt_clip): seq_l, seq_r or clip_l, clip_r; seven per
+ *             slot + first-of-fragment and is-clip bits
+ * (bit layouts: svtyper_amd/csrc/svt_prepare_kernels.h).  Entries that could only add +0.0 -- no straddle bit, a
+ * zero MAPQ, a DEL below the small-deletion gate of classic.py:339,383, all-zero weight pairs -- are not stored;
+ * the order inside every stream is the record order, so every tally receives the reference's additions in the
+ * reference's order and the results are bit-identical to those of the canonical records.  About 3.2 bytes per
+ * fragment record on BASELINE.json's workloads instead of 16.
+ * Limits: one library of at most 2047 histogram bins, DEL lengths >= 0, |var_length| <= 2^30, |key_min| <= 2^29,
+ * mean + 3 sd of the library not within 4e-6 of an integer (svt_pack_evidence returns SVT_ERR_UNSUPPORTED
+ * otherwise and the caller keeps the canonical records).                                                     */
+typedef struct svt_packed_evidence {
+    uint64_t n_units;
+    uint64_t n_slots;            /* 16-byte slots of all units                                              */
+    uint64_t n_records;          /* fragment records the slots were packed from (svt_batch_bytes)           */
+    const uint32_t* slot_offset; /* 3 * n_units + 1 entries: stream k of unit u = slots [slot_offset[3u + k],
+                                    slot_offset[3u + k + 1]); slot_offset[0] == 0                           */
+    const svt_unit* units;       /* n_units                                                                 */
+    const void* slots;           /* n_slots * 16 bytes                                                      */
+    uint32_t common_mapq;        /* mapq_a | mapq_b << 8 of the one-half-word pair entries                  */
+    uint32_t n_libs;             /* 1                                                                       */
+    const svt_library* libs;
+    double split_weight;
+    double disc_weight;
+} svt_packed_evidence;
+
+/* Encode a batch of canonical records (host only, multi-threaded; the record contract is checked here, so the
+ * pass over packed evidence does not check it again).  The slots are placed in page-locked host memory when a
+ * device is present, so svt_batch_create_packed can DMA them without a staging copy.  A producer that never
+ * materialises canonical records (the host packer, svtyper_amd/packer.py; a reader) calls this per chunk of
+ * units it has just produced -- or writes the slots itself.  Release with svt_packed_free.                    */
+int svt_pack_evidence(const svt_evidence_batch* in, svt_packed_evidence** out);
+void svt_packed_free(svt_packed_evidence* p);
+
+/* svt_batch_create for packed evidence (flags: SVT_FLAG_SSO_ASSOCIATION only): upload + tables; the pass
+ * (svt_batch_genotype) is one launch of svt_packed_kernel over the slots as they were uploaded.               */
+int svt_batch_create_packed(const svt_packed_evidence* in, int device, unsigned flags, svt_batch** out);
+
+/* create_packed + genotype + results + destroy.                                                              */
+int svt_genotype_packed(const svt_packed_evidence* in, svt_result* out, int device, unsigned flags);
 
 /* ---- several GPUs of one node from ONE process (no torch, no MPI) -------------------------------------
  * The multi-device form of svt_genotype: the replacement for the multiprocessing.Pool of

@@ -45,7 +45,8 @@ enum Layout : int {
     kLayoutDense = 0,    // canonical 16-byte records
     kLayoutCompact = 1,  // three entry streams, 4-byte pair entries
     kLayoutShort = 2,    // three entry streams, 2-byte pair entries for the batch's most common MAPQ pair
-    kLayoutStream = 3    // the caller's CSR as it is, streamed through per-wave LDS rings (svt_stream_kernel.h)
+    kLayoutStream = 3,   // the caller's CSR as it is, streamed through per-wave LDS rings (svt_stream_kernel.h)
+    kLayoutPacked = 4    // packed evidence (svt_packed_evidence) as uploaded, streamed the same way (svt_packed_kernel.h)
 };
 struct TileDesc {         // 32 B, stored in dispatch (longest-first) order
     uint64_t base;

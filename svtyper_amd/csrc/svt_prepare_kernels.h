@@ -57,7 +57,7 @@ struct UnitGeom {
     double pos_delta_d;
 };
 
-__device__ __forceinline__ UnitGeom unit_geom(const svt_unit& U)
+__host__ __device__ __forceinline__ UnitGeom unit_geom(const svt_unit& U)
 {
     UnitGeom g;
     g.is_del = U.svtype == SVT_SVTYPE_DEL;
@@ -66,7 +66,7 @@ __device__ __forceinline__ UnitGeom unit_geom(const svt_unit& U)
     return g;
 }
 
-__device__ __forceinline__ bool keeps_pair_entry(const uint4 w, const UnitGeom& g, const LibDesc& lib)
+__host__ __device__ __forceinline__ bool keeps_pair_entry(const uint4 w, const UnitGeom& g, const LibDesc& lib)
 {
     if ((w.w & 7u) == 0u) return false;
     if ((w.y & 0xffu) == 0u || (w.y & 0xff00u) == 0u) return false;      // prob_mapq(0) == 0.0
@@ -74,7 +74,7 @@ __device__ __forceinline__ bool keeps_pair_entry(const uint4 w, const UnitGeom& 
     return true;
 }
 
-__device__ __forceinline__ uint32_t pair_code(const uint32_t ospan_len, const UnitGeom& g, const LibDesc& lib)
+__host__ __device__ __forceinline__ uint32_t pair_code(const uint32_t ospan_len, const UnitGeom& g, const LibDesc& lib)
 {
     const int64_t nb = lib.n_bins;
     const int64_t r = (int64_t)(int32_t)ospan_len - (int64_t)lib.key_min;
@@ -89,7 +89,7 @@ __device__ __forceinline__ uint32_t pair_code(const uint32_t ospan_len, const Un
 
 // the gated MAPQ pairs (lo byte, hi byte) of a canonical record that feed ref_seq / alt_seq / alt_clip;
 // 0 = nothing to add
-__device__ __forceinline__ void weight_pairs(const uint4 w, uint32_t k[3])
+__host__ __device__ __forceinline__ void weight_pairs(const uint4 w, uint32_t k[3])
 {
     k[0] = w.y >> 16;            // rs_a | rs_b << 8
     k[1] = w.z & 0xffffu;        // seq_l | seq_r << 8
@@ -222,7 +222,8 @@ struct WeightRowWriter {
     uint4* out;       // row 0 of this lane
     uint32_t n = 0;   // entries so far
     uint32_t w[4] = {0u, 0u, 0u, 0u};
-    __device__ __forceinline__ void put(const uint32_t mapq_pair, const bool first, const bool clip = false)
+    uint32_t stride = kWave;   // slots between consecutive rows of this lane (1: the host packer's unit-major slots)
+    __host__ __device__ __forceinline__ void put(const uint32_t mapq_pair, const bool first, const bool clip = false)
     {
         const uint32_t k = n % 7u;
         const uint32_t half = mapq_pair << ((k & 1u) * 16u);
@@ -235,16 +236,16 @@ struct WeightRowWriter {
         if (first) w[3] |= 1u << (16u + k);
         if (clip) w[3] |= 1u << (24u + k);
         if (k == 6u) {
-            out[(uint64_t)(n / 7u) * kWave] = make_uint4(w[0], w[1], w[2], w[3]);
+            out[(uint64_t)(n / 7u) * stride] = make_uint4(w[0], w[1], w[2], w[3]);
             w[0] = w[1] = w[2] = w[3] = 0u;
         }
         ++n;
     }
-    __device__ __forceinline__ void finish(const uint32_t rows)
+    __host__ __device__ __forceinline__ void finish(const uint32_t rows)
     {
         uint32_t r = n / 7u;
-        if (n % 7u) out[(uint64_t)r++ * kWave] = make_uint4(w[0], w[1], w[2], w[3]);
-        for (; r < rows; ++r) out[(uint64_t)r * kWave] = make_uint4(0, 0, 0, 0);
+        if (n % 7u) out[(uint64_t)r++ * stride] = make_uint4(w[0], w[1], w[2], w[3]);
+        for (; r < rows; ++r) out[(uint64_t)r * stride] = make_uint4(0, 0, 0, 0);
     }
 };
 
@@ -280,7 +281,8 @@ struct ShortRowWriter {
     uint4* out;       // row 0 of this lane
     uint32_t n = 0;   // half-words so far
     uint32_t w[4] = {0u, 0u, 0u, 0u};
-    __device__ __forceinline__ void put_half(const uint32_t hw)
+    uint32_t stride = kWave;
+    __host__ __device__ __forceinline__ void put_half(const uint32_t hw)
     {
         const uint32_t k = n & 7u;
         const uint32_t v = hw << ((k & 1u) * 16u);
@@ -291,12 +293,12 @@ struct ShortRowWriter {
         default: w[3] |= v;
         }
         if (k == 7u) {
-            out[(uint64_t)(n >> 3) * kWave] = make_uint4(w[0], w[1], w[2], w[3]);
+            out[(uint64_t)(n >> 3) * stride] = make_uint4(w[0], w[1], w[2], w[3]);
             w[0] = w[1] = w[2] = w[3] = 0u;
         }
         ++n;
     }
-    __device__ __forceinline__ void put(const uint32_t lo16, const uint32_t mq, const uint32_t common)
+    __host__ __device__ __forceinline__ void put(const uint32_t lo16, const uint32_t mq, const uint32_t common)
     {
         if (mq == common) {
             put_half(lo16);
@@ -306,11 +308,11 @@ struct ShortRowWriter {
             put_half(mq);
         }
     }
-    __device__ __forceinline__ void finish(const uint32_t rows)
+    __host__ __device__ __forceinline__ void finish(const uint32_t rows)
     {
         uint32_t r = n >> 3;
-        if (n & 7u) out[(uint64_t)r++ * kWave] = make_uint4(w[0], w[1], w[2], w[3]);
-        for (; r < rows; ++r) out[(uint64_t)r * kWave] = make_uint4(0, 0, 0, 0);
+        if (n & 7u) out[(uint64_t)r++ * stride] = make_uint4(w[0], w[1], w[2], w[3]);
+        for (; r < rows; ++r) out[(uint64_t)r * stride] = make_uint4(0, 0, 0, 0);
     }
 };
 

@@ -1,0 +1,182 @@
+// svt_ring_engine.h -- per-wave LDS ring fed by LDS-DMA: the machinery that lets ONE lane own a unit whose
+// 16-byte items (evidence records, or the slots of packed evidence) lie contiguously in HBM, in caller order.
+// Internal header of libsvtyper_hip.so (single translation unit: svtyper_hip.hip).
+//
+//   * a workgroup owns 256 * R consecutive units; wg_sort_into_tiles counting-sorts them by their number of
+//     128-byte blocks (LDS atomics + one scan) so that the 64 lanes of a wave run units of similar length, and
+//     hands the sorted 64-unit tiles to the four waves in snake order;
+//   * fetch_block: per step a wave fetches, for each of its 64 units, the next 128-byte block (8 items) of that
+//     unit with eight global_load_lds_dwordx4 -- each instruction serves eight units with eight lanes per unit, so
+//     it moves eight whole cache lines and nothing passes through VGPRs.  A lane only asks for an item of its
+//     unit: the neighbours' items in a unit's first and last line, and every block past the end of a shorter
+//     unit, are not requested at all;
+//   * the block of unit u lands at ring + u * 128 with its eight 16-byte slots XOR-swizzled by (u >> 1) & 7:
+//     read_block then takes the lane's eight items with ds_read_b128 and the 16 lanes the LDS serves per cycle
+//     hit 16 different bank quads (conflict-free, MI355X_MICROARCH LDS table);
+//   * one 8 KB stage per wave: a block leaves the stage for VGPRs in one burst, the fetch of block k + 1 is
+//     issued right behind it and lands while block k is being consumed.
+#ifndef SVT_RING_ENGINE_H
+#define SVT_RING_ENGINE_H
+
+#include "svt_genotype_kernel.h"
+
+namespace svt {
+
+constexpr uint32_t kBlockRecords = 8;                         // records per 128-byte block
+constexpr uint32_t kStageBytes = kWave * 128;                 // one block per lane
+constexpr uint32_t kRingBytes = kStageBytes;                  // per wave: one stage
+constexpr uint32_t kMaxSortKey = 255;                         // units with more blocks share the last sort bucket
+// where the epilogue finds the log10 table of log_choose
+enum L10Place : uint32_t {
+    kL10Shared = 0,   // staged once per workgroup beside the other tables (fits with 3 workgroups per CU)
+    kL10Ring = 1,     // copied into the wave's idle ring before each epilogue
+    kL10Global = 2    // read through L2 (units with thousands of records)
+};
+
+// error bits (shared with svt_scan_kernel)
+constexpr uint32_t kErrStraddleNoPair = 2u, kErrLibIndex = 4u, kErrReservedBits = 8u, kErrNegativeSpan = 16u;
+
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+
+// The eight records of this lane's block, once the LDS-DMA group that filled the ring has landed (it is the
+// only vector-memory work the wave has in flight).  The compiler cannot see that these reads depend on the
+// LDS-DMA writes, hence the explicit counters; when this returns the ring is free for the next block.
+__device__ __forceinline__ void read_block(const uint32_t lane_block, const uint32_t sw16, u32x4 (&w)[8])
+{
+    // logical record j of the lane's block sits in slot j ^ swz: lane_block + ((j << 4) ^ sw16)
+    uint32_t addr[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) addr[j] = lane_block + (((uint32_t)j << 4) ^ sw16);
+    asm volatile("s_waitcnt vmcnt(0)\n\t"
+                 "ds_read_b128 %0, %8\n\t"
+                 "ds_read_b128 %1, %9\n\t"
+                 "ds_read_b128 %2, %10\n\t"
+                 "ds_read_b128 %3, %11\n\t"
+                 "ds_read_b128 %4, %12\n\t"
+                 "ds_read_b128 %5, %13\n\t"
+                 "ds_read_b128 %6, %14\n\t"
+                 "ds_read_b128 %7, %15\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3]), "=&v"(w[4]), "=&v"(w[5]), "=&v"(w[6]), "=&v"(w[7])
+                 : "v"(addr[0]), "v"(addr[1]), "v"(addr[2]), "v"(addr[3]), "v"(addr[4]), "v"(addr[5]), "v"(addr[6]), "v"(addr[7])
+                 : "memory");
+}
+
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, const uint32_t lane)
+{
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+        const uint32_t t = (uint32_t)__shfl_up((int)v, d, kWave);
+        if (lane >= (uint32_t)d) v += t;
+    }
+    return v;
+}
+
+// Block k of every unit of the tile -> ring.  Lane (o, rr) of instruction i serves unit 8 i + o and only asks for
+// a record of that unit: the neighbours' records in a unit's first and last line, and every block past the end
+// of a shorter unit, are not requested at all (the consumer never looks at those slots).
+template <int AUX>
+__device__ __forceinline__ void fetch_block(const uint32_t k, const uint32_t (&src_first)[8], const uint32_t (&src_end)[8],
+                                            const uint32_t col_even, const uint32_t col_odd, const char* __restrict__ rec_bytes,
+                                            unsigned char* ring)
+{
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const uint32_t rec = (src_first[i] & ~7u) + k * kBlockRecords + (((i & 1) ? col_odd : col_even) >> 4);
+        if (rec >= src_first[i] && rec < src_end[i])
+            __builtin_amdgcn_global_load_lds(rec_bytes + ((uint64_t)rec << 4), (lds_void_ptr)(ring + (uint32_t)i * 1024u), 16, 0, AUX);
+    }
+}
+
+// The workgroup's 256 * R units -> R tiles per wave, longest units first.  beg / cnt: first item and item count of
+// the thread's R units (unit wg_base + j * 256 + tid).  info[r] = {first item, items, local unit or kPadUnit, 0} of
+// this lane's unit in the wave's r-th tile.  The sort scratch lives in the rings: call before any streaming;
+// the rings are free again when this returns (it ends with a barrier, which also covers the caller's table staging).
+template <int R>
+__device__ __forceinline__ void wg_sort_into_tiles(unsigned char* rings, const uint32_t (&beg)[R], const uint32_t (&cnt)[R],
+                                                   const uint64_t wg_base, const uint64_t n_units, const uint32_t tid,
+                                                   const uint32_t lane, const uint32_t wave, uint4 (&info)[R])
+{
+    uint32_t* s_hist = reinterpret_cast<uint32_t*>(rings);      // kMaxSortKey + 1 buckets
+    uint32_t* s_start = s_hist + (kMaxSortKey + 1);
+    uint32_t* s_wsum = s_start + (kMaxSortKey + 1);              // kWavesPerBlock
+    uint4* s_info = reinterpret_cast<uint4*>(s_wsum + 8);        // per sorted position
+    uint32_t key[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        const uint32_t nblk = cnt[j] ? ((beg[j] & 7u) + cnt[j] + 7u) >> 3 : 0u;
+        key[j] = min(nblk, kMaxSortKey);
+    }
+    for (uint32_t i = tid; i <= kMaxSortKey; i += kBlock) s_hist[i] = 0u;
+    __syncthreads();
+    uint32_t rank[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) rank[j] = atomicAdd(&s_hist[key[j]], 1u);
+    __syncthreads();
+    {
+        // thread t owns bucket kMaxSortKey - t (kBlock == kMaxSortKey + 1): an exclusive scan over t is the
+        // first sorted position of every bucket in descending key order
+        static_assert(kBlock == (int)kMaxSortKey + 1, "one sort bucket per thread");
+        const uint32_t h = s_hist[kMaxSortKey - tid];
+        const uint32_t incl = wave_inclusive_scan(h, lane);
+        if (lane == kWave - 1) s_wsum[wave] = incl;
+        __syncthreads();
+        uint32_t before = 0;
+#pragma unroll
+        for (int w = 0; w < kWavesPerBlock; ++w) before += (uint32_t)w < wave ? s_wsum[w] : 0u;
+        s_start[kMaxSortKey - tid] = before + incl - h;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        const uint64_t u = wg_base + (uint32_t)j * kBlock + tid;
+        s_info[s_start[key[j]] + rank[j]] = make_uint4(beg[j], cnt[j], u < n_units ? (uint32_t)j * kBlock + tid : kPadUnit, 0u);
+    }
+    __syncthreads();
+    // the r-th tile of this wave in snake order
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const uint32_t tile = (uint32_t)r * kWavesPerBlock + ((r & 1) ? (uint32_t)kWavesPerBlock - 1u - wave : wave);
+        info[r] = s_info[tile * kWave + lane];
+    }
+    __syncthreads();   // the rings are free from here on
+}
+
+// the block count of the longest and of the shortest unit of a sorted tile (wave-uniform)
+__device__ __forceinline__ void tile_block_range(const uint32_t nblk, uint32_t& max_blk, uint32_t& min_blk)
+{
+    // sorted longest first: the tile's first lane has the most blocks -- unless it sits in the last sort bucket,
+    // which holds every longer unit in arrival order
+    max_blk = (uint32_t)__builtin_amdgcn_readfirstlane((int)nblk);
+    if (max_blk >= kMaxSortKey) {
+        uint32_t m = nblk;
+#pragma unroll
+        for (int d = 1; d < kWave; d <<= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d, kWave));
+        max_blk = (uint32_t)__builtin_amdgcn_readfirstlane((int)m);
+    }
+    uint32_t m = nblk;
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) m = min(m, (uint32_t)__shfl_xor((int)m, d, kWave));
+    min_blk = (uint32_t)__builtin_amdgcn_readfirstlane((int)m);
+}
+
+// result records of a tile: lane-major into the ring, unit-major out of it, one full 128-byte line per eight lanes
+__device__ __forceinline__ void store_results_through_ring(unsigned char* ring, const uint4 (&piece)[8], const uint32_t unit,
+                                                           const uint32_t lane, svt_result* __restrict__ out)
+{
+    const uint32_t o = lane >> 3, rr = lane & 7u, sw = (lane >> 1) & 7u;
+    const uint32_t col_even = (rr ^ (o >> 1)) << 4, col_odd = col_even ^ 64u;
+    uint4* st = reinterpret_cast<uint4*>(ring + lane * 128u);
+#pragma unroll
+    for (int p = 0; p < 8; ++p) st[(uint32_t)p ^ sw] = piece[p];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const uint32_t dst_unit = (uint32_t)__shfl((int)unit, 8 * i + (int)o, kWave);
+        const uint4 v = *reinterpret_cast<const uint4*>(ring + (uint32_t)i * 1024u + o * 128u + ((i & 1) ? col_odd : col_even));
+        if (dst_unit != kPadUnit) reinterpret_cast<uint4*>(out + dst_unit)[rr] = v;
+    }
+}
+
+}  // namespace svt
+
+#endif  // SVT_RING_ENGINE_H

@@ -55,13 +55,10 @@
 
 #include <type_traits>
 
-#include "svt_genotype_kernel.h"
+#include "svt_ring_engine.h"
 
 namespace svt {
 
-constexpr uint32_t kBlockRecords = 8;                         // records per 128-byte block
-constexpr uint32_t kStageBytes = kWave * 128;                 // one block per lane
-constexpr uint32_t kRingBytes = kStageBytes;                  // per wave: one stage
 // LDS layout of the streaming kernel, absolute byte addresses (the kernel has no static LDS, so the dynamic
 // segment starts at 0 -- checked at run time): the one-library record consumer turns every field of a record
 // into an LDS address with one instruction and the table base as the ds_read's immediate offset.
@@ -70,17 +67,6 @@ constexpr uint32_t kSPmHalf = kSPm + 256 * 8;         // double[256]  prob_mapq(
 constexpr uint32_t kSWtab = kSPmHalf + 256 * 8;       // kSingleLds: double w_alt[32], w_ref[32] (columns); kGeneral: PairWeights[32]
 constexpr uint32_t kSWref = 32 * 8;                   // byte distance w_alt[i] -> w_ref[i]
 constexpr uint32_t kSBins = kSWtab + 2 * 32 * 8;      // kSingleLds: int32 thr[total_bins], uint32 hist[total_bins]; kGeneral: LibDesc[n_libs]
-constexpr uint32_t kMaxSortKey = 255;                         // units with more blocks share the last sort bucket
-
-// where the epilogue finds the log10 table of log_choose
-enum L10Place : uint32_t {
-    kL10Shared = 0,   // staged once per workgroup beside the other tables (fits with 3 workgroups per CU)
-    kL10Ring = 1,     // copied into the wave's idle ring before each epilogue
-    kL10Global = 2    // read through L2 (units with thousands of records)
-};
-
-// error bits (shared with svt_scan_kernel)
-constexpr uint32_t kErrStraddleNoPair = 2u, kErrLibIndex = 4u, kErrReservedBits = 8u, kErrNegativeSpan = 16u;
 
 struct StreamArgs {
     const uint4* records;        // canonical records; the allocation ends on a 128-byte block boundary, tail zeroed
@@ -106,42 +92,6 @@ struct StreamArgs {
     LibDesc lib0;
     GtConsts c;
 };
-
-typedef __attribute__((address_space(3))) void* lds_void_ptr;
-
-// The eight records of this lane's block, once the LDS-DMA group that filled the ring has landed (it is the
-// only vector-memory work the wave has in flight).  The compiler cannot see that these reads depend on the
-// LDS-DMA writes, hence the explicit counters; when this returns the ring is free for the next block.
-__device__ __forceinline__ void read_block(const uint32_t lane_block, const uint32_t sw16, u32x4 (&w)[8])
-{
-    // logical record j of the lane's block sits in slot j ^ swz: lane_block + ((j << 4) ^ sw16)
-    uint32_t addr[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) addr[j] = lane_block + (((uint32_t)j << 4) ^ sw16);
-    asm volatile("s_waitcnt vmcnt(0)\n\t"
-                 "ds_read_b128 %0, %8\n\t"
-                 "ds_read_b128 %1, %9\n\t"
-                 "ds_read_b128 %2, %10\n\t"
-                 "ds_read_b128 %3, %11\n\t"
-                 "ds_read_b128 %4, %12\n\t"
-                 "ds_read_b128 %5, %13\n\t"
-                 "ds_read_b128 %6, %14\n\t"
-                 "ds_read_b128 %7, %15\n\t"
-                 "s_waitcnt lgkmcnt(0)"
-                 : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3]), "=&v"(w[4]), "=&v"(w[5]), "=&v"(w[6]), "=&v"(w[7])
-                 : "v"(addr[0]), "v"(addr[1]), "v"(addr[2]), "v"(addr[3]), "v"(addr[4]), "v"(addr[5]), "v"(addr[6]), "v"(addr[7])
-                 : "memory");
-}
-
-__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, const uint32_t lane)
-{
-#pragma unroll
-    for (int d = 1; d < kWave; d <<= 1) {
-        const uint32_t t = (uint32_t)__shfl_up((int)v, d, kWave);
-        if (lane >= (uint32_t)d) v += t;
-    }
-    return v;
-}
 
 // The record contract of include/svtyper_hip.h, accumulated over the records of a lane's units at 3-4
 // instructions per record.
@@ -211,46 +161,23 @@ __device__ __forceinline__ void record_single(const u32x4 w, const bool mine, co
     a.ref_span += pp * lds_f64(wa + kSWref);
 }
 
-// Block k of every unit of the tile -> ring.  Lane (o, rr) of instruction i serves unit 8 i + o and only asks for
-// a record of that unit: the neighbours' records in a unit's first and last line, and every block past the end
-// of a shorter unit, are not requested at all (the consumer never looks at those slots).
-template <int AUX>
-__device__ __forceinline__ void fetch_block(const uint32_t k, const uint32_t (&src_first)[8], const uint32_t (&src_end)[8],
-                                            const uint32_t col_even, const uint32_t col_odd, const char* __restrict__ rec_bytes,
-                                            unsigned char* ring)
-{
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const uint32_t rec = (src_first[i] & ~7u) + k * kBlockRecords + (((i & 1) ? col_odd : col_even) >> 4);
-        if (rec >= src_first[i] && rec < src_end[i])
-            __builtin_amdgcn_global_load_lds(rec_bytes + ((uint64_t)rec << 4), (lds_void_ptr)(ring + (uint32_t)i * 1024u), 16, 0, AUX);
-    }
-}
-
 template <bool SSO, int MODE, int R>
 __global__ __launch_bounds__(kBlock, MODE == kSingleLds ? SVT_STREAM_WAVES : 2) void svt_stream_kernel(const StreamArgs a)
 {
     static_assert(MODE == kSingleLds || MODE == kGeneral, "library windows are not used by the streaming kernel");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // (lds_rings is 128-byte aligned)
     constexpr uint32_t kUnitsPerWg = kBlock * R;
-    constexpr uint32_t kTilesPerWg = kWavesPerBlock * R;
     double* s_pm = reinterpret_cast<double*>(smem + kSPm);
     PairWeights* s_wtab = reinterpret_cast<PairWeights*>(smem + kSWtab);   // kGeneral
     LibDesc* s_lib = reinterpret_cast<LibDesc*>(smem + kSBins);            // kGeneral
     // the one-library consumer addresses the tables by absolute LDS byte offsets
     if (MODE == kSingleLds && (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)smem != 0u) __builtin_trap();
     unsigned char* rings = smem + a.lds_rings;
-    // sort scratch: lives in the rings until the streaming starts
-    uint32_t* s_hist = reinterpret_cast<uint32_t*>(rings);      // kMaxSortKey + 1 buckets
-    uint32_t* s_start = s_hist + (kMaxSortKey + 1);
-    uint32_t* s_wsum = s_start + (kMaxSortKey + 1);              // kWavesPerBlock
-    uint4* s_info = reinterpret_cast<uint4*>(s_wsum + 8);        // per sorted position: {first record, records, local unit, -}
-
     const uint32_t tid = threadIdx.x, wave = tid / kWave, lane = tid % kWave;
     const uint64_t wg_base = (uint64_t)blockIdx.x * kUnitsPerWg;
 
     // ---- this thread's R units: record range and sort key (the loads overlap the table staging below)
-    uint32_t beg[R], cnt[R], key[R];
+    uint32_t beg[R], cnt[R];
 #pragma unroll
     for (int j = 0; j < R; ++j) {
         const uint64_t u = wg_base + (uint32_t)j * kBlock + tid;
@@ -261,8 +188,6 @@ __global__ __launch_bounds__(kBlock, MODE == kSingleLds ? SVT_STREAM_WAVES : 2) 
             beg[j] = (uint32_t)lo;
             cnt[j] = (uint32_t)(hi - lo);
         }
-        const uint32_t nblk = cnt[j] ? ((beg[j] & 7u) + cnt[j] + 7u) >> 3 : 0u;
-        key[j] = min(nblk, kMaxSortKey);
     }
 
     // ---- stage the tables in LDS
@@ -297,43 +222,9 @@ __global__ __launch_bounds__(kBlock, MODE == kSingleLds ? SVT_STREAM_WAVES : 2) 
         double* s_l10 = reinterpret_cast<double*>(smem + a.lds_l10);
         for (uint32_t i = tid; i < a.n_l10; i += kBlock) s_l10[i] = a.l10[i];
     }
-    for (uint32_t i = tid; i <= kMaxSortKey; i += kBlock) s_hist[i] = 0u;
-    __syncthreads();
-
-    // ---- counting sort of the workgroup's units by block count, longest first
-    uint32_t rank[R];
-#pragma unroll
-    for (int j = 0; j < R; ++j) rank[j] = atomicAdd(&s_hist[key[j]], 1u);
-    __syncthreads();
-    {
-        // thread t owns bucket kMaxSortKey - t (kBlock == kMaxSortKey + 1): an exclusive scan over t is the
-        // first sorted position of every bucket in descending key order
-        static_assert(kBlock == (int)kMaxSortKey + 1, "one sort bucket per thread");
-        const uint32_t h = s_hist[kMaxSortKey - tid];
-        const uint32_t incl = wave_inclusive_scan(h, lane);
-        if (lane == kWave - 1) s_wsum[wave] = incl;
-        __syncthreads();
-        uint32_t before = 0;
-#pragma unroll
-        for (int w = 0; w < kWavesPerBlock; ++w) before += (uint32_t)w < wave ? s_wsum[w] : 0u;
-        s_start[kMaxSortKey - tid] = before + incl - h;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < R; ++j) {
-        const uint64_t u = wg_base + (uint32_t)j * kBlock + tid;
-        s_info[s_start[key[j]] + rank[j]] = make_uint4(beg[j], cnt[j], u < a.n_units ? (uint32_t)j * kBlock + tid : kPadUnit, 0u);
-    }
-    __syncthreads();
-    // the r-th tile of this wave in snake order
+    // ---- counting sort of the workgroup's units by block count, longest first; R tiles per wave
     uint4 info[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const uint32_t tile = (uint32_t)r * kWavesPerBlock + ((r & 1) ? (uint32_t)kWavesPerBlock - 1u - wave : wave);
-        info[r] = s_info[tile * kWave + lane];
-    }
-    static_assert(kTilesPerWg * kWave == kUnitsPerWg, "tiles cover the workgroup's units");
-    __syncthreads();   // the rings are free from here on
+    wg_sort_into_tiles<R>(rings, beg, cnt, wg_base, a.n_units, tid, lane, wave, info);
 
     Tables t;   // kGeneral: tables through ordinary pointers, bins through L2
     t.pm = s_pm;
@@ -367,19 +258,8 @@ __global__ __launch_bounds__(kBlock, MODE == kSingleLds ? SVT_STREAM_WAVES : 2) 
         if (unit != kPadUnit) U = a.units[unit];
         const uint32_t head = first_rec & 7u, last = head + n_rec;
         const uint32_t nblk = n_rec ? (last + 7u) >> 3 : 0u;
-        // sorted longest first: the tile's first lane has the most blocks -- unless it sits in the last sort
-        // bucket, which holds every longer unit in arrival order
-        uint32_t max_blk = (uint32_t)__builtin_amdgcn_readfirstlane((int)nblk);
-        if (max_blk >= kMaxSortKey) {
-            uint32_t m = nblk;
-#pragma unroll
-            for (int d = 1; d < kWave; d <<= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d, kWave));
-            max_blk = (uint32_t)__builtin_amdgcn_readfirstlane((int)m);
-        }
-        uint32_t min_blk = nblk;    // the first block some lane of the tile ends in
-#pragma unroll
-        for (int d = 1; d < kWave; d <<= 1) min_blk = min(min_blk, (uint32_t)__shfl_xor((int)min_blk, d, kWave));
-        min_blk = (uint32_t)__builtin_amdgcn_readfirstlane((int)min_blk);
+        uint32_t max_blk, min_blk;
+        tile_block_range(nblk, max_blk, min_blk);
         // fetch side: lane (o, rr) of instruction i serves unit 8 i + o -- it needs that unit's record range
         uint32_t src_first[8], src_end[8];
 #pragma unroll
@@ -470,16 +350,7 @@ __global__ __launch_bounds__(kBlock, MODE == kSingleLds ? SVT_STREAM_WAVES : 2) 
         uint4 piece[8];
         unit_epilogue(acc, (uint32_t)U.svtype, (uint32_t)U.flags, a.c, lds_l10, a.l10, a.l10_where != kL10Global, piece);
 
-        // ---- result records: lane-major into the ring, unit-major out of it, one full line per eight lanes
-        uint4* st = reinterpret_cast<uint4*>(ring + lane * 128u);
-#pragma unroll
-        for (int p = 0; p < 8; ++p) st[(uint32_t)p ^ sw] = piece[p];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const uint32_t dst_unit = (uint32_t)__shfl((int)unit, 8 * i + (int)o, kWave);
-            const uint4 v = *reinterpret_cast<const uint4*>(ring + (uint32_t)i * 1024u + o * 128u + ((i & 1) ? col_odd : col_even));
-            if (dst_unit != kPadUnit) reinterpret_cast<uint4*>(a.out + dst_unit)[rr] = v;
-        }
+        store_results_through_ring(ring, piece, unit, lane, a.out);
     }
     const uint32_t bad = check.bits(a.n_libs);
     if (bad) atomicOr(a.err, bad);

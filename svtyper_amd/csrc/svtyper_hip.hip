@@ -42,6 +42,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -73,6 +74,7 @@
 #include "svt_genotype_kernel.h"
 #include "svt_prepare_kernels.h"
 #include "svt_stream_kernel.h"
+#include "svt_packed_kernel.h"
 #include "svt_geometry_kernel.h"
 #include "svt_bayes_kernel.h"
 #include "svt_host_tables.h"
@@ -123,6 +125,10 @@ struct svt_batch {
     uint64_t cap_records = 0, cap_off = 0, cap_units = 0;
     uint32_t* d_err = nullptr;
     StreamArgs sargs{};
+    // kLayoutPacked: packed evidence as uploaded (svt_packed_kernel.h); d_records holds the slots, d_soff the 3n+1 offsets
+    uint32_t* d_soff = nullptr;
+    uint64_t cap_soff = 0, n_slots = 0;
+    PackedArgs pargs{};
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
 
@@ -139,6 +145,7 @@ void free_batch(svt_batch* b)
     g_pool.put(b->device, b->d_records, b->cap_records);
     g_pool.put(b->device, b->d_off, b->cap_off);
     g_pool.put(b->device, b->d_units, b->cap_units);
+    g_pool.put(b->device, b->d_soff, b->cap_soff);
     F(b->d_err);
     F(b->d_tiles); F(b->d_pm); F(b->d_l10); F(b->d_libs);
     F(b->d_bins); F(b->d_wtab); F(b->d_wg);
@@ -209,6 +216,15 @@ const void* stream_kernel_of(const svt_batch* b)
 
 int launch_genotype(svt_batch* b)
 {
+    if (b->layout == kLayoutPacked) {
+        if (b->n_units == 0) return SVT_OK;
+        const dim3 grid((unsigned)((b->n_units + kBlock - 1) / kBlock)), block(kBlock);
+        void* params[] = {&b->pargs};
+        const void* k = (b->flags & SVT_FLAG_SSO_ASSOCIATION) ? reinterpret_cast<const void*>(&svt_packed_kernel<true, 1>)
+                                                             : reinterpret_cast<const void*>(&svt_packed_kernel<false, 1>);
+        HIP_TRY(hipLaunchKernel(k, grid, block, params, b->lds_bytes, b->stream));
+        return SVT_OK;
+    }
     if (b->layout == kLayoutStream) {
         if (b->n_units == 0) return SVT_OK;
         constexpr uint64_t per_wg = (uint64_t)kBlock * SVT_STREAM_R;
@@ -392,6 +408,332 @@ int create_stream(const svt_evidence_batch* in, svt_batch* b, void* d_records_re
     if (b->lds_bytes > 160 * 1024) return fail(SVT_ERR_INVALID, "LDS budget exceeded");
     if (b->lds_bytes > 64 * 1024)
         HIP_TRY(hipFuncSetAttribute(stream_kernel_of(b), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_bytes));
+    return SVT_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// packed evidence (include/svtyper_hip.h: svt_packed_evidence)
+// ------------------------------------------------------------------------------------------
+// Page-locked host buffers for the slots of packed evidence: hipHostMalloc of hundreds of MB costs tens of ms, so
+// svt_packed_free hands the buffer back here (svt_trim releases them).  Without a device plain memory is used.
+struct PinnedPool {
+    struct Item { void* p; uint64_t cap; bool pinned; };
+    std::mutex lock;
+    std::vector<Item> idle, live;
+    void* get(uint64_t bytes)
+    {
+        bytes = std::max<uint64_t>(bytes, 4096);
+        std::lock_guard<std::mutex> g(lock);
+        size_t best = idle.size();
+        for (size_t i = 0; i < idle.size(); ++i)
+            if (idle[i].cap >= bytes && idle[i].cap <= 2 * bytes + (1u << 20) && (best == idle.size() || idle[i].cap < idle[best].cap)) best = i;
+        Item it{};
+        if (best != idle.size()) {
+            it = idle[best];
+            idle.erase(idle.begin() + (long)best);
+        } else {
+            it.cap = bytes + bytes / 8;
+            int ndev = 0;
+            if (hipGetDeviceCount(&ndev) == hipSuccess && ndev > 0 && hipHostMalloc(&it.p, it.cap, hipHostMallocDefault) == hipSuccess) it.pinned = true;
+            else {
+                (void)hipGetLastError();
+                it.p = std::malloc(it.cap);
+                it.pinned = false;
+            }
+            if (!it.p) return nullptr;
+        }
+        live.push_back(it);
+        return it.p;
+    }
+    bool is_pinned(const void* p)
+    {
+        std::lock_guard<std::mutex> g(lock);
+        for (const Item& it : live)
+            if (it.p == p) return it.pinned;
+        return false;
+    }
+    void put(void* p)
+    {
+        if (!p) return;
+        std::lock_guard<std::mutex> g(lock);
+        for (size_t i = 0; i < live.size(); ++i)
+            if (live[i].p == p) {
+                idle.push_back(live[i]);
+                live.erase(live.begin() + (long)i);
+                break;
+            }
+        while (idle.size() > 4) {   // keep the largest
+            size_t smallest = 0;
+            for (size_t i = 1; i < idle.size(); ++i)
+                if (idle[i].cap < idle[smallest].cap) smallest = i;
+            release(idle[smallest]);
+            idle.erase(idle.begin() + (long)smallest);
+        }
+    }
+    static void release(const Item& it)
+    {
+        if (it.pinned) (void)hipHostFree(it.p);
+        else std::free(it.p);
+    }
+    void trim()
+    {
+        std::lock_guard<std::mutex> g(lock);
+        for (const Item& it : idle) release(it);
+        idle.clear();
+    }
+};
+PinnedPool g_pinned;
+
+struct PackedOwner {             // what svt_pack_evidence returns: the public struct first, the storage behind it
+    svt_packed_evidence pub{};
+    std::vector<uint32_t> off;
+    std::vector<svt_unit> units;
+    std::vector<uint32_t> hist;
+    svt_library lib{};
+    void* slots = nullptr;
+};
+
+// can this batch be written as packed evidence?  (the limits of the short entry format, include/svtyper_hip.h)
+int packable(const svt_evidence_batch* in, const HostTables& T)
+{
+    if (in->n_libs != 1) return fail(SVT_ERR_UNSUPPORTED, "packed evidence holds one library");
+    if (T.libs[0].n_bins > kMaxShortBins) return fail(SVT_ERR_UNSUPPORTED, "histogram too wide for the packed pair entries");
+    if (!T.fast_geometry) return fail(SVT_ERR_UNSUPPORTED, "library geometry outside the packed format's range");
+    for (uint64_t u = 0; u < in->n_units; ++u) {
+        const svt_unit& U = in->units[u];
+        if (U.var_length < -(1 << 30) || U.var_length > (1 << 30)) return fail(SVT_ERR_UNSUPPORTED, "var_length outside the packed format's range");
+        if (U.svtype == SVT_SVTYPE_DEL && U.var_length < 0) return fail(SVT_ERR_UNSUPPORTED, "negative DEL length");
+    }
+    return SVT_OK;
+}
+
+int pack_evidence(const svt_evidence_batch* in, svt_packed_evidence** out)
+{
+    if (!in || !out) return fail(SVT_ERR_INVALID, "null argument");
+    *out = nullptr;
+    const uint64_t n = in->n_units;
+    if (n >= 0x55555550ull) return fail(SVT_ERR_INVALID, "too many units in one batch");
+    if (in->n_libs == 0 || in->n_libs > 256 || !in->libs) return fail(SVT_ERR_INVALID, "n_libs must be 1..256");
+    if (n && (!in->rec_offset || !in->units)) return fail(SVT_ERR_INVALID, "null unit arrays");
+    if (n && in->rec_offset[0] != 0) return fail(SVT_ERR_INVALID, "rec_offset[0] must be 0");
+    const uint64_t n_rec = n ? in->rec_offset[n] : 0;
+    if (n_rec && !in->records) return fail(SVT_ERR_INVALID, "null records");
+    if (!(in->split_weight >= 0.0) || !(in->disc_weight >= 0.0) || !std::isfinite(in->split_weight) || !std::isfinite(in->disc_weight))
+        return fail(SVT_ERR_INVALID, "weights must be finite and >= 0");
+    for (uint64_t u = 0; u < n; ++u) {
+        if (in->rec_offset[u + 1] < in->rec_offset[u]) return fail(SVT_ERR_INVALID, "rec_offset not monotone");
+        if (in->rec_offset[u + 1] - in->rec_offset[u] > 0x3FFFFFFFull) return fail(SVT_ERR_INVALID, "unit with too many records");
+        const svt_unit& U = in->units[u];
+        if (U.svtype > SVT_SVTYPE_BND) return fail(SVT_ERR_INVALID, "bad svtype");
+        if (U.reserved != 0 || (U.flags & ~SVT_UNIT_SKIP)) return fail(SVT_ERR_INVALID, "unit reserved/flags bits must be 0");
+    }
+    HostTables T;
+    SVT_TRY(build_tables(in, 0, T));
+    SVT_TRY(packable(in, T));
+    const LibDesc lib = T.libs[0];
+    const uint4* recs = reinterpret_cast<const uint4*>(in->records);
+
+    // the batch's most common (mapq_a, mapq_b) among the first records that keep a pair entry: any answer is
+    // correct, a good one makes the pair stream shorter
+    uint32_t common = kDefaultCommonMapq;
+    {
+        std::vector<uint32_t> votes(65536, 0u);
+        const uint64_t n_vote = std::min<uint64_t>(n_rec, kVoteRecords);
+        for (uint64_t i = 0; i < n_vote; ++i) {
+            const uint4 w = recs[i];
+            if ((w.w & 7u) && (w.y & 0xffu) && (w.y & 0xff00u)) ++votes[w.y & 0xffffu];
+        }
+        uint32_t best = 0;
+        for (uint32_t k = 0; k < 65536u; ++k)
+            if (votes[k] > best) { best = votes[k]; common = k; }
+    }
+
+    auto owner = std::make_unique<PackedOwner>();
+    owner->off.assign(3 * n + 1, 0u);
+    std::vector<uint32_t>& off = owner->off;
+    // ---- pass 1: contract check + slots per stream and unit
+    const uint64_t kChunk = 2048;
+    const uint64_t n_chunks = (n + kChunk - 1) / kChunk;
+    std::vector<uint32_t> bad_bits(std::max<uint64_t>(n_chunks, 1), 0u);
+    parallel_for(n_chunks, [&](uint64_t ch) {
+        uint32_t bad = 0;
+        for (uint64_t u = ch * kChunk; u < std::min(n, (ch + 1) * kChunk); ++u) {
+            const UnitGeom g = unit_geom(in->units[u]);
+            uint32_t n_short = 0, n_ref = 0, n_cand = 0;
+            for (uint64_t j = in->rec_offset[u]; j < in->rec_offset[u + 1]; ++j) {
+                const uint4 w = recs[j];
+                const uint32_t f = w.w;
+                if (!(f & SVT_REC_HAS_PAIR) && (f & 7u)) bad |= kErrStraddleNoPair;
+                if (SVT_REC_LIB(f) != 0u) bad |= kErrLibIndex;
+                if (f & ~SVT_REC_FLAG_MASK) bad |= kErrReservedBits;
+                if ((int32_t)w.x < 0) bad |= kErrNegativeSpan;
+                if (keeps_pair_entry(w, g, lib)) n_short += (w.y & 0xffffu) == common ? 1u : (n_short & 1u) + 2u;
+                uint32_t k[3];
+                weight_pairs(w, k);
+                n_ref += k[0] ? 1u : 0u;
+                n_cand += (k[1] ? 1u : 0u) + (k[2] ? 1u : 0u);
+            }
+            off[3 * u + 1] = (n_short + kHalfwordsPerRow - 1) / kHalfwordsPerRow;
+            off[3 * u + 2] = (n_ref + 6) / 7;
+            off[3 * u + 3] = (n_cand + 6) / 7;
+        }
+        bad_bits[ch] = bad;
+    });
+    uint32_t bad = 0;
+    for (uint32_t b : bad_bits) bad |= b;
+    if (bad) return record_error(bad);
+    uint64_t total = 0;
+    for (uint64_t i = 1; i <= 3 * n; ++i) {
+        total += off[i];
+        if (total >= 0xFFFFFFF0ull) return fail(SVT_ERR_UNSUPPORTED, "too many slots for 32-bit slot offsets");
+        off[i] = (uint32_t)total;
+    }
+    owner->slots = g_pinned.get(std::max<uint64_t>(total, 1) * 16);
+    if (!owner->slots) return fail(SVT_ERR_NOMEM, "out of host memory");
+    uint4* slots = static_cast<uint4*>(owner->slots);
+    // ---- pass 2: the three streams of every unit, in record order (the encoders of svt_prepare_kernels.h)
+    parallel_for(n_chunks, [&](uint64_t ch) {
+        for (uint64_t u = ch * kChunk; u < std::min(n, (ch + 1) * kChunk); ++u) {
+            const UnitGeom g = unit_geom(in->units[u]);
+            ShortRowWriter S{slots + off[3 * u]};
+            WeightRowWriter R{slots + off[3 * u + 1]}, X{slots + off[3 * u + 2]};
+            S.stride = R.stride = X.stride = 1u;
+            bool frag_has[3] = {false, false, false};
+            for (uint64_t j = in->rec_offset[u]; j < in->rec_offset[u + 1]; ++j) {
+                const uint4 w = recs[j];
+                if (!(w.w & SVT_REC_CONTINUATION)) frag_has[0] = frag_has[1] = frag_has[2] = false;
+                if (keeps_pair_entry(w, g, lib)) S.put((w.w & 7u) | (pair_code(w.x, g, lib) << 3), w.y & 0xffffu, common);
+                uint32_t k[3];
+                weight_pairs(w, k);
+                if (k[0]) { R.put(k[0], !frag_has[0]); frag_has[0] = true; }
+                for (int s = 1; s < 3; ++s)
+                    if (k[s]) { X.put(k[s], !frag_has[s], s == 2); frag_has[s] = true; }
+            }
+            S.finish(off[3 * u + 1] - off[3 * u]);
+            R.finish(off[3 * u + 2] - off[3 * u + 1]);
+            X.finish(off[3 * u + 3] - off[3 * u + 2]);
+        }
+    });
+    owner->units.assign(in->units, in->units + n);
+    owner->hist.assign(in->libs[0].hist, in->libs[0].hist + in->libs[0].n_bins);
+    owner->lib = in->libs[0];
+    owner->lib.hist = owner->hist.data();
+    svt_packed_evidence& P = owner->pub;
+    P.n_units = n;
+    P.n_slots = total;
+    P.n_records = n_rec;
+    P.slot_offset = owner->off.data();
+    P.units = owner->units.data();
+    P.slots = owner->slots;
+    P.common_mapq = common;
+    P.n_libs = 1;
+    P.libs = &owner->lib;
+    P.split_weight = in->split_weight;
+    P.disc_weight = in->disc_weight;
+    *out = &owner.release()->pub;
+    return SVT_OK;
+}
+
+// svt_batch_create_packed: upload the slots as they are + tables
+int create_packed(const svt_packed_evidence* in, svt_batch* b)
+{
+    const uint64_t n = in->n_units;
+    StageTimer tm;
+    if (in->n_libs != 1 || !in->libs) return fail(SVT_ERR_INVALID, "packed evidence holds one library");
+    if (n && (!in->slot_offset || !in->units)) return fail(SVT_ERR_INVALID, "null unit arrays");
+    if (n && in->slot_offset[0] != 0) return fail(SVT_ERR_INVALID, "slot_offset[0] must be 0");
+    for (uint64_t i = 0; i < 3 * n; ++i)
+        if (in->slot_offset[i + 1] < in->slot_offset[i]) return fail(SVT_ERR_INVALID, "slot_offset not monotone");
+    if (n && in->slot_offset[3 * n] != in->n_slots) return fail(SVT_ERR_INVALID, "slot_offset does not end at n_slots");
+    if (in->n_slots && !in->slots) return fail(SVT_ERR_INVALID, "null slots");
+    if (in->common_mapq > 0xffffu) return fail(SVT_ERR_INVALID, "common_mapq is two bytes");
+    uint64_t max_f = 0;   // bound of the records behind a unit: 8 pair entries, 7 weight entries per slot
+    for (uint64_t u = 0; u < n; ++u) {
+        const svt_unit& U = in->units[u];
+        if (U.svtype > SVT_SVTYPE_BND) return fail(SVT_ERR_INVALID, "bad svtype");
+        if (U.reserved != 0 || (U.flags & ~SVT_UNIT_SKIP)) return fail(SVT_ERR_INVALID, "unit reserved/flags bits must be 0");
+        const uint64_t pairs = (uint64_t)(in->slot_offset[3 * u + 1] - in->slot_offset[3 * u]) * 8;
+        const uint64_t refs = (uint64_t)(in->slot_offset[3 * u + 2] - in->slot_offset[3 * u + 1]) * 7;
+        const uint64_t cands = (uint64_t)(in->slot_offset[3 * u + 3] - in->slot_offset[3 * u + 2]) * 7;
+        max_f = std::max(max_f, std::max(pairs, std::max(refs, cands)));
+    }
+    svt_evidence_batch shell{};   // what build_tables looks at
+    shell.n_units = n;
+    shell.units = in->units;
+    shell.n_libs = 1;
+    shell.libs = in->libs;
+    shell.split_weight = in->split_weight;
+    shell.disc_weight = in->disc_weight;
+    if (!(shell.split_weight >= 0.0) || !(shell.disc_weight >= 0.0) || !std::isfinite(shell.split_weight) || !std::isfinite(shell.disc_weight))
+        return fail(SVT_ERR_INVALID, "weights must be finite and >= 0");
+    HostTables T;
+    SVT_TRY(build_tables(&shell, max_f, T));
+    SVT_TRY(packable(&shell, T));
+    tm.mark("validate + tables");
+
+    HIP_TRY(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreate(&b->ev0));
+    HIP_TRY(hipEventCreate(&b->ev1));
+    {
+        void* p = nullptr;
+        SVT_TRY(g_pool.get(b->device, std::max<uint64_t>(in->n_slots, 1) * 16, &p, &b->cap_records));
+        b->d_records = p;
+        if (in->n_slots && g_pinned.is_pinned(in->slots))   // page-locked by svt_pack_evidence: straight DMA
+            HIP_TRY(hipMemcpyAsync(b->d_records, in->slots, in->n_slots * 16, hipMemcpyHostToDevice, b->stream));
+        Stager st(b->stream);
+        if (in->n_slots && !g_pinned.is_pinned(in->slots)) SVT_TRY(st.copy(b->d_records, in->slots, in->n_slots * 16));
+        SVT_TRY(g_pool.get(b->device, (3 * n + 1) * sizeof(uint32_t), &p, &b->cap_soff));
+        b->d_soff = static_cast<uint32_t*>(p);
+        if (n) SVT_TRY(st.copy(b->d_soff, in->slot_offset, (3 * n + 1) * sizeof(uint32_t)));
+        SVT_TRY(g_pool.get(b->device, std::max<uint64_t>(n, 1) * sizeof(svt_unit), &p, &b->cap_units));
+        b->d_units = static_cast<svt_unit*>(p);
+        SVT_TRY(st.copy(b->d_units, in->units, n * sizeof(svt_unit)));
+        SVT_TRY(upload(&b->d_pm, T.pm, st));
+        SVT_TRY(upload(&b->d_l10, T.l10, st));
+        SVT_TRY(upload(&b->d_bins, T.bins, st));
+        SVT_TRY(upload(&b->d_wtab, T.wtab, st));
+        SVT_TRY(g_pool.get(b->device, std::max<uint64_t>(n, 1) * sizeof(svt_result), &p, &b->cap_out));
+        b->d_out = static_cast<svt_result*>(p);
+        SVT_TRY(st.finish());
+    }
+    tm.mark("H2D slots + unit arrays + tables");
+    b->mode = kSingleLds;
+    b->n_slots = in->n_slots;
+    b->common_mq = in->common_mapq;
+    PackedArgs& a = b->pargs;
+    a.slots = static_cast<const uint4*>(b->d_records);
+    a.slot_offset = b->d_soff;
+    a.units = b->d_units;
+    a.pm = b->d_pm;
+    a.l10 = b->d_l10;
+    a.bins = b->d_bins;
+    a.wtab = b->d_wtab;
+    a.n_l10 = (uint32_t)T.l10.size();
+    a.total_bins = (uint32_t)T.bins.size();
+    a.common_mq = in->common_mapq;
+    size_t tables = kLdsBins + (size_t)a.total_bins * sizeof(Bin);
+    tables = (tables + 127) & ~size_t(127);
+    constexpr size_t kLdsPerWg = (160 * 1024 / 3) & ~size_t(127);   // three workgroups per CU
+    const size_t l10_bytes = ((size_t)a.n_l10 * 8 + 127) & ~size_t(127);
+    a.lds_l10 = (uint32_t)tables;
+    if (tables + l10_bytes + kWavesPerBlock * kRingBytes <= kLdsPerWg) {
+        a.l10_where = kL10Shared;
+        tables += l10_bytes;
+    } else {
+        a.l10_where = kL10Global;
+    }
+    a.lds_rings = (uint32_t)tables;
+    a.n_units = n;
+    a.out = b->d_out;
+    a.lib0 = T.libs[0];
+    fill_gt_consts(a.c, in->split_weight, in->disc_weight);
+    b->args.out = b->d_out;
+    b->lds_bytes = tables + kWavesPerBlock * kRingBytes;
+    if (b->lds_bytes > 160 * 1024) return fail(SVT_ERR_INVALID, "LDS budget exceeded");
+    if (b->lds_bytes > 64 * 1024) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&svt_packed_kernel<true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_bytes));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&svt_packed_kernel<false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_bytes));
+    }
     return SVT_OK;
 }
 
@@ -944,6 +1286,7 @@ static int svt_batch_bind_device_results_impl(svt_batch* b, svt_result* dev)
     if (dev && (reinterpret_cast<uintptr_t>(dev) & 127u)) return fail(SVT_ERR_INVALID, "result buffer must be 128-byte aligned");
     b->args.out = dev ? dev : b->d_out;
     b->sargs.out = b->args.out;
+    b->pargs.out = b->args.out;
     b->have_results = false;
 
     return SVT_OK;
@@ -959,6 +1302,7 @@ int svt_batch_bytes(const svt_batch* b, uint64_t* algorithmic, uint64_t* residen
     if (!b) return fail(SVT_ERR_INVALID, "null batch");
     if (algorithmic) *algorithmic = 16 * b->n_records + (16 + 96) * b->n_units;
     if (resident) *resident = b->layout == kLayoutStream ? 16 * b->n_records + (8 + 16) * b->n_units
+                              : b->layout == kLayoutPacked ? 16 * b->n_slots + (12 + 16) * b->n_units
                                                          : 16 * b->slots + (uint64_t)b->n_tiles * kWave * sizeof(LaneHdr);
     return SVT_OK;
 }
@@ -1091,6 +1435,69 @@ int svt_genotype_counts(const double* counts, const uint8_t* is_dup, uint64_t n,
     return guarded([&] { return svt_genotype_counts_impl(counts, is_dup, n, split_weight, disc_weight, out, device); });
 }
 
+int svt_pack_evidence(const svt_evidence_batch* in, svt_packed_evidence** out)
+{
+    return guarded([&] { return pack_evidence(in, out); });
+}
+
+void svt_packed_free(svt_packed_evidence* p)
+{
+    if (!p) return;
+    PackedOwner* o = reinterpret_cast<PackedOwner*>(p);   // `pub` is the owner's first member
+    g_pinned.put(o->slots);
+    delete o;
+}
+
+static int svt_batch_create_packed_impl(const svt_packed_evidence* in, int device, unsigned flags, svt_batch** out)
+{
+    if (!in || !out) return fail(SVT_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (flags & ~SVT_FLAG_SSO_ASSOCIATION) return fail(SVT_ERR_INVALID, "packed evidence takes SVT_FLAG_SSO_ASSOCIATION only");
+    if (in->n_units >= 0x55555550ull) return fail(SVT_ERR_INVALID, "too many units in one batch");
+    const int ndev = svt_device_count();
+    if (ndev <= 0) return fail(SVT_ERR_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(SVT_ERR_NO_DEVICE, "device index out of range");
+    HIP_TRY(hipSetDevice(device));
+    svt_batch* b = new (std::nothrow) svt_batch();
+    if (!b) return fail(SVT_ERR_NOMEM, "out of host memory");
+    b->device = device;
+    b->flags = flags;
+    b->layout = kLayoutPacked;
+    b->n_units = in->n_units;
+    b->n_records = in->n_records;
+    const int rc = create_packed(in, b);
+    if (rc != SVT_OK) {
+        const std::string keep = g_err;
+        free_batch(b);
+        g_err = keep;
+        return rc;
+    }
+    *out = b;
+    return SVT_OK;
+}
+
+int svt_batch_create_packed(const svt_packed_evidence* in, int device, unsigned flags, svt_batch** out)
+{
+    return guarded([&] { return svt_batch_create_packed_impl(in, device, flags, out); });
+}
+
+static int svt_genotype_packed_impl(const svt_packed_evidence* in, svt_result* out, int device, unsigned flags)
+{
+    svt_batch* b = nullptr;
+    SVT_TRY(svt_batch_create_packed(in, device, flags, &b));
+    int rc = svt_batch_genotype(b, 1);
+    if (rc == SVT_OK) rc = svt_batch_results(b, out, in->n_units);
+    const std::string keep = g_err;
+    svt_batch_destroy(b);
+    g_err = keep;
+    return rc;
+}
+
+int svt_genotype_packed(const svt_packed_evidence* in, svt_result* out, int device, unsigned flags)
+{
+    return guarded([&] { return svt_genotype_packed_impl(in, out, device, flags); });
+}
+
 void* svt_batch_stream(svt_batch* b) { return b ? (void*)b->stream : nullptr; }
 
 void svt_batch_destroy(svt_batch* b) { free_batch(b); }
@@ -1100,6 +1507,7 @@ void svt_trim(void)
     g_csr_cache.trim();
     g_pool.trim();
     g_host.trim();
+    g_pinned.trim();
 }
 
 static int svt_genotype_impl(const svt_evidence_batch* in, svt_result* out, int device, unsigned flags)

@@ -112,6 +112,23 @@ class CEvidenceBatch(C.Structure):
     ]
 
 
+class CPackedEvidence(C.Structure):
+    """include/svtyper_hip.h: svt_packed_evidence"""
+    _fields_ = [
+        ("n_units", C.c_uint64),
+        ("n_slots", C.c_uint64),
+        ("n_records", C.c_uint64),
+        ("slot_offset", C.POINTER(C.c_uint32)),
+        ("units", C.c_void_p),
+        ("slots", C.c_void_p),
+        ("common_mapq", C.c_uint32),
+        ("n_libs", C.c_uint32),
+        ("libs", C.POINTER(CLibrary)),
+        ("split_weight", C.c_double),
+        ("disc_weight", C.c_double),
+    ]
+
+
 # --------------------------------------------------------------------------- library table
 @dataclass
 class LibraryTable:

@@ -12,7 +12,7 @@ from typing import Optional
 
 import numpy as np
 
-from .evidence import GT_BLANK, CEvidenceBatch, EvidenceBatch, Results
+from .evidence import GT_BLANK, CEvidenceBatch, CPackedEvidence, EvidenceBatch, Results
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SVTYPER_HIP_LIB") or os.path.join(_HERE, "csrc", "libsvtyper_hip.so")
@@ -24,6 +24,7 @@ EXPORTS = (
     "svt_batch_genotype_n", "svt_batch_genotype_timed", "svt_batch_results", "svt_batch_device_results",
     "svt_batch_bind_device_results", "svt_batch_bytes", "svt_batch_layout", "svt_batch_site_qual",
     "svt_batch_stream", "svt_batch_destroy", "svt_trim", "svt_bayes_gt", "svt_genotype_counts", "svt_genotype", "svt_genotype_multi", "svt_shard_bounds",
+    "svt_pack_evidence", "svt_packed_free", "svt_batch_create_packed", "svt_genotype_packed",
     "svt_format_results", "svt_format_free", "svt_results_host_sq",
 )
 
@@ -96,6 +97,14 @@ def load() -> C.CDLL:
     L.svt_genotype_multi.argtypes = [C.POINTER(CEvidenceBatch), C.c_void_p, C.POINTER(C.c_int), C.c_int, C.c_uint32, C.c_uint]
     L.svt_shard_bounds.restype = C.c_int
     L.svt_shard_bounds.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_uint32, C.c_void_p]
+    L.svt_pack_evidence.restype = C.c_int
+    L.svt_pack_evidence.argtypes = [C.POINTER(CEvidenceBatch), C.POINTER(C.POINTER(CPackedEvidence))]
+    L.svt_packed_free.restype = None
+    L.svt_packed_free.argtypes = [C.POINTER(CPackedEvidence)]
+    L.svt_batch_create_packed.restype = C.c_int
+    L.svt_batch_create_packed.argtypes = [C.POINTER(CPackedEvidence), C.c_int, C.c_uint, C.POINTER(C.c_void_p)]
+    L.svt_genotype_packed.restype = C.c_int
+    L.svt_genotype_packed.argtypes = [C.POINTER(CPackedEvidence), C.c_void_p, C.c_int, C.c_uint]
     L.svt_results_host_sq.restype = C.c_int
     L.svt_results_host_sq.argtypes = [C.c_void_p, C.c_uint64]
     L.svt_genotype_counts.restype = C.c_int
@@ -121,6 +130,82 @@ def trim():
 
 def device_count() -> int:
     return int(load().svt_device_count())
+
+
+ERR_UNSUPPORTED = -7
+
+
+class PackedEvidence:
+    """Packed evidence of a batch on the host (svt_packed_evidence, svt_pack_evidence): three sparse streams of small
+    entries per unit instead of 16-byte records -- what crosses PCIe when the records were produced on the host."""
+
+    def __init__(self, batch: EvidenceBatch):
+        L = load()
+        self._lib = L
+        self._p = C.POINTER(CPackedEvidence)()
+        cb = batch.as_c()
+        _check(L.svt_pack_evidence(C.byref(cb), C.byref(self._p)))
+
+    @classmethod
+    def try_pack(cls, batch: EvidenceBatch):
+        """None when the batch cannot be expressed as packed evidence (several libraries, ...)."""
+        try:
+            return cls(batch)
+        except SvtyperHipError as e:
+            if "error %d" % ERR_UNSUPPORTED in str(e):
+                return None
+            raise
+
+    @property
+    def c(self) -> CPackedEvidence:
+        return self._p.contents
+
+    @property
+    def n_units(self) -> int:
+        return int(self.c.n_units)
+
+    @property
+    def n_records(self) -> int:
+        return int(self.c.n_records)
+
+    @property
+    def nbytes(self) -> int:
+        """bytes svt_batch_create_packed uploads: slots + slot offsets + unit headers"""
+        return 16 * int(self.c.n_slots) + 4 * (3 * self.n_units + 1) + 16 * self.n_units
+
+    def slots(self) -> np.ndarray:
+        """uint32 [n_slots, 4] view of the slots"""
+        n = int(self.c.n_slots)
+        if n == 0:
+            return np.zeros((0, 4), np.uint32)
+        return np.ctypeslib.as_array(C.cast(self.c.slots, C.POINTER(C.c_uint32)), shape=(n, 4))
+
+    def slot_offset(self) -> np.ndarray:
+        return np.ctypeslib.as_array(self.c.slot_offset, shape=(3 * self.n_units + 1,))
+
+    def free(self):
+        if self._p:
+            self._lib.svt_packed_free(self._p)
+            self._p = C.POINTER(CPackedEvidence)()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.free()
+
+
+def genotype_packed(packed: PackedEvidence, device: int = 0, flags: int = 0) -> Results:
+    """svt_genotype_packed: create_packed + one pass + results + destroy."""
+    out = Results.empty(packed.n_units)
+    _check(load().svt_genotype_packed(packed._p, C.c_void_p(out.ptr()), int(device), int(flags)))
+    return out
 
 
 class DeviceBatch:
@@ -153,6 +238,18 @@ class DeviceBatch:
                                                  C.c_void_p(recs.ctypes.data) if return_records and recs.size else None,
                                                  C.byref(self._h)))
         self.records = recs
+        return self
+
+    @classmethod
+    def from_packed(cls, packed: "PackedEvidence", device: int = 0, flags: int = 0):
+        """svt_batch_create_packed: the slots go to HBM as they are."""
+        L = load()
+        self = cls.__new__(cls)
+        self._lib = L
+        self._h = C.c_void_p()
+        self.n_units = packed.n_units
+        self.n_records = packed.n_records
+        _check(L.svt_batch_create_packed(packed._p, int(device), int(flags), C.byref(self._h)))
         return self
 
     def genotype(self, sync: bool = True):
@@ -213,7 +310,7 @@ class DeviceBatch:
         common MAPQ pair)"""
         c, m = C.c_int(), C.c_int()
         _check(self._lib.svt_batch_layout(self._h, C.byref(c), C.byref(m)))
-        return ("dense", "compact", "short", "stream")[c.value]
+        return ("dense", "compact", "short", "stream", "packed")[c.value]
 
     def stream(self) -> int:
         return int(self._lib.svt_batch_stream(self._h) or 0)

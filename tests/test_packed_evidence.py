@@ -1,0 +1,159 @@
+"""Packed evidence (svt_packed_evidence): the host encoder svt_pack_evidence pinned on the CPU by an independent
+decoder (oracle/py_packed.py) against the oracle on the canonical records, and -- on the GPU -- the pass over packed
+evidence against the oracle and byte-for-byte against the pass over the canonical records."""
+import numpy as np
+import pytest
+
+from svtyper_amd import evidence as ev
+from svtyper_amd import synth
+
+
+def _tallies_bits(x):
+    return np.ascontiguousarray(x).view(np.uint64)
+
+
+@pytest.mark.parametrize("sso", [0, ev.FLAG_SSO_ASSOCIATION])
+def test_encoder_against_an_independent_decoder(fixture_library, sso):
+    """CPU only: decode the slots the encoder wrote and redo the reference's arithmetic on them."""
+    from oracle import c_oracle, py_packed
+    from svtyper_amd import hip
+    batches = [synth.make_edge_cases([fixture_library], seed=11).slice(0, 300),
+               synth.make_units(400, 7, [fixture_library], svtype_mix=(0.5, 0.2, 0.2, 0.1), min_frags=0, mean_frags=25, sd_frags=20)]
+    b = synth.make_units(300, 8, [fixture_library], svtype_mix=(0.6, 0.2, 0.1, 0.1), mean_frags=30, sd_frags=10)
+    b.records["mapq_a"][::3] = 37                      # wide entries, every alignment case
+    b.records["mapq_b"][::7] = 0
+    b.units["var_length"][::5] = 3                      # below the small-deletion gate
+    b.units["pos_delta"][::5] = 3
+    batches.append(b)
+    for batch in batches:
+        want = c_oracle.genotype_batch(batch, flags=sso).tallies
+        with hip.PackedEvidence(batch) as p:
+            assert p.n_units == batch.n_units and p.n_records == batch.n_records
+            so = p.slot_offset()
+            assert so[0] == 0 and so[-1] == p.c.n_slots and np.all(np.diff(so.astype(np.int64)) >= 0)
+            got = py_packed.tally_packed(p.slots(), so, batch.units, fixture_library, int(p.c.common_mapq), bool(sso))
+        skip = (batch.units["flags"] & ev.UNIT_SKIP) != 0       # (the oracle blanks skipped units; the decoder has no epilogue)
+        assert np.array_equal(_tallies_bits(got[~skip]), _tallies_bits(want[~skip]))
+
+
+def test_pack_rejects_what_the_format_cannot_hold(fixture_library):
+    from svtyper_amd import hip
+    two = synth.make_units(50, 3, [fixture_library, synth.normal_library(420.0, 95.0, seed=3)])
+    assert hip.PackedEvidence.try_pack(two) is None
+    wide = synth.make_units(50, 3, [synth.normal_library(3000.0, 900.0, seed=5)])
+    assert hip.PackedEvidence.try_pack(wide) is None
+    neg = synth.make_units(50, 3, [fixture_library], svtype_mix=(1.0, 0, 0, 0))
+    neg.units["var_length"][3] = -7
+    assert hip.PackedEvidence.try_pack(neg) is None
+    bad = synth.make_units(50, 3, [fixture_library])
+    bad.records["flags"][5] |= 1 << 20
+    with pytest.raises(hip.SvtyperHipError) as e:
+        hip.PackedEvidence(bad)
+    assert "reserved/undefined bits" in str(e.value)
+    bad = synth.make_units(50, 3, [fixture_library])
+    bad.records["flags"][7] = ev.REC_ALT_STRADDLE
+    with pytest.raises(hip.SvtyperHipError):
+        hip.PackedEvidence(bad)
+    empty = synth.make_units(0, 3, [fixture_library])
+    with hip.PackedEvidence(empty) as p:
+        assert p.n_units == 0 and p.c.n_slots == 0
+    ok = synth.make_units(2000, 3, [fixture_library])
+    with hip.PackedEvidence(ok) as p:
+        assert p.nbytes < 0.3 * (16 * ok.n_records)         # the point of the format
+
+
+def _both(batch, flags):
+    from oracle import c_oracle
+    from svtyper_amd import hip
+    with hip.PackedEvidence(batch) as p:
+        got = hip.genotype_packed(p, flags=flags)
+    canon = hip.genotype_batch(batch, flags=flags)
+    assert got.rec.tobytes() == canon.rec.tobytes(), "packed pass differs from the pass over the canonical records"
+    return got, c_oracle.genotype_batch(batch, flags=flags)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sso", [0, ev.FLAG_SSO_ASSOCIATION])
+def test_packed_pass_parity(hip_device, fixture_library, sso):
+    from test_hip_parity import assert_parity, _sweep_batch
+    batches = {
+        "edge": synth.make_edge_cases([fixture_library], seed=11),
+        "c2": synth.make_config("c2_del_100k", [fixture_library], n_units=20_000),
+        "c3": synth.make_config("c3_mixed_1m", [fixture_library], n_units=30_000),
+        "weights": synth.make_units(4000, 17, [fixture_library], svtype_mix=(0.6, 0.2, 0.1, 0.1), split_weight=0.7, disc_weight=1.9),
+    }
+    nb = len(fixture_library.hist)
+    for svtype in (0, 1, 2):
+        batches["sweep%d" % svtype] = _sweep_batch(fixture_library, [0, 1, 37, nb - 1, nb, nb + 1, 3 * nb, 100_000, 2**29], svtype)
+    for n in (1, 63, 64, 65, 255, 257, 4097):
+        batches["tiny%d" % n] = synth.make_units(n, n, [fixture_library], svtype_mix=(0.5, 0.2, 0.2, 0.1), min_frags=0,
+                                                 mean_frags=30, sd_frags=30)
+    for name, batch in batches.items():
+        got, want = _both(batch, sso)
+        assert_parity(got, want)
+    want = batches["edge"]
+    got, oracle = _both(want, sso)
+    assert (oracle.gt == ev.GT_BLANK).any() and (oracle.gt == ev.GT_SKIPPED).any() and (oracle.gt == ev.GT_MISSING).any()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pattern", ["all_common", "all_wide", "alternate", "runs", "random", "mapq255", "vote_other"])
+def test_packed_pair_entry_patterns(hip_device, fixture_library, pattern):
+    """every mix of one-half-word and wide pair entries (and the no-op half-words that align the wide ones)"""
+    import zlib
+    from test_hip_parity import assert_parity
+    rng = np.random.default_rng(zlib.crc32(pattern.encode()))
+    batch = synth.make_units(3000, 61, [fixture_library], svtype_mix=(0.5, 0.2, 0.2, 0.1), mean_frags=40, sd_frags=25, min_frags=0)
+    n = batch.n_records
+    a, b = batch.records["mapq_a"], batch.records["mapq_b"]
+    if pattern == "all_common":
+        a[:], b[:] = 60, 60
+    elif pattern == "all_wide":
+        a[:] = rng.integers(1, 60, n); b[:] = 60 - a // 2
+    elif pattern == "alternate":
+        a[:], b[:] = 60, 60
+        a[::2] = 37
+    elif pattern == "runs":
+        a[:], b[:] = 60, 60
+        wide = (np.arange(n) % 11) < 3
+        a[wide], b[wide] = 23, 59
+    elif pattern == "random":
+        a[:] = rng.choice([60, 60, 60, 0, 1, 40, 255], n); b[:] = rng.choice([60, 60, 60, 0, 13, 255], n)
+    elif pattern == "mapq255":
+        a[:], b[:] = 255, 255
+        a[::5] = 128
+    else:
+        a[:], b[:] = 40, 13
+        a[::4], b[::4] = 60, 60
+    for flags in (0, ev.FLAG_SSO_ASSOCIATION):
+        got, want = _both(batch, flags)
+        assert_parity(got, want)
+
+
+@pytest.mark.gpu
+def test_packed_resident_batch_and_long_units(hip_device, fixture_library):
+    """DeviceBatch.from_packed: re-runs are idempotent, bytes() reports the slots, results bind to a caller buffer;
+    units with thousands of records (log10 table through L2, last sort bucket)."""
+    from svtyper_amd import hip
+    from test_hip_parity import assert_parity
+    from oracle import c_oracle
+    batch = synth.make_units(5000, 5, [fixture_library], svtype_mix=(0.5, 0.2, 0.2, 0.1))
+    with hip.PackedEvidence(batch) as p, hip.DeviceBatch.from_packed(p, hip_device) as d:
+        assert d.layout_name() == "packed"
+        alg, res = d.bytes()
+        assert alg == batch.algorithmic_bytes() and res == 16 * int(p.c.n_slots) + 28 * batch.n_units
+        d.genotype(sync=True)
+        first = d.results()
+        d.genotype(sync=True)
+        assert d.results().rec.tobytes() == first.rec.tobytes()
+    assert_parity(first, c_oracle.genotype_batch(batch))
+    counts = np.array([3000, 5, 7000, 0, 1, 2600])
+    off = np.concatenate([[0], np.cumsum(counts)]).astype(np.uint64)
+    r = np.zeros(int(off[-1]), ev.RECORD_DTYPE)
+    r["flags"] = np.uint32(ev.REC_ALT_STRADDLE | ev.REC_HAS_PAIR)
+    r["mapq_a"], r["mapq_b"], r["rs_a"], r["ospan_len"] = 60, 60, 60, 100_000
+    u = np.zeros(len(counts), ev.UNIT_DTYPE)
+    u["var_length"], u["pos_delta"] = 5000, 5000
+    long_units = ev.EvidenceBatch(off, u, r, [fixture_library], 1.0, 1.0)
+    got, want = _both(long_units, 0)
+    assert_parity(got, want)
