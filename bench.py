@@ -361,6 +361,7 @@ def main():
         if extra:
             # ---- one shot, PCIe included: host arrays (pageable) -> svt_batch_create -> one pass -> result records
             # on the host, steady state (the first create pays the pinned ring and the pooled device buffers)
+            host_out = hip.pinned_results(n)   # the caller's output array, page-locked (svt_pinned_alloc): D2H is one DMA
             try:
                 dbatch.close()
                 walls, parts = [], None
@@ -370,7 +371,7 @@ def main():
                     t1 = time.perf_counter()
                     d1.genotype(sync=True)
                     t2 = time.perf_counter()
-                    r1 = d1.results()
+                    r1 = d1.results(out=host_out)
                     t3 = time.perf_counter()
                     d1.close()
                     if not walls or t3 - t0 < min(walls):
@@ -378,8 +379,8 @@ def main():
                     walls.append(t3 - t0)
                 best = min(walls)
                 out["one_shot"] = {
-                    "what": "svt_batch_create (validate + H2D of the canonical CSR through the pinned ring) + ONE pass + "
-                            "svt_batch_results (D2H), host buffers in pageable memory, best of 3",
+                    "what": "svt_batch_create (validate + H2D of the canonical CSR from pageable memory through the pinned ring) + "
+                            "ONE pass + svt_batch_results (D2H into a page-locked output array), best of 3",
                     "wall_ms": best * 1e3,
                     "create_ms": parts[0] * 1e3, "pass_ms": parts[1] * 1e3, "results_d2h_ms": parts[2] * 1e3,
                     "pcie_inclusive_breakpoints_per_s": n / best,
@@ -389,6 +390,48 @@ def main():
                 dbatch = hip.DeviceBatch(batch, device=local_rank, flags=flags)
             except Exception as e:  # an extra leg must never break the bench line
                 out["one_shot"] = {"error": repr(e)}
+
+            # ---- the same through PACKED evidence: what a host producer hands over when the bytes have to cross PCIe
+            # (svt_pack_evidence: ~3 bytes per fragment record instead of 16; the pass is svt_packed_kernel on the slots)
+            try:
+                t0 = time.perf_counter()
+                packed = hip.PackedEvidence.try_pack(batch)
+                pack_ms = (time.perf_counter() - t0) * 1e3
+                if packed is None:
+                    out["one_shot_packed"] = {"skipped": "this batch cannot be expressed as packed evidence (several libraries)"}
+                else:
+                    walls, parts = [], None
+                    for _ in range(4):
+                        t0 = time.perf_counter()
+                        dp = hip.DeviceBatch.from_packed(packed, device=local_rank, flags=sso)
+                        t1 = time.perf_counter()
+                        dp.genotype(sync=True)
+                        t2 = time.perf_counter()
+                        rp = dp.results(out=host_out)
+                        t3 = time.perf_counter()
+                        if not walls or t3 - t0 < min(walls):
+                            parts = (t1 - t0, t2 - t1, t3 - t2)
+                        walls.append(t3 - t0)
+                        if len(walls) < 4:
+                            dp.close()
+                    p_ms = time_passes(dp, args.steps)
+                    dp.close()
+                    best = min(walls)
+                    out["one_shot_packed"] = {
+                        "what": "svt_batch_create_packed (H2D of the packed slots from page-locked memory) + ONE pass of "
+                                "svt_packed_kernel + svt_batch_results (D2H into a page-locked output array), best of 4; the encoder (svt_pack_evidence, host, "
+                                "%d threads) is the producer's side and is reported as pack_ms, not included" % n_cpu,
+                        "wall_ms": best * 1e3, "create_ms": parts[0] * 1e3, "pass_ms": parts[1] * 1e3,
+                        "results_d2h_ms": parts[2] * 1e3, "pack_ms": pack_ms,
+                        "pcie_inclusive_breakpoints_per_s": n / best,
+                        "h2d_bytes": packed.nbytes, "d2h_bytes": int(128 * n),
+                        "bytes_per_fragment_record": packed.nbytes / max(1, batch.n_records),
+                        "resident_pass_ms": p_ms, "resident_breakpoints_per_s_pass_only": n / (p_ms * 1e-3),
+                        "results_equal_headline": bool(np.array_equal(rp.rec, got.rec)),
+                    }
+                    packed.free()
+            except Exception as e:
+                out["one_shot_packed"] = {"error": repr(e)}
 
             # ---- the tiled layouts: pass time over tiles built once (re-run figures) + what building them costs
             rerun = {"note": "tiled layouts: svt_batch_create re-tiles / re-encodes the batch ONCE on the device (scan + host "

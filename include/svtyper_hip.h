@@ -435,6 +435,13 @@ typedef struct svt_packed_evidence {
     double disc_weight;
 } svt_packed_evidence;
 
+/* Page-locked host memory from the library's pool (plain memory when no device is present): buffers a caller
+ * fills or reads right before / after a transfer -- an output array for svt_batch_results, the arrays of a
+ * svt_packed_evidence it writes itself -- then move by straight DMA instead of through the staging ring.
+ * (The library does not page-lock CALLER memory: unmapping such pages later stalls the GPU queues.)          */
+void* svt_pinned_alloc(size_t bytes);
+void svt_pinned_free(void* p);
+
 /* Encode a batch of canonical records (host only, multi-threaded; the record contract is checked here, so the
  * pass over packed evidence does not check it again).  The slots are placed in page-locked host memory when a
  * device is present, so svt_batch_create_packed can DMA them without a staging copy.  A producer that never

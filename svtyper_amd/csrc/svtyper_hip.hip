@@ -445,11 +445,13 @@ struct PinnedPool {
         live.push_back(it);
         return it.p;
     }
-    bool is_pinned(const void* p)
+    // is [p, p + bytes) inside a live page-locked buffer of this pool?
+    bool is_pinned(const void* p, uint64_t bytes = 1)
     {
         std::lock_guard<std::mutex> g(lock);
+        const char* q = static_cast<const char*>(p);
         for (const Item& it : live)
-            if (it.p == p) return it.pinned;
+            if (it.pinned && q >= static_cast<const char*>(it.p) && q + bytes <= static_cast<const char*>(it.p) + it.cap) return true;
         return false;
     }
     void put(void* p)
@@ -486,11 +488,17 @@ PinnedPool g_pinned;
 
 struct PackedOwner {             // what svt_pack_evidence returns: the public struct first, the storage behind it
     svt_packed_evidence pub{};
-    std::vector<uint32_t> off;
-    std::vector<svt_unit> units;
+    uint32_t* off = nullptr;     // the three arrays that cross PCIe live in page-locked memory (g_pinned)
+    svt_unit* units = nullptr;
+    void* slots = nullptr;
     std::vector<uint32_t> hist;
     svt_library lib{};
-    void* slots = nullptr;
+    ~PackedOwner()
+    {
+        g_pinned.put(off);
+        g_pinned.put(units);
+        g_pinned.put(slots);
+    }
 };
 
 // can this batch be written as packed evidence?  (the limits of the short entry format, include/svtyper_hip.h)
@@ -549,8 +557,11 @@ int pack_evidence(const svt_evidence_batch* in, svt_packed_evidence** out)
     }
 
     auto owner = std::make_unique<PackedOwner>();
-    owner->off.assign(3 * n + 1, 0u);
-    std::vector<uint32_t>& off = owner->off;
+    owner->off = static_cast<uint32_t*>(g_pinned.get((3 * n + 1) * sizeof(uint32_t)));
+    owner->units = static_cast<svt_unit*>(g_pinned.get(std::max<uint64_t>(n, 1) * sizeof(svt_unit)));
+    if (!owner->off || !owner->units) return fail(SVT_ERR_NOMEM, "out of host memory");
+    uint32_t* off = owner->off;
+    off[0] = 0u;
     // ---- pass 1: contract check + slots per stream and unit
     const uint64_t kChunk = 2048;
     const uint64_t n_chunks = (n + kChunk - 1) / kChunk;
@@ -614,7 +625,7 @@ int pack_evidence(const svt_evidence_batch* in, svt_packed_evidence** out)
             X.finish(off[3 * u + 3] - off[3 * u + 2]);
         }
     });
-    owner->units.assign(in->units, in->units + n);
+    if (n) std::memcpy(owner->units, in->units, n * sizeof(svt_unit));
     owner->hist.assign(in->libs[0].hist, in->libs[0].hist + in->libs[0].n_bins);
     owner->lib = in->libs[0];
     owner->lib.hist = owner->hist.data();
@@ -622,8 +633,8 @@ int pack_evidence(const svt_evidence_batch* in, svt_packed_evidence** out)
     P.n_units = n;
     P.n_slots = total;
     P.n_records = n_rec;
-    P.slot_offset = owner->off.data();
-    P.units = owner->units.data();
+    P.slot_offset = owner->off;
+    P.units = owner->units;
     P.slots = owner->slots;
     P.common_mapq = common;
     P.n_libs = 1;
@@ -642,58 +653,82 @@ int create_packed(const svt_packed_evidence* in, svt_batch* b)
     if (in->n_libs != 1 || !in->libs) return fail(SVT_ERR_INVALID, "packed evidence holds one library");
     if (n && (!in->slot_offset || !in->units)) return fail(SVT_ERR_INVALID, "null unit arrays");
     if (n && in->slot_offset[0] != 0) return fail(SVT_ERR_INVALID, "slot_offset[0] must be 0");
-    for (uint64_t i = 0; i < 3 * n; ++i)
-        if (in->slot_offset[i + 1] < in->slot_offset[i]) return fail(SVT_ERR_INVALID, "slot_offset not monotone");
     if (n && in->slot_offset[3 * n] != in->n_slots) return fail(SVT_ERR_INVALID, "slot_offset does not end at n_slots");
     if (in->n_slots && !in->slots) return fail(SVT_ERR_INVALID, "null slots");
     if (in->common_mapq > 0xffffu) return fail(SVT_ERR_INVALID, "common_mapq is two bytes");
-    uint64_t max_f = 0;   // bound of the records behind a unit: 8 pair entries, 7 weight entries per slot
-    for (uint64_t u = 0; u < n; ++u) {
-        const svt_unit& U = in->units[u];
-        if (U.svtype > SVT_SVTYPE_BND) return fail(SVT_ERR_INVALID, "bad svtype");
-        if (U.reserved != 0 || (U.flags & ~SVT_UNIT_SKIP)) return fail(SVT_ERR_INVALID, "unit reserved/flags bits must be 0");
-        const uint64_t pairs = (uint64_t)(in->slot_offset[3 * u + 1] - in->slot_offset[3 * u]) * 8;
-        const uint64_t refs = (uint64_t)(in->slot_offset[3 * u + 2] - in->slot_offset[3 * u + 1]) * 7;
-        const uint64_t cands = (uint64_t)(in->slot_offset[3 * u + 3] - in->slot_offset[3 * u + 2]) * 7;
-        max_f = std::max(max_f, std::max(pairs, std::max(refs, cands)));
-    }
-    svt_evidence_batch shell{};   // what build_tables looks at
-    shell.n_units = n;
-    shell.units = in->units;
-    shell.n_libs = 1;
-    shell.libs = in->libs;
-    shell.split_weight = in->split_weight;
-    shell.disc_weight = in->disc_weight;
-    if (!(shell.split_weight >= 0.0) || !(shell.disc_weight >= 0.0) || !std::isfinite(shell.split_weight) || !std::isfinite(shell.disc_weight))
+    if (!(in->split_weight >= 0.0) || !(in->disc_weight >= 0.0) || !std::isfinite(in->split_weight) || !std::isfinite(in->disc_weight))
         return fail(SVT_ERR_INVALID, "weights must be finite and >= 0");
-    HostTables T;
-    SVT_TRY(build_tables(&shell, max_f, T));
-    SVT_TRY(packable(&shell, T));
-    tm.mark("validate + tables");
 
     HIP_TRY(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreate(&b->ev0));
     HIP_TRY(hipEventCreate(&b->ev1));
+    // ---- the slots leave first (page-locked by svt_pack_evidence: straight DMA); the unit arrays are checked
+    // while they are on the wire
+    void* p = nullptr;
+    SVT_TRY(g_pool.get(b->device, std::max<uint64_t>(in->n_slots, 1) * 16, &p, &b->cap_records));
+    b->d_records = p;
+    SVT_TRY(g_pool.get(b->device, (3 * n + 1) * sizeof(uint32_t), &p, &b->cap_soff));
+    b->d_soff = static_cast<uint32_t*>(p);
+    SVT_TRY(g_pool.get(b->device, std::max<uint64_t>(n, 1) * sizeof(svt_unit), &p, &b->cap_units));
+    b->d_units = static_cast<svt_unit*>(p);
+    SVT_TRY(g_pool.get(b->device, std::max<uint64_t>(n, 1) * sizeof(svt_result), &p, &b->cap_out));
+    b->d_out = static_cast<svt_result*>(p);
+    const bool slots_pinned = in->n_slots && g_pinned.is_pinned(in->slots, in->n_slots * 16);
+    const bool off_pinned = n && g_pinned.is_pinned(in->slot_offset, (3 * n + 1) * sizeof(uint32_t));
+    const bool units_pinned = n && g_pinned.is_pinned(in->units, n * sizeof(svt_unit));
+    if (slots_pinned) HIP_TRY(hipMemcpyAsync(b->d_records, in->slots, in->n_slots * 16, hipMemcpyHostToDevice, b->stream));
+    if (off_pinned) HIP_TRY(hipMemcpyAsync(b->d_soff, in->slot_offset, (3 * n + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, b->stream));
+    if (units_pinned) HIP_TRY(hipMemcpyAsync(b->d_units, in->units, n * sizeof(svt_unit), hipMemcpyHostToDevice, b->stream));
+    tm.mark("allocations + DMA enqueued");
+
+    uint64_t max_f = 0;   // bound of the records behind a unit: 8 pair entries, 7 weight entries per slot
     {
-        void* p = nullptr;
-        SVT_TRY(g_pool.get(b->device, std::max<uint64_t>(in->n_slots, 1) * 16, &p, &b->cap_records));
-        b->d_records = p;
-        if (in->n_slots && g_pinned.is_pinned(in->slots))   // page-locked by svt_pack_evidence: straight DMA
-            HIP_TRY(hipMemcpyAsync(b->d_records, in->slots, in->n_slots * 16, hipMemcpyHostToDevice, b->stream));
+        const uint64_t kChunk = 16384, n_chunks = (n + kChunk - 1) / kChunk;
+        std::vector<uint64_t> chunk_max(std::max<uint64_t>(n_chunks, 1), 0);
+        std::vector<int> chunk_bad(std::max<uint64_t>(n_chunks, 1), 0);
+        parallel_for(n_chunks, [&](uint64_t ch) {
+            uint64_t m = 0;
+            int bad = 0;
+            for (uint64_t u = ch * kChunk; u < std::min(n, (ch + 1) * kChunk); ++u) {
+                const svt_unit& U = in->units[u];
+                const uint32_t* o = in->slot_offset + 3 * u;
+                if (o[1] < o[0] || o[2] < o[1] || o[3] < o[2]) bad |= 1;
+                if (U.svtype > SVT_SVTYPE_BND) bad |= 2;
+                if (U.reserved != 0 || (U.flags & ~SVT_UNIT_SKIP)) bad |= 4;
+                if (U.var_length < -(1 << 30) || U.var_length > (1 << 30)) bad |= 8;
+                if (U.svtype == SVT_SVTYPE_DEL && U.var_length < 0) bad |= 16;
+                m = std::max(m, std::max<uint64_t>((uint64_t)(o[1] - o[0]) * 8, std::max<uint64_t>((uint64_t)(o[2] - o[1]) * 7, (uint64_t)(o[3] - o[2]) * 7)));
+            }
+            chunk_max[ch] = m;
+            chunk_bad[ch] = bad;
+        });
+        int bad = 0;
+        for (uint64_t ch = 0; ch < n_chunks; ++ch) { max_f = std::max(max_f, chunk_max[ch]); bad |= chunk_bad[ch]; }
+        if (bad & 1) return fail(SVT_ERR_INVALID, "slot_offset not monotone");
+        if (bad & 2) return fail(SVT_ERR_INVALID, "bad svtype");
+        if (bad & 4) return fail(SVT_ERR_INVALID, "unit reserved/flags bits must be 0");
+        if (bad & 8) return fail(SVT_ERR_UNSUPPORTED, "var_length outside the packed format's range");
+        if (bad & 16) return fail(SVT_ERR_UNSUPPORTED, "negative DEL length");
+    }
+    svt_evidence_batch shell{};   // what build_tables looks at
+    shell.n_units = 0;
+    shell.n_libs = 1;
+    shell.libs = in->libs;
+    shell.split_weight = in->split_weight;
+    shell.disc_weight = in->disc_weight;
+    HostTables T;
+    SVT_TRY(build_tables(&shell, max_f, T));
+    SVT_TRY(packable(&shell, T));
+    tm.mark("validate + tables");
+    {
         Stager st(b->stream);
-        if (in->n_slots && !g_pinned.is_pinned(in->slots)) SVT_TRY(st.copy(b->d_records, in->slots, in->n_slots * 16));
-        SVT_TRY(g_pool.get(b->device, (3 * n + 1) * sizeof(uint32_t), &p, &b->cap_soff));
-        b->d_soff = static_cast<uint32_t*>(p);
-        if (n) SVT_TRY(st.copy(b->d_soff, in->slot_offset, (3 * n + 1) * sizeof(uint32_t)));
-        SVT_TRY(g_pool.get(b->device, std::max<uint64_t>(n, 1) * sizeof(svt_unit), &p, &b->cap_units));
-        b->d_units = static_cast<svt_unit*>(p);
-        SVT_TRY(st.copy(b->d_units, in->units, n * sizeof(svt_unit)));
+        if (in->n_slots && !slots_pinned) SVT_TRY(st.copy(b->d_records, in->slots, in->n_slots * 16));
+        if (n && !off_pinned) SVT_TRY(st.copy(b->d_soff, in->slot_offset, (3 * n + 1) * sizeof(uint32_t)));
+        if (n && !units_pinned) SVT_TRY(st.copy(b->d_units, in->units, n * sizeof(svt_unit)));
         SVT_TRY(upload(&b->d_pm, T.pm, st));
         SVT_TRY(upload(&b->d_l10, T.l10, st));
         SVT_TRY(upload(&b->d_bins, T.bins, st));
         SVT_TRY(upload(&b->d_wtab, T.wtab, st));
-        SVT_TRY(g_pool.get(b->device, std::max<uint64_t>(n, 1) * sizeof(svt_result), &p, &b->cap_out));
-        b->d_out = static_cast<svt_result*>(p);
         SVT_TRY(st.finish());
     }
     tm.mark("H2D slots + unit arrays + tables");
@@ -1265,6 +1300,11 @@ static int svt_batch_results_impl(svt_batch* b, svt_result* out, uint64_t n_unit
     HIP_TRY(hipSetDevice(b->device));
     HIP_TRY(hipStreamSynchronize(b->stream));   // the pass that produced the records
     SVT_TRY(check_stream_errors(b));
+    if (b->n_units && g_pinned.is_pinned(out, b->n_units * sizeof(svt_result))) {   // svt_pinned_alloc'ed: straight DMA
+        HIP_TRY(hipMemcpyAsync(out, b->args.out, b->n_units * sizeof(svt_result), hipMemcpyDeviceToHost, b->stream));
+        HIP_TRY(hipStreamSynchronize(b->stream));
+        return SVT_OK;
+    }
     return d2h_staged(out, b->args.out, b->n_units * sizeof(svt_result), b->stream);
 }
 
@@ -1435,6 +1475,16 @@ int svt_genotype_counts(const double* counts, const uint8_t* is_dup, uint64_t n,
     return guarded([&] { return svt_genotype_counts_impl(counts, is_dup, n, split_weight, disc_weight, out, device); });
 }
 
+void* svt_pinned_alloc(size_t bytes)
+{
+    try { return g_pinned.get(bytes); } catch (...) { return nullptr; }
+}
+
+void svt_pinned_free(void* p)
+{
+    try { g_pinned.put(p); } catch (...) {}
+}
+
 int svt_pack_evidence(const svt_evidence_batch* in, svt_packed_evidence** out)
 {
     return guarded([&] { return pack_evidence(in, out); });
@@ -1443,9 +1493,7 @@ int svt_pack_evidence(const svt_evidence_batch* in, svt_packed_evidence** out)
 void svt_packed_free(svt_packed_evidence* p)
 {
     if (!p) return;
-    PackedOwner* o = reinterpret_cast<PackedOwner*>(p);   // `pub` is the owner's first member
-    g_pinned.put(o->slots);
-    delete o;
+    delete reinterpret_cast<PackedOwner*>(p);   // `pub` is the owner's first member
 }
 
 static int svt_batch_create_packed_impl(const svt_packed_evidence* in, int device, unsigned flags, svt_batch** out)

@@ -24,7 +24,7 @@ EXPORTS = (
     "svt_batch_genotype_n", "svt_batch_genotype_timed", "svt_batch_results", "svt_batch_device_results",
     "svt_batch_bind_device_results", "svt_batch_bytes", "svt_batch_layout", "svt_batch_site_qual",
     "svt_batch_stream", "svt_batch_destroy", "svt_trim", "svt_bayes_gt", "svt_genotype_counts", "svt_genotype", "svt_genotype_multi", "svt_shard_bounds",
-    "svt_pack_evidence", "svt_packed_free", "svt_batch_create_packed", "svt_genotype_packed",
+    "svt_pinned_alloc", "svt_pinned_free", "svt_pack_evidence", "svt_packed_free", "svt_batch_create_packed", "svt_genotype_packed",
     "svt_format_results", "svt_format_free", "svt_results_host_sq",
 )
 
@@ -97,6 +97,10 @@ def load() -> C.CDLL:
     L.svt_genotype_multi.argtypes = [C.POINTER(CEvidenceBatch), C.c_void_p, C.POINTER(C.c_int), C.c_int, C.c_uint32, C.c_uint]
     L.svt_shard_bounds.restype = C.c_int
     L.svt_shard_bounds.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_uint32, C.c_void_p]
+    L.svt_pinned_alloc.restype = C.c_void_p
+    L.svt_pinned_alloc.argtypes = [C.c_size_t]
+    L.svt_pinned_free.restype = None
+    L.svt_pinned_free.argtypes = [C.c_void_p]
     L.svt_pack_evidence.restype = C.c_int
     L.svt_pack_evidence.argtypes = [C.POINTER(CEvidenceBatch), C.POINTER(C.POINTER(CPackedEvidence))]
     L.svt_packed_free.restype = None
@@ -201,6 +205,35 @@ class PackedEvidence:
         self.free()
 
 
+class _PinnedBuffer:
+    def __init__(self, nbytes: int):
+        self._lib = load()
+        self.nbytes = max(int(nbytes), 1)
+        self.ptr = self._lib.svt_pinned_alloc(self.nbytes)
+        if not self.ptr:
+            raise MemoryError("svt_pinned_alloc(%d)" % self.nbytes)
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                self._lib.svt_pinned_free(self.ptr)
+                self.ptr = None
+        except Exception:
+            pass
+
+
+def pinned_results(n_units: int) -> Results:
+    """A Results whose records live in page-locked memory from the library's pool (svt_pinned_alloc)."""
+    from .evidence import RESULT_DTYPE
+    buf = _PinnedBuffer(n_units * RESULT_DTYPE.itemsize)
+    arr = np.ctypeslib.as_array(C.cast(buf.ptr, C.POINTER(C.c_uint8)), shape=(buf.nbytes,))[: n_units * RESULT_DTYPE.itemsize]
+    res = Results.__new__(Results)
+    res.rec = arr.view(RESULT_DTYPE)
+    res.site_qual = None
+    res._pinned = buf          # keeps the buffer alive as long as the Results
+    return res
+
+
 def genotype_packed(packed: PackedEvidence, device: int = 0, flags: int = 0) -> Results:
     """svt_genotype_packed: create_packed + one pass + results + destroy."""
     out = Results.empty(packed.n_units)
@@ -265,8 +298,13 @@ class DeviceBatch:
         _check(self._lib.svt_batch_genotype_timed(self._h, int(iters), C.byref(ms)))
         return float(ms.value)
 
-    def results(self) -> Results:
-        out = Results.empty(self.n_units)
+    def results(self, out: Optional[Results] = None) -> Results:
+        """The result records of the last pass.  `out`: a Results to fill instead of a fresh one -- pinned_results(n)
+        gives one in page-locked memory, which the records reach by straight DMA."""
+        if out is None:
+            out = Results.empty(self.n_units)
+        elif out.n_units != self.n_units:
+            raise ValueError("out must hold n_units records")
         _check(self._lib.svt_batch_results(self._h, C.c_void_p(out.ptr()), self.n_units))
         return out
 

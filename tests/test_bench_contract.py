@@ -44,6 +44,7 @@ def test_bench_line_has_the_contract_keys(hip_device):
     assert 0 < d["large_batch"]["frac"] <= 1.0
     for name in ("short", "dense"):
         assert d["resident_rerun"][name]["results_equal_headline"] is True
+    assert d["one_shot_packed"]["results_equal_headline"] is True and d["one_shot_packed"]["bytes_per_fragment_record"] < 5
 
 
 @pytest.mark.gpu
