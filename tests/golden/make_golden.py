@@ -245,6 +245,25 @@ def make_multisample_vcf(ref):
     print("wrote %s (%d bytes)" % (os.path.basename(path), os.path.getsize(path)))
 
 
+def make_three_sample_vcf(ref):
+    """classic.sv_genotype over three BAMs with a blank sample in the middle, with and without --sum_quals: pins the
+    running QUAL over a site's samples and its reset by a sample without evidence (classic.py:216-217,485,498)."""
+    import tempfile
+    from test_multisample_qual import three_sample_case
+    with tempfile.TemporaryDirectory() as wd:
+        bams, vcf_path, lib_json = three_sample_case(wd)
+        for sum_quals, name in ((True, "three.sumquals.gt.vcf.gz"), (False, "three.gt.vcf.gz")):
+            out = io.StringIO()
+            out.close = lambda: None
+            with open(vcf_path) as fin:
+                ref.classic.sv_genotype(bams, fin, out, 20, 1, 1, 1000000, lib_json, False, None, None, sum_quals, None, 1e10)
+            text = "\n".join(l for l in out.getvalue().split("\n") if not l.startswith("##fileDate="))
+            path = os.path.join(HERE, name)
+            with gzip.GzipFile(path, "wb", mtime=0) as f:
+                f.write(text.encode())
+            print("wrote %s (%d bytes)" % (name, os.path.getsize(path)))
+
+
 if __name__ == "__main__":
     ref = refload.load_reference(pysam_module=bam_module)
     make_bayes_grid(ref)
@@ -252,3 +271,4 @@ if __name__ == "__main__":
     make_fake(ref)
     make_library_from_bam(ref)
     make_multisample_vcf(ref)
+    make_three_sample_vcf(ref)

@@ -574,3 +574,52 @@ def test_sum_of_likelihoods_across_the_underflow_band(hip_device, fixture_librar
         assert (want.gt == ev.GT_MISSING).any() and called.any()
         # the band where 10**GL is subnormal is covered unit by unit
         assert ((best < -308) & (best > -324)).sum() >= 5
+
+
+# ------------------------------------------------------------------------------------------
+# BASELINE.json configs[4] at full per-GPU size: 65 536 sites x 32 samples = 2.1 M units, 66 libraries
+# (per-sample insert-size tables: the streaming kernel's general mode) through size-independent properties
+# ------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def full_c5():
+    import multiprocessing as mp
+    with mp.get_context("fork").Pool(16) as pool:
+        return synth.make_multisample(65_536, 32, synth.BASE_SEED + 5, mean_frags=40.0, sd_frags=12.0, min_frags=8,
+                                      max_frags=80, pool_map=pool.map)
+
+
+def test_full_size_multisample_properties(hip_device, full_c5):
+    from oracle import c_oracle
+    from svtyper_amd import hip
+    batch = full_c5
+    n, S = batch.n_units, 32
+    assert n == 65_536 * S and len(batch.libs) >= 32 and batch.n_records > 60_000_000
+    assert (batch.units["sample"][: 2 * S] == np.tile(np.arange(S), 2)).all()      # site-major
+    with hip.DeviceBatch(batch, device=hip_device) as d:
+        assert d.layout_name() == "stream"
+        d.genotype(sync=True)
+        first = d.results()
+        qual_dev = d.site_qual(S)
+        d.genotype(sync=True)                                    # idempotence
+        assert np.array_equal(d.results().rec, first.rec)
+    base = _digest(first)
+    assert not first.rec["pad"].any()
+    # QUAL over a site's samples: device kernel == the running host sum (classic.py:485,498), bit for bit
+    assert np.array_equal(qual_dev.view(np.uint64), hip.site_qual_host(first, S).view(np.uint64))
+    # split invariance at a site boundary, and the multi-device entry with group = samples per site
+    cut = 21_845 * S
+    lo = hip.genotype_batch(batch.slice(0, cut), device=hip_device)
+    hi = hip.genotype_batch(batch.slice(cut, n), device=hip_device)
+    assert np.array_equal(np.concatenate([_digest(lo), _digest(hi)]), base)
+    multi = hip.genotype_multi(batch, [hip_device] * 3, group=S)
+    assert np.array_equal(_digest(multi), base)
+    assert all(lo_ % S == 0 for lo_, _ in hip.shard_bounds(batch.rec_offset, 3, S))
+    # the tiled layout with library windows agrees on everything
+    assert np.array_equal(hip.genotype_batch(batch, device=hip_device, flags=ev.FLAG_FIXED_PAIR_ENTRIES).rec, first.rec)
+    # the oracle on a bounded random sample of whole sites
+    rng = np.random.default_rng(7)
+    sites = np.sort(rng.choice(65_536, 700, replace=False))
+    pick = (sites[:, None] * S + np.arange(S)[None, :]).reshape(-1)
+    want = c_oracle.genotype_batch(synth.permute_units(batch, pick), flags=0)
+    assert_parity(ev.Results(first.rec[pick].copy()), want)
+    assert {0, 1, 2} <= set(np.unique(first.gt).tolist())

@@ -144,6 +144,43 @@ def test_sso_integration_hip(tmp_path, hip_device, cores):
     same_vcf(EXPECTED, out)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("driver", ["classic", "sso"])
+@pytest.mark.parametrize("geometry,reader", [("host", "python"), ("device", "python"), ("device", "native")])
+def test_small_chunks_through_the_chunk_pipeline_hip(tmp_path, monkeypatch, hip_device, driver, geometry, reader):
+    """The gpu twin of test_small_chunks_through_the_chunk_pipeline: chunk size << 211 so a run is a dozen device
+    batches through the HIP engine -- svt_batch_create / svt_batch_destroy per chunk with the pooled device buffers
+    and the pinned ring reused, chunk k on the worker thread while chunk k+1 is parsed -- and the bytes stay the
+    reference's."""
+    from svtyper_amd import pipeline
+    calls = []
+    real = pipeline.HipEngine(hip_device)
+
+    class Counting:
+        supports_site_qual = True
+
+        def __call__(self, batch, flags=0, **kw):
+            calls.append(batch.n_units)
+            return real(batch, flags, **kw)
+
+        def genotype_fragments(self, fbatch, flags=0, **kw):
+            calls.append(fbatch.n_units)
+            return real.genotype_fragments(fbatch, flags, **kw)
+
+    out = str(tmp_path / "out.vcf")
+    kw = dict(engine=Counting(), geometry=geometry, reader=reader)
+    with open(IN_VCF) as inf, open(out, "w") as outf:
+        if driver == "classic":
+            monkeypatch.setattr(classic, "CHUNK_UNITS", 17)
+            classic.sv_genotype(IN_BAM, inf, outf, 20, 1, 1, 1000000, LIB_JSON, False, None, None, False, None, 1e10, **kw)
+        else:
+            monkeypatch.setattr(singlesample, "CHUNK_UNITS", 17)
+            singlesample.sso_genotype(IN_BAM, inf, outf, 20, 1, 1, 1000000, LIB_JSON, False, None, False, 1000, 1e10,
+                                      None, 1000, **kw)
+    same_vcf(EXPECTED, out)
+    assert len(calls) >= 12 and max(calls) <= 17
+
+
 def test_library_from_bam_matches_reference():
     """Library.from_bam / Sample.from_bam against the statistics the imported reference computed
     from the same BAM (tests/golden/library_from_bam.json.gz)."""

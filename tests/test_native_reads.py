@@ -85,7 +85,7 @@ def test_summaries_equal_python(setup, mode, max_reads, threads):
 # hard clips, insertions, deletions, N gaps, several SA entries, secondary / supplementary /
 # duplicate / unmapped flags, MAPQ 255, B-typed tags in front of the ones that matter
 # ------------------------------------------------------------------------------------------
-def _synthetic_bam(path, seed=11, n_pairs=700, sample="syn"):
+def _synthetic_bam(path, seed=11, n_pairs=700, sample="syn", only_sites=None):
     import bamwriter as bw
     rng = np.random.default_rng(seed)
     refs = [("1", 200_000), ("2", 100_000)]
@@ -109,8 +109,9 @@ def _synthetic_bam(path, seed=11, n_pairs=700, sample="syn"):
               "25S50M25S", "10S90M", "70M30S", "45M3D20M5I30M", "15H15S70M"]
     tid_of = {"1": 0, "2": 1}
     recs = []
+    covered = list(range(len(sites))) if only_sites is None else list(only_sites)   # the other sites get no read at all
     for k in range(n_pairs):
-        bp = sites[k % len(sites)]
+        bp = sites[covered[k % len(covered)]]
         side = ("A", "B")[int(rng.integers(2))]
         tid = tid_of[bp[side]["chrom"]]
         pos1 = int(bp[side]["pos"] + rng.integers(-450, 150))
