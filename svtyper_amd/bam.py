@@ -398,7 +398,9 @@ class AlignmentFile:
             self._bgzf.seek(self._first_record)
             while True:
                 r = self._next_record()
-                if r is None:
+                # pysam walks an indexed file reference by reference (IteratorRowAllRefs): the unplaced unmapped
+                # reads at the end of a coordinate-sorted BAM (reference id -1) are never yielded
+                if r is None or r.reference_id < 0:
                     return
                 yield r
         tid = self.gettid(reference)

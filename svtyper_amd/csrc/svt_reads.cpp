@@ -571,8 +571,8 @@ int split_candidate(const svt_bam& bam, const Record& r, Split& out)
     bool malformed = false;
     const char* sa = find_z_tag(r, 'S', 'A', &malformed);
     if (malformed) return -1;
+    if (r.cigar.empty()) return 0;   // a mapped read without a CIGAR cannot be a split candidate (fragments.py: add_read)
     if (!sa) {   // the common read: no SA tag and no clipped end -> not a candidate, nothing to build
-        if (r.cigar.empty()) return -1;
         if (!is_clip(r.cigar.front().first) && !is_clip(r.cigar.back().first)) return 0;
     }
     Piece a;
@@ -584,7 +584,6 @@ int split_candidate(const svt_bam& bam, const Record& r, Split& out)
     a.cigar = r.cigar;
     a.qp = query_pos_from_cigar(a.cigar, a.reverse);
     if (!sa) {
-        if (r.cigar.empty()) return -1;
         const bool fc = is_clip(r.cigar.front().first), lc = is_clip(r.cigar.back().first);
         if (!(fc || lc)) return 0;
         const int64_t clip_length = std::max(r.cigar.front().second * (fc ? 1 : 0), r.cigar.back().second * (lc ? 1 : 0));
@@ -723,11 +722,11 @@ inline PieceOut piece_out(const Piece& p)
 
 bool fill_piece(svt_piece_summary& d, const PieceOut& p)
 {
-    if (p.mapq < 0 || p.mapq > 255) return false;
+    if (p.mapq < 0) return false;
     d.tid = p.tid;
     d.start = clip32(p.start);
     d.end = clip32(p.end);
-    d.mapq = (uint8_t)p.mapq;
+    d.mapq = (uint8_t)std::min<int64_t>(p.mapq, 255);   // an SA-tag MAPQ above 255: prob_mapq is exactly 1.0 from 163 on (packer.py: _mapq)
     d.flags = (uint8_t)(SVT_READ_PRESENT | (p.reverse ? SVT_READ_REVERSE : 0));
     return true;
 }
@@ -1221,7 +1220,9 @@ static int svt_bam_scan_library_impl(const svt_bam* bam, uint32_t n_read_groups,
 
     // calc_read_length (parsers.py:516-528)
     z.seek(bam->first_record);
-    for (int64_t seen = 0; read_record(z, buf, r);) {
+    // (an indexed file is walked reference by reference, pysam's IteratorRowAllRefs: the unplaced unmapped reads a
+    //  coordinate-sorted BAM ends with -- reference id -1 -- are never seen by the reference)
+    for (int64_t seen = 0; read_record(z, buf, r) && r.tid >= 0;) {
         const int in = in_library(r);
         if (in < 0) return no_rg(r);
         if (!in) continue;
@@ -1235,7 +1236,7 @@ static int svt_bam_scan_library_impl(const svt_bam* bam, uint32_t n_read_groups,
     std::vector<uint64_t> hist_counts;
     std::unordered_map<int64_t, size_t> hist_slot;
     z.seek(bam->first_record);
-    for (int64_t n = 0; n != num_samp && read_record(z, buf, r);) {
+    for (int64_t n = 0; read_record(z, buf, r) && r.tid >= 0;) {
         if ((r.flag & 0x10) || !(r.flag & 0x20) || (r.flag & (0x4 | 0x8)) || (r.flag & (0x100 | 0x800))) continue;
         if (r.tlen <= 0) continue;
         const int in = in_library(r);
@@ -1249,11 +1250,11 @@ static int svt_bam_scan_library_impl(const svt_bam* bam, uint32_t n_read_groups,
         } else {
             ++hist_counts[slot->second];
         }
-        ++n;
+        if (++n == num_samp) break;    // parsers.py:571-573: tested after the increment, so -n 0 scans the whole file
     }
     // calc_lib_prevalence (parsers.py:501-513)
     z.seek(bam->first_record);
-    while (out->total != 100000 && read_record(z, buf, r)) {
+    while (out->total != 100000 && read_record(z, buf, r) && r.tid >= 0) {
         const int in = in_library(r);
         if (in < 0) return no_rg(r);
         out->in_lib += (uint64_t)in;

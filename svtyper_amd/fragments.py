@@ -246,9 +246,12 @@ class SamFragment:
             return
         self.primary_reads.append(read)
         self.num_primary += 1
-        candidate = SplitRead(read, self.lib)
-        if candidate.is_valid():
-            self.split_reads.append(candidate)
+        # a mapped read without a CIGAR ('*') cannot be a split candidate (the reference indexes cigar[0] and
+        # dies on such a record; one odd read must not end a whole-genome job)
+        if read.cigar:
+            candidate = SplitRead(read, self.lib)
+            if candidate.is_valid():
+                self.split_reads.append(candidate)
         if self.num_primary == 2:
             self.readA, self.readB = self.primary_reads
 

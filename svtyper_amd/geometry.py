@@ -72,9 +72,9 @@ def _clip32(x) -> int:
 
 def _mapq8(q) -> int:
     q = int(q)
-    if q < 0 or q > 255:
+    if q < 0:
         raise ValueError("MAPQ %d does not fit the fragment summary (0..255)" % q)
-    return q
+    return min(q, 255)      # prob_mapq(q) is exactly 1.0 from q = 163 on (packer._mapq)
 
 
 _ABSENT_READ = [-1, 0, 0, 0, 0, 0, 0, 0]   # 8 words of a svt_read_summary

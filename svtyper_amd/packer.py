@@ -27,10 +27,13 @@ _I32_MIN = -(2**31)
 
 
 def _mapq(x) -> int:
+    """MAPQ as the record's byte.  A value above 255 (only an SA tag can carry one: BAM's own field is a byte) is
+    stored as 255: prob_mapq(q) = 1 - 10**(-q / 10) is exactly 1.0 in binary64 for every q >= 163, so the weight the
+    reference would compute is unchanged.  A negative one has no counterpart in the record."""
     q = int(x)
-    if q < 0 or q > 255:
+    if q < 0:
         raise ValueError("MAPQ %d does not fit the evidence record (0..255)" % q)
-    return q
+    return min(q, 255)
 
 
 def _clamp32(x) -> int:

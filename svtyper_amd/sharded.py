@@ -78,6 +78,11 @@ def plan_shards(body: Sequence[str], world: int) -> List[List[int]]:
         plan[moved_to.get(i, owner(i))].append(i)
     for p in plan:
         p.sort()
+    if n and not plan[0]:
+        # every line of rank 0's range was a first mate handed to a later rank: rank 0 would then never see a body
+        # line, and the drivers write the VCF header when they meet the first one (classic.py:166-176) -- the gathered
+        # output would have no header at all.  Inputs that small do not need sharding: one rank takes everything.
+        return [list(range(n))] + [[] for _ in range(world - 1)]
     return plan
 
 

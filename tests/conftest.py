@@ -33,9 +33,15 @@ def fixture_library():
 
 
 @pytest.fixture(scope="session")
-def hip_device():
-    """Loads the HIP library and requires a device; fails loudly otherwise."""
+def hip_device(request):
+    """Loads the HIP library and requires a device.  A run that ASKED for the gpu tests (`-m gpu`, or
+    SVT_REQUIRE_GPU=1) fails loudly without one -- a missing device must never look like a green run; a plain
+    `pytest tests` on a box without an MI355X skips the gpu-marked tests instead of erroring at the first one."""
     from svtyper_amd import hip
     hip.load()
-    assert hip.device_count() > 0, "no MI355X visible: the gpu-marked tests need the real device"
+    if hip.device_count() <= 0:
+        asked = request.config.getoption("-m") or ""
+        if os.environ.get("SVT_REQUIRE_GPU") == "1" or ("gpu" in asked and "not gpu" not in asked):
+            pytest.fail("no MI355X visible: the gpu-marked tests need the real device")
+        pytest.skip("no MI355X visible (run with -m gpu or SVT_REQUIRE_GPU=1 to make this a failure)")
     return 0

@@ -231,3 +231,62 @@ def test_both_inflate_decoders_give_the_same_summaries(tmp_path):
         assert r.returncode == 0, r.stderr[-500:]
         outs.append(r.stdout.strip())
     assert outs[0] == outs[1] and len(outs[0]) > 64
+
+
+def _small_bam_with_unplaced_tail(path, n_pairs=40, n_unplaced=30):
+    """A coordinate-sorted BAM that ends with unplaced unmapped reads (reference id -1), one of them without an RG
+    tag; few enough placed reads that whole-file scans would reach them."""
+    import bamwriter as bw
+    rng = np.random.default_rng(3)
+    header = "@HD\tVN:1.5\tSO:coordinate\n@SQ\tSN:1\tLN:100000\n@RG\tID:rgA\tSM:s\tLB:libA\n"
+    recs = []
+    for k in range(n_pairs):
+        p = 1000 + 50 * k
+        ins = int(rng.integers(250, 400))
+        for mate, (pos, mpos, rev) in enumerate(((p, p + ins - 100, False), (p + ins - 100, p, True))):
+            flag = 0x1 | 0x2 | (0x40 if mate == 0 else 0x80) | (0x10 if rev else 0x20)
+            recs.append(dict(name="p%03d" % k, flag=flag, tid=0, pos=pos, mapq=60, cigar="100M", mtid=0, mpos=mpos,
+                             tlen=ins if not rev else -ins, tags=[("RG", "Z", "rgA")]))
+    recs.sort(key=lambda r: (r["tid"], r["pos"]))
+    for k in range(n_unplaced):                     # after every placed read, as samtools sort leaves them
+        tags = [("RG", "Z", "rgA")] if k != 7 else []
+        recs.append(dict(name="u%03d" % k, flag=0x1 | 0x4 | 0x8 | (0x40 if k % 2 == 0 else 0x80), tid=-1, pos=-1, mapq=0,
+                         cigar="*", mtid=-1, mpos=-1, tlen=0, tags=tags))
+    bw.write_bam(path, header, [("1", 100000)], recs, block_bytes=900)
+    return 2 * n_pairs
+
+
+def test_whole_file_scans_stop_at_the_unplaced_reads(tmp_path):
+    """pysam's fetch() on an indexed BAM walks reference by reference and never yields the unplaced unmapped reads
+    at the end; both readers follow it -- the prevalence denominator, the read length and the -l JSON would differ
+    otherwise, and an unplaced read without RG would abort a run the reference completes."""
+    path = str(tmp_path / "tail.bam")
+    n_placed = _small_bam_with_unplaced_tail(path)
+    pybam = bam.AlignmentFile(path)
+    assert sum(1 for _ in pybam.fetch()) == n_placed
+    assert all(r.reference_id == 0 for r in pybam.fetch())
+    for num_samp in (1000000, 5, 0):                 # 0: the reference's `n == num_samp` test never fires -> whole file
+        a = library.Library.from_bam("libA", pybam, num_samp)
+        b = library.Library.from_bam("libA", pybam, num_samp, native=nr.NativeBam(path))
+        assert (a.read_length, a.mean, a.sd, a.prevalence) == (b.read_length, b.mean, b.sd, b.prevalence)
+        assert list(a.hist.items()) == list(b.hist.items())
+        assert a.prevalence == 1.0 and a.read_length == 100
+        assert sum(a.hist.values()) == (5 if num_samp == 5 else n_placed // 2)
+
+
+def test_odd_records_do_not_end_the_run():
+    """An SA-tag MAPQ above 255 is stored as 255 (prob_mapq is exactly 1.0 from 163 on); a mapped primary without a
+    CIGAR is simply not a split candidate."""
+    import fakereads
+    from svtyper_amd import fragments as fr, packer, geometry
+    assert packer._mapq(255) == 255 and packer._mapq(300) == 255 and geometry._mapq8(100000) == 255
+    assert 1 - 10 ** (-163 / 10.0) == 1.0 and 1 - 10 ** (-255 / 10.0) == 1.0 and 1 - 10 ** (-1000 / 10.0) == 1.0
+    with pytest.raises(ValueError):
+        packer._mapq(-1)
+
+    class _L:
+        mean, sd = 300.0, 50.0
+    r = fakereads.FakeRead("q", 0x1 | 0x40, "1", 1000, "", 60)
+    assert not r.cigar
+    f = fr.SamFragment(r, _L())
+    assert f.num_primary == 1 and f.split_reads == []

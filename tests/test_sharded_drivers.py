@@ -79,6 +79,32 @@ def test_plan_keeps_pairs_whole_and_order():
     assert sharded.plan_shards(body, 4) == [list(range(20)), [], [], []]
 
 
+def test_rank_zero_never_ends_up_without_a_body_line(tmp_path):
+    """Fewer lines than ranks with BND pairs: every line of rank 0's range is a first mate handed to a later rank.
+    The drivers write the header at their first body line, so rank 0 must keep one (here: the whole input)."""
+    pair = [_bnd("1", 2, "a_1", "a_2", "N[1:50["), _bnd("1", 50, "a_2", "a_1", "]1:2]N")]
+    assert sharded.plan_shards(pair, 2) == [[0, 1], []]
+    assert sharded.plan_shards(pair, 5) == [[0, 1], [], [], [], []]
+    three = pair + ["1\t90\tv\tN\t<DEL>\t0\t.\tSVTYPE=DEL;END=190\n"]
+    for world in (2, 3, 4):
+        plan = sharded.plan_shards(three, world)
+        assert plan[0] and sorted(i for p in plan for i in p) == [0, 1, 2]
+    # and the joined output of such an input has its header
+    lines = open(H.IN_VCF).read().splitlines(True)
+    head = [l for l in lines if l.startswith("#")]
+    in_path = str(tmp_path / "pair.vcf")
+    open(in_path, "w").write("".join(head + pair))
+    want = _single(classic.sv_genotype, in_path, _classic_args())
+    got = ""
+    for rank, mine in enumerate(sharded.plan_shards(pair, 2)):
+        sink = sharded._Sink()
+        classic.sv_genotype(H.IN_BAM, sharded._Lines(head + [pair[i] for i in mine], in_path), sink, *_classic_args(),
+                            engine=H.oracle_engine)
+        text = sink.getvalue()
+        got += text if rank == 0 else "".join(l for l in text.splitlines(True) if not l.startswith("#"))
+    assert got == want and got.startswith("##fileformat")
+
+
 @pytest.mark.parametrize("driver", ["classic", "sso"])
 @pytest.mark.parametrize("world", [2, 3, 5])
 def test_concatenated_shares_equal_the_single_run(tmp_path, driver, world):
