@@ -38,7 +38,7 @@
 #define SVT_STREAM_AUX 2   // cache policy bits of the record fetches (2 = nt: every line is used once)
 #endif
 #ifndef SVT_STREAM_PROBE
-#define SVT_STREAM_PROBE 0 // timing-only builds (wrong results): 1 = fetch without the record arithmetic, 2 = arithmetic without fetches
+#define SVT_STREAM_PROBE 0 // timing-only builds (wrong results): 1 = fetch without the record arithmetic, 2 = arithmetic without fetches, 3 = no epilogue
 #endif
 #ifndef SVT_STREAM_SPLIT
 #define SVT_STREAM_SPLIT 4 // scheduling barrier before this record of a block (8 = none)
@@ -348,6 +348,10 @@ __global__ __launch_bounds__(kBlock, MODE == kSingleLds ? SVT_STREAM_WAVES : 2) 
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         uint4 piece[8];
+        if (SVT_STREAM_PROBE == 3) {   // timing only: the records leave without the likelihood / decision arithmetic
+#pragma unroll
+            for (int p = 0; p < 8; ++p) piece[p] = pack2d(acc.ref_seq + p, acc.alt_span);
+        } else
         unit_epilogue(acc, (uint32_t)U.svtype, (uint32_t)U.flags, a.c, lds_l10, a.l10, a.l10_where != kL10Global, piece);
 
         store_results_through_ring(ring, piece, unit, lane, a.out);
