@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SVT_ABI_VERSION 8
+#define SVT_ABI_VERSION 9
 
 /* ---- error codes (0 = ok, <0 = error; text via svt_last_error()) ---------- */
 #define SVT_OK 0
@@ -143,8 +143,16 @@ typedef struct svt_unit {
     uint16_t sample;    /* sample index (informational; libraries are per record) */
     uint8_t svtype;     /* SVT_SVTYPE_*                                          */
     uint8_t flags;      /* SVT_UNIT_* bits                                       */
-    uint32_t reserved;  /* must be 0                                             */
+    uint32_t libs;      /* optional hint, SVT_UNIT_LIBS(first, count): the libraries of
+                           the unit's sample (sample.lib_dict, parsers.py:432-447) are
+                           libs[first .. first + count) of the batch and every record
+                           of the unit names one of them; 0 = no hint.  With the hint
+                           on every unit of a several-library batch the pass stages
+                           only a sample's histograms per workgroup;
+                           a record outside its unit's window is a contract violation.
+                           Upper 16 bits must be 0.                               */
 } svt_unit;
+#define SVT_UNIT_LIBS(first, count) ((uint32_t)(first) | (uint32_t)(count) << 8)
 
 #define SVT_UNIT_SKIP (1u << 0) /* too many reads: GT './.' only (classic.py:282-284,
                                    singlesample.py:478-480)                      */
@@ -224,7 +232,8 @@ typedef struct svt_breakpoint {
     uint8_t svtype;                  /* SVT_SVTYPE_* */
     uint8_t flags;                   /* bit0: side A is_reverse, bit1: side B is_reverse,
                                         bit2: SVT_UNIT_SKIP                                       */
-    uint32_t reserved[2];
+    uint32_t reserved[2];            /* [0]: SVT_UNIT_LIBS(first, count) hint of the unit's sample, 0 = none (svt_unit.libs);
+                                        [1]: must be 0                                            */
 } svt_breakpoint;
 #define SVT_BP_REV_A (1u << 0)
 #define SVT_BP_REV_B (1u << 1)

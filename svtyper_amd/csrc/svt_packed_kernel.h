@@ -87,7 +87,7 @@ __global__ __launch_bounds__(kBlock, 3) void svt_packed_kernel(const PackedArgs 
         for (uint32_t i = tid; i < a.n_l10; i += kBlock) s_l10[i] = a.l10[i];
     }
     uint4 info[R];
-    wg_sort_into_tiles<R>(rings, beg, cnt, wg_base, a.n_units, tid, lane, wave, info);
+    wg_sort_into_tiles<R>(rings, beg, cnt, (uint32_t)min((uint64_t)kUnitsPerWg, a.n_units - wg_base), tid, lane, wave, info);
 
     unsigned char* ring = rings + wave * kRingBytes;
     const uint32_t ring_addr = (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)ring;

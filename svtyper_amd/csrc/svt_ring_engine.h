@@ -89,12 +89,12 @@ __device__ __forceinline__ void fetch_block(const uint32_t k, const uint32_t (&s
 }
 
 // The workgroup's 256 * R units -> R tiles per wave, longest units first.  beg / cnt: first item and item count of
-// the thread's R units (unit wg_base + j * 256 + tid).  info[r] = {first item, items, local unit or kPadUnit, 0} of
+// the thread's R units (local index j * 256 + tid; `n_here` of them exist).  info[r] = {first item, items, local index or kPadUnit, 0} of
 // this lane's unit in the wave's r-th tile.  The sort scratch lives in the rings: call before any streaming;
 // the rings are free again when this returns (it ends with a barrier, which also covers the caller's table staging).
 template <int R>
 __device__ __forceinline__ void wg_sort_into_tiles(unsigned char* rings, const uint32_t (&beg)[R], const uint32_t (&cnt)[R],
-                                                   const uint64_t wg_base, const uint64_t n_units, const uint32_t tid,
+                                                   const uint32_t n_here, const uint32_t tid,
                                                    const uint32_t lane, const uint32_t wave, uint4 (&info)[R])
 {
     uint32_t* s_hist = reinterpret_cast<uint32_t*>(rings);      // kMaxSortKey + 1 buckets
@@ -129,8 +129,8 @@ __device__ __forceinline__ void wg_sort_into_tiles(unsigned char* rings, const u
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < R; ++j) {
-        const uint64_t u = wg_base + (uint32_t)j * kBlock + tid;
-        s_info[s_start[key[j]] + rank[j]] = make_uint4(beg[j], cnt[j], u < n_units ? (uint32_t)j * kBlock + tid : kPadUnit, 0u);
+        const uint32_t local = (uint32_t)j * kBlock + tid;
+        s_info[s_start[key[j]] + rank[j]] = make_uint4(beg[j], cnt[j], local < n_here ? local : kPadUnit, 0u);
     }
     __syncthreads();
     // the r-th tile of this wave in snake order

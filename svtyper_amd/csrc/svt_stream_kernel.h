@@ -89,25 +89,46 @@ struct StreamArgs {
     uint64_t n_units;
     svt_result* out;
     uint32_t* err;
+    // kMultiLds: units grouped by the library window of their sample (svt_unit.libs)
+    const uint32_t* perm;        // unit indices, grouped by window, original order inside a group
+    const uint2* chunks;         // one per workgroup: {first position in perm, units (<= 256 * R)} -- never crosses a group
+    const WgDesc* windows;       // one per workgroup: the libraries / bins it stages
+    uint32_t lds_winlibs;        // byte offset of the WinLib descriptors (after the bins)
+    uint32_t pad0;
     LibDesc lib0;
     GtConsts c;
 };
+
+// kMultiLds: one library of the workgroup's window, 32 bytes in LDS
+struct WinLib {
+    uint32_t kmin;      // (uint32) key_min
+    uint32_t nb;        // n_bins == index of the library's sentinel bin
+    uint32_t thr_at;    // LDS byte address of this library's thr[0]
+    uint32_t hist_at;   // LDS byte address of this library's hist[0]
+    double sd2;         // 2 * sd: the small-deletion gate (classic.py:339,383)
+    double pad;
+};
+static_assert(sizeof(WinLib) == 32, "WinLib is read as two 16-byte halves");
 
 // The record contract of include/svtyper_hip.h, accumulated over the records of a lane's units at 3-4
 // instructions per record.
 template <int MODE>
 struct RecordCheck {
     uint32_t flags_or = 0, span_or = 0, lone = 0, lib_max = 0;
-    __device__ __forceinline__ void see(const u32x4 w)
+    __device__ __forceinline__ void see(const u32x4 w, const uint32_t lib_lo = 0u)
     {
         flags_or |= w.w;                                     // undefined bits; with one library also the library byte
         span_or |= w.x;                                      // sign bit: a negative ospan_len
         lone = max(lone, (w.w & 0x17u) ^ 0x10u);             // > 0x10: straddle bits without HAS_PAIR
-        if (MODE != kSingleLds) lib_max = max(lib_max, w.w & 0xff00u);
+        if (MODE == kGeneral) lib_max = max(lib_max, w.w & 0xff00u);
+        if (MODE == kMultiLds) lib_max = max(lib_max, SVT_REC_LIB(w.w) - lib_lo);   // (unsigned: below the window = huge)
     }
-    __device__ __forceinline__ uint32_t bits(const uint32_t n_libs) const
+    // kMultiLds: `limit` = libraries in the unit's window
+    __device__ __forceinline__ uint32_t bits(const uint32_t limit) const
     {
-        const bool bad_lib = MODE == kSingleLds ? (flags_or & 0xff00u) != 0u : (lib_max >> SVT_REC_LIB_SHIFT) >= n_libs;
+        const uint32_t n_libs = limit;
+        const bool bad_lib = MODE == kSingleLds ? (flags_or & 0xff00u) != 0u
+                             : MODE == kMultiLds ? lib_max >= limit : (lib_max >> SVT_REC_LIB_SHIFT) >= n_libs;
         return (lone > 0x10u ? kErrStraddleNoPair : 0u) | (bad_lib ? kErrLibIndex : 0u) |
                ((flags_or & ~SVT_REC_FLAG_MASK) ? kErrReservedBits : 0u) | ((int32_t)span_or < 0 ? kErrNegativeSpan : 0u);
     }
@@ -128,8 +149,9 @@ struct StreamCtx {
 // instruction.  (pm(l) * L + pm(r) * R) / 2.0 (classic.py:324) is taken as pm(l)/2 + pm(r)/2 from a second
 // table: halving a binary64 in [0.2, 1] is exact, so the sum rounds identically.  EDGE: the record may belong
 // to a neighbouring unit -- its weight bytes are then read as MAPQ 0, which adds +0.0 to every sum.
+// the split-read / reference-read part of a record (classic.py:306-328); returns pm(mapq_a) * pm(mapq_b)
 template <bool SSO, bool EDGE>
-__device__ __forceinline__ void record_single(const u32x4 w, const bool mine, const StreamCtx& c, Acc& a)
+__device__ __forceinline__ double record_weights(const u32x4 w, const bool mine, Acc& a)
 {
     const uint32_t wy = EDGE ? (mine ? w.y : 0u) : w.y;   // mapq_a | mapq_b << 8 | rs_a << 16 | rs_b << 24
     const uint32_t wz = EDGE ? (mine ? w.z : 0u) : w.z;   // seq_l | seq_r << 8 | clip_l << 16 | clip_r << 24
@@ -150,13 +172,53 @@ __device__ __forceinline__ void record_single(const u32x4 w, const bool mine, co
         a.alt_seq += p_seq;
         a.alt_clip += p_clip;
     }
+    return pm_a * pm_b;
+}
+
+template <bool SSO, bool EDGE>
+__device__ __forceinline__ void record_single(const u32x4 w, const bool mine, const StreamCtx& c, Acc& a)
+{
+    const double pp = record_weights<SSO, EDGE>(w, mine, a);
     // p_concordant as the integer test hist[o - v] <= thr[o] (svt_host_tables.h), out-of-range -> sentinel bin
     const uint32_t i1 = min(w.x - c.kmin, c.nb), i2 = min(w.x - c.sub2, c.nb);
     const int32_t thr1 = lds_i32(kSBins + (i1 << 2));
     const uint32_t h2 = lds_u32(c.hist_at + (i2 << 2));
     const bool p_conc = (int32_t)h2 <= thr1;
     const uint32_t wa = (p_conc ? c.wt1 : c.wt0) | ((w.w & c.fmask) << 3);   // &w_alt[f3 | p_conc << 3 | del16]
-    const double pp = pm_a * pm_b;
+    a.alt_span += pp * lds_f64(wa);
+    a.ref_span += pp * lds_f64(wa + kSWref);
+}
+
+// per-lane constants of the unit for the library-window consumer
+struct WindowCtx {
+    uint32_t lib_lo;       // first library of the workgroup's window
+    uint32_t lib_last;     // libraries in the window - 1
+    uint32_t winlibs_at;   // LDS byte address of the window's WinLib descriptors
+    uint32_t vl_or_never;  // DEL ? var_length : 0x80000000 - key_min is added per library
+    uint32_t wt0, wt1;
+    double pos_delta_d;
+    bool is_del;
+};
+
+typedef __attribute__((address_space(3))) const u32x4 lds_cu32x4;
+
+// The same record with several libraries: the record's library picks one of the window's descriptors (a
+// record that names a library outside its unit's window is reported by RecordCheck and reads the nearest one).
+template <bool SSO, bool EDGE>
+__device__ __forceinline__ void record_window(const u32x4 w, const bool mine, const WindowCtx& c, Acc& a)
+{
+    const double pp = record_weights<SSO, EDGE>(w, mine, a);
+    const uint32_t la = c.winlibs_at + min(SVT_REC_LIB(w.w) - c.lib_lo, c.lib_last) * (uint32_t)sizeof(WinLib);
+    const u32x4 d = *reinterpret_cast<lds_cu32x4*>((size_t)la);          // kmin, nb, thr_at, hist_at
+    const double sd2 = lds_f64(la + 16u);
+    const bool small_del = c.is_del && (c.pos_delta_d < sd2);             // classic.py:339,383
+    const uint32_t f3 = small_del ? 0u : (w.w & 7u);
+    const uint32_t sub2 = c.is_del ? c.vl_or_never + d.x : 0x80000000u;
+    const uint32_t i1 = min(w.x - d.x, d.y), i2 = min(w.x - sub2, d.y);
+    const int32_t thr1 = lds_i32(d.z + (i1 << 2));
+    const uint32_t h2 = lds_u32(d.w + (i2 << 2));
+    const bool p_conc = (int32_t)h2 <= thr1;
+    const uint32_t wa = (p_conc ? c.wt1 : c.wt0) | (f3 << 3);
     a.alt_span += pp * lds_f64(wa);
     a.ref_span += pp * lds_f64(wa + kSWref);
 }
@@ -164,26 +226,38 @@ __device__ __forceinline__ void record_single(const u32x4 w, const bool mine, co
 template <bool SSO, int MODE, int R>
 __global__ __launch_bounds__(kBlock, MODE == kSingleLds ? SVT_STREAM_WAVES : 2) void svt_stream_kernel(const StreamArgs a)
 {
-    static_assert(MODE == kSingleLds || MODE == kGeneral, "library windows are not used by the streaming kernel");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // (lds_rings is 128-byte aligned)
     constexpr uint32_t kUnitsPerWg = kBlock * R;
     double* s_pm = reinterpret_cast<double*>(smem + kSPm);
     PairWeights* s_wtab = reinterpret_cast<PairWeights*>(smem + kSWtab);   // kGeneral
     LibDesc* s_lib = reinterpret_cast<LibDesc*>(smem + kSBins);            // kGeneral
     // the one-library consumer addresses the tables by absolute LDS byte offsets
-    if (MODE == kSingleLds && (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)smem != 0u) __builtin_trap();
+    if (MODE != kGeneral && (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)smem != 0u) __builtin_trap();
     unsigned char* rings = smem + a.lds_rings;
     const uint32_t tid = threadIdx.x, wave = tid / kWave, lane = tid % kWave;
-    const uint64_t wg_base = (uint64_t)blockIdx.x * kUnitsPerWg;
+    // this workgroup's units: 256 * R consecutive ones, or (library windows) a chunk of the permutation that groups
+    // the units by the libraries of their sample
+    uint32_t wg_base = blockIdx.x * kUnitsPerWg, n_here;
+    WgDesc wd{};
+    if (MODE == kMultiLds) {
+        const uint2 ch = a.chunks[blockIdx.x];
+        wg_base = ch.x;
+        n_here = ch.y;
+        wd = a.windows[blockIdx.x];
+    } else {
+        n_here = (uint32_t)min((uint64_t)kUnitsPerWg, a.n_units - wg_base);
+    }
+    auto unit_at = [&](const uint32_t local) -> uint32_t { return MODE == kMultiLds ? a.perm[wg_base + local] : wg_base + local; };
 
     // ---- this thread's R units: record range and sort key (the loads overlap the table staging below)
     uint32_t beg[R], cnt[R];
 #pragma unroll
     for (int j = 0; j < R; ++j) {
-        const uint64_t u = wg_base + (uint32_t)j * kBlock + tid;
+        const uint32_t local = (uint32_t)j * kBlock + tid;
         beg[j] = 0u;
         cnt[j] = 0u;
-        if (u < a.n_units) {
+        if (local < n_here) {
+            const uint32_t u = unit_at(local);
             const uint64_t lo = a.rec_offset[u], hi = a.rec_offset[u + 1];
             beg[j] = (uint32_t)lo;
             cnt[j] = (uint32_t)(hi - lo);
@@ -198,7 +272,7 @@ __global__ __launch_bounds__(kBlock, MODE == kSingleLds ? SVT_STREAM_WAVES : 2) 
     }
     if (tid < 32) {
         const PairWeights pw = a.wtab[tid];
-        if (MODE == kSingleLds) {
+        if (MODE != kGeneral) {
             reinterpret_cast<double*>(smem + kSWtab)[tid] = pw.w_alt;
             reinterpret_cast<double*>(smem + kSWtab + kSWref)[tid] = pw.w_ref;
         } else {
@@ -214,6 +288,26 @@ __global__ __launch_bounds__(kBlock, MODE == kSingleLds ? SVT_STREAM_WAVES : 2) 
             s_thr[i] = bn.thr;
             s_hst[i] = bn.hist;
         }
+    } else if (MODE == kMultiLds) {
+        // the window's bins as thr[bin_cnt], hist[bin_cnt] and one WinLib per library of the window
+        int32_t* s_thr = reinterpret_cast<int32_t*>(smem + kSBins);
+        uint32_t* s_hst = reinterpret_cast<uint32_t*>(smem + kSBins) + wd.bin_cnt;
+        for (uint32_t i = tid; i < wd.bin_cnt; i += kBlock) {
+            const Bin bn = a.bins[wd.bin_lo + i];
+            s_thr[i] = bn.thr;
+            s_hst[i] = bn.hist;
+        }
+        if (tid < wd.lib_cnt) {
+            const LibDesc L = a.libs[wd.lib_lo + tid];
+            WinLib wl;
+            wl.kmin = (uint32_t)L.key_min;
+            wl.nb = L.n_bins;
+            wl.thr_at = kSBins + (L.tab_off - wd.bin_lo) * 4u;
+            wl.hist_at = kSBins + (wd.bin_cnt + L.tab_off - wd.bin_lo) * 4u;
+            wl.sd2 = L.sd2;
+            wl.pad = 0.0;
+            reinterpret_cast<WinLib*>(smem + a.lds_winlibs)[tid] = wl;
+        }
     } else {
         for (uint32_t i = tid; i < a.n_libs * (uint32_t)(sizeof(LibDesc) / 8); i += kBlock)
             reinterpret_cast<uint64_t*>(s_lib)[i] = reinterpret_cast<const uint64_t*>(a.libs)[i];
@@ -224,7 +318,7 @@ __global__ __launch_bounds__(kBlock, MODE == kSingleLds ? SVT_STREAM_WAVES : 2) 
     }
     // ---- counting sort of the workgroup's units by block count, longest first; R tiles per wave
     uint4 info[R];
-    wg_sort_into_tiles<R>(rings, beg, cnt, wg_base, a.n_units, tid, lane, wave, info);
+    wg_sort_into_tiles<R>(rings, beg, cnt, n_here, tid, lane, wave, info);
 
     Tables t;   // kGeneral: tables through ordinary pointers, bins through L2
     t.pm = s_pm;
@@ -253,7 +347,7 @@ __global__ __launch_bounds__(kBlock, MODE == kSingleLds ? SVT_STREAM_WAVES : 2) 
 #endif
     for (int r = 0; r < R; ++r) {
         const uint32_t first_rec = info[r].x, n_rec = info[r].y;
-        const uint32_t unit = info[r].z == kPadUnit ? kPadUnit : (uint32_t)wg_base + info[r].z;   // n_units < 2^32
+        const uint32_t unit = info[r].z == kPadUnit ? kPadUnit : unit_at(info[r].z);
         svt_unit U{};
         if (unit != kPadUnit) U = a.units[unit];
         const uint32_t head = first_rec & 7u, last = head + n_rec;
@@ -294,11 +388,31 @@ __global__ __launch_bounds__(kBlock, MODE == kSingleLds ? SVT_STREAM_WAVES : 2) 
             sc.wt0 = kSWtab + c.del16 * 8u;
             sc.wt1 = sc.wt0 + 8u * 8u;
         }
+        if (MODE == kMultiLds) {
+            // a window of ONE library (the usual sample) takes the one-library consumer with that library's constants
+            const WinLib w0 = reinterpret_cast<const WinLib*>(smem + a.lds_winlibs)[0];
+            const bool small_del = c.is_del && (c.pos_delta_d < w0.sd2);
+            sc.fmask = small_del ? 0u : 7u;
+            sc.kmin = w0.kmin;
+            sc.nb = w0.nb;
+            sc.sub2 = c.is_del ? (uint32_t)U.var_length + w0.kmin : 0x80000000u;
+            sc.hist_at = w0.hist_at;
+        }
+        WindowCtx wc;  // kMultiLds
+        wc.lib_lo = wd.lib_lo;
+        wc.lib_last = wd.lib_cnt - 1u;
+        wc.winlibs_at = a.lds_winlibs;
+        wc.vl_or_never = (uint32_t)U.var_length;
+        wc.wt0 = sc.wt0;
+        wc.wt1 = sc.wt1;
+        wc.pos_delta_d = c.pos_delta_d;
+        wc.is_del = c.is_del;
         Acc acc = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
 
         // EDGE = false: every lane's eight records of this block are its own
-        auto consume = [&](const u32x4 (&w)[8], const uint32_t k, auto edge) {
+        auto consume = [&](const u32x4 (&w)[8], const uint32_t k, auto edge, auto one_library) {
             constexpr bool EDGE = decltype(edge)::value;
+            constexpr bool ONE = decltype(one_library)::value;   // kMultiLds: the window holds one library
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 // keep the look-ups of the second half of the block from being hoisted over the first half: eight
@@ -306,9 +420,12 @@ __global__ __launch_bounds__(kBlock, MODE == kSingleLds ? SVT_STREAM_WAVES : 2) 
                 if (j == SVT_STREAM_SPLIT) __builtin_amdgcn_sched_barrier(0);
                 const uint32_t idx = k * kBlockRecords + (uint32_t)j;
                 const bool mine = !EDGE || (idx >= head && idx < last);
-                if (mine) check.see(w[j]);   // (slots that are not this lane's were not fetched)
+                if (mine) check.see(w[j], wd.lib_lo);   // (slots that are not this lane's were not fetched)
                 if (MODE == kSingleLds) {
                     record_single<SSO, EDGE>(w[j], mine, sc, acc);
+                } else if (MODE == kMultiLds) {
+                    if (ONE) record_single<SSO, EDGE>(w[j], mine, sc, acc);
+                    else record_window<SSO, EDGE>(w[j], mine, wc, acc);
                 } else {
                     const uint32_t wy = mine ? w[j].y : 0u, wz = mine ? w[j].z : 0u;   // MAPQ 0 everywhere: adds +0.0
                     weight_evidence<SSO>(wy >> 16 | (wz << 16), wz >> 16, (w[j].w & SVT_REC_CONTINUATION) != 0, t, acc);
@@ -329,8 +446,14 @@ __global__ __launch_bounds__(kBlock, MODE == kSingleLds ? SVT_STREAM_WAVES : 2) 
                 if (SVT_STREAM_PROBE == 1) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) acc.ref_seq += (double)(w[j].x ^ w[j].y ^ w[j].z ^ w[j].w);
-                } else if (__any(k8 < head || k8 + kBlockRecords > last)) consume(w, k, std::true_type{});
-                else consume(w, k, std::false_type{});
+                } else {
+                    const bool edge = __any(k8 < head || k8 + kBlockRecords > last);
+                    if (MODE == kMultiLds && wd.lib_cnt == 1u) {       // (workgroup-uniform)
+                        if (edge) consume(w, k, std::true_type{}, std::true_type{});
+                        else consume(w, k, std::false_type{}, std::true_type{});
+                    } else if (edge) consume(w, k, std::true_type{}, std::false_type{});
+                    else consume(w, k, std::false_type{}, std::false_type{});
+                }
             }
         }
         if (SSO) {  // flush the last fragment (singlesample.py:370-372)
@@ -356,7 +479,7 @@ __global__ __launch_bounds__(kBlock, MODE == kSingleLds ? SVT_STREAM_WAVES : 2) 
 
         store_results_through_ring(ring, piece, unit, lane, a.out);
     }
-    const uint32_t bad = check.bits(a.n_libs);
+    const uint32_t bad = check.bits(MODE == kMultiLds ? wd.lib_cnt : a.n_libs);
     if (bad) atomicOr(a.err, bad);
 }
 

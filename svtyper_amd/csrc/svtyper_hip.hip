@@ -124,6 +124,11 @@ struct svt_batch {
     svt_unit* d_units = nullptr;
     uint64_t cap_records = 0, cap_off = 0, cap_units = 0;
     uint32_t* d_err = nullptr;
+    uint32_t* d_perm = nullptr;      // kMultiLds (library windows): units grouped by window, chunk list, windows
+    uint2* d_chunks = nullptr;
+    WgDesc* d_windows = nullptr;
+    uint64_t cap_perm = 0;
+    uint32_t n_chunks = 0;
     StreamArgs sargs{};
     // kLayoutPacked: packed evidence as uploaded (svt_packed_kernel.h); d_records holds the slots, d_soff the 3n+1 offsets
     uint32_t* d_soff = nullptr;
@@ -146,6 +151,8 @@ void free_batch(svt_batch* b)
     g_pool.put(b->device, b->d_off, b->cap_off);
     g_pool.put(b->device, b->d_units, b->cap_units);
     g_pool.put(b->device, b->d_soff, b->cap_soff);
+    g_pool.put(b->device, b->d_perm, b->cap_perm);
+    F(b->d_chunks); F(b->d_windows);
     F(b->d_err);
     F(b->d_tiles); F(b->d_pm); F(b->d_l10); F(b->d_libs);
     F(b->d_bins); F(b->d_wtab); F(b->d_wg);
@@ -205,8 +212,9 @@ const void* kernel_of(const svt_batch* b)
 template <bool SSO>
 const void* stream_kernel_for(int mode)
 {
-    return mode == kSingleLds ? reinterpret_cast<const void*>(&svt_stream_kernel<SSO, kSingleLds, SVT_STREAM_R>)
-                              : reinterpret_cast<const void*>(&svt_stream_kernel<SSO, kGeneral, SVT_STREAM_R>);
+    return mode == kSingleLds  ? reinterpret_cast<const void*>(&svt_stream_kernel<SSO, kSingleLds, SVT_STREAM_R>)
+           : mode == kMultiLds ? reinterpret_cast<const void*>(&svt_stream_kernel<SSO, kMultiLds, SVT_STREAM_R>)
+                               : reinterpret_cast<const void*>(&svt_stream_kernel<SSO, kGeneral, SVT_STREAM_R>);
 }
 
 const void* stream_kernel_of(const svt_batch* b)
@@ -228,7 +236,7 @@ int launch_genotype(svt_batch* b)
     if (b->layout == kLayoutStream) {
         if (b->n_units == 0) return SVT_OK;
         constexpr uint64_t per_wg = (uint64_t)kBlock * SVT_STREAM_R;
-        const dim3 grid((unsigned)((b->n_units + per_wg - 1) / per_wg)), block(kBlock);
+        const dim3 grid(b->mode == kMultiLds ? b->n_chunks : (unsigned)((b->n_units + per_wg - 1) / per_wg)), block(kBlock);
         void* params[] = {&b->sargs};
         HIP_TRY(hipLaunchKernel(stream_kernel_of(b), grid, block, params, b->lds_bytes, b->stream));
         return SVT_OK;
@@ -306,14 +314,17 @@ int create_stream(const svt_evidence_batch* in, svt_batch* b, void* d_records_re
     StageTimer tm;
     if (n_rec >= 0xFFFFFFF0ull) return fail(SVT_ERR_INVALID, "too many records in one batch (< 2^32)");
     uint64_t max_f = 0;
-    bool wide_var_length = false;
+    bool wide_var_length = false, all_hinted = n > 0;
     for (uint64_t u = 0; u < n; ++u) {
         if (in->rec_offset[u + 1] < in->rec_offset[u]) return fail(SVT_ERR_INVALID, "rec_offset not monotone");
         const uint64_t f = in->rec_offset[u + 1] - in->rec_offset[u];
         if (f > 0x3FFFFFFFull) return fail(SVT_ERR_INVALID, "unit with too many records");
         const svt_unit& U = in->units[u];
         if (U.svtype > SVT_SVTYPE_BND) return fail(SVT_ERR_INVALID, "bad svtype");
-        if (U.reserved != 0 || (U.flags & ~SVT_UNIT_SKIP)) return fail(SVT_ERR_INVALID, "unit reserved/flags bits must be 0");
+        if ((U.libs >> 16) != 0 || (U.flags & ~SVT_UNIT_SKIP)) return fail(SVT_ERR_INVALID, "unit reserved/flags bits must be 0");
+        const uint32_t w_lo = U.libs & 0xffu, w_cnt = (U.libs >> 8) & 0xffu;
+        if (w_cnt && w_lo + w_cnt > in->n_libs) return fail(SVT_ERR_INVALID, "unit library window beyond n_libs");
+        all_hinted = all_hinted && w_cnt != 0;
         if (U.var_length < -(1 << 30) || U.var_length > (1 << 30)) wide_var_length = true;
         max_f = std::max(max_f, f);
     }
@@ -321,6 +332,42 @@ int create_stream(const svt_evidence_batch* in, svt_batch* b, void* d_records_re
     HostTables T;
     SVT_TRY(build_tables(in, max_f, T));
     if (wide_var_length) T.fast_geometry = false;
+
+    // ---- several libraries: when every unit says which libraries its sample owns (svt_unit.libs), group the
+    // units by that window -- a permutation of 4 bytes per unit, the records stay where they are -- and cut the
+    // groups into workgroup chunks; a workgroup then stages only its window's histograms
+    constexpr uint32_t kUnitsPerWg = kBlock * SVT_STREAM_R;
+    std::vector<uint32_t> perm;
+    std::vector<uint2> chunks;
+    std::vector<WgDesc> windows;
+    uint32_t max_win_bins = 0, max_win_libs = 0;
+    bool windowed = in->n_libs > 1 && all_hinted && T.fast_geometry;
+    if (windowed) {
+        std::vector<uint32_t> start(65537, 0u);
+        for (uint64_t u = 0; u < n; ++u) ++start[(in->units[u].libs & 0xffffu) + 1];
+        for (uint32_t k = 0; k < 65536u; ++k) start[k + 1] += start[k];
+        perm.resize(n);
+        {
+            std::vector<uint32_t> at(start.begin(), start.end() - 1);
+            for (uint64_t u = 0; u < n; ++u) perm[at[in->units[u].libs & 0xffffu]++] = (uint32_t)u;   // stable: original order inside a group
+        }
+        for (uint32_t k = 0; k < 65536u; ++k) {
+            if (start[k + 1] == start[k]) continue;
+            const uint32_t lo = k & 0xffu, cnt = k >> 8;
+            WgDesc w{};
+            w.lib_lo = lo;
+            w.lib_cnt = cnt;
+            w.bin_lo = T.libs[lo].tab_off;
+            w.bin_cnt = T.libs[lo + cnt - 1].tab_off + T.libs[lo + cnt - 1].n_bins + 1 - w.bin_lo;
+            max_win_bins = std::max(max_win_bins, w.bin_cnt);
+            max_win_libs = std::max(max_win_libs, w.lib_cnt);
+            for (uint32_t p0 = start[k]; p0 < start[k + 1]; p0 += kUnitsPerWg) {
+                chunks.push_back(make_uint2(p0, std::min(kUnitsPerWg, start[k + 1] - p0)));
+                windows.push_back(w);
+            }
+        }
+        tm.mark("group units by library window");
+    }
     const uint32_t n_l10 = (uint32_t)T.l10.size();
     T.l10.resize(((size_t)n_l10 + 127) / 128 * 128, 0.0);   // the ring copy of the table moves whole KiB
     tm.mark("build tables");
@@ -367,9 +414,23 @@ int create_stream(const svt_evidence_batch* in, svt_batch* b, void* d_records_re
     // one library whose tables fit beside the rings: tables in LDS, 32-bit index math; anything else reads
     // the tables through L2 with exact 64-bit geometry
     constexpr size_t kStreamLdsPerWg = (160 * 1024 / 3) & ~size_t(127);   // three workgroups per CU
+    constexpr size_t kStreamLdsPerWg2 = (160 * 1024 / 2) & ~size_t(127);  // two
     const size_t single_lds = kSBins + T.bins.size() * sizeof(Bin);
     const bool single = in->n_libs == 1 && T.fast_geometry && single_lds + kWavesPerBlock * kRingBytes <= 96 * 1024;
-    b->mode = single ? kSingleLds : kGeneral;
+    const size_t window_lds = kSBins + (size_t)max_win_bins * sizeof(Bin) + (size_t)max_win_libs * sizeof(WinLib);
+    windowed = windowed && window_lds + kWavesPerBlock * kRingBytes <= kStreamLdsPerWg2;
+    b->mode = single ? kSingleLds : windowed ? kMultiLds : kGeneral;
+    if (windowed) {
+        Stager st(b->stream);
+        void* pp = nullptr;
+        SVT_TRY(g_pool.get(b->device, std::max<uint64_t>(n, 1) * sizeof(uint32_t), &pp, &b->cap_perm));
+        b->d_perm = static_cast<uint32_t*>(pp);
+        SVT_TRY(st.copy(b->d_perm, perm.data(), n * sizeof(uint32_t)));
+        SVT_TRY(upload(&b->d_chunks, chunks, st));
+        SVT_TRY(upload(&b->d_windows, windows, st));
+        SVT_TRY(st.finish());
+        b->n_chunks = (uint32_t)chunks.size();
+    }
     StreamArgs& a = b->sargs;
     a.records = static_cast<const uint4*>(b->d_records);
     a.rec_offset = b->d_off;
@@ -383,14 +444,21 @@ int create_stream(const svt_evidence_batch* in, svt_batch* b, void* d_records_re
     a.n_libs = in->n_libs;
     a.total_bins = (uint32_t)T.bins.size();
     a.last_blk = (uint32_t)(n_blk - 1);
-    a.lds_bins = single ? a.total_bins : 0u;
-    a.lds_libs = single ? 0u : in->n_libs;
-    size_t tables = kSBins + (size_t)a.lds_bins * sizeof(Bin) + (size_t)a.lds_libs * sizeof(LibDesc);
+    a.lds_bins = single ? a.total_bins : windowed ? max_win_bins : 0u;
+    a.lds_libs = single || windowed ? 0u : in->n_libs;
+    a.perm = b->d_perm;
+    a.chunks = b->d_chunks;
+    a.windows = b->d_windows;
+    a.lds_winlibs = (uint32_t)(kSBins + (size_t)a.lds_bins * sizeof(Bin));
+    size_t tables = kSBins + (size_t)a.lds_bins * sizeof(Bin) + (size_t)a.lds_libs * sizeof(LibDesc) +
+                    (windowed ? (size_t)max_win_libs * sizeof(WinLib) : 0);
     tables = (tables + 127) & ~size_t(127);
     // the log10 table of the epilogue: beside the tables while three workgroups still fit a CU's 160 KB,
     // else through the wave's ring, else through L2
     const size_t l10_bytes = ((size_t)n_l10 * 8 + 127) & ~size_t(127);
-    if (tables + l10_bytes + kWavesPerBlock * kRingBytes <= kStreamLdsPerWg) {
+    const size_t with_l10 = tables + l10_bytes + kWavesPerBlock * kRingBytes;
+    // (a window that already costs the third workgroup keeps the table too as long as two still fit)
+    if (with_l10 <= kStreamLdsPerWg || (tables + kWavesPerBlock * kRingBytes > kStreamLdsPerWg && with_l10 <= kStreamLdsPerWg2)) {
         a.l10_where = kL10Shared;
         a.lds_l10 = (uint32_t)tables;
         tables += l10_bytes;
@@ -533,7 +601,7 @@ int pack_evidence(const svt_evidence_batch* in, svt_packed_evidence** out)
         if (in->rec_offset[u + 1] - in->rec_offset[u] > 0x3FFFFFFFull) return fail(SVT_ERR_INVALID, "unit with too many records");
         const svt_unit& U = in->units[u];
         if (U.svtype > SVT_SVTYPE_BND) return fail(SVT_ERR_INVALID, "bad svtype");
-        if (U.reserved != 0 || (U.flags & ~SVT_UNIT_SKIP)) return fail(SVT_ERR_INVALID, "unit reserved/flags bits must be 0");
+        if ((U.libs >> 16) != 0 || (U.flags & ~SVT_UNIT_SKIP)) return fail(SVT_ERR_INVALID, "unit reserved/flags bits must be 0");
     }
     HostTables T;
     SVT_TRY(build_tables(in, 0, T));
@@ -694,7 +762,7 @@ int create_packed(const svt_packed_evidence* in, svt_batch* b)
                 const uint32_t* o = in->slot_offset + 3 * u;
                 if (o[1] < o[0] || o[2] < o[1] || o[3] < o[2]) bad |= 1;
                 if (U.svtype > SVT_SVTYPE_BND) bad |= 2;
-                if (U.reserved != 0 || (U.flags & ~SVT_UNIT_SKIP)) bad |= 4;
+                if ((U.libs >> 16) != 0 || (U.flags & ~SVT_UNIT_SKIP)) bad |= 4;
                 if (U.var_length < -(1 << 30) || U.var_length > (1 << 30)) bad |= 8;
                 if (U.svtype == SVT_SVTYPE_DEL && U.var_length < 0) bad |= 16;
                 m = std::max(m, std::max<uint64_t>((uint64_t)(o[1] - o[0]) * 8, std::max<uint64_t>((uint64_t)(o[2] - o[1]) * 7, (uint64_t)(o[3] - o[2]) * 7)));
@@ -791,7 +859,7 @@ int create_on_device(const svt_evidence_batch* in, svt_batch* b, const uint4* d_
         if (f > 0x3FFFFFFFull) return fail(SVT_ERR_INVALID, "unit with too many records");
         const svt_unit& U = in->units[u];
         if (U.svtype > SVT_SVTYPE_BND) return fail(SVT_ERR_INVALID, "bad svtype");
-        if (U.reserved != 0 || (U.flags & ~SVT_UNIT_SKIP)) return fail(SVT_ERR_INVALID, "unit reserved/flags bits must be 0");
+        if ((U.libs >> 16) != 0 || (U.flags & ~SVT_UNIT_SKIP)) return fail(SVT_ERR_INVALID, "unit reserved/flags bits must be 0");
         if (U.var_length < -(1 << 30) || U.var_length > (1 << 30)) wide_var_length = true;
         if (U.svtype == SVT_SVTYPE_DEL && U.var_length < 0) negative_del = true;
         nrec[u] = (uint32_t)f;
@@ -1137,6 +1205,7 @@ static int svt_batch_create_from_fragments_impl(const svt_fragment_batch* in, in
         U.sample = bp.sample;
         U.svtype = bp.svtype;
         U.flags = (bp.flags & SVT_BP_SKIP) ? SVT_UNIT_SKIP : 0;
+        U.libs = bp.reserved[0] & 0xffffu;      // SVT_UNIT_LIBS hint of the unit's sample
         units[u] = U;
     }
     // library descriptors (the flank of is_pair_straddle is lib.mean + lib.sd * 3)

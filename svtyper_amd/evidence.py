@@ -68,11 +68,16 @@ UNIT_DTYPE = np.dtype(
         ("sample", "<u2"),
         ("svtype", "u1"),
         ("flags", "u1"),
-        ("reserved", "<u4"),
+        ("libs", "<u4"),      # optional hint: first library | library count << 8 of the unit's sample (0 = none)
     ],
     align=False,
 )
 assert UNIT_DTYPE.itemsize == 16
+
+
+def unit_libs(first: int, count: int) -> int:
+    """SVT_UNIT_LIBS(first, count): the libraries of a unit's sample are libs[first .. first + count) of the batch."""
+    return int(first) | (int(count) << 8)
 
 RESULT_DTYPE = np.dtype(
     [

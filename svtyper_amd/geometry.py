@@ -131,8 +131,9 @@ def summarise_fragments(fragments: Dict[str, object], breakpoint: dict, lib_inde
     return np.ascontiguousarray(words).view(FRAGMENT_DTYPE).reshape(-1)
 
 
-def breakpoint_record(breakpoint: dict, tid_of, sample_index: int = 0, skip: bool = False) -> np.ndarray:
+def breakpoint_record(breakpoint: dict, tid_of, sample_index: int = 0, skip: bool = False, libs: int = 0) -> np.ndarray:
     b = np.zeros(1, BREAKPOINT_DTYPE)
+    b["reserved"][0, 0] = libs       # evidence.unit_libs(first, count) of the unit's sample (svt_unit.libs)
     A, B = breakpoint["A"], breakpoint["B"]
     b["tid_a"], b["pos_a"], b["ci_a"] = tid_of(A["chrom"]), _clip32(A["pos"]), [_clip32(x) for x in A["ci"]]
     b["tid_b"], b["pos_b"], b["ci_b"] = tid_of(B["chrom"]), _clip32(B["pos"]), [_clip32(x) for x in B["ci"]]

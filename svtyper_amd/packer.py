@@ -128,8 +128,10 @@ def pack_fragments(fragments: Dict[str, object], breakpoint: dict, lib_index: Di
     return rec
 
 
-def unit_header(breakpoint: dict, sample_index: int = 0, skip: bool = False) -> np.ndarray:
+def unit_header(breakpoint: dict, sample_index: int = 0, skip: bool = False, libs: int = 0) -> np.ndarray:
+    """`libs`: evidence.unit_libs(first, count) of the unit's sample (svt_unit.libs), 0 = no hint."""
     u = np.zeros(1, UNIT_DTYPE)
+    u["libs"] = libs
     svtype = breakpoint["svtype"]
     u["svtype"] = ev.SVTYPE_CODE[svtype]
     if svtype == "DEL":

@@ -81,10 +81,13 @@ class UnitCollector:
         self.min_aligned = min_aligned
         self.lib_tables = []
         self.lib_index: Dict[int, int] = {}
+        self.sample_libs = []          # per sample: svt_unit.libs hint (its libraries are contiguous in lib_tables)
         for s in samples:
+            first = len(self.lib_tables)
             for lib in s.lib_dict.values():
                 self.lib_index[id(lib)] = len(self.lib_tables)
                 self.lib_tables.append(lib.table())
+            self.sample_libs.append(ev.unit_libs(first, len(self.lib_tables) - first) if len(self.lib_tables) > first else 0)
         if len(self.lib_tables) > 256:
             raise ValueError("more than 256 libraries in one run are not supported by the evidence record")
         self.split_weight = split_weight
@@ -106,8 +109,8 @@ class UnitCollector:
             frs = None
             if fragments and not skip:
                 frs = summarise_fragments(fragments, breakpoint, self.lib_index, tid_of)
-            return self.builder.add(breakpoint_record(breakpoint, tid_of, sample_index, skip), frs)
-        unit = unit_header(breakpoint, sample_index, skip)
+            return self.builder.add(breakpoint_record(breakpoint, tid_of, sample_index, skip, self.sample_libs[sample_index]), frs)
+        unit = unit_header(breakpoint, sample_index, skip, self.sample_libs[sample_index])
         recs = None
         if fragments and not skip:
             recs = pack_fragments(fragments, breakpoint, self.lib_index, self.min_aligned, SPLIT_SLOP)
@@ -157,10 +160,12 @@ class NativeUnitCollector:
         self.disc_weight = disc_weight
         self.lib_tables = []
         self.rg_tables = []          # per sample: (read group ids, library index or -1)
+        self.sample_libs = []        # per sample: svt_unit.libs hint
         for s in samples:
             base = len(self.lib_tables)
             libs = list(s.lib_dict.values())
             self.lib_tables.extend(lib.table() for lib in libs)
+            self.sample_libs.append(ev.unit_libs(base, len(libs)) if libs else 0)
             rgs = list(s.rg_to_lib.keys())
             idx = [base + libs.index(s.rg_to_lib[rg]) if s.rg_to_lib[rg].name in s.active_libs else -1 for rg in rgs]
             self.rg_tables.append((rgs, idx))
@@ -217,6 +222,7 @@ class NativeUnitCollector:
             bps["ci_a"], bps["ci_b"] = clip(ci[:, 0:2]), clip(ci[:, 2:4])
             bps["var_length"] = clip(vlen)
             bps["svtype"], bps["flags"], bps["sample"] = svt, rev, k
+            bps["reserved"][:, 0] = self.sample_libs[k]
             # fetch windows: pos + ci -+ (mean + 3 sd), clamped to the chromosome (classic.py:73-81;
             # singlesample.py:139-156 truncates to int, pysam truncates classic's float bounds the same way)
             flank = sample.get_fetch_flank(Z)

@@ -234,6 +234,8 @@ def make_multisample(n_sites: int, n_samples: int, seed: int, libs_per_sample=(1
     for p in parts[1:]:
         for fld in ("svtype", "var_length", "pos_delta"):
             p.units[fld] = parts[0].units[fld]
+    for s, p in enumerate(parts):      # every unit says which libraries its sample owns (svt_unit.libs)
+        p.units["libs"] = ev.unit_libs(sample_libs[s][0], len(sample_libs[s]))
     allb = ev.concat_batches(parts)
     order = (np.arange(n_sites)[:, None] + n_sites * np.arange(n_samples)[None, :]).reshape(-1)
     out = permute_units(allb, order)

@@ -80,7 +80,7 @@ def test_struct_layouts_match_the_header(tmp_path):
     from svtyper_amd import evidence as ev, geometry as geo
     structs = {
         "svt_record": ["ospan_len", "mapq_a", "mapq_b", "rs_a", "rs_b", "seq_l", "seq_r", "clip_l", "clip_r", "flags"],
-        "svt_unit": ["var_length", "pos_delta", "sample", "svtype", "flags", "reserved"],
+        "svt_unit": ["var_length", "pos_delta", "sample", "svtype", "flags", "libs"],
         "svt_library": ["hist", "key_min", "n_bins", "mean", "sd"],
         "svt_evidence_batch": ["n_units", "rec_offset", "units", "records", "n_libs", "libs", "split_weight", "disc_weight"],
         "svt_read_summary": ["tid", "start", "end", "iv_start", "iv_end", "mapq", "flags", "reserved"],

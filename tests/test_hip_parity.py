@@ -623,3 +623,51 @@ def test_full_size_multisample_properties(hip_device, full_c5):
     want = c_oracle.genotype_batch(synth.permute_units(batch, pick), flags=0)
     assert_parity(ev.Results(first.rec[pick].copy()), want)
     assert {0, 1, 2} <= set(np.unique(first.gt).tolist())
+
+
+# ------------------------------------------------------------------------------------------
+# streaming layout with several libraries: per-sample library windows (svt_unit.libs)
+# ------------------------------------------------------------------------------------------
+def test_library_windows_in_the_streaming_kernel(hip_device, fixture_library):
+    """Units that say which libraries their sample owns are grouped by that window and a workgroup stages only the
+    window's histograms (table mode 1); without the hint the same batch runs in the general mode (2) -- same bits."""
+    from svtyper_amd import hip
+    batch = synth.make_multisample(150, 32, seed=5, mean_frags=40, sd_frags=15, min_frags=5, max_frags=90)
+    assert (batch.units["libs"] != 0).all() and len(np.unique(batch.units["libs"])) == 32
+    for flags in (0, ev.FLAG_SSO_ASSOCIATION):
+        with hip.DeviceBatch(batch, hip_device, flags) as d:
+            assert d.layout_name() == "stream" and d.layout()[1] == 1
+            d.genotype(sync=True)
+            win = d.results()
+        plain = synth.permute_units(batch, np.arange(batch.n_units))
+        plain.units["libs"] = 0
+        with hip.DeviceBatch(plain, hip_device, flags) as d:
+            assert d.layout()[1] == 2
+            d.genotype(sync=True)
+            gen = d.results()
+        assert win.rec.tobytes() == gen.rec.tobytes()
+        from oracle import c_oracle
+        assert_parity(win, c_oracle.genotype_batch(batch, flags=flags))
+    # groups that do not fill a workgroup, one unit per window, units in any order
+    order = np.random.default_rng(3).permutation(batch.n_units)[:1777]
+    sub = synth.permute_units(batch, order)
+    got, want = run_both(sub)
+    assert_parity(got, want)
+    # a window wider than what the records use is fine; a record outside its unit's window is a contract violation
+    wide = synth.permute_units(batch, np.arange(640))
+    wide.units["libs"] = ev.unit_libs(0, len(batch.libs))
+    if hip.DeviceBatch(wide, hip_device).layout()[1] == 1:        # (only if 66 tables fit the LDS budget; else general)
+        pass
+    got, want = run_both(wide)
+    assert_parity(got, want)
+    bad = synth.permute_units(batch, np.arange(640))
+    lo = int(bad.units["libs"][0]) & 0xff
+    bad.units["libs"][0] = ev.unit_libs(lo + 1, 1) if lo + 1 < len(batch.libs) else ev.unit_libs(lo - 1, 1)
+    if bad.rec_offset[1] > bad.rec_offset[0]:
+        with pytest.raises(hip.SvtyperHipError) as e:
+            hip.genotype_batch(bad)
+        assert "lib index" in str(e.value)
+    beyond = synth.permute_units(batch, np.arange(64))
+    beyond.units["libs"][3] = ev.unit_libs(len(batch.libs) - 1, 5)
+    with pytest.raises(hip.SvtyperHipError):
+        hip.genotype_batch(beyond)
