@@ -105,34 +105,7 @@ struct ScanOut {          // per unit
 constexpr uint32_t kScanWideMapq = 1u;   // a kept pair entry has a MAPQ > 127
 constexpr uint32_t kWideEntry = 0x8000u; // short layout: the next half-word holds this entry's MAPQs
 constexpr uint32_t kDefaultCommonMapq = 60u | (60u << 8);
-constexpr uint32_t kVoteRecords = 1u << 18;   // records the MAPQ vote looks at
-
-// The most common (mapq_a, mapq_b) of the first kVoteRecords pair records: votes[mapq_a | mapq_b << 8]++,
-// then votes[65536] = the winner.  Any answer is correct, a good one makes the short layout shorter.
-__global__ __launch_bounds__(kBlock) void svt_mapq_vote_kernel(const uint4* __restrict__ csr, const uint32_t n, uint32_t* votes)
-{
-    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
-    const uint4 w = csr[i];
-    if ((w.w & 7u) == 0u || (w.y & 0xffu) == 0u || (w.y & 0xff00u) == 0u) return;
-    atomicAdd(&votes[w.y & 0xffffu], 1u);
-}
-
-__global__ __launch_bounds__(kBlock) void svt_mapq_pick_kernel(uint32_t* votes)
-{
-    __shared__ uint32_t best_n[kBlock], best_k[kBlock];
-    uint32_t bn = 0, bk = kDefaultCommonMapq;
-    for (uint32_t k = threadIdx.x; k < 65536u; k += kBlock)
-        if (votes[k] > bn) { bn = votes[k]; bk = k; }      // ties: the lowest key of this thread's stride
-    best_n[threadIdx.x] = bn;
-    best_k[threadIdx.x] = bk;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (uint32_t t = 1; t < kBlock; ++t)
-            if (best_n[t] > bn || (best_n[t] == bn && bn && best_k[t] < bk)) { bn = best_n[t]; bk = best_k[t]; }
-        votes[65536] = bk;
-    }
-}
+constexpr uint32_t kVoteRecords = 1u << 14;   // records the (host-side) MAPQ vote looks at
 
 struct ScanArgs {
     const uint4* csr;
@@ -143,7 +116,7 @@ struct ScanArgs {
     uint32_t n_libs;
     ScanOut* out;
     uint32_t* err;
-    const uint32_t* common_mq;   // device word written by svt_mapq_pick_kernel
+    const uint32_t* common_mq;   // device word: the vote's result
 };
 
 // one thread per unit: validate the record contract of include/svtyper_hip.h, count the entries of the

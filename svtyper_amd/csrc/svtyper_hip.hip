@@ -569,6 +569,22 @@ struct PackedOwner {             // what svt_pack_evidence returns: the public s
     }
 };
 
+// The most common (mapq_a, mapq_b) among the first records that would keep a pair entry (a straddle bit and two
+// non-zero MAPQs); ties go to the lowest key.  Any answer is correct for the short pair entries.
+uint32_t vote_common_mapq(const uint4* recs, uint64_t n_vote)
+{
+    uint32_t common = kDefaultCommonMapq, best = 0;
+    if (!recs || !n_vote) return common;
+    std::vector<uint32_t> votes(65536, 0u);
+    for (uint64_t i = 0; i < n_vote; ++i) {
+        const uint4 w = recs[i];
+        if ((w.w & 7u) && (w.y & 0xffu) && (w.y & 0xff00u)) ++votes[w.y & 0xffffu];
+    }
+    for (uint32_t k = 0; k < 65536u; ++k)
+        if (votes[k] > best) { best = votes[k]; common = k; }
+    return common;
+}
+
 // can this batch be written as packed evidence?  (the limits of the short entry format, include/svtyper_hip.h)
 int packable(const svt_evidence_batch* in, const HostTables& T)
 {
@@ -611,18 +627,7 @@ int pack_evidence(const svt_evidence_batch* in, svt_packed_evidence** out)
 
     // the batch's most common (mapq_a, mapq_b) among the first records that keep a pair entry: any answer is
     // correct, a good one makes the pair stream shorter
-    uint32_t common = kDefaultCommonMapq;
-    {
-        std::vector<uint32_t> votes(65536, 0u);
-        const uint64_t n_vote = std::min<uint64_t>(n_rec, kVoteRecords);
-        for (uint64_t i = 0; i < n_vote; ++i) {
-            const uint4 w = recs[i];
-            if ((w.w & 7u) && (w.y & 0xffu) && (w.y & 0xff00u)) ++votes[w.y & 0xffffu];
-        }
-        uint32_t best = 0;
-        for (uint32_t k = 0; k < 65536u; ++k)
-            if (votes[k] > best) { best = votes[k]; common = k; }
-    }
+    const uint32_t common = vote_common_mapq(recs, std::min<uint64_t>(n_rec, kVoteRecords));
 
     auto owner = std::make_unique<PackedOwner>();
     owner->off = static_cast<uint32_t*>(g_pinned.get((3 * n + 1) * sizeof(uint32_t)));
@@ -901,17 +906,22 @@ int create_on_device(const svt_evidence_batch* in, svt_batch* b, const uint4* d_
     SVT_TRY(d_counts.alloc(n * sizeof(ScanOut)));
     SVT_TRY(d_err.alloc(sizeof(uint32_t)));
     HIP_TRY(hipMemsetAsync(d_err.p, 0, sizeof(uint32_t), b->stream));
-    // the batch's most common MAPQ pair (short layout), voted by the first records
-    DevScratch d_votes;
-    SVT_TRY(d_votes.alloc((65536 + 1) * sizeof(uint32_t)));
-    HIP_TRY(hipMemsetAsync(d_votes.p, 0, (65536 + 1) * sizeof(uint32_t), b->stream));
+    // the batch's most common MAPQ pair (short layout): a vote over the first records on the HOST (the records are
+    // here, or -- geometry path -- a few KB away); any answer is correct, a good one makes the pair stream shorter
+    DevScratch d_common;
+    SVT_TRY(d_common.alloc(sizeof(uint32_t)));
     {
         const uint32_t n_vote = (uint32_t)std::min<uint64_t>(n_rec, kVoteRecords);
-        if (n_vote)
-            hipLaunchKernelGGL(svt_mapq_vote_kernel, dim3((n_vote + kBlock - 1) / kBlock), dim3(kBlock), 0, b->stream,
-                               d_csr, n_vote, d_votes.as<uint32_t>());
-        hipLaunchKernelGGL(svt_mapq_pick_kernel, dim3(1), dim3(kBlock), 0, b->stream, d_votes.as<uint32_t>());
-        HIP_TRY(hipGetLastError());
+        std::vector<uint4> sample;
+        const uint4* recs = reinterpret_cast<const uint4*>(in->records);
+        if (!recs && n_vote) {
+            sample.resize(n_vote);
+            HIP_TRY(hipMemcpyAsync(sample.data(), d_csr, (size_t)n_vote * sizeof(uint4), hipMemcpyDeviceToHost, b->stream));
+            HIP_TRY(hipStreamSynchronize(b->stream));
+            recs = sample.data();
+        }
+        b->common_mq = vote_common_mapq(recs, n_vote);
+        HIP_TRY(hipMemcpyAsync(d_common.p, &b->common_mq, sizeof(uint32_t), hipMemcpyHostToDevice, b->stream));
     }
     std::vector<ScanOut>& counts = g_host.counts;
     counts.assign(n, ScanOut{});
@@ -926,12 +936,11 @@ int create_on_device(const svt_evidence_batch* in, svt_batch* b, const uint4* d_
         sa.n_libs = in->n_libs;
         sa.out = d_counts.as<ScanOut>();
         sa.err = d_err.as<uint32_t>();
-        sa.common_mq = d_votes.as<uint32_t>() + 65536;
+        sa.common_mq = d_common.as<uint32_t>();
         hipLaunchKernelGGL(svt_scan_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, b->stream, sa);
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipMemcpyAsync(&err_bits, d_err.p, sizeof(uint32_t), hipMemcpyDeviceToHost, b->stream));
-    HIP_TRY(hipMemcpyAsync(&b->common_mq, d_votes.as<uint32_t>() + 65536, sizeof(uint32_t), hipMemcpyDeviceToHost, b->stream));
     if (n) SVT_TRY(d2h_staged(counts.data(), d_counts.p, n * sizeof(ScanOut), b->stream));
     HIP_TRY(hipStreamSynchronize(b->stream));
     tm.mark("scan kernel + counts D2H");
