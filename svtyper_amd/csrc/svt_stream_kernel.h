@@ -6,28 +6,21 @@
 // bayes_gt -> GT/GQ/SQ (svtyper/classic.py:296-513, singlesample.py:246-473).  Every record is read from
 // HBM exactly once, nothing is re-encoded, sorted or tiled on the host or in a separate kernel.
 //
-// The five tallies are sequential binary64 sums in record order, so a unit still belongs to ONE lane.
-// What makes that coalesced here is a per-wave LDS ring filled by LDS-DMA (global_load_lds_dwordx4):
+// The five tallies are sequential binary64 sums in record order, so a unit still belongs to ONE lane.  What makes
+// that coalesced is the per-wave LDS ring of svt_ring_engine.h (workgroup length sort, LDS-DMA fetch of one 128-byte
+// line per unit and step, XOR-swizzled conflict-free reads, results written as full lines through the same ring).
+// This file adds the record arithmetic on top of it:
 //
-//   * a workgroup owns 256 * R consecutive units; it counting-sorts them by their number of 128-byte
-//     record blocks (LDS atomics + one scan) so that the 64 lanes of a wave run units of similar
-//     length, and hands the sorted 64-unit tiles to its four waves in snake order (wave w: tiles w,
-//     7 - w, 8 + w, ...), which balances the waves of the workgroup;
-//   * per step a wave fetches, for each of its 64 units, the next 128-byte block (8 records) of that
-//     unit: eight LDS-DMA instructions, each serving eight units with eight lanes per unit, so every
-//     instruction moves eight whole cache lines and nothing passes through VGPRs;
-//   * the block of unit u lands at ring + u * 128 with its eight 16-byte slots XOR-swizzled by
-//     (u >> 1) & 7 -- the lane that owns unit u then reads its records with ds_read_b128 and the 16
-//     lanes the LDS serves per cycle hit 16 different bank quads (conflict-free, MI355X_MICROARCH LDS table);
-//   * one 8 KB stage per wave: a block leaves the stage for VGPRs in one burst of eight ds_read_b128, the
-//     fetch of block k + 1 is issued right behind it and lands while block k is being consumed -- 12 waves
-//     per CU fit beside the tables instead of 8 with a second stage;
-//   * slots of a block that lie outside the unit (the neighbours' records in its first and last line,
-//     everything past the end of a shorter unit) are not fetched; the consumer reads them as records with
-//     MAPQ 0 everywhere: prob_mapq(0) == +0.0 exactly, and x + 0.0 == x for these non-negative sums (the
-//     argument of include/svtyper_hip.h for gated-off reads);
-//   * the result records leave through the same ring: each lane stores its eight pieces to LDS, the wave
-//     reads them back unit-major and every group of eight lanes writes one full 128-byte line.
+//   * record_single  one library: every table at a fixed LDS address, every field of a record turned into a
+//                    ds_read address by ONE instruction (SDWA byte select + immediate table base);
+//   * record_window  several libraries with per-sample library windows (svt_unit.libs): the units are grouped by
+//                    window on the host (a permutation of unit indices, the records stay where they are) and a
+//                    workgroup stages only its window's histograms;
+//   * the general mode (any geometry, no hints): weight_evidence / pair_evidence<kGeneral> with tables through L2;
+//   * slots of a block that lie outside the unit (the neighbours' records in its first and last line, everything
+//     past the end of a shorter unit) are not fetched; the consumer reads them as records with MAPQ 0 everywhere:
+//     prob_mapq(0) == +0.0 exactly, and x + 0.0 == x for these non-negative sums (the argument of
+//     include/svtyper_hip.h for gated-off reads).
 //
 // The record contract of include/svtyper_hip.h is checked on the fly (svt_scan_kernel's job for the
 // tiled layouts): violations are OR-ed into *err, which the host reads after the pass.

@@ -315,18 +315,39 @@ int create_stream(const svt_evidence_batch* in, svt_batch* b, void* d_records_re
     if (n_rec >= 0xFFFFFFF0ull) return fail(SVT_ERR_INVALID, "too many records in one batch (< 2^32)");
     uint64_t max_f = 0;
     bool wide_var_length = false, all_hinted = n > 0;
-    for (uint64_t u = 0; u < n; ++u) {
-        if (in->rec_offset[u + 1] < in->rec_offset[u]) return fail(SVT_ERR_INVALID, "rec_offset not monotone");
-        const uint64_t f = in->rec_offset[u + 1] - in->rec_offset[u];
-        if (f > 0x3FFFFFFFull) return fail(SVT_ERR_INVALID, "unit with too many records");
-        const svt_unit& U = in->units[u];
-        if (U.svtype > SVT_SVTYPE_BND) return fail(SVT_ERR_INVALID, "bad svtype");
-        if ((U.libs >> 16) != 0 || (U.flags & ~SVT_UNIT_SKIP)) return fail(SVT_ERR_INVALID, "unit reserved/flags bits must be 0");
-        const uint32_t w_lo = U.libs & 0xffu, w_cnt = (U.libs >> 8) & 0xffu;
-        if (w_cnt && w_lo + w_cnt > in->n_libs) return fail(SVT_ERR_INVALID, "unit library window beyond n_libs");
-        all_hinted = all_hinted && w_cnt != 0;
-        if (U.var_length < -(1 << 30) || U.var_length > (1 << 30)) wide_var_length = true;
-        max_f = std::max(max_f, f);
+    {   // the unit arrays, checked by several host threads
+        const uint64_t kChunk = 16384, n_chunks = (n + kChunk - 1) / kChunk;
+        struct Part { uint64_t max_f = 0; int bad = 0; bool wide = false, hinted = true; };
+        std::vector<Part> parts(std::max<uint64_t>(n_chunks, 1));
+        parallel_for(n_chunks, [&](uint64_t ch) {
+            Part p;
+            for (uint64_t u = ch * kChunk; u < std::min(n, (ch + 1) * kChunk); ++u) {
+                if (in->rec_offset[u + 1] < in->rec_offset[u]) { p.bad |= 1; continue; }
+                const uint64_t f = in->rec_offset[u + 1] - in->rec_offset[u];
+                if (f > 0x3FFFFFFFull) p.bad |= 2;
+                const svt_unit& U = in->units[u];
+                if (U.svtype > SVT_SVTYPE_BND) p.bad |= 4;
+                if ((U.libs >> 16) != 0 || (U.flags & ~SVT_UNIT_SKIP)) p.bad |= 8;
+                const uint32_t w_lo = U.libs & 0xffu, w_cnt = (U.libs >> 8) & 0xffu;
+                if (w_cnt && w_lo + w_cnt > in->n_libs) p.bad |= 16;
+                p.hinted = p.hinted && w_cnt != 0;
+                if (U.var_length < -(1 << 30) || U.var_length > (1 << 30)) p.wide = true;
+                p.max_f = std::max(p.max_f, f);
+            }
+            parts[ch] = p;
+        });
+        int bad = 0;
+        for (uint64_t ch = 0; ch < n_chunks; ++ch) {
+            bad |= parts[ch].bad;
+            max_f = std::max(max_f, parts[ch].max_f);
+            wide_var_length = wide_var_length || parts[ch].wide;
+            all_hinted = all_hinted && parts[ch].hinted;
+        }
+        if (bad & 1) return fail(SVT_ERR_INVALID, "rec_offset not monotone");
+        if (bad & 2) return fail(SVT_ERR_INVALID, "unit with too many records");
+        if (bad & 4) return fail(SVT_ERR_INVALID, "bad svtype");
+        if (bad & 8) return fail(SVT_ERR_INVALID, "unit reserved/flags bits must be 0");
+        if (bad & 16) return fail(SVT_ERR_INVALID, "unit library window beyond n_libs");
     }
     tm.mark("validate units");
     HostTables T;
