@@ -104,6 +104,106 @@ struct DevicePool {
 };
 inline DevicePool g_pool;
 
+// Streams, events and the small table buffers of a batch, kept between batches: hipStreamCreate / hipStreamDestroy /
+// hipEventCreate / hipMalloc / hipFree of a dozen objects per batch cost ~10 ms of a 45 ms one-shot (hipFree and
+// hipStreamDestroy synchronise the device), which a chunked driver pays on every chunk.  Everything handed back
+// must be idle.  svt_trim() releases the lot.
+struct HandlePool {
+    static constexpr int kMaxDevices = CsrScratchCache::kMaxDevices;
+    std::mutex lock;
+    std::vector<hipStream_t> streams[kMaxDevices];
+    std::vector<hipEvent_t> timing_events[kMaxDevices], plain_events[kMaxDevices];
+    struct Small { void* p; uint64_t cap; };
+    std::vector<Small> smalls[kMaxDevices];
+    static int dev()
+    {
+        int d = 0;
+        if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= kMaxDevices) d = 0;
+        return d;
+    }
+    int get_stream(hipStream_t* s)
+    {
+        const int d = dev();
+        {
+            std::lock_guard<std::mutex> g(lock);
+            if (!streams[d].empty()) { *s = streams[d].back(); streams[d].pop_back(); return SVT_OK; }
+        }
+        HIP_TRY(hipStreamCreateWithFlags(s, hipStreamNonBlocking));
+        return SVT_OK;
+    }
+    void put_stream(hipStream_t s)
+    {
+        if (!s) return;
+        std::lock_guard<std::mutex> g(lock);
+        streams[dev()].push_back(s);
+    }
+    int get_event(hipEvent_t* e, bool timing)
+    {
+        const int d = dev();
+        {
+            std::lock_guard<std::mutex> g(lock);
+            auto& v = timing ? timing_events[d] : plain_events[d];
+            if (!v.empty()) { *e = v.back(); v.pop_back(); return SVT_OK; }
+        }
+        if (timing) HIP_TRY(hipEventCreate(e));
+        else HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
+        return SVT_OK;
+    }
+    void put_event(hipEvent_t e, bool timing)
+    {
+        if (!e) return;
+        std::lock_guard<std::mutex> g(lock);
+        (timing ? timing_events : plain_events)[dev()].push_back(e);
+    }
+    // device buffers of at most 1 MiB (look-up tables, descriptors): sizes rounded up to a power of two
+    int get_small(uint64_t bytes, void** p)
+    {
+        uint64_t cap = 256;
+        while (cap < bytes) cap <<= 1;
+        const int d = dev();
+        {
+            std::lock_guard<std::mutex> g(lock);
+            for (size_t i = 0; i < smalls[d].size(); ++i)
+                if (smalls[d][i].cap == cap) {
+                    *p = smalls[d][i].p;
+                    smalls[d].erase(smalls[d].begin() + (long)i);
+                    return SVT_OK;
+                }
+        }
+        HIP_TRY(hipMalloc(p, cap));
+        std::lock_guard<std::mutex> g(lock);
+        small_caps.push_back(Small{*p, cap});
+        return SVT_OK;
+    }
+    void put_small(void* p)
+    {
+        if (!p) return;
+        std::lock_guard<std::mutex> g(lock);
+        for (const Small& s : small_caps)
+            if (s.p == p) { smalls[dev()].push_back(s); return; }
+        (void)hipFree(p);   // not one of ours
+    }
+    std::vector<Small> small_caps;   // every small buffer ever handed out (pointer -> capacity)
+    void trim()
+    {
+        std::lock_guard<std::mutex> g(lock);
+        for (int d = 0; d < kMaxDevices; ++d) {
+            if (streams[d].empty() && timing_events[d].empty() && plain_events[d].empty() && smalls[d].empty()) continue;
+            (void)hipSetDevice(d);
+            for (hipStream_t s : streams[d]) (void)hipStreamDestroy(s);
+            for (hipEvent_t e : timing_events[d]) (void)hipEventDestroy(e);
+            for (hipEvent_t e : plain_events[d]) (void)hipEventDestroy(e);
+            for (const Small& s : smalls[d]) {
+                (void)hipFree(s.p);
+                for (size_t i = 0; i < small_caps.size(); ++i)
+                    if (small_caps[i].p == s.p) { small_caps.erase(small_caps.begin() + (long)i); break; }
+            }
+            streams[d].clear(); timing_events[d].clear(); plain_events[d].clear(); smalls[d].clear();
+        }
+    }
+};
+inline HandlePool g_handles;
+
 // Pinned staging rings, one per device (allocated on first use): the callers of one device take turns on its
 // ring, callers of different devices (svt_genotype_multi: one host thread per GPU) copy concurrently.
 struct StagingRing {
@@ -146,8 +246,7 @@ public:
     ~Stager()
     {
         (void)hipStreamSynchronize(stream_);   // the ring is reusable once the last piece has left
-        for (int i = 0; i < StagingRing::kSlots; ++i)
-            if (done_[i]) (void)hipEventDestroy(done_[i]);
+        for (int i = 0; i < StagingRing::kSlots; ++i) g_handles.put_event(done_[i], false);
     }
     int copy(void* dst, const void* src, uint64_t bytes)
     {
@@ -158,8 +257,7 @@ public:
         }
         SVT_TRY(ring_.ensure());
         for (int i = 0; i < StagingRing::kSlots; ++i)
-            if (!done_[i] && hipEventCreateWithFlags(&done_[i], hipEventDisableTiming) != hipSuccess)
-                return fail(SVT_ERR_HIP, "hipEventCreate");
+            if (!done_[i]) SVT_TRY(g_handles.get_event(&done_[i], false));
         const unsigned nt = std::min(host_threads(), 6u);   // 4-8 threads saturate the host copy
         for (uint64_t off = 0; off < bytes; slot_ = (slot_ + 1) % StagingRing::kSlots) {
             const uint64_t len = std::min(StagingRing::kPiece, bytes - off);

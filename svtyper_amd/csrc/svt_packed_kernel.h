@@ -32,6 +32,8 @@ struct PackedArgs {
     uint32_t lds_rings;           // byte offset of wave 0's ring (128-byte aligned)
     uint32_t l10_where;           // kL10Shared / kL10Global
     uint32_t lds_l10;
+    uint32_t unit_begin;          // this launch covers units [unit_begin, unit_end)
+    uint32_t unit_end;
     uint64_t n_units;
     svt_result* out;
     LibDesc lib0;
@@ -48,7 +50,7 @@ __global__ __launch_bounds__(kBlock, 3) void svt_packed_kernel(const PackedArgs 
     if ((uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)smem != 0u) __builtin_trap();
     unsigned char* rings = smem + a.lds_rings;
     const uint32_t tid = threadIdx.x, wave = tid / kWave, lane = tid % kWave;
-    const uint64_t wg_base = (uint64_t)blockIdx.x * kUnitsPerWg;
+    const uint64_t wg_base = (uint64_t)a.unit_begin + (uint64_t)blockIdx.x * kUnitsPerWg;
 
     uint32_t beg[R], cnt[R];
 #pragma unroll
@@ -56,7 +58,7 @@ __global__ __launch_bounds__(kBlock, 3) void svt_packed_kernel(const PackedArgs 
         const uint64_t u = wg_base + (uint32_t)j * kBlock + tid;
         beg[j] = 0u;
         cnt[j] = 0u;
-        if (u < a.n_units) {
+        if (u < a.unit_end) {
             beg[j] = a.slot_offset[3 * u];
             cnt[j] = a.slot_offset[3 * u + 3] - beg[j];
         }
@@ -87,7 +89,7 @@ __global__ __launch_bounds__(kBlock, 3) void svt_packed_kernel(const PackedArgs 
         for (uint32_t i = tid; i < a.n_l10; i += kBlock) s_l10[i] = a.l10[i];
     }
     uint4 info[R];
-    wg_sort_into_tiles<R>(rings, beg, cnt, (uint32_t)min((uint64_t)kUnitsPerWg, a.n_units - wg_base), tid, lane, wave, info);
+    wg_sort_into_tiles<R>(rings, beg, cnt, (uint32_t)min((uint64_t)kUnitsPerWg, (uint64_t)a.unit_end - wg_base), tid, lane, wave, info);
 
     unsigned char* ring = rings + wave * kRingBytes;
     const uint32_t ring_addr = (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)ring;

@@ -87,6 +87,8 @@ struct StreamArgs {
     const uint2* chunks;         // one per workgroup: {first position in perm, units (<= 256 * R)} -- never crosses a group
     const WgDesc* windows;       // one per workgroup: the libraries / bins it stages
     uint32_t lds_winlibs;        // byte offset of the WinLib descriptors (after the bins)
+    uint32_t unit_begin;         // this launch covers units [unit_begin, unit_end) (the pipelined one-shot launches
+    uint32_t unit_end;           // one range per uploaded piece; a pass over a resident batch: [0, n_units))
     uint32_t pad0;
     LibDesc lib0;
     GtConsts c;
@@ -230,7 +232,7 @@ __global__ __launch_bounds__(kBlock, MODE == kSingleLds ? SVT_STREAM_WAVES : 2) 
     const uint32_t tid = threadIdx.x, wave = tid / kWave, lane = tid % kWave;
     // this workgroup's units: 256 * R consecutive ones, or (library windows) a chunk of the permutation that groups
     // the units by the libraries of their sample
-    uint32_t wg_base = blockIdx.x * kUnitsPerWg, n_here;
+    uint32_t wg_base = a.unit_begin + blockIdx.x * kUnitsPerWg, n_here;
     WgDesc wd{};
     if (MODE == kMultiLds) {
         const uint2 ch = a.chunks[blockIdx.x];
@@ -238,7 +240,7 @@ __global__ __launch_bounds__(kBlock, MODE == kSingleLds ? SVT_STREAM_WAVES : 2) 
         n_here = ch.y;
         wd = a.windows[blockIdx.x];
     } else {
-        n_here = (uint32_t)min((uint64_t)kUnitsPerWg, a.n_units - wg_base);
+        n_here = min(kUnitsPerWg, a.unit_end - wg_base);
     }
     auto unit_at = [&](const uint32_t local) -> uint32_t { return MODE == kMultiLds ? a.perm[wg_base + local] : wg_base + local; };
 

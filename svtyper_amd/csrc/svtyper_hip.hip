@@ -143,7 +143,10 @@ void free_batch(svt_batch* b)
 {
     if (!b) return;
     (void)hipSetDevice(b->device);
-    auto F = [](void* p) { if (p) (void)hipFree(p); };
+    // nothing of this batch may still be in flight when its buffers go back to the pool for the next one to take
+    // (a create that failed half way has copies enqueued; a caller may destroy right after an asynchronous pass)
+    if (b->stream) (void)hipStreamSynchronize(b->stream);
+    auto F = [](void* p) { g_handles.put_small(p); };
     g_pool.put(b->device, b->d_tiled, b->cap_tiled);
     g_pool.put(b->device, b->d_hdr, b->cap_hdr);
     g_pool.put(b->device, b->d_out, b->cap_out);
@@ -156,9 +159,9 @@ void free_batch(svt_batch* b)
     F(b->d_err);
     F(b->d_tiles); F(b->d_pm); F(b->d_l10); F(b->d_libs);
     F(b->d_bins); F(b->d_wtab); F(b->d_wg);
-    if (b->ev0) (void)hipEventDestroy(b->ev0);
-    if (b->ev1) (void)hipEventDestroy(b->ev1);
-    if (b->stream) (void)hipStreamDestroy(b->stream);
+    g_handles.put_event(b->ev0, true);
+    g_handles.put_event(b->ev1, true);
+    g_handles.put_stream(b->stream);   // (idle: synchronised above)
     delete b;
 }
 
@@ -177,7 +180,11 @@ struct DevScratch {
 template <typename T>
 int upload(T** dptr, const std::vector<T>& v, Stager& st)
 {
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(dptr), std::max<size_t>(v.size(), 1) * sizeof(T)));
+    void* p = nullptr;
+    const uint64_t bytes = std::max<size_t>(v.size(), 1) * sizeof(T);
+    if (bytes <= (1u << 20)) SVT_TRY(g_handles.get_small(bytes, &p));     // free_batch hands these back (put_small)
+    else HIP_TRY(hipMalloc(&p, bytes));
+    *dptr = static_cast<T*>(p);
     return st.copy(*dptr, v.data(), v.size() * sizeof(T));
 }
 
@@ -220,6 +227,31 @@ const void* stream_kernel_for(int mode)
 const void* stream_kernel_of(const svt_batch* b)
 {
     return (b->flags & SVT_FLAG_SSO_ASSOCIATION) ? stream_kernel_for<true>(b->mode) : stream_kernel_for<false>(b->mode);
+}
+
+// units [u0, u1) of a streamed layout (stream: not the library-window mode, whose launch covers window chunks)
+int launch_range(svt_batch* b, uint64_t u0, uint64_t u1, hipStream_t stream)
+{
+    if (u1 <= u0) return SVT_OK;
+    if (b->layout == kLayoutPacked) {
+        PackedArgs a = b->pargs;
+        a.unit_begin = (uint32_t)u0;
+        a.unit_end = (uint32_t)u1;
+        const dim3 grid((unsigned)((u1 - u0 + kBlock - 1) / kBlock)), block(kBlock);
+        void* params[] = {&a};
+        const void* k = (b->flags & SVT_FLAG_SSO_ASSOCIATION) ? reinterpret_cast<const void*>(&svt_packed_kernel<true, 1>)
+                                                             : reinterpret_cast<const void*>(&svt_packed_kernel<false, 1>);
+        HIP_TRY(hipLaunchKernel(k, grid, block, params, b->lds_bytes, stream));
+        return SVT_OK;
+    }
+    StreamArgs a = b->sargs;
+    a.unit_begin = (uint32_t)u0;
+    a.unit_end = (uint32_t)u1;
+    constexpr uint64_t per_wg = (uint64_t)kBlock * SVT_STREAM_R;
+    const dim3 grid((unsigned)((u1 - u0 + per_wg - 1) / per_wg)), block(kBlock);
+    void* params[] = {&a};
+    HIP_TRY(hipLaunchKernel(stream_kernel_of(b), grid, block, params, b->lds_bytes, stream));
+    return SVT_OK;
 }
 
 int launch_genotype(svt_batch* b)
@@ -307,7 +339,8 @@ int check_stream_errors(svt_batch* b)
 // svt_batch_create for the streaming layout: validate the unit arrays, build the tables, put the canonical
 // CSR in HBM as it is.  No scan, no tiling, no re-encoding: the pass reads the records where they lie.
 // `d_records_resident` (from the geometry stage) is adopted: the batch then owns that pool buffer.
-int create_stream(const svt_evidence_batch* in, svt_batch* b, void* d_records_resident = nullptr, uint64_t resident_cap = 0)
+int create_stream(const svt_evidence_batch* in, svt_batch* b, void* d_records_resident = nullptr, uint64_t resident_cap = 0,
+                  bool defer_records = false)   // defer_records: the caller uploads the records itself (pipelined one-shot)
 {
     const uint64_t n = in->n_units;
     const uint64_t n_rec = n ? in->rec_offset[n] : 0;
@@ -393,9 +426,9 @@ int create_stream(const svt_evidence_batch* in, svt_batch* b, void* d_records_re
     T.l10.resize(((size_t)n_l10 + 127) / 128 * 128, 0.0);   // the ring copy of the table moves whole KiB
     tm.mark("build tables");
 
-    HIP_TRY(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
-    HIP_TRY(hipEventCreate(&b->ev0));
-    HIP_TRY(hipEventCreate(&b->ev1));
+    SVT_TRY(g_handles.get_stream(&b->stream));
+    SVT_TRY(g_handles.get_event(&b->ev0, true));
+    SVT_TRY(g_handles.get_event(&b->ev1, true));
 
     const uint64_t n_blk = std::max<uint64_t>((n_rec + kBlockRecords - 1) / kBlockRecords, 1);
     {
@@ -412,7 +445,7 @@ int create_stream(const svt_evidence_batch* in, svt_batch* b, void* d_records_re
         // the tail of the last 128-byte block is read (and contract-checked) like any record: zero it
         if (n_blk * 128 > n_rec * 16)
             HIP_TRY(hipMemsetAsync(static_cast<char*>(b->d_records) + n_rec * 16, 0, n_blk * 128 - n_rec * 16, b->stream));
-        if (!d_records_resident) SVT_TRY(st.copy(b->d_records, in->records, n_rec * sizeof(uint4)));
+        if (!d_records_resident && !defer_records) SVT_TRY(st.copy(b->d_records, in->records, n_rec * sizeof(uint4)));
         SVT_TRY(g_pool.get(b->device, (n + 1) * sizeof(uint64_t), &p, &b->cap_off));
         b->d_off = static_cast<uint64_t*>(p);
         if (n) SVT_TRY(st.copy(b->d_off, in->rec_offset, (n + 1) * sizeof(uint64_t)));
@@ -426,7 +459,8 @@ int create_stream(const svt_evidence_batch* in, svt_batch* b, void* d_records_re
         SVT_TRY(upload(&b->d_wtab, T.wtab, st));
         SVT_TRY(g_pool.get(b->device, std::max<uint64_t>(n, 1) * sizeof(svt_result), &p, &b->cap_out));
         b->d_out = static_cast<svt_result*>(p);
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&b->d_err), sizeof(uint32_t)));
+        SVT_TRY(g_handles.get_small(sizeof(uint32_t), &p));
+        b->d_err = static_cast<uint32_t*>(p);
         HIP_TRY(hipMemsetAsync(b->d_err, 0, sizeof(uint32_t), b->stream));
         SVT_TRY(st.finish());
     }
@@ -488,6 +522,8 @@ int create_stream(const svt_evidence_batch* in, svt_batch* b, void* d_records_re
     }
     a.lds_rings = (uint32_t)tables;
     a.n_units = n;
+    a.unit_begin = 0;
+    a.unit_end = (uint32_t)n;
     a.out = b->d_out;
     a.err = b->d_err;
     a.lib0 = T.libs[0];
@@ -740,7 +776,7 @@ int pack_evidence(const svt_evidence_batch* in, svt_packed_evidence** out)
 }
 
 // svt_batch_create_packed: upload the slots as they are + tables
-int create_packed(const svt_packed_evidence* in, svt_batch* b)
+int create_packed(const svt_packed_evidence* in, svt_batch* b, bool defer_slots = false)
 {
     const uint64_t n = in->n_units;
     StageTimer tm;
@@ -753,9 +789,9 @@ int create_packed(const svt_packed_evidence* in, svt_batch* b)
     if (!(in->split_weight >= 0.0) || !(in->disc_weight >= 0.0) || !std::isfinite(in->split_weight) || !std::isfinite(in->disc_weight))
         return fail(SVT_ERR_INVALID, "weights must be finite and >= 0");
 
-    HIP_TRY(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
-    HIP_TRY(hipEventCreate(&b->ev0));
-    HIP_TRY(hipEventCreate(&b->ev1));
+    SVT_TRY(g_handles.get_stream(&b->stream));
+    SVT_TRY(g_handles.get_event(&b->ev0, true));
+    SVT_TRY(g_handles.get_event(&b->ev1, true));
     // ---- the slots leave first (page-locked by svt_pack_evidence: straight DMA); the unit arrays are checked
     // while they are on the wire
     void* p = nullptr;
@@ -770,7 +806,7 @@ int create_packed(const svt_packed_evidence* in, svt_batch* b)
     const bool slots_pinned = in->n_slots && g_pinned.is_pinned(in->slots, in->n_slots * 16);
     const bool off_pinned = n && g_pinned.is_pinned(in->slot_offset, (3 * n + 1) * sizeof(uint32_t));
     const bool units_pinned = n && g_pinned.is_pinned(in->units, n * sizeof(svt_unit));
-    if (slots_pinned) HIP_TRY(hipMemcpyAsync(b->d_records, in->slots, in->n_slots * 16, hipMemcpyHostToDevice, b->stream));
+    if (slots_pinned && !defer_slots) HIP_TRY(hipMemcpyAsync(b->d_records, in->slots, in->n_slots * 16, hipMemcpyHostToDevice, b->stream));
     if (off_pinned) HIP_TRY(hipMemcpyAsync(b->d_soff, in->slot_offset, (3 * n + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, b->stream));
     if (units_pinned) HIP_TRY(hipMemcpyAsync(b->d_units, in->units, n * sizeof(svt_unit), hipMemcpyHostToDevice, b->stream));
     tm.mark("allocations + DMA enqueued");
@@ -816,7 +852,7 @@ int create_packed(const svt_packed_evidence* in, svt_batch* b)
     tm.mark("validate + tables");
     {
         Stager st(b->stream);
-        if (in->n_slots && !slots_pinned) SVT_TRY(st.copy(b->d_records, in->slots, in->n_slots * 16));
+        if (in->n_slots && !slots_pinned && !defer_slots) SVT_TRY(st.copy(b->d_records, in->slots, in->n_slots * 16));
         if (n && !off_pinned) SVT_TRY(st.copy(b->d_soff, in->slot_offset, (3 * n + 1) * sizeof(uint32_t)));
         if (n && !units_pinned) SVT_TRY(st.copy(b->d_units, in->units, n * sizeof(svt_unit)));
         SVT_TRY(upload(&b->d_pm, T.pm, st));
@@ -853,6 +889,8 @@ int create_packed(const svt_packed_evidence* in, svt_batch* b)
     }
     a.lds_rings = (uint32_t)tables;
     a.n_units = n;
+    a.unit_begin = 0;
+    a.unit_end = (uint32_t)n;
     a.out = b->d_out;
     a.lib0 = T.libs[0];
     fill_gt_consts(a.c, in->split_weight, in->disc_weight);
@@ -898,9 +936,9 @@ int create_on_device(const svt_evidence_batch* in, svt_batch* b, const uint4* d_
     if (wide_var_length) T.fast_geometry = false;
     tm.mark("build tables");
 
-    HIP_TRY(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
-    HIP_TRY(hipEventCreate(&b->ev0));
-    HIP_TRY(hipEventCreate(&b->ev1));
+    SVT_TRY(g_handles.get_stream(&b->stream));
+    SVT_TRY(g_handles.get_event(&b->ev0, true));
+    SVT_TRY(g_handles.get_event(&b->ev1, true));
 
     // ---- canonical records to the device; validate them and count the sparse-stream entries
     DevScratch d_off, d_counts, d_err, d_units;
@@ -1143,6 +1181,90 @@ int create_on_device(const svt_evidence_batch* in, svt_batch* b, const uint4* d_
     return SVT_OK;
 }
 
+// ------------------------------------------------------------------------------------------
+// one shot, pipelined: H2D || kernel || D2H (the reference's 2-pass batch pipeline, singlesample.py:710-762,
+// re-cast for one GPU).  The payload -- records or packed slots -- goes up in pieces of whole units on the batch's
+// stream; a piece's units are genotyped on a second stream as soon as it has landed (one launch per piece) and,
+// when the caller's output array is page-locked (svt_pinned_alloc), their result records go down on a third
+// stream while the next piece is still on the wire.  PCIe is full duplex, so the wall time is the upload plus the
+// last piece's pass and download.
+// ------------------------------------------------------------------------------------------
+struct PipeStreams {
+    hipStream_t compute = nullptr, down = nullptr;
+    std::vector<hipEvent_t> events;
+    ~PipeStreams()
+    {
+        if (compute) (void)hipStreamSynchronize(compute);
+        if (down) (void)hipStreamSynchronize(down);
+        for (hipEvent_t e : events) g_handles.put_event(e, false);
+        g_handles.put_stream(compute);
+        g_handles.put_stream(down);
+    }
+    int event(hipEvent_t* e)
+    {
+        SVT_TRY(g_handles.get_event(e, false));
+        events.push_back(*e);
+        return SVT_OK;
+    }
+};
+
+// payload_of(u) = first payload item (16 bytes each) of unit u; upload(i0, i1) enqueues items [i0, i1) on b->stream
+template <typename PayloadOf, typename Upload>
+int run_pipelined(svt_batch* b, svt_result* out, bool* download_left, PayloadOf&& payload_of, Upload&& upload)
+{
+    *download_left = false;
+    const uint64_t n = b->n_units;
+    StageTimer tm0;
+    PipeStreams ps;
+    SVT_TRY(g_handles.get_stream(&ps.compute));
+    SVT_TRY(g_handles.get_stream(&ps.down));
+    const bool out_pinned = n && g_pinned.is_pinned(out, n * sizeof(svt_result));
+    StageTimer tm;
+    static const uint64_t piece_mb = std::getenv("SVT_PIPE_MB") ? std::strtoull(std::getenv("SVT_PIPE_MB"), nullptr, 10) : 64;
+    const uint64_t kPieceItems = (std::max<uint64_t>(piece_mb, 1) << 20) / 16;   // payload per piece (the staging ring's piece size)
+    uint64_t u0 = 0;
+    while (u0 < n) {
+        // the next piece: whole units up to kPieceItems of payload (at least one unit)
+        uint64_t lo = u0 + 1, hi = n;
+        const uint64_t want = payload_of(u0) + kPieceItems;
+        while (lo < hi) {   // largest u1 with payload_of(u1) <= want
+            const uint64_t mid = lo + (hi - lo + 1) / 2;
+            if (payload_of(mid) <= want) lo = mid; else hi = mid - 1;
+        }
+        const uint64_t u1 = lo;
+        SVT_TRY(upload(payload_of(u0), payload_of(u1)));
+        hipEvent_t landed, done;
+        SVT_TRY(ps.event(&landed));
+        HIP_TRY(hipEventRecord(landed, b->stream));
+        HIP_TRY(hipStreamWaitEvent(ps.compute, landed, 0));
+        SVT_TRY(launch_range(b, u0, u1, ps.compute));
+        if (out_pinned) {
+            SVT_TRY(ps.event(&done));
+            HIP_TRY(hipEventRecord(done, ps.compute));
+            HIP_TRY(hipStreamWaitEvent(ps.down, done, 0));
+            HIP_TRY(hipMemcpyAsync(out + u0, b->args.out + u0, (u1 - u0) * sizeof(svt_result), hipMemcpyDeviceToHost, ps.down));
+        }
+        u0 = u1;
+    }
+    tm.mark("pipeline: pieces enqueued");
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    tm.mark("pipeline: uploads done");
+    HIP_TRY(hipStreamSynchronize(ps.compute));
+    b->have_results = true;
+    SVT_TRY(check_stream_errors(b));
+    tm.mark("pipeline: passes done");
+    if (out_pinned) {
+        HIP_TRY(hipStreamSynchronize(ps.down));
+    } else {
+        *download_left = true;   // pageable output: the caller downloads through the staging ring once it is free
+    }
+    tm.mark("pipeline: downloads done");
+    (void)tm0;
+    return SVT_OK;
+}
+
+constexpr uint64_t kPipelineMinUnits = 32768;   // below this one upload + one launch is as good
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------
@@ -1247,8 +1369,8 @@ static int svt_batch_create_from_fragments_impl(const svt_fragment_batch* in, in
 
     // geometry on the device
     hipStream_t s = nullptr;
-    HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-    struct StreamGuard { hipStream_t s; ~StreamGuard() { (void)hipStreamDestroy(s); } } sg{s};
+    SVT_TRY(g_handles.get_stream(&s));
+    struct StreamGuard { hipStream_t s; ~StreamGuard() { (void)hipStreamSynchronize(s); g_handles.put_stream(s); } } sg{s};
     StageTimer tm;
     // the two big buffers of this stage come from the pool svt_batch_destroy refills (svt_host_transfer.h)
     struct Pooled {
@@ -1630,6 +1752,40 @@ int svt_batch_create_packed(const svt_packed_evidence* in, int device, unsigned 
 
 static int svt_genotype_packed_impl(const svt_packed_evidence* in, svt_result* out, int device, unsigned flags)
 {
+    if (in && out && !(flags & ~SVT_FLAG_SSO_ASSOCIATION) && in->n_units >= kPipelineMinUnits && in->n_units < 0x55555550ull &&
+        in->slot_offset && in->slots) {
+        const int ndev = svt_device_count();
+        if (ndev <= 0) return fail(SVT_ERR_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
+        if (device < 0 || device >= ndev) return fail(SVT_ERR_NO_DEVICE, "device index out of range");
+        HIP_TRY(hipSetDevice(device));
+        svt_batch* b = new (std::nothrow) svt_batch();
+        if (!b) return fail(SVT_ERR_NOMEM, "out of host memory");
+        b->device = device;
+        b->flags = flags;
+        b->layout = kLayoutPacked;
+        b->n_units = in->n_units;
+        b->n_records = in->n_records;
+        int rc = create_packed(in, b, /*defer_slots=*/true);
+        if (rc == SVT_OK) {
+            bool download_left = false;
+            {
+            Stager st(b->stream);
+            const bool pinned = g_pinned.is_pinned(in->slots, in->n_slots * 16);
+            rc = run_pipelined(b, out, &download_left, [&](uint64_t u) { return (uint64_t)in->slot_offset[3 * u]; },
+                               [&](uint64_t i0, uint64_t i1) -> int {
+                                   char* dst = static_cast<char*>(b->d_records) + i0 * 16;
+                                   const char* src = static_cast<const char*>(in->slots) + i0 * 16;
+                                   if (pinned) { HIP_TRY(hipMemcpyAsync(dst, src, (i1 - i0) * 16, hipMemcpyHostToDevice, b->stream)); return SVT_OK; }
+                                   return st.copy(dst, src, (i1 - i0) * 16);
+                               });
+            }
+            if (rc == SVT_OK && download_left) rc = d2h_staged(out, b->args.out, in->n_units * sizeof(svt_result), b->stream);
+        }
+        const std::string keep = g_err;
+        free_batch(b);
+        g_err = keep;
+        return rc;
+    }
     svt_batch* b = nullptr;
     SVT_TRY(svt_batch_create_packed(in, device, flags, &b));
     int rc = svt_batch_genotype(b, 1);
@@ -1655,10 +1811,55 @@ void svt_trim(void)
     g_pool.trim();
     g_host.trim();
     g_pinned.trim();
+    g_handles.trim();
 }
 
 static int svt_genotype_impl(const svt_evidence_batch* in, svt_result* out, int device, unsigned flags)
 {
+    // the streamed layout from host records: upload, pass and download overlap by unit ranges
+    if (in && out && layout_of_flags(flags) == kLayoutStream && !(flags & ~kKnownFlags) && in->n_units >= kPipelineMinUnits &&
+        in->n_units < 0xFFFFFFF0ull && in->rec_offset && in->units && in->records && in->n_libs >= 1 && in->n_libs <= 256 && in->libs &&
+        in->rec_offset[0] == 0 && in->split_weight >= 0.0 && in->disc_weight >= 0.0 && std::isfinite(in->split_weight) &&
+        std::isfinite(in->disc_weight)) {
+        const int ndev = svt_device_count();
+        if (ndev <= 0) return fail(SVT_ERR_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
+        if (device < 0 || device >= ndev) return fail(SVT_ERR_NO_DEVICE, "device index out of range");
+        HIP_TRY(hipSetDevice(device));
+        svt_batch* b = new (std::nothrow) svt_batch();
+        if (!b) return fail(SVT_ERR_NOMEM, "out of host memory");
+        b->device = device;
+        b->flags = flags;
+        b->layout = kLayoutStream;
+        b->n_units = in->n_units;
+        b->n_records = in->rec_offset[in->n_units];
+        int rc = create_stream(in, b, nullptr, 0, /*defer_records=*/true);
+        if (rc == SVT_OK && b->mode == kMultiLds) {
+            // library windows: the launch walks window chunks, not unit ranges -- upload in one piece, one launch
+            rc = h2d_staged(b->d_records, in->records, b->n_records * sizeof(uint4), b->stream);
+            if (rc == SVT_OK) rc = svt_batch_genotype(b, 1);
+            if (rc == SVT_OK) rc = svt_batch_results(b, out, in->n_units);
+        } else if (rc == SVT_OK) {
+            bool download_left = false;
+            {
+            Stager st(b->stream);   // (holds this device's staging ring)
+            const bool pinned = g_pinned.is_pinned(in->records, b->n_records * sizeof(uint4));
+            rc = run_pipelined(b, out, &download_left, [&](uint64_t u) { return in->rec_offset[u]; },
+                               [&](uint64_t i0, uint64_t i1) -> int {
+                                   char* dst = static_cast<char*>(b->d_records) + i0 * 16;
+                                   const char* src = reinterpret_cast<const char*>(in->records) + i0 * 16;
+                                   if (pinned) { HIP_TRY(hipMemcpyAsync(dst, src, (i1 - i0) * 16, hipMemcpyHostToDevice, b->stream)); return SVT_OK; }
+                                   return st.copy(dst, src, (i1 - i0) * 16);
+                               });
+            }
+            if (rc == SVT_OK && download_left) rc = d2h_staged(out, b->args.out, in->n_units * sizeof(svt_result), b->stream);
+        }
+        const std::string keep = g_err;
+        StageTimer tm;
+        free_batch(b);
+        tm.mark("one shot: batch released");
+        g_err = keep;
+        return rc;
+    }
     svt_batch* b = nullptr;
     SVT_TRY(svt_batch_create(in, device, flags, &b));
     int rc = svt_batch_genotype(b, 1);

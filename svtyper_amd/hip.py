@@ -234,9 +234,11 @@ def pinned_results(n_units: int) -> Results:
     return res
 
 
-def genotype_packed(packed: PackedEvidence, device: int = 0, flags: int = 0) -> Results:
-    """svt_genotype_packed: create_packed + one pass + results + destroy."""
-    out = Results.empty(packed.n_units)
+def genotype_packed(packed: PackedEvidence, device: int = 0, flags: int = 0, out: Optional[Results] = None) -> Results:
+    """svt_genotype_packed: create_packed + one pass + results + destroy, upload / pass / download overlapped by unit
+    ranges.  `out`: a Results to fill (pinned_results(n): the records then come down by DMA while later pieces go up)."""
+    if out is None:
+        out = Results.empty(packed.n_units)
     _check(load().svt_genotype_packed(packed._p, C.c_void_p(out.ptr()), int(device), int(flags)))
     return out
 
@@ -405,13 +407,15 @@ def genotype_fragments(fbatch, device: int = 0, flags: int = 0, site_qual=None) 
         return _finish(d, site_qual)
 
 
-def genotype_batch(batch: EvidenceBatch, device: int = 0, flags: int = 0, site_qual=None) -> Results:
-    """create + genotype + results + destroy (svt_genotype)."""
+def genotype_batch(batch: EvidenceBatch, device: int = 0, flags: int = 0, site_qual=None, out: Optional[Results] = None) -> Results:
+    """create + genotype + results + destroy (svt_genotype: upload, pass and download overlapped by unit ranges).
+    `out`: a Results to fill instead of a fresh one (pinned_results(n) for a page-locked one)."""
     if site_qual is not None:
         with DeviceBatch(batch, device, flags) as d:
             return _finish(d, site_qual)
     L = load()
-    out = Results.empty(batch.n_units)
+    if out is None:
+        out = Results.empty(batch.n_units)
     cb = batch.as_c()
     _check(L.svt_genotype(C.byref(cb), C.c_void_p(out.ptr()), int(device), int(flags)))
     return out

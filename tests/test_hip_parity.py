@@ -671,3 +671,38 @@ def test_library_windows_in_the_streaming_kernel(hip_device, fixture_library):
     beyond.units["libs"][3] = ev.unit_libs(len(batch.libs) - 1, 5)
     with pytest.raises(hip.SvtyperHipError):
         hip.genotype_batch(beyond)
+
+
+# ------------------------------------------------------------------------------------------
+# svt_genotype / svt_genotype_packed: upload || pass || download by unit ranges (f4)
+# ------------------------------------------------------------------------------------------
+def test_pipelined_one_shot_equals_the_resident_batch(hip_device, fixture_library):
+    """Above 32 768 units the one-shot entry points upload the payload in pieces of whole units, launch one pass per
+    piece on a second stream and -- into a page-locked output array -- download its records on a third.  Same bytes
+    as create + pass + results, for pageable and page-locked outputs, both associations, records and packed slots;
+    a malformed record in the LAST piece is still reported."""
+    from svtyper_amd import hip
+    batch = synth.make_units(120_000, 91, [fixture_library], svtype_mix=(0.6, 0.2, 0.1, 0.1), mean_frags=60, sd_frags=30,
+                             min_frags=0)
+    assert batch.n_records * 16 > 3 * (32 << 20)          # several 32 MB pieces
+    for flags in (0, ev.FLAG_SSO_ASSOCIATION):
+        with hip.DeviceBatch(batch, hip_device, flags) as d:
+            d.genotype(sync=True)
+            want = d.results().rec.tobytes()
+        assert hip.genotype_batch(batch, hip_device, flags).rec.tobytes() == want
+        pinned = hip.pinned_results(batch.n_units)
+        assert hip.genotype_batch(batch, hip_device, flags, out=pinned).rec.tobytes() == want
+        with hip.PackedEvidence(batch) as p:
+            assert hip.genotype_packed(p, hip_device, flags).rec.tobytes() == want
+            assert hip.genotype_packed(p, hip_device, flags, out=pinned).rec.tobytes() == want
+    bad = synth.make_units(120_000, 91, [fixture_library], svtype_mix=(0.6, 0.2, 0.1, 0.1), mean_frags=60, sd_frags=30, min_frags=0)
+    bad.records["flags"][bad.n_records - 3] |= 1 << 20
+    with pytest.raises(hip.SvtyperHipError) as e:
+        hip.genotype_batch(bad, hip_device)
+    assert "reserved/undefined bits" in str(e.value)
+    # several libraries with windows: one piece, one launch over the window chunks -- same entry point
+    ms = synth.make_multisample(1100, 32, seed=11, mean_frags=30, sd_frags=10, min_frags=4, max_frags=60)
+    assert ms.n_units >= 32768
+    with hip.DeviceBatch(ms, hip_device) as d:
+        d.genotype(sync=True)
+        assert hip.genotype_batch(ms, hip_device).rec.tobytes() == d.results().rec.tobytes()
