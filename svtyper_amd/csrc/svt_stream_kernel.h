@@ -203,7 +203,11 @@ template <bool SSO, bool EDGE>
 __device__ __forceinline__ void record_window(const u32x4 w, const bool mine, const WindowCtx& c, Acc& a)
 {
     const double pp = record_weights<SSO, EDGE>(w, mine, a);
+#if SVT_STREAM_PROBE == 4   // timing only: every record reads descriptor 0
+    const uint32_t la = c.winlibs_at + (min(SVT_REC_LIB(w.w) - c.lib_lo, c.lib_last) >> 8) * (uint32_t)sizeof(WinLib);
+#else
     const uint32_t la = c.winlibs_at + min(SVT_REC_LIB(w.w) - c.lib_lo, c.lib_last) * (uint32_t)sizeof(WinLib);
+#endif
     const u32x4 d = *reinterpret_cast<lds_cu32x4*>((size_t)la);          // kmin, nb, thr_at, hist_at
     const double sd2 = lds_f64(la + 16u);
     const bool small_del = c.is_del && (c.pos_delta_d < sd2);             // classic.py:339,383
@@ -443,7 +447,7 @@ __global__ __launch_bounds__(kBlock, MODE == kSingleLds ? SVT_STREAM_WAVES : 2) 
                     for (int j = 0; j < 8; ++j) acc.ref_seq += (double)(w[j].x ^ w[j].y ^ w[j].z ^ w[j].w);
                 } else {
                     const bool edge = __any(k8 < head || k8 + kBlockRecords > last);
-                    if (MODE == kMultiLds && wd.lib_cnt == 1u) {       // (workgroup-uniform)
+                    if (MODE == kMultiLds && (wd.lib_cnt == 1u || SVT_STREAM_PROBE == 5)) {       // (workgroup-uniform; probe 5: timing only)
                         if (edge) consume(w, k, std::true_type{}, std::true_type{});
                         else consume(w, k, std::false_type{}, std::true_type{});
                     } else if (edge) consume(w, k, std::true_type{}, std::false_type{});
