@@ -12,7 +12,7 @@ import bench
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 first = int(sys.argv[2]) if len(sys.argv) > 2 else 0      # seeds derive from the iteration number
-t0, it, units = time.time(), first, 0
+t0, it, units, n_packed = time.time(), first, 0, 0
 fixture = bench.fixture_library()
 while time.time() - t0 < budget:
     rng = np.random.default_rng(1000 + it)
@@ -20,7 +20,7 @@ while time.time() - t0 < budget:
     libs = [fixture if (k == 0 and rng.random() < 0.5) else
             synth.normal_library(float(rng.uniform(150, 900)), float(rng.uniform(15, 260)), n=int(rng.integers(3000, 60000)),
                                  seed=int(rng.integers(1 << 30))) for k in range(n_libs)]
-    kind = it % 4
+    kind = it % 5
     if kind == 0:
         b = P._fuzz_batch(5000 + it, libs, wide=bool(rng.integers(2)))
     elif kind == 1:
@@ -30,6 +30,12 @@ while time.time() - t0 < budget:
                              split_weight=float(rng.choice([1.0, 1.0, 0.5, 2.3])), disc_weight=float(rng.choice([1.0, 1.0, 0.25, 3.0])))
     elif kind == 2:
         b = synth.make_edge_cases(libs, seed=it)
+    elif kind == 4:  # several samples with their own libraries: the streaming kernel's library windows (svt_unit.libs)
+        b = synth.make_multisample(int(rng.integers(1, 400)), int(rng.choice([1, 2, 3, 8, 32, 40])), seed=it,
+                                   mean_frags=float(rng.uniform(2, 80)), sd_frags=float(rng.uniform(1, 30)), min_frags=0,
+                                   max_frags=int(rng.integers(40, 200)))
+        if rng.random() < 0.5:      # units in any order, some dropped
+            b = synth.permute_units(b, rng.permutation(b.n_units)[:max(1, int(b.n_units * rng.uniform(0.3, 1.0)))])
     else:   # random bytes again, but inside what the compact layout can express: it must not fall back
         b = P._fuzz_batch(9000 + it, libs, wide=False)
         b.units["var_length"] = np.abs(b.units["var_length"])
@@ -43,7 +49,7 @@ while time.time() - t0 < budget:
             b.records["mapq_a"] &= 0x7f
             b.records["mapq_b"] &= 0x7f
         if all(len(l.hist) <= 4095 for l in libs):
-            with hip.DeviceBatch(b, 0, 0) as d:
+            with hip.DeviceBatch(b, 0, ev.FLAG_COMPACT_LAYOUT) as d:
                 assert d.layout()[0], "expected the compact layout"
     for flags in P.ALL_FLAGS:
         got = hip.genotype_batch(b, 0, flags)
@@ -53,6 +59,18 @@ while time.time() - t0 < budget:
         except AssertionError as e:
             print("MISMATCH at iteration %d (kind %d, %d libs, flags %d): %s" % (it, kind, n_libs, flags, e))
             sys.exit(1)
+    try:                # the packed evidence format, where it can hold the batch: same bytes as the canonical pass
+        packed = hip.PackedEvidence(b)
+    except hip.SvtyperHipError:
+        packed = None
+    if packed is not None:
+        with packed:
+            n_packed += 1
+            for flags in (0, ev.FLAG_SSO_ASSOCIATION):
+                if hip.genotype_packed(packed, 0, flags).rec.tobytes() != hip.genotype_batch(b, 0, flags).rec.tobytes():
+                    print("PACKED MISMATCH at iteration %d (kind %d, %d libs, flags %d)" % (it, kind, n_libs, flags))
+                    sys.exit(1)
     it += 1
     units += b.n_units
-print("soak ok: iterations %d..%d, %d units, %d flag combinations each, %.0f s" % (first, it - 1, units, len(P.ALL_FLAGS), time.time() - t0))
+print("soak ok: iterations %d..%d, %d units, %d flag combinations each, %d batches also as packed evidence, %.0f s"
+      % (first, it - 1, units, len(P.ALL_FLAGS), n_packed, time.time() - t0))
