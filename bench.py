@@ -89,8 +89,9 @@ def generate(name: str, n_units: int, rank: int, workers: int, first_chunk: int 
         import multiprocessing as mp
         from svtyper_amd import synth
         with mp.get_context("fork").Pool(min(max(1, workers), 32)) as pool:
+            lo, hi = (int(x) for x in os.environ.get("SVT_BENCH_C5_LIBS", "1,3").split(","))   # (probes: libraries per sample)
             return synth.make_multisample(max(1, n_units // N_SAMPLES_C5), N_SAMPLES_C5, synth.BASE_SEED + 5 + 7919 * rank,
-                                          pool_map=pool.map)
+                                          libs_per_sample=(lo, hi), pool_map=pool.map)
     chunk = 50_000
     jobs = [(name, min(chunk, n_units - i), first_chunk + i // chunk, rank) for i in range(0, n_units, chunk)]
     if workers > 1 and len(jobs) > 1:

@@ -19,6 +19,10 @@ typedef __attribute__((address_space(3))) const int32_t lds_ci32;
 __device__ __forceinline__ double lds_f64(const uint32_t addr) { return *reinterpret_cast<lds_cf64*>((size_t)addr); }
 __device__ __forceinline__ uint32_t lds_u32(const uint32_t addr) { return *reinterpret_cast<lds_cu32*>((size_t)addr); }
 __device__ __forceinline__ int32_t lds_i32(const uint32_t addr) { return *reinterpret_cast<lds_ci32*>((size_t)addr); }
+typedef __attribute__((address_space(3))) const int16_t lds_ci16;
+typedef __attribute__((address_space(3))) const uint16_t lds_cu16;
+__device__ __forceinline__ int32_t lds_i16(const uint32_t addr) { return *reinterpret_cast<lds_ci16*>((size_t)addr); }
+__device__ __forceinline__ uint32_t lds_u16(const uint32_t addr) { return *reinterpret_cast<lds_cu16*>((size_t)addr); }
 
 // (byte N of e) * 8 in one VALU instruction (SDWA source select + shift): the LDS byte offset of
 // prob_mapq[byte] in the double[256] table

@@ -56,11 +56,12 @@ inline void fill_gt_consts(GtConsts& c, double split_weight, double disc_weight)
 
 struct HostTables {
     std::vector<LibDesc> libs;
-    std::vector<Bin> bins;           // per library: n_bins {threshold, count} + sentinel {-1, 0}
+    std::vector<Bin> bins;           // per library: n_bins {threshold, count} + sentinel {-1, 0}, both as ranks (build_tables)
     std::vector<PairWeights> wtab;   // 32
     std::vector<double> pm;          // 256
     std::vector<double> l10;
     bool fast_geometry = true;       // 32-bit index math + "non-DEL key never integral" valid?
+    bool narrow_bins = true;         // every library's ranks fit 16 bits (the streaming kernel's LDS tables)
 };
 
 inline int build_tables(const svt_evidence_batch* in, uint64_t max_records_per_unit, HostTables& T)
@@ -108,6 +109,26 @@ inline int build_tables(const svt_evidence_batch* in, uint64_t max_records_per_u
         }
         // out-of-range sentinel: Counter miss -> count 0; hist[o] == 0 -> never concordant
         T.bins.push_back(Bin{-1, 0u});
+        // The kernels only ever ask `hist[a] <= thr[b]` inside one library: replace counts and thresholds by their
+        // ranks among the library's values (an order-preserving map, thr = -1 "never" stays -1).  2 n_bins + 1 values
+        // at most, so a library of up to 16 383 bins fits 16-bit tables in LDS (svt_stream_kernel.h).
+        {
+            Bin* lb = T.bins.data() + d.tab_off;
+            std::vector<uint32_t> vals;
+            vals.reserve(2 * (size_t)L.n_bins + 2);
+            for (uint32_t i = 0; i <= L.n_bins; ++i) {
+                vals.push_back(lb[i].hist);
+                if (lb[i].thr >= 0) vals.push_back((uint32_t)lb[i].thr);
+            }
+            std::sort(vals.begin(), vals.end());
+            vals.erase(std::unique(vals.begin(), vals.end()), vals.end());
+            auto rank = [&](const uint32_t x) { return (uint32_t)(std::lower_bound(vals.begin(), vals.end(), x) - vals.begin()); };
+            for (uint32_t i = 0; i <= L.n_bins; ++i) {
+                lb[i].hist = rank(lb[i].hist);
+                if (lb[i].thr >= 0) lb[i].thr = (int32_t)rank((uint32_t)lb[i].thr);
+            }
+            if (vals.size() > 32767) T.narrow_bins = false;
+        }
     }
     // paired-end decision table (see PairWeights)
     T.wtab.resize(32);

@@ -46,6 +46,13 @@
 #define SVT_STREAM_WAVES 3 // waves per SIMD the register allocation must allow (three workgroups per CU)
 #endif
 
+#ifndef SVT_PROBE_LDS_PAD
+#define SVT_PROBE_LDS_PAD 0 // timing only: unused LDS added to every streaming workgroup (fewer resident workgroups per CU)
+#endif
+#ifndef SVT_WINDOW_WAVES
+#define SVT_WINDOW_WAVES 3 // library windows: waves per SIMD the register allocation must allow (3 spilled registers at 3; 2: 178 VGPRs)
+#endif
+
 #include <type_traits>
 
 #include "svt_ring_engine.h"
@@ -59,7 +66,7 @@ constexpr uint32_t kSPm = 0;                          // double[256]  prob_mapq(
 constexpr uint32_t kSPmHalf = kSPm + 256 * 8;         // double[256]  prob_mapq(q) / 2 (exact: a power-of-two scaling)
 constexpr uint32_t kSWtab = kSPmHalf + 256 * 8;       // kSingleLds: double w_alt[32], w_ref[32] (columns); kGeneral: PairWeights[32]
 constexpr uint32_t kSWref = 32 * 8;                   // byte distance w_alt[i] -> w_ref[i]
-constexpr uint32_t kSBins = kSWtab + 2 * 32 * 8;      // kSingleLds: int32 thr[total_bins], uint32 hist[total_bins]; kGeneral: LibDesc[n_libs]
+constexpr uint32_t kSBins = kSWtab + 2 * 32 * 8;      // kSingleLds: int16 thr[total_bins], uint16 hist[total_bins] (ranks, svt_host_tables.h); kGeneral: LibDesc[n_libs]
 
 struct StreamArgs {
     const uint4* records;        // canonical records; the allocation ends on a 128-byte block boundary, tail zeroed
@@ -110,20 +117,25 @@ static_assert(sizeof(WinLib) == 32, "WinLib is read as two 16-byte halves");
 template <int MODE>
 struct RecordCheck {
     uint32_t flags_or = 0, span_or = 0, lone = 0, lib_max = 0;
-    __device__ __forceinline__ void see(const u32x4 w, const uint32_t lib_lo = 0u)
+    // kMultiLds: `lib_key` = the library byte every record must carry when the window holds ONE library (else 0)
+    __device__ __forceinline__ void see(const u32x4 w, const uint32_t lib_key = 0u)
     {
-        flags_or |= w.w;                                     // undefined bits; with one library also the library byte
+        if (MODE == kMultiLds) flags_or |= w.w ^ lib_key;   // a one-library window: the library byte must cancel
+        else flags_or |= w.w;                                // undefined bits; with one library also the library byte
         span_or |= w.x;                                      // sign bit: a negative ospan_len
         lone = max(lone, (w.w & 0x17u) ^ 0x10u);             // > 0x10: straddle bits without HAS_PAIR
         if (MODE == kGeneral) lib_max = max(lib_max, w.w & 0xff00u);
-        if (MODE == kMultiLds) lib_max = max(lib_max, SVT_REC_LIB(w.w) - lib_lo);   // (unsigned: below the window = huge)
     }
+    // kMultiLds, windows of several libraries: the consumer has `library - first library of the window` at hand
+    // (unsigned: below the window = huge).  One more loop-carried value in see() costs the kernel its third wave.
+    __device__ __forceinline__ void window_lib(const uint32_t d) { lib_max = max(lib_max, d); }
     // kMultiLds: `limit` = libraries in the unit's window
     __device__ __forceinline__ uint32_t bits(const uint32_t limit) const
     {
         const uint32_t n_libs = limit;
         const bool bad_lib = MODE == kSingleLds ? (flags_or & 0xff00u) != 0u
-                             : MODE == kMultiLds ? lib_max >= limit : (lib_max >> SVT_REC_LIB_SHIFT) >= n_libs;
+                             : MODE == kMultiLds ? (limit == 1u ? (flags_or & 0xff00u) != 0u : lib_max >= limit)
+                                                 : (lib_max >> SVT_REC_LIB_SHIFT) >= n_libs;
         return (lone > 0x10u ? kErrStraddleNoPair : 0u) | (bad_lib ? kErrLibIndex : 0u) |
                ((flags_or & ~SVT_REC_FLAG_MASK) ? kErrReservedBits : 0u) | ((int32_t)span_or < 0 ? kErrNegativeSpan : 0u);
     }
@@ -176,8 +188,8 @@ __device__ __forceinline__ void record_single(const u32x4 w, const bool mine, co
     const double pp = record_weights<SSO, EDGE>(w, mine, a);
     // p_concordant as the integer test hist[o - v] <= thr[o] (svt_host_tables.h), out-of-range -> sentinel bin
     const uint32_t i1 = min(w.x - c.kmin, c.nb), i2 = min(w.x - c.sub2, c.nb);
-    const int32_t thr1 = lds_i32(kSBins + (i1 << 2));
-    const uint32_t h2 = lds_u32(c.hist_at + (i2 << 2));
+    const int32_t thr1 = lds_i16(kSBins + (i1 << 1));
+    const uint32_t h2 = lds_u16(c.hist_at + (i2 << 1));
     const bool p_conc = (int32_t)h2 <= thr1;
     const uint32_t wa = (p_conc ? c.wt1 : c.wt0) | ((w.w & c.fmask) << 3);   // &w_alt[f3 | p_conc << 3 | del16]
     a.alt_span += pp * lds_f64(wa);
@@ -199,10 +211,11 @@ typedef __attribute__((address_space(3))) const u32x4 lds_cu32x4;
 
 // The same record with several libraries: the record's library picks one of the window's descriptors (a
 // record that names a library outside its unit's window is reported by RecordCheck and reads the nearest one).
-template <bool SSO, bool EDGE>
-__device__ __forceinline__ void record_window(const u32x4 w, const bool mine, const WindowCtx& c, Acc& a)
+template <bool SSO, bool EDGE, class CHECK>
+__device__ __forceinline__ void record_window(const u32x4 w, const bool mine, const WindowCtx& c, Acc& a, CHECK& check)
 {
     const double pp = record_weights<SSO, EDGE>(w, mine, a);
+    check.window_lib(EDGE && !mine ? 0u : SVT_REC_LIB(w.w) - c.lib_lo);
 #if SVT_STREAM_PROBE == 4   // timing only: every record reads descriptor 0
     const uint32_t la = c.winlibs_at + (min(SVT_REC_LIB(w.w) - c.lib_lo, c.lib_last) >> 8) * (uint32_t)sizeof(WinLib);
 #else
@@ -214,8 +227,8 @@ __device__ __forceinline__ void record_window(const u32x4 w, const bool mine, co
     const uint32_t f3 = small_del ? 0u : (w.w & 7u);
     const uint32_t sub2 = c.is_del ? c.vl_or_never + d.x : 0x80000000u;
     const uint32_t i1 = min(w.x - d.x, d.y), i2 = min(w.x - sub2, d.y);
-    const int32_t thr1 = lds_i32(d.z + (i1 << 2));
-    const uint32_t h2 = lds_u32(d.w + (i2 << 2));
+    const int32_t thr1 = lds_i16(d.z + (i1 << 1));
+    const uint32_t h2 = lds_u16(d.w + (i2 << 1));
     const bool p_conc = (int32_t)h2 <= thr1;
     const uint32_t wa = (p_conc ? c.wt1 : c.wt0) | (f3 << 3);
     a.alt_span += pp * lds_f64(wa);
@@ -223,7 +236,7 @@ __device__ __forceinline__ void record_window(const u32x4 w, const bool mine, co
 }
 
 template <bool SSO, int MODE, int R>
-__global__ __launch_bounds__(kBlock, MODE == kSingleLds ? SVT_STREAM_WAVES : 2) void svt_stream_kernel(const StreamArgs a)
+__global__ __launch_bounds__(kBlock, MODE == kSingleLds ? SVT_STREAM_WAVES : MODE == kMultiLds ? SVT_WINDOW_WAVES : 2) void svt_stream_kernel(const StreamArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // (lds_rings is 128-byte aligned)
     constexpr uint32_t kUnitsPerWg = kBlock * R;
@@ -279,30 +292,31 @@ __global__ __launch_bounds__(kBlock, MODE == kSingleLds ? SVT_STREAM_WAVES : 2) 
         }
     }
     if (MODE == kSingleLds) {
-        // thr[] and hist[] as two 4-byte arrays: the random look-ups of a wave spread over every LDS bank
-        int32_t* s_thr = reinterpret_cast<int32_t*>(smem + kSBins);
-        uint32_t* s_hst = reinterpret_cast<uint32_t*>(smem + kSBins) + a.total_bins;
+        // thr[] and hist[] as two 2-byte arrays (svt_host_tables.h replaced the counts by their ranks, which is
+        // all `hist[o - v] <= thr[o]` needs): the random look-ups of a wave spread over every LDS bank
+        int16_t* s_thr = reinterpret_cast<int16_t*>(smem + kSBins);
+        uint16_t* s_hst = reinterpret_cast<uint16_t*>(smem + kSBins) + a.total_bins;
         for (uint32_t i = tid; i < a.total_bins; i += kBlock) {
             const Bin bn = a.bins[i];
-            s_thr[i] = bn.thr;
-            s_hst[i] = bn.hist;
+            s_thr[i] = (int16_t)bn.thr;
+            s_hst[i] = (uint16_t)bn.hist;
         }
     } else if (MODE == kMultiLds) {
         // the window's bins as thr[bin_cnt], hist[bin_cnt] and one WinLib per library of the window
-        int32_t* s_thr = reinterpret_cast<int32_t*>(smem + kSBins);
-        uint32_t* s_hst = reinterpret_cast<uint32_t*>(smem + kSBins) + wd.bin_cnt;
+        int16_t* s_thr = reinterpret_cast<int16_t*>(smem + kSBins);
+        uint16_t* s_hst = reinterpret_cast<uint16_t*>(smem + kSBins) + wd.bin_cnt;
         for (uint32_t i = tid; i < wd.bin_cnt; i += kBlock) {
             const Bin bn = a.bins[wd.bin_lo + i];
-            s_thr[i] = bn.thr;
-            s_hst[i] = bn.hist;
+            s_thr[i] = (int16_t)bn.thr;
+            s_hst[i] = (uint16_t)bn.hist;
         }
         if (tid < wd.lib_cnt) {
             const LibDesc L = a.libs[wd.lib_lo + tid];
             WinLib wl;
             wl.kmin = (uint32_t)L.key_min;
             wl.nb = L.n_bins;
-            wl.thr_at = kSBins + (L.tab_off - wd.bin_lo) * 4u;
-            wl.hist_at = kSBins + (wd.bin_cnt + L.tab_off - wd.bin_lo) * 4u;
+            wl.thr_at = kSBins + (L.tab_off - wd.bin_lo) * 2u;
+            wl.hist_at = kSBins + (wd.bin_cnt + L.tab_off - wd.bin_lo) * 2u;
             wl.sd2 = L.sd2;
             wl.pad = 0.0;
             reinterpret_cast<WinLib*>(smem + a.lds_winlibs)[tid] = wl;
@@ -338,6 +352,7 @@ __global__ __launch_bounds__(kBlock, MODE == kSingleLds ? SVT_STREAM_WAVES : 2) 
     const char* rec_bytes = reinterpret_cast<const char*>(a.records);
 
     RecordCheck<MODE> check;
+    const uint32_t lib_key = MODE == kMultiLds && wd.lib_cnt == 1u ? wd.lib_lo << SVT_REC_LIB_SHIFT : 0u;
 
 #if SVT_STREAM_UNROLL_TILES
 #pragma unroll
@@ -383,7 +398,7 @@ __global__ __launch_bounds__(kBlock, MODE == kSingleLds ? SVT_STREAM_WAVES : 2) 
             sc.kmin = (uint32_t)a.lib0.key_min;
             sc.nb = a.lib0.n_bins;
             sc.sub2 = c.is_del ? (uint32_t)U.var_length + (uint32_t)a.lib0.key_min : 0x80000000u;
-            sc.hist_at = kSBins + a.total_bins * 4u;
+            sc.hist_at = kSBins + a.total_bins * 2u;
             sc.wt0 = kSWtab + c.del16 * 8u;
             sc.wt1 = sc.wt0 + 8u * 8u;
         }
@@ -409,9 +424,9 @@ __global__ __launch_bounds__(kBlock, MODE == kSingleLds ? SVT_STREAM_WAVES : 2) 
         Acc acc = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
 
         // EDGE = false: every lane's eight records of this block are its own
-        auto consume = [&](const u32x4 (&w)[8], const uint32_t k, auto edge, auto one_library) {
+        auto consume = [&](const u32x4 (&w)[8], const uint32_t k, auto edge, auto window_kind) {
             constexpr bool EDGE = decltype(edge)::value;
-            constexpr bool ONE = decltype(one_library)::value;   // kMultiLds: the window holds one library
+            constexpr int KIND = decltype(window_kind)::value;   // kMultiLds: 1 = the window holds one library, 0 = several
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 // keep the look-ups of the second half of the block from being hoisted over the first half: eight
@@ -419,12 +434,12 @@ __global__ __launch_bounds__(kBlock, MODE == kSingleLds ? SVT_STREAM_WAVES : 2) 
                 if (j == SVT_STREAM_SPLIT) __builtin_amdgcn_sched_barrier(0);
                 const uint32_t idx = k * kBlockRecords + (uint32_t)j;
                 const bool mine = !EDGE || (idx >= head && idx < last);
-                if (mine) check.see(w[j], wd.lib_lo);   // (slots that are not this lane's were not fetched)
+                if (mine) check.see(w[j], lib_key);     // (slots that are not this lane's were not fetched)
                 if (MODE == kSingleLds) {
                     record_single<SSO, EDGE>(w[j], mine, sc, acc);
                 } else if (MODE == kMultiLds) {
-                    if (ONE) record_single<SSO, EDGE>(w[j], mine, sc, acc);
-                    else record_window<SSO, EDGE>(w[j], mine, wc, acc);
+                    if (KIND == 1) record_single<SSO, EDGE>(w[j], mine, sc, acc);
+                    else record_window<SSO, EDGE>(w[j], mine, wc, acc, check);
                 } else {
                     const uint32_t wy = mine ? w[j].y : 0u, wz = mine ? w[j].z : 0u;   // MAPQ 0 everywhere: adds +0.0
                     weight_evidence<SSO>(wy >> 16 | (wz << 16), wz >> 16, (w[j].w & SVT_REC_CONTINUATION) != 0, t, acc);
@@ -447,11 +462,13 @@ __global__ __launch_bounds__(kBlock, MODE == kSingleLds ? SVT_STREAM_WAVES : 2) 
                     for (int j = 0; j < 8; ++j) acc.ref_seq += (double)(w[j].x ^ w[j].y ^ w[j].z ^ w[j].w);
                 } else {
                     const bool edge = __any(k8 < head || k8 + kBlockRecords > last);
+                    using kind_any = std::integral_constant<int, 0>;
+                    using kind_one = std::integral_constant<int, 1>;
                     if (MODE == kMultiLds && (wd.lib_cnt == 1u || SVT_STREAM_PROBE == 5)) {       // (workgroup-uniform; probe 5: timing only)
-                        if (edge) consume(w, k, std::true_type{}, std::true_type{});
-                        else consume(w, k, std::false_type{}, std::true_type{});
-                    } else if (edge) consume(w, k, std::true_type{}, std::false_type{});
-                    else consume(w, k, std::false_type{}, std::false_type{});
+                        if (edge) consume(w, k, std::true_type{}, kind_one{});
+                        else consume(w, k, std::false_type{}, kind_one{});
+                    } else if (edge) consume(w, k, std::true_type{}, kind_any{});
+                    else consume(w, k, std::false_type{}, kind_any{});
                 }
             }
         }

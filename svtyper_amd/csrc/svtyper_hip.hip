@@ -470,10 +470,11 @@ int create_stream(const svt_evidence_batch* in, svt_batch* b, void* d_records_re
     // the tables through L2 with exact 64-bit geometry
     constexpr size_t kStreamLdsPerWg = (160 * 1024 / 3) & ~size_t(127);   // three workgroups per CU
     constexpr size_t kStreamLdsPerWg2 = (160 * 1024 / 2) & ~size_t(127);  // two
-    const size_t single_lds = kSBins + T.bins.size() * sizeof(Bin);
-    const bool single = in->n_libs == 1 && T.fast_geometry && single_lds + kWavesPerBlock * kRingBytes <= 96 * 1024;
-    const size_t window_lds = kSBins + (size_t)max_win_bins * sizeof(Bin) + (size_t)max_win_libs * sizeof(WinLib);
-    windowed = windowed && window_lds + kWavesPerBlock * kRingBytes <= kStreamLdsPerWg2;
+    constexpr size_t kLdsBin = 2 * sizeof(uint16_t);   // thr + hist of one bin in LDS: 16-bit ranks
+    const size_t single_lds = kSBins + T.bins.size() * kLdsBin;
+    const bool single = in->n_libs == 1 && T.fast_geometry && T.narrow_bins && single_lds + kWavesPerBlock * kRingBytes <= 96 * 1024;
+    const size_t window_lds = kSBins + (((size_t)max_win_bins * kLdsBin + 15) & ~size_t(15)) + (size_t)max_win_libs * sizeof(WinLib);
+    windowed = windowed && T.narrow_bins && window_lds + kWavesPerBlock * kRingBytes <= kStreamLdsPerWg2;
     b->mode = single ? kSingleLds : windowed ? kMultiLds : kGeneral;
     if (windowed) {
         Stager st(b->stream);
@@ -504,9 +505,8 @@ int create_stream(const svt_evidence_batch* in, svt_batch* b, void* d_records_re
     a.perm = b->d_perm;
     a.chunks = b->d_chunks;
     a.windows = b->d_windows;
-    a.lds_winlibs = (uint32_t)(kSBins + (size_t)a.lds_bins * sizeof(Bin));
-    size_t tables = kSBins + (size_t)a.lds_bins * sizeof(Bin) + (size_t)a.lds_libs * sizeof(LibDesc) +
-                    (windowed ? (size_t)max_win_libs * sizeof(WinLib) : 0);
+    a.lds_winlibs = (uint32_t)(kSBins + (((size_t)a.lds_bins * kLdsBin + 15) & ~size_t(15)));   // (WinLib is read as 16-byte halves)
+    size_t tables = a.lds_winlibs + (size_t)a.lds_libs * sizeof(LibDesc) + (windowed ? (size_t)max_win_libs * sizeof(WinLib) : 0);
     tables = (tables + 127) & ~size_t(127);
     // the log10 table of the epilogue: beside the tables while three workgroups still fit a CU's 160 KB,
     // else through the wave's ring, else through L2
@@ -529,7 +529,7 @@ int create_stream(const svt_evidence_batch* in, svt_batch* b, void* d_records_re
     a.lib0 = T.libs[0];
     fill_gt_consts(a.c, in->split_weight, in->disc_weight);
     b->args.out = b->d_out;   // svt_batch_device_results / svt_batch_bind_device_results / svt_batch_site_qual
-    b->lds_bytes = tables + kWavesPerBlock * kRingBytes;
+    b->lds_bytes = tables + kWavesPerBlock * kRingBytes + SVT_PROBE_LDS_PAD;
     if (b->lds_bytes > 160 * 1024) return fail(SVT_ERR_INVALID, "LDS budget exceeded");
     if (b->lds_bytes > 64 * 1024)
         HIP_TRY(hipFuncSetAttribute(stream_kernel_of(b), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_bytes));
