@@ -9,8 +9,8 @@ A *step* is ONE pass of the whole hot path over one synthetic batch whose canoni
 rec_offset[], 16-byte unit headers, 16-byte evidence records, exactly as the C ABI receives them) is already
 resident in HBM: a single launch of svt_stream_kernel reads every record once and does the evidence tally, the
 zeroing rules, QR/QA, bayes_gt and the GT/GQ/SQ decision, leaving the 128-byte result records in HBM.  Nothing
-is pre-digested outside the timed region: svt_batch_create for this layout is upload only (no scan, no tiling,
-no re-encoding), so `roofline.achieved` = algorithmic bytes / kernel time cannot exceed the HBM peak.
+is pre-digested outside the timed region: svt_batch_create is upload only (no scan, no tiling, no re-encoding),
+so `roofline.achieved` = algorithmic bytes / kernel time cannot exceed the HBM peak.
 
 Workload: BASELINE.json configs[2] -- 1 M mixed DEL/DUP/INV breakpoints, one library (the reference fixture's
 empirical insert-size histogram, staged in LDS), ~100 fragment records (~200 reads) per breakpoint.
@@ -22,8 +22,8 @@ After the timed region every rank's result records are gathered onto rank 0 with
 (north_star: "a single RCCL gather ... at the end"); its time is reported separately under "gather".
 
 Extra keys on the N=1 line (clearly labelled, never part of `value`): `one_shot` (host buffers -> results on the
-host, PCIe included), `large_batch` (4 M units per GPU: working set far beyond the 256 MiB Infinity Cache),
-`resident_rerun` (the tiled layouts, whose one-off re-encoding is NOT in their pass time), `cpu_baseline`.
+host, PCIe included), `one_shot_packed` (the same from packed evidence), `large_batch` (4 M units per GPU: working
+set far beyond the 256 MiB Infinity Cache), `cpu_baseline`, `parity`.
 
 Prints ONE JSON line on rank 0.
 """
@@ -157,11 +157,8 @@ def main():
     ap.add_argument("--workload", default="c3_mixed_1m", choices=["c3_mixed_1m", "c2_del_100k", "c5_multisample"])
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--sso", action="store_true", help="singlesample.py floating-point association")
-    ap.add_argument("--layout", default="stream", choices=["stream", "short", "compact", "dense"],
-                    help="stream (default): ONE kernel over the canonical CSR records as they lie in HBM; "
-                         "short / compact / dense: the tiled layouts svt_batch_create builds once (re-run figures)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra-legs", action="store_true", help="skip one_shot / large_batch / resident_rerun (N=1 only)")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip one_shot / one_shot_packed / large_batch (N=1 only)")
     ap.add_argument("--no-dense-leg", action="store_true", help="(kept for old command lines) = --no-extra-legs")
     ap.add_argument("--large-units", type=int, default=4_000_000)
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
@@ -223,10 +220,8 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))
 
-    layout_flags = {"stream": 0, "short": ev.FLAG_COMPACT_LAYOUT, "compact": ev.FLAG_FIXED_PAIR_ENTRIES,
-                    "dense": ev.FLAG_DENSE_LAYOUT}
     sso = ev.FLAG_SSO_ASSOCIATION if args.sso else 0
-    flags = sso | layout_flags[args.layout]
+    flags = sso
     t0 = time.time()
     dbatch = hip.DeviceBatch(batch, device=local_rank, flags=flags)
     upload_s = time.time() - t0
@@ -297,7 +292,6 @@ def main():
             "c2_del_100k": "BASELINE.json configs[1]: %d DEL breakpoints%s, 1 library, %.1f fragment records/site",
         }[args.workload] % (total_units if args.scaling == "strong" else n,
                             " in total, sharded over %d GPU(s)" % world if args.scaling == "strong" else " per GPU", per_site)
-        tiled = layout_name != "stream"
         out = {
             "metric": "breakpoints genotyped/sec",
             "value": value,
@@ -317,19 +311,14 @@ def main():
                 "records_per_gpu": batch.n_records,
                 "total_units": total_units,
                 "association": "sso" if args.sso else "classic",
-                "step": ("one launch of svt_stream_kernel over the canonical CSR records resident in HBM -> result records "
-                         "in HBM (whole hot path; nothing pre-digested outside the timed region)") if not tiled else
-                        "one launch of svt_genotype_kernel over tiles svt_batch_create built ONCE, outside the timed region",
-                "device_layout": {"dense": "dense 16-byte records, tiled once at svt_batch_create",
-                                  "compact": "compact sparse 4-byte entry streams, re-encoded once at svt_batch_create",
-                                  "short": "compact sparse entry streams, 2-byte pair entries for the common MAPQ pair, "
-                                           "re-encoded once at svt_batch_create",
-                                  "stream": "the canonical CSR records as uploaded, streamed by the pass itself"}[layout_name],
+                "step": "one launch of svt_stream_kernel over the canonical CSR records resident in HBM -> result records "
+                        "in HBM (whole hot path; nothing pre-digested outside the timed region)",
+                "device_layout": "the canonical CSR records as uploaded, streamed by the pass itself",
                 "parallelism": "units sharded over %d GPU(s), no data-path collective per step" % world,
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "svt_stream_kernel" if not tiled else "svt_genotype_kernel",
+                "kernel": "svt_stream_kernel",
                 "achieved": ach,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
@@ -345,10 +334,8 @@ def main():
                 "kernel_ms_note": "HIP events around the `steps` back-to-back launches of the timed region, divided by `steps`: "
                                   "includes the ~5-10 us between consecutive dispatches that rocprofv3's per-kernel duration leaves out",
                 "library_sha16": library_stamp(),
-                "note": ("`achieved` = ALGORITHMIC bytes (16 B per fragment record + 112 B per unit) over the time of the ONE "
-                         "kernel that does all the work from the canonical input: <= peak by construction") if not tiled else
-                        ("RE-RUN figure: the tiles were built once outside the timed region, so `achieved` (algorithmic bytes "
-                         "over pass time) is not a roofline fraction of the whole path; see --layout stream"),
+                "note": "`achieved` = ALGORITHMIC bytes (16 B per fragment record + 112 B per unit) over the time of the ONE "
+                        "kernel that does all the work from the canonical input: <= peak by construction",
             },
             "host": {"generate_s": gen_s, "first_create_s": upload_s},
         }
@@ -449,27 +436,6 @@ def main():
                     packed.free()
             except Exception as e:
                 out["one_shot_packed"] = {"error": repr(e)}
-
-            # ---- the tiled layouts: pass time over tiles built once (re-run figures) + what building them costs
-            rerun = {"note": "tiled layouts: svt_batch_create re-tiles / re-encodes the batch ONCE on the device (scan + host "
-                             "tiling + repack, inside `create_ms`), the pass then re-runs over the resident tiles; a real "
-                             "caller creates a batch, runs it once and destroys it, so these are not headline numbers"}
-            for name in ("short", "dense"):
-                if name == layout_name:
-                    continue
-                try:
-                    t0 = time.perf_counter()
-                    with hip.DeviceBatch(batch, device=local_rank, flags=sso | layout_flags[name]) as dd:
-                        c_ms = (time.perf_counter() - t0) * 1e3
-                        dd.genotype(sync=True)
-                        d_ms = time_passes(dd, args.steps)
-                        _, d_res = dd.bytes()
-                        same = bool(np.array_equal(dd.results().rec, got.rec))
-                    rerun[name] = {"pass_ms": d_ms, "create_ms": c_ms, "breakpoints_per_s_pass_only": n / (d_ms * 1e-3),
-                                   "resident_bytes": d_res, "results_equal_headline": same}
-                except Exception as e:
-                    rerun[name] = {"error": repr(e)}
-            out["resident_rerun"] = rerun
 
         if world == 1 and not args.no_cpu_baseline:
             # CPU baseline: the C restatement (oracle/, a port of the reference's algorithm) on the

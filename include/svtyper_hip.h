@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SVT_ABI_VERSION 9
+#define SVT_ABI_VERSION 10
 
 /* ---- error codes (0 = ok, <0 = error; text via svt_last_error()) ---------- */
 #define SVT_OK 0
@@ -61,30 +61,13 @@ extern "C" {
  *   1 (sso)    : contributions are first summed per fragment starting from 0,
  *                then added to the site total (singlesample.py:246-276,367-372) */
 #define SVT_FLAG_SSO_ASSOCIATION 0x1u
-/* device layout of the resident batch:
- *   0 (default, "stream"): nothing is re-tiled or re-encoded -- the CSR arrays go to HBM as the caller
- *       packed them and ONE kernel (svt_stream_kernel) takes them to the result records, streaming every
- *       record from HBM exactly once through per-wave LDS rings.  svt_batch_create is upload only; the
- *       record contract is checked by the pass itself, so a malformed record is reported by
- *       svt_batch_genotype(sync) / svt_batch_results / svt_genotype instead of svt_batch_create.
- *   The other layouts re-tile the batch once at svt_batch_create (scan + host tiling + repack) into
- *   64-unit lane-interleaved tiles; they only pay for a batch that is genotyped many times while resident:
- *   SVT_FLAG_COMPACT_LAYOUT: the records are re-encoded into sparse streams of small entries per unit --
- *       pair entries (straddle bits, mapq_a, mapq_b and ospan_len translated into the index space of the
- *       library's histogram tables) for fragments with a straddle bit and two non-zero MAPQs, weight
- *       entries (one gated MAPQ pair + its kind) for every non-zero reference / split / clip pair.
- *       Dropped entries could only have added +0.0.  The encoding needs histograms of at most 4095 bins,
- *       DEL lengths >= 0 and, with several libraries, units whose libraries span at most 4 consecutive
- *       indices and MAPQs <= 127 on the kept pair entries; a batch that does not qualify silently uses
- *       the dense tiles (svt_batch_layout tells which one it got).  With one library of at most 2047
- *       bins the pair entries are written in half-words ("short" layout): an entry whose two MAPQs are
- *       the batch's most common pair (60, 60 for bwa alignments) takes 2 bytes, any other one 4.
- *   SVT_FLAG_FIXED_PAIR_ENTRIES: the compact layout, but every pair entry keeps its 4 bytes.
- *   SVT_FLAG_DENSE_LAYOUT: tiles of the 16-byte records as they are.
- * Results are bit-identical between all of them.                                                    */
-#define SVT_FLAG_DENSE_LAYOUT 0x2u
-#define SVT_FLAG_FIXED_PAIR_ENTRIES 0x4u
-#define SVT_FLAG_COMPACT_LAYOUT 0x8u
+/* (bits 1..3 selected round 1's tiled device layouts, which are gone: they are rejected as unknown bits.)
+ * Device layout of a resident batch: nothing is re-tiled or re-encoded -- the CSR arrays go to HBM as the
+ * caller packed them and ONE kernel (svt_stream_kernel) takes them to the result records, streaming every
+ * record from HBM exactly once through per-wave LDS rings.  svt_batch_create is upload only; the record
+ * contract is checked by the pass itself, so a malformed record is reported by svt_batch_genotype(sync) /
+ * svt_batch_results / svt_genotype instead of svt_batch_create.  (svt_batch_create_packed: the same for
+ * packed evidence, below.)                                                                            */
 
 /* ---- evidence record: one per read-fragment (query name) of a unit, 16 B --
  * Records of a unit are stored in the order the reference walks them:
@@ -294,8 +277,7 @@ int svt_device_count(void);
 const char* svt_last_error(void);
 
 /* Make `in` resident in HBM on `device`: validates the unit arrays, builds the look-up tables and
- * uploads the CSR as it is (default); with one of the tiled layouts it also re-tiles / re-encodes the
- * records on the device (DESIGN.md "HBM layout").  `flags`: SVT_FLAG_*.
+ * uploads the CSR as it is (DESIGN.md "HBM layout").  `flags`: SVT_FLAG_*.
  * Replaces the hand-over of `read_batch` to the per-sample block of
  * classic.py:279-296 / the `sam_fragments` argument of singlesample.py:355.     */
 int svt_batch_create(const svt_evidence_batch* in, int device, unsigned flags,
@@ -328,13 +310,12 @@ int svt_batch_device_results(svt_batch* b, svt_result** dev_ptr);
 int svt_batch_bind_device_results(svt_batch* b, svt_result* dev_ptr);
 
 /* Bytes the genotype kernel must move per pass by the definition of SURVEY.md
- * section 8(d): sum_u (16*F(u) + 16 + 96); and what the tiled layout really
- * holds (padding included).                                                     */
+ * section 8(d): sum_u (16*F(u) + 16 + 96); and what the batch really holds in
+ * HBM (records or packed slots + offsets + unit headers).                       */
 int svt_batch_bytes(const svt_batch* b, uint64_t* algorithmic, uint64_t* resident);
 
-/* Which device layout / kernel flavour the batch got: *compact = 0 for the dense tiles, 1 for the
- * compact entry streams with 4-byte pair entries, 2 for the short pair entries, 3 for the streamed CSR, 4 for
- * streamed packed evidence; *table_mode = 0 one library, tables in LDS; 1 several libraries,
+/* Which kernel flavour the batch got: *compact = 3 for the streamed CSR, 4 for streamed packed evidence
+ * (0..2 were round 1's tiled layouts); *table_mode = 0 one library, tables in LDS; 1 several libraries,
  * per-workgroup library windows in LDS; 2 general geometry, tables read through L2.          */
 int svt_batch_layout(const svt_batch* b, int* compact, int* table_mode);
 
@@ -421,7 +402,7 @@ int svt_genotype(const svt_evidence_batch* in, svt_result* out, int device,
  *             fragment bits;
  *   stream 2  split / clip candidate entries (-> alt_seq / alt_clip): seq_l, seq_r or clip_l, clip_r; seven per
  *             slot + first-of-fragment and is-clip bits
- * (bit layouts: svtyper_amd/csrc/svt_prepare_kernels.h).  Entries that could only add +0.0 -- no straddle bit, a
+ * (bit layouts: svtyper_amd/csrc/svt_entry_formats.h).  Entries that could only add +0.0 -- no straddle bit, a
  * zero MAPQ, a DEL below the small-deletion gate of classic.py:339,383, all-zero weight pairs -- are not stored;
  * the order inside every stream is the record order, so every tally receives the reference's additions in the
  * reference's order and the results are bit-identical to those of the canonical records.  About 3.2 bytes per

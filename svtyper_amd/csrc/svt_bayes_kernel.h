@@ -3,7 +3,7 @@
 #ifndef SVT_BAYES_KERNEL_H
 #define SVT_BAYES_KERNEL_H
 
-#include "svt_genotype_kernel.h"
+#include "svt_unit_math.h"
 
 namespace svt {
 

@@ -20,61 +20,35 @@ struct LibDesc {          // 32 B, one per library
     double sd2;           // 2 * lib.sd              (classic.py:339)
 };
 
-struct LaneHdr {          // 16 B, one per tile lane
-    int32_t var_length;
-    int32_t pos_delta;
-    uint32_t unit;        // original unit index, kPadUnit for padding lanes
-    uint32_t packed;      // svtype | flags << 8 | first library of the unit << 16
-};
-
-// One 64-unit tile: `rows[k]` rows of stream k, stored back to back from `base` (in 16-byte row
-// slots; row j holds the j-th 16 bytes of each of the 64 lanes).  Dense layout: one stream of
-// canonical 16-byte records (rows[0] = longest unit).  Compact layout: three streams of entries --
-// pair entries (4 bytes, four per row slot), reference-read weight entries and split/clip candidate
-// weight entries (2 bytes, seven per row slot) (svt_prepare_kernels.h has the formats).
-constexpr int kStreams = 3;
-enum Stream : int { kPairs = 0, kRefReads = 1, kCandidates = 2 };
-// entries per 16-byte row slot: 4-byte pair entries; 2-byte reference-read and candidate entries
-// (seven MAPQ pairs in bytes 0..13, their flag bits in bytes 14..15)
-constexpr uint32_t kEntriesPerRow[kStreams] = {4u, 7u, 7u};
-// kLayoutShort: the pair stream is counted in half-words (2-byte short entries, 4-byte wide ones), eight per slot
+// packed evidence: the pair stream is counted in half-words (2-byte entries, 4-byte wide ones), eight per 16-byte slot
 constexpr uint32_t kHalfwordsPerRow = 8u;
 
 // device layout of a batch's evidence
-enum Layout : int {
-    kLayoutDense = 0,    // canonical 16-byte records
-    kLayoutCompact = 1,  // three entry streams, 4-byte pair entries
-    kLayoutShort = 2,    // three entry streams, 2-byte pair entries for the batch's most common MAPQ pair
+enum Layout : int {     // (0..2 were round 1's tiled layouts)
     kLayoutStream = 3,   // the caller's CSR as it is, streamed through per-wave LDS rings (svt_stream_kernel.h)
     kLayoutPacked = 4    // packed evidence (svt_packed_evidence) as uploaded, streamed the same way (svt_packed_kernel.h)
 };
-struct TileDesc {         // 32 B, stored in dispatch (longest-first) order
-    uint64_t base;
-    uint32_t rows[kStreams];
-    uint32_t lane_base;   // first LaneHdr of the tile
-    uint32_t pad[2];
-};
-
 // one bin of a library's insert-size tables: thr = largest h2 for which p_concordant still holds
-// (svt_host_tables.h), hist = the Counter value.  Every library owns n_bins + 1 of them; the last one
-// is the out-of-range sentinel {-1, 0}.
+// (svt_host_tables.h), hist = the Counter value -- both replaced by their rank among the library's values, which
+// is all `hist[a] <= thr[b]` needs.  Every library owns n_bins + 1 of them; the last one is the out-of-range
+// sentinel {-1, rank of 0}.
 struct Bin {
     int32_t thr;
     uint32_t hist;
 };
 
-// LDS layout of the genotype kernel, in bytes from the start of the workgroup's LDS (the kernel has
-// no static LDS, so the dynamic segment starts at 0 -- checked at run time).  The first three
-// regions have fixed addresses; the compact entries are consumed with these as immediates.
+// LDS layout of the packed-evidence kernel, in bytes from the start of the workgroup's LDS (the kernel has
+// no static LDS, so the dynamic segment starts at 0 -- checked at run time).  The first regions have fixed
+// addresses; the entries are consumed with these as immediates.  (svt_stream_kernel.h has its own: kS*.)
 constexpr uint32_t kLdsPm = 0;                       // double[256]      prob_mapq
 constexpr uint32_t kLdsWtab = kLdsPm + 256 * 8;      // PairWeights[32]  paired-end decision table
-// the compact layouts read the decision table column-wise: w_alt[32] then w_ref[32], 8-byte rows.  Rows that differ
+// the entries read the decision table column-wise: w_alt[32] then w_ref[32], 8-byte rows.  Rows that differ
 // only in p_concordant then sit in different LDS banks (with 16-byte {w_alt, w_ref} rows every (p_concordant, is_DEL)
 // variant of a straddle pattern shares its four banks and the lanes of a wave serialise on them)
 constexpr uint32_t kLdsWcol = kLdsWtab + 32 * 16;    // double[32] w_alt, double[32] w_ref
-constexpr uint32_t kLdsWcolC = kLdsWcol + 2 * 32 * 8;   // the same two columns times pmA * pmB of the batch's common MAPQ pair (short layout)
+constexpr uint32_t kLdsWcolC = kLdsWcol + 2 * 32 * 8;   // the same two columns times pmA * pmB of the batch's common MAPQ pair 
 constexpr uint32_t kWcolRef = 32 * 8;                // byte distance from a w_alt entry to its w_ref entry
-constexpr uint32_t kLdsBins = kLdsWcolC + 2 * 32 * 8;   // Bin[lds_bins], then LibDesc[lds_libs], then log10
+constexpr uint32_t kLdsBins = kLdsWcolC + 2 * 32 * 8;   // int32 thr[total_bins], uint32 hist[total_bins], then log10, then the rings
 
 struct GtConsts {
     double lgp[2][3];     // [is_dup][genotype] log(p)/log(10)      (statistics.py:33-35)
@@ -99,36 +73,11 @@ enum LibMode : int {
     kGeneral = 2     // any geometry: 64-bit index math, exact float Counter key, tables in HBM/L2
 };
 
-// Library window of one workgroup (its 4 tiles): the descriptors [lib_lo, lib_lo + lib_cnt) and the
-// histogram/threshold bins [bin_lo, bin_lo + bin_cnt) are the only ones its records can reference, so
-// only they are staged in LDS (kMultiLds).  Units are sorted by library first, so a window normally
-// holds the 1..3 libraries of one sample.
+// Library window of one workgroup: the descriptors [lib_lo, lib_lo + lib_cnt) and the histogram/threshold
+// bins [bin_lo, bin_lo + bin_cnt) are the only ones its records can reference, so only they are staged in LDS
+// (kMultiLds).  A window normally holds the 1..3 libraries of one sample (svt_unit.libs).
 struct WgDesc {
     uint32_t lib_lo, lib_cnt, bin_lo, bin_cnt;
-};
-
-struct KernelArgs {
-    const uint4* tiled;
-    const TileDesc* tiles;
-    const WgDesc* wg;          // one per workgroup (kMultiLds)
-    const LaneHdr* hdr;
-    const double* pm;          // 256
-    const double* l10;         // n_l10
-    const LibDesc* libs;       // n_libs
-    const Bin* bins;           // total_bins (sentinels included)
-    const PairWeights* wtab;   // 32
-    uint32_t n_l10;
-    uint32_t n_libs;
-    uint32_t total_bins;
-    uint32_t n_tiles;
-    uint32_t l10_in_lds;
-    uint32_t lds_libs;         // LDS capacity in library descriptors (largest window)
-    uint32_t lds_bins;         // LDS capacity in histogram bins (largest window)
-    uint32_t common_mq;        // kLayoutShort: mapq_a | mapq_b << 8 of the short pair entries
-    uint64_t n_units;
-    svt_result* out;           // [n_units]
-    LibDesc lib0;              // copy of libs[0] (kSingleLds)
-    GtConsts c;
 };
 
 

@@ -1,48 +1,35 @@
-// svt_host_transfer.h -- device scratch cache and pinned staging ring (H2D / D2H)
+// svt_host_transfer.h -- buffer / handle pools and the pinned staging ring (H2D / D2H)
 // Internal header of libsvtyper_hip.so (single translation unit: svtyper_hip.hip).
 #ifndef SVT_HOST_TRANSFER_H
 #define SVT_HOST_TRANSFER_H
 
-#include "svt_host_tiling.h"
+#include <algorithm>
+#include <mutex>
+#include <vector>
+
+#include "svt_device_types.h"
+#include "svt_error.h"
+#include "svt_host_cpus.h"
 
 namespace svt {
 
-// Device scratch for the canonical records of the batch being created: a 1.6 GB hipMalloc costs
-// ~100 ms, so the buffer is kept per device between calls (grow-only; svt_trim() releases it).
-struct CsrScratchCache {
-    static constexpr int kMaxDevices = 64;
-    void* ptr[kMaxDevices] = {};
-    uint64_t cap[kMaxDevices] = {};
-    std::mutex lock;   // held for the whole svt_batch_create of a device-sharing caller
-    int acquire(int device, uint64_t bytes, void** out)
-    {
-        if (device >= kMaxDevices) return fail(SVT_ERR_INVALID, "device index too large for the scratch cache");
-        if (cap[device] < bytes) {
-            if (ptr[device]) (void)hipFree(ptr[device]);
-            ptr[device] = nullptr;
-            cap[device] = 0;
-            const uint64_t want = bytes + bytes / 8;   // a little slack for the next, slightly larger batch
-            HIP_TRY(hipMalloc(&ptr[device], want));
-            cap[device] = want;
-        }
-        *out = ptr[device];
-        return SVT_OK;
-    }
-    void trim()
-    {
-        std::lock_guard<std::mutex> g(lock);
-        for (int d = 0; d < kMaxDevices; ++d)
-            if (ptr[d]) {
-                (void)hipSetDevice(d);
-                (void)hipFree(ptr[d]);
-                ptr[d] = nullptr;
-                cap[d] = 0;
-            }
-    }
-};
-inline CsrScratchCache g_csr_cache;
+constexpr int kMaxDevices = 64;   // per-device pools and rings are indexed by the HIP device number
 
-// Pool of the large resident device buffers (tiled image, result records, lane headers): a fresh
+inline unsigned host_threads()
+{
+    return std::max(1u, std::min(usable_cpus(), 16u));
+}
+
+// run fn(i) for i in [0, n) on up to host_threads() threads
+template <typename Fn>
+inline void parallel_for(uint64_t n, Fn&& fn)
+{
+    const unsigned nt = (unsigned)std::min<uint64_t>(host_threads(), n);
+    if (nt == 0) return;
+    run_threads(nt, [&](unsigned t) { for (uint64_t i = t; i < n; i += nt) fn(i); });
+}
+
+// Pool of the large resident device buffers (records, offsets, unit headers, result records): a fresh
 // hipMalloc is not only slow by itself, the first kernel that touches the new memory also waits ~10-20 ms
 // for the driver's asynchronous clear of it (measured: tools/first_pass_probe.py), so a pipeline that
 // creates one batch per chunk would pay that on every chunk.  svt_batch_destroy returns the buffers
@@ -109,7 +96,6 @@ inline DevicePool g_pool;
 // hipStreamDestroy synchronise the device), which a chunked driver pays on every chunk.  Everything handed back
 // must be idle.  svt_trim() releases the lot.
 struct HandlePool {
-    static constexpr int kMaxDevices = CsrScratchCache::kMaxDevices;
     std::mutex lock;
     std::vector<hipStream_t> streams[kMaxDevices];
     std::vector<hipEvent_t> timing_events[kMaxDevices], plain_events[kMaxDevices];
@@ -219,13 +205,13 @@ struct StagingRing {
         return SVT_OK;
     }
 };
-inline StagingRing g_rings[CsrScratchCache::kMaxDevices];
+inline StagingRing g_rings[kMaxDevices];
 
 // the ring of the calling thread's current device (every entry point has called hipSetDevice)
 inline StagingRing& current_ring()
 {
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= CsrScratchCache::kMaxDevices) dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) dev = 0;
     return g_rings[dev];
 }
 

@@ -2,13 +2,13 @@
 // Internal header of libsvtyper_hip.so (single translation unit: svtyper_hip.hip).
 //
 // Packed evidence is what a host producer emits instead of 16-byte canonical records when the bytes have to cross
-// PCIe: per unit three sparse streams of small entries in 16-byte slots, unit after unit (svt_prepare_kernels.h has
+// PCIe: per unit three sparse streams of small entries in 16-byte slots, unit after unit (svt_entry_formats.h has
 // the entry formats; svt_pack_evidence in svtyper_hip.hip is the encoder) -- pair entries (2 bytes for the batch's
 // most common MAPQ pair, 4 otherwise), reference-read entries and split / clip candidate entries (2 bytes each).
 // Entries that could only add +0.0 are not stored.  ~3.2 bytes per fragment record instead of 16.
 //
 // The kernel is the streaming kernel's structure (svt_ring_engine.h: workgroup sort, per-wave LDS ring fed by
-// LDS-DMA, one unit per lane) with the slot arithmetic of the tiled compact layouts (svt_genotype_kernel.h:
+// LDS-DMA, one unit per lane) with the slot arithmetic of svt_unit_math.h (
 // short_pair_dword / ref_read_row / candidate_row).  A unit's slots are consumed in stream order, so every tally
 // sees the additions of the reference in the reference's order (classic.py:296-408, singlesample.py:246-353).
 #ifndef SVT_PACKED_KERNEL_H
@@ -45,7 +45,7 @@ __global__ __launch_bounds__(kBlock, 3) void svt_packed_kernel(const PackedArgs 
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr uint32_t kUnitsPerWg = kBlock * R;
-    // LDS (svt_device_types.h, the layout of the tiled short kernel): pm[256] | wtab[32] | w_alt[32], w_ref[32] | the same
+    // LDS (svt_device_types.h): pm[256] | wtab[32] | w_alt[32], w_ref[32] | the same
     // x the common pair's weight | thr[total_bins], hist[total_bins] | log10 | rings.  Entries address it by absolute offsets.
     if ((uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)smem != 0u) __builtin_trap();
     unsigned char* rings = smem + a.lds_rings;

@@ -18,7 +18,7 @@
 #ifndef SVT_RING_ENGINE_H
 #define SVT_RING_ENGINE_H
 
-#include "svt_genotype_kernel.h"
+#include "svt_unit_math.h"
 
 namespace svt {
 

@@ -152,7 +152,7 @@ struct StreamCtx {
 };
 
 // One canonical record, one library, tables at fixed LDS addresses: the arithmetic of weight_evidence +
-// pair_evidence<kSingleLds> (svt_genotype_kernel.h; classic.py:306-408) with every table index formed by one
+// pair_evidence<kSingleLds> (svt_unit_math.h; classic.py:306-408) with every table index formed by one
 // instruction.  (pm(l) * L + pm(r) * R) / 2.0 (classic.py:324) is taken as pm(l)/2 + pm(r)/2 from a second
 // table: halving a binary64 in [0.2, 1] is exact, so the sum rounds identically.  EDGE: the record may belong
 // to a neighbouring unit -- its weight bytes are then read as MAPQ 0, which adds +0.0 to every sum.

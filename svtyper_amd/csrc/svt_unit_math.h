@@ -1,7 +1,8 @@
-// svt_genotype_kernel.h -- evidence arithmetic and the genotype kernel (the hot path)
+// svt_unit_math.h -- what every kernel shares: LDS access by byte address, the per-record evidence arithmetic
+// (canonical records and packed entries) and the per-unit epilogue (QR/QA, log_choose, likelihoods, decision)
 // Internal header of libsvtyper_hip.so (single translation unit: svtyper_hip.hip).
-#ifndef SVT_GENOTYPE_KERNEL_H
-#define SVT_GENOTYPE_KERNEL_H
+#ifndef SVT_UNIT_MATH_H
+#define SVT_UNIT_MATH_H
 
 #include "svt_device_types.h"
 
@@ -178,39 +179,8 @@ __device__ __forceinline__ void pair_evidence(const uint32_t o, const uint32_t m
     a.ref_span += pp * pw.w_ref;
 }
 
-// ---- compact layout (svt_prepare_kernels.h describes the entries) -------------------------------
-// Pair entry: the two bin addresses come from the entry's table code by clamping; the look-ups, the
-// p_concordant decision and the sums are the ones of pair_evidence above.
-template <int MODE>
-__device__ __forceinline__ void pair_entry(const uint32_t e, const LaneCtx& c, Acc& a)
-{
-    const uint32_t code8 = e & 0xfff8u;          // byte offset of bins[code] inside the library's table
-    double pm_a, pm_b;
-    int32_t thr1;
-    uint32_t h2;
-    if (MODE == kSingleLds) {
-        pm_a = lds_f64(kLdsPm + byte2_x8(e));
-        pm_b = lds_f64(kLdsPm + byte3_x8(e));
-        thr1 = lds_i32(kLdsBins + min(code8, c.nb8));
-        h2 = lds_u32(kLdsBins + 4u + min(code8 - c.off2_8, c.nb8));
-    } else {
-        pm_a = lds_f64(kLdsPm + ((e >> 15) & 0x3f8u));
-        pm_b = lds_f64(kLdsPm + ((e >> 22) & 0x3f8u));
-        const uint32_t xa = c.libx_lane + ((e >> 13) & 0x18u);               // + (lib - lib_min) * 8
-        const uint32_t base = lds_u32(xa), nb8 = lds_u32(xa + 4u);           // &bins[tab_off], n_bins * 8
-        const uint32_t off2_8 = min(c.vl8, nb8) | c.nodel;                   // DEL ? min(var_length, n_bins) * 8 : never
-        thr1 = lds_i32(base + min(code8, nb8));
-        h2 = lds_u32(base + 4u + min(code8 - off2_8, nb8));
-    }
-    const bool p_conc = (int32_t)h2 <= thr1;
-    const uint32_t wa = (p_conc ? c.wt1 : c.wt0) | ((e << 3) & 0x38u);   // &w_alt[f3 | p_conc << 3 | del16]
-    const double w_alt = lds_f64(wa), w_ref = lds_f64(wa + kWcolRef);
-    const double pp = pm_a * pm_b;
-    a.alt_span += pp * w_alt;
-    a.ref_span += pp * w_ref;
-}
-
-// Short layout (one library): a 16-byte row slot is four dwords, each either two one-half-word entries that carry
+// ---- packed evidence (svt_entry_formats.h describes the entries) ---------------------------------
+// Pair slot (one library): a 16-byte slot is four dwords, each either two one-half-word entries that carry
 // the batch's common MAPQ pair, or one wide entry (low half f3 | code << 3 | 0x8000, high half its two MAPQs).
 // code4 = byte offset of thr[code] / hist[code], f3x8 = f3 << 3 (byte offset inside a decision-table column), pp = pmA * pmB.
 __device__ __forceinline__ void pair_eval_single(const uint32_t code4, const uint32_t f3x8, const double pp,
@@ -468,216 +438,6 @@ __device__ __forceinline__ void unit_epilogue(const Acc& acc, const uint32_t svt
     for (int i = 0; i < 8; ++i) piece[i] = out_piece[i];
 }
 
-// The result records of a lane pair, written 32 contiguous bytes at a time.  Stored directly, the eight 16-byte
-// pieces of a record reach the L2 as eight partial-line transactions, and the write path is paced by transactions
-// (a timing build writing the same bytes with this pattern ran 8 % faster).  So the two lanes of a pair exchange
-// halves: for the even lane's record the even lane stores piece 2k and the odd lane piece 2k + 1 -- which it takes
-// from its neighbour -- and the other way round for the odd lane's record.
-__device__ __forceinline__ void st_results_by_pairs(const uint4 (&piece)[8], const uint32_t unit, svt_result* __restrict__ out,
-                                                    const uint32_t lane)
-{
-    const bool odd = (lane & 1u) != 0u;
-    const uint32_t other = pair_swap(unit);
-    const uint32_t unit_even = odd ? other : unit, unit_odd = odd ? unit : other;
-    uint4* __restrict__ dst_even = reinterpret_cast<uint4*>(out + unit_even) + (odd ? 1 : 0);
-    uint4* __restrict__ dst_odd = reinterpret_cast<uint4*>(out + unit_odd) + (odd ? 1 : 0);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const uint4 a = piece[2 * k], b = piece[2 * k + 1];
-        const uint4 from_even = pair_swap(b), from_odd = pair_swap(a);   // the neighbour's odd / even piece
-        const uint4 v_even = odd ? from_even : a;   // pieces 2k, 2k + 1 of the even lane's record
-        const uint4 v_odd = odd ? b : from_odd;     // pieces 2k, 2k + 1 of the odd lane's record
-        if (unit_even != kPadUnit) dst_even[2 * k] = v_even;   // plain stores (non-temporal ones reach HBM piecewise)
-        if (unit_odd != kPadUnit) dst_odd[2 * k] = v_odd;
-    }
-}
-
-// The rows of a tile, read once, in order, two rows ahead of the row being consumed.  The streams of a
-// tile follow each other in memory, so one reader serves all of them: run(n, f) consumes the next n
-// rows with f and the look-ahead simply continues into the next stream (the tiled buffer carries
-// kTailPadRows rows of slack, so it never leaves the allocation).
-struct RowReader {
-    const uint4* __restrict__ next;   // row after the two held ones (this lane's slot)
-    uint4 r0, r1;                     // the next two rows to consume
-    __device__ __forceinline__ explicit RowReader(const uint4* __restrict__ p)
-        : next(p + 2 * kWave), r0(ld_stream(p)), r1(ld_stream(p + kWave)) {}
-    template <typename F>
-    __device__ __forceinline__ void run(const uint32_t n, F&& consume)
-    {
-        uint32_t j = 0;
-        for (; j + 2 <= n; j += 2) {
-            const uint4 w0 = r0, w1 = r1;
-            r0 = ld_stream(next);
-            r1 = ld_stream(next + kWave);
-            next += 2 * kWave;
-            consume(w0);
-            consume(w1);
-        }
-        if (j < n) {                  // odd row count (wave-uniform): rotate by one
-            const uint4 w0 = r0;
-            r0 = r1;
-            r1 = ld_stream(next);
-            next += kWave;
-            consume(w0);
-        }
-    }
-};
-
-// ------------------------------------------------------------------------------------------
-// genotype kernel
-// ------------------------------------------------------------------------------------------
-template <bool SSO, int MODE, int LAYOUT>
-__global__ __launch_bounds__(kBlock, SVT_MIN_WAVES) void svt_genotype_kernel(const KernelArgs a)
-{
-    constexpr bool COMPACT = LAYOUT != kLayoutDense;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // LDS layout (svt_device_types.h): pm[256] | wtab[32] | w_alt[32], w_ref[32] | the same x common pair | bins[lds_bins] | libs[lds_libs] | libx[lds_libs] | l10[n_l10]
-    double* s_pm = reinterpret_cast<double*>(smem + kLdsPm);
-    PairWeights* s_wtab = reinterpret_cast<PairWeights*>(smem + kLdsWtab);
-    Bin* s_bins = reinterpret_cast<Bin*>(smem + kLdsBins);
-    LibDesc* s_lib = reinterpret_cast<LibDesc*>(s_bins + a.lds_bins);
-    uint2* s_libx = reinterpret_cast<uint2*>(s_lib + a.lds_libs);   // compact kMultiLds: {LDS address of the library's bins, n_bins * 8}
-    double* s_l10 = reinterpret_cast<double*>(s_libx + a.lds_libs);
-    // the compact entries address the tables by absolute LDS byte offsets
-    if (COMPACT && (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)smem != 0u) __builtin_trap();
-    // this wave's tile and this lane's unit: requested before the tables are staged so that the two
-    // dependent loads overlap the staging instead of following the barrier
-    const uint32_t wave = threadIdx.x / kWave;
-    const uint32_t lane = threadIdx.x % kWave;
-    const uint32_t tile_idx = blockIdx.x * kWavesPerBlock + wave;
-    TileDesc td{};
-    td.lane_base = kPadUnit;
-    if (tile_idx < a.n_tiles) td = a.tiles[tile_idx];
-    const bool live = td.lane_base != kPadUnit;    // not the padding of the last workgroup
-    LaneHdr h{};
-    if (live) h = a.hdr[td.lane_base + lane];
-
-    // library window of this workgroup (everything when the tables of the whole batch fit)
-    WgDesc wd = {0u, a.n_libs, 0u, MODE != kGeneral ? a.total_bins : 0u};
-    if (MODE == kMultiLds) wd = a.wg[blockIdx.x];
-
-    // ---- stage the tables in LDS (they are L2-resident after the first workgroups)
-    for (uint32_t i = threadIdx.x; i < 256; i += kBlock) s_pm[i] = a.pm[i];
-    if (threadIdx.x < 32) {
-        const PairWeights w = a.wtab[threadIdx.x];
-        s_wtab[threadIdx.x] = w;
-        if (COMPACT) {
-            reinterpret_cast<double*>(smem + kLdsWcol)[threadIdx.x] = w.w_alt;
-            reinterpret_cast<double*>(smem + kLdsWcol + kWcolRef)[threadIdx.x] = w.w_ref;
-        }
-    }
-    if (LAYOUT == kLayoutShort && threadIdx.x < 32) {   // the decision table times the common pair's pmA * pmB (the very product an entry would form)
-        const double pp0 = a.pm[a.common_mq & 0xffu] * a.pm[(a.common_mq >> 8) & 0xffu];
-        const PairWeights w = a.wtab[threadIdx.x];
-        reinterpret_cast<double*>(smem + kLdsWcolC)[threadIdx.x] = pp0 * w.w_alt;
-        reinterpret_cast<double*>(smem + kLdsWcolC + kWcolRef)[threadIdx.x] = pp0 * w.w_ref;
-    }
-    if (a.l10_in_lds)
-        for (uint32_t i = threadIdx.x; i < a.n_l10; i += kBlock) s_l10[i] = a.l10[i];
-    for (uint32_t i = threadIdx.x; i < wd.lib_cnt * (uint32_t)(sizeof(LibDesc) / 8); i += kBlock)
-        reinterpret_cast<uint64_t*>(s_lib)[i] =
-            reinterpret_cast<const uint64_t*>(a.libs + wd.lib_lo)[i];
-    if (LAYOUT == kLayoutShort) {
-        // thr[] and hist[] as two 4-byte arrays: the random look-ups of a wave then spread over every LDS bank
-        // (interleaved {thr, hist} pairs would put all thr reads on the even banks and all hist reads on the odd ones)
-        int32_t* s_thr = reinterpret_cast<int32_t*>(s_bins);
-        uint32_t* s_hist = reinterpret_cast<uint32_t*>(s_bins) + wd.bin_cnt;
-        for (uint32_t i = threadIdx.x; i < wd.bin_cnt; i += kBlock) {
-            const Bin bn = a.bins[wd.bin_lo + i];
-            s_thr[i] = bn.thr;
-            s_hist[i] = bn.hist;
-        }
-    } else if (MODE != kGeneral)
-        for (uint32_t i = threadIdx.x; i < wd.bin_cnt; i += kBlock)
-            reinterpret_cast<uint64_t*>(s_bins)[i] = reinterpret_cast<const uint64_t*>(a.bins + wd.bin_lo)[i];
-    if (COMPACT && MODE == kMultiLds)
-        for (uint32_t i = threadIdx.x; i < wd.lib_cnt; i += kBlock) {
-            const LibDesc L = a.libs[wd.lib_lo + i];
-            s_libx[i] = make_uint2(kLdsBins + (L.tab_off - wd.bin_lo) * (uint32_t)sizeof(Bin), L.n_bins * (uint32_t)sizeof(Bin));
-        }
-    __syncthreads();
-
-    if (!live) return;
-    const uint32_t svtype = h.packed & 0xffu;
-    const uint32_t uflags = (h.packed >> 8) & 0xffu;
-
-    Tables t;
-    t.pm = s_pm;
-    t.wtab = s_wtab;
-    t.libs = s_lib;
-    t.bins = MODE != kGeneral ? s_bins : a.bins;
-
-    LaneCtx c;
-    c.is_del = svtype == SVT_SVTYPE_DEL;
-    c.del16 = c.is_del ? 16u : 0u;
-    c.var_length = h.var_length;
-    c.pos_delta_d = (double)h.pos_delta;
-    c.lib_lo = wd.lib_lo;
-    c.lib_last = wd.lib_cnt - 1u;
-    c.bin_lo = wd.bin_lo;
-    c.lib_min = h.unit == kPadUnit ? wd.lib_lo : (h.packed >> 16) & 0xffu;   // padding lanes stream zero entries: keep their look-ups inside the window
-    c.libx_lane = kLdsBins + a.lds_bins * (uint32_t)sizeof(Bin) + a.lds_libs * (uint32_t)sizeof(LibDesc) +
-                  (c.lib_min - wd.lib_lo) * (uint32_t)sizeof(uint2);
-    c.vl8 = (uint32_t)min(max(h.var_length, 0), 8191) * 8u;
-    c.nodel = c.is_del ? 0u : 0x80000000u;
-    c.wt0 = kLdsWcol + c.del16 * 8u;
-    c.wt1 = c.wt0 + 8u * 8u;
-    {
-        const bool small_del = c.is_del && (c.pos_delta_d < a.lib0.sd2);  // classic.py:339,383
-        c.fmask = small_del ? 0u : 7u;
-        c.kmin = (uint32_t)a.lib0.key_min;
-        c.nb = a.lib0.n_bins;
-        c.sub2 = c.is_del ? (uint32_t)h.var_length + (uint32_t)a.lib0.key_min : 0x80000000u;
-        c.nb8 = a.lib0.n_bins * 8u;
-        c.off2_8 = c.is_del ? min((uint32_t)h.var_length, a.lib0.n_bins) * 8u : 0x80000000u;
-        c.nb4 = a.lib0.n_bins * 4u;
-        c.off2_4 = c.is_del ? min((uint32_t)h.var_length, a.lib0.n_bins) * 4u : 0x80000000u;
-        c.hist_at = kLdsBins + a.total_bins * 4u;   // kSingleLds: the window is the whole table (n_bins + 1 entries)
-    }
-
-    c.common_mq = a.common_mq;
-
-    Acc acc = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-
-    // ---- stream the tile: row j is one contiguous 1 KiB line for the wave
-    RowReader rows(a.tiled + td.base + lane);
-    if (COMPACT) {
-        if (LAYOUT == kLayoutShort) {
-            rows.run(td.rows[kPairs], [&](const uint4 w) {
-                short_pair_dword(w.x, c, acc);
-                short_pair_dword(w.y, c, acc);
-                short_pair_dword(w.z, c, acc);
-                short_pair_dword(w.w, c, acc);
-            });
-        } else {
-            rows.run(td.rows[kPairs], [&](const uint4 w) {
-                pair_entry<MODE>(w.x, c, acc);
-                pair_entry<MODE>(w.y, c, acc);
-                pair_entry<MODE>(w.z, c, acc);
-                pair_entry<MODE>(w.w, c, acc);
-            });
-        }
-        rows.run(td.rows[kRefReads], [&](const uint4 w) { ref_read_row<SSO>(w, acc); });
-        rows.run(td.rows[kCandidates], [&](const uint4 w) { candidate_row<SSO>(w, acc); });
-    } else {
-        // canonical 16-byte records (include/svtyper_hip.h: svt_record)
-        rows.run(td.rows[0], [&](const uint4 w) {
-            weight_evidence<SSO>(w.y >> 16 | (w.z << 16), w.z >> 16, (w.w & SVT_REC_CONTINUATION) != 0, t, acc);
-            pair_evidence<MODE>(w.x, w.y & 0xffffu, w.w & 7u, SVT_REC_LIB(w.w), t, c, acc);
-        });
-    }
-    if (SSO) {  // flush the last fragment (singlesample.py:370-372)
-        acc.ref_seq += acc.l_ref_seq;
-        acc.alt_seq += acc.l_alt_seq;
-        acc.alt_clip += acc.l_alt_clip;
-    }
-
-    uint4 piece[8];
-    unit_epilogue(acc, svtype, uflags, a.c, s_l10, a.l10, a.l10_in_lds != 0u, piece);
-    st_results_by_pairs(piece, h.unit, a.out, lane);
-}
-
-
 }  // namespace svt
 
-#endif  // SVT_GENOTYPE_KERNEL_H
+#endif  // SVT_UNIT_MATH_H

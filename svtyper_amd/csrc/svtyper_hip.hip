@@ -22,7 +22,7 @@
 //         pair entries (straddle bits, both MAPQs, ospan_len translated into the histogram's index
 //         space; 4 bytes), reference-read and split / clip candidate entries (one gated MAPQ pair,
 //         2 bytes); entries that could only add +0.0 are dropped, which the reference's sums cannot
-//         observe (svt_prepare_kernels.h has the formats);
+//         observe (svt_entry_formats.h has the formats);
 //       - short (what a one-library batch of <= 2047 bins gets): the same with 2-byte pair entries
 //         for the batch's most common MAPQ pair;
 //       - dense (SVT_FLAG_DENSE_LAYOUT): the canonical 16-byte records as they are.
@@ -50,35 +50,19 @@
 
 #include "../../include/svtyper_hip.h"
 
-#ifndef SVT_GROUP
-#define SVT_GROUP 4   // rows fetched per look-ahead group (dense layout)
-#endif
-#ifndef SVT_GROUP_A
-#define SVT_GROUP_A 2 // compact layout, pair-entry rows
-#endif
-#ifndef SVT_GROUP_B
-#define SVT_GROUP_B 2 // compact layout, weight-entry rows
-#endif
-#ifndef SVT_MIN_WAVES
-#define SVT_MIN_WAVES 1
-#endif
-#ifndef SVT_CHUNK
-#define SVT_CHUNK 16384
-#endif
 #ifndef SVT_STREAM_R
 #define SVT_STREAM_R 1   // streaming kernel: 64-unit tiles per wave (a workgroup sorts 256 * R consecutive units)
 #endif
 
 #include "svt_common.h"
 #include "svt_device_types.h"
-#include "svt_genotype_kernel.h"
-#include "svt_prepare_kernels.h"
+#include "svt_unit_math.h"
+#include "svt_entry_formats.h"
 #include "svt_stream_kernel.h"
 #include "svt_packed_kernel.h"
 #include "svt_geometry_kernel.h"
 #include "svt_bayes_kernel.h"
 #include "svt_host_tables.h"
-#include "svt_host_tiling.h"
 #include "svt_host_transfer.h"
 
 using namespace svt;
@@ -86,38 +70,26 @@ using namespace svt;
 // ------------------------------------------------------------------------------------------
 // batch object
 // ------------------------------------------------------------------------------------------
-constexpr unsigned kKnownFlags = SVT_FLAG_SSO_ASSOCIATION | SVT_FLAG_DENSE_LAYOUT | SVT_FLAG_FIXED_PAIR_ENTRIES | SVT_FLAG_COMPACT_LAYOUT;
-
-inline int layout_of_flags(unsigned flags)
-{
-    return (flags & SVT_FLAG_DENSE_LAYOUT) ? svt::kLayoutDense
-           : (flags & (SVT_FLAG_COMPACT_LAYOUT | SVT_FLAG_FIXED_PAIR_ENTRIES)) ? svt::kLayoutCompact : svt::kLayoutStream;
-}
+constexpr unsigned kKnownFlags = SVT_FLAG_SSO_ASSOCIATION;
 
 struct svt_batch {
     int device = 0;
     unsigned flags = 0;
     hipStream_t stream = nullptr;
-    uint64_t n_units = 0, n_records = 0, slots = 0;
-    uint32_t n_tiles = 0;
+    uint64_t n_units = 0, n_records = 0;
     int mode = kSingleLds;
-    int layout = kLayoutCompact;   // svt_device_types.h: Layout
-    uint32_t common_mq = kDefaultCommonMapq;   // kLayoutShort: the MAPQ pair of the one-half-word entries
+    int layout = kLayoutStream;   // svt_device_types.h: Layout
     size_t lds_bytes = 0;
     bool have_results = false;
-    // device buffers
-    uint4* d_tiled = nullptr;     // d_tiled, d_hdr and d_out come from (and go back to) g_pool
-    uint64_t cap_tiled = 0, cap_hdr = 0, cap_out = 0;
-    TileDesc* d_tiles = nullptr;  // dispatch order
-    LaneHdr* d_hdr = nullptr;
+    // device buffers; the big ones come from (and go back to) g_pool, the small ones from g_handles
+    uint64_t cap_out = 0;
     double* d_pm = nullptr;
     double* d_l10 = nullptr;
     LibDesc* d_libs = nullptr;
     Bin* d_bins = nullptr;
     PairWeights* d_wtab = nullptr;
-    WgDesc* d_wg = nullptr;
     svt_result* d_out = nullptr;
-    KernelArgs args{};
+    svt_result* out_dev = nullptr;   // where the pass writes: d_out, or the buffer of svt_batch_bind_device_results
     // kLayoutStream: the canonical CSR as it is (svt_stream_kernel.h); d_records / d_off / d_units come from g_pool
     void* d_records = nullptr;
     uint64_t* d_off = nullptr;
@@ -147,8 +119,6 @@ void free_batch(svt_batch* b)
     // (a create that failed half way has copies enqueued; a caller may destroy right after an asynchronous pass)
     if (b->stream) (void)hipStreamSynchronize(b->stream);
     auto F = [](void* p) { g_handles.put_small(p); };
-    g_pool.put(b->device, b->d_tiled, b->cap_tiled);
-    g_pool.put(b->device, b->d_hdr, b->cap_hdr);
     g_pool.put(b->device, b->d_out, b->cap_out);
     g_pool.put(b->device, b->d_records, b->cap_records);
     g_pool.put(b->device, b->d_off, b->cap_off);
@@ -157,8 +127,8 @@ void free_batch(svt_batch* b)
     g_pool.put(b->device, b->d_perm, b->cap_perm);
     F(b->d_chunks); F(b->d_windows);
     F(b->d_err);
-    F(b->d_tiles); F(b->d_pm); F(b->d_l10); F(b->d_libs);
-    F(b->d_bins); F(b->d_wtab); F(b->d_wg);
+    F(b->d_pm); F(b->d_l10); F(b->d_libs);
+    F(b->d_bins); F(b->d_wtab);
     g_handles.put_event(b->ev0, true);
     g_handles.put_event(b->ev1, true);
     g_handles.put_stream(b->stream);   // (idle: synchronised above)
@@ -193,27 +163,6 @@ int upload(DevScratch& d, const std::vector<T>& v, Stager& st)
 {
     SVT_TRY(d.alloc(v.size() * sizeof(T)));
     return st.copy(d.p, v.data(), v.size() * sizeof(T));
-}
-
-template <bool SSO>
-const void* kernel_for(int mode, int layout)
-{
-    if (layout == kLayoutShort)     // one library, tables in LDS (create_on_device)
-        return reinterpret_cast<const void*>(&svt_genotype_kernel<SSO, kSingleLds, kLayoutShort>);
-    if (layout == kLayoutCompact)   // only chosen together with one of the LDS modes (create_on_device)
-        return mode == kSingleLds ? reinterpret_cast<const void*>(&svt_genotype_kernel<SSO, kSingleLds, kLayoutCompact>)
-                                  : reinterpret_cast<const void*>(&svt_genotype_kernel<SSO, kMultiLds, kLayoutCompact>);
-    switch (mode) {
-    case kSingleLds: return reinterpret_cast<const void*>(&svt_genotype_kernel<SSO, kSingleLds, kLayoutDense>);
-    case kMultiLds:  return reinterpret_cast<const void*>(&svt_genotype_kernel<SSO, kMultiLds, kLayoutDense>);
-    default:         return reinterpret_cast<const void*>(&svt_genotype_kernel<SSO, kGeneral, kLayoutDense>);
-    }
-}
-
-const void* kernel_of(const svt_batch* b)
-{
-    return (b->flags & SVT_FLAG_SSO_ASSOCIATION) ? kernel_for<true>(b->mode, b->layout)
-                                                 : kernel_for<false>(b->mode, b->layout);
 }
 
 template <bool SSO>
@@ -265,18 +214,11 @@ int launch_genotype(svt_batch* b)
         HIP_TRY(hipLaunchKernel(k, grid, block, params, b->lds_bytes, b->stream));
         return SVT_OK;
     }
-    if (b->layout == kLayoutStream) {
-        if (b->n_units == 0) return SVT_OK;
-        constexpr uint64_t per_wg = (uint64_t)kBlock * SVT_STREAM_R;
-        const dim3 grid(b->mode == kMultiLds ? b->n_chunks : (unsigned)((b->n_units + per_wg - 1) / per_wg)), block(kBlock);
-        void* params[] = {&b->sargs};
-        HIP_TRY(hipLaunchKernel(stream_kernel_of(b), grid, block, params, b->lds_bytes, b->stream));
-        return SVT_OK;
-    }
-    if (b->n_tiles == 0) return SVT_OK;
-    const dim3 grid((b->n_tiles + kWavesPerBlock - 1) / kWavesPerBlock), block(kBlock);
-    void* params[] = {&b->args};
-    HIP_TRY(hipLaunchKernel(kernel_of(b), grid, block, params, b->lds_bytes, b->stream));
+    if (b->n_units == 0) return SVT_OK;
+    constexpr uint64_t per_wg = (uint64_t)kBlock * SVT_STREAM_R;
+    const dim3 grid(b->mode == kMultiLds ? b->n_chunks : (unsigned)((b->n_units + per_wg - 1) / per_wg)), block(kBlock);
+    void* params[] = {&b->sargs};
+    HIP_TRY(hipLaunchKernel(stream_kernel_of(b), grid, block, params, b->lds_bytes, b->stream));
     return SVT_OK;
 }
 
@@ -293,29 +235,7 @@ struct StageTimer {
     }
 };
 
-// Host-side work arrays of svt_batch_create (per-unit counts, the tiling, the dispatch list): ~100 MB
-// for a 1 M-unit batch.  Kept between calls -- allocating and releasing them per batch costs ~10 ms of
-// page faults and munmap -- and handed to one svt_batch_create at a time; svt_trim() releases them.
-struct HostScratch {
-    std::mutex lock;
-    std::vector<uint32_t> nrec;
-    std::vector<ScanOut> counts;
-    Tiling G;
-    std::vector<TileDesc> dispatch;
-    std::vector<WgDesc> windows;
-    void trim()
-    {
-        std::lock_guard<std::mutex> g(lock);
-        std::vector<uint32_t>().swap(nrec);
-        std::vector<ScanOut>().swap(counts);
-        G.slots = 0;
-        std::vector<TileDesc>().swap(dispatch);
-        std::vector<WgDesc>().swap(windows);
-    }
-};
-HostScratch g_host;
-
-// the record-contract violations the kernels report (svt_scan_kernel / svt_stream_kernel)
+// the record-contract violations svt_stream_kernel reports
 int record_error(uint32_t err_bits)
 {
     std::string m = "invalid evidence records:";
@@ -528,7 +448,7 @@ int create_stream(const svt_evidence_batch* in, svt_batch* b, void* d_records_re
     a.err = b->d_err;
     a.lib0 = T.libs[0];
     fill_gt_consts(a.c, in->split_weight, in->disc_weight);
-    b->args.out = b->d_out;   // svt_batch_device_results / svt_batch_bind_device_results / svt_batch_site_qual
+    b->out_dev = b->d_out;   // svt_batch_device_results / svt_batch_bind_device_results / svt_batch_site_qual
     b->lds_bytes = tables + kWavesPerBlock * kRingBytes + SVT_PROBE_LDS_PAD;
     if (b->lds_bytes > 160 * 1024) return fail(SVT_ERR_INVALID, "LDS budget exceeded");
     if (b->lds_bytes > 64 * 1024)
@@ -732,13 +652,12 @@ int pack_evidence(const svt_evidence_batch* in, svt_packed_evidence** out)
     owner->slots = g_pinned.get(std::max<uint64_t>(total, 1) * 16);
     if (!owner->slots) return fail(SVT_ERR_NOMEM, "out of host memory");
     uint4* slots = static_cast<uint4*>(owner->slots);
-    // ---- pass 2: the three streams of every unit, in record order (the encoders of svt_prepare_kernels.h)
+    // ---- pass 2: the three streams of every unit, in record order (the encoders of svt_entry_formats.h)
     parallel_for(n_chunks, [&](uint64_t ch) {
         for (uint64_t u = ch * kChunk; u < std::min(n, (ch + 1) * kChunk); ++u) {
             const UnitGeom g = unit_geom(in->units[u]);
             ShortRowWriter S{slots + off[3 * u]};
             WeightRowWriter R{slots + off[3 * u + 1]}, X{slots + off[3 * u + 2]};
-            S.stride = R.stride = X.stride = 1u;
             bool frag_has[3] = {false, false, false};
             for (uint64_t j = in->rec_offset[u]; j < in->rec_offset[u + 1]; ++j) {
                 const uint4 w = recs[j];
@@ -864,7 +783,6 @@ int create_packed(const svt_packed_evidence* in, svt_batch* b, bool defer_slots 
     tm.mark("H2D slots + unit arrays + tables");
     b->mode = kSingleLds;
     b->n_slots = in->n_slots;
-    b->common_mq = in->common_mapq;
     PackedArgs& a = b->pargs;
     a.slots = static_cast<const uint4*>(b->d_records);
     a.slot_offset = b->d_soff;
@@ -894,290 +812,13 @@ int create_packed(const svt_packed_evidence* in, svt_batch* b, bool defer_slots 
     a.out = b->d_out;
     a.lib0 = T.libs[0];
     fill_gt_consts(a.c, in->split_weight, in->disc_weight);
-    b->args.out = b->d_out;
+    b->out_dev = b->d_out;
     b->lds_bytes = tables + kWavesPerBlock * kRingBytes;
     if (b->lds_bytes > 160 * 1024) return fail(SVT_ERR_INVALID, "LDS budget exceeded");
     if (b->lds_bytes > 64 * 1024) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&svt_packed_kernel<true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_bytes));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&svt_packed_kernel<false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_bytes));
     }
-    return SVT_OK;
-}
-
-// everything of svt_batch_create that needs the device; `b` is freed by the caller on failure
-int create_on_device(const svt_evidence_batch* in, svt_batch* b, const uint4* d_records_resident = nullptr)
-{
-    const uint64_t n = in->n_units;
-    const uint64_t n_rec = n ? in->rec_offset[n] : 0;
-    StageTimer tm;
-
-    // ---- per-unit record counts + validation of the CSR
-    std::lock_guard<std::mutex> host_guard(g_host.lock);
-    std::vector<uint32_t>& nrec = g_host.nrec;
-    nrec.assign(n, 0u);
-    uint64_t max_f = 0;
-    bool wide_var_length = false, negative_del = false;
-    for (uint64_t u = 0; u < n; ++u) {
-        if (in->rec_offset[u + 1] < in->rec_offset[u]) return fail(SVT_ERR_INVALID, "rec_offset not monotone");
-        const uint64_t f = in->rec_offset[u + 1] - in->rec_offset[u];
-        if (f > 0x3FFFFFFFull) return fail(SVT_ERR_INVALID, "unit with too many records");
-        const svt_unit& U = in->units[u];
-        if (U.svtype > SVT_SVTYPE_BND) return fail(SVT_ERR_INVALID, "bad svtype");
-        if ((U.libs >> 16) != 0 || (U.flags & ~SVT_UNIT_SKIP)) return fail(SVT_ERR_INVALID, "unit reserved/flags bits must be 0");
-        if (U.var_length < -(1 << 30) || U.var_length > (1 << 30)) wide_var_length = true;
-        if (U.svtype == SVT_SVTYPE_DEL && U.var_length < 0) negative_del = true;
-        nrec[u] = (uint32_t)f;
-        max_f = std::max(max_f, f);
-    }
-
-    tm.mark("validate units");
-    HostTables T;
-    SVT_TRY(build_tables(in, max_f, T));
-    if (wide_var_length) T.fast_geometry = false;
-    tm.mark("build tables");
-
-    SVT_TRY(g_handles.get_stream(&b->stream));
-    SVT_TRY(g_handles.get_event(&b->ev0, true));
-    SVT_TRY(g_handles.get_event(&b->ev1, true));
-
-    // ---- canonical records to the device; validate them and count the sparse-stream entries
-    DevScratch d_off, d_counts, d_err, d_units;
-    std::unique_lock<std::mutex> csr_guard(g_csr_cache.lock, std::defer_lock);
-    const uint4* d_csr = d_records_resident;
-    {   // every host -> device copy goes through the pinned ring (svt_host_transfer.h: Stager)
-        Stager st(b->stream);
-        if (!d_csr) {
-            csr_guard.lock();   // the cached scratch is ours until we return
-            void* d_csr_p = nullptr;
-            SVT_TRY(g_csr_cache.acquire(b->device, std::max<uint64_t>(n_rec, 1) * sizeof(uint4), &d_csr_p));
-            d_csr = static_cast<const uint4*>(d_csr_p);
-            tm.mark("stream/event/alloc");
-            SVT_TRY(st.copy(d_csr_p, in->records, n_rec * sizeof(uint4)));
-        }
-        SVT_TRY(d_off.alloc((n + 1) * sizeof(uint64_t)));
-        if (n) SVT_TRY(st.copy(d_off.p, in->rec_offset, (n + 1) * sizeof(uint64_t)));
-        SVT_TRY(d_units.alloc(n * sizeof(svt_unit)));
-        SVT_TRY(st.copy(d_units.p, in->units, n * sizeof(svt_unit)));
-        SVT_TRY(upload(&b->d_libs, T.libs, st));
-        SVT_TRY(st.finish());
-        tm.mark("H2D records + unit arrays (staged)");
-    }
-    SVT_TRY(d_counts.alloc(n * sizeof(ScanOut)));
-    SVT_TRY(d_err.alloc(sizeof(uint32_t)));
-    HIP_TRY(hipMemsetAsync(d_err.p, 0, sizeof(uint32_t), b->stream));
-    // the batch's most common MAPQ pair (short layout): a vote over the first records on the HOST (the records are
-    // here, or -- geometry path -- a few KB away); any answer is correct, a good one makes the pair stream shorter
-    DevScratch d_common;
-    SVT_TRY(d_common.alloc(sizeof(uint32_t)));
-    {
-        const uint32_t n_vote = (uint32_t)std::min<uint64_t>(n_rec, kVoteRecords);
-        std::vector<uint4> sample;
-        const uint4* recs = reinterpret_cast<const uint4*>(in->records);
-        if (!recs && n_vote) {
-            sample.resize(n_vote);
-            HIP_TRY(hipMemcpyAsync(sample.data(), d_csr, (size_t)n_vote * sizeof(uint4), hipMemcpyDeviceToHost, b->stream));
-            HIP_TRY(hipStreamSynchronize(b->stream));
-            recs = sample.data();
-        }
-        b->common_mq = vote_common_mapq(recs, n_vote);
-        HIP_TRY(hipMemcpyAsync(d_common.p, &b->common_mq, sizeof(uint32_t), hipMemcpyHostToDevice, b->stream));
-    }
-    std::vector<ScanOut>& counts = g_host.counts;
-    counts.assign(n, ScanOut{});
-    uint32_t err_bits = 0;
-    if (n) {
-        ScanArgs sa{};
-        sa.csr = d_csr;
-        sa.rec_offset = d_off.as<uint64_t>();
-        sa.units = d_units.as<svt_unit>();
-        sa.libs = b->d_libs;
-        sa.n_units = n;
-        sa.n_libs = in->n_libs;
-        sa.out = d_counts.as<ScanOut>();
-        sa.err = d_err.as<uint32_t>();
-        sa.common_mq = d_common.as<uint32_t>();
-        hipLaunchKernelGGL(svt_scan_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, b->stream, sa);
-        HIP_TRY(hipGetLastError());
-    }
-    HIP_TRY(hipMemcpyAsync(&err_bits, d_err.p, sizeof(uint32_t), hipMemcpyDeviceToHost, b->stream));
-    if (n) SVT_TRY(d2h_staged(counts.data(), d_counts.p, n * sizeof(ScanOut), b->stream));
-    HIP_TRY(hipStreamSynchronize(b->stream));
-    tm.mark("scan kernel + counts D2H");
-    if (err_bits) return record_error(err_bits);
-
-    // ---- layout: the compact entries need the 32-bit table geometry, histograms narrow enough for
-    // the 13-bit code, DEL lengths >= 0 and, with several libraries, at most 4 consecutive libraries
-    // per unit and 7-bit MAPQs on the kept pair entries; anything else keeps the canonical records
-    if (b->layout != kLayoutDense) {
-        bool ok = T.fast_geometry && !negative_del;
-        for (const LibDesc& L : T.libs) ok = ok && L.n_bins <= kMaxCompactBins;
-        if (ok && in->n_libs > 1)
-            for (uint64_t u = 0; u < n && ok; ++u)
-                ok = ((counts[u].libs >> 8) & 0xffu) - (counts[u].libs & 0xffu) < kMaxCompactLibSpan &&
-                     !(counts[u].flags & kScanWideMapq);
-        // short pair entries: one library whose table code fits 12 bits (bit 15 of the half-word marks a wide entry)
-        const bool can_short = in->n_libs == 1 && T.libs[0].n_bins <= kMaxShortBins && !(b->flags & SVT_FLAG_FIXED_PAIR_ENTRIES);
-        b->layout = !ok ? kLayoutDense : can_short ? kLayoutShort : kLayoutCompact;
-    }
-
-    // ---- tiling
-    Tiling& G = g_host.G;
-    std::vector<TileDesc>& dispatch = g_host.dispatch;
-    std::vector<WgDesc>& windows = g_host.windows;
-    uint32_t n_groups = 0, max_win_libs = 1, max_win_bins = 1;
-    auto plan = [&]() -> int {
-        G.slots = 0;
-        build_tiling(in, nrec, counts, b->layout, G);
-        if (G.tiles.size() > 0xFFFFFFF0ull / kWave) return fail(SVT_ERR_INVALID, "too many tiles");
-        b->n_tiles = (uint32_t)G.tiles.size();
-        b->slots = G.slots;
-        // dispatch order: tiles stay in groups of 4 consecutive (= one workgroup, similar length, same
-        // libraries); the groups go longest first (LPT) so the tail of the grid is made of short tiles
-        n_groups = (b->n_tiles + kWavesPerBlock - 1) / kWavesPerBlock;
-        std::vector<uint32_t> group_order(n_groups);
-        std::vector<uint64_t> group_cost(n_groups, 0);
-        for (uint32_t g = 0; g < n_groups; ++g) {
-            group_order[g] = g;
-            for (uint32_t t = g * kWavesPerBlock; t < std::min(b->n_tiles, (g + 1) * kWavesPerBlock); ++t)
-                for (int k = 0; k < kStreams; ++k) group_cost[g] += G.tiles[t].rows[k];
-        }
-        std::stable_sort(group_order.begin(), group_order.end(),
-                         [&](uint32_t x, uint32_t y) { return group_cost[x] > group_cost[y]; });
-        dispatch.clear();
-        windows.clear();
-        dispatch.reserve((size_t)n_groups * kWavesPerBlock);
-        max_win_libs = 1;
-        max_win_bins = 1;
-        for (uint32_t g : group_order) {
-            uint32_t lo = 0xffffffffu, hi = 0;
-            for (uint32_t k = 0; k < (uint32_t)kWavesPerBlock; ++k) {
-                const uint32_t t = g * kWavesPerBlock + k;
-                if (t < b->n_tiles) {
-                    dispatch.push_back(G.tiles[t]);
-                    if (G.tile_lib_lo[t] != 0xffffffffu) {   // the tile references a library at all
-                        lo = std::min(lo, G.tile_lib_lo[t]);
-                        hi = std::max(hi, G.tile_lib_hi[t]);
-                    }
-                } else {
-                    TileDesc pad{};
-                    pad.lane_base = kPadUnit;          // marks a tile that does not exist
-                    dispatch.push_back(pad);
-                }
-            }
-            if (lo == 0xffffffffu) lo = hi = 0;        // a group of empty units: any window will do
-            WgDesc w{};
-            w.lib_lo = lo;
-            w.lib_cnt = hi - lo + 1;
-            w.bin_lo = T.libs[lo].tab_off;
-            w.bin_cnt = T.libs[hi].tab_off + T.libs[hi].n_bins + 1 - w.bin_lo;
-            windows.push_back(w);
-            max_win_libs = std::max(max_win_libs, w.lib_cnt);
-            max_win_bins = std::max(max_win_bins, w.bin_cnt);
-        }
-        return SVT_OK;
-    };
-    SVT_TRY(plan());
-    const bool lds_tables = T.fast_geometry && (size_t)max_win_bins * sizeof(Bin) <= kMaxLdsTableBytes;
-    if (b->layout != kLayoutDense && !lds_tables) {   // the compact entries only exist for the LDS modes
-        b->layout = kLayoutDense;
-        SVT_TRY(plan());
-    }
-
-    tm.mark("tiling (host sort)");
-    // ---- resident device objects
-    DevScratch d_tiles_store, d_lane_src, d_lane_nrec;
-    {
-        Stager st(b->stream);
-        SVT_TRY(upload(&b->d_tiles, dispatch, st));
-        SVT_TRY(upload(d_tiles_store, G.tiles, st));
-        void* p = nullptr;
-        SVT_TRY(g_pool.get(b->device, G.hdr.size() * sizeof(LaneHdr), &p, &b->cap_hdr));
-        b->d_hdr = static_cast<LaneHdr*>(p);
-        SVT_TRY(st.copy(b->d_hdr, G.hdr.data(), G.hdr.size() * sizeof(LaneHdr)));
-        SVT_TRY(upload(d_lane_src, G.lane_src, st));
-        SVT_TRY(upload(d_lane_nrec, G.lane_nrec, st));
-        SVT_TRY(upload(&b->d_pm, T.pm, st));
-        SVT_TRY(upload(&b->d_l10, T.l10, st));
-        SVT_TRY(upload(&b->d_bins, T.bins, st));
-        SVT_TRY(upload(&b->d_wtab, T.wtab, st));
-        SVT_TRY(upload(&b->d_wg, windows, st));
-        SVT_TRY(st.finish());
-    }
-    {
-        void* p = nullptr;
-        SVT_TRY(g_pool.get(b->device, (G.slots + kTailPadRows * kWave) * sizeof(uint4), &p, &b->cap_tiled));
-        b->d_tiled = static_cast<uint4*>(p);
-        HIP_TRY(hipMemsetAsync(b->d_tiled + G.slots, 0, kTailPadRows * kWave * sizeof(uint4), b->stream));
-        SVT_TRY(g_pool.get(b->device, std::max<uint64_t>(n, 1) * sizeof(svt_result), &p, &b->cap_out));
-        b->d_out = static_cast<svt_result*>(p);
-    }
-
-    // ---- re-tile on the device
-    if (b->n_tiles) {
-        RepackArgs ra{};
-        ra.csr = d_csr;
-        ra.lane_src = d_lane_src.as<uint64_t>();
-        ra.lane_nrec = d_lane_nrec.as<uint32_t>();
-        ra.tiles = d_tiles_store.as<TileDesc>();
-        ra.hdr = b->d_hdr;
-        ra.units = d_units.as<svt_unit>();
-        ra.libs = b->d_libs;
-        ra.tiled = b->d_tiled;
-        ra.n_tiles = b->n_tiles;
-        ra.multi_lib = in->n_libs > 1 ? 1u : 0u;
-        ra.short_pairs = b->layout == kLayoutShort ? 1u : 0u;
-        ra.common_mq = b->common_mq;
-        const dim3 grid((b->n_tiles + kWavesPerBlock - 1) / kWavesPerBlock), block(kBlock);
-        if (b->layout != kLayoutDense) hipLaunchKernelGGL(svt_repack_compact_kernel, grid, block, 0, b->stream, ra);
-        else hipLaunchKernelGGL(svt_repack_dense_kernel, grid, block, 0, b->stream, ra);
-        HIP_TRY(hipGetLastError());
-    }
-    HIP_TRY(hipStreamSynchronize(b->stream));  // scratch buffers are released on return
-    tm.mark("uploads + repack kernel");
-
-    // ---- kernel arguments
-    KernelArgs& a = b->args;
-    a.tiled = b->d_tiled;
-    a.tiles = b->d_tiles;
-    a.hdr = b->d_hdr;
-    a.pm = b->d_pm;
-    a.l10 = b->d_l10;
-    a.libs = b->d_libs;
-    a.bins = b->d_bins;
-    a.wtab = b->d_wtab;
-    a.n_l10 = (uint32_t)T.l10.size();
-    a.n_libs = in->n_libs;
-    a.total_bins = (uint32_t)T.bins.size();
-    a.n_tiles = n_groups * kWavesPerBlock;   // the dispatch list is padded to whole workgroups
-    a.n_units = n;
-    a.out = b->d_out;
-    a.lib0 = T.libs[0];
-    a.common_mq = b->common_mq;
-    fill_gt_consts(a.c, in->split_weight, in->disc_weight);
-
-    a.wg = b->d_wg;
-    // kernel flavour: tables in LDS when the 32-bit geometry holds and the largest per-workgroup
-    // library window fits the LDS budget; otherwise the general kernel reads them through L2
-    if (lds_tables) {
-        b->mode = in->n_libs == 1 ? kSingleLds : kMultiLds;
-        a.lds_libs = in->n_libs == 1 ? 1u : max_win_libs;
-        a.lds_bins = in->n_libs == 1 ? a.total_bins : max_win_bins;
-    } else {
-        b->mode = kGeneral;
-        a.lds_libs = in->n_libs;   // descriptors only
-        a.lds_bins = 0;
-    }
-    // the log10 table of the epilogue shares LDS with the bins only when there is one library: with
-    // per-workgroup library windows the 9 KB are better spent on occupancy (0.191 -> 0.183 ms on the
-    // 32-sample workload), the loop then reads the table through L2
-    a.l10_in_lds = (b->mode != kMultiLds && a.n_l10 <= kMaxL10Lds) ? 1u : 0u;
-    const uint32_t n_l10_lds = a.l10_in_lds ? ((a.n_l10 + 1u) & ~1u) : 0u;
-    b->lds_bytes = kLdsBins + (size_t)a.lds_bins * sizeof(Bin) + (size_t)a.lds_libs * (sizeof(LibDesc) + sizeof(uint2)) +
-                   (size_t)n_l10_lds * 8;
-    b->lds_bytes = (b->lds_bytes + 15) & ~size_t(15);
-    if (b->lds_bytes > 160 * 1024) return fail(SVT_ERR_INVALID, "LDS budget exceeded");
-    if (b->lds_bytes > 64 * 1024)
-        HIP_TRY(hipFuncSetAttribute(kernel_of(b), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_bytes));
     return SVT_OK;
 }
 
@@ -1242,7 +883,7 @@ int run_pipelined(svt_batch* b, svt_result* out, bool* download_left, PayloadOf&
             SVT_TRY(ps.event(&done));
             HIP_TRY(hipEventRecord(done, ps.compute));
             HIP_TRY(hipStreamWaitEvent(ps.down, done, 0));
-            HIP_TRY(hipMemcpyAsync(out + u0, b->args.out + u0, (u1 - u0) * sizeof(svt_result), hipMemcpyDeviceToHost, ps.down));
+            HIP_TRY(hipMemcpyAsync(out + u0, b->out_dev + u0, (u1 - u0) * sizeof(svt_result), hipMemcpyDeviceToHost, ps.down));
         }
         u0 = u1;
     }
@@ -1307,10 +948,10 @@ static int svt_batch_create_impl(const svt_evidence_batch* in, int device, unsig
     if (!b) return fail(SVT_ERR_NOMEM, "out of host memory");
     b->device = device;
     b->flags = flags;
-    b->layout = layout_of_flags(flags);
+    b->layout = kLayoutStream;
     b->n_units = n;
     b->n_records = n ? in->rec_offset[n] : 0;
-    const int rc = b->layout == kLayoutStream ? create_stream(in, b) : create_on_device(in, b);
+    const int rc = create_stream(in, b);
     if (rc != SVT_OK) {
         const std::string keep = g_err;
         free_batch(b);
@@ -1437,17 +1078,12 @@ static int svt_batch_create_from_fragments_impl(const svt_fragment_batch* in, in
     if (!b) return fail(SVT_ERR_NOMEM, "out of host memory");
     b->device = device;
     b->flags = flags;
-    b->layout = layout_of_flags(flags);
+    b->layout = kLayoutStream;
     b->n_units = n;
     b->n_records = n_frag;
-    int rc;
-    if (b->layout == kLayoutStream) {
-        const uint64_t cap = d_records.cap;
-        rc = create_stream(&eb, b, d_records.p, cap);
-        if (b->d_records == d_records.p) d_records.release();   // the batch owns the records now
-    } else {
-        rc = create_on_device(&eb, b, static_cast<const uint4*>(d_records.p));
-    }
+    const uint64_t cap = d_records.cap;
+    const int rc = create_stream(&eb, b, d_records.p, cap);
+    if (b->d_records == d_records.p) d_records.release();   // the batch owns the records now
     if (rc != SVT_OK) {
         const std::string keep = g_err;
         free_batch(b);
@@ -1522,11 +1158,11 @@ static int svt_batch_results_impl(svt_batch* b, svt_result* out, uint64_t n_unit
     HIP_TRY(hipStreamSynchronize(b->stream));   // the pass that produced the records
     SVT_TRY(check_stream_errors(b));
     if (b->n_units && g_pinned.is_pinned(out, b->n_units * sizeof(svt_result))) {   // svt_pinned_alloc'ed: straight DMA
-        HIP_TRY(hipMemcpyAsync(out, b->args.out, b->n_units * sizeof(svt_result), hipMemcpyDeviceToHost, b->stream));
+        HIP_TRY(hipMemcpyAsync(out, b->out_dev, b->n_units * sizeof(svt_result), hipMemcpyDeviceToHost, b->stream));
         HIP_TRY(hipStreamSynchronize(b->stream));
         return SVT_OK;
     }
-    return d2h_staged(out, b->args.out, b->n_units * sizeof(svt_result), b->stream);
+    return d2h_staged(out, b->out_dev, b->n_units * sizeof(svt_result), b->stream);
 }
 
 int svt_batch_results(svt_batch* b, svt_result* out, uint64_t n_units)
@@ -1537,7 +1173,7 @@ int svt_batch_results(svt_batch* b, svt_result* out, uint64_t n_units)
 int svt_batch_device_results(svt_batch* b, svt_result** dev)
 {
     if (!b || !dev) return fail(SVT_ERR_INVALID, "null argument");
-    *dev = b->args.out;
+    *dev = b->out_dev;
     return SVT_OK;
 }
 
@@ -1545,9 +1181,9 @@ static int svt_batch_bind_device_results_impl(svt_batch* b, svt_result* dev)
 {
     if (!b) return fail(SVT_ERR_INVALID, "null batch");
     if (dev && (reinterpret_cast<uintptr_t>(dev) & 127u)) return fail(SVT_ERR_INVALID, "result buffer must be 128-byte aligned");
-    b->args.out = dev ? dev : b->d_out;
-    b->sargs.out = b->args.out;
-    b->pargs.out = b->args.out;
+    b->out_dev = dev ? dev : b->d_out;
+    b->sargs.out = b->out_dev;
+    b->pargs.out = b->out_dev;
     b->have_results = false;
 
     return SVT_OK;
@@ -1562,9 +1198,8 @@ int svt_batch_bytes(const svt_batch* b, uint64_t* algorithmic, uint64_t* residen
 {
     if (!b) return fail(SVT_ERR_INVALID, "null batch");
     if (algorithmic) *algorithmic = 16 * b->n_records + (16 + 96) * b->n_units;
-    if (resident) *resident = b->layout == kLayoutStream ? 16 * b->n_records + (8 + 16) * b->n_units
-                              : b->layout == kLayoutPacked ? 16 * b->n_slots + (12 + 16) * b->n_units
-                                                         : 16 * b->slots + (uint64_t)b->n_tiles * kWave * sizeof(LaneHdr);
+    if (resident) *resident = b->layout == kLayoutPacked ? 16 * b->n_slots + (12 + 16) * b->n_units
+                                                         : 16 * b->n_records + (8 + 16) * b->n_units;
     return SVT_OK;
 }
 
@@ -1592,7 +1227,7 @@ static int svt_batch_site_qual_impl(svt_batch* b, uint32_t n_samples, const doub
         SVT_TRY(st.finish());
     }
     hipLaunchKernelGGL(svt_site_qual_kernel, dim3((unsigned)((n_sites + kBlock - 1) / kBlock)), dim3(kBlock), 0, b->stream,
-                       b->args.out, n_samples, initial ? d_init.as<double>() : nullptr, d_qual.as<double>(), n_sites);
+                       b->out_dev, n_samples, initial ? d_init.as<double>() : nullptr, d_qual.as<double>(), n_sites);
     HIP_TRY(hipGetLastError());
     return d2h_staged(qual_out, d_qual.p, n_sites * sizeof(double), b->stream);
 }
@@ -1779,7 +1414,7 @@ static int svt_genotype_packed_impl(const svt_packed_evidence* in, svt_result* o
                                    return st.copy(dst, src, (i1 - i0) * 16);
                                });
             }
-            if (rc == SVT_OK && download_left) rc = d2h_staged(out, b->args.out, in->n_units * sizeof(svt_result), b->stream);
+            if (rc == SVT_OK && download_left) rc = d2h_staged(out, b->out_dev, in->n_units * sizeof(svt_result), b->stream);
         }
         const std::string keep = g_err;
         free_batch(b);
@@ -1807,9 +1442,7 @@ void svt_batch_destroy(svt_batch* b) { free_batch(b); }
 
 void svt_trim(void)
 {
-    g_csr_cache.trim();
     g_pool.trim();
-    g_host.trim();
     g_pinned.trim();
     g_handles.trim();
 }
@@ -1817,7 +1450,7 @@ void svt_trim(void)
 static int svt_genotype_impl(const svt_evidence_batch* in, svt_result* out, int device, unsigned flags)
 {
     // the streamed layout from host records: upload, pass and download overlap by unit ranges
-    if (in && out && layout_of_flags(flags) == kLayoutStream && !(flags & ~kKnownFlags) && in->n_units >= kPipelineMinUnits &&
+    if (in && out && !(flags & ~kKnownFlags) && in->n_units >= kPipelineMinUnits &&
         in->n_units < 0xFFFFFFF0ull && in->rec_offset && in->units && in->records && in->n_libs >= 1 && in->n_libs <= 256 && in->libs &&
         in->rec_offset[0] == 0 && in->split_weight >= 0.0 && in->disc_weight >= 0.0 && std::isfinite(in->split_weight) &&
         std::isfinite(in->disc_weight)) {
@@ -1851,7 +1484,7 @@ static int svt_genotype_impl(const svt_evidence_batch* in, svt_result* out, int 
                                    return st.copy(dst, src, (i1 - i0) * 16);
                                });
             }
-            if (rc == SVT_OK && download_left) rc = d2h_staged(out, b->args.out, in->n_units * sizeof(svt_result), b->stream);
+            if (rc == SVT_OK && download_left) rc = d2h_staged(out, b->out_dev, in->n_units * sizeof(svt_result), b->stream);
         }
         const std::string keep = g_err;
         StageTimer tm;

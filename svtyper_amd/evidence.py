@@ -19,10 +19,6 @@ SVTYPE_CODE = {"DEL": 0, "DUP": 1, "INV": 2, "BND": 3}  # classic.py:228
 SVTYPE_NAME = {v: k for k, v in SVTYPE_CODE.items()}
 
 FLAG_SSO_ASSOCIATION = 0x1
-FLAG_STREAM_LAYOUT = 0x0        # default: the CSR as it is, streamed through per-wave LDS rings by the pass itself
-FLAG_DENSE_LAYOUT = 0x2         # tiled once at svt_batch_create: 16-byte records
-FLAG_FIXED_PAIR_ENTRIES = 0x4   # tiled compact layout with 4-byte pair entries only (no 2-byte short entries)
-FLAG_COMPACT_LAYOUT = 0x8       # tiled compact entry streams (2-byte "short" pair entries where the batch allows)
 
 REC_ALT_STRADDLE = 1 << 0
 REC_REF_STRADDLE_A = 1 << 1

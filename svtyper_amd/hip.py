@@ -16,7 +16,7 @@ from .evidence import GT_BLANK, CEvidenceBatch, CPackedEvidence, EvidenceBatch, 
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SVTYPER_HIP_LIB") or os.path.join(_HERE, "csrc", "libsvtyper_hip.so")
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 EXPORTS = (
     "svt_version", "svt_device_count", "svt_last_error", "svt_batch_create", "svt_batch_create_from_fragments",
@@ -338,19 +338,17 @@ class DeviceBatch:
                                              out.ctypes.data, n_sites))
         return out
 
-    def layout(self):
-        """(compact entry streams: bool, table_mode: 0 one library in LDS / 1 library windows in LDS / 2 general)"""
+    def table_mode(self) -> int:
+        """0 one library, tables in LDS / 1 library windows in LDS (svt_unit.libs hints) / 2 general (tables through L2)"""
         c, m = C.c_int(), C.c_int()
         _check(self._lib.svt_batch_layout(self._h, C.byref(c), C.byref(m)))
-        return c.value in (1, 2), int(m.value)
+        return int(m.value)
 
     def layout_name(self) -> str:
-        """"stream" (default: the CSR as uploaded), or one of the tiled layouts: "dense" (16-byte records), "compact"
-        (entry streams, 4-byte pair entries), "short" (entry streams, 2-byte pair entries for the batch's most
-        common MAPQ pair)"""
+        """"stream" (the canonical CSR as uploaded) or "packed" (packed evidence as uploaded)"""
         c, m = C.c_int(), C.c_int()
         _check(self._lib.svt_batch_layout(self._h, C.byref(c), C.byref(m)))
-        return ("dense", "compact", "short", "stream", "packed")[c.value]
+        return {3: "stream", 4: "packed"}[c.value]
 
     def stream(self) -> int:
         return int(self._lib.svt_batch_stream(self._h) or 0)

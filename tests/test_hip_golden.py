@@ -10,10 +10,19 @@ pytestmark = pytest.mark.gpu
 SQ_TOL = 1e-6  # north_star tolerance; everything else must be exact
 
 
-def _check(sites, libs_json, flags, hip_device):
+def _check(sites, libs_json, flags, hip_device, form="records"):
+    """form: "records" = the canonical records through svt_genotype; "packed" = the same sites as packed evidence
+    through svt_genotype_packed (skipped where the format cannot hold the batch: several libraries)"""
     from svtyper_amd import hip
     batch = gio.batch_from_sites(sites, libs_json)
-    got = hip.genotype_batch(batch, device=hip_device, flags=flags)
+    if form == "packed":
+        packed = hip.PackedEvidence.try_pack(batch)
+        if packed is None:
+            return False
+        with packed:
+            got = hip.genotype_packed(packed, device=hip_device, flags=flags)
+    else:
+        got = hip.genotype_batch(batch, device=hip_device, flags=flags)
     for k, s in enumerate(sites):
         for j, t in enumerate(gio.TALLIES):
             if flags & ev.FLAG_SSO_ASSOCIATION:
@@ -23,25 +32,26 @@ def _check(sites, libs_json, flags, hip_device):
             assert float(got.tallies[k, j]).hex() == float(want).hex(), (s["breakpoint"]["id"], t)
         gio.assert_result_equal(result_from_record(got.rec[k]), gio.golden_result(s["result"]), SQ_TOL,
                                 s["breakpoint"]["id"])
+    return True
 
 
-@pytest.mark.parametrize("layout", [0, ev.FLAG_DENSE_LAYOUT, ev.FLAG_COMPACT_LAYOUT])
-def test_fixture_sites_sso(hip_device, layout):
+@pytest.mark.parametrize("form", ["records", "packed"])
+def test_fixture_sites_sso(hip_device, form):
     g = gio.load("fixture_sites.json.gz")
-    _check(g["sites"], g["libraries"], ev.FLAG_SSO_ASSOCIATION | layout, hip_device)
+    assert _check(g["sites"], g["libraries"], ev.FLAG_SSO_ASSOCIATION, hip_device, form)
 
 
-@pytest.mark.parametrize("layout", [0, ev.FLAG_DENSE_LAYOUT, ev.FLAG_COMPACT_LAYOUT])
-def test_fixture_sites_classic(hip_device, layout):
+@pytest.mark.parametrize("form", ["records", "packed"])
+def test_fixture_sites_classic(hip_device, form):
     g = gio.load("fixture_sites.json.gz")
-    _check(g["sites"], g["libraries"], layout, hip_device)
+    assert _check(g["sites"], g["libraries"], 0, hip_device, form)
 
 
-@pytest.mark.parametrize("layout", [0, ev.FLAG_DENSE_LAYOUT, ev.FLAG_COMPACT_LAYOUT])
-def test_fake_sites(hip_device, layout):
+@pytest.mark.parametrize("form", ["records", "packed"])
+def test_fake_sites(hip_device, form):
     g = gio.load("fake_sites.json.gz")
-    for grp in g["groups"]:
-        _check(grp["sites"], grp["libraries"], ev.FLAG_SSO_ASSOCIATION | layout, hip_device)
+    ran = [_check(grp["sites"], grp["libraries"], ev.FLAG_SSO_ASSOCIATION, hip_device, form) for grp in g["groups"]]
+    assert any(ran)
 
 
 def test_bayes_gt_seam(hip_device):

@@ -34,20 +34,25 @@ def assert_parity(got: ev.Results, want: ev.Results, exact_float=True):
 
 
 def run_both(batch, flags=0, device=0):
+    """HIP (canonical records through svt_genotype) and the oracle; where the packed format can hold the batch the
+    same units also go through svt_pack_evidence -> svt_genotype_packed and must come back with the same bytes."""
     from oracle import c_oracle
     from svtyper_amd import hip
     got = hip.genotype_batch(batch, device=device, flags=flags)
     want = c_oracle.genotype_batch(batch, flags=flags & ev.FLAG_SSO_ASSOCIATION)
+    packed = hip.PackedEvidence.try_pack(batch)
+    if packed is not None:
+        with packed:
+            again = hip.genotype_packed(packed, device=device, flags=flags)
+        assert again.rec.tobytes() == got.rec.tobytes(), "packed pass differs from the pass over the canonical records"
     return got, want
 
 
-ALL_FLAGS = [0, ev.FLAG_SSO_ASSOCIATION, ev.FLAG_DENSE_LAYOUT, ev.FLAG_DENSE_LAYOUT | ev.FLAG_SSO_ASSOCIATION,
-             ev.FLAG_FIXED_PAIR_ENTRIES, ev.FLAG_FIXED_PAIR_ENTRIES | ev.FLAG_SSO_ASSOCIATION,
-             ev.FLAG_COMPACT_LAYOUT, ev.FLAG_COMPACT_LAYOUT | ev.FLAG_SSO_ASSOCIATION]
+ALL_FLAGS = [0, ev.FLAG_SSO_ASSOCIATION]
 
 
 def oracle_flags(flags):
-    return flags & ev.FLAG_SSO_ASSOCIATION   # the device layout is invisible to the oracle
+    return flags & ev.FLAG_SSO_ASSOCIATION
 
 
 @pytest.mark.parametrize("flags", ALL_FLAGS)
@@ -70,7 +75,7 @@ def test_c2_slice(hip_device, fixture_library, flags):
     assert_parity(got, want)
 
 
-@pytest.mark.parametrize("flags", [0, ev.FLAG_DENSE_LAYOUT, ev.FLAG_COMPACT_LAYOUT])
+@pytest.mark.parametrize("flags", ALL_FLAGS)
 def test_c3_slice_mixed(hip_device, fixture_library, flags):
     """configs[2]: mixed DEL/DUP/INV."""
     batch = synth.make_config("c3_mixed_1m", [fixture_library], n_units=30_000)
@@ -303,9 +308,9 @@ def test_full_size_properties(hip_device, full_c3):
     perm = hip.genotype_batch(synth.permute_units(batch, order), device=hip_device)
     assert np.array_equal(_digest(perm), base[order])
 
-    # every device layout agrees on everything
-    for other in (ev.FLAG_DENSE_LAYOUT, ev.FLAG_COMPACT_LAYOUT):
-        assert np.array_equal(hip.genotype_batch(batch, device=hip_device, flags=other).rec, first.rec)
+    # the same million units as packed evidence (svt_pack_evidence -> svt_genotype_packed) agree on everything
+    with hip.PackedEvidence(batch) as packed:
+        assert np.array_equal(hip.genotype_packed(packed, device=hip_device).rec, first.rec)
 
     # the oracle on a bounded random sample of the same units
     pick = np.sort(rng.choice(n, 20_000, replace=False))
@@ -324,12 +329,13 @@ def test_full_size_properties(hip_device, full_c3):
 
 
 # ------------------------------------------------------------------------------------------
-# compact layout: the ospan_len -> table-code translation and the fallbacks to the dense records
+# histogram windows: ospan_len against [key_min, key_min + n_bins) and the same shifted by var_length
+# (the clamped table indices of the streaming kernel, the table codes of packed pair entries)
 # ------------------------------------------------------------------------------------------
-def _layout_of(batch, flags=ev.FLAG_COMPACT_LAYOUT, device=0):
+def _mode_of(batch, flags=0, device=0):
     from svtyper_amd import hip
     with hip.DeviceBatch(batch, device, flags) as d:
-        return d.layout()
+        return d.table_mode()
 
 
 def _sweep_batch(lib, var_lengths, svtype, extra_libs=()):
@@ -362,25 +368,30 @@ def _sweep_batch(lib, var_lengths, svtype, extra_libs=()):
 
 
 @pytest.mark.parametrize("svtype", [0, 1, 2])
-def test_compact_code_windows(hip_device, fixture_library, svtype):
+def test_histogram_windows(hip_device, fixture_library, svtype):
     nb = len(fixture_library.hist)
     vls = [0, 1, 37, nb - 1, nb, nb + 1, 3 * nb, 100_000, 2**29]
     batch = _sweep_batch(fixture_library, vls, svtype)
-    assert _layout_of(batch) == (True, 0)
+    assert _mode_of(batch) == 0
     for flags in ALL_FLAGS:
         got, want = run_both(batch, flags)
         assert_parity(got, want)
 
 
-def test_compact_code_windows_multi_library(hip_device, fixture_library):
+def test_histogram_windows_multi_library(hip_device, fixture_library):
     other = synth.normal_library(420.0, 95.0, seed=3)
     nb = len(other.hist)
     batch = _sweep_batch(other, [0, 5, nb - 1, nb, nb + 7, 50_000], 0, extra_libs=(fixture_library,))
     batch.records["flags"][1::2] |= np.uint32(1 << ev.REC_LIB_SHIFT)   # alternate the two libraries
-    assert _layout_of(batch) == (True, 1)
+    assert _mode_of(batch) == 2                     # no svt_unit.libs hints: general mode
+    hinted = synth.permute_units(batch, np.arange(batch.n_units))
+    hinted.units["libs"] = ev.unit_libs(0, 2)
+    assert _mode_of(hinted) == 1                    # both libraries in every unit's window
     for flags in ALL_FLAGS:
         got, want = run_both(batch, flags)
         assert_parity(got, want)
+        again, _ = run_both(hinted, flags)
+        assert again.rec.tobytes() == got.rec.tobytes()
 
 
 def test_small_deletion_gate_per_library(hip_device, fixture_library):
@@ -390,15 +401,18 @@ def test_small_deletion_gate_per_library(hip_device, fixture_library):
     batch = synth.make_units(3000, 21, [tight, wide], svtype_mix=(1.0, 0, 0, 0))
     batch.units["pos_delta"] = np.resize([10, 39, 40, 41, 100, 239, 240, 241, 1000], batch.n_units)
     batch.units["var_length"] = batch.units["pos_delta"]
-    assert _layout_of(batch)[0]
+    hinted = synth.permute_units(batch, np.arange(batch.n_units))
+    hinted.units["libs"] = ev.unit_libs(0, 2)
+    assert _mode_of(batch) == 2 and _mode_of(hinted) == 1
     for flags in ALL_FLAGS:
         got, want = run_both(batch, flags)
         assert_parity(got, want)
+        assert run_both(hinted, flags)[0].rec.tobytes() == got.rec.tobytes()
 
 
-def test_compact_fallbacks_stay_exact(hip_device, fixture_library):
-    """Batches the compact encoding cannot express take the dense layout, silently and exactly."""
-    # (a) a histogram wider than the 13-bit code allows
+def test_shapes_outside_the_fast_modes_stay_exact(hip_device, fixture_library):
+    """Batches the LDS modes / the packed format cannot express take the general mode, silently and exactly."""
+    # (a) a histogram wider than a packed pair entry's 12-bit code allows (one library: still tables in LDS)
     broad = synth.normal_library(3000.0, 900.0, seed=5)
     assert len(broad.hist) > 4095
     a = synth.make_units(1500, 31, [broad], svtype_mix=(0.6, 0.2, 0.2, 0.0))
@@ -406,7 +420,7 @@ def test_compact_fallbacks_stay_exact(hip_device, fixture_library):
     libs = [fixture_library, synth.normal_library(420.0, 95.0, seed=3)]
     b = synth.make_units(1500, 32, libs, svtype_mix=(0.6, 0.2, 0.2, 0.0))
     b.records["mapq_a"][::11] = 200
-    # (c) a unit whose records reference libraries more than 4 apart
+    # (c) a unit whose records reference libraries far apart
     many = [synth.normal_library(300.0 + 10 * i, 40.0 + i, seed=40 + i) for i in range(7)]
     c = synth.make_units(1500, 33, many, svtype_mix=(0.6, 0.2, 0.2, 0.0))
     fl = c.records["flags"] & ~np.uint32(0xff << ev.REC_LIB_SHIFT)
@@ -414,15 +428,13 @@ def test_compact_fallbacks_stay_exact(hip_device, fixture_library):
     # (d) a negative DEL length
     d = synth.make_units(1500, 34, [fixture_library], svtype_mix=(1.0, 0, 0, 0))
     d.units["var_length"][::9] = -250
+    from svtyper_amd import hip
+    assert hip.PackedEvidence.try_pack(a) is None and hip.PackedEvidence.try_pack(d) is None
+    assert [_mode_of(x) for x in (a, b, c, d)] == [0, 2, 2, 0]
     for batch in (a, b, c, d):
-        assert _layout_of(batch)[0] is False
-        for flags in (ev.FLAG_COMPACT_LAYOUT, ev.FLAG_COMPACT_LAYOUT | ev.FLAG_SSO_ASSOCIATION):
+        for flags in ALL_FLAGS:
             got, want = run_both(batch, flags)
             assert_parity(got, want)
-    # the same shapes without the offending feature do take the compact layout
-    b.records["mapq_a"][::11] = 60
-    d.units["var_length"][::9] = 250
-    assert _layout_of(b)[0] and _layout_of(d)[0]
 
 
 def test_pooled_buffers_do_not_leak_state(hip_device, fixture_library):
@@ -433,10 +445,10 @@ def test_pooled_buffers_do_not_leak_state(hip_device, fixture_library):
     small = synth.make_units(17_000, 72, [fixture_library], svtype_mix=(0.5, 0.2, 0.2, 0.1), mean_frags=40, sd_frags=30,
                              min_frags=0, max_frags=120)
     want_small = run_both(small)[1]
-    for flags in (0, ev.FLAG_DENSE_LAYOUT, ev.FLAG_COMPACT_LAYOUT, 0):
+    for flags in (0, ev.FLAG_SSO_ASSOCIATION, 0):
         got_big, want_big = run_both(big, flags)
         assert_parity(got_big, want_big)
-        assert_parity(hip.genotype_batch(small, device=hip_device, flags=flags), want_small)
+        assert_parity(hip.genotype_batch(small, device=hip_device, flags=flags), want_small if not flags else run_both(small, flags)[1])
     hip.trim()
     assert_parity(hip.genotype_batch(small, device=hip_device), want_small)
 
@@ -475,32 +487,11 @@ def test_site_qual_on_device(hip_device, fixture_library, n_samples):
 
 
 # ------------------------------------------------------------------------------------------
-# short layout: 2-byte pair entries for the batch's most common MAPQ pair, 4-byte-aligned wide entries otherwise
+# MAPQ patterns: every mix of common / other MAPQ pairs (the one-half-word and wide pair entries of packed
+# evidence, which run_both sends through svt_genotype_packed as well), MAPQ 0 / 255 on either read
 # ------------------------------------------------------------------------------------------
-def _name_of(batch, flags=ev.FLAG_COMPACT_LAYOUT, device=0):
-    from svtyper_amd import hip
-    with hip.DeviceBatch(batch, device, flags) as d:
-        return d.layout_name()
-
-
-def test_short_layout_is_what_the_compact_flag_gives_one_narrow_library(hip_device, fixture_library):
-    assert len(fixture_library.hist) <= 2047
-    batch = synth.make_units(4000, 51, [fixture_library], svtype_mix=(0.6, 0.2, 0.1, 0.1))
-    assert _name_of(batch, 0) == "stream"            # the default layout streams the CSR as it is
-    assert _name_of(batch) == "short"
-    assert _name_of(batch, ev.FLAG_FIXED_PAIR_ENTRIES) == "compact"
-    assert _name_of(batch, ev.FLAG_DENSE_LAYOUT) == "dense"
-    # a library between 2048 and 4095 bins keeps the 4-byte entries; several libraries as well
-    mid = synth.normal_library(1500.0, 420.0, seed=9)
-    assert 2047 < len(mid.hist) <= 4095
-    assert _name_of(synth.make_units(500, 52, [mid])) == "compact"
-    assert _name_of(synth.make_units(500, 53, [fixture_library, synth.normal_library(420.0, 95.0, seed=3)])) == "compact"
-
-
 @pytest.mark.parametrize("pattern", ["all_common", "all_wide", "alternate", "runs", "random", "mapq255", "vote_other"])
-def test_short_layout_mapq_patterns(hip_device, fixture_library, pattern):
-    """Every mix of one-half-word and wide entries (and the no-op half-words that align the wide ones), with the
-    common pair found by the vote -- which need not be (60, 60)."""
+def test_mapq_patterns(hip_device, fixture_library, pattern):
     import zlib
     rng = np.random.default_rng(zlib.crc32(pattern.encode()))
     batch = synth.make_units(3000, 61, [fixture_library], svtype_mix=(0.5, 0.2, 0.2, 0.1), mean_frags=40, sd_frags=25,
@@ -527,24 +518,9 @@ def test_short_layout_mapq_patterns(hip_device, fixture_library, pattern):
     else:   # the vote picks (40, 13); (60, 60) entries are then the wide ones
         a[:], b[:] = 40, 13
         a[::4], b[::4] = 60, 60
-    assert _name_of(batch) == "short"
     for flags in ALL_FLAGS:
         got, want = run_both(batch, flags)
         assert_parity(got, want)
-
-
-def test_short_layout_is_smaller_and_equal_on_the_headline_shape(hip_device, fixture_library):
-    from svtyper_amd import hip
-    batch = synth.make_config("c3_mixed_1m", [fixture_library], n_units=30_000)
-    sizes, results = {}, {}
-    for name, flags in (("short", ev.FLAG_COMPACT_LAYOUT), ("compact", ev.FLAG_FIXED_PAIR_ENTRIES), ("dense", ev.FLAG_DENSE_LAYOUT)):
-        with hip.DeviceBatch(batch, hip_device, flags) as d:
-            assert d.layout_name() == name
-            sizes[name] = d.bytes()[1]
-            d.genotype(sync=True)
-            results[name] = d.results().rec.tobytes()
-    assert results["short"] == results["compact"] == results["dense"]
-    assert sizes["short"] < 0.8 * sizes["compact"] < sizes["dense"]
 
 
 def test_sum_of_likelihoods_across_the_underflow_band(hip_device, fixture_library):
@@ -565,7 +541,7 @@ def test_sum_of_likelihoods_across_the_underflow_band(hip_device, fixture_librar
         u["var_length"] = 5000 if svtype == 0 else 0
         u["pos_delta"] = 5000
         batch = ev.EvidenceBatch(off, u, r, [fixture_library], 1.0, 1.0)
-        for flags in (0, ev.FLAG_DENSE_LAYOUT, ev.FLAG_COMPACT_LAYOUT):
+        for flags in ALL_FLAGS:
             got, want = run_both(batch, flags)
             assert_parity(got, want)
         best = want.gl.max(axis=1)
@@ -614,8 +590,11 @@ def test_full_size_multisample_properties(hip_device, full_c5):
     multi = hip.genotype_multi(batch, [hip_device] * 3, group=S)
     assert np.array_equal(_digest(multi), base)
     assert all(lo_ % S == 0 for lo_, _ in hip.shard_bounds(batch.rec_offset, 3, S))
-    # the tiled layout with library windows agrees on everything
-    assert np.array_equal(hip.genotype_batch(batch, device=hip_device, flags=ev.FLAG_FIXED_PAIR_ENTRIES).rec, first.rec)
+    # without the svt_unit.libs hints the same batch takes the general mode (tables through L2) and agrees on everything
+    units = batch.units.copy()
+    units["libs"] = 0
+    plain = ev.EvidenceBatch(batch.rec_offset, units, batch.records, batch.libs, batch.split_weight, batch.disc_weight)
+    assert np.array_equal(hip.genotype_batch(plain, device=hip_device).rec, first.rec)
     # the oracle on a bounded random sample of whole sites
     rng = np.random.default_rng(7)
     sites = np.sort(rng.choice(65_536, 700, replace=False))
@@ -636,13 +615,13 @@ def test_library_windows_in_the_streaming_kernel(hip_device, fixture_library):
     assert (batch.units["libs"] != 0).all() and len(np.unique(batch.units["libs"])) == 32
     for flags in (0, ev.FLAG_SSO_ASSOCIATION):
         with hip.DeviceBatch(batch, hip_device, flags) as d:
-            assert d.layout_name() == "stream" and d.layout()[1] == 1
+            assert d.layout_name() == "stream" and d.table_mode() == 1
             d.genotype(sync=True)
             win = d.results()
         plain = synth.permute_units(batch, np.arange(batch.n_units))
         plain.units["libs"] = 0
         with hip.DeviceBatch(plain, hip_device, flags) as d:
-            assert d.layout()[1] == 2
+            assert d.table_mode() == 2
             d.genotype(sync=True)
             gen = d.results()
         assert win.rec.tobytes() == gen.rec.tobytes()
@@ -656,8 +635,6 @@ def test_library_windows_in_the_streaming_kernel(hip_device, fixture_library):
     # a window wider than what the records use is fine; a record outside its unit's window is a contract violation
     wide = synth.permute_units(batch, np.arange(640))
     wide.units["libs"] = ev.unit_libs(0, len(batch.libs))
-    if hip.DeviceBatch(wide, hip_device).layout()[1] == 1:        # (only if 66 tables fit the LDS budget; else general)
-        pass
     got, want = run_both(wide)
     assert_parity(got, want)
     bad = synth.permute_units(batch, np.arange(640))

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """A/B timing of library build variants (svtyper_amd/csrc/variants/lib_*.so, see tools/stream_variants.sh) on one
-workload generated once:   python tools/ab_stream.py [units] [layout flags]
+workload generated once:   python tools/ab_stream.py [units] [flags]
 Each variant runs in its own process (SVTYPER_HIP_LIB), prints the pass time and a digest of the result records."""
 import hashlib, os, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -53,8 +53,7 @@ try:
         if r:
             avg_us = r[0] / 1e3 if r[0] > 1e4 else r[0]
     layout = bj["config"]["device_layout"].split(",")[0]
-    key = {"the canonical CSR records as uploaded": "stream", "dense 16-byte records": "dense",
-           "compact sparse 4-byte entry streams": "compact", "compact sparse entry streams": "short"}.get(layout, layout)
+    key = {"the canonical CSR records as uploaded": "stream"}.get(layout, layout)
     entry = {key: {
         "kernel": kern, "workload": bj["config"]["workload"], "units": bj["config"]["units_per_gpu"],
         "records": bj["config"]["records_per_gpu"], "FETCH_SIZE_KB": vals.get("FETCH_SIZE"), "WRITE_SIZE_KB": vals.get("WRITE_SIZE"),
