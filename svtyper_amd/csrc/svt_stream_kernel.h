@@ -16,14 +16,14 @@
 //   * record_window  several libraries with per-sample library windows (svt_unit.libs): the units are grouped by
 //                    window on the host (a permutation of unit indices, the records stay where they are) and a
 //                    workgroup stages only its window's histograms;
-//   * the general mode (any geometry, no hints): weight_evidence / pair_evidence<kGeneral> with tables through L2;
+//   * the general mode (any geometry, no hints): weight_evidence / pair_evidence with tables through L2;
 //   * slots of a block that lie outside the unit (the neighbours' records in its first and last line, everything
 //     past the end of a shorter unit) are not fetched; the consumer reads them as records with MAPQ 0 everywhere:
 //     prob_mapq(0) == +0.0 exactly, and x + 0.0 == x for these non-negative sums (the argument of
 //     include/svtyper_hip.h for gated-off reads).
 //
-// The record contract of include/svtyper_hip.h is checked on the fly (svt_scan_kernel's job for the
-// tiled layouts): violations are OR-ed into *err, which the host reads after the pass.
+// The record contract of include/svtyper_hip.h is checked on the fly: violations are OR-ed into *err, which the
+// host reads after the pass.
 #ifndef SVT_STREAM_KERNEL_H
 #define SVT_STREAM_KERNEL_H
 
@@ -152,7 +152,7 @@ struct StreamCtx {
 };
 
 // One canonical record, one library, tables at fixed LDS addresses: the arithmetic of weight_evidence +
-// pair_evidence<kSingleLds> (svt_unit_math.h; classic.py:306-408) with every table index formed by one
+// pair_evidence (svt_unit_math.h; classic.py:306-408) with every table index formed by one
 // instruction.  (pm(l) * L + pm(r) * R) / 2.0 (classic.py:324) is taken as pm(l)/2 + pm(r)/2 from a second
 // table: halving a binary64 in [0.2, 1] is exact, so the sum rounds identically.  EDGE: the record may belong
 // to a neighbouring unit -- its weight bytes are then read as MAPQ 0, which adds +0.0 to every sum.
@@ -444,7 +444,7 @@ __global__ __launch_bounds__(kBlock, MODE == kSingleLds ? SVT_STREAM_WAVES : MOD
                     const uint32_t wy = mine ? w[j].y : 0u, wz = mine ? w[j].z : 0u;   // MAPQ 0 everywhere: adds +0.0
                     weight_evidence<SSO>(wy >> 16 | (wz << 16), wz >> 16, (w[j].w & SVT_REC_CONTINUATION) != 0, t, acc);
                     // (a library index beyond the batch's is reported through *err)
-                    pair_evidence<MODE>(w[j].x, wy & 0xffffu, w[j].w & 7u, min(SVT_REC_LIB(w[j].w), a.n_libs - 1u), t, c, acc);
+                    pair_evidence(w[j].x, wy & 0xffffu, w[j].w & 7u, min(SVT_REC_LIB(w[j].w), a.n_libs - 1u), t, c, acc);
                 }
             }
         };

@@ -44,11 +44,11 @@ SVT_BYTE_X8(3)
 // ------------------------------------------------------------------------------------------
 // evidence arithmetic
 // ------------------------------------------------------------------------------------------
-struct Tables {               // dense layout: tables through ordinary pointers
+struct Tables {               // general mode: tables through ordinary pointers
     const double* pm;          // LDS
     const PairWeights* wtab;   // LDS
     const LibDesc* libs;       // LDS
-    const Bin* bins;           // LDS (kGeneral: global)
+    const Bin* bins;           // global (through L2)
 };
 
 struct Acc {
@@ -56,33 +56,20 @@ struct Acc {
     double l_ref_seq, l_alt_seq, l_alt_clip;  // sso fragment-local sums
 };
 
-// per-lane constants of the unit, hoisted out of the record loop
+// per-lane constants of the unit, hoisted out of the record loop (general mode and packed entries)
 struct LaneCtx {
     uint32_t del16;       // is_DEL ? 16 : 0 (decision-table index bit)
-    uint32_t fmask;       // dense kSingleLds: straddle-bit mask with the small-DEL gate applied
-    uint32_t kmin;        // dense kSingleLds: (uint32) key_min
-    uint32_t nb;          // dense kSingleLds: n_bins (== sentinel index)
-    uint32_t sub2;        // dense kSingleLds: DEL ? var_length + key_min : 0x80000000 (never in range)
-    uint32_t nb8;         // compact kSingleLds: n_bins * 8 (byte offset of the sentinel bin)
-    uint32_t off2_8;      // compact kSingleLds: DEL ? min(var_length, n_bins) * 8 : 0x80000000
-    uint32_t wt0, wt1;    // compact: LDS address of w_alt[del16] / w_alt[del16 + 8] (p_concordant = 0 / 1) in the column-wise table
-    uint32_t lib_min;     // compact kMultiLds: first library of the lane's unit
-    uint32_t lib_lo;      // kMultiLds: first library / first bin staged by this workgroup
-    uint32_t lib_last;    // kMultiLds: index of the last staged library inside the window
-    uint32_t bin_lo;
-    uint32_t libx_lane;   // compact kMultiLds: LDS address of the {bins address, n_bins * 8} pair of the
-                          // lane's first library (svt_genotype_kernel stages one pair per window library)
-    uint32_t vl8;         // compact kMultiLds: min(var_length, 8191) * 8
-    uint32_t nodel;       // compact kMultiLds: DEL ? 0 : 0x80000000
     int32_t var_length;
     double pos_delta_d;
     bool is_del;
-    uint32_t common_mq;   // short layout: mapq_a | mapq_b << 8 of the one-half-word pair entries
-    uint32_t nb4, off2_4; // short layout: nb8 / 2, off2_8 / 2 (thr[] and hist[] are separate 4-byte arrays there)
-    uint32_t hist_at;     // short layout: LDS address of hist[0]
+    // packed entries (one library, tables at fixed LDS addresses)
+    uint32_t wt0, wt1;    // LDS address of w_alt[del16] / w_alt[del16 + 8] (p_concordant = 0 / 1) in the column-wise table
+    uint32_t common_mq;   // mapq_a | mapq_b << 8 of the one-half-word pair entries
+    uint32_t nb4, off2_4; // n_bins * 4 (byte offset of the sentinel bin); DEL ? min(var_length, n_bins) * 4 : 0x80000000
+    uint32_t hist_at;     // LDS address of hist[0]
 };
 
-// ---- dense layout: one canonical 16-byte record -------------------------------------------------
+// ---- one canonical 16-byte record, any geometry (svt_stream_kernel.h: kGeneral) --------------------
 // Split-read / reference-read weights of one fragment record (classic.py:306-328).  Every add is
 // unconditional: gated-off evidence arrives as MAPQ 0, whose weight prob_mapq(0) is exactly +0.0,
 // and x + 0.0 == x bit-for-bit for these non-negative sums.
@@ -118,7 +105,6 @@ __device__ __forceinline__ void weight_evidence(const uint32_t wa, const uint32_
 
 // Paired-end evidence of one fragment (classic.py:339-408).
 //   o = ospan_len, mq = mapq_a | mapq_b << 8, f3 = alt | refA << 1 | refB << 2, lib = library index
-template <int MODE>
 __device__ __forceinline__ void pair_evidence(const uint32_t o, const uint32_t mq, uint32_t f3,
                                               const uint32_t lib_idx, const Tables& t, const LaneCtx& c, Acc& a)
 {
@@ -131,26 +117,7 @@ __device__ __forceinline__ void pair_evidence(const uint32_t o, const uint32_t m
     // with the reference's own expression), -1 where hist[o] == 0 (p == 0 or ZeroDivisionError).
     int32_t thr1;
     uint32_t h2;
-    if (MODE == kSingleLds) {
-        f3 &= c.fmask;                                  // small-DEL gate (classic.py:339,383)
-        const uint32_t i1 = min(o - c.kmin, c.nb);      // out of range -> sentinel (thr -1)
-        const uint32_t i2 = min(o - c.sub2, c.nb);      // out of range -> sentinel (hist 0)
-        thr1 = t.bins[i1].thr;
-        h2 = t.bins[i2].hist;
-    } else if (MODE == kMultiLds) {
-        // (an all-zero padding record names library 0, which may lie below the window: any staged library
-        // will do for it, its MAPQ-0 weights make the contribution exactly +0.0)
-        const LibDesc lib = t.libs[min(lib_idx - c.lib_lo, c.lib_last)];
-        const bool small_del = c.is_del && (c.pos_delta_d < lib.sd2);
-        f3 = small_del ? 0u : f3;
-        const uint32_t kmin = (uint32_t)lib.key_min;
-        const uint32_t sub2 = c.is_del ? (uint32_t)c.var_length + kmin : 0x80000000u;
-        const uint32_t i1 = min(o - kmin, lib.n_bins);
-        const uint32_t i2 = min(o - sub2, lib.n_bins);
-        const uint32_t base = lib.tab_off - c.bin_lo;
-        thr1 = t.bins[base + i1].thr;
-        h2 = t.bins[base + i2].hist;
-    } else {
+    {
         const LibDesc lib = t.libs[lib_idx];
         const bool small_del = c.is_del && (c.pos_delta_d < lib.sd2);
         f3 = small_del ? 0u : f3;
@@ -300,27 +267,10 @@ __device__ __forceinline__ double log_choose_dev(const double* __restrict__ l10,
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-// streaming read of one 16-byte row slot (read exactly once per pass): non-temporal
-__device__ __forceinline__ uint4 ld_stream(const uint4* __restrict__ p)
-{
-    const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
-    return make_uint4(v.x, v.y, v.z, v.w);
-}
-
 __device__ __forceinline__ uint4 pack2d(double x, double y)
 {
     const uint64_t a = (uint64_t)__double_as_longlong(x), b = (uint64_t)__double_as_longlong(y);
     return make_uint4((uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32));
-}
-
-// value of the neighbouring lane of the pair (lane ^ 1), by DPP quad permutation [1, 0, 3, 2]
-__device__ __forceinline__ uint32_t pair_swap(const uint32_t x)
-{
-    return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xF, 0xF, true);
-}
-__device__ __forceinline__ uint4 pair_swap(const uint4 v)
-{
-    return make_uint4(pair_swap(v.x), pair_swap(v.y), pair_swap(v.z), pair_swap(v.w));
 }
 
 // ------------------------------------------------------------------------------------------

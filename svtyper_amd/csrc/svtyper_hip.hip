@@ -11,24 +11,20 @@
 //   GT/GQ/SQ decision           svtyper/classic.py:446,473-495
 //
 // Design (DESIGN.md has the long form):
-//   * one (breakpoint, sample) unit per lane, 64 units per wave ("tile"): the five tallies
-//     are sequential binary64 sums in record order, exactly as CPython evaluates them, so the
-//     truncated integer counts are bit-exact.  No FMA contraction (-ffp-contract=off).
-//   * records are re-tiled once per batch into lane-interleaved tiles: row j of a tile holds
-//     the j-th 16 bytes of its 64 units back to back, so every wave-level load is one contiguous
-//     1 KiB global_load_dwordx4.  Units are sorted by length inside 16384-unit chunks so that the
-//     zero-padding of a tile stays small.  Three device layouts:
-//       - compact (default): a unit's evidence becomes three sparse streams of small entries --
-//         pair entries (straddle bits, both MAPQs, ospan_len translated into the histogram's index
-//         space; 4 bytes), reference-read and split / clip candidate entries (one gated MAPQ pair,
-//         2 bytes); entries that could only add +0.0 are dropped, which the reference's sums cannot
-//         observe (svt_entry_formats.h has the formats);
-//       - short (what a one-library batch of <= 2047 bins gets): the same with 2-byte pair entries
-//         for the batch's most common MAPQ pair;
-//       - dense (SVT_FLAG_DENSE_LAYOUT): the canonical 16-byte records as they are.
-//   * all look-up tables (prob_mapq, insert-size histogram + p_concordant thresholds, log10,
-//     paired-end decision weights) are built on the host with the same libm CPython uses and
-//     staged in LDS per workgroup.
+//   * one (breakpoint, sample) unit per lane: the five tallies are sequential binary64 sums in record order,
+//     exactly as CPython evaluates them, so the truncated integer counts are bit-exact.  No FMA contraction
+//     (-ffp-contract=off).
+//   * nothing is re-tiled or re-encoded on the way: the caller's CSR (rec_offset / unit headers / 16-byte records)
+//     goes to HBM as it is and ONE kernel takes it to the result records (svt_stream_kernel.h).  A workgroup of 256
+//     consecutive units sorts them by length, every wave streams its 64 units' records through an LDS ring filled
+//     by LDS-DMA (one whole 128-byte line per unit and step, svt_ring_engine.h), the lanes consume them in order.
+//   * a producer behind PCIe can hand over packed evidence instead (svt_pack_evidence: three sparse streams of
+//     2/4-byte entries per unit, ~3 bytes per record; svt_entry_formats.h has the formats, svt_packed_kernel.h the
+//     pass): entries that could only add +0.0 are dropped, which the reference's sums cannot observe.
+//   * all look-up tables (prob_mapq, insert-size histogram + p_concordant thresholds as 16-bit ranks, log10,
+//     paired-end decision weights) are built on the host with the same libm CPython uses and staged in LDS per
+//     workgroup; several libraries: per-sample library windows (svt_unit.libs), else tables through L2.
+//   * the one-shot entry points overlap upload, pass and download by unit ranges on three streams (run_pipelined).
 //   * HBM-bound byte/integer/fp64 streaming: no MFMA anywhere (nothing here is a contraction).
 //
 // There is no CPU fallback in this file.
