@@ -148,6 +148,8 @@ def time_passes(dbatch, steps: int) -> float:
 
 def main():
     json_out = claim_stdout()
+    # the host driver only supports dmabuf IPC: RCCL across processes fails without this (already exported on the GPU boxes)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)

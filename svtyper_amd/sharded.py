@@ -235,6 +235,7 @@ def init(local_rank: int, backend: Optional[str] = None):
     if backend is None:
         backend = "nccl" if local_world <= n_dev and torch.cuda.is_available() else "gloo"
     if backend == "nccl":
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on these hosts; RCCL needs it
         torch.cuda.set_device(device)
     if not dist.is_initialized():
         dist.init_process_group(backend)
