@@ -31,7 +31,8 @@
 #define SVT_STREAM_AUX 2   // cache policy bits of the record fetches (2 = nt: every line is used once)
 #endif
 #ifndef SVT_STREAM_PROBE
-#define SVT_STREAM_PROBE 0 // timing-only builds (wrong results): 1 = fetch without the record arithmetic, 2 = arithmetic without fetches, 3 = no epilogue
+#define SVT_STREAM_PROBE 0 // timing-only builds (wrong results): 1 = fetch without the record arithmetic, 2 = arithmetic without fetches, 3 = no epilogue,
+                           // 4 = library windows: every record reads descriptor 0, 5 = every window through the one-library consumer
 #endif
 #ifndef SVT_STREAM_SPLIT
 #define SVT_STREAM_SPLIT 4 // scheduling barrier before this record of a block (8 = none)
