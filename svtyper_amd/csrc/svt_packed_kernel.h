@@ -49,7 +49,8 @@ __global__ __launch_bounds__(kBlock, 3) void svt_packed_kernel(const PackedArgs 
     // x the common pair's weight | thr[total_bins], hist[total_bins] | log10 | rings.  Entries address it by absolute offsets.
     if ((uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)smem != 0u) __builtin_trap();
     unsigned char* rings = smem + a.lds_rings;
-    const uint32_t tid = threadIdx.x, wave = tid / kWave, lane = tid % kWave;
+    const uint32_t tid = threadIdx.x, lane = tid % kWave;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid / kWave));   // wave-uniform: ring addresses stay in SGPRs
     const uint64_t wg_base = (uint64_t)a.unit_begin + (uint64_t)blockIdx.x * kUnitsPerWg;
 
     uint32_t beg[R], cnt[R];
@@ -113,11 +114,12 @@ __global__ __launch_bounds__(kBlock, 3) void svt_packed_kernel(const PackedArgs 
         const uint32_t nblk = n_slots ? (last + 7u) >> 3 : 0u;
         uint32_t max_blk, min_blk;
         tile_block_range(nblk, max_blk, min_blk);
-        uint32_t src_first[8], src_end[8];
+        uint32_t src_first[8], src_end[8], src_base[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             src_first[i] = (uint32_t)__shfl((int)first, 8 * i + (int)o, kWave);
             src_end[i] = src_first[i] + (uint32_t)__shfl((int)n_slots, 8 * i + (int)o, kWave);
+            src_base[i] = (src_first[i] & ~7u) + (((i & 1) ? col_odd : col_even) >> 4);
         }
 
         LaneCtx c{};
@@ -132,12 +134,12 @@ __global__ __launch_bounds__(kBlock, 3) void svt_packed_kernel(const PackedArgs 
         Acc acc = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
 
         if (max_blk) {
-            fetch_block<SVT_STREAM_AUX>(0, src_first, src_end, col_even, col_odd, slot_bytes, ring);
+            fetch_block<SVT_STREAM_AUX, true>(0, src_base, src_first, src_end, slot_bytes, ring);
             u32x4 w[8];
 #pragma unroll 1
             for (uint32_t k = 0; k < max_blk; ++k) {
                 read_block(lane_block, sw16, w);
-                if (k + 1 < max_blk) fetch_block<SVT_STREAM_AUX>(k + 1, src_first, src_end, col_even, col_odd, slot_bytes, ring);
+                if (k + 1 < max_blk) fetch_block<SVT_STREAM_AUX, false>(k + 1, src_base, src_first, src_end, slot_bytes, ring);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const uint32_t idx = k * kBlockRecords + (uint32_t)j;

@@ -75,15 +75,17 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, const uint32
 // Block k of every unit of the tile -> ring.  Lane (o, rr) of instruction i serves unit 8 i + o and only asks for
 // a record of that unit: the neighbours' records in a unit's first and last line, and every block past the end
 // of a shorter unit, are not requested at all (the consumer never looks at those slots).
-template <int AUX>
-__device__ __forceinline__ void fetch_block(const uint32_t k, const uint32_t (&src_first)[8], const uint32_t (&src_end)[8],
-                                            const uint32_t col_even, const uint32_t col_odd, const char* __restrict__ rec_bytes,
-                                            unsigned char* ring)
+//   src_base[i] = the item this lane would fetch from block 0 of its unit: (first item & ~7) + its column
+//   FIRST: k == 0 -- only a unit's first block can hold items in front of the unit, so only that one needs the
+//   lower bound (and src_first[] need not stay in registers over the block loop)
+template <int AUX, bool FIRST>
+__device__ __forceinline__ void fetch_block(const uint32_t k, const uint32_t (&src_base)[8], const uint32_t (&src_first)[8],
+                                            const uint32_t (&src_end)[8], const char* __restrict__ rec_bytes, unsigned char* ring)
 {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        const uint32_t rec = (src_first[i] & ~7u) + k * kBlockRecords + (((i & 1) ? col_odd : col_even) >> 4);
-        if (rec >= src_first[i] && rec < src_end[i])
+        const uint32_t rec = src_base[i] + (FIRST ? 0u : k * kBlockRecords);
+        if ((!FIRST || rec >= src_first[i]) && rec < src_end[i])
             __builtin_amdgcn_global_load_lds(rec_bytes + ((uint64_t)rec << 4), (lds_void_ptr)(ring + (uint32_t)i * 1024u), 16, 0, AUX);
     }
 }

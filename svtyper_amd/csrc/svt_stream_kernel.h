@@ -247,7 +247,8 @@ __global__ __launch_bounds__(kBlock, MODE == kSingleLds ? SVT_STREAM_WAVES : MOD
     // the one-library consumer addresses the tables by absolute LDS byte offsets
     if (MODE != kGeneral && (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)smem != 0u) __builtin_trap();
     unsigned char* rings = smem + a.lds_rings;
-    const uint32_t tid = threadIdx.x, wave = tid / kWave, lane = tid % kWave;
+    const uint32_t tid = threadIdx.x, lane = tid % kWave;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid / kWave));   // wave-uniform: ring addresses stay in SGPRs
     // this workgroup's units: 256 * R consecutive ones, or (library windows) a chunk of the permutation that groups
     // the units by the libraries of their sample
     uint32_t wg_base = a.unit_begin + blockIdx.x * kUnitsPerWg, n_here;
@@ -370,21 +371,25 @@ __global__ __launch_bounds__(kBlock, MODE == kSingleLds ? SVT_STREAM_WAVES : MOD
         uint32_t max_blk, min_blk;
         tile_block_range(nblk, max_blk, min_blk);
         // fetch side: lane (o, rr) of instruction i serves unit 8 i + o -- it needs that unit's record range
-        uint32_t src_first[8], src_end[8];
+        uint32_t src_first[8], src_end[8], src_base[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             src_first[i] = (uint32_t)__shfl((int)first_rec, 8 * i + (int)o, kWave);
             src_end[i] = src_first[i] + (uint32_t)__shfl((int)n_rec, 8 * i + (int)o, kWave);
+            src_base[i] = (src_first[i] & ~7u) + (((i & 1) ? col_odd : col_even) >> 4);
         }
 
         // interior blocks are read once and never again (non-temporal); a unit's first and last line are shared
         // with its neighbours in the CSR, which another wave fetches at another time: they can be given another
         // policy (SVT_STREAM_EDGE_AUX) so that the second request may be served by L2 / Infinity Cache
-        auto fetch = [&](const uint32_t k) {
-            if (SVT_STREAM_EDGE_AUX != SVT_STREAM_AUX && (k == 0 || k + 1 >= min_blk))
-                fetch_block<SVT_STREAM_EDGE_AUX>(k, src_first, src_end, col_even, col_odd, rec_bytes, ring);
+        auto fetch_first = [&]() {
+            fetch_block<SVT_STREAM_EDGE_AUX, true>(0, src_base, src_first, src_end, rec_bytes, ring);
+        };
+        auto fetch = [&](const uint32_t k) {   // k >= 1
+            if (SVT_STREAM_EDGE_AUX != SVT_STREAM_AUX && k + 1 >= min_blk)
+                fetch_block<SVT_STREAM_EDGE_AUX, false>(k, src_base, src_first, src_end, rec_bytes, ring);
             else
-                fetch_block<SVT_STREAM_AUX>(k, src_first, src_end, col_even, col_odd, rec_bytes, ring);
+                fetch_block<SVT_STREAM_AUX, false>(k, src_base, src_first, src_end, rec_bytes, ring);
         };
 
         LaneCtx c{};   // kGeneral
@@ -451,7 +456,7 @@ __global__ __launch_bounds__(kBlock, MODE == kSingleLds ? SVT_STREAM_WAVES : MOD
         };
 
         if (max_blk) {
-            fetch(0);
+            fetch_first();
             u32x4 w[8];
 #pragma unroll 1
             for (uint32_t k = 0; k < max_blk; ++k) {
@@ -489,15 +494,19 @@ __global__ __launch_bounds__(kBlock, MODE == kSingleLds ? SVT_STREAM_WAVES : MOD
         }
         uint4 piece[8];
         if (SVT_STREAM_PROBE == 3) {   // timing only: the records leave without the likelihood / decision arithmetic
+            // (every tally stays live, or the compiler would drop its part of the record arithmetic as well)
 #pragma unroll
-            for (int p = 0; p < 8; ++p) piece[p] = pack2d(acc.ref_seq + p, acc.alt_span);
+            for (int p = 0; p < 8; ++p) piece[p] = pack2d(0.0, 0.0);
+            piece[0] = pack2d(acc.ref_seq, acc.alt_seq);
+            piece[1] = pack2d(acc.alt_clip, acc.ref_span);
+            piece[2] = pack2d(acc.alt_span, (double)U.svtype);
         } else
         unit_epilogue(acc, (uint32_t)U.svtype, (uint32_t)U.flags, a.c, lds_l10, a.l10, a.l10_where != kL10Global, piece);
 
         store_results_through_ring(ring, piece, unit, lane, a.out);
     }
     const uint32_t bad = check.bits(MODE == kMultiLds ? wd.lib_cnt : a.n_libs);
-    if (bad) atomicOr(a.err, bad);
+    if (bad && SVT_STREAM_PROBE != 2) atomicOr(a.err, bad);   // (probe 2 consumes whatever the ring holds)
 }
 
 }  // namespace svt
