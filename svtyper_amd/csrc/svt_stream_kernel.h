@@ -158,7 +158,10 @@ struct StreamCtx {
 // table: halving a binary64 in [0.2, 1] is exact, so the sum rounds identically.  EDGE: the record may belong
 // to a neighbouring unit -- its weight bytes are then read as MAPQ 0, which adds +0.0 to every sum.
 // the split-read / reference-read part of a record (classic.py:306-328); returns pm(mapq_a) * pm(mapq_b)
-template <bool SSO, bool EDGE>
+// CONT = false (sso only): no lane's record of this block continues a fragment, so every record starts one: the
+// previous fragment's sums go to the site totals and the new ones start from 0.0 + x == x (x >= +0.0) -- the same
+// values as the general form below without its selects.
+template <bool SSO, bool EDGE, bool CONT = true>
 __device__ __forceinline__ double record_weights(const u32x4 w, const bool mine, Acc& a)
 {
     const uint32_t wy = EDGE ? (mine ? w.y : 0u) : w.y;   // mapq_a | mapq_b << 8 | rs_a << 16 | rs_b << 24
@@ -167,7 +170,14 @@ __device__ __forceinline__ double record_weights(const u32x4 w, const bool mine,
     const double rs_a = lds_f64(kSPm + byte2_x8(wy)), rs_b = lds_f64(kSPm + byte3_x8(wy));
     const double p_seq = lds_f64(kSPmHalf + byte0_x8(wz)) + lds_f64(kSPmHalf + byte1_x8(wz));
     const double p_clip = lds_f64(kSPmHalf + byte2_x8(wz)) + lds_f64(kSPmHalf + byte3_x8(wz));
-    if (SSO) {   // singlesample.py:246-276,367-372: per-fragment sums, added to the site totals when the next fragment starts
+    if (SSO && !CONT) {
+        a.ref_seq += a.l_ref_seq;
+        a.alt_seq += a.l_alt_seq;
+        a.alt_clip += a.l_alt_clip;
+        a.l_ref_seq = rs_a + rs_b;
+        a.l_alt_seq = p_seq;
+        a.l_alt_clip = p_clip;
+    } else if (SSO) {   // singlesample.py:246-276,367-372: per-fragment sums, added to the site totals when the next fragment starts
         const bool cont = (w.w & SVT_REC_CONTINUATION) != 0u;
         a.ref_seq += cont ? 0.0 : a.l_ref_seq;
         a.alt_seq += cont ? 0.0 : a.l_alt_seq;
@@ -183,10 +193,10 @@ __device__ __forceinline__ double record_weights(const u32x4 w, const bool mine,
     return pm_a * pm_b;
 }
 
-template <bool SSO, bool EDGE>
+template <bool SSO, bool EDGE, bool CONT>
 __device__ __forceinline__ void record_single(const u32x4 w, const bool mine, const StreamCtx& c, Acc& a)
 {
-    const double pp = record_weights<SSO, EDGE>(w, mine, a);
+    const double pp = record_weights<SSO, EDGE, CONT>(w, mine, a);
     // p_concordant as the integer test hist[o - v] <= thr[o] (svt_host_tables.h), out-of-range -> sentinel bin
     const uint32_t i1 = min(w.x - c.kmin, c.nb), i2 = min(w.x - c.sub2, c.nb);
     const int32_t thr1 = lds_i16(kSBins + (i1 << 1));
@@ -212,10 +222,10 @@ typedef __attribute__((address_space(3))) const u32x4 lds_cu32x4;
 
 // The same record with several libraries: the record's library picks one of the window's descriptors (a
 // record that names a library outside its unit's window is reported by RecordCheck and reads the nearest one).
-template <bool SSO, bool EDGE, class CHECK>
+template <bool SSO, bool EDGE, bool CONT, class CHECK>
 __device__ __forceinline__ void record_window(const u32x4 w, const bool mine, const WindowCtx& c, Acc& a, CHECK& check)
 {
-    const double pp = record_weights<SSO, EDGE>(w, mine, a);
+    const double pp = record_weights<SSO, EDGE, CONT>(w, mine, a);
     check.window_lib(EDGE && !mine ? 0u : SVT_REC_LIB(w.w) - c.lib_lo);
 #if SVT_STREAM_PROBE == 4   // timing only: every record reads descriptor 0
     const uint32_t la = c.winlibs_at + (min(SVT_REC_LIB(w.w) - c.lib_lo, c.lib_last) >> 8) * (uint32_t)sizeof(WinLib);
@@ -430,8 +440,9 @@ __global__ __launch_bounds__(kBlock, MODE == kSingleLds ? SVT_STREAM_WAVES : MOD
         Acc acc = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
 
         // EDGE = false: every lane's eight records of this block are its own
-        auto consume = [&](const u32x4 (&w)[8], const uint32_t k, auto edge, auto window_kind) {
+        auto consume = [&](const u32x4 (&w)[8], const uint32_t k, auto edge, auto window_kind, auto continuations) {
             constexpr bool EDGE = decltype(edge)::value;
+            constexpr bool CONT = decltype(continuations)::value;   // sso: some record of the block may continue a fragment
             constexpr int KIND = decltype(window_kind)::value;   // kMultiLds: 1 = the window holds one library, 0 = several
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -442,10 +453,10 @@ __global__ __launch_bounds__(kBlock, MODE == kSingleLds ? SVT_STREAM_WAVES : MOD
                 const bool mine = !EDGE || (idx >= head && idx < last);
                 if (mine) check.see(w[j], lib_key);     // (slots that are not this lane's were not fetched)
                 if (MODE == kSingleLds) {
-                    record_single<SSO, EDGE>(w[j], mine, sc, acc);
+                    record_single<SSO, EDGE, CONT>(w[j], mine, sc, acc);
                 } else if (MODE == kMultiLds) {
-                    if (KIND == 1) record_single<SSO, EDGE>(w[j], mine, sc, acc);
-                    else record_window<SSO, EDGE>(w[j], mine, wc, acc, check);
+                    if (KIND == 1) record_single<SSO, EDGE, CONT>(w[j], mine, sc, acc);
+                    else record_window<SSO, EDGE, CONT>(w[j], mine, wc, acc, check);
                 } else {
                     const uint32_t wy = mine ? w[j].y : 0u, wz = mine ? w[j].z : 0u;   // MAPQ 0 everywhere: adds +0.0
                     weight_evidence<SSO>(wy >> 16 | (wz << 16), wz >> 16, (w[j].w & SVT_REC_CONTINUATION) != 0, t, acc);
@@ -468,13 +479,23 @@ __global__ __launch_bounds__(kBlock, MODE == kSingleLds ? SVT_STREAM_WAVES : MOD
                     for (int j = 0; j < 8; ++j) acc.ref_seq += (double)(w[j].x ^ w[j].y ^ w[j].z ^ w[j].w);
                 } else {
                     const bool edge = __any(k8 < head || k8 + kBlockRecords > last);
+                    // sso: a block in which no lane holds a continuation record (nearly all of them: a fragment
+                    // with a second split candidate is rare) takes the select-free form of the fragment-local sums.
+                    // Slots that were not fetched hold older records: at worst they send the block the general way.
+                    bool has_cont = false;
+                    if (SSO && MODE != kGeneral)
+                        has_cont = __any(((w[0].w | w[1].w | w[2].w | w[3].w | w[4].w | w[5].w | w[6].w | w[7].w) & SVT_REC_CONTINUATION) != 0u);
                     using kind_any = std::integral_constant<int, 0>;
                     using kind_one = std::integral_constant<int, 1>;
+                    auto run = [&](auto edge_tag, auto kind_tag) {
+                        if (!SSO || MODE == kGeneral || has_cont) consume(w, k, edge_tag, kind_tag, std::true_type{});
+                        else consume(w, k, edge_tag, kind_tag, std::false_type{});
+                    };
                     if (MODE == kMultiLds && (wd.lib_cnt == 1u || SVT_STREAM_PROBE == 5)) {       // (workgroup-uniform; probe 5: timing only)
-                        if (edge) consume(w, k, std::true_type{}, kind_one{});
-                        else consume(w, k, std::false_type{}, kind_one{});
-                    } else if (edge) consume(w, k, std::true_type{}, kind_any{});
-                    else consume(w, k, std::false_type{}, kind_any{});
+                        if (edge) run(std::true_type{}, kind_one{});
+                        else run(std::false_type{}, kind_one{});
+                    } else if (edge) run(std::true_type{}, kind_any{});
+                    else run(std::false_type{}, kind_any{});
                 }
             }
         }

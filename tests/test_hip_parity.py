@@ -114,6 +114,21 @@ def test_integral_nondel_var_length(hip_device):
     assert_parity(got, want)
 
 
+def test_sso_rare_continuations(hip_device, fixture_library):
+    """singlesample association: a block of records without any continuation record takes the select-free form of
+    the fragment-local sums, a block with one the general form -- here both kinds alternate inside every unit."""
+    batch = synth.make_units(6000, 23, [fixture_library], svtype_mix=(0.5, 0.2, 0.2, 0.1), mean_frags=90, sd_frags=40, min_frags=0)
+    rng = np.random.default_rng(23)
+    for rate in (0.002, 0.05):
+        b = synth.permute_units(batch, np.arange(batch.n_units))
+        cont = rng.random(b.n_records) < rate
+        b.records["flags"][cont] |= np.uint32(ev.REC_CONTINUATION)
+        assert cont.any() and not cont.all()
+        for flags in ALL_FLAGS:
+            got, want = run_both(b, flags)
+            assert_parity(got, want)
+
+
 def test_weights(hip_device, fixture_library):
     batch = synth.make_units(4000, 17, [fixture_library], svtype_mix=(0.6, 0.2, 0.1, 0.1),
                              split_weight=0.7, disc_weight=1.9)
