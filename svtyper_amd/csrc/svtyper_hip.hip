@@ -162,16 +162,44 @@ int upload(DevScratch& d, const std::vector<T>& v, Stager& st)
 }
 
 template <bool SSO>
-const void* stream_kernel_for(int mode)
+const void* stream_kernel_for(int mode, int tiles)
 {
+    if (mode == kSingleLds && tiles == 2) return reinterpret_cast<const void*>(&svt_stream_kernel<SSO, kSingleLds, 2>);
     return mode == kSingleLds  ? reinterpret_cast<const void*>(&svt_stream_kernel<SSO, kSingleLds, SVT_STREAM_R>)
            : mode == kMultiLds ? reinterpret_cast<const void*>(&svt_stream_kernel<SSO, kMultiLds, SVT_STREAM_R>)
                                : reinterpret_cast<const void*>(&svt_stream_kernel<SSO, kGeneral, SVT_STREAM_R>);
 }
 
-const void* stream_kernel_of(const svt_batch* b)
+const void* stream_kernel_of(const svt_batch* b, int tiles = SVT_STREAM_R)
 {
-    return (b->flags & SVT_FLAG_SSO_ASSOCIATION) ? stream_kernel_for<true>(b->mode) : stream_kernel_for<false>(b->mode);
+    return (b->flags & SVT_FLAG_SSO_ASSOCIATION) ? stream_kernel_for<true>(b->mode, tiles) : stream_kernel_for<false>(b->mode, tiles);
+}
+
+// 64-unit tiles per wave for a launch over `units` units.  One tile per wave leaves a third of a workgroup's
+// wave-time waiting for the wave that holds its longest units; two tiles in snake order even that out (DESIGN.md
+// 3.1) but make a workgroup run longer, which pays once the one-tile launch would need more than one round of
+// resident workgroups: measured -17 % at 250 k units, +-1 % at 500 k, -9 % at 1 M, -6 % at 2 M; +10 % at exactly
+// one round (196 608), no difference below.  One library only (the other modes are register-bound).
+constexpr uint64_t kTwoTilesMinUnits = 768ull * kBlock * 9 / 8;   // a little more than the chip's resident workgroups hold
+int tiles_per_wave(const svt_batch* b, uint64_t units)
+{
+#if SVT_STREAM_R == 1 && !defined(SVT_STREAM_ONE_TILE)
+    if (b->mode == kSingleLds && units >= kTwoTilesMinUnits) return 2;
+#endif
+    (void)b; (void)units;
+    return SVT_STREAM_R;
+}
+
+// one launch of the streaming kernel over units [a.unit_begin, a.unit_end) (not the library-window mode)
+int launch_stream(svt_batch* b, StreamArgs& a, hipStream_t stream)
+{
+    const uint64_t units = (uint64_t)a.unit_end - a.unit_begin;
+    const int tiles = tiles_per_wave(b, units);
+    const uint64_t per_wg = (uint64_t)kBlock * (uint64_t)tiles;
+    const dim3 grid((unsigned)((units + per_wg - 1) / per_wg)), block(kBlock);
+    void* params[] = {&a};
+    HIP_TRY(hipLaunchKernel(stream_kernel_of(b, tiles), grid, block, params, b->lds_bytes, stream));
+    return SVT_OK;
 }
 
 // units [u0, u1) of a streamed layout (stream: not the library-window mode, whose launch covers window chunks)
@@ -192,11 +220,7 @@ int launch_range(svt_batch* b, uint64_t u0, uint64_t u1, hipStream_t stream)
     StreamArgs a = b->sargs;
     a.unit_begin = (uint32_t)u0;
     a.unit_end = (uint32_t)u1;
-    constexpr uint64_t per_wg = (uint64_t)kBlock * SVT_STREAM_R;
-    const dim3 grid((unsigned)((u1 - u0 + per_wg - 1) / per_wg)), block(kBlock);
-    void* params[] = {&a};
-    HIP_TRY(hipLaunchKernel(stream_kernel_of(b), grid, block, params, b->lds_bytes, stream));
-    return SVT_OK;
+    return launch_stream(b, a, stream);
 }
 
 int launch_genotype(svt_batch* b)
@@ -211,8 +235,8 @@ int launch_genotype(svt_batch* b)
         return SVT_OK;
     }
     if (b->n_units == 0) return SVT_OK;
-    constexpr uint64_t per_wg = (uint64_t)kBlock * SVT_STREAM_R;
-    const dim3 grid(b->mode == kMultiLds ? b->n_chunks : (unsigned)((b->n_units + per_wg - 1) / per_wg)), block(kBlock);
+    if (b->mode != kMultiLds) return launch_stream(b, b->sargs, b->stream);
+    const dim3 grid(b->n_chunks), block(kBlock);   // library windows: one workgroup per chunk of a window's units
     void* params[] = {&b->sargs};
     HIP_TRY(hipLaunchKernel(stream_kernel_of(b), grid, block, params, b->lds_bytes, b->stream));
     return SVT_OK;
@@ -448,7 +472,8 @@ int create_stream(const svt_evidence_batch* in, svt_batch* b, void* d_records_re
     b->lds_bytes = tables + kWavesPerBlock * kRingBytes + SVT_PROBE_LDS_PAD;
     if (b->lds_bytes > 160 * 1024) return fail(SVT_ERR_INVALID, "LDS budget exceeded");
     if (b->lds_bytes > 64 * 1024)
-        HIP_TRY(hipFuncSetAttribute(stream_kernel_of(b), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_bytes));
+        for (int tiles = 1; tiles <= 2; ++tiles)
+            HIP_TRY(hipFuncSetAttribute(stream_kernel_of(b, tiles), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_bytes));
     return SVT_OK;
 }
 

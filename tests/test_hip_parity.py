@@ -114,6 +114,21 @@ def test_integral_nondel_var_length(hip_device):
     assert_parity(got, want)
 
 
+def test_two_tiles_per_wave(hip_device, fixture_library):
+    """From 221 184 units per launch on, a one-library pass gives every wave two 64-unit tiles in snake order
+    (a workgroup sorts 512 units): ragged lengths incl. empty units, a last workgroup that is not full, both associations."""
+    n = 221_184 + 512 * 3 + 77
+    batch = synth.make_units(n, 29, [fixture_library], svtype_mix=(0.5, 0.2, 0.2, 0.1), mean_frags=14, sd_frags=12,
+                             min_frags=0, max_frags=150, frac_empty=0.03, frac_skip=0.01)
+    for flags in ALL_FLAGS:
+        got, want = run_both(batch, flags)
+        assert_parity(got, want)
+    # the same units in launches too small for two tiles give the same bytes
+    from svtyper_amd import hip
+    lo = hip.genotype_batch(batch.slice(0, 100_000), device=hip_device)
+    assert np.array_equal(lo.rec, hip.genotype_batch(batch, device=hip_device).rec[:100_000])
+
+
 def test_sso_rare_continuations(hip_device, fixture_library):
     """singlesample association: a block of records without any continuation record takes the select-free form of
     the fragment-local sums, a block with one the general form -- here both kinds alternate inside every unit."""
