@@ -127,6 +127,13 @@ def test_two_tiles_per_wave(hip_device, fixture_library):
     from svtyper_amd import hip
     lo = hip.genotype_batch(batch.slice(0, 100_000), device=hip_device)
     assert np.array_equal(lo.rec, hip.genotype_batch(batch, device=hip_device).rec[:100_000])
+    # a wider histogram leaves no room for the log10 table beside the other tables: the epilogue of a wave's first
+    # tile then borrows the ring (LDS-DMA copy of the table) that its second tile streams through right after
+    broad = synth.normal_library(1500.0, 400.0, seed=9)
+    assert len(broad.hist) > 2500
+    wide = synth.make_units(n, 31, [broad], svtype_mix=(0.5, 0.2, 0.2, 0.1), mean_frags=14, sd_frags=12, min_frags=0, max_frags=150)
+    got, want = run_both(wide, 0)
+    assert_parity(got, want)
 
 
 def test_sso_rare_continuations(hip_device, fixture_library):
