@@ -20,7 +20,7 @@ while time.time() - t0 < budget:
     libs = [fixture if (k == 0 and rng.random() < 0.5) else
             synth.normal_library(float(rng.uniform(150, 900)), float(rng.uniform(15, 260)), n=int(rng.integers(3000, 60000)),
                                  seed=int(rng.integers(1 << 30))) for k in range(n_libs)]
-    kind = it % 5
+    kind = it % 5 if it % 11 else 5
     if kind == 0:
         b = P._fuzz_batch(5000 + it, libs, wide=bool(rng.integers(2)))
     elif kind == 1:
@@ -30,6 +30,12 @@ while time.time() - t0 < budget:
                              split_weight=float(rng.choice([1.0, 1.0, 0.5, 2.3])), disc_weight=float(rng.choice([1.0, 1.0, 0.25, 3.0])))
     elif kind == 2:
         b = synth.make_edge_cases(libs, seed=it)
+    elif kind == 5:  # one library, enough units for two tiles per wave (launches of >= 221 184 units), ragged lengths
+        libs = libs[:1]
+        n_libs = 1
+        b = synth.make_units(int(rng.integers(221_184, 300_000)), 3000 + it, libs, svtype_mix=tuple(rng.dirichlet([2, 1, 1, 1])),
+                             mean_frags=float(rng.uniform(2, 25)), sd_frags=float(rng.uniform(1, 20)), min_frags=0,
+                             max_frags=int(rng.integers(30, 260)), frac_empty=0.02, frac_skip=0.01)
     elif kind == 4:  # several samples with their own libraries: the streaming kernel's library windows (svt_unit.libs)
         b = synth.make_multisample(int(rng.integers(1, 400)), int(rng.choice([1, 2, 3, 8, 32, 40])), seed=it,
                                    mean_frags=float(rng.uniform(2, 80)), sd_frags=float(rng.uniform(1, 30)), min_frags=0,
