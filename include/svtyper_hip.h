@@ -133,6 +133,10 @@ typedef struct svt_unit {
                            on every unit of a several-library batch the pass stages
                            only a sample's histograms per workgroup;
                            a record outside its unit's window is a contract violation.
+                           Without hints a batch whose libraries all fit LDS together
+                           (a sample with a few read-group libraries) is treated as ONE
+                           window; a joint batch of many samples needs the hints to stay
+                           out of the slow general mode.
                            Upper 16 bits must be 0.                               */
 } svt_unit;
 #define SVT_UNIT_LIBS(first, count) ((uint32_t)(first) | (uint32_t)(count) << 8)

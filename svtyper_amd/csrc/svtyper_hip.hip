@@ -335,15 +335,24 @@ int create_stream(const svt_evidence_batch* in, svt_batch* b, void* d_records_re
     std::vector<uint2> chunks;
     std::vector<WgDesc> windows;
     uint32_t max_win_bins = 0, max_win_libs = 0;
-    bool windowed = in->n_libs > 1 && all_hinted && T.fast_geometry;
+    // Without hints (on every unit) the only window that is known to hold every record's library is the whole batch:
+    // a run with a handful of libraries (one sample with 2-3 read-group libraries) still fits LDS that way; a joint
+    // batch of many samples does not and needs the hints (else: general mode, tables through L2).
+    uint64_t all_bins = 0;
+    for (const LibDesc& L : T.libs) all_bins += L.n_bins + 1;
+    const bool whole_batch_window = !all_hinted && n > 0 && in->n_libs <= 255 &&
+                                    kSBins + all_bins * 4 + in->n_libs * sizeof(WinLib) + 64 + kWavesPerBlock * kRingBytes <= (160 * 1024 / 2);
+    const uint32_t whole_key = in->n_libs << 8;   // SVT_UNIT_LIBS(0, n_libs)
+    auto window_key = [&](uint64_t u) { return all_hinted ? in->units[u].libs & 0xffffu : whole_key; };
+    bool windowed = in->n_libs > 1 && (all_hinted || whole_batch_window) && T.fast_geometry;
     if (windowed) {
         std::vector<uint32_t> start(65537, 0u);
-        for (uint64_t u = 0; u < n; ++u) ++start[(in->units[u].libs & 0xffffu) + 1];
+        for (uint64_t u = 0; u < n; ++u) ++start[window_key(u) + 1];
         for (uint32_t k = 0; k < 65536u; ++k) start[k + 1] += start[k];
         perm.resize(n);
         {
             std::vector<uint32_t> at(start.begin(), start.end() - 1);
-            for (uint64_t u = 0; u < n; ++u) perm[at[in->units[u].libs & 0xffffu]++] = (uint32_t)u;   // stable: original order inside a group
+            for (uint64_t u = 0; u < n; ++u) perm[at[window_key(u)]++] = (uint32_t)u;   // stable: original order inside a group
         }
         for (uint32_t k = 0; k < 65536u; ++k) {
             if (start[k + 1] == start[k]) continue;

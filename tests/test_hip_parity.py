@@ -420,7 +420,7 @@ def test_histogram_windows_multi_library(hip_device, fixture_library):
     nb = len(other.hist)
     batch = _sweep_batch(other, [0, 5, nb - 1, nb, nb + 7, 50_000], 0, extra_libs=(fixture_library,))
     batch.records["flags"][1::2] |= np.uint32(1 << ev.REC_LIB_SHIFT)   # alternate the two libraries
-    assert _mode_of(batch) == 2                     # no svt_unit.libs hints: general mode
+    assert _mode_of(batch) == 1                     # no svt_unit.libs hints, but both libraries fit LDS: one window = the batch
     hinted = synth.permute_units(batch, np.arange(batch.n_units))
     hinted.units["libs"] = ev.unit_libs(0, 2)
     assert _mode_of(hinted) == 1                    # both libraries in every unit's window
@@ -440,7 +440,7 @@ def test_small_deletion_gate_per_library(hip_device, fixture_library):
     batch.units["var_length"] = batch.units["pos_delta"]
     hinted = synth.permute_units(batch, np.arange(batch.n_units))
     hinted.units["libs"] = ev.unit_libs(0, 2)
-    assert _mode_of(batch) == 2 and _mode_of(hinted) == 1
+    assert _mode_of(batch) == 1 and _mode_of(hinted) == 1
     for flags in ALL_FLAGS:
         got, want = run_both(batch, flags)
         assert_parity(got, want)
@@ -448,7 +448,7 @@ def test_small_deletion_gate_per_library(hip_device, fixture_library):
 
 
 def test_shapes_outside_the_fast_modes_stay_exact(hip_device, fixture_library):
-    """Batches the LDS modes / the packed format cannot express take the general mode, silently and exactly."""
+    """Batches the packed format / the one-library mode cannot express take another mode, silently and exactly."""
     # (a) a histogram wider than a packed pair entry's 12-bit code allows (one library: still tables in LDS)
     broad = synth.normal_library(3000.0, 900.0, seed=5)
     assert len(broad.hist) > 4095
@@ -467,7 +467,7 @@ def test_shapes_outside_the_fast_modes_stay_exact(hip_device, fixture_library):
     d.units["var_length"][::9] = -250
     from svtyper_amd import hip
     assert hip.PackedEvidence.try_pack(a) is None and hip.PackedEvidence.try_pack(d) is None
-    assert [_mode_of(x) for x in (a, b, c, d)] == [0, 2, 2, 0]
+    assert [_mode_of(x) for x in (a, b, c, d)] == [0, 1, 1, 0]     # (b, c: no hints, the batch's libraries as one window)
     for batch in (a, b, c, d):
         for flags in ALL_FLAGS:
             got, want = run_both(batch, flags)
