@@ -38,7 +38,7 @@
 #define SVT_STREAM_SPLIT 4 // scheduling barrier before this record of a block (8 = none)
 #endif
 #ifndef SVT_STREAM_EDGE_AUX
-#define SVT_STREAM_EDGE_AUX 2 // cache policy of the blocks that hold a unit's first / last line
+#define SVT_STREAM_EDGE_AUX 0 // cache policy of the blocks that hold a unit's first / last line (0 = default: the neighbour's request may hit L2)
 #endif
 #ifndef SVT_STREAM_UNROLL_TILES
 #define SVT_STREAM_UNROLL_TILES 1 // the R tiles of a wave as straight-line code (a loop lets LICM hoist the epilogue's ~40 constants into registers that then spill)
@@ -392,12 +392,15 @@ __global__ __launch_bounds__(kBlock, MODE == kSingleLds ? SVT_STREAM_WAVES : MOD
         // interior blocks are read once and never again (non-temporal); a unit's first and last line are shared
         // with its neighbours in the CSR, which another wave fetches at another time: they can be given another
         // policy (SVT_STREAM_EDGE_AUX) so that the second request may be served by L2 / Infinity Cache
+        // (measured: the second policy pays with two tiles per wave -- 512 neighbouring units per workgroup --, and
+        // costs 2 % with one)
+        constexpr int kEdgeAux = R >= 2 ? SVT_STREAM_EDGE_AUX : SVT_STREAM_AUX;
         auto fetch_first = [&]() {
-            fetch_block<SVT_STREAM_EDGE_AUX, true>(0, src_base, src_first, src_end, rec_bytes, ring);
+            fetch_block<kEdgeAux, true>(0, src_base, src_first, src_end, rec_bytes, ring);
         };
         auto fetch = [&](const uint32_t k) {   // k >= 1
-            if (SVT_STREAM_EDGE_AUX != SVT_STREAM_AUX && k + 1 >= min_blk)
-                fetch_block<SVT_STREAM_EDGE_AUX, false>(k, src_base, src_first, src_end, rec_bytes, ring);
+            if (kEdgeAux != SVT_STREAM_AUX && k + 1 >= min_blk)
+                fetch_block<kEdgeAux, false>(k, src_base, src_first, src_end, rec_bytes, ring);
             else
                 fetch_block<SVT_STREAM_AUX, false>(k, src_base, src_first, src_end, rec_bytes, ring);
         };
