@@ -709,6 +709,16 @@ def test_pipelined_one_shot_equals_the_resident_batch(hip_device, fixture_librar
         with hip.PackedEvidence(batch) as p:
             assert hip.genotype_packed(p, hip_device, flags).rec.tobytes() == want
             assert hip.genotype_packed(p, hip_device, flags, out=pinned).rec.tobytes() == want
+    # many short units: a 64 MB piece then holds more than 221 184 units and its launch takes two tiles per wave,
+    # starting at a unit range that does not begin at 0
+    tiny = synth.make_units(700_000, 93, [fixture_library], svtype_mix=(0.6, 0.2, 0.1, 0.1), mean_frags=8, sd_frags=4, min_frags=0,
+                            max_frags=40)
+    assert tiny.n_records * 16 > (64 << 20) and tiny.n_records * 16 / 700_000 * 221_184 < (64 << 20)
+    with hip.DeviceBatch(tiny, hip_device, 0) as d:
+        d.genotype(sync=True)
+        want = d.results().rec.tobytes()
+    assert hip.genotype_batch(tiny, hip_device, 0).rec.tobytes() == want
+    assert hip.genotype_batch(tiny, hip_device, 0, out=hip.pinned_results(tiny.n_units)).rec.tobytes() == want
     bad = synth.make_units(120_000, 91, [fixture_library], svtype_mix=(0.6, 0.2, 0.1, 0.1), mean_frags=60, sd_frags=30, min_frags=0)
     bad.records["flags"][bad.n_records - 3] |= 1 << 20
     with pytest.raises(hip.SvtyperHipError) as e:
