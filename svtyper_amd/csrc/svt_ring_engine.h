@@ -33,7 +33,7 @@ enum L10Place : uint32_t {
     kL10Global = 2    // read through L2 (units with thousands of records)
 };
 
-// error bits (shared with svt_scan_kernel)
+// error bits (also what svt_pack_evidence reports for the same violations)
 constexpr uint32_t kErrStraddleNoPair = 2u, kErrLibIndex = 4u, kErrReservedBits = 8u, kErrNegativeSpan = 16u;
 
 typedef __attribute__((address_space(3))) void* lds_void_ptr;

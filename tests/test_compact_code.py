@@ -1,8 +1,8 @@
-"""The algebra behind the compact pair entries (svtyper_amd/csrc/svt_prepare_kernels.h: pair_code; consumed by
-pair_entry in svt_genotype_kernel.h): one table code per entry from which the kernel gets BOTH histogram indices
+"""The algebra behind the pair entries of packed evidence (svtyper_amd/csrc/svt_entry_formats.h: pair_code; consumed by
+short_pair_dword in svt_unit_math.h): one table code per entry from which the kernel gets BOTH histogram indices
 by clamping.  Exhaustive over small geometries, against the direct definition of the two look-ups
 (svtyper/parsers.py:870-878).  Pure arithmetic -- the device code itself is covered by the gpu tests
-(tests/test_hip_parity.py::test_compact_code_windows)."""
+(tests/test_hip_parity.py::test_histogram_windows, tests/test_packed_evidence.py)."""
 import itertools
 
 M32 = (1 << 32) - 1
@@ -23,7 +23,7 @@ def pair_code(ospan_len, key_min, n_bins, is_del, var_length):
 
 
 def kernel_indices(code, n_bins, is_del, var_length):
-    """what pair_entry computes (in bins; the kernel works in bytes = bins * 8, unsigned 32-bit)"""
+    """what the consumer computes (in bins; the kernel works in byte offsets, unsigned 32-bit)"""
     off2 = min(var_length, n_bins) if is_del else 0x80000000 // 8
     i1 = min(code, n_bins)
     i2 = min((code - off2) & M32, n_bins)
