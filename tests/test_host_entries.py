@@ -1,0 +1,44 @@
+"""Host-only entry points of libsvtyper_hip.so (no device needed): svt_results_host_sq, svt_shard_bounds."""
+import math
+
+import numpy as np
+
+from svtyper_amd import evidence as ev
+
+
+def test_host_sq_is_the_reference_arithmetic():
+    """SQ = abs(-10 * (GL[0] - log10(sum(10 ** GL)))) with the host libm (classic.py:473-481), for called units only."""
+    from svtyper_amd import hip
+    rng = np.random.default_rng(5)
+    n = 4000
+    rec = np.zeros(n, ev.RESULT_DTYPE)
+    gl = -np.abs(rng.normal(0, 40, (n, 3)))
+    gl[rng.integers(0, n, n // 10), rng.integers(0, 3, n // 10)] = 0.0
+    gl[::97] = [-300.0, -305.5, -321.0]                      # deep in the subnormal band of 10 ** GL
+    rec["gl"] = gl
+    rec["gt"] = rng.choice([0, 1, 2, ev.GT_BLANK, ev.GT_SKIPPED, ev.GT_MISSING], n, p=[0.3, 0.3, 0.3, 0.04, 0.03, 0.03])
+    rec["sq"] = 12345.0                                      # must be overwritten for called units, kept otherwise
+    res = hip.host_sq(ev.Results(rec.copy()))
+    for k in range(n):
+        if rec["gt"][k] >= 0:
+            s = sum(10.0 ** float(x) for x in gl[k])
+            want = abs(-10.0 * (float(gl[k, 0]) - math.log(s) / math.log(10.0))) if s > 0.0 else None
+            if want is not None:
+                assert float(res.sq[k]).hex() == float(want).hex(), (k, gl[k])
+        else:
+            assert res.sq[k] == 12345.0
+
+
+def test_shard_bounds_balance_bytes_and_keep_groups_whole():
+    from svtyper_amd import hip
+    rng = np.random.default_rng(7)
+    counts = rng.integers(0, 400, 12_800)
+    off = np.concatenate([[0], np.cumsum(counts)]).astype(np.uint64)
+    for shards, group in ((1, 1), (3, 1), (8, 32), (5, 7)):
+        b = hip.shard_bounds(off, shards, group)
+        assert len(b) == shards and b[0][0] == 0 and b[-1][1] == len(counts)
+        assert all(lo <= hi for lo, hi in b) and all(b[i][1] == b[i + 1][0] for i in range(shards - 1))
+        assert all(lo % group == 0 for lo, _ in b)
+        cost = [int(16 * (off[hi] - off[lo]) + 112 * (hi - lo)) for lo, hi in b]
+        biggest_group = 16 * int(counts.max()) * group + 112 * group
+        assert max(cost) - min(cost) <= 2 * biggest_group or shards == 1
