@@ -1,3 +1,6 @@
+#!/usr/bin/env python
+"""Pass time of a 1 M-unit batch with three libraries and NO svt_unit.libs hints: the whole batch becomes one library
+window when its tables fit LDS (table mode 1), else the general mode (2).   python tools/multilib_nohints.py"""
 import sys, os
 sys.path.insert(0, os.getcwd())
 import numpy as np, bench

@@ -1,3 +1,6 @@
+#!/usr/bin/env python
+"""Stage times of the pipelined one-shot entry points (svt_genotype / svt_genotype_packed) on the headline workload;
+run with SVT_TRACE=1 for the library's own stage timer, SVT_PIPE_MB=<n> for another piece size."""
 import os, sys, time
 sys.path.insert(0, os.getcwd())
 import numpy as np, bench
