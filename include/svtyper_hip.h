@@ -304,7 +304,10 @@ int svt_batch_genotype_timed(svt_batch* b, int iters, float* ms_total);
 int svt_batch_results(svt_batch* b, svt_result* out, uint64_t n_units);
 
 /* Device pointer of the result records (svt_result[n_units]) the kernel currently
- * writes to, for a caller that keeps working on the GPU.                          */
+ * writes to, for a caller that keeps working on the GPU.  The record contract is checked by
+ * the pass and reported by the SYNCHRONISING entry points (svt_batch_genotype(b, 1),
+ * svt_batch_results, svt_batch_site_qual, svt_batch_genotype_timed): a consumer of the device
+ * records runs one of them -- svt_batch_genotype(b, 1) is enough -- before trusting them.     */
 int svt_batch_device_results(svt_batch* b, svt_result** dev_ptr);
 
 /* Make the kernel write its result records straight into a caller-owned DEVICE buffer of

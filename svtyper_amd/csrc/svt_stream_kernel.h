@@ -34,6 +34,9 @@
 #define SVT_STREAM_PROBE 0 // timing-only builds (wrong results): 1 = fetch without the record arithmetic, 2 = arithmetic without fetches, 3 = no epilogue,
                            // 4 = library windows: every record reads descriptor 0, 5 = every window through the one-library consumer
 #endif
+#ifndef SVT_PROBE_SKIP
+#define SVT_PROBE_SKIP 0   // timing only (wrong results), bits: 1 = no epilogue arithmetic, 2 = no result store, 4 = no table staging
+#endif
 #ifndef SVT_STREAM_SPLIT
 #define SVT_STREAM_SPLIT 4 // scheduling barrier before this record of a block (8 = none)
 #endif
@@ -289,6 +292,7 @@ __global__ __launch_bounds__(kBlock, MODE == kSingleLds ? SVT_STREAM_WAVES : MOD
     }
 
     // ---- stage the tables in LDS
+    if (!(SVT_PROBE_SKIP & 4))
     for (uint32_t i = tid; i < 256; i += kBlock) {
         const double p = a.pm[i];
         s_pm[i] = p;
@@ -303,7 +307,8 @@ __global__ __launch_bounds__(kBlock, MODE == kSingleLds ? SVT_STREAM_WAVES : MOD
             s_wtab[tid] = pw;
         }
     }
-    if (MODE == kSingleLds) {
+    if (SVT_PROBE_SKIP & 4) {
+    } else if (MODE == kSingleLds) {
         // thr[] and hist[] as two 2-byte arrays (svt_host_tables.h replaced the counts by their ranks, which is
         // all `hist[o - v] <= thr[o]` needs): the random look-ups of a wave spread over every LDS bank
         int16_t* s_thr = reinterpret_cast<int16_t*>(smem + kSBins);
@@ -337,7 +342,7 @@ __global__ __launch_bounds__(kBlock, MODE == kSingleLds ? SVT_STREAM_WAVES : MOD
         for (uint32_t i = tid; i < a.n_libs * (uint32_t)(sizeof(LibDesc) / 8); i += kBlock)
             reinterpret_cast<uint64_t*>(s_lib)[i] = reinterpret_cast<const uint64_t*>(a.libs)[i];
     }
-    if (a.l10_where == kL10Shared) {
+    if (a.l10_where == kL10Shared && !(SVT_PROBE_SKIP & 4)) {
         double* s_l10 = reinterpret_cast<double*>(smem + a.lds_l10);
         for (uint32_t i = tid; i < a.n_l10; i += kBlock) s_l10[i] = a.l10[i];
     }
@@ -517,7 +522,7 @@ __global__ __launch_bounds__(kBlock, MODE == kSingleLds ? SVT_STREAM_WAVES : MOD
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         uint4 piece[8];
-        if (SVT_STREAM_PROBE == 3) {   // timing only: the records leave without the likelihood / decision arithmetic
+        if (SVT_STREAM_PROBE == 3 || (SVT_PROBE_SKIP & 1)) {   // timing only: the records leave without the likelihood / decision arithmetic
             // (every tally stays live, or the compiler would drop its part of the record arithmetic as well)
 #pragma unroll
             for (int p = 0; p < 8; ++p) piece[p] = pack2d(0.0, 0.0);
@@ -527,7 +532,8 @@ __global__ __launch_bounds__(kBlock, MODE == kSingleLds ? SVT_STREAM_WAVES : MOD
         } else
         unit_epilogue(acc, (uint32_t)U.svtype, (uint32_t)U.flags, a.c, lds_l10, a.l10, a.l10_where != kL10Global, piece);
 
-        store_results_through_ring(ring, piece, unit, lane, a.out);
+        if (!(SVT_PROBE_SKIP & 2)) store_results_through_ring(ring, piece, unit, lane, a.out);
+        else if (piece[0].x == 0x12345u && piece[2].y == 77u) a.out[unit].sq = 1.0;
     }
     const uint32_t bad = check.bits(MODE == kMultiLds ? wd.lib_cnt : a.n_libs);
     if (bad && SVT_STREAM_PROBE != 2) atomicOr(a.err, bad);   // (probe 2 consumes whatever the ring holds)

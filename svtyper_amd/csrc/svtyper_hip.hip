@@ -1248,6 +1248,7 @@ static int svt_batch_site_qual_impl(svt_batch* b, uint32_t n_samples, const doub
     if (n_samples == 0 || n_sites * n_samples != b->n_units) return fail(SVT_ERR_INVALID, "n_sites * n_samples != n_units");
     if (n_sites == 0) return SVT_OK;
     HIP_TRY(hipSetDevice(b->device));
+    SVT_TRY(check_stream_errors(b));   // (after svt_batch_genotype(b, 0) / _n nobody has looked at the contract word yet)
     DevScratch d_init, d_qual;
     SVT_TRY(d_qual.alloc(n_sites * sizeof(double)));
     if (initial) {

@@ -223,22 +223,34 @@ class _PinnedBuffer:
 
 
 def pinned_results(n_units: int) -> Results:
-    """A Results whose records live in page-locked memory from the library's pool (svt_pinned_alloc)."""
+    """A Results whose records live in page-locked memory from the library's pool (svt_pinned_alloc).  The block is
+    owned by the ARRAY (its base keeps the buffer object alive), so a caller that keeps only `.rec` -- or a view of
+    it -- keeps the memory too; it returns to the pool when the last view is gone."""
     from .evidence import RESULT_DTYPE
-    buf = _PinnedBuffer(n_units * RESULT_DTYPE.itemsize)
-    arr = np.ctypeslib.as_array(C.cast(buf.ptr, C.POINTER(C.c_uint8)), shape=(buf.nbytes,))[: n_units * RESULT_DTYPE.itemsize]
+    nbytes = int(n_units) * RESULT_DTYPE.itemsize
+    buf = _PinnedBuffer(nbytes)
+    raw = (C.c_uint8 * buf.nbytes).from_address(buf.ptr)
+    raw._owner = buf           # ndarray.base -> this ctypes array -> the pooled block
+    arr = np.frombuffer(raw, dtype=np.uint8, count=nbytes)
     res = Results.__new__(Results)
     res.rec = arr.view(RESULT_DTYPE)
     res.site_qual = None
-    res._pinned = buf          # keeps the buffer alive as long as the Results
     return res
+
+
+def _check_out(out: Results, n_units: int) -> Results:
+    """The C side writes n_units * 128 bytes through out.ptr() (by DMA when the block is page-locked)."""
+    if out.n_units != int(n_units):
+        raise ValueError("out holds %d records, the batch has %d units" % (out.n_units, int(n_units)))
+    if not out.rec.flags["C_CONTIGUOUS"] or not out.rec.flags["WRITEABLE"]:
+        raise ValueError("out.rec must be a writable C-contiguous array of result records")
+    return out
 
 
 def genotype_packed(packed: PackedEvidence, device: int = 0, flags: int = 0, out: Optional[Results] = None) -> Results:
     """svt_genotype_packed: create_packed + one pass + results + destroy, upload / pass / download overlapped by unit
     ranges.  `out`: a Results to fill (pinned_results(n): the records then come down by DMA while later pieces go up)."""
-    if out is None:
-        out = Results.empty(packed.n_units)
+    out = Results.empty(packed.n_units) if out is None else _check_out(out, packed.n_units)
     _check(load().svt_genotype_packed(packed._p, C.c_void_p(out.ptr()), int(device), int(flags)))
     return out
 
@@ -303,10 +315,7 @@ class DeviceBatch:
     def results(self, out: Optional[Results] = None) -> Results:
         """The result records of the last pass.  `out`: a Results to fill instead of a fresh one -- pinned_results(n)
         gives one in page-locked memory, which the records reach by straight DMA."""
-        if out is None:
-            out = Results.empty(self.n_units)
-        elif out.n_units != self.n_units:
-            raise ValueError("out must hold n_units records")
+        out = Results.empty(self.n_units) if out is None else _check_out(out, self.n_units)
         _check(self._lib.svt_batch_results(self._h, C.c_void_p(out.ptr()), self.n_units))
         return out
 
@@ -407,13 +416,15 @@ def genotype_fragments(fbatch, device: int = 0, flags: int = 0, site_qual=None) 
 
 def genotype_batch(batch: EvidenceBatch, device: int = 0, flags: int = 0, site_qual=None, out: Optional[Results] = None) -> Results:
     """create + genotype + results + destroy (svt_genotype: upload, pass and download overlapped by unit ranges).
-    `out`: a Results to fill instead of a fresh one (pinned_results(n) for a page-locked one)."""
+    `out`: a Results to fill instead of a fresh one (pinned_results(n) for a page-locked one); not accepted together
+    with `site_qual` (that route refines SQ on a fresh host copy)."""
     if site_qual is not None:
+        if out is not None:
+            raise ValueError("out= cannot be combined with site_qual=")
         with DeviceBatch(batch, device, flags) as d:
             return _finish(d, site_qual)
     L = load()
-    if out is None:
-        out = Results.empty(batch.n_units)
+    out = Results.empty(batch.n_units) if out is None else _check_out(out, batch.n_units)
     cb = batch.as_c()
     _check(L.svt_genotype(C.byref(cb), C.c_void_p(out.ptr()), int(device), int(flags)))
     return out
