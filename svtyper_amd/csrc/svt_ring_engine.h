@@ -90,6 +90,41 @@ __device__ __forceinline__ void fetch_block(const uint32_t k, const uint32_t (&s
     }
 }
 
+// Block k of every unit of the tile when k is an interior block of ALL of them (1 <= k, k + 1 < the tile's shortest
+// unit): every piece of every line belongs to its unit, so there is nothing to test -- eight address computations
+// and eight LDS-DMA instructions with the full wave.  Most steps of a length-sorted tile are of this kind.
+template <int AUX>
+__device__ __forceinline__ void fetch_block_interior(const uint32_t k, const uint32_t (&src_base)[8], const char* __restrict__ rec_bytes,
+                                                     unsigned char* ring)
+{
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const uint32_t rec = src_base[i] + k * kBlockRecords;
+        __builtin_amdgcn_global_load_lds(rec_bytes + ((uint64_t)rec << 4), (lds_void_ptr)(ring + (uint32_t)i * 1024u), 16, 0, AUX);
+    }
+}
+
+// The same for a step in which some unit of the tile reaches its last block: only the lanes whose block IS their unit's
+// last one -- the line the unit shares with its successor in the CSR, which another lane requests at another time --
+// take the cache policy EDGE_AUX (so that the second request can be served by L2); every other line of the step is
+// read once and leaves with AUX.  (With one policy for the whole step a third of all lines were allocated in L2,
+// which pushed the shared lines out again before their second request came.)
+template <int AUX, int EDGE_AUX>
+__device__ __forceinline__ void fetch_block_tail_exact(const uint32_t k, const uint32_t (&src_base)[8], const uint32_t (&src_end)[8],
+                                                       const char* __restrict__ rec_bytes, unsigned char* ring)
+{
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const uint32_t rec = src_base[i] + k * kBlockRecords;
+        if (rec < src_end[i]) {
+            if ((rec | 7u) + 1u >= src_end[i])
+                __builtin_amdgcn_global_load_lds(rec_bytes + ((uint64_t)rec << 4), (lds_void_ptr)(ring + (uint32_t)i * 1024u), 16, 0, EDGE_AUX);
+            else
+                __builtin_amdgcn_global_load_lds(rec_bytes + ((uint64_t)rec << 4), (lds_void_ptr)(ring + (uint32_t)i * 1024u), 16, 0, AUX);
+        }
+    }
+}
+
 // The workgroup's 256 * R units -> R tiles per wave, longest units first.  beg / cnt: first item and item count of
 // the thread's R units (local index j * 256 + tid; `n_here` of them exist).  info[r] = {first item, items, local index or kPadUnit, 0} of
 // this lane's unit in the wave's r-th tile.  The sort scratch lives in the rings: call before any streaming;

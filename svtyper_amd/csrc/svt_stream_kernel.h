@@ -37,11 +37,26 @@
 #ifndef SVT_PROBE_SKIP
 #define SVT_PROBE_SKIP 0   // timing only (wrong results), bits: 1 = no epilogue arithmetic, 2 = no result store, 4 = no table staging
 #endif
+#ifndef SVT_STREAM_ONE_TRIP
+#define SVT_STREAM_ONE_TRIP 0  // record_single: both decision-table candidates are read with the first look-ups (no dependent LDS read)
+#endif
+#ifndef SVT_STREAM_PIPELINED
+#define SVT_STREAM_PIPELINED 0 // one-library blocks: explicit two-stage look-up pipeline (look_issue / look_use); 0 = record_single
+#endif
 #ifndef SVT_STREAM_SPLIT
 #define SVT_STREAM_SPLIT 4 // scheduling barrier before this record of a block (8 = none)
 #endif
 #ifndef SVT_STREAM_EDGE_AUX
 #define SVT_STREAM_EDGE_AUX 0 // cache policy of the blocks that hold a unit's first / last line (0 = default: the neighbour's request may hit L2)
+#endif
+#ifndef SVT_FETCH_FAST_INTERIOR
+#define SVT_FETCH_FAST_INTERIOR 1 // steps in which every unit of the tile is inside its record range fetch without range tests
+#endif
+#ifndef SVT_FETCH_PRIO
+#define SVT_FETCH_PRIO 0 // wave priority while a block leaves the ring and the next fetch is issued (0 = unchanged)
+#endif
+#ifndef SVT_EDGE_EXACT
+#define SVT_EDGE_EXACT 1 // steps that hold some unit's last block: 1 = only those blocks take SVT_STREAM_EDGE_AUX, 0 = the whole step
 #endif
 #ifndef SVT_STREAM_UNROLL_TILES
 #define SVT_STREAM_UNROLL_TILES 1 // the R tiles of a wave as straight-line code (a loop lets LICM hoist the epilogue's ~40 constants into registers that then spill)
@@ -70,7 +85,9 @@ constexpr uint32_t kSPm = 0;                          // double[256]  prob_mapq(
 constexpr uint32_t kSPmHalf = kSPm + 256 * 8;         // double[256]  prob_mapq(q) / 2 (exact: a power-of-two scaling)
 constexpr uint32_t kSWtab = kSPmHalf + 256 * 8;       // kSingleLds: double w_alt[32], w_ref[32] (columns); kGeneral: PairWeights[32]
 constexpr uint32_t kSWref = 32 * 8;                   // byte distance w_alt[i] -> w_ref[i]
-constexpr uint32_t kSBins = kSWtab + 2 * 32 * 8;      // kSingleLds: int16 thr[total_bins], uint16 hist[total_bins] (ranks, svt_host_tables.h); kGeneral: LibDesc[n_libs]
+constexpr uint32_t kSWhi = kSWtab + 2 * 32 * 8;       // kSingleLds / kMultiLds: uint32 high words of w_alt[32], w_ref[32] (their low words are 0)
+constexpr uint32_t kSWhiRef = 32 * 4;                 // byte distance w_alt_hi[i] -> w_ref_hi[i]
+constexpr uint32_t kSBins = kSWhi + 2 * 32 * 4;       // kSingleLds: int16 thr[total_bins], uint16 hist[total_bins] (ranks, svt_host_tables.h); kGeneral: LibDesc[n_libs]
 
 struct StreamArgs {
     const uint4* records;        // canonical records; the allocation ends on a 128-byte block boundary, tail zeroed
@@ -153,6 +170,7 @@ struct StreamCtx {
     uint32_t sub2;     // DEL ? var_length + key_min : 0x80000000 (never in range)
     uint32_t hist_at;  // LDS address of hist[0]
     uint32_t wt0, wt1; // LDS address of w_alt[del16] / w_alt[del16 + 8] (p_concordant = 0 / 1)
+    uint32_t wh0;      // LDS address of w_alt_hi[del16]
 };
 
 // One canonical record, one library, tables at fixed LDS addresses: the arithmetic of weight_evidence +
@@ -199,6 +217,19 @@ __device__ __forceinline__ double record_weights(const u32x4 w, const bool mine,
 template <bool SSO, bool EDGE, bool CONT>
 __device__ __forceinline__ void record_single(const u32x4 w, const bool mine, const StreamCtx& c, Acc& a)
 {
+#if SVT_STREAM_ONE_TRIP
+    // the decision table is read for both values of p_concordant together with the other look-ups (high words only:
+    // the weights are 0, 0.5 or 1), so a record costs one LDS round trip instead of two dependent ones
+    const uint32_t wt = c.wh0 | ((w.w & c.fmask) << 2);   // &w_alt_hi[f3 | del16]
+    const uint32_t wa0 = lds_u32(wt), wa1 = lds_u32(wt + 8u * 4u), wr1 = lds_u32(wt + kSWhiRef + 8u * 4u);
+    const uint32_t i1 = min(w.x - c.kmin, c.nb), i2 = min(w.x - c.sub2, c.nb);
+    const int32_t thr1 = lds_i16(kSBins + (i1 << 1));
+    const uint32_t h2 = lds_u16(c.hist_at + (i2 << 1));
+    const double pp = record_weights<SSO, EDGE, CONT>(w, mine, a);
+    const bool p_conc = (int32_t)h2 <= thr1;
+    a.alt_span += pp * __hiloint2double((int)(p_conc ? wa1 : wa0), 0);
+    a.ref_span += pp * __hiloint2double((int)(p_conc ? wr1 : 0u), 0);
+#else
     const double pp = record_weights<SSO, EDGE, CONT>(w, mine, a);
     // p_concordant as the integer test hist[o - v] <= thr[o] (svt_host_tables.h), out-of-range -> sentinel bin
     const uint32_t i1 = min(w.x - c.kmin, c.nb), i2 = min(w.x - c.sub2, c.nb);
@@ -208,6 +239,95 @@ __device__ __forceinline__ void record_single(const u32x4 w, const bool mine, co
     const uint32_t wa = (p_conc ? c.wt1 : c.wt0) | ((w.w & c.fmask) << 3);   // &w_alt[f3 | p_conc << 3 | del16]
     a.alt_span += pp * lds_f64(wa);
     a.ref_span += pp * lds_f64(wa + kSWref);
+#endif
+}
+
+// ---- the same record arithmetic as a two-stage pipeline (one library; interior and edge blocks) --------------------
+// record_single leaves the order of the table look-ups to the compiler, which serialises every record into
+// "ten ds_reads, wait, compare, the dependent read of the decision table, wait, multiply": two exposed LDS round
+// trips per record, sixteen per block.  Here every look-up of a record is issued in ONE group -- the decision table
+// is read for both values of p_concordant (high words only: the weights are 0, 0.5 or 1, whose low words are 0) --
+// and the group of record j + 1 is issued before the arithmetic of record j, so that arithmetic covers its latency.
+// The ds_reads are inline assembly because only their textual order keeps them ahead of the previous record's VALU
+// work; the waits name the looked-up values as in-out operands, which orders every use behind them.  (At most one
+// group -- 13 LDS operations -- is outstanding at a wait; the LGKM counter holds 15.)
+struct Look {
+    double pm_a, pm_b, rs_a, rs_b, sq_l, sq_r, cl_l, cl_r;
+    int32_t thr;
+    uint32_t hist, wa0, wa1, wr1;
+};
+
+template <bool EDGE>
+__device__ __forceinline__ void look_issue(const u32x4 w, const bool mine, const StreamCtx& c, Look& L)
+{
+    const uint32_t wy = EDGE ? (mine ? w.y : 0u) : w.y;   // mapq_a | mapq_b << 8 | rs_a << 16 | rs_b << 24
+    const uint32_t wz = EDGE ? (mine ? w.z : 0u) : w.z;   // seq_l | seq_r << 8 | clip_l << 16 | clip_r << 24
+    const uint32_t a0 = byte0_x8(wy), a1 = byte1_x8(wy), a2 = byte2_x8(wy), a3 = byte3_x8(wy);
+    const uint32_t b0 = byte0_x8(wz), b1 = byte1_x8(wz), b2 = byte2_x8(wz), b3 = byte3_x8(wz);
+    const uint32_t i1 = min(w.x - c.kmin, c.nb) << 1;
+    const uint32_t i2 = c.hist_at + (min(w.x - c.sub2, c.nb) << 1);
+    const uint32_t wt = c.wh0 | ((w.w & c.fmask) << 2);   // &w_alt_hi[f3 | del16]
+    asm volatile("ds_read_b64 %0, %8\n\t"
+                 "ds_read_b64 %1, %9\n\t"
+                 "ds_read_b64 %2, %10\n\t"
+                 "ds_read_b64 %3, %11\n\t"
+                 "ds_read_b64 %4, %12 offset:%16\n\t"
+                 "ds_read_b64 %5, %13 offset:%16\n\t"
+                 "ds_read_b64 %6, %14 offset:%16\n\t"
+                 "ds_read_b64 %7, %15 offset:%16"
+                 : "=&v"(L.pm_a), "=&v"(L.pm_b), "=&v"(L.rs_a), "=&v"(L.rs_b), "=&v"(L.sq_l), "=&v"(L.sq_r), "=&v"(L.cl_l), "=&v"(L.cl_r)
+                 : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(b0), "v"(b1), "v"(b2), "v"(b3), "n"(kSPmHalf)
+                 : "memory");
+    asm volatile("ds_read_i16 %0, %5 offset:%8\n\t"
+                 "ds_read_u16 %1, %6\n\t"
+                 "ds_read_b32 %2, %7\n\t"
+                 "ds_read_b32 %3, %7 offset:%9\n\t"
+                 "ds_read_b32 %4, %7 offset:%10"
+                 : "=&v"(L.thr), "=&v"(L.hist), "=&v"(L.wa0), "=&v"(L.wa1), "=&v"(L.wr1)
+                 : "v"(i1), "v"(i2), "v"(wt), "n"(kSBins), "n"(8 * 4), "n"(kSWhiRef + 8 * 4)
+                 : "memory");
+}
+
+__device__ __forceinline__ void look_wait(Look& L)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(L.pm_a), "+v"(L.pm_b), "+v"(L.rs_a), "+v"(L.rs_b), "+v"(L.sq_l), "+v"(L.sq_r), "+v"(L.cl_l), "+v"(L.cl_r),
+                   "+v"(L.thr), "+v"(L.hist), "+v"(L.wa0), "+v"(L.wa1), "+v"(L.wr1)
+                 :
+                 : "memory");
+}
+
+// the arithmetic of one record on its looked-up values: record_weights + the paired-end part of record_single
+template <bool SSO, bool CONT>
+__device__ __forceinline__ void look_use(const Look& L, const u32x4 w, Acc& a)
+{
+    const double p_seq = L.sq_l + L.sq_r, p_clip = L.cl_l + L.cl_r;
+    if (SSO && !CONT) {
+        a.ref_seq += a.l_ref_seq;
+        a.alt_seq += a.l_alt_seq;
+        a.alt_clip += a.l_alt_clip;
+        a.l_ref_seq = L.rs_a + L.rs_b;
+        a.l_alt_seq = p_seq;
+        a.l_alt_clip = p_clip;
+    } else if (SSO) {
+        const bool cont = (w.w & SVT_REC_CONTINUATION) != 0u;
+        a.ref_seq += cont ? 0.0 : a.l_ref_seq;
+        a.alt_seq += cont ? 0.0 : a.l_alt_seq;
+        a.alt_clip += cont ? 0.0 : a.l_alt_clip;
+        a.l_ref_seq = ((cont ? a.l_ref_seq : 0.0) + L.rs_a) + L.rs_b;
+        a.l_alt_seq = (cont ? a.l_alt_seq : 0.0) + p_seq;
+        a.l_alt_clip = (cont ? a.l_alt_clip : 0.0) + p_clip;
+    } else {
+        a.ref_seq = (a.ref_seq + L.rs_a) + L.rs_b;
+        a.alt_seq += p_seq;
+        a.alt_clip += p_clip;
+    }
+    const bool p_conc = (int32_t)L.hist <= L.thr;   // hist[o - v] <= thr[o] (svt_host_tables.h)
+    const double w_alt = __hiloint2double((int)(p_conc ? L.wa1 : L.wa0), 0);
+    const double w_ref = __hiloint2double((int)(p_conc ? L.wr1 : 0u), 0);
+    const double pp = L.pm_a * L.pm_b;
+    a.alt_span += pp * w_alt;
+    a.ref_span += pp * w_ref;
 }
 
 // per-lane constants of the unit for the library-window consumer
@@ -303,6 +423,8 @@ __global__ __launch_bounds__(kBlock, MODE == kSingleLds ? SVT_STREAM_WAVES : MOD
         if (MODE != kGeneral) {
             reinterpret_cast<double*>(smem + kSWtab)[tid] = pw.w_alt;
             reinterpret_cast<double*>(smem + kSWtab + kSWref)[tid] = pw.w_ref;
+            reinterpret_cast<uint32_t*>(smem + kSWhi)[tid] = (uint32_t)__double2hiint(pw.w_alt);
+            reinterpret_cast<uint32_t*>(smem + kSWhi + kSWhiRef)[tid] = (uint32_t)__double2hiint(pw.w_ref);
         } else {
             s_wtab[tid] = pw;
         }
@@ -404,8 +526,12 @@ __global__ __launch_bounds__(kBlock, MODE == kSingleLds ? SVT_STREAM_WAVES : MOD
             fetch_block<kEdgeAux, true>(0, src_base, src_first, src_end, rec_bytes, ring);
         };
         auto fetch = [&](const uint32_t k) {   // k >= 1
-            if (kEdgeAux != SVT_STREAM_AUX && k + 1 >= min_blk)
-                fetch_block<kEdgeAux, false>(k, src_base, src_first, src_end, rec_bytes, ring);
+            if (SVT_FETCH_FAST_INTERIOR && k + 1 < min_blk) {
+                fetch_block_interior<SVT_STREAM_AUX>(k, src_base, rec_bytes, ring);
+            } else if (kEdgeAux != SVT_STREAM_AUX && k + 1 >= min_blk) {
+                if (SVT_EDGE_EXACT) fetch_block_tail_exact<SVT_STREAM_AUX, kEdgeAux>(k, src_base, src_end, rec_bytes, ring);
+                else fetch_block<kEdgeAux, false>(k, src_base, src_first, src_end, rec_bytes, ring);
+            }
             else
                 fetch_block<SVT_STREAM_AUX, false>(k, src_base, src_first, src_end, rec_bytes, ring);
         };
@@ -425,6 +551,7 @@ __global__ __launch_bounds__(kBlock, MODE == kSingleLds ? SVT_STREAM_WAVES : MOD
             sc.hist_at = kSBins + a.total_bins * 2u;
             sc.wt0 = kSWtab + c.del16 * 8u;
             sc.wt1 = sc.wt0 + 8u * 8u;
+            sc.wh0 = kSWhi + c.del16 * 4u;
         }
         if (MODE == kMultiLds) {
             // a window of ONE library (the usual sample) takes the one-library consumer with that library's constants
@@ -452,13 +579,35 @@ __global__ __launch_bounds__(kBlock, MODE == kSingleLds ? SVT_STREAM_WAVES : MOD
             constexpr bool EDGE = decltype(edge)::value;
             constexpr bool CONT = decltype(continuations)::value;   // sso: some record of the block may continue a fragment
             constexpr int KIND = decltype(window_kind)::value;   // kMultiLds: 1 = the window holds one library, 0 = several
+            auto is_mine = [&](const int j) -> bool {
+                const uint32_t idx = k * kBlockRecords + (uint32_t)j;
+                return !EDGE || (idx >= head && idx < last);
+            };
+            if (SVT_STREAM_PIPELINED && (MODE == kSingleLds || (MODE == kMultiLds && KIND == 1))) {
+                // one library: the look-ups of record j + 1 are in flight while record j is summed (look_issue)
+                Look L0, L1;
+                look_issue<EDGE>(w[0], is_mine(0), sc, L0);
+#pragma unroll
+                for (int j = 0; j < 8; j += 2) {
+                    look_wait(L0);
+                    look_issue<EDGE>(w[j + 1], is_mine(j + 1), sc, L1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (is_mine(j)) check.see(w[j], lib_key);
+                    look_use<SSO, CONT>(L0, w[j], acc);
+                    look_wait(L1);
+                    if (j + 2 < 8) look_issue<EDGE>(w[j + 2], is_mine(j + 2), sc, L0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (is_mine(j + 1)) check.see(w[j + 1], lib_key);
+                    look_use<SSO, CONT>(L1, w[j + 1], acc);
+                }
+                return;
+            }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 // keep the look-ups of the second half of the block from being hoisted over the first half: eight
                 // records' worth of live table values would not fit the register budget of three waves per SIMD
                 if (j == SVT_STREAM_SPLIT) __builtin_amdgcn_sched_barrier(0);
-                const uint32_t idx = k * kBlockRecords + (uint32_t)j;
-                const bool mine = !EDGE || (idx >= head && idx < last);
+                const bool mine = is_mine(j);
                 if (mine) check.see(w[j], lib_key);     // (slots that are not this lane's were not fetched)
                 if (MODE == kSingleLds) {
                     record_single<SSO, EDGE, CONT>(w[j], mine, sc, acc);
@@ -479,8 +628,10 @@ __global__ __launch_bounds__(kBlock, MODE == kSingleLds ? SVT_STREAM_WAVES : MOD
             u32x4 w[8];
 #pragma unroll 1
             for (uint32_t k = 0; k < max_blk; ++k) {
+                if (SVT_FETCH_PRIO) __builtin_amdgcn_s_setprio(SVT_FETCH_PRIO);
                 read_block(lane_block, sw16, w);
                 if (SVT_STREAM_PROBE != 2 && k + 1 < max_blk) fetch(k + 1);
+                if (SVT_FETCH_PRIO) __builtin_amdgcn_s_setprio(0);
                 const uint32_t k8 = k * kBlockRecords;
                 if (SVT_STREAM_PROBE == 1) {
 #pragma unroll
