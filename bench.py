@@ -21,9 +21,12 @@ empirical insert-size histogram, staged in LDS), ~100 fragment records (~200 rea
 After the timed region every rank's result records are gathered onto rank 0 with ONE RCCL gather over xGMI
 (north_star: "a single RCCL gather ... at the end"); its time is reported separately under "gather".
 
-Extra keys on the N=1 line (clearly labelled, never part of `value`): `one_shot` (host buffers -> results on the
-host, PCIe included), `one_shot_packed` (the same from packed evidence), `large_batch` (4 M units per GPU: working
-set far beyond the 256 MiB Infinity Cache), `cpu_baseline`, `parity`.
+Extra keys on the N=1 line (clearly labelled, never part of `value`; --legs selects them): `sso` (the same launch with
+the singlesample association) and `c5_multisample` (the configs[4] shape: 32 samples, per-sample libraries; plus the
+same batch without library hints) each with their own roofline object, `shard_of_8` (shard 0 of the 8-GPU cut of
+the headline workload, timed alone), `one_shot` (host buffers -> results on the host, PCIe included),
+`one_shot_packed` (the same from packed evidence, the host encoder's time included), `large_batch` (4 M units per
+GPU: working set far beyond the 256 MiB Infinity Cache), `cpu_baseline`, `parity`.  N > 1 adds `value_with_gather`.
 
 Prints ONE JSON line on rank 0.
 """
@@ -123,22 +126,62 @@ def library_stamp() -> str:
     return h.hexdigest()[:16]
 
 
-def measured_traffic(layout_name: str, n_units: int, n_records: int):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (tools/profile.sh ->
-    profiles/hbm_traffic.json; rocprofv3 cannot wrap this process from inside).  An entry only counts when it was
-    measured on THIS build of the library and on this workload: a stale entry is refused, not reused."""
+def source_stamp() -> str:
+    """Identity of the kernel SOURCES (sha256 over svtyper_amd/csrc/{*.hip,*.h,*.cpp,Makefile} and include/*.h, first
+    16 hex digits).  hipcc does not produce the same bytes twice from the same sources, so a PMC entry is keyed by
+    this and survives a rebuild by build() -- and is still refused once any kernel source has changed."""
+    import glob
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(ROOT, "svtyper_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "svtyper_amd", "csrc", "*.h")) +
+                   glob.glob(os.path.join(ROOT, "svtyper_amd", "csrc", "*.cpp")) + [os.path.join(ROOT, "svtyper_amd", "csrc", "Makefile")] +
+                   glob.glob(os.path.join(ROOT, "include", "*.h")))
+    for path in files:
+        h.update(os.path.basename(path).encode() + b"\0")
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def measured_traffic(key: str, n_units: int, n_records: int):
+    """HBM bytes per launch of a leg's kernel from the committed PMC passes (tools/profile.sh -> profiles/hbm_traffic.json;
+    rocprofv3 cannot wrap this process from inside).  An entry only counts when it was measured on THESE kernel sources
+    (source_stamp) and on this workload: a stale entry is refused, not reused."""
     try:
         with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as f:
-            tj = json.load(f)[layout_name]
+            tj = json.load(f)[key]
     except (OSError, ValueError, KeyError):
-        return None, "no PMC entry for this layout in profiles/hbm_traffic.json"
+        return None, "no PMC entry '%s' in profiles/hbm_traffic.json" % key
     if tj.get("units") != n_units or tj.get("records") != n_records:
-        return None, "profiles/hbm_traffic.json was measured on another workload (%s units): refused" % tj.get("units")
-    if tj.get("library_sha16") != library_stamp():
-        return None, ("profiles/hbm_traffic.json was measured on another build of libsvtyper_hip.so (%s, this one is %s): "
-                      "refused; re-run tools/profile.sh" % (tj.get("library_sha16"), library_stamp()))
-    return tj["traffic_bytes_per_launch"], ("rocprofv3 PMC (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE) on this build, "
-                                            "profiles/hbm_traffic.json")
+        return None, "profiles/hbm_traffic.json['%s'] was measured on another workload (%s units): refused" % (key, tj.get("units"))
+    if tj.get("source_sha16") != source_stamp():
+        return None, ("profiles/hbm_traffic.json['%s'] was measured on other kernel sources (%s, these are %s): refused; re-run "
+                      "tools/profile.sh" % (key, tj.get("source_sha16"), source_stamp()))
+    return tj["traffic_bytes_per_launch"], ("rocprofv3 PMC (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE) on these kernel sources, "
+                                            "profiles/hbm_traffic.json['%s']" % key)
+
+
+def cpu_model() -> str:
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+LEGS = ("sso", "c5", "shard", "one_shot", "packed", "large")
+
+
+def roofline_of(kernel_ms: float, alg_bytes: int, key: str, n_units: int, n_records: int) -> dict:
+    """the roofline object of one leg: algorithmic bytes over the measured launch time, PMC traffic when this build has it"""
+    ach = alg_bytes / (kernel_ms * 1e-3) / 1e9
+    traffic, note = measured_traffic(key, n_units, n_records)
+    return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+            "traffic_unit": "bytes per launch", "traffic_source": note,
+            "traffic_over_algorithmic": (traffic / alg_bytes) if traffic else None,
+            "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": kernel_ms}
 
 
 def time_passes(dbatch, steps: int) -> float:
@@ -160,7 +203,8 @@ def main():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--sso", action="store_true", help="singlesample.py floating-point association")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra-legs", action="store_true", help="skip one_shot / one_shot_packed / large_batch (N=1 only)")
+    ap.add_argument("--no-extra-legs", action="store_true", help="headline only (N=1: no sso / c5 / shard / one_shot / packed / large legs)")
+    ap.add_argument("--legs", default="all", help="comma list of the extra N=1 legs to run: " + ",".join(LEGS) + " [all]")
     ap.add_argument("--no-dense-leg", action="store_true", help="(kept for old command lines) = --no-extra-legs")
     ap.add_argument("--large-units", type=int, default=4_000_000)
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
@@ -169,6 +213,9 @@ def main():
     args = ap.parse_args()
     if args.no_dense_leg:
         args.no_extra_legs = True
+    legs = set() if args.no_extra_legs else set(LEGS) if args.legs == "all" else set(x for x in args.legs.split(",") if x)
+    if legs - set(LEGS):
+        sys.exit("unknown --legs entries: %s" % sorted(legs - set(LEGS)))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -200,8 +247,13 @@ def main():
         counts = [batch.n_units] * world
         total_units = batch.n_units * world
     gen_s = time.time() - t0
-    more = None
-    if world == 1 and not args.no_extra_legs and args.workload == "c3_mixed_1m" and args.large_units > batch.n_units:
+    if world != 1 or args.workload != "c3_mixed_1m" or args.scaling != "weak":
+        legs = set()
+    more = c5_batch = None
+    if "c5" in legs:
+        # the configs[4] shape at the headline's size: sites x 32 samples with per-sample libraries (svt_unit.libs hints)
+        c5_batch = generate("c5_multisample", batch.n_units, rank, workers)
+    if "large" in legs and args.large_units > batch.n_units:
         # the rest of the `large_batch` leg's workload (also generated before any GPU context exists)
         more = generate(args.workload, args.large_units - batch.n_units, rank, workers,
                         first_chunk=(batch.n_units + 49_999) // 50_000)
@@ -283,8 +335,8 @@ def main():
     if rank == 0:
         got = dbatch.results()
         value = total_units * args.steps / elapsed
-        ach = alg_bytes / (kern_ms * 1e-3) / 1e9
-        traffic, traffic_note = measured_traffic(layout_name, n, batch.n_records)
+        traffic_key = "c5_windows" if args.workload == "c5_multisample" else "stream_sso" if args.sso else "stream"
+        roof = roofline_of(kern_ms, alg_bytes, traffic_key, n, batch.n_records)
         per_site = batch.n_records / max(1, n)
         workload = {
             "c3_mixed_1m": "BASELINE.json configs[2]: %d mixed DEL/DUP/INV breakpoints%s, 1 library (fixture insert-size "
@@ -318,37 +370,32 @@ def main():
                 "device_layout": "the canonical CSR records as uploaded, streamed by the pass itself",
                 "parallelism": "units sharded over %d GPU(s), no data-path collective per step" % world,
             },
-            "roofline": {
-                "bound": "hbm",
+            "roofline": dict(roof, **{
                 "kernel": "svt_stream_kernel",
-                "achieved": ach,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": ach / HBM_PEAK_GBS,
-                "traffic": traffic,
-                "traffic_unit": "bytes per launch",
-                "traffic_source": traffic_note,
-                "traffic_frac_of_peak": (traffic / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
-                "algorithmic_bytes_per_launch": alg_bytes,
+                "traffic_frac_of_peak": (roof["traffic"] / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if roof["traffic"] else None,
                 "resident_bytes_per_launch": resident_bytes,
-                "kernel_ms": kern_ms,
                 "kernel_ms_max_over_ranks": kern_ms_max,
                 "kernel_ms_note": "HIP events around the `steps` back-to-back launches of the timed region, divided by `steps`: "
                                   "includes the ~5-10 us between consecutive dispatches that rocprofv3's per-kernel duration leaves out",
                 "library_sha16": library_stamp(),
+                "source_sha16": source_stamp(),
                 "note": "`achieved` = ALGORITHMIC bytes (16 B per fragment record + 112 B per unit) over the time of the ONE "
                         "kernel that does all the work from the canonical input: <= peak by construction",
-            },
+            }),
             "host": {"generate_s": gen_s, "first_create_s": upload_s},
         }
         if gather:
             out["gather"] = gather
+            # the job as north_star states it -- every rank's pass, then ONE gather of the result records onto rank 0 --
+            # per pass: `value` times the passes alone (the contract's timed region), this one adds the gather once per pass
+            out["value_with_gather"] = total_units / (elapsed / args.steps + gather["ms"] * 1e-3)
+            out["value_with_gather_note"] = "units / (ms_per_step + gather.ms): one pass followed by its RCCL gather"
         if args.workload == "c5_multisample":   # one breakpoint = one VCF site; a unit = (site, sample)
             out["sites_per_s"] = value / N_SAMPLES_C5
             out["units_per_s"] = value
 
-        extra = world == 1 and not args.no_extra_legs
-        if extra:
+        host_out = None
+        if "one_shot" in legs:
             # ---- one shot, PCIe included: host arrays (pageable) -> svt_batch_create -> one pass -> result records
             # on the host, steady state (the first create pays the pinned ring and the pooled device buffers)
             host_out = hip.pinned_results(n)   # the caller's output array, page-locked (svt_pinned_alloc): D2H is one DMA
@@ -376,7 +423,7 @@ def main():
                 best = min(pipe)
                 out["one_shot"] = {
                     "what": "svt_genotype: host arrays in pageable memory -> result records in a page-locked output array; the "
-                            "canonical CSR goes up through the pinned ring in 32 MB pieces, every piece's units are genotyped by "
+                            "canonical CSR goes up through the pinned ring in 64 MB pieces, every piece's units are genotyped by "
                             "their own launch as soon as it has landed and their records come down on a third stream; best of 3. "
                             "`serial_*`: the same as svt_batch_create + pass + svt_batch_results one after the other",
                     "wall_ms": best * 1e3,
@@ -390,12 +437,22 @@ def main():
             except Exception as e:  # an extra leg must never break the bench line
                 out["one_shot"] = {"error": repr(e)}
 
+        if "packed" in legs:
             # ---- the same through PACKED evidence: what a host producer hands over when the bytes have to cross PCIe
             # (svt_pack_evidence: ~3 bytes per fragment record instead of 16; the pass is svt_packed_kernel on the slots)
             try:
-                t0 = time.perf_counter()
-                packed = hip.PackedEvidence.try_pack(batch)
-                pack_ms = (time.perf_counter() - t0) * 1e3
+                if host_out is None:
+                    host_out = hip.pinned_results(n)
+                pack_ms = None
+                for _ in range(3):          # best of 3 (the first call pays the page-locked pool)
+                    t0 = time.perf_counter()
+                    packed = hip.PackedEvidence.try_pack(batch)
+                    dt = (time.perf_counter() - t0) * 1e3
+                    pack_ms = dt if pack_ms is None else min(pack_ms, dt)
+                    if packed is None:
+                        break
+                    if _ < 2:
+                        packed.free()
                 if packed is None:
                     out["one_shot_packed"] = {"skipped": "this batch cannot be expressed as packed evidence (several libraries)"}
                 else:
@@ -424,11 +481,15 @@ def main():
                     best = min(pipe)
                     out["one_shot_packed"] = {
                         "what": "svt_genotype_packed: packed slots (page-locked, written by svt_pack_evidence) -> result records in a "
-                                "page-locked output array, upload || svt_packed_kernel || download by unit ranges, best of 4; the "
-                                "encoder (svt_pack_evidence, host, %d threads) is the producer's side and is reported as pack_ms, "
-                                "not included.  `serial_*`: svt_batch_create_packed + pass + svt_batch_results one after the other" % n_cpu,
+                                "page-locked output array, upload || svt_packed_kernel || download by unit ranges, best of 4.  The "
+                                "leg's headline is `pack_inclusive_breakpoints_per_s`: the encoder (svt_pack_evidence, host, %d threads, "
+                                "`pack_ms`, best of 3) runs over records that already exist in host memory, so its time belongs to the "
+                                "route; `pcie_inclusive_breakpoints_per_s` alone is what a producer that emits slots directly would "
+                                "see.  `serial_*`: svt_batch_create_packed + pass + svt_batch_results one after the other" % n_cpu,
                         "wall_ms": best * 1e3, "serial_wall_ms": serial * 1e3, "serial_create_ms": parts[0] * 1e3,
                         "serial_pass_ms": parts[1] * 1e3, "serial_results_d2h_ms": parts[2] * 1e3, "pack_ms": pack_ms,
+                        "pack_inclusive_wall_ms": pack_ms + best * 1e3,
+                        "pack_inclusive_breakpoints_per_s": n / (pack_ms * 1e-3 + best),
                         "pcie_inclusive_breakpoints_per_s": n / best,
                         "h2d_bytes": packed.nbytes, "d2h_bytes": int(128 * n),
                         "bytes_per_fragment_record": packed.nbytes / max(1, batch.n_records),
@@ -465,6 +526,7 @@ def main():
                 "value": sample_n * reps / cpu_s,
                 "unit": "breakpoints/s",
                 "cores": threads,
+                "cpu_model": cpu_model(),
                 "one_thread": one_thread,
                 "kind": "port",
                 "sample": "the workload's %d units x %d repetitions, oracle/svt_oracle.c "
@@ -498,7 +560,72 @@ def main():
                 "max_abs_dSQ": float(np.max(np.abs(got.sq[:sample_n] - want.sq))),
             }
 
-        if extra and more is not None:
+        if "sso" in legs and not args.sso:
+            # ---- the same launch with the singlesample association of the split-read sums (svtyper/singlesample.py:246-276,367-372)
+            try:
+                with hip.DeviceBatch(batch, device=local_rank, flags=ev.FLAG_SSO_ASSOCIATION) as ds:
+                    ds.genotype(sync=True)
+                    s_ms = time_passes(ds, args.steps)
+                    s_alg, _ = ds.bytes()
+                out["sso"] = dict(roofline_of(s_ms, s_alg, "stream_sso", n, batch.n_records),
+                                  what="the headline's workload and launch with SVT_FLAG_SSO_ASSOCIATION (svtyper-sso's summation order)",
+                                  kernel="svt_stream_kernel<sso>", units=n, breakpoints_per_s=n / (s_ms * 1e-3))
+            except Exception as e:
+                out["sso"] = {"error": repr(e)}
+
+        if c5_batch is not None:
+            # ---- BASELINE.json configs[4] shape at the headline's size: (site, sample) units, 32 samples, per-sample libraries
+            try:
+                with hip.DeviceBatch(c5_batch, device=local_rank, flags=sso) as dc:
+                    dc.genotype(sync=True)
+                    c_ms = time_passes(dc, args.steps)
+                    c_alg, _ = dc.bytes()
+                    c_mode = dc.table_mode()
+                leg = roofline_of(c_ms, c_alg, "c5_windows", c5_batch.n_units, c5_batch.n_records)
+                leg.update(what="configs[4] shape: %d sites x %d samples, %d libraries, every unit carries its sample's library window "
+                                "(svt_unit.libs); one launch of the library-window kernel" % (c5_batch.n_units // N_SAMPLES_C5, N_SAMPLES_C5, len(c5_batch.libs)),
+                           kernel="svt_stream_kernel<windows>", table_mode=c_mode, units=c5_batch.n_units, records=c5_batch.n_records,
+                           units_per_s=c5_batch.n_units / (c_ms * 1e-3), sites_per_s=c5_batch.n_units / N_SAMPLES_C5 / (c_ms * 1e-3))
+                # the same batch WITHOUT the hints: any-geometry mode, histogram tables through L2
+                nh_units = c5_batch.units.copy()
+                nh_units["libs"] = 0
+                nh = ev.EvidenceBatch(c5_batch.rec_offset, nh_units, c5_batch.records, c5_batch.libs, c5_batch.split_weight, c5_batch.disc_weight)
+                with hip.DeviceBatch(nh, device=local_rank, flags=sso) as dn:
+                    dn.genotype(sync=True)
+                    g_ms = time_passes(dn, max(3, args.steps // 2))
+                    leg["hintless"] = {"table_mode": dn.table_mode(), "kernel_ms": g_ms, "frac": c_alg / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                out["c5_multisample"] = leg
+                del nh, nh_units
+            except Exception as e:
+                out["c5_multisample"] = {"error": repr(e)}
+            c5_batch = None
+
+        if "shard" in legs:
+            # ---- strong scaling, the part one GPU can measure: the headline workload cut by the 8-GPU shard rule
+            # (svt_shard_bounds == distributed.shard_bounds), shard 0 timed alone = what every rank of configs[3] runs
+            try:
+                from svtyper_amd import distributed as D
+                lo, hi = D.shard_bounds(batch.rec_offset, 8, 1)[0]
+                sh = batch.slice(lo, hi)
+                with hip.DeviceBatch(sh, device=local_rank, flags=flags) as dsb:
+                    dsb.genotype(sync=True)
+                    sh_ms = time_passes(dsb, max(args.steps, 20))
+                    sh_alg, _ = dsb.bytes()
+                    same = bool(np.array_equal(dsb.results().rec, got.rec[lo:hi]))
+                out["shard_of_8"] = {
+                    "what": "units [%d, %d) = shard 0 of the headline workload under the 8-GPU shard rule, one launch; "
+                            "`speedup_vs_headline` is the per-GPU strong-scaling factor a rank of configs[3] can reach before the gather "
+                            "(8 = ideal)" % (lo, hi),
+                    "units": hi - lo, "records": sh.n_records, "kernel_ms": sh_ms,
+                    "frac": sh_alg / (sh_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "speedup_vs_headline": kern_ms / sh_ms,
+                    "expected_speedup_model": "t(n) = t_fixed + n * t_unit fitted through this launch and the headline: t_fixed = %.4f ms"
+                                              % max(0.0, (sh_ms * n - kern_ms * (hi - lo)) / max(1, n - (hi - lo))),
+                    "results_equal_headline": same,
+                }
+            except Exception as e:
+                out["shard_of_8"] = {"error": repr(e)}
+
+        if more is not None:
             # ---- the same step at 4 M units per GPU: 6.5 GB of records, far beyond the 256 MiB Infinity Cache
             try:
                 dbatch.close()

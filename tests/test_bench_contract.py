@@ -30,19 +30,29 @@ def test_bench_line_has_the_contract_keys(hip_device):
     cpu = d["cpu_baseline"]
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in cpu, key
-    assert cpu["kind"] == "port" and cpu["cores"] >= 1
+    assert cpu["kind"] == "port" and cpu["cores"] >= 1 and isinstance(cpu["cpu_model"], str) and cpu["cpu_model"]
     assert d["value"] > 0 and abs(d["value"] - 30000 * 3 / (d["ms_per_step"] * 3 * 1e-3)) / d["value"] < 1e-6
     assert d["parity"]["integer_mismatches"] == 0 and d["parity"]["max_abs_dGL"] <= 1e-6 and d["parity"]["max_abs_dSQ"] <= 1e-6
     # the timed step is the whole path from the canonical input: the algorithmic rate cannot exceed the HBM peak
     assert roof["kernel"] == "svt_stream_kernel" and 0 < roof["frac"] <= 1.0
     assert "nothing pre-digested" in d["config"]["step"]
     # a traffic figure is only reported when it was measured on this very build
-    assert roof["traffic"] is None or "this build" in roof["traffic_source"]
+    assert roof["traffic"] is None or "these kernel sources" in roof["traffic_source"]
+    assert len(roof["source_sha16"]) == 16 and len(roof["library_sha16"]) == 16
     # the labelled extra legs
     assert d["one_shot"]["pcie_inclusive_breakpoints_per_s"] > 0 and d["one_shot"]["wall_ms"] > 0
     assert d["large_batch"]["units"] == 70000 and d["large_batch"]["first_units_equal_headline"] is True
     assert 0 < d["large_batch"]["frac"] <= 1.0
     assert d["one_shot_packed"]["results_equal_headline"] is True and d["one_shot_packed"]["bytes_per_fragment_record"] < 5
+    assert d["one_shot_packed"]["pack_inclusive_wall_ms"] > d["one_shot_packed"]["wall_ms"]
+    # the singlesample association, the configs[4] shape and the 8-GPU shard: own fractions, own (or no) traffic figures
+    assert 0 < d["sso"]["frac"] <= 1.0 and d["sso"]["units"] == 30000
+    c5 = d["c5_multisample"]
+    assert 0 < c5["frac"] <= 1.0 and c5["table_mode"] == 1 and c5["units"] % 32 == 0 and c5["hintless"]["table_mode"] == 2
+    for leg in (d["sso"], c5):
+        assert leg["traffic"] is None or "these kernel sources" in leg["traffic_source"]
+    sh = d["shard_of_8"]
+    assert sh["results_equal_headline"] is True and 0 < sh["units"] < 30000 and sh["speedup_vs_headline"] > 0
 
 
 @pytest.mark.gpu
