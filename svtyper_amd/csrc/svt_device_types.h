@@ -23,6 +23,10 @@ struct LibDesc {          // 32 B, one per library
 // packed evidence: the pair stream is counted in half-words (2-byte entries, 4-byte wide ones), eight per 16-byte slot
 constexpr uint32_t kHalfwordsPerRow = 8u;
 
+// record-contract violations (include/svtyper_hip.h: svt_record), as the streaming pass ORs them into its error word
+// and as the host encoder of packed evidence reports them
+constexpr uint32_t kErrStraddleNoPair = 2u, kErrLibIndex = 4u, kErrReservedBits = 8u, kErrNegativeSpan = 16u;
+
 // device layout of a batch's evidence
 enum Layout : int {     // (0..2 were round 1's tiled layouts)
     kLayoutStream = 3,   // the caller's CSR as it is, streamed through per-wave LDS rings (svt_stream_kernel.h)

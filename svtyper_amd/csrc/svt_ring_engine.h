@@ -25,6 +25,11 @@ namespace svt {
 constexpr uint32_t kBlockRecords = 8;                         // records per 128-byte block
 constexpr uint32_t kStageBytes = kWave * 128;                 // one block per lane
 constexpr uint32_t kRingBytes = kStageBytes;                  // per wave: one stage
+#ifndef SVT_STREAM_DEPTH
+#define SVT_STREAM_DEPTH 1   // stages per wave in svt_stream_kernel (2: block k + 2 is in flight while block k is summed)
+#endif
+constexpr uint32_t kStreamDepth = SVT_STREAM_DEPTH;
+constexpr uint32_t kStreamRingBytes = kStageBytes * kStreamDepth;
 constexpr uint32_t kMaxSortKey = 255;                         // units with more blocks share the last sort bucket
 // where the epilogue finds the log10 table of log_choose
 enum L10Place : uint32_t {
@@ -33,32 +38,35 @@ enum L10Place : uint32_t {
     kL10Global = 2    // read through L2 (units with thousands of records)
 };
 
-// error bits (also what svt_pack_evidence reports for the same violations)
-constexpr uint32_t kErrStraddleNoPair = 2u, kErrLibIndex = 4u, kErrReservedBits = 8u, kErrNegativeSpan = 16u;
 
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
 
 // The eight records of this lane's block, once the LDS-DMA group that filled the ring has landed (it is the
 // only vector-memory work the wave has in flight).  The compiler cannot see that these reads depend on the
 // LDS-DMA writes, hence the explicit counters; when this returns the ring is free for the next block.
+// STAGE_OFF: byte offset of the stage inside the wave's ring (immediate of the ds_reads); PENDING: vector-memory
+// instructions that may still be outstanding -- the LDS-DMA group of the NEXT block, when the ring has two stages and
+// that group is known to be exactly eight instructions.
+template <uint32_t STAGE_OFF = 0, int PENDING = 0>
 __device__ __forceinline__ void read_block(const uint32_t lane_block, const uint32_t sw16, u32x4 (&w)[8])
 {
     // logical record j of the lane's block sits in slot j ^ swz: lane_block + ((j << 4) ^ sw16)
     uint32_t addr[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) addr[j] = lane_block + (((uint32_t)j << 4) ^ sw16);
-    asm volatile("s_waitcnt vmcnt(0)\n\t"
-                 "ds_read_b128 %0, %8\n\t"
-                 "ds_read_b128 %1, %9\n\t"
-                 "ds_read_b128 %2, %10\n\t"
-                 "ds_read_b128 %3, %11\n\t"
-                 "ds_read_b128 %4, %12\n\t"
-                 "ds_read_b128 %5, %13\n\t"
-                 "ds_read_b128 %6, %14\n\t"
-                 "ds_read_b128 %7, %15\n\t"
+    asm volatile("s_waitcnt vmcnt(%16)\n\t"
+                 "ds_read_b128 %0, %8 offset:%17\n\t"
+                 "ds_read_b128 %1, %9 offset:%17\n\t"
+                 "ds_read_b128 %2, %10 offset:%17\n\t"
+                 "ds_read_b128 %3, %11 offset:%17\n\t"
+                 "ds_read_b128 %4, %12 offset:%17\n\t"
+                 "ds_read_b128 %5, %13 offset:%17\n\t"
+                 "ds_read_b128 %6, %14 offset:%17\n\t"
+                 "ds_read_b128 %7, %15 offset:%17\n\t"
                  "s_waitcnt lgkmcnt(0)"
                  : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3]), "=&v"(w[4]), "=&v"(w[5]), "=&v"(w[6]), "=&v"(w[7])
-                 : "v"(addr[0]), "v"(addr[1]), "v"(addr[2]), "v"(addr[3]), "v"(addr[4]), "v"(addr[5]), "v"(addr[6]), "v"(addr[7])
+                 : "v"(addr[0]), "v"(addr[1]), "v"(addr[2]), "v"(addr[3]), "v"(addr[4]), "v"(addr[5]), "v"(addr[6]), "v"(addr[7]),
+                   "n"(PENDING), "n"(STAGE_OFF)
                  : "memory");
 }
 

@@ -478,7 +478,7 @@ __global__ __launch_bounds__(kBlock, MODE == kSingleLds ? SVT_STREAM_WAVES : MOD
     t.libs = s_lib;
     t.bins = a.bins;
 
-    unsigned char* ring = rings + wave * kRingBytes;
+    unsigned char* ring = rings + wave * kStreamRingBytes;
     const uint32_t ring_addr = (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)ring;
     // LDS-DMA: lane (o, rr) of instruction i fetches 16 bytes of the block of unit 8 i + o; they land at
     // ring + (8 i + o) * 128 + rr * 16.  The slot rr of unit u holds logical record rr ^ swz(u), swz(u) = (u >> 1) & 7
@@ -525,15 +525,18 @@ __global__ __launch_bounds__(kBlock, MODE == kSingleLds ? SVT_STREAM_WAVES : MOD
         auto fetch_first = [&]() {
             fetch_block<kEdgeAux, true>(0, src_base, src_first, src_end, rec_bytes, ring);
         };
-        auto fetch = [&](const uint32_t k) {   // k >= 1
+        // block k (k >= 1) -> stage `st` of the ring; true when the group was exactly eight instructions (read_block's PENDING)
+        auto fetch = [&](const uint32_t k, const uint32_t st = 0u) -> bool {
+            unsigned char* stage = ring + st * kStageBytes;
             if (SVT_FETCH_FAST_INTERIOR && k + 1 < min_blk) {
-                fetch_block_interior<SVT_STREAM_AUX>(k, src_base, rec_bytes, ring);
+                fetch_block_interior<SVT_STREAM_AUX>(k, src_base, rec_bytes, stage);
+                return true;
             } else if (kEdgeAux != SVT_STREAM_AUX && k + 1 >= min_blk) {
-                if (SVT_EDGE_EXACT) fetch_block_tail_exact<SVT_STREAM_AUX, kEdgeAux>(k, src_base, src_end, rec_bytes, ring);
-                else fetch_block<kEdgeAux, false>(k, src_base, src_first, src_end, rec_bytes, ring);
-            }
-            else
-                fetch_block<SVT_STREAM_AUX, false>(k, src_base, src_first, src_end, rec_bytes, ring);
+                if (SVT_EDGE_EXACT) fetch_block_tail_exact<SVT_STREAM_AUX, kEdgeAux>(k, src_base, src_end, rec_bytes, stage);
+                else fetch_block<kEdgeAux, false>(k, src_base, src_first, src_end, rec_bytes, stage);
+            } else
+                fetch_block<SVT_STREAM_AUX, false>(k, src_base, src_first, src_end, rec_bytes, stage);
+            return false;
         };
 
         LaneCtx c{};   // kGeneral
@@ -626,11 +629,26 @@ __global__ __launch_bounds__(kBlock, MODE == kSingleLds ? SVT_STREAM_WAVES : MOD
         if (max_blk) {
             fetch_first();
             u32x4 w[8];
+            bool exact_behind = false;   // two stages: is the group issued last -- the one behind the block we wait for -- exactly 8 instructions?
+            if (kStreamDepth == 2 && max_blk > 1) exact_behind = fetch(1, 1);
 #pragma unroll 1
             for (uint32_t k = 0; k < max_blk; ++k) {
                 if (SVT_FETCH_PRIO) __builtin_amdgcn_s_setprio(SVT_FETCH_PRIO);
-                read_block(lane_block, sw16, w);
-                if (SVT_STREAM_PROBE != 2 && k + 1 < max_blk) fetch(k + 1);
+                if (kStreamDepth == 2) {
+                    // block k sits in stage k & 1; the group behind it (block k + 1) may stay in flight
+                    const bool pend = k + 1 < max_blk && exact_behind;
+                    if (k & 1u) {
+                        if (pend) read_block<kStageBytes, 8>(lane_block, sw16, w);
+                        else read_block<kStageBytes, 0>(lane_block, sw16, w);
+                    } else {
+                        if (pend) read_block<0, 8>(lane_block, sw16, w);
+                        else read_block<0, 0>(lane_block, sw16, w);
+                    }
+                    if (SVT_STREAM_PROBE != 2 && k + 2 < max_blk) exact_behind = fetch(k + 2, k & 1u);
+                } else {
+                    read_block(lane_block, sw16, w);
+                    if (SVT_STREAM_PROBE != 2 && k + 1 < max_blk) fetch(k + 1);
+                }
                 if (SVT_FETCH_PRIO) __builtin_amdgcn_s_setprio(0);
                 const uint32_t k8 = k * kBlockRecords;
                 if (SVT_STREAM_PROBE == 1) {

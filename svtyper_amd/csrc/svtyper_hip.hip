@@ -54,6 +54,7 @@
 #include "svt_device_types.h"
 #include "svt_unit_math.h"
 #include "svt_entry_formats.h"
+#include "svt_pack.h"
 #include "svt_stream_kernel.h"
 #include "svt_packed_kernel.h"
 #include "svt_geometry_kernel.h"
@@ -258,12 +259,7 @@ struct StageTimer {
 // the record-contract violations svt_stream_kernel reports
 int record_error(uint32_t err_bits)
 {
-    std::string m = "invalid evidence records:";
-    if (err_bits & kErrStraddleNoPair) m += " straddle bits without HAS_PAIR;";
-    if (err_bits & kErrLibIndex) m += " lib index >= n_libs;";
-    if (err_bits & kErrReservedBits) m += " reserved/undefined bits set;";
-    if (err_bits & kErrNegativeSpan) m += " negative ospan_len;";
-    return fail(SVT_ERR_INVALID, m);
+    return fail(SVT_ERR_INVALID, record_error_text(err_bits));
 }
 
 // kLayoutStream: has the last pass seen a record that breaks the contract?  (blocking)
@@ -341,7 +337,7 @@ int create_stream(const svt_evidence_batch* in, svt_batch* b, void* d_records_re
     uint64_t all_bins = 0;
     for (const LibDesc& L : T.libs) all_bins += L.n_bins + 1;
     const bool whole_batch_window = !all_hinted && n > 0 && in->n_libs <= 255 &&
-                                    kSBins + all_bins * 4 + in->n_libs * sizeof(WinLib) + 64 + kWavesPerBlock * kRingBytes <= (160 * 1024 / 2);
+                                    kSBins + all_bins * 4 + in->n_libs * sizeof(WinLib) + 64 + kWavesPerBlock * kStreamRingBytes <= (160 * 1024 / 2);
     const uint32_t whole_key = in->n_libs << 8;   // SVT_UNIT_LIBS(0, n_libs)
     auto window_key = [&](uint64_t u) { return all_hinted ? in->units[u].libs & 0xffffu : whole_key; };
     bool windowed = in->n_libs > 1 && (all_hinted || whole_batch_window) && T.fast_geometry;
@@ -421,9 +417,9 @@ int create_stream(const svt_evidence_batch* in, svt_batch* b, void* d_records_re
     constexpr size_t kStreamLdsPerWg2 = (160 * 1024 / 2) & ~size_t(127);  // two
     constexpr size_t kLdsBin = 2 * sizeof(uint16_t);   // thr + hist of one bin in LDS: 16-bit ranks
     const size_t single_lds = kSBins + T.bins.size() * kLdsBin;
-    const bool single = in->n_libs == 1 && T.fast_geometry && T.narrow_bins && single_lds + kWavesPerBlock * kRingBytes <= 96 * 1024;
+    const bool single = in->n_libs == 1 && T.fast_geometry && T.narrow_bins && single_lds + kWavesPerBlock * kStreamRingBytes <= 96 * 1024;
     const size_t window_lds = kSBins + (((size_t)max_win_bins * kLdsBin + 15) & ~size_t(15)) + (size_t)max_win_libs * sizeof(WinLib);
-    windowed = windowed && T.narrow_bins && window_lds + kWavesPerBlock * kRingBytes <= kStreamLdsPerWg2;
+    windowed = windowed && T.narrow_bins && window_lds + kWavesPerBlock * kStreamRingBytes <= kStreamLdsPerWg2;
     b->mode = single ? kSingleLds : windowed ? kMultiLds : kGeneral;
     if (windowed) {
         Stager st(b->stream);
@@ -460,14 +456,14 @@ int create_stream(const svt_evidence_batch* in, svt_batch* b, void* d_records_re
     // the log10 table of the epilogue: beside the tables while three workgroups still fit a CU's 160 KB,
     // else through the wave's ring, else through L2
     const size_t l10_bytes = ((size_t)n_l10 * 8 + 127) & ~size_t(127);
-    const size_t with_l10 = tables + l10_bytes + kWavesPerBlock * kRingBytes;
+    const size_t with_l10 = tables + l10_bytes + kWavesPerBlock * kStreamRingBytes;
     // (a window that already costs the third workgroup keeps the table too as long as two still fit)
-    if (with_l10 <= kStreamLdsPerWg || (tables + kWavesPerBlock * kRingBytes > kStreamLdsPerWg && with_l10 <= kStreamLdsPerWg2)) {
+    if (with_l10 <= kStreamLdsPerWg || (tables + kWavesPerBlock * kStreamRingBytes > kStreamLdsPerWg && with_l10 <= kStreamLdsPerWg2)) {
         a.l10_where = kL10Shared;
         a.lds_l10 = (uint32_t)tables;
         tables += l10_bytes;
     } else {
-        a.l10_where = (uint64_t)n_l10 * 8 <= kRingBytes ? kL10Ring : kL10Global;
+        a.l10_where = (uint64_t)n_l10 * 8 <= kStreamRingBytes ? kL10Ring : kL10Global;
     }
     a.lds_rings = (uint32_t)tables;
     a.n_units = n;
@@ -478,7 +474,7 @@ int create_stream(const svt_evidence_batch* in, svt_batch* b, void* d_records_re
     a.lib0 = T.libs[0];
     fill_gt_consts(a.c, in->split_weight, in->disc_weight);
     b->out_dev = b->d_out;   // svt_batch_device_results / svt_batch_bind_device_results / svt_batch_site_qual
-    b->lds_bytes = tables + kWavesPerBlock * kRingBytes + SVT_PROBE_LDS_PAD;
+    b->lds_bytes = tables + kWavesPerBlock * kStreamRingBytes + SVT_PROBE_LDS_PAD;
     if (b->lds_bytes > 160 * 1024) return fail(SVT_ERR_INVALID, "LDS budget exceeded");
     if (b->lds_bytes > 64 * 1024)
         for (int tiles = 1; tiles <= 2; ++tiles)
@@ -576,146 +572,29 @@ struct PackedOwner {             // what svt_pack_evidence returns: the public s
     }
 };
 
-// The most common (mapq_a, mapq_b) among the first records that would keep a pair entry (a straddle bit and two
-// non-zero MAPQs); ties go to the lowest key.  Any answer is correct for the short pair entries.
-uint32_t vote_common_mapq(const uint4* recs, uint64_t n_vote)
-{
-    uint32_t common = kDefaultCommonMapq, best = 0;
-    if (!recs || !n_vote) return common;
-    std::vector<uint32_t> votes(65536, 0u);
-    for (uint64_t i = 0; i < n_vote; ++i) {
-        const uint4 w = recs[i];
-        if ((w.w & 7u) && (w.y & 0xffu) && (w.y & 0xff00u)) ++votes[w.y & 0xffffu];
-    }
-    for (uint32_t k = 0; k < 65536u; ++k)
-        if (votes[k] > best) { best = votes[k]; common = k; }
-    return common;
-}
-
-// can this batch be written as packed evidence?  (the limits of the short entry format, include/svtyper_hip.h)
-int packable(const svt_evidence_batch* in, const HostTables& T)
-{
-    if (in->n_libs != 1) return fail(SVT_ERR_UNSUPPORTED, "packed evidence holds one library");
-    if (T.libs[0].n_bins > kMaxShortBins) return fail(SVT_ERR_UNSUPPORTED, "histogram too wide for the packed pair entries");
-    if (!T.fast_geometry) return fail(SVT_ERR_UNSUPPORTED, "library geometry outside the packed format's range");
-    for (uint64_t u = 0; u < in->n_units; ++u) {
-        const svt_unit& U = in->units[u];
-        if (U.var_length < -(1 << 30) || U.var_length > (1 << 30)) return fail(SVT_ERR_UNSUPPORTED, "var_length outside the packed format's range");
-        if (U.svtype == SVT_SVTYPE_DEL && U.var_length < 0) return fail(SVT_ERR_UNSUPPORTED, "negative DEL length");
-    }
-    return SVT_OK;
-}
-
+// svt_pack_evidence: the encoder itself is host-only code in svt_pack.cpp; here it gets the page-locked pool as allocator
 int pack_evidence(const svt_evidence_batch* in, svt_packed_evidence** out)
 {
     if (!in || !out) return fail(SVT_ERR_INVALID, "null argument");
     *out = nullptr;
-    const uint64_t n = in->n_units;
-    if (n >= 0x55555550ull) return fail(SVT_ERR_INVALID, "too many units in one batch");
-    if (in->n_libs == 0 || in->n_libs > 256 || !in->libs) return fail(SVT_ERR_INVALID, "n_libs must be 1..256");
-    if (n && (!in->rec_offset || !in->units)) return fail(SVT_ERR_INVALID, "null unit arrays");
-    if (n && in->rec_offset[0] != 0) return fail(SVT_ERR_INVALID, "rec_offset[0] must be 0");
-    const uint64_t n_rec = n ? in->rec_offset[n] : 0;
-    if (n_rec && !in->records) return fail(SVT_ERR_INVALID, "null records");
-    if (!(in->split_weight >= 0.0) || !(in->disc_weight >= 0.0) || !std::isfinite(in->split_weight) || !std::isfinite(in->disc_weight))
-        return fail(SVT_ERR_INVALID, "weights must be finite and >= 0");
-    for (uint64_t u = 0; u < n; ++u) {
-        if (in->rec_offset[u + 1] < in->rec_offset[u]) return fail(SVT_ERR_INVALID, "rec_offset not monotone");
-        if (in->rec_offset[u + 1] - in->rec_offset[u] > 0x3FFFFFFFull) return fail(SVT_ERR_INVALID, "unit with too many records");
-        const svt_unit& U = in->units[u];
-        if (U.svtype > SVT_SVTYPE_BND) return fail(SVT_ERR_INVALID, "bad svtype");
-        if ((U.libs >> 16) != 0 || (U.flags & ~SVT_UNIT_SKIP)) return fail(SVT_ERR_INVALID, "unit reserved/flags bits must be 0");
-    }
-    HostTables T;
-    SVT_TRY(build_tables(in, 0, T));
-    SVT_TRY(packable(in, T));
-    const LibDesc lib = T.libs[0];
-    const uint4* recs = reinterpret_cast<const uint4*>(in->records);
-
-    // the batch's most common (mapq_a, mapq_b) among the first records that keep a pair entry: any answer is
-    // correct, a good one makes the pair stream shorter
-    const uint32_t common = vote_common_mapq(recs, std::min<uint64_t>(n_rec, kVoteRecords));
-
+    const PackAlloc pool{[](uint64_t bytes) { return g_pinned.get(bytes); }, [](void* p) { g_pinned.put(p); }};
+    PackedArrays arr;
+    SVT_TRY(encode_packed(in, pool, &arr));
     auto owner = std::make_unique<PackedOwner>();
-    owner->off = static_cast<uint32_t*>(g_pinned.get((3 * n + 1) * sizeof(uint32_t)));
-    owner->units = static_cast<svt_unit*>(g_pinned.get(std::max<uint64_t>(n, 1) * sizeof(svt_unit)));
-    if (!owner->off || !owner->units) return fail(SVT_ERR_NOMEM, "out of host memory");
-    uint32_t* off = owner->off;
-    off[0] = 0u;
-    // ---- pass 1: contract check + slots per stream and unit
-    const uint64_t kChunk = 2048;
-    const uint64_t n_chunks = (n + kChunk - 1) / kChunk;
-    std::vector<uint32_t> bad_bits(std::max<uint64_t>(n_chunks, 1), 0u);
-    parallel_for(n_chunks, [&](uint64_t ch) {
-        uint32_t bad = 0;
-        for (uint64_t u = ch * kChunk; u < std::min(n, (ch + 1) * kChunk); ++u) {
-            const UnitGeom g = unit_geom(in->units[u]);
-            uint32_t n_short = 0, n_ref = 0, n_cand = 0;
-            for (uint64_t j = in->rec_offset[u]; j < in->rec_offset[u + 1]; ++j) {
-                const uint4 w = recs[j];
-                const uint32_t f = w.w;
-                if (!(f & SVT_REC_HAS_PAIR) && (f & 7u)) bad |= kErrStraddleNoPair;
-                if (SVT_REC_LIB(f) != 0u) bad |= kErrLibIndex;
-                if (f & ~SVT_REC_FLAG_MASK) bad |= kErrReservedBits;
-                if ((int32_t)w.x < 0) bad |= kErrNegativeSpan;
-                if (keeps_pair_entry(w, g, lib)) n_short += (w.y & 0xffffu) == common ? 1u : (n_short & 1u) + 2u;
-                uint32_t k[3];
-                weight_pairs(w, k);
-                n_ref += k[0] ? 1u : 0u;
-                n_cand += (k[1] ? 1u : 0u) + (k[2] ? 1u : 0u);
-            }
-            off[3 * u + 1] = (n_short + kHalfwordsPerRow - 1) / kHalfwordsPerRow;
-            off[3 * u + 2] = (n_ref + 6) / 7;
-            off[3 * u + 3] = (n_cand + 6) / 7;
-        }
-        bad_bits[ch] = bad;
-    });
-    uint32_t bad = 0;
-    for (uint32_t b : bad_bits) bad |= b;
-    if (bad) return record_error(bad);
-    uint64_t total = 0;
-    for (uint64_t i = 1; i <= 3 * n; ++i) {
-        total += off[i];
-        if (total >= 0xFFFFFFF0ull) return fail(SVT_ERR_UNSUPPORTED, "too many slots for 32-bit slot offsets");
-        off[i] = (uint32_t)total;
-    }
-    owner->slots = g_pinned.get(std::max<uint64_t>(total, 1) * 16);
-    if (!owner->slots) return fail(SVT_ERR_NOMEM, "out of host memory");
-    uint4* slots = static_cast<uint4*>(owner->slots);
-    // ---- pass 2: the three streams of every unit, in record order (the encoders of svt_entry_formats.h)
-    parallel_for(n_chunks, [&](uint64_t ch) {
-        for (uint64_t u = ch * kChunk; u < std::min(n, (ch + 1) * kChunk); ++u) {
-            const UnitGeom g = unit_geom(in->units[u]);
-            ShortRowWriter S{slots + off[3 * u]};
-            WeightRowWriter R{slots + off[3 * u + 1]}, X{slots + off[3 * u + 2]};
-            bool frag_has[3] = {false, false, false};
-            for (uint64_t j = in->rec_offset[u]; j < in->rec_offset[u + 1]; ++j) {
-                const uint4 w = recs[j];
-                if (!(w.w & SVT_REC_CONTINUATION)) frag_has[0] = frag_has[1] = frag_has[2] = false;
-                if (keeps_pair_entry(w, g, lib)) S.put((w.w & 7u) | (pair_code(w.x, g, lib) << 3), w.y & 0xffffu, common);
-                uint32_t k[3];
-                weight_pairs(w, k);
-                if (k[0]) { R.put(k[0], !frag_has[0]); frag_has[0] = true; }
-                for (int s = 1; s < 3; ++s)
-                    if (k[s]) { X.put(k[s], !frag_has[s], s == 2); frag_has[s] = true; }
-            }
-            S.finish(off[3 * u + 1] - off[3 * u]);
-            R.finish(off[3 * u + 2] - off[3 * u + 1]);
-            X.finish(off[3 * u + 3] - off[3 * u + 2]);
-        }
-    });
-    if (n) std::memcpy(owner->units, in->units, n * sizeof(svt_unit));
+    owner->off = arr.off;
+    owner->units = arr.units;
+    owner->slots = arr.slots;
     owner->hist.assign(in->libs[0].hist, in->libs[0].hist + in->libs[0].n_bins);
     owner->lib = in->libs[0];
     owner->lib.hist = owner->hist.data();
     svt_packed_evidence& P = owner->pub;
-    P.n_units = n;
-    P.n_slots = total;
-    P.n_records = n_rec;
+    P.n_units = in->n_units;
+    P.n_slots = arr.n_slots;
+    P.n_records = arr.n_records;
     P.slot_offset = owner->off;
     P.units = owner->units;
     P.slots = owner->slots;
-    P.common_mapq = common;
+    P.common_mapq = arr.common;
     P.n_libs = 1;
     P.libs = &owner->lib;
     P.split_weight = in->split_weight;
@@ -797,7 +676,9 @@ int create_packed(const svt_packed_evidence* in, svt_batch* b, bool defer_slots 
     shell.disc_weight = in->disc_weight;
     HostTables T;
     SVT_TRY(build_tables(&shell, max_f, T));
-    SVT_TRY(packable(&shell, T));
+    // the limits of the packed format (include/svtyper_hip.h), library side; the unit side was checked above
+    if (T.libs[0].n_bins > kMaxShortBins) return fail(SVT_ERR_UNSUPPORTED, "histogram too wide for the packed pair entries");
+    if (!T.fast_geometry) return fail(SVT_ERR_UNSUPPORTED, "library geometry outside the packed format's range");
     tm.mark("validate + tables");
     {
         Stager st(b->stream);

@@ -72,8 +72,14 @@ assert UNIT_DTYPE.itemsize == 16
 
 
 def unit_libs(first: int, count: int) -> int:
-    """SVT_UNIT_LIBS(first, count): the libraries of a unit's sample are libs[first .. first + count) of the batch."""
-    return int(first) | (int(count) << 8)
+    """SVT_UNIT_LIBS(first, count): the libraries of a unit's sample are libs[first .. first + count) of the batch.
+    The hint stores both numbers in 8 bits: a sample that cannot be described (no library, more than 255 libraries, a
+    first index beyond 255) gets 0 = "no hint" -- the pass then takes such a batch without windows instead of
+    rejecting it."""
+    first, count = int(first), int(count)
+    if count <= 0 or count > 255 or first > 255:
+        return 0
+    return first | (count << 8)
 
 RESULT_DTYPE = np.dtype(
     [

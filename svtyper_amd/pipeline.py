@@ -87,7 +87,7 @@ class UnitCollector:
             for lib in s.lib_dict.values():
                 self.lib_index[id(lib)] = len(self.lib_tables)
                 self.lib_tables.append(lib.table())
-            self.sample_libs.append(ev.unit_libs(first, len(self.lib_tables) - first) if len(self.lib_tables) > first else 0)
+            self.sample_libs.append(ev.unit_libs(first, len(self.lib_tables) - first))   # (0 = no hint when it does not fit)
         if len(self.lib_tables) > 256:
             raise ValueError("more than 256 libraries in one run are not supported by the evidence record")
         self.split_weight = split_weight
@@ -165,7 +165,7 @@ class NativeUnitCollector:
             base = len(self.lib_tables)
             libs = list(s.lib_dict.values())
             self.lib_tables.extend(lib.table() for lib in libs)
-            self.sample_libs.append(ev.unit_libs(base, len(libs)) if libs else 0)
+            self.sample_libs.append(ev.unit_libs(base, len(libs)))   # (0 = no hint when it does not fit)
             rgs = list(s.rg_to_lib.keys())
             idx = [base + libs.index(s.rg_to_lib[rg]) if s.rg_to_lib[rg].name in s.active_libs else -1 for rg in rgs]
             self.rg_tables.append((rgs, idx))

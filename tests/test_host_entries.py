@@ -42,3 +42,50 @@ def test_shard_bounds_balance_bytes_and_keep_groups_whole():
         cost = [int(16 * (off[hi] - off[lo]) + 112 * (hi - lo)) for lo, hi in b]
         biggest_group = 16 * int(counts.max()) * group + 112 * group
         assert max(cost) - min(cost) <= 2 * biggest_group or shards == 1
+
+
+def test_library_hint_that_does_not_fit_is_no_hint():
+    """SVT_UNIT_LIBS keeps first and count in 8 bits each: 256 libraries in one sample, or a sample whose first
+    library has index 256, must become `no hint` (0), never a value with reserved bits set."""
+    assert ev.unit_libs(3, 2) == (3 | 2 << 8)
+    assert ev.unit_libs(0, 255) == (255 << 8)
+    assert ev.unit_libs(0, 256) == 0 and ev.unit_libs(256, 1) == 0 and ev.unit_libs(5, 0) == 0
+    for first in range(0, 300, 37):
+        for count in (0, 1, 3, 255, 256, 300):
+            assert ev.unit_libs(first, count) >> 16 == 0
+
+
+def test_pinned_results_memory_lives_as_long_as_any_view():
+    """hip.pinned_results: the page-locked block belongs to the array (not to the Results wrapper), so code that keeps
+    only `.rec`, or a slice of it, keeps the memory."""
+    import gc
+    from svtyper_amd import hip
+    r = hip.pinned_results(100)
+    rec = r.rec
+    tail = rec[50:]
+    del r
+    gc.collect()
+    rec["sq"] = 1.5             # (the block comes from a pool: its old contents are whatever they were)
+    rec["gt"] = 0
+    tail["gt"] = 2
+    assert float(rec["sq"].sum()) == 150.0 and int(rec["gt"].sum()) == 100
+    base = tail
+    while getattr(base, "base", None) is not None:
+        base = base.base
+    assert hasattr(base, "_owner")          # the ctypes array that owns the pooled block
+    del rec, base
+    gc.collect()
+    assert int(tail["gt"].sum()) == 100      # still alive through the slice
+
+
+def test_out_buffers_are_checked_before_the_c_side_writes_through_them():
+    import pytest
+    from svtyper_amd import hip
+    small = hip.Results.empty(3)
+    with pytest.raises(ValueError):
+        hip._check_out(small, 4)
+    strided = hip.Results.empty(8)
+    strided.rec = strided.rec[::2]
+    with pytest.raises(ValueError):
+        hip._check_out(strided, 4)
+    assert hip._check_out(hip.Results.empty(4), 4).n_units == 4

@@ -1,0 +1,58 @@
+"""The host side of libsvtyper_hip.so under AddressSanitizer + UndefinedBehaviorSanitizer (SURVEY.md section 5 asked
+the new build for sanitizer runs of its native code; the reference has none).  `make -C svtyper_amd/csrc asan` builds
+the library once more with -fsanitize=address,undefined on the host code -- svt_reads.cpp parses untrusted BAM / BGZF /
+BAI bytes, svt_pack.cpp and svt_format.cpp index caller arrays -- and the host-side test files plus a bounded corpus of
+corrupted BAMs (tools/fuzz_bam.py) run against it in a subprocess with the sanitizer runtime preloaded.  A finding
+aborts that process (halt_on_error), which fails the test.  CPU only: no device is involved."""
+import glob
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "svtyper_amd", "csrc")
+ASAN_LIB = os.path.join(CSRC, "variants", "libsvtyper_hip_asan.so")
+
+
+@pytest.fixture(scope="module")
+def asan_env():
+    rt = sorted(glob.glob("/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so"))
+    if not rt or not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("no hipcc / clang sanitizer runtime in this image")
+    r = subprocess.run(["make", "-s", "-C", CSRC, "asan"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and os.path.exists(ASAN_LIB), r.stderr[-3000:]
+    syms = subprocess.run(["nm", "-D", ASAN_LIB], capture_output=True, text=True).stdout
+    assert "__asan_init" in syms and "__ubsan_handle" in syms, "the library is not instrumented"
+    return dict(os.environ, LD_PRELOAD=rt[-1], SVTYPER_HIP_LIB=ASAN_LIB, SVT_ALLOW_NO_GPU="1",
+                ASAN_OPTIONS="detect_leaks=0:halt_on_error=1:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+
+
+def test_the_sanitizer_reports_through_this_setup(asan_env):
+    """a deliberate heap overflow inside an instrumented call must kill the child: proves the runtime is live"""
+    code = ("import ctypes as C, os\n"
+            "L = C.CDLL(os.environ['SVTYPER_HIP_LIB'])\n"
+            "buf = (C.c_uint8 * 64)()\n"      # 64 bytes where svt_results_host_sq expects 2 * 128
+            "L.svt_results_host_sq.argtypes = [C.c_void_p, C.c_uint64]\n"
+            "import ctypes.util\n"
+            "libc = C.CDLL(None); libc.malloc.restype = C.c_void_p; p = libc.malloc(64)\n"
+            "L.svt_results_host_sq(C.c_void_p(p), 2)\n"
+            "print('survived')\n")
+    r = subprocess.run([sys.executable, "-c", code], env=asan_env, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "AddressSanitizer" in r.stderr and "survived" not in r.stdout, (r.returncode, r.stderr[-500:])
+
+
+def test_host_side_tests_under_asan_and_ubsan(asan_env):
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "not gpu", "-p", "no:cacheprovider",
+                        "tests/test_native_reads.py", "tests/test_packed_evidence.py", "tests/test_cpp_helpers.py",
+                        "tests/test_host_entries.py"], cwd=ROOT, env=asan_env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-3000:])
+    assert " passed" in r.stdout and "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr
+
+
+def test_corrupted_bams_under_asan_and_ubsan(asan_env):
+    env = dict(asan_env, SVT_FUZZ_ITERS="18")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_bam.py")], cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-2000:])
+    assert "crash" not in r.stdout and ("ok" in r.stdout or "error" in r.stdout), r.stdout[-1000:]

@@ -29,7 +29,7 @@ json.dump(info, open(os.path.join(tmp, "info.json"), "w")); json.dump(sites, ope
 raw = open(good, "rb").read(); bai = open(good + ".bai", "rb").read()
 rng = random.Random(5)
 outcomes = {}
-for it in range(60):
+for it in range(int(os.environ.get('SVT_FUZZ_ITERS', '60'))):
     b = bytearray(raw)
     mode = it % 3
     if mode == 0:
@@ -46,3 +46,5 @@ for it in range(60):
     outcomes[key] = outcomes.get(key, 0) + 1
     if r.returncode != 0: print(it, mode, r.stderr[-300:])
 print(outcomes)
+if any(k.startswith("crash") for k in outcomes):
+    sys.exit(1)
