@@ -51,6 +51,19 @@ struct WeightStream {
             k = bits = 0u;
         }
     }
+    // the same without a data-dependent branch: the entry is written either way and kept when keep = 1 (whether a record
+    // has a reference read is close to a coin toss, which the branch predictor loses)
+    inline void put_if(const uint32_t mapq_pair, const uint32_t keep, const uint32_t first)
+    {
+        row[k] = (uint16_t)mapq_pair;
+        bits |= (keep & first) << k;
+        k += keep;
+        if (k == 7u) {
+            row[7] = (uint16_t)bits;
+            row += 8;
+            k = bits = 0u;
+        }
+    }
     inline uint32_t finish()    // slots used
     {
         if (k) {
@@ -101,6 +114,9 @@ uint32_t vote_common_mapq(const Slot* recs, uint64_t n_vote)
     return common;
 }
 
+#ifndef SVT_PACK_BRANCHLESS_REF
+#define SVT_PACK_BRANCHLESS_REF 1
+#endif
 constexpr uint64_t kChunkUnits = 256;
 static_assert(SVT_REC_CONTINUATION == (1u << 3) && SVT_REC_HAS_PAIR == (1u << 4), "bit positions used by the encoder's loop");
 
@@ -181,7 +197,9 @@ int encode_packed(const svt_evidence_batch* in, const PackAlloc& A, PackedArrays
     out->common = common;
     mark("tables + allocations");
     const uint64_t n_chunks = (n + kChunkUnits - 1) / kChunkUnits;
-    const unsigned nt = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(std::min(usable_cpus(), 16u), n_chunks));
+    unsigned want = std::min(usable_cpus(), 16u);
+    if (const char* e = std::getenv("SVT_PACK_THREADS")) want = (unsigned)std::max(1, std::atoi(e));   // (measurements)
+    const unsigned nt = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(want, n_chunks));
     std::vector<Worker> workers(nt);
     std::vector<ChunkOut> chunks(n_chunks);
 
@@ -244,7 +262,12 @@ int encode_packed(const svt_evidence_batch* in, const PackAlloc& A, PackedArrays
                         S.put((fl & 7u) | (code << 3), w.y & 0xffffu, common);
                     }
                     const uint32_t k_ref = w.y >> 16, k_seq = w.z & 0xffffu, k_clip = w.z >> 16;   // gated MAPQ pairs; 0 = nothing to add
+#if SVT_PACK_BRANCHLESS_REF
+                    R.put_if(k_ref, k_ref ? 1u : 0u, has_r ? 0u : 1u);
+                    has_r |= k_ref != 0u;
+#else
                     if (k_ref) { R.put(k_ref, !has_r, false); has_r = true; }
+#endif
                     if (k_seq) { X.put(k_seq, !has_s, false); has_s = true; }
                     if (k_clip) { X.put(k_clip, !has_c, true); has_c = true; }
                 }
