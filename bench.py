@@ -574,18 +574,36 @@ def main():
                 out["sso"] = {"error": repr(e)}
 
         if c5_batch is not None:
-            # ---- BASELINE.json configs[4] shape at the headline's size: (site, sample) units, 32 samples, per-sample libraries
+            # ---- BASELINE.json configs[4] shape at the headline's size: (site, sample) units, 32 samples, per-sample libraries.
+            # The producer hands the units over SAMPLE-MAJOR (it reads BAM by BAM; a sample's units, which share its library
+            # window, are then contiguous in HBM) and svt_batch_result_order makes the pass write the records SITE-MAJOR, the
+            # order QUAL, the shard rule and the VCF writer use.  `site_major_input`: the same units handed over site-major.
             try:
-                with hip.DeviceBatch(c5_batch, device=local_rank, flags=sso) as dc:
+                from svtyper_amd import synth
+                sm_batch, _ = synth.to_sample_major(c5_batch, N_SAMPLES_C5)
+                with hip.DeviceBatch(sm_batch, device=local_rank, flags=sso) as dc:
+                    dc.result_order(N_SAMPLES_C5)
                     dc.genotype(sync=True)
                     c_ms = time_passes(dc, args.steps)
                     c_alg, _ = dc.bytes()
                     c_mode = dc.table_mode()
-                leg = roofline_of(c_ms, c_alg, "c5_windows", c5_batch.n_units, c5_batch.n_records)
+                    c_res = dc.results().rec
+                    c_qual = dc.site_qual(N_SAMPLES_C5)
+                leg = roofline_of(c_ms, c_alg, "c5_windows", sm_batch.n_units, sm_batch.n_records)
                 leg.update(what="configs[4] shape: %d sites x %d samples, %d libraries, every unit carries its sample's library window "
-                                "(svt_unit.libs); one launch of the library-window kernel" % (c5_batch.n_units // N_SAMPLES_C5, N_SAMPLES_C5, len(c5_batch.libs)),
-                           kernel="svt_stream_kernel<windows>", table_mode=c_mode, units=c5_batch.n_units, records=c5_batch.n_records,
-                           units_per_s=c5_batch.n_units / (c_ms * 1e-3), sites_per_s=c5_batch.n_units / N_SAMPLES_C5 / (c_ms * 1e-3))
+                                "(svt_unit.libs); units handed over sample-major, result records written site-major "
+                                "(svt_batch_result_order); one launch of the library-window kernel"
+                                % (c5_batch.n_units // N_SAMPLES_C5, N_SAMPLES_C5, len(c5_batch.libs)),
+                           kernel="svt_stream_kernel<windows>", table_mode=c_mode, units=sm_batch.n_units, records=sm_batch.n_records,
+                           units_per_s=sm_batch.n_units / (c_ms * 1e-3), sites_per_s=sm_batch.n_units / N_SAMPLES_C5 / (c_ms * 1e-3))
+                del sm_batch
+                with hip.DeviceBatch(c5_batch, device=local_rank, flags=sso) as dc:
+                    dc.genotype(sync=True)
+                    s_ms = time_passes(dc, args.steps)
+                    same = bool(np.array_equal(dc.results().rec, c_res)) and bool(np.array_equal(dc.site_qual(N_SAMPLES_C5), c_qual))
+                leg["site_major_input"] = {"kernel_ms": s_ms, "frac": c_alg / (s_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                           "results_and_site_qual_equal": same}
+                del c_res
                 # the same batch WITHOUT the hints: any-geometry mode, histogram tables through L2
                 nh_units = c5_batch.units.copy()
                 nh_units["libs"] = 0

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SVT_ABI_VERSION 10
+#define SVT_ABI_VERSION 11
 
 /* ---- error codes (0 = ok, <0 = error; text via svt_last_error()) ---------- */
 #define SVT_OK 0
@@ -315,6 +315,19 @@ int svt_batch_device_results(svt_batch* b, svt_result** dev_ptr);
  * gathered over RCCL).  The buffer must stay alive until svt_batch_destroy or the next bind;
  * pass NULL to return to the library's own buffer.                                         */
 int svt_batch_bind_device_results(svt_batch* b, svt_result* dev_ptr);
+
+/* Result order for a SAMPLE-MAJOR batch.  A joint run over several samples has one unit per (site, sample).  The
+ * reference walks them site-major (classic.py:279: for every variant, for every sample), and that is the order
+ * svt_batch_site_qual, the shard rule's `group` and the VCF writer want the RESULTS in.  The EVIDENCE, however, is
+ * produced BAM by BAM, and a sample's units -- which share that sample's library window (svt_unit.libs) -- are best
+ * contiguous in HBM: the pass then streams them like a one-library batch (a unit's first and last 128-byte line
+ * are shared with its neighbours of the same workgroup instead of with 31 other samples' units).  So a producer
+ * may hand over the units sample-major -- all sites of sample 0, then all sites of sample 1, ...: unit index
+ * i = sample * n_sites + site, n_units = n_samples * n_sites -- and call this before svt_batch_genotype: the pass
+ * then writes the record of unit i to index (i % n_sites) * n_samples + i / n_sites, i.e. the result array
+ * (svt_batch_results, svt_batch_device_results, svt_batch_site_qual) is site-major, exactly as if the units had
+ * been handed over site-major.  n_samples = 0 or 1 restores unit order.  Canonical records only.               */
+int svt_batch_result_order(svt_batch* b, uint32_t n_samples);
 
 /* Bytes the genotype kernel must move per pass by the definition of SURVEY.md
  * section 8(d): sum_u (16*F(u) + 16 + 96); and what the batch really holds in

@@ -40,6 +40,9 @@
 #ifndef SVT_STREAM_ONE_TRIP
 #define SVT_STREAM_ONE_TRIP 0  // record_single: both decision-table candidates are read with the first look-ups (no dependent LDS read)
 #endif
+#ifndef SVT_WINDOW_ONE_TRIP
+#define SVT_WINDOW_ONE_TRIP 0  // record_window: the same for windows of several libraries
+#endif
 #ifndef SVT_STREAM_PIPELINED
 #define SVT_STREAM_PIPELINED 0 // one-library blocks: explicit two-stage look-up pipeline (look_issue / look_use); 0 = record_single
 #endif
@@ -111,13 +114,14 @@ struct StreamArgs {
     svt_result* out;
     uint32_t* err;
     // kMultiLds: units grouped by the library window of their sample (svt_unit.libs)
-    const uint32_t* perm;        // unit indices, grouped by window, original order inside a group
+    const uint32_t* perm;        // unit indices, grouped by window, original order inside a group; nullptr = the identity
     const uint2* chunks;         // one per workgroup: {first position in perm, units (<= 256 * R)} -- never crosses a group
     const WgDesc* windows;       // one per workgroup: the libraries / bins it stages
     uint32_t lds_winlibs;        // byte offset of the WinLib descriptors (after the bins)
     uint32_t unit_begin;         // this launch covers units [unit_begin, unit_end) (the pipelined one-shot launches
     uint32_t unit_end;           // one range per uploaded piece; a pass over a resident batch: [0, n_units))
-    uint32_t pad0;
+    uint32_t out_samples;        // svt_batch_result_order: > 1 = the units are sample-major (unit = sample * out_sites + site) and the
+    uint32_t out_sites;          // result record of a unit goes to index site * out_samples + sample (site-major); 0 = unit order
     LibDesc lib0;
     GtConsts c;
 };
@@ -337,6 +341,7 @@ struct WindowCtx {
     uint32_t winlibs_at;   // LDS byte address of the window's WinLib descriptors
     uint32_t vl_or_never;  // DEL ? var_length : 0x80000000 - key_min is added per library
     uint32_t wt0, wt1;
+    uint32_t wh0;          // LDS address of w_alt_hi[del16]
     double pos_delta_d;
     bool is_del;
 };
@@ -361,12 +366,24 @@ __device__ __forceinline__ void record_window(const u32x4 w, const bool mine, co
     const uint32_t f3 = small_del ? 0u : (w.w & 7u);
     const uint32_t sub2 = c.is_del ? c.vl_or_never + d.x : 0x80000000u;
     const uint32_t i1 = min(w.x - d.x, d.y), i2 = min(w.x - sub2, d.y);
+#if SVT_WINDOW_ONE_TRIP
+    // the decision table is read for both values of p_concordant beside thr / hist (high words: the weights are 0, 0.5, 1):
+    // two dependent LDS round trips per record (descriptor, then everything else) instead of three
+    const uint32_t wt = c.wh0 | (f3 << 2);
+    const uint32_t wa0 = lds_u32(wt), wa1 = lds_u32(wt + 8u * 4u), wr1 = lds_u32(wt + kSWhiRef + 8u * 4u);
+    const int32_t thr1 = lds_i16(d.z + (i1 << 1));
+    const uint32_t h2 = lds_u16(d.w + (i2 << 1));
+    const bool p_conc = (int32_t)h2 <= thr1;
+    a.alt_span += pp * __hiloint2double((int)(p_conc ? wa1 : wa0), 0);
+    a.ref_span += pp * __hiloint2double((int)(p_conc ? wr1 : 0u), 0);
+#else
     const int32_t thr1 = lds_i16(d.z + (i1 << 1));
     const uint32_t h2 = lds_u16(d.w + (i2 << 1));
     const bool p_conc = (int32_t)h2 <= thr1;
     const uint32_t wa = (p_conc ? c.wt1 : c.wt0) | (f3 << 3);
     a.alt_span += pp * lds_f64(wa);
     a.ref_span += pp * lds_f64(wa + kSWref);
+#endif
 }
 
 template <bool SSO, int MODE, int R>
@@ -394,7 +411,8 @@ __global__ __launch_bounds__(kBlock, MODE == kSingleLds ? SVT_STREAM_WAVES : MOD
     } else {
         n_here = min(kUnitsPerWg, a.unit_end - wg_base);
     }
-    auto unit_at = [&](const uint32_t local) -> uint32_t { return MODE == kMultiLds ? a.perm[wg_base + local] : wg_base + local; };
+    // (library windows: a.perm == nullptr when the units already come grouped by window)
+    auto unit_at = [&](const uint32_t local) -> uint32_t { return MODE == kMultiLds && a.perm ? a.perm[wg_base + local] : wg_base + local; };
 
     // ---- this thread's R units: record range and sort key (the loads overlap the table staging below)
     uint32_t beg[R], cnt[R];
@@ -573,6 +591,7 @@ __global__ __launch_bounds__(kBlock, MODE == kSingleLds ? SVT_STREAM_WAVES : MOD
         wc.vl_or_never = (uint32_t)U.var_length;
         wc.wt0 = sc.wt0;
         wc.wt1 = sc.wt1;
+        wc.wh0 = sc.wh0;
         wc.pos_delta_d = c.pos_delta_d;
         wc.is_del = c.is_del;
         Acc acc = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
@@ -626,6 +645,12 @@ __global__ __launch_bounds__(kBlock, MODE == kSingleLds ? SVT_STREAM_WAVES : MOD
             }
         };
 
+        // kL10Ring: the log10 table of the epilogue goes through the wave's ring once the tile's last block has left it
+        auto l10_into_ring = [&]() {
+            const char* l10_bytes = reinterpret_cast<const char*>(a.l10);
+            for (uint32_t off = 0; off < a.n_l10 * 8u; off += 1024u)
+                __builtin_amdgcn_global_load_lds(l10_bytes + off + lane * 16u, (lds_void_ptr)(ring + off), 16, 0, 0);
+        };
         if (max_blk) {
             fetch_first();
             u32x4 w[8];
@@ -648,6 +673,7 @@ __global__ __launch_bounds__(kBlock, MODE == kSingleLds ? SVT_STREAM_WAVES : MOD
                 } else {
                     read_block(lane_block, sw16, w);
                     if (SVT_STREAM_PROBE != 2 && k + 1 < max_blk) fetch(k + 1);
+                    else if (a.l10_where == kL10Ring) l10_into_ring();   // the tile's last block has left the ring: the copy lands while it is summed
                 }
                 if (SVT_FETCH_PRIO) __builtin_amdgcn_s_setprio(0);
                 const uint32_t k8 = k * kBlockRecords;
@@ -685,9 +711,7 @@ __global__ __launch_bounds__(kBlock, MODE == kSingleLds ? SVT_STREAM_WAVES : MOD
         // ---- epilogue: the log10 table of log_choose sits beside the tables, or goes through the (now idle) ring
         const double* lds_l10 = reinterpret_cast<const double*>(a.l10_where == kL10Shared ? smem + a.lds_l10 : ring);
         if (a.l10_where == kL10Ring) {
-            const char* l10_bytes = reinterpret_cast<const char*>(a.l10);
-            for (uint32_t off = 0; off < a.n_l10 * 8u; off += 1024u)
-                __builtin_amdgcn_global_load_lds(l10_bytes + off + lane * 16u, (lds_void_ptr)(ring + off), 16, 0, 0);
+            if (!max_blk || kStreamDepth == 2) l10_into_ring();   // (an empty tile never entered the loop; two stages: copied here)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         uint4 piece[8];
@@ -701,7 +725,13 @@ __global__ __launch_bounds__(kBlock, MODE == kSingleLds ? SVT_STREAM_WAVES : MOD
         } else
         unit_epilogue(acc, (uint32_t)U.svtype, (uint32_t)U.flags, a.c, lds_l10, a.l10, a.l10_where != kL10Global, piece);
 
-        if (!(SVT_PROBE_SKIP & 2)) store_results_through_ring(ring, piece, unit, lane, a.out);
+        // where the record goes: the unit's own index, or (svt_batch_result_order) the site-major index of a sample-major unit
+        uint32_t unit_out = unit;
+        if (a.out_samples > 1u && unit != kPadUnit) {
+            const uint32_t sample = unit / a.out_sites;
+            unit_out = (unit - sample * a.out_sites) * a.out_samples + sample;
+        }
+        if (!(SVT_PROBE_SKIP & 2)) store_results_through_ring(ring, piece, unit_out, lane, a.out);
         else if (piece[0].x == 0x12345u && piece[2].y == 77u) a.out[unit].sq = 1.0;
     }
     const uint32_t bad = check.bits(MODE == kMultiLds ? wd.lib_cnt : a.n_libs);

@@ -46,6 +46,9 @@
 
 #include "../../include/svtyper_hip.h"
 
+#ifndef SVT_WINDOW_TILES
+#define SVT_WINDOW_TILES 2   // library-window mode: tiles per wave of large launches (1 = always one)
+#endif
 #ifndef SVT_STREAM_R
 #define SVT_STREAM_R 1   // streaming kernel: 64-unit tiles per wave (a workgroup sorts 256 * R consecutive units)
 #endif
@@ -98,6 +101,7 @@ struct svt_batch {
     WgDesc* d_windows = nullptr;
     uint64_t cap_perm = 0;
     uint32_t n_chunks = 0;
+    int window_tiles = 1;            // kMultiLds: 64-unit tiles per wave (chunks hold up to 256 * window_tiles units)
     StreamArgs sargs{};
     // kLayoutPacked: packed evidence as uploaded (svt_packed_kernel.h); d_records holds the slots, d_soff the 3n+1 offsets
     uint32_t* d_soff = nullptr;
@@ -166,6 +170,7 @@ template <bool SSO>
 const void* stream_kernel_for(int mode, int tiles)
 {
     if (mode == kSingleLds && tiles == 2) return reinterpret_cast<const void*>(&svt_stream_kernel<SSO, kSingleLds, 2>);
+    if (mode == kMultiLds && tiles == 2) return reinterpret_cast<const void*>(&svt_stream_kernel<SSO, kMultiLds, 2>);
     return mode == kSingleLds  ? reinterpret_cast<const void*>(&svt_stream_kernel<SSO, kSingleLds, SVT_STREAM_R>)
            : mode == kMultiLds ? reinterpret_cast<const void*>(&svt_stream_kernel<SSO, kMultiLds, SVT_STREAM_R>)
                                : reinterpret_cast<const void*>(&svt_stream_kernel<SSO, kGeneral, SVT_STREAM_R>);
@@ -239,7 +244,7 @@ int launch_genotype(svt_batch* b)
     if (b->mode != kMultiLds) return launch_stream(b, b->sargs, b->stream);
     const dim3 grid(b->n_chunks), block(kBlock);   // library windows: one workgroup per chunk of a window's units
     void* params[] = {&b->sargs};
-    HIP_TRY(hipLaunchKernel(stream_kernel_of(b), grid, block, params, b->lds_bytes, b->stream));
+    HIP_TRY(hipLaunchKernel(stream_kernel_of(b, b->window_tiles), grid, block, params, b->lds_bytes, b->stream));
     return SVT_OK;
 }
 
@@ -326,7 +331,10 @@ int create_stream(const svt_evidence_batch* in, svt_batch* b, void* d_records_re
     // ---- several libraries: when every unit says which libraries its sample owns (svt_unit.libs), group the
     // units by that window -- a permutation of 4 bytes per unit, the records stay where they are -- and cut the
     // groups into workgroup chunks; a workgroup then stages only its window's histograms
-    constexpr uint32_t kUnitsPerWg = kBlock * SVT_STREAM_R;
+    // library windows: two tiles per wave for launches that need more than one round of resident workgroups anyway
+    // (the same rule and the same reason as tiles_per_wave for one library)
+    b->window_tiles = (SVT_STREAM_R == 1 && SVT_WINDOW_TILES == 2 && n >= kTwoTilesMinUnits) ? 2 : SVT_STREAM_R;
+    const uint32_t kUnitsPerWg = (uint32_t)kBlock * (uint32_t)b->window_tiles;
     std::vector<uint32_t> perm;
     std::vector<uint2> chunks;
     std::vector<WgDesc> windows;
@@ -424,9 +432,15 @@ int create_stream(const svt_evidence_batch* in, svt_batch* b, void* d_records_re
     if (windowed) {
         Stager st(b->stream);
         void* pp = nullptr;
-        SVT_TRY(g_pool.get(b->device, std::max<uint64_t>(n, 1) * sizeof(uint32_t), &pp, &b->cap_perm));
-        b->d_perm = static_cast<uint32_t*>(pp);
-        SVT_TRY(st.copy(b->d_perm, perm.data(), n * sizeof(uint32_t)));
+        // units that already come grouped by window (a sample-major batch, a one-window batch) need no permutation:
+        // the kernel then walks the units themselves (no index loads in front of every unit header)
+        bool identity = true;
+        for (uint64_t u = 0; u < n && identity; ++u) identity = perm[u] == (uint32_t)u;
+        if (!identity) {
+            SVT_TRY(g_pool.get(b->device, std::max<uint64_t>(n, 1) * sizeof(uint32_t), &pp, &b->cap_perm));
+            b->d_perm = static_cast<uint32_t*>(pp);
+            SVT_TRY(st.copy(b->d_perm, perm.data(), n * sizeof(uint32_t)));
+        }
         SVT_TRY(upload(&b->d_chunks, chunks, st));
         SVT_TRY(upload(&b->d_windows, windows, st));
         SVT_TRY(st.finish());
@@ -478,7 +492,8 @@ int create_stream(const svt_evidence_batch* in, svt_batch* b, void* d_records_re
     if (b->lds_bytes > 160 * 1024) return fail(SVT_ERR_INVALID, "LDS budget exceeded");
     if (b->lds_bytes > 64 * 1024)
         for (int tiles = 1; tiles <= 2; ++tiles)
-            HIP_TRY(hipFuncSetAttribute(stream_kernel_of(b, tiles), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_bytes));
+            if (b->mode != kGeneral || tiles == 1)
+                HIP_TRY(hipFuncSetAttribute(stream_kernel_of(b, tiles), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_bytes));
     return SVT_OK;
 }
 
@@ -1079,6 +1094,22 @@ static int svt_batch_results_impl(svt_batch* b, svt_result* out, uint64_t n_unit
 int svt_batch_results(svt_batch* b, svt_result* out, uint64_t n_units)
 {
     return guarded([&] { return svt_batch_results_impl(b, out, n_units); });
+}
+
+int svt_batch_result_order(svt_batch* b, uint32_t n_samples)
+{
+    if (!b) return fail(SVT_ERR_INVALID, "null batch");
+    if (b->layout != kLayoutStream) return fail(SVT_ERR_INVALID, "svt_batch_result_order: canonical records only (not packed evidence)");
+    if (n_samples <= 1) {
+        b->sargs.out_samples = 0;
+        b->sargs.out_sites = 0;
+        return SVT_OK;
+    }
+    if (b->n_units % n_samples) return fail(SVT_ERR_INVALID, "svt_batch_result_order: n_units is not a multiple of n_samples");
+    b->sargs.out_samples = n_samples;
+    b->sargs.out_sites = (uint32_t)(b->n_units / n_samples);
+    b->have_results = false;   // (records written in the other order are not results of this order)
+    return SVT_OK;
 }
 
 int svt_batch_device_results(svt_batch* b, svt_result** dev)

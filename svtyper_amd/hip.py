@@ -16,13 +16,13 @@ from .evidence import GT_BLANK, CEvidenceBatch, CPackedEvidence, EvidenceBatch, 
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SVTYPER_HIP_LIB") or os.path.join(_HERE, "csrc", "libsvtyper_hip.so")
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 EXPORTS = (
     "svt_version", "svt_device_count", "svt_last_error", "svt_batch_create", "svt_batch_create_from_fragments",
     "svt_batch_genotype",
     "svt_batch_genotype_n", "svt_batch_genotype_timed", "svt_batch_results", "svt_batch_device_results",
-    "svt_batch_bind_device_results", "svt_batch_bytes", "svt_batch_layout", "svt_batch_site_qual",
+    "svt_batch_bind_device_results", "svt_batch_result_order", "svt_batch_bytes", "svt_batch_layout", "svt_batch_site_qual",
     "svt_batch_stream", "svt_batch_destroy", "svt_trim", "svt_bayes_gt", "svt_genotype_counts", "svt_genotype", "svt_genotype_multi", "svt_shard_bounds",
     "svt_pinned_alloc", "svt_pinned_free", "svt_pack_evidence", "svt_packed_free", "svt_batch_create_packed", "svt_genotype_packed",
     "svt_format_results", "svt_format_free", "svt_results_host_sq",
@@ -71,6 +71,8 @@ def load() -> C.CDLL:
     L.svt_batch_genotype_timed.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float)]
     L.svt_batch_results.restype = C.c_int
     L.svt_batch_results.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+    L.svt_batch_result_order.restype = C.c_int
+    L.svt_batch_result_order.argtypes = [C.c_void_p, C.c_uint32]
     L.svt_batch_device_results.restype = C.c_int
     L.svt_batch_device_results.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
     L.svt_batch_bind_device_results.restype = C.c_int
@@ -318,6 +320,11 @@ class DeviceBatch:
         out = Results.empty(self.n_units) if out is None else _check_out(out, self.n_units)
         _check(self._lib.svt_batch_results(self._h, C.c_void_p(out.ptr()), self.n_units))
         return out
+
+    def result_order(self, n_samples: int):
+        """svt_batch_result_order: the units are sample-major (unit = sample * n_sites + site); the pass writes their
+        records site-major (index site * n_samples + sample).  0 / 1 = unit order."""
+        _check(self._lib.svt_batch_result_order(self._h, int(n_samples)))
 
     def device_results_ptr(self) -> int:
         """Device address of the svt_result[n_units] array the kernel writes to."""

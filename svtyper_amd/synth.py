@@ -285,3 +285,21 @@ def make_edge_cases(libs: Sequence[LibraryTable], seed: int = 1) -> EvidenceBatc
     d.records["mapq_b"] = 60
     parts.append(d)
     return ev.concat_batches(parts)
+
+
+def to_sample_major(batch, n_samples: int):
+    """The same (site, sample) units reordered from site-major (unit = site * n_samples + sample: what a joint
+    caller walks, svtyper/classic.py:279) to sample-major (all sites of sample 0, then sample 1, ...: what a producer
+    that reads BAM by BAM emits).  Returns (batch, order) with new unit k = old unit order[k].  Pair with
+    hip.DeviceBatch.result_order(n_samples): the results then come back site-major."""
+    n = batch.n_units
+    if n % n_samples:
+        raise ValueError("n_units must be a multiple of n_samples")
+    n_sites = n // n_samples
+    order = (np.arange(n_sites, dtype=np.int64)[None, :] * n_samples + np.arange(n_samples, dtype=np.int64)[:, None]).reshape(-1)
+    off = batch.rec_offset.astype(np.int64)
+    cnt = (off[1:] - off[:-1])[order]
+    new_off = np.zeros(n + 1, np.uint64)
+    new_off[1:] = np.cumsum(cnt)
+    src = np.repeat(off[:-1][order] - new_off[:-1].astype(np.int64), cnt) + np.arange(int(new_off[-1]), dtype=np.int64)
+    return ev.EvidenceBatch(new_off, batch.units[order], batch.records[src], batch.libs, batch.split_weight, batch.disc_weight), order

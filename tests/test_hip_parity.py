@@ -730,3 +730,67 @@ def test_pipelined_one_shot_equals_the_resident_batch(hip_device, fixture_librar
     with hip.DeviceBatch(ms, hip_device) as d:
         d.genotype(sync=True)
         assert hip.genotype_batch(ms, hip_device).rec.tobytes() == d.results().rec.tobytes()
+
+
+def test_sample_major_units_come_back_site_major(hip_device, fixture_library):
+    """svt_batch_result_order: the same (site, sample) units handed over sample-major (what a producer that reads BAM by
+    BAM emits; a sample's units are then contiguous in HBM) with the results scattered back site-major must give the
+    bytes of the site-major batch -- in the library-window mode, without hints (general mode), with one library,
+    for both associations, for launches of one and of two tiles per wave -- and QUAL over a site's samples
+    (svt_batch_site_qual reads the site-major result array) must not change either."""
+    from svtyper_amd import hip
+    n_samples = 32
+    for n_sites, tag in ((150, "one tile"), (7500, "two tiles")):          # 240 000 units >= the two-tile threshold
+        site = synth.make_multisample(n_sites, n_samples, seed=11, mean_frags=12 if n_sites > 1000 else 40, sd_frags=5,
+                                      min_frags=2, max_frags=40 if n_sites > 1000 else 90)
+        samp, order = synth.to_sample_major(site, n_samples)
+        assert samp.n_units == site.n_units and np.array_equal(samp.units, site.units[order])
+        for flags in (0, ev.FLAG_SSO_ASSOCIATION):
+            with hip.DeviceBatch(site, hip_device, flags) as d:
+                assert d.table_mode() == 1
+                d.genotype(sync=True)
+                want = d.results()
+                want_q = d.site_qual(n_samples)
+            with hip.DeviceBatch(samp, hip_device, flags) as d:
+                assert d.table_mode() == 1
+                d.genotype(sync=True)
+                plain = d.results()                               # unit order = sample-major
+                d.result_order(n_samples)
+                d.genotype(sync=True)
+                got = d.results()
+                got_q = d.site_qual(n_samples)
+                d.result_order(0)
+                d.genotype(sync=True)
+                back = d.results()
+            assert plain.rec.tobytes() == want.rec[order].tobytes(), tag
+            assert got.rec.tobytes() == want.rec.tobytes(), tag
+            assert back.rec.tobytes() == plain.rec.tobytes(), tag
+            assert got_q.tobytes() == want_q.tobytes(), tag
+        if n_sites > 1000:
+            continue
+        # the general mode (no hints) and a one-library batch take the same scatter
+        nh_site = synth.permute_units(site, np.arange(site.n_units))
+        nh_site.units["libs"] = 0
+        nh_samp = synth.permute_units(samp, np.arange(samp.n_units))
+        nh_samp.units["libs"] = 0
+        with hip.DeviceBatch(nh_samp, hip_device, 0) as d:
+            assert d.table_mode() == 2
+            d.result_order(n_samples)
+            d.genotype(sync=True)
+            assert d.results().rec.tobytes() == want0(nh_site, hip_device).rec.tobytes()
+    one = synth.make_units(640, 3, [fixture_library])
+    o_samp, o_order = synth.to_sample_major(one, 4)
+    with hip.DeviceBatch(o_samp, hip_device, 0) as d:
+        assert d.table_mode() == 0
+        d.result_order(4)
+        d.genotype(sync=True)
+        assert d.results().rec.tobytes() == want0(one, hip_device).rec.tobytes()
+        with pytest.raises(hip.SvtyperHipError):
+            d.result_order(7)                                     # 640 units are not a multiple of 7
+
+
+def want0(batch, device):
+    from svtyper_amd import hip
+    with hip.DeviceBatch(batch, device, 0) as d:
+        d.genotype(sync=True)
+        return d.results()
