@@ -241,8 +241,11 @@ def main():
         batch = total.slice(lo, hi)
         counts = [b[1] - b[0] for b in bounds]
         total_units = total.n_units
-        del total
+        if rank != 0 or world == 1:
+            del total        # rank 0 keeps the whole workload: after the gather it runs it alone and compares the bytes
+            total = None
     else:
+        total = None
         batch = generate(args.workload, args.units, rank, workers)
         counts = [batch.n_units] * world
         total_units = batch.n_units * world
@@ -331,6 +334,16 @@ def main():
         gather = {"bytes_per_rank": int(cur), "ms": g_s * 1e3,
                   "GB/s_into_root": sum(counts[1:] or counts) * ev.RESULT_DTYPE.itemsize / g_s / 1e9,
                   "collective": "rccl gather", "units_per_rank": counts}
+        if rank == 0 and args.scaling == "strong" and total is not None:
+            # the sharded job against the same workload on one rank: the gathered records must be the same bytes
+            with hip.DeviceBatch(total, device=local_rank, flags=flags) as d_all:
+                d_all.genotype(sync=True)
+                alone = d_all.results().rec
+            same = bool(np.array_equal(D.results_from_bytes(gathered).rec, alone))
+            gather["equals_single_rank_pass"] = same
+            assert same, "the gathered result records differ from the single-rank pass over the same workload"
+            del alone
+            total = None
 
     if rank == 0:
         got = dbatch.results()

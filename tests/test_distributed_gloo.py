@@ -18,7 +18,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out_path):
+def _worker(rank, world, port, out_path, scenario="c3"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     sys.path.insert(0, ROOT)
@@ -29,11 +29,19 @@ def _worker(rank, world, port, out_path):
     from svtyper_amd import synth
 
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    lib = synth.normal_library(n=50000)
-    batch = synth.make_units(3001, 77, [lib], svtype_mix=(0.6, 0.2, 0.1, 0.1), mean_frags=30, sd_frags=15,
-                             min_frags=0)
-    bounds = D.shard_bounds(batch.rec_offset, world)
-    shard, (lo, hi) = D.local_shard(batch, rank, world)
+    group = 1
+    if scenario == "c3":
+        lib = synth.normal_library(n=50000)
+        batch = synth.make_units(3001, 77, [lib], svtype_mix=(0.6, 0.2, 0.1, 0.1), mean_frags=30, sd_frags=15,
+                                 min_frags=0)
+    else:       # the configs[4] shape; "empty": fewer sites than ranks, one rank has nothing to contribute
+        group = 8
+        batch = synth.make_multisample(1 if scenario == "empty" else 75, group, seed=4, mean_frags=20, sd_frags=8, min_frags=1, max_frags=50)
+    bounds = D.shard_bounds(batch.rec_offset, world, group)
+    assert all(lo % group == 0 for lo, _ in bounds)
+    if scenario == "empty":
+        assert sorted(hi - lo for lo, hi in bounds) == [0, group]
+    shard, (lo, hi) = D.local_shard(batch, rank, world, group)
     local = c_oracle.genotype_batch(shard, n_threads=1)
     t = torch.from_numpy(local.rec.view(np.uint8).copy())
     gathered = D.gather_result_records(t, [b[1] - b[0] for b in bounds], dst=0)
@@ -47,10 +55,11 @@ def _worker(rank, world, port, out_path):
     dist.destroy_process_group()
 
 
-def test_two_rank_shard_and_gather(tmp_path):
+@pytest.mark.parametrize("scenario", ["c3", "c5", "empty"])
+def test_two_rank_shard_and_gather(tmp_path, scenario):
     import torch.multiprocessing as mp
     out = str(tmp_path / "result.txt")
-    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), out, scenario), nprocs=2, join=True)
     assert open(out).read() == "ok"
 
 

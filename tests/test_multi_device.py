@@ -67,7 +67,7 @@ def _free_port():
     return p
 
 
-def _rank(rank, world, port, out_path):
+def _rank(rank, world, port, out_path, scenario="c3"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -83,11 +83,24 @@ def _rank(rank, world, port, out_path):
     torch.cuda.set_device(device)
     dist.init_process_group("nccl" if rccl else "gloo", rank=rank, world_size=world,
                             **({"device_id": torch.device("cuda", device)} if rccl else {}))
-    lib = synth.normal_library(n=50000)
-    batch = synth.make_units(30_001, 77, [lib], svtype_mix=(0.6, 0.2, 0.1, 0.1), mean_frags=40, sd_frags=20, min_frags=0)
-    bounds = D.shard_bounds(batch.rec_offset, world)
-    shard, (lo, hi) = D.local_shard(batch, rank, world)
+    group = 1
+    if scenario == "c3":            # configs[3]: one library, mixed SV types
+        lib = synth.normal_library(n=50000)
+        batch = synth.make_units(30_001, 77, [lib], svtype_mix=(0.6, 0.2, 0.1, 0.1), mean_frags=40, sd_frags=20, min_frags=0)
+    elif scenario == "c5":          # configs[4]: 32 samples with their own libraries (library windows), a site's samples on one rank
+        group = 32
+        batch = synth.make_multisample(301, 32, seed=21, mean_frags=30, sd_frags=12, min_frags=2, max_frags=80)
+    else:                           # "empty": fewer sites than ranks -- one rank gets no unit at all
+        group = 32
+        batch = synth.make_multisample(1, 32, seed=22, mean_frags=30, sd_frags=12, min_frags=2, max_frags=80)
+    bounds = D.shard_bounds(batch.rec_offset, world, group)
+    assert all(lo % group == 0 for lo, _ in bounds)
+    if scenario == "empty":
+        assert any(hi == lo for lo, hi in bounds) and any(hi > lo for lo, hi in bounds)
+    shard, (lo, hi) = D.local_shard(batch, rank, world, group)
     with hip.DeviceBatch(shard, device=device) as d:
+        if scenario == "c5":
+            assert d.table_mode() == 1
         buf = torch.zeros(max(1, shard.n_units) * 128, dtype=torch.uint8, device="cuda")
         d.bind_device_results(buf.data_ptr())        # the kernel writes straight into the tensor that is gathered
         d.genotype(sync=True)
@@ -98,6 +111,12 @@ def _rank(rank, world, port, out_path):
         got = D.results_from_bytes(gathered)
         single = hip.genotype_batch(batch, device=device)
         want = c_oracle.genotype_batch(batch)
+        if group > 1:     # QUAL over a site's samples from the gathered (site-major) records == the single-rank device pass
+            with hip.DeviceBatch(batch, device=device) as d1:
+                d1.genotype(sync=True)
+                q1 = d1.site_qual(group)
+            assert hip.site_qual_host(got, group).tobytes() == hip.site_qual_host(single, group).tobytes()
+            assert np.allclose(q1, hip.site_qual_host(single, group), rtol=0, atol=1e-6)
         ok = (got.rec.tobytes() == single.rec.tobytes() and np.array_equal(got.gt, want.gt)
               and np.array_equal(got.counts, want.counts) and np.array_equal(got.gl.view(np.uint64), want.gl.view(np.uint64))
               and float(np.max(np.abs(got.sq - want.sq))) <= 1e-6)
@@ -108,10 +127,13 @@ def _rank(rank, world, port, out_path):
 
 
 @pytest.mark.gpu
-def test_two_ranks_shard_hip_gather(hip_device, tmp_path):
+@pytest.mark.parametrize("scenario", ["c3", "c5", "empty"])
+def test_two_ranks_shard_hip_gather(hip_device, tmp_path, scenario):
     """world 2: shard_bounds -> the HIP path on every rank -> ONE gather of the 128-byte records; byte-equal to the
-    single-rank result and parity-equal to the oracle (RCCL when two devices are visible, gloo on one)."""
+    single-rank result and parity-equal to the oracle (RCCL when two devices are visible, gloo on one).  c3: one
+    library; c5: the configs[4] shape (library windows, shards cut at whole sites: group = 32, QUAL per site from the
+    gathered records); empty: fewer sites than ranks, so one rank contributes nothing to the gather."""
     import torch.multiprocessing as mp
     out = str(tmp_path / "result.txt")
-    mp.spawn(_rank, args=(2, _free_port(), out), nprocs=2, join=True)
+    mp.spawn(_rank, args=(2, _free_port(), out, scenario), nprocs=2, join=True)
     assert open(out).read().startswith("ok")
