@@ -43,9 +43,6 @@
 #ifndef SVT_WINDOW_ONE_TRIP
 #define SVT_WINDOW_ONE_TRIP 0  // record_window: the same for windows of several libraries
 #endif
-#ifndef SVT_STREAM_PIPELINED
-#define SVT_STREAM_PIPELINED 0 // one-library blocks: explicit two-stage look-up pipeline (look_issue / look_use); 0 = record_single
-#endif
 #ifndef SVT_STREAM_SPLIT
 #define SVT_STREAM_SPLIT 4 // scheduling barrier before this record of a block (8 = none)
 #endif
@@ -55,8 +52,8 @@
 #ifndef SVT_FETCH_FAST_INTERIOR
 #define SVT_FETCH_FAST_INTERIOR 1 // steps in which every unit of the tile is inside its record range fetch without range tests
 #endif
-#ifndef SVT_FETCH_PRIO
-#define SVT_FETCH_PRIO 0 // wave priority while a block leaves the ring and the next fetch is issued (0 = unchanged)
+#ifndef SVT_TAIL_AUX
+#define SVT_TAIL_AUX -1 // cache policy of a unit's LAST line (-1 = the same as its first line, SVT_STREAM_EDGE_AUX)
 #endif
 #ifndef SVT_EDGE_EXACT
 #define SVT_EDGE_EXACT 1 // steps that hold some unit's last block: 1 = only those blocks take SVT_STREAM_EDGE_AUX, 0 = the whole step
@@ -244,94 +241,6 @@ __device__ __forceinline__ void record_single(const u32x4 w, const bool mine, co
     a.alt_span += pp * lds_f64(wa);
     a.ref_span += pp * lds_f64(wa + kSWref);
 #endif
-}
-
-// ---- the same record arithmetic as a two-stage pipeline (one library; interior and edge blocks) --------------------
-// record_single leaves the order of the table look-ups to the compiler, which serialises every record into
-// "ten ds_reads, wait, compare, the dependent read of the decision table, wait, multiply": two exposed LDS round
-// trips per record, sixteen per block.  Here every look-up of a record is issued in ONE group -- the decision table
-// is read for both values of p_concordant (high words only: the weights are 0, 0.5 or 1, whose low words are 0) --
-// and the group of record j + 1 is issued before the arithmetic of record j, so that arithmetic covers its latency.
-// The ds_reads are inline assembly because only their textual order keeps them ahead of the previous record's VALU
-// work; the waits name the looked-up values as in-out operands, which orders every use behind them.  (At most one
-// group -- 13 LDS operations -- is outstanding at a wait; the LGKM counter holds 15.)
-struct Look {
-    double pm_a, pm_b, rs_a, rs_b, sq_l, sq_r, cl_l, cl_r;
-    int32_t thr;
-    uint32_t hist, wa0, wa1, wr1;
-};
-
-template <bool EDGE>
-__device__ __forceinline__ void look_issue(const u32x4 w, const bool mine, const StreamCtx& c, Look& L)
-{
-    const uint32_t wy = EDGE ? (mine ? w.y : 0u) : w.y;   // mapq_a | mapq_b << 8 | rs_a << 16 | rs_b << 24
-    const uint32_t wz = EDGE ? (mine ? w.z : 0u) : w.z;   // seq_l | seq_r << 8 | clip_l << 16 | clip_r << 24
-    const uint32_t a0 = byte0_x8(wy), a1 = byte1_x8(wy), a2 = byte2_x8(wy), a3 = byte3_x8(wy);
-    const uint32_t b0 = byte0_x8(wz), b1 = byte1_x8(wz), b2 = byte2_x8(wz), b3 = byte3_x8(wz);
-    const uint32_t i1 = min(w.x - c.kmin, c.nb) << 1;
-    const uint32_t i2 = c.hist_at + (min(w.x - c.sub2, c.nb) << 1);
-    const uint32_t wt = c.wh0 | ((w.w & c.fmask) << 2);   // &w_alt_hi[f3 | del16]
-    asm volatile("ds_read_b64 %0, %8\n\t"
-                 "ds_read_b64 %1, %9\n\t"
-                 "ds_read_b64 %2, %10\n\t"
-                 "ds_read_b64 %3, %11\n\t"
-                 "ds_read_b64 %4, %12 offset:%16\n\t"
-                 "ds_read_b64 %5, %13 offset:%16\n\t"
-                 "ds_read_b64 %6, %14 offset:%16\n\t"
-                 "ds_read_b64 %7, %15 offset:%16"
-                 : "=&v"(L.pm_a), "=&v"(L.pm_b), "=&v"(L.rs_a), "=&v"(L.rs_b), "=&v"(L.sq_l), "=&v"(L.sq_r), "=&v"(L.cl_l), "=&v"(L.cl_r)
-                 : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(b0), "v"(b1), "v"(b2), "v"(b3), "n"(kSPmHalf)
-                 : "memory");
-    asm volatile("ds_read_i16 %0, %5 offset:%8\n\t"
-                 "ds_read_u16 %1, %6\n\t"
-                 "ds_read_b32 %2, %7\n\t"
-                 "ds_read_b32 %3, %7 offset:%9\n\t"
-                 "ds_read_b32 %4, %7 offset:%10"
-                 : "=&v"(L.thr), "=&v"(L.hist), "=&v"(L.wa0), "=&v"(L.wa1), "=&v"(L.wr1)
-                 : "v"(i1), "v"(i2), "v"(wt), "n"(kSBins), "n"(8 * 4), "n"(kSWhiRef + 8 * 4)
-                 : "memory");
-}
-
-__device__ __forceinline__ void look_wait(Look& L)
-{
-    asm volatile("s_waitcnt lgkmcnt(0)"
-                 : "+v"(L.pm_a), "+v"(L.pm_b), "+v"(L.rs_a), "+v"(L.rs_b), "+v"(L.sq_l), "+v"(L.sq_r), "+v"(L.cl_l), "+v"(L.cl_r),
-                   "+v"(L.thr), "+v"(L.hist), "+v"(L.wa0), "+v"(L.wa1), "+v"(L.wr1)
-                 :
-                 : "memory");
-}
-
-// the arithmetic of one record on its looked-up values: record_weights + the paired-end part of record_single
-template <bool SSO, bool CONT>
-__device__ __forceinline__ void look_use(const Look& L, const u32x4 w, Acc& a)
-{
-    const double p_seq = L.sq_l + L.sq_r, p_clip = L.cl_l + L.cl_r;
-    if (SSO && !CONT) {
-        a.ref_seq += a.l_ref_seq;
-        a.alt_seq += a.l_alt_seq;
-        a.alt_clip += a.l_alt_clip;
-        a.l_ref_seq = L.rs_a + L.rs_b;
-        a.l_alt_seq = p_seq;
-        a.l_alt_clip = p_clip;
-    } else if (SSO) {
-        const bool cont = (w.w & SVT_REC_CONTINUATION) != 0u;
-        a.ref_seq += cont ? 0.0 : a.l_ref_seq;
-        a.alt_seq += cont ? 0.0 : a.l_alt_seq;
-        a.alt_clip += cont ? 0.0 : a.l_alt_clip;
-        a.l_ref_seq = ((cont ? a.l_ref_seq : 0.0) + L.rs_a) + L.rs_b;
-        a.l_alt_seq = (cont ? a.l_alt_seq : 0.0) + p_seq;
-        a.l_alt_clip = (cont ? a.l_alt_clip : 0.0) + p_clip;
-    } else {
-        a.ref_seq = (a.ref_seq + L.rs_a) + L.rs_b;
-        a.alt_seq += p_seq;
-        a.alt_clip += p_clip;
-    }
-    const bool p_conc = (int32_t)L.hist <= L.thr;   // hist[o - v] <= thr[o] (svt_host_tables.h)
-    const double w_alt = __hiloint2double((int)(p_conc ? L.wa1 : L.wa0), 0);
-    const double w_ref = __hiloint2double((int)(p_conc ? L.wr1 : 0u), 0);
-    const double pp = L.pm_a * L.pm_b;
-    a.alt_span += pp * w_alt;
-    a.ref_span += pp * w_ref;
 }
 
 // per-lane constants of the unit for the library-window consumer
@@ -550,7 +459,7 @@ __global__ __launch_bounds__(kBlock, MODE == kSingleLds ? SVT_STREAM_WAVES : MOD
                 fetch_block_interior<SVT_STREAM_AUX>(k, src_base, rec_bytes, stage);
                 return true;
             } else if (kEdgeAux != SVT_STREAM_AUX && k + 1 >= min_blk) {
-                if (SVT_EDGE_EXACT) fetch_block_tail_exact<SVT_STREAM_AUX, kEdgeAux>(k, src_base, src_end, rec_bytes, stage);
+                if (SVT_EDGE_EXACT) fetch_block_tail_exact<SVT_STREAM_AUX, SVT_TAIL_AUX < 0 ? kEdgeAux : SVT_TAIL_AUX>(k, src_base, src_end, rec_bytes, stage);
                 else fetch_block<kEdgeAux, false>(k, src_base, src_first, src_end, rec_bytes, stage);
             } else
                 fetch_block<SVT_STREAM_AUX, false>(k, src_base, src_first, src_end, rec_bytes, stage);
@@ -605,25 +514,6 @@ __global__ __launch_bounds__(kBlock, MODE == kSingleLds ? SVT_STREAM_WAVES : MOD
                 const uint32_t idx = k * kBlockRecords + (uint32_t)j;
                 return !EDGE || (idx >= head && idx < last);
             };
-            if (SVT_STREAM_PIPELINED && (MODE == kSingleLds || (MODE == kMultiLds && KIND == 1))) {
-                // one library: the look-ups of record j + 1 are in flight while record j is summed (look_issue)
-                Look L0, L1;
-                look_issue<EDGE>(w[0], is_mine(0), sc, L0);
-#pragma unroll
-                for (int j = 0; j < 8; j += 2) {
-                    look_wait(L0);
-                    look_issue<EDGE>(w[j + 1], is_mine(j + 1), sc, L1);
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (is_mine(j)) check.see(w[j], lib_key);
-                    look_use<SSO, CONT>(L0, w[j], acc);
-                    look_wait(L1);
-                    if (j + 2 < 8) look_issue<EDGE>(w[j + 2], is_mine(j + 2), sc, L0);
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (is_mine(j + 1)) check.see(w[j + 1], lib_key);
-                    look_use<SSO, CONT>(L1, w[j + 1], acc);
-                }
-                return;
-            }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 // keep the look-ups of the second half of the block from being hoisted over the first half: eight
@@ -658,7 +548,6 @@ __global__ __launch_bounds__(kBlock, MODE == kSingleLds ? SVT_STREAM_WAVES : MOD
             if (kStreamDepth == 2 && max_blk > 1) exact_behind = fetch(1, 1);
 #pragma unroll 1
             for (uint32_t k = 0; k < max_blk; ++k) {
-                if (SVT_FETCH_PRIO) __builtin_amdgcn_s_setprio(SVT_FETCH_PRIO);
                 if (kStreamDepth == 2) {
                     // block k sits in stage k & 1; the group behind it (block k + 1) may stay in flight
                     const bool pend = k + 1 < max_blk && exact_behind;
@@ -675,7 +564,6 @@ __global__ __launch_bounds__(kBlock, MODE == kSingleLds ? SVT_STREAM_WAVES : MOD
                     if (SVT_STREAM_PROBE != 2 && k + 1 < max_blk) fetch(k + 1);
                     else if (a.l10_where == kL10Ring) l10_into_ring();   // the tile's last block has left the ring: the copy lands while it is summed
                 }
-                if (SVT_FETCH_PRIO) __builtin_amdgcn_s_setprio(0);
                 const uint32_t k8 = k * kBlockRecords;
                 if (SVT_STREAM_PROBE == 1) {
 #pragma unroll

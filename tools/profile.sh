@@ -12,10 +12,20 @@ export TMPDIR=/tmp
 # the headline plus the sso and configs[4]-shape legs: each has its own kernel instantiation, so the per-kernel PMC means stay apart
 BENCH="python bench.py --steps 10 --warmup 2 --no-cpu-baseline --legs ${LEGS:-sso,c5} ${BENCH_ARGS:-}"
 BENCH_SHORT="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --legs ${LEGS:-sso,c5} ${BENCH_ARGS:-}"
-timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/stats -o stats -- $BENCH > $OUT/stats_bench.json 2> $OUT/stats.err
-timeout 300 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS -d $OUT/pmc_sq1 -o pmc -- $BENCH_SHORT > /dev/null 2> $OUT/pmc_sq1.err
-timeout 300 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_VMEM_RD -d $OUT/pmc_sq2 -o pmc -- $BENCH_SHORT > /dev/null 2> $OUT/pmc_sq2.err
-timeout 300 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o pmc -- $BENCH_SHORT > /dev/null 2> $OUT/pmc_fetch.err
-timeout 300 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o pmc -- $BENCH_SHORT > /dev/null 2> $OUT/pmc_write.err
+# one rocprofv3 pass; a pass that hangs (seen: a counter pass that never returns) is killed after 150 s and tried once more
+run_pass() {   # run_pass <subdir> <stdout file> <bench command> -- <rocprofv3 options...>
+    local sub=$1 outf=$2 cmd=$3; shift 4
+    for attempt in 1 2; do
+        rm -rf $OUT/$sub
+        if timeout -k 10 150 rocprofv3 "$@" -d $OUT/$sub -o ${sub%%_*} -- $cmd > $outf 2> $OUT/$sub.err; then return 0; fi
+        echo "pass $sub attempt $attempt failed" >> $OUT/passes.log
+    done
+    return 1
+}
+run_pass stats $OUT/stats_bench.json "$BENCH" -- --kernel-trace --stats
+run_pass pmc_sq1 /dev/null "$BENCH_SHORT" -- --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS
+run_pass pmc_sq2 /dev/null "$BENCH_SHORT" -- --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_VMEM_RD
+run_pass pmc_fetch /dev/null "$BENCH_SHORT" -- --pmc FETCH_SIZE
+run_pass pmc_write /dev/null "$BENCH_SHORT" -- --pmc WRITE_SIZE
 python tools/summarize_prof.py $OUT > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt
