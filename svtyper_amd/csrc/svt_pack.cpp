@@ -18,6 +18,12 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
+
+#include <pthread.h>
+#include <sched.h>
+#include <sys/syscall.h>
+#include <unistd.h>
 
 #include "svt_entry_formats.h"
 #include "svt_host_cpus.h"
@@ -114,9 +120,187 @@ uint32_t vote_common_mapq(const Slot* recs, uint64_t n_vote)
     return common;
 }
 
+// what the record loop needs to know about the unit, and what it carries from record to record
+struct UnitCtx {
+    bool gated;                  // a DEL below the small-deletion gate of classic.py:339,383: no pair entry adds anything
+    int64_t key_min, nb, vl;     // library key_min / n_bins, the unit's var_length
+    uint64_t lim1, lim2;         // pair_code (svt_entry_formats.h) with the unit's constants folded: code = r when
+    uint32_t code_out;           // (uint64) r < lim1, else nb + (r - vl) when (uint64)(r - vl) < lim2, else code_out = 2 nb
+    uint32_t common;             // the batch's common MAPQ pair
+};
+struct UnitState {
+    bool has_r = false, has_s = false, has_c = false;    // the fragment already has a kept entry for that tally
+    uint32_t or_flags = 0, or_span = 0, lone = 0;        // the record contract, folded like the device's RecordCheck
+};
+
 #ifndef SVT_PACK_BRANCHLESS_REF
 #define SVT_PACK_BRANCHLESS_REF 1
 #endif
+
+// records [r0, r1) of a unit, one at a time (also the tail and the odd groups of the vector form below)
+inline void encode_records(const Slot* recs, const uint64_t r0, const uint64_t r1, const UnitCtx& c, UnitState& st,
+                           PairStream& S, WeightStream& R, WeightStream& X)
+{
+    for (uint64_t j = r0; j < r1; ++j) {
+        const Slot w = recs[j];
+        const uint32_t fl = w.w;
+        st.or_flags |= fl;
+        st.or_span |= w.x;
+        st.lone |= (fl & 7u) & (((fl >> 4) & 1u) - 1u);     // straddle bits of a record without HAS_PAIR
+        if (!(fl & SVT_REC_CONTINUATION)) st.has_r = st.has_s = st.has_c = false;
+        // a pair entry that could only add +0.0 is not stored: no straddle bit, a zero MAPQ (prob_mapq(0) == 0.0), a gated DEL
+        if ((fl & 7u) && (w.y & 0xffu) && (w.y & 0xff00u) && !c.gated) {
+            const int64_t r = (int64_t)(int32_t)w.x - c.key_min;
+            const uint32_t code = (uint64_t)r < c.lim1 ? (uint32_t)r : (uint64_t)(r - c.vl) < c.lim2 ? (uint32_t)(c.nb + r - c.vl) : c.code_out;
+            S.put((fl & 7u) | (code << 3), w.y & 0xffffu, c.common);
+        }
+        const uint32_t k_ref = w.y >> 16, k_seq = w.z & 0xffffu, k_clip = w.z >> 16;   // gated MAPQ pairs; 0 = nothing to add
+#if SVT_PACK_BRANCHLESS_REF
+        R.put_if(k_ref, k_ref ? 1u : 0u, st.has_r ? 0u : 1u);
+        st.has_r |= k_ref != 0u;
+#else
+        if (k_ref) { R.put(k_ref, !st.has_r, false); st.has_r = true; }
+#endif
+        if (k_seq) { X.put(k_seq, !st.has_s, false); st.has_s = true; }
+        if (k_clip) { X.put(k_clip, !st.has_c, true); st.has_c = true; }
+    }
+}
+
+#if defined(__x86_64__)
+#define SVT_PACK_AVX512 1
+#include <immintrin.h>
+// The same for sixteen records at a time (AVX-512 F / BW / VL; chosen at run time).  The four dwords of the records are
+// transposed into four vectors; which records keep a pair entry, their codes, which carry a reference read or a split
+// candidate come out of a dozen vector instructions instead of sixteen times a dozen branches; the entries themselves
+// are then emitted in record order: runs of one-half-word pair entries by a compressing store, the few wide ones and
+// the weight entries from the set bits of the masks.  A group that holds a continuation record (a fragment with a
+// second record: the first-of-fragment bits then depend on the records before it) is left to encode_records.
+__attribute__((target("avx512f,avx512bw,avx512vl")))
+inline void encode_records_avx512(const Slot* recs, const uint64_t r0, const uint64_t r1, const UnitCtx& c, UnitState& st,
+                                  PairStream& S, WeightStream& R, WeightStream& X)
+{
+    // the gated unit keeps no pair entry at all; negative codes cannot happen for it either way
+    const __m512i idx_lo = _mm512_setr_epi32(0, 4, 8, 12, 16, 20, 24, 28, 0, 0, 0, 0, 0, 0, 0, 0);      // dword 0 of records 0..7 of (A, B)
+    const __m512i idx_hi = _mm512_setr_epi32(0, 0, 0, 0, 0, 0, 0, 0, 0, 4, 8, 12, 16, 20, 24, 28);      // ... into lanes 8..15
+    const __m512i one = _mm512_set1_epi32(1);
+    __m512i acc_flags = _mm512_setzero_si512(), acc_span = _mm512_setzero_si512(), acc_lone = _mm512_setzero_si512();
+    const __m512i v_kmin = _mm512_set1_epi32((int32_t)c.key_min), v_vl = _mm512_set1_epi32((int32_t)c.vl);
+    const __m512i v_nb = _mm512_set1_epi32((int32_t)c.nb), v_out = _mm512_set1_epi32((int32_t)c.code_out);
+    const __m512i v_lim1 = _mm512_set1_epi32((int32_t)(uint32_t)c.lim1), v_lim2 = _mm512_set1_epi32((int32_t)(uint32_t)c.lim2);
+    const __m512i v_common = _mm512_set1_epi32((int32_t)c.common);
+    uint64_t j = r0;
+    for (; j + 16 <= r1; j += 16) {
+        const __m512i a = _mm512_loadu_si512(recs + j), b = _mm512_loadu_si512(recs + j + 4);
+        const __m512i d = _mm512_loadu_si512(recs + j + 8), e = _mm512_loadu_si512(recs + j + 12);
+        // dword K of the sixteen records (a lambda would not inherit this function's target attribute)
+#define SVT_FIELD(K)                                                                                                            \
+    _mm512_mask_blend_epi32(0xFF00, _mm512_permutex2var_epi32(a, _mm512_add_epi32(idx_lo, _mm512_set1_epi32(K)), b),             \
+                            _mm512_permutex2var_epi32(d, _mm512_add_epi32(idx_hi, _mm512_set1_epi32(K)), e))
+        const __m512i fw = SVT_FIELD(3);
+        if (_mm512_test_epi32_mask(fw, _mm512_set1_epi32((int32_t)SVT_REC_CONTINUATION))) {   // (rare) a fragment goes on: record by record
+            encode_records(recs, j, j + 16, c, st, S, R, X);
+            continue;
+        }
+        const __m512i fx = SVT_FIELD(0), fy = SVT_FIELD(1), fz = SVT_FIELD(2);
+#undef SVT_FIELD
+        acc_flags = _mm512_or_si512(acc_flags, fw);
+        acc_span = _mm512_or_si512(acc_span, fx);
+        // straddle bits of a record without HAS_PAIR: (fl & 7) & (((fl >> 4) & 1) - 1)
+        acc_lone = _mm512_or_si512(acc_lone, _mm512_and_si512(_mm512_and_si512(fw, _mm512_set1_epi32(7)),
+                                                              _mm512_sub_epi32(_mm512_and_si512(_mm512_srli_epi32(fw, 4), one), one)));
+        // ---- pair entries
+        __mmask16 keep = 0;
+        if (!c.gated)
+            keep = _mm512_test_epi32_mask(fw, _mm512_set1_epi32(7)) & _mm512_test_epi32_mask(fy, _mm512_set1_epi32(0xff)) &
+                   _mm512_test_epi32_mask(fy, _mm512_set1_epi32(0xff00));
+        if (keep) {
+            // r = ospan_len - key_min as the 32-bit value it is under the format's limits (|key_min| <= 2^29, ospan_len >= 0
+            // or rejected): a negative r is a huge unsigned number and fails both range tests, like the 64-bit form
+            const __m512i r = _mm512_sub_epi32(fx, v_kmin), r2 = _mm512_sub_epi32(r, v_vl);
+            const __mmask16 in1 = _mm512_cmplt_epu32_mask(r, v_lim1), in2 = _mm512_cmplt_epu32_mask(r2, v_lim2);
+            __m512i code = _mm512_mask_blend_epi32(in2, v_out, _mm512_add_epi32(v_nb, r2));
+            code = _mm512_mask_blend_epi32(in1, code, r);
+            const __m512i mq = _mm512_and_si512(fy, _mm512_set1_epi32(0xffff));
+            const __m512i ent = _mm512_or_si512(_mm512_and_si512(fw, _mm512_set1_epi32(7)), _mm512_slli_epi32(code, 3));
+            __mmask16 wide = keep & _mm512_cmpneq_epi32_mask(mq, v_common);
+            if (!wide) {
+                // all of them one half-word: compress the kept entries and store them as sixteen half-words (the
+                // scratch has room; what lies behind the kept ones is overwritten by whatever comes next)
+                _mm256_storeu_si256(reinterpret_cast<__m256i*>(S.begin + S.n), _mm512_cvtepi32_epi16(_mm512_maskz_compress_epi32(keep, ent)));
+                S.n += (uint32_t)__builtin_popcount(keep);
+            } else {
+                alignas(64) uint32_t e32[16], m32[16];
+                _mm512_store_si512(e32, ent);
+                _mm512_store_si512(m32, mq);
+                unsigned from = 0;
+                while (true) {
+                    const unsigned i = wide ? (unsigned)__builtin_ctz(wide) : 16u;
+                    const __mmask16 run = (__mmask16)(keep & ((1u << i) - 1u) & ~((1u << from) - 1u));   // one-half-word entries in front of lane i
+                    if (run) {
+                        _mm256_storeu_si256(reinterpret_cast<__m256i*>(S.begin + S.n), _mm512_cvtepi32_epi16(_mm512_maskz_compress_epi32(run, ent)));
+                        S.n += (uint32_t)__builtin_popcount(run);
+                    }
+                    if (i == 16u) break;
+                    S.begin[S.n] = 0;                      // the no-op half-word in front of a wide entry at an odd half-word
+                    S.n += S.n & 1u;
+                    S.begin[S.n++] = (uint16_t)(e32[i] | kWideEntry);
+                    S.begin[S.n++] = (uint16_t)m32[i];
+                    from = i + 1u;
+                    wide = (__mmask16)(wide & (wide - 1u));
+                }
+            }
+        }
+        // ---- reference reads (every record of the group starts a fragment: each kept entry is its fragment's first)
+        const __m512i kref = _mm512_srli_epi32(fy, 16);
+        __mmask16 nz = _mm512_test_epi32_mask(kref, kref);
+        if (nz) {
+            alignas(32) uint16_t t[16];
+            _mm256_store_si256(reinterpret_cast<__m256i*>(t), _mm512_cvtepi32_epi16(_mm512_maskz_compress_epi32(nz, kref)));
+            uint32_t cnt = (uint32_t)__builtin_popcount(nz), at = 0;
+            while (cnt) {
+                const uint32_t take = std::min(cnt, 7u - R.k);
+                for (uint32_t q = 0; q < take; ++q) R.row[R.k + q] = t[at + q];
+                R.bits |= ((1u << take) - 1u) << R.k;
+                R.k += take;
+                at += take;
+                cnt -= take;
+                if (R.k == 7u) {
+                    R.row[7] = (uint16_t)R.bits;
+                    R.row += 8;
+                    R.k = R.bits = 0u;
+                }
+            }
+        }
+        // ---- split / clip candidates (few): in record order, the split candidate of a record before its clip candidate
+        const __mmask16 any_x = _mm512_test_epi32_mask(fz, fz);
+        if (any_x) {
+            alignas(64) uint32_t z32[16];
+            _mm512_store_si512(z32, fz);
+            for (unsigned m = any_x; m; m &= m - 1u) {
+                const uint32_t z = z32[__builtin_ctz(m)];
+                if (z & 0xffffu) X.put(z & 0xffffu, true, false);
+                if (z >> 16) X.put(z >> 16, true, true);
+            }
+        }
+        // what a continuation record right behind this group would see of its fragment (the group's last record)
+        const uint32_t last_y = recs[j + 15].y, last_z = recs[j + 15].z;
+        st.has_r = (last_y >> 16) != 0u;
+        st.has_s = (last_z & 0xffffu) != 0u;
+        st.has_c = (last_z >> 16) != 0u;
+    }
+    st.or_flags |= (uint32_t)_mm512_reduce_or_epi32(acc_flags);
+    st.or_span |= (uint32_t)_mm512_reduce_or_epi32(acc_span);
+    st.lone |= (uint32_t)_mm512_reduce_or_epi32(acc_lone);
+    encode_records(recs, j, r1, c, st, S, R, X);
+}
+
+inline bool cpu_has_avx512()
+{
+    static const bool yes = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512bw") && __builtin_cpu_supports("avx512vl");
+    return yes;
+}
+#endif
+
 constexpr uint64_t kChunkUnits = 256;
 static_assert(SVT_REC_CONTINUATION == (1u << 3) && SVT_REC_HAS_PAIR == (1u << 4), "bit positions used by the encoder's loop");
 
@@ -127,8 +311,57 @@ struct ChunkOut {          // where a chunk's slots wait for the final copy
     uint64_t base = 0;     // first slot in the final array
 };
 
+// A worker's arena: plain memory that is neither zero-filled when it grows nor handed back between calls.  Fresh pages
+// cost a page fault each and concurrent faults of one process serialise in the kernel: with arenas allocated per call
+// sixteen threads ran at half the per-thread speed of one.
+struct Arena {
+    Slot* p = nullptr;
+    size_t size = 0, cap = 0;
+    void reserve(const size_t want)
+    {
+        if (want <= cap) return;
+        const size_t ncap = std::max(want, cap + cap / 2 + 4096);
+        Slot* q = static_cast<Slot*>(std::realloc(p, ncap * sizeof(Slot)));
+        if (!q) throw std::bad_alloc();
+        p = q;
+        cap = ncap;
+    }
+};
+struct ArenaPool {       // arenas wait here for the next svt_pack_evidence call (released by svt_pack_trim)
+    std::mutex lock;
+    std::vector<Arena> idle;
+    Arena get()
+    {
+        std::lock_guard<std::mutex> g(lock);
+        if (idle.empty()) return Arena{};
+        size_t best = 0;
+        for (size_t i = 1; i < idle.size(); ++i)
+            if (idle[i].cap > idle[best].cap) best = i;
+        Arena a = idle[best];
+        idle.erase(idle.begin() + (long)best);
+        a.size = 0;
+        return a;
+    }
+    void put(Arena a)
+    {
+        if (!a.p) return;
+        std::lock_guard<std::mutex> g(lock);
+        if (idle.size() >= 64) { std::free(a.p); return; }
+        idle.push_back(a);
+    }
+    void trim()
+    {
+        std::lock_guard<std::mutex> g(lock);
+        for (Arena& a : idle) std::free(a.p);
+        idle.clear();
+    }
+};
+ArenaPool g_arenas;
+
 struct Worker {
-    std::vector<Slot> arena;       // the slots of this worker's chunks, chunk after chunk
+    Arena arena;                   // the slots of this worker's chunks, chunk after chunk
+    double ms = 0.0;               // SVT_TRACE: how long this worker ran
+    ~Worker() { g_arenas.put(arena); }
     std::vector<uint16_t> scratch; // one unit's three streams at worst-case size, as half-words
     uint32_t bad = 0;              // record-contract bits (kErr*)
     int unit_error = 0;            // first unit-array violation (1-based code below), 0 = none
@@ -136,6 +369,97 @@ struct Worker {
 
 enum UnitError { kUnitOk = 0, kUnitOffsets, kUnitTooLong, kUnitSvtype, kUnitReserved, kUnitVarLength, kUnitNegativeDel };
 
+}  // namespace
+
+void pack_trim() { g_arenas.trim(); }
+
+namespace {
+// The CPUs this process may use, grouped by the L3 cache they share (one group per CCD on an EPYC), with the socket
+// each group sits on.  The encoder is a stream over 1.6 GB per million units: worker t is asked to run on one core of
+// group t mod n_groups, taking only groups on the CALLING thread's socket -- the records were most likely first touched
+// there, and workers on the other socket of a two-socket host read them over the inter-socket links (measured: the
+// remote half of sixteen workers took 42 ms where the local half took 32).  SVT_PACK_SPREAD=0 leaves placement to the
+// scheduler.
+struct L3Group {
+    cpu_set_t cpus;
+    long package;   // socket
+    long node;      // NUMA node of the group's first CPU
+};
+const std::vector<L3Group>& l3_groups()
+{
+    static const std::vector<L3Group> groups = [] {
+        std::vector<L3Group> out;
+        std::vector<long> ids;
+        cpu_set_t mine;
+        if (sched_getaffinity(0, sizeof mine, &mine) != 0) return out;
+        auto read_long = [](const char* fmt, int cpu) {
+            char path[160];
+            std::snprintf(path, sizeof path, fmt, cpu);
+            long v = -1;
+            if (FILE* f = std::fopen(path, "r")) {
+                if (std::fscanf(f, "%ld", &v) != 1) v = -1;
+                std::fclose(f);
+            }
+            return v;
+        };
+        for (int cpu = 0; cpu < CPU_SETSIZE; ++cpu) {
+            if (!CPU_ISSET(cpu, &mine)) continue;
+            const long id = read_long("/sys/devices/system/cpu/cpu%d/cache/index3/id", cpu);
+            const long pkg = read_long("/sys/devices/system/cpu/cpu%d/topology/physical_package_id", cpu);
+            if (id < 0 || pkg < 0) return std::vector<L3Group>();   // topology not readable: no placement
+            const long key = pkg * 100000 + id;
+            size_t g = 0;
+            while (g < ids.size() && ids[g] != key) ++g;
+            if (g == ids.size()) {
+                ids.push_back(key);
+                L3Group ng;
+                CPU_ZERO(&ng.cpus);
+                ng.package = pkg;
+                ng.node = -2;   // filled below
+                out.push_back(ng);
+            }
+            CPU_SET(cpu, &out[g].cpus);
+        }
+        return out;
+    }();
+    return groups;
+}
+// the NUMA node most of [p, p + bytes) lives on, asked from the kernel for a few sample pages (-1: unknown)
+long node_of_memory(const void* p, uint64_t bytes)
+{
+    if (!p || bytes < (1u << 20)) return -1;
+    constexpr int kSamples = 16;
+    void* pages[kSamples];
+    int status[kSamples];
+    for (int i = 0; i < kSamples; ++i) {
+        const uint64_t at = (bytes / kSamples) * (uint64_t)i;
+        pages[i] = reinterpret_cast<void*>((reinterpret_cast<uintptr_t>(p) + at) & ~uintptr_t(4095));
+        status[i] = -1;
+    }
+    if (syscall(SYS_move_pages, 0, (unsigned long)kSamples, pages, nullptr, status, 0) != 0) return -1;
+    int votes[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < kSamples; ++i)
+        if (status[i] >= 0 && status[i] < 8) ++votes[status[i]];
+    int best = 0;
+    for (int k = 1; k < 8; ++k)
+        if (votes[k] > votes[best]) best = k;
+    return votes[best] ? best : -1;
+}
+long node_of_cpu(int cpu)
+{
+    for (int node = 0; node < 8; ++node) {
+        char path[160];
+        std::snprintf(path, sizeof path, "/sys/devices/system/cpu/cpu%d/node%d", cpu, node);
+        if (access(path, F_OK) == 0) return node;
+    }
+    return -1;
+}
+long package_of_cpu(int cpu)
+{
+    for (const L3Group& g : l3_groups())
+        if (cpu >= 0 && cpu < CPU_SETSIZE && CPU_ISSET(cpu, &g.cpus)) return g.package;
+    return -1;
+}
 }  // namespace
 
 std::string record_error_text(uint32_t err_bits)
@@ -203,15 +527,54 @@ int encode_packed(const svt_evidence_batch* in, const PackAlloc& A, PackedArrays
     std::vector<Worker> workers(nt);
     std::vector<ChunkOut> chunks(n_chunks);
 
+    bool use_avx512 = false;
+#if SVT_PACK_AVX512
+    use_avx512 = cpu_has_avx512() && std::getenv("SVT_PACK_SCALAR") == nullptr;   // (SVT_PACK_SCALAR: tests compare the two forms)
+#endif
     // ---- the one pass over the records: contract check + the three streams of every unit (record order)
+    const char* spread_env = std::getenv("SVT_PACK_SPREAD");
+    const bool spread = nt > 1 && (spread_env ? std::atoi(spread_env) != 0 : true);
+    std::vector<const cpu_set_t*> home;      // the L3 groups next to the records: on their NUMA node, else on the caller's socket
+    if (spread) {
+        const long node = node_of_memory(in->records, n_rec_claimed * 16);
+        if (node >= 0) {
+            for (const L3Group& g : l3_groups()) {
+                int first = -1;
+                for (int cpu = 0; cpu < CPU_SETSIZE && first < 0; ++cpu)
+                    if (CPU_ISSET(cpu, &g.cpus)) first = cpu;
+                if (node_of_cpu(first) == node) home.push_back(&g.cpus);
+            }
+        }
+        if (home.empty()) {
+            const long pkg = package_of_cpu(sched_getcpu());
+            for (const L3Group& g : l3_groups())
+                if (g.package == pkg) home.push_back(&g.cpus);
+        }
+        if (trace) std::fprintf(stderr, "[svt] pack: records on NUMA node %ld, %zu L3 groups chosen\n", node, home.size());
+    }
     run_threads(nt, [&](unsigned t) {
+        const auto w_t0 = std::chrono::steady_clock::now();
+        // (worker 0 is the calling thread: its placement is the caller's business)
+        if (spread && t > 0 && home.size() > 1) {
+            const size_t n_groups = home.size();
+            const cpu_set_t& g = *home[t % n_groups];
+            // the (t / n_groups)-th CPU of the group: the low CPU numbers of a group are distinct cores, their SMT siblings follow
+            cpu_set_t one;
+            CPU_ZERO(&one);
+            unsigned want_k = t / (unsigned)n_groups, k = 0;
+            for (int cpu = 0; cpu < CPU_SETSIZE; ++cpu)
+                if (CPU_ISSET(cpu, &g) && k++ == want_k) { CPU_SET(cpu, &one); break; }
+            if (CPU_COUNT(&one) == 0) one = g;
+            (void)pthread_setaffinity_np(pthread_self(), sizeof one, &one);
+        }
         Worker& W = workers[t];
         // a guess at this worker's share (3.2 bytes per record is typical): growing later is only a copy
+        W.arena = g_arenas.get();
         W.arena.reserve((size_t)(n_rec_claimed / nt / 4 + 4096));
         for (uint64_t ch = t; ch < n_chunks; ch += nt) {
             ChunkOut& C = chunks[ch];
             C.worker = t;
-            C.arena_at = W.arena.size();
+            C.arena_at = W.arena.size;
             const uint64_t u0 = ch * kChunkUnits, u1 = std::min(n, u0 + kChunkUnits);
             std::memcpy(out->units + u0, in->units + u0, (u1 - u0) * sizeof(svt_unit));
             for (uint64_t u = u0; u < u1; ++u) {
@@ -230,63 +593,51 @@ int encode_packed(const svt_evidence_batch* in, const PackAlloc& A, PackedArrays
                     continue;                      // (the batch is rejected; nothing of this unit is read)
                 }
                 const bool is_del = U.svtype == SVT_SVTYPE_DEL;
-                const bool gated = is_del && (double)U.pos_delta < lib.sd2;            // classic.py:339,383: no pair entry adds anything
-                // pair_code (svt_entry_formats.h) with the unit's constants folded: code = r when (uint64) r < lim1, else
-                // nb + (r - vl) when (uint64)(r - vl) < lim2, else 2 nb          (r = ospan_len - key_min)
-                const int64_t vl = U.var_length;
-                const uint64_t lim1 = !is_del ? (uint64_t)nb : vl < nb ? (uint64_t)(vl + nb) : (uint64_t)nb;
-                const uint64_t lim2 = is_del && vl >= nb ? (uint64_t)nb : 0u;
-                const uint32_t code_out = (uint32_t)(2 * nb);
+                UnitCtx c;
+                c.gated = is_del && (double)U.pos_delta < lib.sd2;                  // classic.py:339,383
+                c.key_min = key_min;
+                c.nb = nb;
+                c.vl = U.var_length;
+                c.lim1 = !is_del ? (uint64_t)nb : c.vl < nb ? (uint64_t)(c.vl + nb) : (uint64_t)nb;
+                c.lim2 = is_del && c.vl >= nb ? (uint64_t)nb : 0u;
+                c.code_out = (uint32_t)(2 * nb);
+                c.common = common;
                 const uint64_t f = r1 - r0;
                 // worst case per stream: every record a wide pair entry behind a pad half-word (3 half-words), one
-                // reference-read entry, two candidate entries
-                const uint64_t cap_s = (3 * f + 8 + 7) / 8 + 1, cap_r = f / 7 + 2, cap_x = 2 * f / 7 + 2;   // (+ room for the unconditional writes)
+                // reference-read entry, two candidate entries; + two slots: the vector form stores sixteen half-words at once
+                const uint64_t cap_s = (3 * f + 8 + 7) / 8 + 3, cap_r = f / 7 + 2, cap_x = 2 * f / 7 + 2;
                 if (W.scratch.size() < (cap_s + cap_r + cap_x) * 8) W.scratch.resize((cap_s + cap_r + cap_x) * 8);
                 PairStream S(W.scratch.data());
                 WeightStream R(W.scratch.data() + cap_s * 8), X(W.scratch.data() + (cap_s + cap_r) * 8);
-                bool has_r = false, has_s = false, has_c = false;    // the fragment already has a kept entry for that tally
-                uint32_t or_flags = 0, or_span = 0, lone = 0;        // the record contract, folded like the device's RecordCheck
-                // (measured: writing every entry unconditionally and advancing by 0 / 1 instead of branching is slower --
-                // the loop then retires seven stores per record; the branches below are mostly predictable)
-                for (uint64_t j = r0; j < r1; ++j) {
-                    const Slot w = recs[j];
-                    const uint32_t fl = w.w;
-                    or_flags |= fl;
-                    or_span |= w.x;
-                    lone |= (fl & 7u) & (((fl >> 4) & 1u) - 1u);     // straddle bits of a record without HAS_PAIR
-                    if (!(fl & SVT_REC_CONTINUATION)) has_r = has_s = has_c = false;
-                    // a pair entry that could only add +0.0 is not stored: no straddle bit, a zero MAPQ (prob_mapq(0) == 0.0), a gated DEL
-                    if ((fl & 7u) && (w.y & 0xffu) && (w.y & 0xff00u) && !gated) {
-                        const int64_t r = (int64_t)(int32_t)w.x - key_min;
-                        const uint32_t code = (uint64_t)r < lim1 ? (uint32_t)r : (uint64_t)(r - vl) < lim2 ? (uint32_t)(nb + r - vl) : code_out;
-                        S.put((fl & 7u) | (code << 3), w.y & 0xffffu, common);
-                    }
-                    const uint32_t k_ref = w.y >> 16, k_seq = w.z & 0xffffu, k_clip = w.z >> 16;   // gated MAPQ pairs; 0 = nothing to add
-#if SVT_PACK_BRANCHLESS_REF
-                    R.put_if(k_ref, k_ref ? 1u : 0u, has_r ? 0u : 1u);
-                    has_r |= k_ref != 0u;
-#else
-                    if (k_ref) { R.put(k_ref, !has_r, false); has_r = true; }
+                UnitState st;
+#if SVT_PACK_AVX512
+                if (use_avx512) encode_records_avx512(recs, r0, r1, c, st, S, R, X);
+                else
 #endif
-                    if (k_seq) { X.put(k_seq, !has_s, false); has_s = true; }
-                    if (k_clip) { X.put(k_clip, !has_c, true); has_c = true; }
-                }
+                encode_records(recs, r0, r1, c, st, S, R, X);
+                const uint32_t lone = st.lone, or_flags = st.or_flags, or_span = st.or_span;
                 W.bad |= (lone ? kErrStraddleNoPair : 0u) | ((or_flags & 0xff00u) ? kErrLibIndex : 0u) |
                          ((or_flags & ~SVT_REC_FLAG_MASK) ? kErrReservedBits : 0u) | ((int32_t)or_span < 0 ? kErrNegativeSpan : 0u);
                 const uint32_t ns = S.finish(), nr = R.finish(), nx = X.finish();
                 off[3 * u + 1] = ns;
                 off[3 * u + 2] = nr;
                 off[3 * u + 3] = nx;
-                const size_t at = W.arena.size();
-                if (W.arena.capacity() < at + ns + nr + nx) W.arena.reserve(2 * W.arena.capacity() + ns + nr + nx);
-                W.arena.resize(at + ns + nr + nx);
-                std::memcpy(W.arena.data() + at, W.scratch.data(), (size_t)ns * 16);
-                std::memcpy(W.arena.data() + at + ns, W.scratch.data() + cap_s * 8, (size_t)nr * 16);
-                std::memcpy(W.arena.data() + at + ns + nr, W.scratch.data() + (cap_s + cap_r) * 8, (size_t)nx * 16);
+                const size_t at = W.arena.size;
+                W.arena.reserve(at + ns + nr + nx);
+                W.arena.size = at + ns + nr + nx;
+                std::memcpy(W.arena.p + at, W.scratch.data(), (size_t)ns * 16);
+                std::memcpy(W.arena.p + at + ns, W.scratch.data() + cap_s * 8, (size_t)nr * 16);
+                std::memcpy(W.arena.p + at + ns + nr, W.scratch.data() + (cap_s + cap_r) * 8, (size_t)nx * 16);
             }
-            C.n_slots = W.arena.size() - C.arena_at;
+            C.n_slots = W.arena.size - C.arena_at;
         }
+        W.ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w_t0).count();
     });
+    if (trace) {
+        std::fprintf(stderr, "[svt] pack: worker ms:");
+        for (const Worker& W : workers) std::fprintf(stderr, " %.1f", W.ms);
+        std::fprintf(stderr, "\n");
+    }
     mark("encode (one pass)");
     uint32_t bad = 0;
     int unit_error = kUnitOk;
@@ -325,7 +676,7 @@ int encode_packed(const svt_evidence_batch* in, const PackAlloc& A, PackedArrays
                 run += off[i];
                 off[i] = (uint32_t)run;
             }
-            std::memcpy(slots + C.base, workers[C.worker].arena.data() + C.arena_at, (size_t)C.n_slots * 16);
+            if (C.n_slots) std::memcpy(slots + C.base, workers[C.worker].arena.p + C.arena_at, (size_t)C.n_slots * 16);
         }
     });
     mark("offsets + final copy");

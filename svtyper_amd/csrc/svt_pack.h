@@ -24,6 +24,9 @@ struct PackedArrays {
     uint32_t common = 0;         // mapq_a | mapq_b << 8 of the one-half-word pair entries
 };
 
+// release the worker arenas svt_pack_evidence keeps between calls (svt_trim)
+void pack_trim();
+
 // the text svt_last_error() gives for the record-contract bits kErr* (also what the streaming pass reports)
 std::string record_error_text(uint32_t err_bits);
 

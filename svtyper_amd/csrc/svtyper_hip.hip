@@ -1388,6 +1388,7 @@ void svt_trim(void)
     g_pool.trim();
     g_pinned.trim();
     g_handles.trim();
+    pack_trim();
 }
 
 static int svt_genotype_impl(const svt_evidence_batch* in, svt_result* out, int device, unsigned flags)

@@ -157,3 +157,41 @@ def test_packed_resident_batch_and_long_units(hip_device, fixture_library):
     long_units = ev.EvidenceBatch(off, u, r, [fixture_library], 1.0, 1.0)
     got, want = _both(long_units, 0)
     assert_parity(got, want)
+
+
+def test_vector_and_scalar_encoders_write_the_same_slots(fixture_library):
+    """svt_pack.cpp encodes sixteen records at a time with AVX-512 where the host has it (runs of one-half-word pair
+    entries by compressing stores, wide entries / weight entries from mask bits, groups with a continuation record one
+    record at a time) and record by record otherwise (SVT_PACK_SCALAR=1 forces that form): same slots, same offsets,
+    on batches that mix every kind of record, unit lengths around the group size, gated deletions and empty units."""
+    import os
+    from svtyper_amd import hip
+    rng = np.random.default_rng(2026)
+    for trial in range(6):
+        batch = synth.make_units(3000, 100 + trial, [fixture_library], svtype_mix=(0.6, 0.2, 0.1, 0.1),
+                                 mean_frags=(5, 17, 33, 64, 100, 180)[trial], sd_frags=(4, 9, 16, 20, 30, 60)[trial], min_frags=0)
+        rec = batch.records
+        n = batch.n_records
+        firsts = set(int(x) for x in batch.rec_offset[:-1])
+        # continuation records (never a unit's first), odd MAPQ pairs (wide pair entries), reference reads and candidates
+        cont = np.array([i for i in rng.choice(n, n // 40, replace=False) if int(i) not in firsts], dtype=np.int64)
+        rec["flags"][cont] = (rec["flags"][cont] & 0xff00) | ev.REC_CONTINUATION
+        for name in ("ospan_len", "mapq_a", "mapq_b"):
+            rec[name][cont] = 0
+        odd = rng.choice(n, n // 5, replace=False)
+        rec["mapq_a"][odd] = rng.integers(0, 256, odd.size)
+        rec["mapq_b"][odd] = rng.integers(0, 256, odd.size)
+        for name, share in (("rs_a", 3), ("rs_b", 3), ("seq_l", 9), ("seq_r", 9), ("clip_l", 11), ("clip_r", 11)):
+            pick = rng.choice(n, n // share, replace=False)
+            rec[name][pick] = rng.integers(0, 256, pick.size)
+        rec["ospan_len"][rng.choice(n, n // 7, replace=False)] = rng.integers(0, 200000, n // 7)
+        got = {}
+        for mode in ("vector", "scalar"):
+            if mode == "scalar":
+                os.environ["SVT_PACK_SCALAR"] = "1"
+            try:
+                with hip.PackedEvidence(batch) as p:
+                    got[mode] = (p.slots().tobytes(), p.slot_offset().tobytes(), int(p.c.common_mapq))
+            finally:
+                os.environ.pop("SVT_PACK_SCALAR", None)
+        assert got["vector"] == got["scalar"], trial
