@@ -527,6 +527,7 @@ int encode_packed(const svt_evidence_batch* in, const PackAlloc& A, PackedArrays
     std::vector<Worker> workers(nt);
     std::vector<ChunkOut> chunks(n_chunks);
 
+    const bool read_only_probe = std::getenv("SVT_PACK_PROBE") != nullptr;
     bool use_avx512 = false;
 #if SVT_PACK_AVX512
     use_avx512 = cpu_has_avx512() && std::getenv("SVT_PACK_SCALAR") == nullptr;   // (SVT_PACK_SCALAR: tests compare the two forms)
@@ -610,6 +611,12 @@ int encode_packed(const svt_evidence_batch* in, const PackAlloc& A, PackedArrays
                 PairStream S(W.scratch.data());
                 WeightStream R(W.scratch.data() + cap_s * 8), X(W.scratch.data() + (cap_s + cap_r) * 8);
                 UnitState st;
+                if (read_only_probe) {     // SVT_PACK_PROBE=1 (measurements): touch the unit's records and nothing else
+                    uint32_t x = 0;
+                    for (uint64_t j = r0; j < r1; ++j) x ^= recs[j].x ^ recs[j].w;
+                    st.or_span = x & 0x7fffffffu;
+                    st.or_flags = 0;
+                } else
 #if SVT_PACK_AVX512
                 if (use_avx512) encode_records_avx512(recs, r0, r1, c, st, S, R, X);
                 else

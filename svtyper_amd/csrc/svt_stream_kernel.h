@@ -52,6 +52,11 @@
 #ifndef SVT_FETCH_FAST_INTERIOR
 #define SVT_FETCH_FAST_INTERIOR 1 // steps in which every unit of the tile is inside its record range fetch without range tests
 #endif
+#ifndef SVT_WINDOW_SINGLE_PATH
+#define SVT_WINDOW_SINGLE_PATH 0 // 1: library windows of ONE library take the one-library consumer (record_single) -- 7 % fewer
+                                 // instructions for those windows, but with both consumers in one kernel the two-tile build spills
+                                 // 25 registers (41 MB of scratch per launch); with record_window alone it spills none and runs 2-9 % faster
+#endif
 #ifndef SVT_LAST_TILE_TAIL_NT
 #define SVT_LAST_TILE_TAIL_NT 1 // two tiles per wave: the last lines of the second tile's units are read for the last time
 #endif
@@ -592,7 +597,7 @@ __global__ __launch_bounds__(kBlock, MODE == kSingleLds ? SVT_STREAM_WAVES : MOD
                         if (!SSO || MODE == kGeneral || has_cont) consume(w, k, edge_tag, kind_tag, std::true_type{});
                         else consume(w, k, edge_tag, kind_tag, std::false_type{});
                     };
-                    if (MODE == kMultiLds && (wd.lib_cnt == 1u || SVT_STREAM_PROBE == 5)) {       // (workgroup-uniform; probe 5: timing only)
+                    if (MODE == kMultiLds && SVT_WINDOW_SINGLE_PATH && (wd.lib_cnt == 1u || SVT_STREAM_PROBE == 5)) {       // (workgroup-uniform; probe 5: timing only)
                         if (edge) run(std::true_type{}, kind_one{});
                         else run(std::false_type{}, kind_one{});
                     } else if (edge) run(std::true_type{}, kind_any{});
