@@ -205,10 +205,13 @@ __device__ __forceinline__ void tile_block_range(const uint32_t nblk, uint32_t& 
     min_blk = (uint32_t)__builtin_amdgcn_readfirstlane((int)m);
 }
 
-#ifndef SVT_STORE_POLICY
-#define SVT_STORE_POLICY " nt"   // cache policy of the result stores ("", " nt", " sc1", " sc0 sc1"): a result line is written once and
-                                 // read by nobody on the device; measured on the 1 M-unit pass: nt 0.340 ms, sc1 0.354, default 0.359
-#endif
+// Result records leave with non-temporal stores: a result line is written once and read by nobody on the device
+// (measured on the 1 M-unit pass: nt 0.340 ms, sc1 0.354, default policy 0.359).  The store is the compiler's own
+// (__builtin_nontemporal_store -> global_store_dwordx4 ... nt): an inline-assembly store is invisible to the
+// hazard recognizer -- a 16-byte VMEM store whose data registers are overwritten by the very next instruction needs a
+// wait state -- and one build of the two-tile window kernel, whose register allocation put a spill reload right
+// behind such a store, wrote a foreign dword into four pieces of a few result records.
+// SVT_STORE_POLICY (measurements only): "" / " sc1" / " sc0 sc1" select an assembly store with that policy (+ s_nop).
 #ifndef SVT_STORE_DIRECT
 #define SVT_STORE_DIRECT 0    // 1: every lane stores the eight pieces of its own record (no LDS staging)
 #endif
@@ -216,7 +219,11 @@ __device__ __forceinline__ void tile_block_range(const uint32_t nblk, uint32_t& 
 __device__ __forceinline__ void store_piece(uint4* dst, const uint4 v)
 {
     const u32x4 vv = {v.x, v.y, v.z, v.w};
-    asm volatile("global_store_dwordx4 %0, %1, off" SVT_STORE_POLICY ::"v"(dst), "v"(vv) : "memory");
+#ifdef SVT_STORE_POLICY
+    asm volatile("global_store_dwordx4 %0, %1, off" SVT_STORE_POLICY "\n\ts_nop 1" ::"v"(dst), "v"(vv) : "memory");
+#else
+    __builtin_nontemporal_store(vv, reinterpret_cast<u32x4*>(dst));
+#endif
 }
 
 // result records of a tile: lane-major into the ring, unit-major out of it, one full 128-byte line per eight lanes
