@@ -20,7 +20,8 @@ while time.time() - t0 < budget:
     libs = [fixture if (k == 0 and rng.random() < 0.5) else
             synth.normal_library(float(rng.uniform(150, 900)), float(rng.uniform(15, 260)), n=int(rng.integers(3000, 60000)),
                                  seed=int(rng.integers(1 << 30))) for k in range(n_libs)]
-    kind = it % 5 if it % 11 else 5
+    kind = 6 if it % 13 == 7 else (it % 5 if it % 11 else 5)
+    by_sample = 0       # > 0: the batch is site-major with this many samples per site (also checked sample-major)
     if kind == 0:
         b = P._fuzz_batch(5000 + it, libs, wide=bool(rng.integers(2)))
     elif kind == 1:
@@ -37,11 +38,18 @@ while time.time() - t0 < budget:
                              mean_frags=float(rng.uniform(2, 25)), sd_frags=float(rng.uniform(1, 20)), min_frags=0,
                              max_frags=int(rng.integers(30, 260)), frac_empty=0.02, frac_skip=0.01)
     elif kind == 4:  # several samples with their own libraries: the streaming kernel's library windows (svt_unit.libs)
-        b = synth.make_multisample(int(rng.integers(1, 400)), int(rng.choice([1, 2, 3, 8, 32, 40])), seed=it,
+        by_sample = int(rng.choice([1, 2, 3, 8, 32, 40]))
+        b = synth.make_multisample(int(rng.integers(1, 400)), by_sample, seed=it,
                                    mean_frags=float(rng.uniform(2, 80)), sd_frags=float(rng.uniform(1, 30)), min_frags=0,
                                    max_frags=int(rng.integers(40, 200)))
         if rng.random() < 0.5:      # units in any order, some dropped
+            by_sample = 0
             b = synth.permute_units(b, rng.permutation(b.n_units)[:max(1, int(b.n_units * rng.uniform(0.3, 1.0)))])
+    elif kind == 6:  # many samples and enough units for two tiles per wave in the library-window kernel
+        by_sample = int(rng.choice([8, 32]))
+        b = synth.make_multisample(int(rng.integers(221_184, 280_000)) // by_sample + 1, by_sample, seed=it,
+                                   mean_frags=float(rng.uniform(2, 20)), sd_frags=float(rng.uniform(1, 12)), min_frags=0,
+                                   max_frags=int(rng.integers(30, 120)))
     else:   # random bytes again, libraries close together per unit, MAPQs <= 127
         b = P._fuzz_batch(9000 + it, libs, wide=False)
         b.units["var_length"] = np.abs(b.units["var_length"])
@@ -62,6 +70,15 @@ while time.time() - t0 < budget:
         except AssertionError as e:
             print("MISMATCH at iteration %d (kind %d, %d libs, flags %d): %s" % (it, kind, n_libs, flags, e))
             sys.exit(1)
+    if by_sample > 1:   # the same units handed over sample-major, result records written site-major (svt_batch_result_order)
+        sm, _ = synth.to_sample_major(b, by_sample)
+        for flags in (0, ev.FLAG_SSO_ASSOCIATION):
+            with hip.DeviceBatch(sm, 0, flags) as d:
+                d.result_order(by_sample)
+                d.genotype(sync=True)
+                if d.results().rec.tobytes() != hip.genotype_batch(b, 0, flags).rec.tobytes():
+                    print("RESULT-ORDER MISMATCH at iteration %d (kind %d, %d samples, flags %d)" % (it, kind, by_sample, flags))
+                    sys.exit(1)
     try:                # the packed evidence format, where it can hold the batch: same bytes as the canonical pass
         packed = hip.PackedEvidence(b)
     except hip.SvtyperHipError:
