@@ -127,13 +127,14 @@ def library_stamp() -> str:
 
 
 def source_stamp() -> str:
-    """Identity of the kernel SOURCES (sha256 over svtyper_amd/csrc/{*.hip,*.h,*.cpp,Makefile} and include/*.h, first
-    16 hex digits).  hipcc does not produce the same bytes twice from the same sources, so a PMC entry is keyed by
-    this and survives a rebuild by build() -- and is still refused once any kernel source has changed."""
+    """Identity of the kernel SOURCES (sha256 over svtyper_amd/csrc/{*.hip,*.h,Makefile} and include/*.h, first 16 hex
+    digits; the host-only *.cpp files -- BAM reader, formatter, packed-evidence encoder -- do not reach the device
+    code).  hipcc does not produce the same bytes twice from the same sources, so a PMC entry is keyed by this and
+    survives a rebuild by build() -- and is still refused once any kernel source has changed."""
     import glob
     h = hashlib.sha256()
     files = sorted(glob.glob(os.path.join(ROOT, "svtyper_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "svtyper_amd", "csrc", "*.h")) +
-                   glob.glob(os.path.join(ROOT, "svtyper_amd", "csrc", "*.cpp")) + [os.path.join(ROOT, "svtyper_amd", "csrc", "Makefile")] +
+                   [os.path.join(ROOT, "svtyper_amd", "csrc", "Makefile")] +
                    glob.glob(os.path.join(ROOT, "include", "*.h")))
     for path in files:
         h.update(os.path.basename(path).encode() + b"\0")

@@ -166,6 +166,9 @@ inline void encode_records(const Slot* recs, const uint64_t r0, const uint64_t r
     }
 }
 
+#ifndef SVT_PACK_PREFETCH
+#define SVT_PACK_PREFETCH 128   // records (16 bytes each) the vector loop prefetches ahead; 0 = none
+#endif
 #if defined(__x86_64__)
 #define SVT_PACK_AVX512 1
 #include <immintrin.h>
@@ -190,6 +193,14 @@ inline void encode_records_avx512(const Slot* recs, const uint64_t r0, const uin
     const __m512i v_common = _mm512_set1_epi32((int32_t)c.common);
     uint64_t j = r0;
     for (; j + 16 <= r1; j += 16) {
+#if SVT_PACK_PREFETCH
+        // the records are a pure stream: ask for the lines a few groups ahead (sixteen workers share the memory system, and
+        // what the hardware prefetcher brings on its own arrives late under that load)
+        _mm_prefetch(reinterpret_cast<const char*>(recs + j + SVT_PACK_PREFETCH), _MM_HINT_T0);
+        _mm_prefetch(reinterpret_cast<const char*>(recs + j + SVT_PACK_PREFETCH + 4), _MM_HINT_T0);
+        _mm_prefetch(reinterpret_cast<const char*>(recs + j + SVT_PACK_PREFETCH + 8), _MM_HINT_T0);
+        _mm_prefetch(reinterpret_cast<const char*>(recs + j + SVT_PACK_PREFETCH + 12), _MM_HINT_T0);
+#endif
         const __m512i a = _mm512_loadu_si512(recs + j), b = _mm512_loadu_si512(recs + j + 4);
         const __m512i d = _mm512_loadu_si512(recs + j + 8), e = _mm512_loadu_si512(recs + j + 12);
         // dword K of the sixteen records (a lambda would not inherit this function's target attribute)

@@ -1,9 +1,14 @@
+#!/usr/bin/env python
+"""svt_pack_evidence (host encoder of packed evidence) on the configs[2] workload with 1 / 8 / 16 worker threads
+(SVT_PACK_THREADS), best of three with pauses (the box's cgroup schedules 16 CPUs per 100 ms: bursts right behind one
+another get throttled).  SVT_PACK_SCALAR=1: the record-by-record form; SVT_PACK_SPREAD=0: no worker placement;
+SVT_PACK_PROBE=1: read the records only; SVT_TRACE=1: stage and per-worker times.   python tools/pack_scale.py"""
 import time, sys, os
 sys.path.insert(0, os.getcwd())
 import bench
 from svtyper_amd import hip
 b = bench.generate("c3_mixed_1m", 1000000, 0, bench.usable_cpus())
-for nt in (1, 8, 16):
+for nt in (1, 16):
     os.environ["SVT_PACK_THREADS"] = str(nt)
     best = 1e9
     for i in range(3):
