@@ -12,6 +12,7 @@
 // two passes over the 1.6 GB of records per million units -- count, then write -- and validated the unit arrays
 // serially: 113-125 ms per million units on 16 threads; this one: see DESIGN.md 3.2.)
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <chrono>
 #include <cstdio>
@@ -395,6 +396,8 @@ struct L3Group {
     cpu_set_t cpus;
     long package;   // socket
     long node;      // NUMA node of the group's first CPU
+    unsigned cores; // physical cores among `cpus` (distinct core ids)
+    std::vector<long> core_ids;
 };
 const std::vector<L3Group>& l3_groups()
 {
@@ -418,6 +421,7 @@ const std::vector<L3Group>& l3_groups()
             const long id = read_long("/sys/devices/system/cpu/cpu%d/cache/index3/id", cpu);
             const long pkg = read_long("/sys/devices/system/cpu/cpu%d/topology/physical_package_id", cpu);
             if (id < 0 || pkg < 0) return std::vector<L3Group>();   // topology not readable: no placement
+            const long core = read_long("/sys/devices/system/cpu/cpu%d/topology/core_id", cpu);
             const long key = pkg * 100000 + id;
             size_t g = 0;
             while (g < ids.size() && ids[g] != key) ++g;
@@ -427,9 +431,14 @@ const std::vector<L3Group>& l3_groups()
                 CPU_ZERO(&ng.cpus);
                 ng.package = pkg;
                 ng.node = -2;   // filled below
+                ng.cores = 0;
                 out.push_back(ng);
             }
             CPU_SET(cpu, &out[g].cpus);
+            if (std::find(out[g].core_ids.begin(), out[g].core_ids.end(), core) == out[g].core_ids.end()) {
+                out[g].core_ids.push_back(core);
+                ++out[g].cores;
+            }
         }
         return out;
     }();
@@ -532,58 +541,76 @@ int encode_packed(const svt_evidence_batch* in, const PackAlloc& A, PackedArrays
     out->common = common;
     mark("tables + allocations");
     const uint64_t n_chunks = (n + kChunkUnits - 1) / kChunkUnits;
-    unsigned want = std::min(usable_cpus(), 16u);
-    if (const char* e = std::getenv("SVT_PACK_THREADS")) want = (unsigned)std::max(1, std::atoi(e));   // (measurements)
-    const unsigned nt = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(want, n_chunks));
-    std::vector<Worker> workers(nt);
-    std::vector<ChunkOut> chunks(n_chunks);
-
     const bool read_only_probe = std::getenv("SVT_PACK_PROBE") != nullptr;
     bool use_avx512 = false;
 #if SVT_PACK_AVX512
     use_avx512 = cpu_has_avx512() && std::getenv("SVT_PACK_SCALAR") == nullptr;   // (SVT_PACK_SCALAR: tests compare the two forms)
 #endif
-    // ---- the one pass over the records: contract check + the three streams of every unit (record order)
+    // ---- where the workers run: the L3 groups next to the records (on their NUMA node, else on the caller's socket)
     const char* spread_env = std::getenv("SVT_PACK_SPREAD");
-    const bool spread = nt > 1 && (spread_env ? std::atoi(spread_env) != 0 : true);
-    std::vector<const cpu_set_t*> home;      // the L3 groups next to the records: on their NUMA node, else on the caller's socket
-    if (spread) {
+    const int spread = n_chunks > 1 && spread_env ? std::atoi(spread_env) : 0;   // 0: placement is the scheduler's business, 1: a worker stays in its L3 group, 2: on one CPU of it
+    std::vector<const L3Group*> home;
+    if (n_chunks > 1) {
         const long node = node_of_memory(in->records, n_rec_claimed * 16);
         if (node >= 0) {
             for (const L3Group& g : l3_groups()) {
                 int first = -1;
                 for (int cpu = 0; cpu < CPU_SETSIZE && first < 0; ++cpu)
                     if (CPU_ISSET(cpu, &g.cpus)) first = cpu;
-                if (node_of_cpu(first) == node) home.push_back(&g.cpus);
+                if (node_of_cpu(first) == node) home.push_back(&g);
             }
         }
         if (home.empty()) {
             const long pkg = package_of_cpu(sched_getcpu());
             for (const L3Group& g : l3_groups())
-                if (g.package == pkg) home.push_back(&g.cpus);
+                if (g.package == pkg) home.push_back(&g);
         }
         if (trace) std::fprintf(stderr, "[svt] pack: records on NUMA node %ld, %zu L3 groups chosen\n", node, home.size());
     }
+    // ---- how many: the encoder is a burst of a few ms per worker.  A cgroup CPU quota is CPU time per accounting period
+    // (16 CPUs = 1.6 s per 100 ms), not a number of threads: a call whose whole work fits well inside one period's
+    // allowance runs one worker per physical core next to the records (measured on 2 x EPYC 9575F, 1 M units: 16 / 32 / 64
+    // / 128 workers -> 38 / 20 / 11 / 15 ms); a longer one is bound by the quota whatever it starts and keeps to
+    // usable_cpus() (<= 16: the memory system of one socket does not feed more sustained workers any faster).
+    unsigned want = std::min(usable_cpus(), 16u);
+    {
+        unsigned cores = 0;
+        for (const L3Group* g : home) cores += g->cores;
+        cores = std::min(cores, 64u);
+        const CpuQuota q = cpu_quota();
+        const double est_cpu_s = (double)n_rec_claimed * 6e-9 + (double)n * 50e-9;
+        if (cores > want && (q.period_s == 0.0 || est_cpu_s <= 0.6 * q.cpu_s)) want = cores;
+    }
+    if (const char* e = std::getenv("SVT_PACK_THREADS")) want = (unsigned)std::max(1, std::atoi(e));   // (measurements)
+    const unsigned nt = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(want, n_chunks));
+    std::vector<Worker> workers(nt);
+    std::vector<ChunkOut> chunks(n_chunks);
+    if (trace) std::fprintf(stderr, "[svt] pack: %u workers\n", nt);
+    // ---- the one pass over the records: contract check + the three streams of every unit (record order).  Chunks are
+    // claimed, not dealt: a worker that shares its core or loses its CPU for a while just takes fewer.
+    std::atomic<uint64_t> next_chunk{0};
     run_threads(nt, [&](unsigned t) {
         const auto w_t0 = std::chrono::steady_clock::now();
         // (worker 0 is the calling thread: its placement is the caller's business)
         if (spread && t > 0 && home.size() > 1) {
             const size_t n_groups = home.size();
-            const cpu_set_t& g = *home[t % n_groups];
-            // the (t / n_groups)-th CPU of the group: the low CPU numbers of a group are distinct cores, their SMT siblings follow
-            cpu_set_t one;
-            CPU_ZERO(&one);
-            unsigned want_k = t / (unsigned)n_groups, k = 0;
-            for (int cpu = 0; cpu < CPU_SETSIZE; ++cpu)
-                if (CPU_ISSET(cpu, &g) && k++ == want_k) { CPU_SET(cpu, &one); break; }
-            if (CPU_COUNT(&one) == 0) one = g;
+            const cpu_set_t& g = home[t % n_groups]->cpus;
+            cpu_set_t one = g;
+            if (spread == 2) {
+                // the (t / n_groups)-th CPU of the group: the low CPU numbers of a group are distinct cores, their SMT siblings follow
+                CPU_ZERO(&one);
+                unsigned want_k = t / (unsigned)n_groups, k = 0;
+                for (int cpu = 0; cpu < CPU_SETSIZE; ++cpu)
+                    if (CPU_ISSET(cpu, &g) && k++ == want_k) { CPU_SET(cpu, &one); break; }
+                if (CPU_COUNT(&one) == 0) one = g;
+            }
             (void)pthread_setaffinity_np(pthread_self(), sizeof one, &one);
         }
         Worker& W = workers[t];
         // a guess at this worker's share (3.2 bytes per record is typical): growing later is only a copy
         W.arena = g_arenas.get();
-        W.arena.reserve((size_t)(n_rec_claimed / nt / 4 + 4096));
-        for (uint64_t ch = t; ch < n_chunks; ch += nt) {
+        W.arena.reserve((size_t)(n_rec_claimed / nt / 4 * 3 / 2 + 4096));   // (chunks are claimed: shares differ)
+        for (uint64_t ch; (ch = next_chunk.fetch_add(1, std::memory_order_relaxed)) < n_chunks;) {
             ChunkOut& C = chunks[ch];
             C.worker = t;
             C.arena_at = W.arena.size;

@@ -45,6 +45,7 @@ def test_bench_line_has_the_contract_keys(hip_device):
     assert 0 < d["large_batch"]["frac"] <= 1.0
     assert d["one_shot_packed"]["results_equal_headline"] is True and d["one_shot_packed"]["bytes_per_fragment_record"] < 5
     assert d["one_shot_packed"]["pack_inclusive_wall_ms"] > d["one_shot_packed"]["wall_ms"]
+    assert d["one_shot_packed"]["from_records_wall_ms"] > d["one_shot_packed"]["wall_ms"]
     # the singlesample association, the configs[4] shape and the 8-GPU shard: own fractions, own (or no) traffic figures
     assert 0 < d["sso"]["frac"] <= 1.0 and d["sso"]["units"] == 30000
     c5 = d["c5_multisample"]
