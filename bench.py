@@ -662,16 +662,30 @@ def main():
                     same = bool(np.array_equal(dc.results().rec, c_res)) and bool(np.array_equal(dc.site_qual(N_SAMPLES_C5), c_qual))
                 leg["site_major_input"] = {"kernel_ms": s_ms, "frac": c_alg / (s_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                            "results_and_site_qual_equal": same}
+                c_res_site = c_res
                 del c_res
-                # the same batch WITHOUT the hints: any-geometry mode, histogram tables through L2
+                # the same batch WITHOUT the hints: svt_batch_create reads every unit's library window off the uploaded
+                # records (svt_window_scan_kernel, `create_scan_ms` = what that adds to the create) and the pass stages
+                # windows as before; `general_tables`: SVT_FLAG_GENERAL_TABLES, every histogram look-up through L2
                 nh_units = c5_batch.units.copy()
                 nh_units["libs"] = 0
                 nh = ev.EvidenceBatch(c5_batch.rec_offset, nh_units, c5_batch.records, c5_batch.libs, c5_batch.split_weight, c5_batch.disc_weight)
+                t0 = time.perf_counter()
                 with hip.DeviceBatch(nh, device=local_rank, flags=sso) as dn:
+                    create_nh = time.perf_counter() - t0
                     dn.genotype(sync=True)
                     g_ms = time_passes(dn, max(3, args.steps // 2))
-                    leg["hintless"] = {"table_mode": dn.table_mode(), "kernel_ms": g_ms, "frac": c_alg / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
-                del nh, nh_units
+                    leg["hintless"] = {"table_mode": dn.table_mode(), "kernel_ms": g_ms, "frac": c_alg / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                       "results_equal": bool(np.array_equal(dn.results().rec, c_res_site)), "create_ms": create_nh * 1e3}
+                t0 = time.perf_counter()
+                with hip.DeviceBatch(nh, device=local_rank, flags=sso | ev.FLAG_GENERAL_TABLES) as dn:
+                    create_gen = time.perf_counter() - t0
+                    dn.genotype(sync=True)
+                    g_ms = time_passes(dn, max(3, args.steps // 2))
+                    leg["general_tables"] = {"table_mode": dn.table_mode(), "kernel_ms": g_ms, "frac": c_alg / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                             "create_ms": create_gen * 1e3}
+                leg["hintless"]["create_scan_ms"] = (create_nh - create_gen) * 1e3
+                del nh, nh_units, c_res_site
             except StopIteration:
                 pass
             except Exception as e:

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SVT_ABI_VERSION 11
+#define SVT_ABI_VERSION 12
 
 /* ---- error codes (0 = ok, <0 = error; text via svt_last_error()) ---------- */
 #define SVT_OK 0
@@ -61,6 +61,9 @@ extern "C" {
  *   1 (sso)    : contributions are first summed per fragment starting from 0,
  *                then added to the site total (singlesample.py:246-276,367-372) */
 #define SVT_FLAG_SSO_ASSOCIATION 0x1u
+/* keep every look-up table in L2 (the pass's general mode) even where a workgroup could stage its libraries'
+ * histograms in LDS: for measurements and for tests that compare the two table paths.  Results are the same.  */
+#define SVT_FLAG_GENERAL_TABLES 0x10u
 /* (bits 1..3 selected round 1's tiled device layouts, which are gone: they are rejected as unknown bits.)
  * Device layout of a resident batch: nothing is re-tiled or re-encoded -- the CSR arrays go to HBM as the
  * caller packed them and ONE kernel (svt_stream_kernel) takes them to the result records, streaming every
@@ -135,8 +138,11 @@ typedef struct svt_unit {
                            a record outside its unit's window is a contract violation.
                            Without hints a batch whose libraries all fit LDS together
                            (a sample with a few read-group libraries) is treated as ONE
-                           window; a joint batch of many samples needs the hints to stay
-                           out of the slow general mode.
+                           window; for a joint batch of many samples svt_batch_create
+                           reads the windows off the uploaded records itself (one
+                           streaming pass on the device, ~0.3 ms per 1.6 GB); only the
+                           pipelined one-shot (svt_genotype), which uploads while it
+                           runs, then takes the slow general mode.
                            Upper 16 bits must be 0.                               */
 } svt_unit;
 #define SVT_UNIT_LIBS(first, count) ((uint32_t)(first) | (uint32_t)(count) << 8)

@@ -60,6 +60,7 @@
 #include "svt_pack.h"
 #include "svt_stream_kernel.h"
 #include "svt_packed_kernel.h"
+#include "svt_window_scan_kernel.h"
 #include "svt_geometry_kernel.h"
 #include "svt_bayes_kernel.h"
 #include "svt_host_tables.h"
@@ -70,7 +71,7 @@ using namespace svt;
 // ------------------------------------------------------------------------------------------
 // batch object
 // ------------------------------------------------------------------------------------------
-constexpr unsigned kKnownFlags = SVT_FLAG_SSO_ASSOCIATION;
+constexpr unsigned kKnownFlags = SVT_FLAG_SSO_ASSOCIATION | SVT_FLAG_GENERAL_TABLES;
 
 struct svt_batch {
     int device = 0;
@@ -347,16 +348,20 @@ int create_stream(const svt_evidence_batch* in, svt_batch* b, void* d_records_re
     const bool whole_batch_window = !all_hinted && n > 0 && in->n_libs <= 255 &&
                                     kSBins + all_bins * 4 + in->n_libs * sizeof(WinLib) + 64 + kWavesPerBlock * kStreamRingBytes <= (160 * 1024 / 2);
     const uint32_t whole_key = in->n_libs << 8;   // SVT_UNIT_LIBS(0, n_libs)
-    auto window_key = [&](uint64_t u) { return all_hinted ? in->units[u].libs & 0xffffu : whole_key; };
-    bool windowed = in->n_libs > 1 && (all_hinted || whole_batch_window) && T.fast_geometry;
-    if (windowed) {
+    const bool may_window = in->n_libs > 1 && T.fast_geometry && !(b->flags & SVT_FLAG_GENERAL_TABLES);
+    bool windowed = may_window && (all_hinted || whole_batch_window);
+    // No hints and too many libraries for one window: the windows are read off the records themselves, on the device,
+    // right after the upload (svt_window_scan_kernel.h) -- not when the caller uploads the records later (pipelined one-shot)
+    const bool derive_windows = may_window && !windowed && n > 0 && in->n_libs <= 255 && T.narrow_bins && !defer_records;
+    // group the units by window key (a counting sort: stable, original order inside a group) and cut the groups into chunks
+    auto group_units = [&](auto&& key_of) {
         std::vector<uint32_t> start(65537, 0u);
-        for (uint64_t u = 0; u < n; ++u) ++start[window_key(u) + 1];
+        for (uint64_t u = 0; u < n; ++u) ++start[key_of(u) + 1];
         for (uint32_t k = 0; k < 65536u; ++k) start[k + 1] += start[k];
         perm.resize(n);
         {
             std::vector<uint32_t> at(start.begin(), start.end() - 1);
-            for (uint64_t u = 0; u < n; ++u) perm[at[window_key(u)]++] = (uint32_t)u;   // stable: original order inside a group
+            for (uint64_t u = 0; u < n; ++u) perm[at[key_of(u)]++] = (uint32_t)u;
         }
         for (uint32_t k = 0; k < 65536u; ++k) {
             if (start[k + 1] == start[k]) continue;
@@ -373,6 +378,9 @@ int create_stream(const svt_evidence_batch* in, svt_batch* b, void* d_records_re
                 windows.push_back(w);
             }
         }
+    };
+    if (windowed) {
+        group_units([&](uint64_t u) -> uint32_t { return all_hinted ? in->units[u].libs & 0xffffu : whole_key; });
         tm.mark("group units by library window");
     }
     const uint32_t n_l10 = (uint32_t)T.l10.size();
@@ -419,6 +427,29 @@ int create_stream(const svt_evidence_batch* in, svt_batch* b, void* d_records_re
     }
     tm.mark("H2D CSR + tables (staged)");
 
+    if (derive_windows) {
+        // the scan's output borrows the buffer of the permutation it leads to
+        void* pp = nullptr;
+        SVT_TRY(g_pool.get(b->device, n * sizeof(uint32_t), &pp, &b->cap_perm));
+        b->d_perm = static_cast<uint32_t*>(pp);
+        const uint32_t n32 = (uint32_t)n;
+        const unsigned waves = (unsigned)std::min<uint64_t>(n, 256ull * 32);          // the waves one pass of the chip holds
+        const dim3 grid((waves + kScanBlock / kWave - 1) / (kScanBlock / kWave)), block(kScanBlock);
+        hipLaunchKernelGGL(svt_window_scan_kernel, grid, block, 0, b->stream, static_cast<const uint4*>(b->d_records), b->d_off, n32, b->d_perm);
+        HIP_TRY(hipGetLastError());
+        std::vector<uint32_t> seen(n);
+        HIP_TRY(hipMemcpyAsync(seen.data(), b->d_perm, n * sizeof(uint32_t), hipMemcpyDeviceToHost, b->stream));
+        HIP_TRY(hipStreamSynchronize(b->stream));
+        tm.mark("library windows from the records (device scan)");
+        bool all_seen = true;
+        for (uint64_t u = 0; u < n && all_seen; ++u) all_seen = seen[u] != 0u;   // (0: a unit whose libraries lie > 255 apart)
+        if (all_seen) {
+            group_units([&](uint64_t u) -> uint32_t { return seen[u] & 0xffffu; });
+            windowed = true;
+            tm.mark("group units by library window");
+        }
+    }
+
     // one library whose tables fit beside the rings: tables in LDS, 32-bit index math; anything else reads
     // the tables through L2 with exact 64-bit geometry
     constexpr size_t kStreamLdsPerWg = (160 * 1024 / 3) & ~size_t(127);   // three workgroups per CU
@@ -429,22 +460,29 @@ int create_stream(const svt_evidence_batch* in, svt_batch* b, void* d_records_re
     const size_t window_lds = kSBins + (((size_t)max_win_bins * kLdsBin + 15) & ~size_t(15)) + (size_t)max_win_libs * sizeof(WinLib);
     windowed = windowed && T.narrow_bins && window_lds + kWavesPerBlock * kStreamRingBytes <= kStreamLdsPerWg2;
     b->mode = single ? kSingleLds : windowed ? kMultiLds : kGeneral;
+    // units that already come grouped by window (a sample-major batch, a one-window batch) need no permutation:
+    // the kernel then walks the units themselves (no index loads in front of every unit header)
+    bool identity = true;
     if (windowed) {
         Stager st(b->stream);
         void* pp = nullptr;
-        // units that already come grouped by window (a sample-major batch, a one-window batch) need no permutation:
-        // the kernel then walks the units themselves (no index loads in front of every unit header)
-        bool identity = true;
         for (uint64_t u = 0; u < n && identity; ++u) identity = perm[u] == (uint32_t)u;
         if (!identity) {
-            SVT_TRY(g_pool.get(b->device, std::max<uint64_t>(n, 1) * sizeof(uint32_t), &pp, &b->cap_perm));
-            b->d_perm = static_cast<uint32_t*>(pp);
+            if (!b->d_perm) {
+                SVT_TRY(g_pool.get(b->device, std::max<uint64_t>(n, 1) * sizeof(uint32_t), &pp, &b->cap_perm));
+                b->d_perm = static_cast<uint32_t*>(pp);
+            }
             SVT_TRY(st.copy(b->d_perm, perm.data(), n * sizeof(uint32_t)));
         }
         SVT_TRY(upload(&b->d_chunks, chunks, st));
         SVT_TRY(upload(&b->d_windows, windows, st));
         SVT_TRY(st.finish());
         b->n_chunks = (uint32_t)chunks.size();
+    }
+    if (b->d_perm && (!windowed || identity)) {   // (the scan's buffer when no permutation came of it)
+        g_pool.put(b->device, b->d_perm, b->cap_perm);
+        b->d_perm = nullptr;
+        b->cap_perm = 0;
     }
     StreamArgs& a = b->sargs;
     a.records = static_cast<const uint4*>(b->d_records);

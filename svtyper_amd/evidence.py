@@ -19,6 +19,7 @@ SVTYPE_CODE = {"DEL": 0, "DUP": 1, "INV": 2, "BND": 3}  # classic.py:228
 SVTYPE_NAME = {v: k for k, v in SVTYPE_CODE.items()}
 
 FLAG_SSO_ASSOCIATION = 0x1
+FLAG_GENERAL_TABLES = 0x10     # keep every table in L2 (the general mode): measurements, table-path comparisons
 
 REC_ALT_STRADDLE = 1 << 0
 REC_REF_STRADDLE_A = 1 << 1

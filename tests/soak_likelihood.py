@@ -13,6 +13,7 @@ import bench
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 first = int(sys.argv[2]) if len(sys.argv) > 2 else 0      # seeds derive from the iteration number
 t0, it, units, n_packed = time.time(), first, 0, 0
+modes = {}            # table modes the hint-less / general-table resident batches ran in
 fixture = bench.fixture_library()
 while time.time() - t0 < budget:
     rng = np.random.default_rng(1000 + it)
@@ -70,6 +71,18 @@ while time.time() - t0 < budget:
         except AssertionError as e:
             print("MISMATCH at iteration %d (kind %d, %d libs, flags %d): %s" % (it, kind, n_libs, flags, e))
             sys.exit(1)
+    if n_libs > 1:      # resident batches without hints (one window, or windows read off the records) and with every table in L2
+        nh = synth.permute_units(b, np.arange(b.n_units))
+        nh.units["libs"] = 0
+        for flags in (0, ev.FLAG_SSO_ASSOCIATION):
+            ref_bytes = hip.genotype_batch(b, 0, flags).rec.tobytes()
+            for x, fl in ((nh, flags), (nh, flags | ev.FLAG_GENERAL_TABLES), (b, flags | ev.FLAG_GENERAL_TABLES)):
+                with hip.DeviceBatch(x, 0, fl) as d:
+                    d.genotype(sync=True)
+                    modes[d.table_mode()] = modes.get(d.table_mode(), 0) + 1
+                    if d.results().rec.tobytes() != ref_bytes:
+                        print("TABLE-PATH MISMATCH at iteration %d (kind %d, %d libs, flags %#x, mode %d)" % (it, kind, n_libs, fl, d.table_mode()))
+                        sys.exit(1)
     if by_sample > 1:   # the same units handed over sample-major, result records written site-major (svt_batch_result_order)
         sm, _ = synth.to_sample_major(b, by_sample)
         for flags in (0, ev.FLAG_SSO_ASSOCIATION):
@@ -92,5 +105,5 @@ while time.time() - t0 < budget:
                     sys.exit(1)
     it += 1
     units += b.n_units
-print("soak ok: iterations %d..%d, %d units, %d flag combinations each, %d batches also as packed evidence, %.0f s"
-      % (first, it - 1, units, len(P.ALL_FLAGS), n_packed, time.time() - t0))
+print("soak ok: iterations %d..%d, %d units, %d flag combinations each, %d batches also as packed evidence, table modes of the "
+      "hint-less / general-table batches %s, %.0f s" % (first, it - 1, units, len(P.ALL_FLAGS), n_packed, sorted(modes.items()), time.time() - t0))

@@ -49,7 +49,7 @@ def test_bench_line_has_the_contract_keys(hip_device):
     # the singlesample association, the configs[4] shape and the 8-GPU shard: own fractions, own (or no) traffic figures
     assert 0 < d["sso"]["frac"] <= 1.0 and d["sso"]["units"] == 30000
     c5 = d["c5_multisample"]
-    assert 0 < c5["frac"] <= 1.0 and c5["table_mode"] == 1 and c5["units"] % 32 == 0 and c5["hintless"]["table_mode"] == 2
+    assert 0 < c5["frac"] <= 1.0 and c5["table_mode"] == 1 and c5["units"] % 32 == 0 and c5["hintless"]["table_mode"] == 1 and c5["hintless"]["results_equal"] and c5["general_tables"]["table_mode"] == 2
     assert c5["site_major_input"]["results_and_site_qual_equal"] is True
     for leg in (d["sso"], c5):
         assert leg["traffic"] is None or "these kernel sources" in leg["traffic_source"]

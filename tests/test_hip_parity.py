@@ -627,11 +627,20 @@ def test_full_size_multisample_properties(hip_device, full_c5):
     multi = hip.genotype_multi(batch, [hip_device] * 3, group=S)
     assert np.array_equal(_digest(multi), base)
     assert all(lo_ % S == 0 for lo_, _ in hip.shard_bounds(batch.rec_offset, 3, S))
-    # without the svt_unit.libs hints the same batch takes the general mode (tables through L2) and agrees on everything
+    # without the svt_unit.libs hints svt_batch_create reads the windows off the uploaded records (svt_window_scan_kernel);
+    # the pipelined one-shot and SVT_FLAG_GENERAL_TABLES take the general mode (tables through L2): the same bytes each way
     units = batch.units.copy()
     units["libs"] = 0
     plain = ev.EvidenceBatch(batch.rec_offset, units, batch.records, batch.libs, batch.split_weight, batch.disc_weight)
+    with hip.DeviceBatch(plain, device=hip_device) as d:
+        assert d.table_mode() == 1
+        d.genotype(sync=True)
+        assert np.array_equal(d.results().rec, first.rec)
     assert np.array_equal(hip.genotype_batch(plain, device=hip_device).rec, first.rec)
+    with hip.DeviceBatch(batch, device=hip_device, flags=ev.FLAG_GENERAL_TABLES) as d:
+        assert d.table_mode() == 2
+        d.genotype(sync=True)
+        assert np.array_equal(d.results().rec, first.rec)
     # the oracle on a bounded random sample of whole sites
     rng = np.random.default_rng(7)
     sites = np.sort(rng.choice(65_536, 700, replace=False))
@@ -646,7 +655,9 @@ def test_full_size_multisample_properties(hip_device, full_c5):
 # ------------------------------------------------------------------------------------------
 def test_library_windows_in_the_streaming_kernel(hip_device, fixture_library):
     """Units that say which libraries their sample owns are grouped by that window and a workgroup stages only the
-    window's histograms (table mode 1); without the hint the same batch runs in the general mode (2) -- same bits."""
+    window's histograms (table mode 1); without the hint svt_batch_create derives the windows from the records on the
+    device (mode 1 again, windows as narrow as the records allow); SVT_FLAG_GENERAL_TABLES keeps every table in L2 (the
+    general mode, 2) -- the same bits each way."""
     from svtyper_amd import hip
     batch = synth.make_multisample(150, 32, seed=5, mean_frags=40, sd_frags=15, min_frags=5, max_frags=90)
     assert (batch.units["libs"] != 0).all() and len(np.unique(batch.units["libs"])) == 32
@@ -658,10 +669,16 @@ def test_library_windows_in_the_streaming_kernel(hip_device, fixture_library):
         plain = synth.permute_units(batch, np.arange(batch.n_units))
         plain.units["libs"] = 0
         with hip.DeviceBatch(plain, hip_device, flags) as d:
-            assert d.table_mode() == 2
+            assert d.table_mode() == 1
             d.genotype(sync=True)
-            gen = d.results()
-        assert win.rec.tobytes() == gen.rec.tobytes()
+            derived = d.results()
+        assert win.rec.tobytes() == derived.rec.tobytes()
+        for b_ in (batch, plain):
+            with hip.DeviceBatch(b_, hip_device, flags | ev.FLAG_GENERAL_TABLES) as d:
+                assert d.table_mode() == 2
+                d.genotype(sync=True)
+                gen = d.results()
+            assert win.rec.tobytes() == gen.rec.tobytes()
         from oracle import c_oracle
         assert_parity(win, c_oracle.genotype_batch(batch, flags=flags))
     # groups that do not fill a workgroup, one unit per window, units in any order
@@ -735,7 +752,7 @@ def test_pipelined_one_shot_equals_the_resident_batch(hip_device, fixture_librar
 def test_sample_major_units_come_back_site_major(hip_device, fixture_library):
     """svt_batch_result_order: the same (site, sample) units handed over sample-major (what a producer that reads BAM by
     BAM emits; a sample's units are then contiguous in HBM) with the results scattered back site-major must give the
-    bytes of the site-major batch -- in the library-window mode, without hints (general mode), with one library,
+    bytes of the site-major batch -- in the library-window mode, without hints (derived windows; general mode), with one library,
     for both associations, for launches of one and of two tiles per wave -- and QUAL over a site's samples
     (svt_batch_site_qual reads the site-major result array) must not change either."""
     from svtyper_amd import hip
@@ -773,11 +790,12 @@ def test_sample_major_units_come_back_site_major(hip_device, fixture_library):
         nh_site.units["libs"] = 0
         nh_samp = synth.permute_units(samp, np.arange(samp.n_units))
         nh_samp.units["libs"] = 0
-        with hip.DeviceBatch(nh_samp, hip_device, 0) as d:
-            assert d.table_mode() == 2
-            d.result_order(n_samples)
-            d.genotype(sync=True)
-            assert d.results().rec.tobytes() == want0(nh_site, hip_device).rec.tobytes()
+        for fl, mode in ((0, 1), (ev.FLAG_GENERAL_TABLES, 2)):    # windows derived from the records / the general mode
+            with hip.DeviceBatch(nh_samp, hip_device, fl) as d:
+                assert d.table_mode() == mode
+                d.result_order(n_samples)
+                d.genotype(sync=True)
+                assert d.results().rec.tobytes() == want0(nh_site, hip_device).rec.tobytes()
     one = synth.make_units(640, 3, [fixture_library])
     o_samp, o_order = synth.to_sample_major(one, 4)
     with hip.DeviceBatch(o_samp, hip_device, 0) as d:

@@ -6,7 +6,7 @@ import numpy as np, bench
 from svtyper_amd import hip, evidence as ev
 b = bench.generate("c5_multisample", 500_000, 0, bench.usable_cpus())
 b.units["libs"] = 0
-with hip.DeviceBatch(b, 0, 0) as d:
+with hip.DeviceBatch(b, 0, ev.FLAG_GENERAL_TABLES if os.environ.get("GENERAL", "1") == "1" else 0) as d:   # GENERAL=0: windows derived from the records
     d.genotype(sync=True)
     ms = min(d.genotype_timed(5) / 5 for _ in range(3))
     alg, _ = d.bytes()
