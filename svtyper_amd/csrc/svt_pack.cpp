@@ -20,6 +20,7 @@
 #include <cstring>
 #include <memory>
 #include <mutex>
+#include <thread>
 
 #include <pthread.h>
 #include <sched.h>
@@ -492,6 +493,78 @@ std::string record_error_text(uint32_t err_bits)
     return m;
 }
 
+namespace {
+// first(t) on `nt` threads (t = 0: the caller), then between() on the caller once every first() has returned, then -- if
+// that said SVT_OK -- second(t) on the same threads: one round of thread creation for both phases (sixty-four threads cost
+// ~1.5 ms to start).  A thread that cannot be started is simply missing: both phases hand out their work through atomic
+// counters.  Waiting threads back off to short sleeps (between() may take a page-locked allocation's tens of ms the first
+// time).  An exception in any thread is rethrown on the caller after the join, like run_threads does.
+template <typename First, typename Between, typename Second>
+int run_two_phases(unsigned nt, First&& first, Between&& between, Second&& second)
+{
+    std::atomic<unsigned> arrived{0}, expected{~0u};
+    std::atomic<int> go{0};                  // 1: second phase, -1: stop
+    std::exception_ptr thrown;
+    std::mutex lock;
+    int rc = SVT_OK;
+    auto guarded_call = [&](auto&& f) {
+        try {
+            f();
+        } catch (...) {
+            std::lock_guard<std::mutex> g(lock);
+            if (!thrown) thrown = std::current_exception();
+        }
+    };
+    auto wait_until = [](auto&& done) {
+        for (unsigned spins = 0; !done(); ++spins) {
+            if (spins < 4096) {
+#if defined(__x86_64__)
+                __builtin_ia32_pause();
+#endif
+            } else {
+                std::this_thread::sleep_for(std::chrono::microseconds(30));
+            }
+        }
+    };
+    auto body = [&](unsigned t) {
+        guarded_call([&] { first(t); });
+        arrived.fetch_add(1, std::memory_order_acq_rel);
+        if (t == 0) {
+            wait_until([&] { return arrived.load(std::memory_order_acquire) == expected.load(std::memory_order_acquire); });
+            bool failed;
+            {
+                std::lock_guard<std::mutex> g(lock);
+                failed = (bool)thrown;
+            }
+            if (!failed) guarded_call([&] { rc = between(); });
+            {
+                std::lock_guard<std::mutex> g(lock);
+                failed = (bool)thrown;
+            }
+            go.store(!failed && rc == SVT_OK ? 1 : -1, std::memory_order_release);
+        } else {
+            wait_until([&] { return go.load(std::memory_order_acquire) != 0; });
+        }
+        if (go.load(std::memory_order_acquire) == 1) guarded_call([&] { second(t); });
+    };
+    std::vector<std::thread> pool;
+    pool.reserve(nt ? nt - 1 : 0);
+    unsigned started = 1;
+    for (; started < nt; ++started) {
+        try {
+            pool.emplace_back(body, started);
+        } catch (const std::system_error&) {
+            break;
+        }
+    }
+    expected.store(started, std::memory_order_release);
+    body(0);
+    for (auto& th : pool) th.join();
+    if (thrown) std::rethrow_exception(thrown);
+    return rc;
+}
+}  // namespace
+
 int encode_packed(const svt_evidence_batch* in, const PackAlloc& A, PackedArrays* out)
 {
     if (!in || !out) return fail(SVT_ERR_INVALID, "null argument");
@@ -589,7 +662,7 @@ int encode_packed(const svt_evidence_batch* in, const PackAlloc& A, PackedArrays
     // ---- the one pass over the records: contract check + the three streams of every unit (record order).  Chunks are
     // claimed, not dealt: a worker that shares its core or loses its CPU for a while just takes fewer.
     std::atomic<uint64_t> next_chunk{0};
-    run_threads(nt, [&](unsigned t) {
+    auto encode_phase = [&](unsigned t) {
         const auto w_t0 = std::chrono::steady_clock::now();
         // (worker 0 is the calling thread: its placement is the caller's business)
         if (spread && t > 0 && home.size() > 1) {
@@ -677,43 +750,50 @@ int encode_packed(const svt_evidence_batch* in, const PackAlloc& A, PackedArrays
             C.n_slots = W.arena.size - C.arena_at;
         }
         W.ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w_t0).count();
-    });
-    if (trace) {
-        std::fprintf(stderr, "[svt] pack: worker ms:");
-        for (const Worker& W : workers) std::fprintf(stderr, " %.1f", W.ms);
-        std::fprintf(stderr, "\n");
-    }
-    mark("encode (one pass)");
-    uint32_t bad = 0;
-    int unit_error = kUnitOk;
-    for (const Worker& W : workers) {
-        bad |= W.bad;
-        if (W.unit_error && !unit_error) unit_error = W.unit_error;
-    }
-    switch (unit_error) {
-    case kUnitOffsets: return fail(SVT_ERR_INVALID, "rec_offset not monotone");
-    case kUnitTooLong: return fail(SVT_ERR_INVALID, "unit with too many records");
-    case kUnitSvtype: return fail(SVT_ERR_INVALID, "bad svtype");
-    case kUnitReserved: return fail(SVT_ERR_INVALID, "unit reserved/flags bits must be 0");
-    case kUnitVarLength: return fail(SVT_ERR_UNSUPPORTED, "var_length outside the packed format's range");
-    case kUnitNegativeDel: return fail(SVT_ERR_UNSUPPORTED, "negative DEL length");
-    default: break;
-    }
-    if (bad) return fail(SVT_ERR_INVALID, record_error_text(bad));
-
-    // ---- slot counts -> slot offsets: chunk bases serially, inside a chunk in parallel
+    };
+    // ---- between the phases, on the calling thread (svt_last_error is thread-local): verdict on the batch, slot counts
+    // -> chunk bases, the output array
     uint64_t total = 0;
-    for (ChunkOut& C : chunks) {
-        C.base = total;
-        total += C.n_slots;
-        if (total >= 0xFFFFFFF0ull) return fail(SVT_ERR_UNSUPPORTED, "too many slots for 32-bit slot offsets");
-    }
-    out->slots = A.get(std::max<uint64_t>(total, 1) * 16);
-    if (!out->slots) return fail(SVT_ERR_NOMEM, "out of host memory");
-    Slot* slots = static_cast<Slot*>(out->slots);
-    mark("allocate slots");
-    run_threads(nt, [&](unsigned t) {
-        for (uint64_t ch = t; ch < n_chunks; ch += nt) {
+    Slot* slots = nullptr;
+    auto between_phases = [&]() -> int {
+        if (trace) {
+            std::fprintf(stderr, "[svt] pack: worker ms:");
+            for (const Worker& W : workers) std::fprintf(stderr, " %.1f", W.ms);
+            std::fprintf(stderr, "\n");
+        }
+        mark("encode (one pass)");
+        uint32_t bad = 0;
+        int unit_error = kUnitOk;
+        for (const Worker& W : workers) {
+            bad |= W.bad;
+            if (W.unit_error && !unit_error) unit_error = W.unit_error;
+        }
+        switch (unit_error) {
+        case kUnitOffsets: return fail(SVT_ERR_INVALID, "rec_offset not monotone");
+        case kUnitTooLong: return fail(SVT_ERR_INVALID, "unit with too many records");
+        case kUnitSvtype: return fail(SVT_ERR_INVALID, "bad svtype");
+        case kUnitReserved: return fail(SVT_ERR_INVALID, "unit reserved/flags bits must be 0");
+        case kUnitVarLength: return fail(SVT_ERR_UNSUPPORTED, "var_length outside the packed format's range");
+        case kUnitNegativeDel: return fail(SVT_ERR_UNSUPPORTED, "negative DEL length");
+        default: break;
+        }
+        if (bad) return fail(SVT_ERR_INVALID, record_error_text(bad));
+
+        // slot counts -> slot offsets: chunk bases serially, inside a chunk in parallel (second phase)
+        for (ChunkOut& C : chunks) {
+            C.base = total;
+            total += C.n_slots;
+            if (total >= 0xFFFFFFF0ull) return fail(SVT_ERR_UNSUPPORTED, "too many slots for 32-bit slot offsets");
+        }
+        out->slots = A.get(std::max<uint64_t>(total, 1) * 16);
+        if (!out->slots) return fail(SVT_ERR_NOMEM, "out of host memory");
+        slots = static_cast<Slot*>(out->slots);
+        mark("allocate slots");
+        return SVT_OK;
+    };
+    std::atomic<uint64_t> next_copy{0};
+    auto copy_phase = [&](unsigned) {
+        for (uint64_t ch; (ch = next_copy.fetch_add(1, std::memory_order_relaxed)) < n_chunks;) {
             const ChunkOut& C = chunks[ch];
             const uint64_t u0 = ch * kChunkUnits, u1 = std::min(n, u0 + kChunkUnits);
             uint64_t run = C.base;
@@ -723,7 +803,8 @@ int encode_packed(const svt_evidence_batch* in, const PackAlloc& A, PackedArrays
             }
             if (C.n_slots) std::memcpy(slots + C.base, workers[C.worker].arena.p + C.arena_at, (size_t)C.n_slots * 16);
         }
-    });
+    };
+    SVT_TRY(run_two_phases(nt, encode_phase, between_phases, copy_phase));
     mark("offsets + final copy");
     out->n_slots = total;
     out->n_records = n_rec_claimed;

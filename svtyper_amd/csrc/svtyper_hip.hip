@@ -441,8 +441,10 @@ int create_stream(const svt_evidence_batch* in, svt_batch* b, void* d_records_re
         HIP_TRY(hipMemcpyAsync(seen.data(), b->d_perm, n * sizeof(uint32_t), hipMemcpyDeviceToHost, b->stream));
         HIP_TRY(hipStreamSynchronize(b->stream));
         tm.mark("library windows from the records (device scan)");
+        // (0: a unit whose libraries lie > 255 apart; a window beyond n_libs: some record names a library the batch does
+        // not have -- the general mode reports it as the contract violation it is)
         bool all_seen = true;
-        for (uint64_t u = 0; u < n && all_seen; ++u) all_seen = seen[u] != 0u;   // (0: a unit whose libraries lie > 255 apart)
+        for (uint64_t u = 0; u < n && all_seen; ++u) all_seen = seen[u] != 0u && (seen[u] & 0xffu) + ((seen[u] >> 8) & 0xffu) <= in->n_libs;
         if (all_seen) {
             group_units([&](uint64_t u) -> uint32_t { return seen[u] & 0xffffu; });
             windowed = true;

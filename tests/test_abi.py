@@ -96,7 +96,9 @@ def test_struct_layouts_match_the_header(tmp_path):
         lines.append('printf("%s %%zu\\n", sizeof(%s));' % (name, name))
         for f in fields:
             lines.append('printf("%s.%s %%zu\\n", offsetof(%s, %s));' % (name, f, name, f))
-    lines += ['printf("SVT_ABI_VERSION %d\\n", SVT_ABI_VERSION);', 'return 0; }']
+    for macro in ("SVT_ABI_VERSION", "SVT_FLAG_SSO_ASSOCIATION", "SVT_FLAG_GENERAL_TABLES", "SVT_REC_LIB_SHIFT", "SVT_REC_CONTINUATION", "SVT_REC_HAS_PAIR"):
+        lines.append('printf("%s %%d\\n", (int)%s);' % (macro, macro))
+    lines += ['return 0; }']
     src = tmp_path / "probe.c"
     src.write_text("\n".join(lines))
     exe = str(tmp_path / "probe")
@@ -106,6 +108,8 @@ def test_struct_layouts_match_the_header(tmp_path):
 
     from svtyper_amd import hip
     assert c["SVT_ABI_VERSION"] == hip.ABI_VERSION
+    assert (c["SVT_FLAG_SSO_ASSOCIATION"], c["SVT_FLAG_GENERAL_TABLES"]) == (ev.FLAG_SSO_ASSOCIATION, ev.FLAG_GENERAL_TABLES)
+    assert (c["SVT_REC_LIB_SHIFT"], c["SVT_REC_CONTINUATION"], c["SVT_REC_HAS_PAIR"]) == (ev.REC_LIB_SHIFT, ev.REC_CONTINUATION, ev.REC_HAS_PAIR)
     dtypes = {"svt_record": ev.RECORD_DTYPE, "svt_unit": ev.UNIT_DTYPE, "svt_result": ev.RESULT_DTYPE,
               "svt_read_summary": geo.READ_DTYPE, "svt_piece_summary": geo.PIECE_DTYPE, "svt_fragment": geo.FRAGMENT_DTYPE,
               "svt_breakpoint": geo.BREAKPOINT_DTYPE}

@@ -702,6 +702,28 @@ def test_library_windows_in_the_streaming_kernel(hip_device, fixture_library):
     beyond.units["libs"][3] = ev.unit_libs(len(batch.libs) - 1, 5)
     with pytest.raises(hip.SvtyperHipError):
         hip.genotype_batch(beyond)
+    # without hints: a record that names a library the batch does not have reaches the window scan first; it must still
+    # come out as the contract violation it is, and units without records must not disturb the scan
+    rogue = synth.permute_units(batch, np.arange(640))
+    rogue.units["libs"] = 0
+    rogue.records["flags"][int(rogue.rec_offset[7])] |= np.uint32(0xff << ev.REC_LIB_SHIFT)
+    with pytest.raises(hip.SvtyperHipError) as e:
+        with hip.DeviceBatch(rogue, hip_device) as d:
+            d.genotype(sync=True)
+    assert "lib index" in str(e.value)
+    keep = np.ones(batch.n_units, bool)
+    keep[::7] = False
+    sparse = synth.permute_units(batch, np.arange(batch.n_units))
+    sparse.units["libs"] = 0
+    counts = np.diff(sparse.rec_offset.astype(np.int64)) * keep               # every seventh unit loses its records
+    take = np.repeat(keep, np.diff(sparse.rec_offset.astype(np.int64)))
+    sparse = ev.EvidenceBatch(np.concatenate([[0], np.cumsum(counts)]).astype(np.uint64), sparse.units, sparse.records[take],
+                              sparse.libs, sparse.split_weight, sparse.disc_weight)
+    with hip.DeviceBatch(sparse, hip_device) as d:
+        assert d.table_mode() == 1
+        d.genotype(sync=True)
+        from oracle import c_oracle
+        assert_parity(d.results(), c_oracle.genotype_batch(sparse, flags=0))
 
 
 # ------------------------------------------------------------------------------------------

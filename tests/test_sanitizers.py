@@ -56,3 +56,24 @@ def test_corrupted_bams_under_asan_and_ubsan(asan_env):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_bam.py")], cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-2000:])
     assert "crash" not in r.stdout and ("ok" in r.stdout or "error" in r.stdout), r.stdout[-1000:]
+
+
+def test_packed_encoder_under_thread_sanitizer(tmp_path):
+    """svt_pack.cpp hands chunks out through atomic counters and runs both of its phases on one set of threads with a
+    hand-written barrier between them: a data race there would be silent.  tests/native/tsan_pack_main.cpp drives it
+    (success and error path) with eight workers under -fsanitize=thread."""
+    import shutil
+    if not shutil.which("g++"):
+        pytest.skip("no g++")
+    exe = str(tmp_path / "tsan_pack")
+    r = subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=thread", "-I", CSRC, "-I", os.path.join(ROOT, "include"),
+                        os.path.join(ROOT, "tests", "native", "tsan_pack_main.cpp"), os.path.join(CSRC, "svt_pack.cpp"), "-o", exe,
+                        "-lpthread"], capture_output=True, text=True, timeout=600)
+    if r.returncode != 0 and "tsan" in r.stderr.lower():
+        pytest.skip("this g++ has no ThreadSanitizer runtime")
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run([exe], env=dict(os.environ, SVT_PACK_THREADS="8", TSAN_OPTIONS="halt_on_error=1"), capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0 and "ThreadSanitizer" not in r.stderr, (r.stdout[-1000:], r.stderr[-3000:])
+    lines = r.stdout.strip().splitlines()
+    assert len(lines) == 5 and all(" rc 0 " in l for l in lines[:3]) and all("rec_offset not monotone" in l for l in lines[3:]), lines

@@ -1,3 +1,7 @@
+#!/usr/bin/env python
+"""svt_batch_create + pass of the configs[4] shape (1 M units, 66 libraries) three ways: with the svt_unit.libs hints,
+without them (windows read off the records by svt_window_scan_kernel at create), and with SVT_FLAG_GENERAL_TABLES; the
+last create runs with SVT_TRACE=1 (stage times).   python tools/scan_time.py"""
 import os, sys, time
 sys.path.insert(0, os.getcwd())
 import numpy as np, bench
