@@ -307,6 +307,21 @@ inline void encode_records_avx512(const Slot* recs, const uint64_t r0, const uin
     encode_records(recs, j, r1, c, st, S, R, X);
 }
 
+// memcpy whose stores bypass the caches: the destination is the page-locked output array, which the CPU never reads
+// again (the next reader is the DMA engine) -- ordinary stores would first fetch every destination line for ownership.
+__attribute__((target("avx512f")))
+inline void copy_streaming(void* dst, const void* src, size_t bytes)
+{
+    char* d = static_cast<char*>(dst);
+    const char* s = static_cast<const char*>(src);
+    const size_t head = std::min(bytes, (size_t)((64u - (reinterpret_cast<uintptr_t>(d) & 63u)) & 63u));
+    std::memcpy(d, s, head);
+    d += head; s += head; bytes -= head;
+    for (; bytes >= 64; d += 64, s += 64, bytes -= 64) _mm512_stream_si512(reinterpret_cast<__m512i*>(d), _mm512_loadu_si512(s));
+    std::memcpy(d, s, bytes);
+    _mm_sfence();
+}
+
 inline bool cpu_has_avx512()
 {
     static const bool yes = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512bw") && __builtin_cpu_supports("avx512vl");
@@ -801,7 +816,12 @@ int encode_packed(const svt_evidence_batch* in, const PackAlloc& A, PackedArrays
                 run += off[i];
                 off[i] = (uint32_t)run;
             }
-            if (C.n_slots) std::memcpy(slots + C.base, workers[C.worker].arena.p + C.arena_at, (size_t)C.n_slots * 16);
+            if (!C.n_slots) continue;
+#if SVT_PACK_AVX512
+            if (use_avx512) copy_streaming(slots + C.base, workers[C.worker].arena.p + C.arena_at, (size_t)C.n_slots * 16);
+            else
+#endif
+            std::memcpy(slots + C.base, workers[C.worker].arena.p + C.arena_at, (size_t)C.n_slots * 16);
         }
     };
     SVT_TRY(run_two_phases(nt, encode_phase, between_phases, copy_phase));
