@@ -23,7 +23,8 @@ After the timed region every rank's result records are gathered onto rank 0 with
 
 Extra keys on the N=1 line (clearly labelled, never part of `value`; --legs selects them): `sso` (the same launch with
 the singlesample association) and `c5_multisample` (the configs[4] shape: 32 samples, per-sample libraries; plus the
-same batch without library hints) each with their own roofline object, `shard_of_8` (shard 0 of the 8-GPU cut of
+same batch site-major, without library hints -- windows read off the records at create -- and with every table in L2)
+each with their own roofline object, `shard_of_8` (shard 0 of the 8-GPU cut of
 the headline workload, timed alone), `one_shot` (host buffers -> results on the host, PCIe included),
 `one_shot_packed` (the same from packed evidence, the host encoder's time included), `large_batch` (4 M units per
 GPU: working set far beyond the 256 MiB Infinity Cache), `cpu_baseline`, `parity`.  N > 1 adds `value_with_gather`.

@@ -61,8 +61,9 @@ extern "C" {
  *   1 (sso)    : contributions are first summed per fragment starting from 0,
  *                then added to the site total (singlesample.py:246-276,367-372) */
 #define SVT_FLAG_SSO_ASSOCIATION 0x1u
-/* keep every look-up table in L2 (the pass's general mode) even where a workgroup could stage its libraries'
- * histograms in LDS: for measurements and for tests that compare the two table paths.  Results are the same.  */
+/* keep every look-up table in L2 (the pass's general mode, which also evaluates the histogram keys in exact 64-bit
+ * arithmetic) even where a workgroup could stage its libraries' histograms in LDS -- one library or many: for
+ * measurements and for tests that compare the table paths.  Results are the same.                              */
 #define SVT_FLAG_GENERAL_TABLES 0x10u
 /* (bits 1..3 selected round 1's tiled device layouts, which are gone: they are rejected as unknown bits.)
  * Device layout of a resident batch: nothing is re-tiled or re-encoded -- the CSR arrays go to HBM as the

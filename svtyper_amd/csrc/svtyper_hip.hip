@@ -458,7 +458,8 @@ int create_stream(const svt_evidence_batch* in, svt_batch* b, void* d_records_re
     constexpr size_t kStreamLdsPerWg2 = (160 * 1024 / 2) & ~size_t(127);  // two
     constexpr size_t kLdsBin = 2 * sizeof(uint16_t);   // thr + hist of one bin in LDS: 16-bit ranks
     const size_t single_lds = kSBins + T.bins.size() * kLdsBin;
-    const bool single = in->n_libs == 1 && T.fast_geometry && T.narrow_bins && single_lds + kWavesPerBlock * kStreamRingBytes <= 96 * 1024;
+    const bool single = in->n_libs == 1 && T.fast_geometry && T.narrow_bins && single_lds + kWavesPerBlock * kStreamRingBytes <= 96 * 1024 &&
+                        !(b->flags & SVT_FLAG_GENERAL_TABLES);
     const size_t window_lds = kSBins + (((size_t)max_win_bins * kLdsBin + 15) & ~size_t(15)) + (size_t)max_win_libs * sizeof(WinLib);
     windowed = windowed && T.narrow_bins && window_lds + kWavesPerBlock * kStreamRingBytes <= kStreamLdsPerWg2;
     b->mode = single ? kSingleLds : windowed ? kMultiLds : kGeneral;

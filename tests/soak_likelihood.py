@@ -71,12 +71,12 @@ while time.time() - t0 < budget:
         except AssertionError as e:
             print("MISMATCH at iteration %d (kind %d, %d libs, flags %d): %s" % (it, kind, n_libs, flags, e))
             sys.exit(1)
-    if n_libs > 1:      # resident batches without hints (one window, or windows read off the records) and with every table in L2
+    if n_libs > 1 or it % 3 == 0:   # resident batches with every table in L2 and, for several libraries, without hints (one window, or windows read off the records)
         nh = synth.permute_units(b, np.arange(b.n_units))
         nh.units["libs"] = 0
         for flags in (0, ev.FLAG_SSO_ASSOCIATION):
             ref_bytes = hip.genotype_batch(b, 0, flags).rec.tobytes()
-            for x, fl in ((nh, flags), (nh, flags | ev.FLAG_GENERAL_TABLES), (b, flags | ev.FLAG_GENERAL_TABLES)):
+            for x, fl in ((nh, flags), (nh, flags | ev.FLAG_GENERAL_TABLES), (b, flags | ev.FLAG_GENERAL_TABLES))[0 if n_libs > 1 else 2:]:
                 with hip.DeviceBatch(x, 0, fl) as d:
                     d.genotype(sync=True)
                     modes[d.table_mode()] = modes.get(d.table_mode(), 0) + 1

@@ -474,6 +474,23 @@ def test_shapes_outside_the_fast_modes_stay_exact(hip_device, fixture_library):
             assert_parity(got, want)
 
 
+def test_general_tables_flag_gives_the_same_bytes(hip_device, fixture_library):
+    """SVT_FLAG_GENERAL_TABLES sends any batch through the general mode (tables through L2, exact 64-bit keys), which is
+    otherwise reserved for geometries the 32-bit keys cannot express: one library, both associations, edge cases."""
+    from svtyper_amd import hip
+    for batch in (synth.make_units(9000, 41, [fixture_library], svtype_mix=(0.5, 0.2, 0.2, 0.1), min_frags=0),
+                  synth.make_edge_cases([fixture_library], seed=9)):
+        for flags in ALL_FLAGS:
+            with hip.DeviceBatch(batch, hip_device, flags) as d:
+                assert d.table_mode() == 0
+                d.genotype(sync=True)
+                want = d.results().rec.tobytes()
+            with hip.DeviceBatch(batch, hip_device, flags | ev.FLAG_GENERAL_TABLES) as d:
+                assert d.table_mode() == 2
+                d.genotype(sync=True)
+                assert d.results().rec.tobytes() == want
+
+
 def test_pooled_buffers_do_not_leak_state(hip_device, fixture_library):
     """svt_batch_destroy hands the big device buffers to a pool and the next create reuses them
     (larger than needed, full of the previous batch's bytes): results must not depend on that."""
