@@ -195,3 +195,26 @@ def test_vector_and_scalar_encoders_write_the_same_slots(fixture_library):
             finally:
                 os.environ.pop("SVT_PACK_SCALAR", None)
         assert got["vector"] == got["scalar"], trial
+
+
+def test_worker_count_does_not_change_the_slots(fixture_library):
+    """The encoder's workers claim chunks of 256 units from a counter, so which worker encodes which chunk differs from
+    call to call; the output is placed by chunk, not by worker: one, three, eight and forty workers (SVT_PACK_THREADS)
+    must write the same slots and offsets -- also when there are fewer chunks than workers."""
+    import os
+    from svtyper_amd import hip
+    for n_units in (100, 5000):
+        batch = synth.make_units(n_units, 77, [fixture_library], svtype_mix=(0.6, 0.2, 0.1, 0.1), mean_frags=40, sd_frags=30, min_frags=0)
+        got = []
+        keep = os.environ.get("SVT_PACK_THREADS")
+        try:
+            for nt in (1, 3, 8, 40):
+                os.environ["SVT_PACK_THREADS"] = str(nt)
+                with hip.PackedEvidence(batch) as p:
+                    got.append((p.slots().tobytes(), p.slot_offset().tobytes(), int(p.c.common_mapq)))
+        finally:
+            if keep is None:
+                os.environ.pop("SVT_PACK_THREADS", None)
+            else:
+                os.environ["SVT_PACK_THREADS"] = keep
+        assert all(g == got[0] for g in got[1:])
