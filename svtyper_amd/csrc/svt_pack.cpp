@@ -188,13 +188,15 @@ inline void encode_records_avx512(const Slot* recs, const uint64_t r0, const uin
     const __m512i idx_lo = _mm512_setr_epi32(0, 4, 8, 12, 16, 20, 24, 28, 0, 0, 0, 0, 0, 0, 0, 0);      // dword 0 of records 0..7 of (A, B)
     const __m512i idx_hi = _mm512_setr_epi32(0, 0, 0, 0, 0, 0, 0, 0, 0, 4, 8, 12, 16, 20, 24, 28);      // ... into lanes 8..15
     const __m512i one = _mm512_set1_epi32(1);
+    const __m256i iota16 = _mm256_setr_epi16(0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
     __m512i acc_flags = _mm512_setzero_si512(), acc_span = _mm512_setzero_si512(), acc_lone = _mm512_setzero_si512();
     const __m512i v_kmin = _mm512_set1_epi32((int32_t)c.key_min), v_vl = _mm512_set1_epi32((int32_t)c.vl);
     const __m512i v_nb = _mm512_set1_epi32((int32_t)c.nb), v_out = _mm512_set1_epi32((int32_t)c.code_out);
     const __m512i v_lim1 = _mm512_set1_epi32((int32_t)(uint32_t)c.lim1), v_lim2 = _mm512_set1_epi32((int32_t)(uint32_t)c.lim2);
     const __m512i v_common = _mm512_set1_epi32((int32_t)c.common);
     uint64_t j = r0;
-    for (; j + 16 <= r1; j += 16) {
+    for (; j < r1; j += 16) {
+        const unsigned n_here = (unsigned)std::min<uint64_t>(16, r1 - j);   // < 16: the unit's last records, the lanes behind them read as all-zero records
 #if SVT_PACK_PREFETCH
         // the records are a pure stream: ask for the lines a few groups ahead (sixteen workers share the memory system, and
         // what the hardware prefetcher brings on its own arrives late under that load)
@@ -203,15 +205,28 @@ inline void encode_records_avx512(const Slot* recs, const uint64_t r0, const uin
         _mm_prefetch(reinterpret_cast<const char*>(recs + j + SVT_PACK_PREFETCH + 8), _MM_HINT_T0);
         _mm_prefetch(reinterpret_cast<const char*>(recs + j + SVT_PACK_PREFETCH + 12), _MM_HINT_T0);
 #endif
-        const __m512i a = _mm512_loadu_si512(recs + j), b = _mm512_loadu_si512(recs + j + 4);
-        const __m512i d = _mm512_loadu_si512(recs + j + 8), e = _mm512_loadu_si512(recs + j + 12);
+        __m512i a, b, d, e;
+        if (n_here == 16u) {
+            a = _mm512_loadu_si512(recs + j);
+            b = _mm512_loadu_si512(recs + j + 4);
+            d = _mm512_loadu_si512(recs + j + 8);
+            e = _mm512_loadu_si512(recs + j + 12);
+        } else {
+            // (a masked load does not touch what it masks out: nothing behind the unit's last record is read.)  An all-zero
+            // record keeps no entry of any kind and sets no contract bit, so the group's arithmetic below needs no mask
+            const uint64_t dwords = ((uint64_t)1 << (4u * n_here)) - 1u;      // four dwords per record
+            a = _mm512_maskz_loadu_epi32((__mmask16)(dwords & 0xffffu), recs + j);
+            b = _mm512_maskz_loadu_epi32((__mmask16)((dwords >> 16) & 0xffffu), recs + j + 4);
+            d = _mm512_maskz_loadu_epi32((__mmask16)((dwords >> 32) & 0xffffu), recs + j + 8);
+            e = _mm512_maskz_loadu_epi32((__mmask16)((dwords >> 48) & 0xffffu), recs + j + 12);
+        }
         // dword K of the sixteen records (a lambda would not inherit this function's target attribute)
 #define SVT_FIELD(K)                                                                                                            \
     _mm512_mask_blend_epi32(0xFF00, _mm512_permutex2var_epi32(a, _mm512_add_epi32(idx_lo, _mm512_set1_epi32(K)), b),             \
                             _mm512_permutex2var_epi32(d, _mm512_add_epi32(idx_hi, _mm512_set1_epi32(K)), e))
         const __m512i fw = SVT_FIELD(3);
         if (_mm512_test_epi32_mask(fw, _mm512_set1_epi32((int32_t)SVT_REC_CONTINUATION))) {   // (rare) a fragment goes on: record by record
-            encode_records(recs, j, j + 16, c, st, S, R, X);
+            encode_records(recs, j, j + n_here, c, st, S, R, X);
             continue;
         }
         const __m512i fx = SVT_FIELD(0), fy = SVT_FIELD(1), fz = SVT_FIELD(2);
@@ -267,21 +282,24 @@ inline void encode_records_avx512(const Slot* recs, const uint64_t r0, const uin
         const __m512i kref = _mm512_srli_epi32(fy, 16);
         __mmask16 nz = _mm512_test_epi32_mask(kref, kref);
         if (nz) {
-            alignas(32) uint16_t t[16];
-            _mm256_store_si256(reinterpret_cast<__m256i*>(t), _mm512_cvtepi32_epi16(_mm512_maskz_compress_epi32(nz, kref)));
-            uint32_t cnt = (uint32_t)__builtin_popcount(nz), at = 0;
-            while (cnt) {
+            // the kept entries, compressed to the front; a row takes what it has room for (seven entries + the bits half-word),
+            // the rest moves down by a half-word permutation.  Each store writes sixteen half-words: what lies behind the
+            // entries just placed is overwritten by the next store, the row's bits half-word or finish() (the scratch has the room)
+            __m256i v = _mm512_cvtepi32_epi16(_mm512_maskz_compress_epi32(nz, kref));
+            uint32_t cnt = (uint32_t)__builtin_popcount(nz);
+            for (;;) {
                 const uint32_t take = std::min(cnt, 7u - R.k);
-                for (uint32_t q = 0; q < take; ++q) R.row[R.k + q] = t[at + q];
+                _mm256_storeu_si256(reinterpret_cast<__m256i*>(R.row + R.k), v);
                 R.bits |= ((1u << take) - 1u) << R.k;
                 R.k += take;
-                at += take;
                 cnt -= take;
                 if (R.k == 7u) {
                     R.row[7] = (uint16_t)R.bits;
                     R.row += 8;
                     R.k = R.bits = 0u;
                 }
+                if (!cnt) break;
+                v = _mm256_permutexvar_epi16(_mm256_add_epi16(iota16, _mm256_set1_epi16((short)take)), v);
             }
         }
         // ---- split / clip candidates (few): in record order, the split candidate of a record before its clip candidate
@@ -296,7 +314,7 @@ inline void encode_records_avx512(const Slot* recs, const uint64_t r0, const uin
             }
         }
         // what a continuation record right behind this group would see of its fragment (the group's last record)
-        const uint32_t last_y = recs[j + 15].y, last_z = recs[j + 15].z;
+        const uint32_t last_y = recs[j + n_here - 1u].y, last_z = recs[j + n_here - 1u].z;
         st.has_r = (last_y >> 16) != 0u;
         st.has_s = (last_z & 0xffffu) != 0u;
         st.has_c = (last_z >> 16) != 0u;
@@ -304,7 +322,6 @@ inline void encode_records_avx512(const Slot* recs, const uint64_t r0, const uin
     st.or_flags |= (uint32_t)_mm512_reduce_or_epi32(acc_flags);
     st.or_span |= (uint32_t)_mm512_reduce_or_epi32(acc_span);
     st.lone |= (uint32_t)_mm512_reduce_or_epi32(acc_lone);
-    encode_records(recs, j, r1, c, st, S, R, X);
 }
 
 // memcpy whose stores bypass the caches: the destination is the page-locked output array, which the CPU never reads
@@ -731,8 +748,8 @@ int encode_packed(const svt_evidence_batch* in, const PackAlloc& A, PackedArrays
                 c.common = common;
                 const uint64_t f = r1 - r0;
                 // worst case per stream: every record a wide pair entry behind a pad half-word (3 half-words), one
-                // reference-read entry, two candidate entries; + two slots: the vector form stores sixteen half-words at once
-                const uint64_t cap_s = (3 * f + 8 + 7) / 8 + 3, cap_r = f / 7 + 2, cap_x = 2 * f / 7 + 2;
+                // reference-read entry, two candidate entries; + two or three slots: the vector form stores sixteen half-words at once
+                const uint64_t cap_s = (3 * f + 8 + 7) / 8 + 3, cap_r = f / 7 + 4, cap_x = 2 * f / 7 + 2;
                 if (W.scratch.size() < (cap_s + cap_r + cap_x) * 8) W.scratch.resize((cap_s + cap_r + cap_x) * 8);
                 PairStream S(W.scratch.data());
                 WeightStream R(W.scratch.data() + cap_s * 8), X(W.scratch.data() + (cap_s + cap_r) * 8);
