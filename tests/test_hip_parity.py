@@ -690,6 +690,8 @@ def test_library_windows_in_the_streaming_kernel(hip_device, fixture_library):
             d.genotype(sync=True)
             derived = d.results()
         assert win.rec.tobytes() == derived.rec.tobytes()
+        # (the multi-device entry creates one resident batch per shard on its own host thread: each derives its own windows)
+        assert hip.genotype_multi(plain, [hip_device, hip_device], group=32, flags=flags).rec.tobytes() == win.rec.tobytes()
         for b_ in (batch, plain):
             with hip.DeviceBatch(b_, hip_device, flags | ev.FLAG_GENERAL_TABLES) as d:
                 assert d.table_mode() == 2
