@@ -420,11 +420,12 @@ void pack_trim() { g_arenas.trim(); }
 
 namespace {
 // The CPUs this process may use, grouped by the L3 cache they share (one group per CCD on an EPYC), with the socket
-// each group sits on.  The encoder is a stream over 1.6 GB per million units: worker t is asked to run on one core of
-// group t mod n_groups, taking only groups on the CALLING thread's socket -- the records were most likely first touched
-// there, and workers on the other socket of a two-socket host read them over the inter-socket links (measured: the
-// remote half of sixteen workers took 42 ms where the local half took 32).  SVT_PACK_SPREAD=0 leaves placement to the
-// scheduler.
+// each group sits on and its number of physical cores.  The encoder counts the cores next to the records (their NUMA
+// node, else the calling thread's socket) to decide how many workers a short call starts.  Where the workers then run is
+// the scheduler's business by default: with sixteen workers pinning them to the records' socket was worth 25 % (the remote
+// half took 42 ms where the local half took 32), but with one worker per core every pinned form lost to the scheduler --
+// SVT_PACK_SPREAD=1 keeps a worker inside one L3 group (SMT siblings end up sharing cores: 20-27 ms instead of 13-18),
+// =2 on one CPU of it (same best time, 35-90 ms whenever another tenant's thread sits on that CPU).
 struct L3Group {
     cpu_set_t cpus;
     long package;   // socket

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """svt_pack_evidence (host encoder of packed evidence) on the configs[2] workload with 1 / 8 / 16 worker threads
 (SVT_PACK_THREADS), best of three with pauses (the box's cgroup schedules 16 CPUs per 100 ms: bursts right behind one
-another get throttled).  SVT_PACK_SCALAR=1: the record-by-record form; SVT_PACK_SPREAD=0: no worker placement;
+another get throttled).  SVT_PACK_SCALAR=1: the record-by-record form; SVT_PACK_SPREAD=1 / 2: workers pinned to an L3 group / to one CPU of it (default: the scheduler places them);
 SVT_PACK_PROBE=1: read the records only; SVT_TRACE=1: stage and per-worker times.   python tools/pack_scale.py"""
 import time, sys, os
 sys.path.insert(0, os.getcwd())
