@@ -34,11 +34,86 @@ inline void parallel_for(uint64_t n, Fn&& fn)
 // for the driver's asynchronous clear of it (measured: tools/first_pass_probe.py), so a pipeline that
 // creates one batch per chunk would pay that on every chunk.  svt_batch_destroy returns the buffers
 // here; svt_trim() releases them.
+//
+// Large buffers (a batch's records) are not one hipMalloc but one virtual range mapped onto physical chunks of 256 MB
+// (hipMemCreate / hipMemMap).  How fast the pass streams its records depends on where in HBM they lie relative to the
+// result records it writes: with the records in ONE physical allocation the same batch ran at either of two levels 6-8 %
+// apart, decided per pair of allocations and constant while they stay put; over records made of separately allocated
+// chunks every trial ran at the fast level (profiles/r03_placement_variance.txt, tools/placement_vmm.hip).
 struct DevicePool {
     struct Item { void* p; uint64_t cap; int device; };
     static constexpr size_t kMaxItems = 8;
+    static constexpr uint64_t kChunkedMin = 512ull << 20, kChunk = 256ull << 20;
     std::mutex lock;
     std::vector<Item> items;
+    std::vector<std::pair<void*, uint64_t>> mapped;   // chunked buffers: virtual base, mapped bytes (guarded by `lock`)
+    // `bytes` of device memory as one virtual range over 256 MB physical chunks; false: not available, nothing left behind
+    bool alloc_chunked(int device, uint64_t bytes, void** out, uint64_t* cap)
+    {
+        if (const char* e = std::getenv("SVT_CHUNKED_BUFFERS")) if (std::atoi(e) == 0) return false;   // (measurements)
+        hipMemAllocationProp prop = {};
+        prop.type = hipMemAllocationTypePinned;
+        prop.location.type = hipMemLocationTypeDevice;
+        prop.location.id = device;
+        size_t gran = 0;
+        if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) != hipSuccess || gran == 0 || kChunk % gran) {
+            (void)hipGetLastError();
+            return false;
+        }
+        const uint64_t total = (bytes + kChunk - 1) / kChunk * kChunk;
+        void* va = nullptr;
+        if (hipMemAddressReserve(&va, total, 0, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); return false; }
+        uint64_t done = 0;
+        bool ok = true;
+        for (; ok && done < total; done += kChunk) {
+            hipMemGenericAllocationHandle_t h;
+            ok = hipMemCreate(&h, kChunk, &prop, 0) == hipSuccess;
+            if (!ok) break;
+            ok = hipMemMap(static_cast<char*>(va) + done, kChunk, 0, h, 0) == hipSuccess;
+            (void)hipMemRelease(h);        // (the mapping keeps the chunk alive)
+            if (!ok) break;
+        }
+        if (ok) {
+            hipMemAccessDesc acc = {};
+            acc.location = prop.location;
+            acc.flags = hipMemAccessFlagsProtReadWrite;
+            ok = hipMemSetAccess(va, total, &acc, 1) == hipSuccess;
+        }
+        if (!ok) {
+            (void)hipGetLastError();
+            if (done) (void)hipMemUnmap(va, done);
+            (void)hipMemAddressFree(va, total);
+            return false;
+        }
+        {
+            std::lock_guard<std::mutex> g(lock);
+            mapped.emplace_back(va, total);
+        }
+        *out = va;
+        *cap = total;
+        return true;
+    }
+    // hipFree, or unmap + release of a chunked buffer
+    void release(void* p)
+    {
+        uint64_t total = 0;
+        {
+            std::lock_guard<std::mutex> g(lock);
+            for (size_t i = 0; i < mapped.size(); ++i)
+                if (mapped[i].first == p) {
+                    total = mapped[i].second;
+                    mapped.erase(mapped.begin() + (long)i);
+                    break;
+                }
+        }
+        if (total) {
+            (void)hipDeviceSynchronize();          // (hipFree waits for the device too)
+            (void)hipMemUnmap(p, total);
+            (void)hipMemAddressFree(p, total);
+        } else {
+            (void)hipFree(p);
+        }
+    }
     // a buffer of at least `bytes` (best fit, at most 2x + 1 MiB oversized), else a new allocation
     int get(int device, uint64_t bytes, void** out, uint64_t* cap)
     {
@@ -58,6 +133,7 @@ struct DevicePool {
             }
         }
         const uint64_t want = bytes + bytes / 8;   // room for the next, slightly larger batch
+        if (want >= kChunkedMin && alloc_chunked(device, want, out, cap)) return SVT_OK;
         HIP_TRY(hipMalloc(out, want));
         *cap = want;
         return SVT_OK;
@@ -77,16 +153,19 @@ struct DevicePool {
                 items.erase(items.begin() + (long)smallest);
             }
         }
-        if (drop) (void)hipFree(drop);
+        if (drop) release(drop);
     }
     void trim()
     {
-        std::lock_guard<std::mutex> g(lock);
-        for (const Item& it : items) {
-            (void)hipSetDevice(it.device);
-            (void)hipFree(it.p);
+        std::vector<Item> all;
+        {
+            std::lock_guard<std::mutex> g(lock);
+            all.swap(items);
         }
-        items.clear();
+        for (const Item& it : all) {
+            (void)hipSetDevice(it.device);
+            release(it.p);
+        }
     }
 };
 inline DevicePool g_pool;
