@@ -308,10 +308,10 @@ def main():
     alg_bytes, resident_bytes = dbatch.bytes()
     layout_name = dbatch.layout_name()
 
-    # result records straight into a torch buffer (so the final RCCL gather needs no extra copy)
-    res_buf = torch.zeros(max(n, 1) * ev.RESULT_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
-    assert res_buf.data_ptr() % 128 == 0
-    dbatch.bind_device_results(res_buf.data_ptr())
+    # the batch's own result buffer as a torch tensor (zero-copy view): the final RCCL gather needs no extra copy, and the
+    # result records stay where svt_batch_create put them (binding a tensor torch allocated costs 3-6 % of the pass: DESIGN.md 3.1)
+    res_buf = dbatch.device_results_tensor()
+    assert res_buf.data_ptr() % 128 == 0 and res_buf.numel() >= n * ev.RESULT_DTYPE.itemsize
     cur = n * ev.RESULT_DTYPE.itemsize
 
     def barrier():

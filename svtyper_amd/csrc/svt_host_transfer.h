@@ -115,7 +115,9 @@ struct DevicePool {
         }
     }
     // a buffer of at least `bytes` (best fit, at most 2x + 1 MiB oversized), else a new allocation
-    int get(int device, uint64_t bytes, void** out, uint64_t* cap)
+    // `records`: the buffer will hold a batch's records (only those are built from chunks: a result buffer may be handed to
+    // RCCL or another process, which a plain allocation always allows)
+    int get(int device, uint64_t bytes, void** out, uint64_t* cap, bool records = false)
     {
         bytes = std::max<uint64_t>(bytes, 256);
         {
@@ -133,7 +135,7 @@ struct DevicePool {
             }
         }
         const uint64_t want = bytes + bytes / 8;   // room for the next, slightly larger batch
-        if (want >= kChunkedMin && alloc_chunked(device, want, out, cap)) return SVT_OK;
+        if (records && want >= kChunkedMin && alloc_chunked(device, want, out, cap)) return SVT_OK;
         HIP_TRY(hipMalloc(out, want));
         *cap = want;
         return SVT_OK;

@@ -400,7 +400,7 @@ int create_stream(const svt_evidence_batch* in, svt_batch* b, void* d_records_re
             b->d_records = d_records_resident;
             b->cap_records = resident_cap;
         } else {
-            SVT_TRY(g_pool.get(b->device, n_blk * 128, &p, &b->cap_records));
+            SVT_TRY(g_pool.get(b->device, n_blk * 128, &p, &b->cap_records, /*records=*/true));
             b->d_records = p;
         }
         // the tail of the last 128-byte block is read (and contract-checked) like any record: zero it
@@ -986,7 +986,7 @@ static int svt_batch_create_from_fragments_impl(const svt_fragment_batch* in, in
         void* p = nullptr;
         uint64_t cap = 0;
         ~Pooled() { g_pool.put(device, p, cap); }
-        int get(uint64_t bytes) { return g_pool.get(device, bytes, &p, &cap); }
+        int get(uint64_t bytes, bool records = false) { return g_pool.get(device, bytes, &p, &cap, records); }
         void* release() { void* q = p; p = nullptr; return q; }
     } d_frags{device}, d_records{device};
     DevScratch d_frag_off, d_bps, d_libs, d_err;
@@ -1002,7 +1002,7 @@ static int svt_batch_create_from_fragments_impl(const svt_fragment_batch* in, in
         SVT_TRY(st.finish());
         tm.mark("H2D fragment summaries + unit arrays (staged)");
     }
-    SVT_TRY(d_records.get((n_frag + kBlockRecords) * sizeof(uint4)));   // whole 128-byte blocks (kLayoutStream)
+    SVT_TRY(d_records.get((n_frag + kBlockRecords) * sizeof(uint4), /*records=*/true));   // whole 128-byte blocks (kLayoutStream)
     SVT_TRY(d_err.alloc(sizeof(uint32_t)));
     HIP_TRY(hipMemsetAsync(d_err.p, 0, sizeof(uint32_t), s));
     if (n_frag) {

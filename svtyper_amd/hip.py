@@ -266,6 +266,7 @@ class DeviceBatch:
         self._h = C.c_void_p()
         self.n_units = batch.n_units
         self.n_records = batch.n_records
+        self.device = int(device)
         cb = batch.as_c()
         _check(L.svt_batch_create(C.byref(cb), int(device), int(flags), C.byref(self._h)))
 
@@ -280,6 +281,7 @@ class DeviceBatch:
         self._lib = L
         self._h = C.c_void_p()
         self.n_units = fbatch.n_units
+        self.device = int(device)
         self.n_records = fbatch.n_fragments
         recs = np.zeros(fbatch.n_fragments, RECORD_DTYPE) if return_records else None
         cb = fbatch.as_c()
@@ -297,6 +299,7 @@ class DeviceBatch:
         self._lib = L
         self._h = C.c_void_p()
         self.n_units = packed.n_units
+        self.device = int(device)
         self.n_records = packed.n_records
         _check(L.svt_batch_create_packed(packed._p, int(device), int(flags), C.byref(self._h)))
         return self
@@ -331,6 +334,23 @@ class DeviceBatch:
         p = C.c_void_p()
         _check(self._lib.svt_batch_device_results(self._h, C.byref(p)))
         return int(p.value or 0)
+
+    def device_results_tensor(self):
+        """The batch's result records in HBM as a torch uint8 tensor: a zero-copy view of the buffer the pass writes (valid while
+        the batch is), e.g. to hand to torch.distributed for the gather.  (The other way round -- binding a tensor torch
+        allocated -- works too, but where the result records lie in HBM relative to the records decides 3-6 % of the pass
+        time, and the batch's own buffer is the placement that measured fast: DESIGN.md 3.1.)"""
+        import torch
+        from .evidence import RESULT_DTYPE
+
+        class _View:
+            pass
+        v = _View()
+        v.__cuda_array_interface__ = {"shape": (max(self.n_units, 1) * RESULT_DTYPE.itemsize,), "typestr": "|u1",
+                                      "data": (self.device_results_ptr(), False), "version": 2}
+        t = torch.as_tensor(v, device=torch.device("cuda", getattr(self, "device", 0)))
+        t._svt_batch = self          # the view must not outlive the batch
+        return t
 
     def bind_device_results(self, dev_ptr: int):
         """Caller-owned device buffer (n_units * 128 bytes, 128-byte aligned), e.g. a torch
