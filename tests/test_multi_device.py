@@ -48,6 +48,25 @@ def test_genotype_multi_equals_one_device_and_the_oracle(hip_device, fixture_lib
 
 
 @pytest.mark.gpu
+def test_result_records_as_a_torch_view(hip_device, fixture_library):
+    """DeviceBatch.device_results_tensor: the buffer the pass writes, handed to torch without a copy (what bench.py gathers over
+    RCCL): same address, same bytes as svt_batch_results, and the next pass writes through it."""
+    torch = pytest.importorskip("torch")
+    from svtyper_amd import hip, synth
+    batch = synth.make_units(5000, 3, [fixture_library], svtype_mix=(0.6, 0.2, 0.1, 0.1))
+    with hip.DeviceBatch(batch, hip_device) as d:
+        d.genotype(sync=True)
+        t = d.device_results_tensor()
+        assert t.is_cuda and t.dtype == torch.uint8 and t.numel() == batch.n_units * 128 and t.data_ptr() == d.device_results_ptr()
+        want = d.results().rec.tobytes()
+        assert t.cpu().numpy().tobytes() == want
+        t.zero_()
+        torch.cuda.synchronize()
+        d.genotype(sync=True)
+        assert t.cpu().numpy().tobytes() == want
+
+
+@pytest.mark.gpu
 def test_genotype_multi_reports_the_failing_device(hip_device, fixture_library):
     from svtyper_amd import evidence as ev, hip, synth
     b = synth.make_units(3000, 3, [fixture_library])
