@@ -47,23 +47,35 @@ def test_genotype_multi_equals_one_device_and_the_oracle(hip_device, fixture_lib
     assert hip.genotype_multi(synth.make_units(0, 3, [fixture_library]), [0, 0]).n_units == 0
 
 
+_TORCH_VIEW = """
+import sys, numpy as np, torch          # (torch first: its HIP runtime must be the one the process initialises)
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import bench
+from svtyper_amd import hip, synth
+batch = synth.make_units(5000, 3, [bench.fixture_library()], svtype_mix=(0.6, 0.2, 0.1, 0.1))
+with hip.DeviceBatch(batch, %d) as d:
+    d.genotype(sync=True)
+    t = d.device_results_tensor()
+    assert t.is_cuda and t.dtype == torch.uint8 and t.numel() == batch.n_units * 128 and t.data_ptr() == d.device_results_ptr()
+    want = d.results().rec.tobytes()
+    assert t.cpu().numpy().tobytes() == want
+    t.zero_()
+    torch.cuda.synchronize()
+    d.genotype(sync=True)
+    assert t.cpu().numpy().tobytes() == want
+print("view ok")
+"""
+
+
 @pytest.mark.gpu
-def test_result_records_as_a_torch_view(hip_device, fixture_library):
+def test_result_records_as_a_torch_view(hip_device):
     """DeviceBatch.device_results_tensor: the buffer the pass writes, handed to torch without a copy (what bench.py gathers over
-    RCCL): same address, same bytes as svt_batch_results, and the next pass writes through it."""
-    torch = pytest.importorskip("torch")
-    from svtyper_amd import hip, synth
-    batch = synth.make_units(5000, 3, [fixture_library], svtype_mix=(0.6, 0.2, 0.1, 0.1))
-    with hip.DeviceBatch(batch, hip_device) as d:
-        d.genotype(sync=True)
-        t = d.device_results_tensor()
-        assert t.is_cuda and t.dtype == torch.uint8 and t.numel() == batch.n_units * 128 and t.data_ptr() == d.device_results_ptr()
-        want = d.results().rec.tobytes()
-        assert t.cpu().numpy().tobytes() == want
-        t.zero_()
-        torch.cuda.synchronize()
-        d.genotype(sync=True)
-        assert t.cpu().numpy().tobytes() == want
+    RCCL): same address, same bytes as svt_batch_results, and the next pass writes through it.  (Own process: torch has to
+    be imported before the library initialises HIP.)"""
+    import subprocess
+    r = subprocess.run([sys.executable, "-c", _TORCH_VIEW % (ROOT, os.path.join(ROOT, "tests"), hip_device)], capture_output=True,
+                       text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0 and "view ok" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
 
 
 @pytest.mark.gpu
