@@ -4,6 +4,7 @@
 #define SVT_HOST_TRANSFER_H
 
 #include <algorithm>
+#include <atomic>
 #include <mutex>
 #include <vector>
 
@@ -41,16 +42,18 @@ inline void parallel_for(uint64_t n, Fn&& fn)
 // apart, decided per pair of allocations and constant while they stay put; over records made of separately allocated
 // chunks every trial ran at the fast level (profiles/r03_placement_variance.txt, tools/placement_vmm.hip).
 struct DevicePool {
-    struct Item { void* p; uint64_t cap; int device; };
+    struct Item { void* p; uint64_t cap; int device; bool chunked; };
     static constexpr size_t kMaxItems = 8;
     static constexpr uint64_t kChunkedMin = 512ull << 20, kChunk = 256ull << 20;
     std::mutex lock;
     std::vector<Item> items;
     std::vector<std::pair<void*, uint64_t>> mapped;   // chunked buffers: virtual base, mapped bytes (guarded by `lock`)
+    std::atomic<bool> chunked_available{true};                    // false once alloc_chunked has failed (guarded by `lock` where it matters)
     // `bytes` of device memory as one virtual range over 256 MB physical chunks; false: not available, nothing left behind
     bool alloc_chunked(int device, uint64_t bytes, void** out, uint64_t* cap)
     {
-        if (const char* e = std::getenv("SVT_CHUNKED_BUFFERS")) if (std::atoi(e) == 0) return false;   // (measurements)
+        static const bool enabled = [] { const char* e = std::getenv("SVT_CHUNKED_BUFFERS"); return !(e && std::atoi(e) == 0); }();
+        if (!enabled) return false;   // (measurements)
         hipMemAllocationProp prop = {};
         prop.type = hipMemAllocationTypePinned;
         prop.location.type = hipMemLocationTypeDevice;
@@ -93,8 +96,21 @@ struct DevicePool {
         *cap = total;
         return true;
     }
-    // hipFree, or unmap + release of a chunked buffer
-    void release(void* p)
+    // hipFree, or unmap + release of a chunked buffer, on the device the buffer lives on (the caller's current device is restored)
+    void release(void* p, int device)
+    {
+        int before = -1;
+        if (hipGetDevice(&before) != hipSuccess) before = -1;
+        if (before != device) (void)hipSetDevice(device);
+        release_here(p);
+        if (before >= 0 && before != device) (void)hipSetDevice(before);
+    }
+    bool is_chunked_locked(const void* p) const
+    {
+        for (const auto& m : mapped) if (m.first == p) return true;
+        return false;
+    }
+    void release_here(void* p)
     {
         uint64_t total = 0;
         {
@@ -123,8 +139,13 @@ struct DevicePool {
         {
             std::lock_guard<std::mutex> g(lock);
             size_t best = items.size();
+            // a chunked (virtual-memory) buffer only ever serves a record request of chunked size, a plain allocation
+            // everything else: result records may be handed to RCCL or to another process, and a record buffer must keep
+            // the placement it was built for
+            const bool want_chunked = records && bytes + bytes / 8 >= kChunkedMin;
             for (size_t i = 0; i < items.size(); ++i)
                 if (items[i].device == device && items[i].cap >= bytes && items[i].cap <= 2 * bytes + (1u << 20) &&
+                    (items[i].chunked == want_chunked || (want_chunked && !chunked_available)) &&
                     (best == items.size() || items[i].cap < items[best].cap))
                     best = i;
             if (best != items.size()) {
@@ -135,7 +156,10 @@ struct DevicePool {
             }
         }
         const uint64_t want = bytes + bytes / 8;   // room for the next, slightly larger batch
-        if (records && want >= kChunkedMin && alloc_chunked(device, want, out, cap)) return SVT_OK;
+        if (records && want >= kChunkedMin) {
+            if (alloc_chunked(device, want, out, cap)) return SVT_OK;
+            chunked_available = false;   // (no virtual-memory API, or switched off: plain buffers serve record requests too)
+        }
         HIP_TRY(hipMalloc(out, want));
         *cap = want;
         return SVT_OK;
@@ -143,19 +167,19 @@ struct DevicePool {
     void put(int device, void* p, uint64_t cap)
     {
         if (!p) return;
-        void* drop = nullptr;
+        Item drop{nullptr, 0, 0, false};
         {
             std::lock_guard<std::mutex> g(lock);
-            items.push_back(Item{p, cap, device});
+            items.push_back(Item{p, cap, device, is_chunked_locked(p)});
             if (items.size() > kMaxItems) {   // keep the largest ones
                 size_t smallest = 0;
                 for (size_t i = 1; i < items.size(); ++i)
                     if (items[i].cap < items[smallest].cap) smallest = i;
-                drop = items[smallest].p;
+                drop = items[smallest];
                 items.erase(items.begin() + (long)smallest);
             }
         }
-        if (drop) release(drop);
+        if (drop.p) release(drop.p, drop.device);
     }
     void trim()
     {
@@ -164,10 +188,7 @@ struct DevicePool {
             std::lock_guard<std::mutex> g(lock);
             all.swap(items);
         }
-        for (const Item& it : all) {
-            (void)hipSetDevice(it.device);
-            release(it.p);
-        }
+        for (const Item& it : all) release(it.p, it.device);
     }
 };
 inline DevicePool g_pool;

@@ -1142,14 +1142,15 @@ int svt_batch_result_order(svt_batch* b, uint32_t n_samples)
     if (!b) return fail(SVT_ERR_INVALID, "null batch");
     if (b->layout != kLayoutStream) return fail(SVT_ERR_INVALID, "svt_batch_result_order: canonical records only (not packed evidence)");
     if (n_samples <= 1) {
+        if (b->sargs.out_samples > 1) b->have_results = false;   // (site-major records are not results in unit order)
         b->sargs.out_samples = 0;
         b->sargs.out_sites = 0;
         return SVT_OK;
     }
     if (b->n_units % n_samples) return fail(SVT_ERR_INVALID, "svt_batch_result_order: n_units is not a multiple of n_samples");
+    if (b->sargs.out_samples != n_samples) b->have_results = false;   // (records written in another order are not results of this one)
     b->sargs.out_samples = n_samples;
     b->sargs.out_sites = (uint32_t)(b->n_units / n_samples);
-    b->have_results = false;   // (records written in the other order are not results of this order)
     return SVT_OK;
 }
 
@@ -1199,6 +1200,10 @@ static int svt_batch_site_qual_impl(svt_batch* b, uint32_t n_samples, const doub
     if (!b || (!qual_out && n_sites)) return fail(SVT_ERR_INVALID, "null argument");
     if (!b->have_results) return fail(SVT_ERR_STATE, "svt_batch_genotype has not run");
     if (n_samples == 0 || n_sites * n_samples != b->n_units) return fail(SVT_ERR_INVALID, "n_sites * n_samples != n_units");
+    // the records of a sample-major batch were written site-major for out_samples samples per site: QUAL over groups of
+    // another size would silently sum the wrong records
+    if (b->layout == kLayoutStream && b->sargs.out_samples > 1 && n_samples != b->sargs.out_samples)
+        return fail(SVT_ERR_INVALID, "svt_batch_site_qual: n_samples differs from the batch's svt_batch_result_order");
     if (n_sites == 0) return SVT_OK;
     HIP_TRY(hipSetDevice(b->device));
     SVT_TRY(check_stream_errors(b));   // (after svt_batch_genotype(b, 0) / _n nobody has looked at the contract word yet)

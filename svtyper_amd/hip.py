@@ -336,10 +336,18 @@ class DeviceBatch:
         return int(p.value or 0)
 
     def device_results_tensor(self):
-        """The batch's result records in HBM as a torch uint8 tensor: a zero-copy view of the buffer the pass writes (valid while
-        the batch is), e.g. to hand to torch.distributed for the gather.  (The other way round -- binding a tensor torch
-        allocated -- works too, but where the result records lie in HBM relative to the records decides 3-6 % of the pass
-        time, and the batch's own buffer is the placement that measured fast: DESIGN.md 3.1.)"""
+        """The batch's result records in HBM as a torch uint8 tensor: a zero-copy view of the buffer the pass writes, e.g. to
+        hand to torch.distributed for the gather.  (The other way round -- binding a tensor torch allocated -- works too, but
+        where the result records lie in HBM relative to the records decides 3-6 % of the pass time, and the batch's own
+        buffer is the placement that measured fast: DESIGN.md 3.1.)
+
+        Lifetime: the tensor's STORAGE owns a reference to this batch (through the array-interface object torch keeps as the
+        storage's owner), so every derived view -- slices, .view(), what torch.distributed holds -- keeps the batch from
+        being garbage-collected.  An explicit close() (or leaving the `with` block) while such a storage is alive raises
+        instead of handing the buffer back to the pool under the view.  The device ordinal is the library's: torch and the
+        library share one HIP runtime in the process and therefore one enumeration."""
+        import weakref
+
         import torch
         from .evidence import RESULT_DTYPE
 
@@ -348,8 +356,12 @@ class DeviceBatch:
         v = _View()
         v.__cuda_array_interface__ = {"shape": (max(self.n_units, 1) * RESULT_DTYPE.itemsize,), "typestr": "|u1",
                                       "data": (self.device_results_ptr(), False), "version": 2}
+        v._svt_batch = self          # storage -> v -> batch
         t = torch.as_tensor(v, device=torch.device("cuda", getattr(self, "device", 0)))
-        t._svt_batch = self          # the view must not outlive the batch
+        if not hasattr(self, "_views"):
+            self._views = []
+        self._views.append(weakref.ref(v))
+        del v
         return t
 
     def bind_device_results(self, dev_ptr: int):
@@ -389,8 +401,11 @@ class DeviceBatch:
     def stream(self) -> int:
         return int(self._lib.svt_batch_stream(self._h) or 0)
 
-    def close(self):
+    def close(self, force: bool = False):
         if self._h:
+            if not force and any(r() is not None for r in getattr(self, "_views", ())):
+                raise SvtyperHipError("DeviceBatch.close(): a tensor from device_results_tensor() (or a view of it) is still alive; "
+                                      "drop it first -- its memory goes back to the buffer pool here")
             self._lib.svt_batch_destroy(self._h)
             self._h = C.c_void_p()
 
@@ -404,7 +419,7 @@ class DeviceBatch:
         return self
 
     def __exit__(self, *exc):
-        self.close()
+        self.close(force=exc[0] is not None)   # (never mask the exception that is leaving the block)
 
 
 def host_sq(results: Results) -> Results:

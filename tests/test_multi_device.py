@@ -63,6 +63,16 @@ with hip.DeviceBatch(batch, %d) as d:
     torch.cuda.synchronize()
     d.genotype(sync=True)
     assert t.cpu().numpy().tobytes() == want
+    # the storage owns a reference to the batch: a derived view alone keeps close() from handing the buffer back to the pool
+    part = t[: 128 * 10].view(torch.int32)
+    del t
+    try:
+        d.close()
+        raise SystemExit("close() under a live view did not raise")
+    except hip.SvtyperHipError as e:
+        assert "still alive" in str(e)
+    assert part.cpu().numpy().tobytes() == want[: 128 * 10]
+    del part
 print("view ok")
 """
 
