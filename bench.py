@@ -86,7 +86,7 @@ def _gen_chunk(args):
                             [fixture_library()], svtype_mix=cfg["svtype_mix"])
 
 
-def generate(name: str, n_units: int, rank: int, workers: int, first_chunk: int = 0):
+def generate(name: str, n_units: int, rank: int, workers: int, first_chunk: int = 0, layout: str = "site"):
     """The synthetic workload of this rank (chunks generated in parallel host processes)."""
     from svtyper_amd import evidence as ev
     if name == "c5_multisample":
@@ -95,7 +95,7 @@ def generate(name: str, n_units: int, rank: int, workers: int, first_chunk: int 
         with mp.get_context("fork").Pool(min(max(1, workers), 32)) as pool:
             lo, hi = (int(x) for x in os.environ.get("SVT_BENCH_C5_LIBS", "1,3").split(","))   # (probes: libraries per sample)
             return synth.make_multisample(max(1, n_units // N_SAMPLES_C5), N_SAMPLES_C5, synth.BASE_SEED + 5 + 7919 * rank,
-                                          libs_per_sample=(lo, hi), pool_map=pool.map)
+                                          libs_per_sample=(lo, hi), pool_map=pool.map, layout=layout)
     chunk = 50_000
     jobs = [(name, min(chunk, n_units - i), first_chunk + i // chunk, rank) for i in range(0, n_units, chunk)]
     if workers > 1 and len(jobs) > 1:
@@ -127,6 +127,23 @@ def library_stamp() -> str:
     return h.hexdigest()[:16]
 
 
+_COMPILER = None
+
+
+def compiler_stamp() -> str:
+    """the device compiler the in-tree library is built with (`hipcc --version`: HIP version + clang version lines)"""
+    global _COMPILER
+    if _COMPILER is None:
+        import subprocess
+        try:
+            text = subprocess.run([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "--version"], capture_output=True, text=True, timeout=60).stdout
+            keep = [l.strip() for l in text.splitlines() if l.startswith("HIP version") or "clang version" in l]
+            _COMPILER = "; ".join(keep) or "unknown"
+        except Exception:
+            _COMPILER = "unknown"
+    return _COMPILER
+
+
 def source_stamp() -> str:
     """Identity of the kernel SOURCES (sha256 over svtyper_amd/csrc/{*.hip,*.h,Makefile} and include/*.h, first 16 hex
     digits; the host-only *.cpp files -- BAM reader, formatter, packed-evidence encoder -- do not reach the device
@@ -134,6 +151,7 @@ def source_stamp() -> str:
     survives a rebuild by build() -- and is still refused once any kernel source has changed."""
     import glob
     h = hashlib.sha256()
+    h.update(compiler_stamp().encode() + b"\0")   # (an entry must not survive a toolchain change either)
     files = sorted(glob.glob(os.path.join(ROOT, "svtyper_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "svtyper_amd", "csrc", "*.h")) +
                    [os.path.join(ROOT, "svtyper_amd", "csrc", "Makefile")] +
                    glob.glob(os.path.join(ROOT, "include", "*.h")))
@@ -173,7 +191,7 @@ def cpu_model() -> str:
     return "unknown"
 
 
-LEGS = ("sso", "c5", "c5x", "shard", "one_shot", "packed", "large")   # c5x: the c5 leg's comparison launches (site-major input, no hints)
+LEGS = ("sso", "c5", "c5x", "shard", "one_shot", "packed", "large", "real")   # c5x: the c5 leg's comparison launches (site-major input, no hints)
 
 
 def roofline_of(kernel_ms: float, alg_bytes: int, key: str, n_units: int, n_records: int) -> dict:
@@ -209,6 +227,172 @@ def time_passes(dbatch, steps: int) -> float:
     return dbatch.genotype_timed(steps) / steps
 
 
+def _wgs_like_bam(path: str, genome: int = 1_200_000, coverage: float = 30.0, spacing: int = 4_000, seed: int = 1):
+    """A bounded BAM that looks like whole-genome sequencing (tests/bamwriter.py): 150-bp pairs at ~30x with random bases and
+    binned qualities (BGZF blocks inflate at a realistic cost), one DEL site every few kb -- every site touches blocks nobody
+    has inflated yet.  Returns (library info dict, breakpoint dicts)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import bamwriter as bw
+    rng = np.random.default_rng(seed)
+    n_pairs = int(genome * coverage / 300)
+    header = "@HD\tVN:1.5\tSO:coordinate\n@SQ\tSN:1\tLN:%d\n@RG\tID:rg\tSM:smp\tLB:lib\n" % genome
+    starts = rng.integers(0, genome - 1000, n_pairs)
+    isz = np.clip(rng.normal(400, 60, n_pairs), 160, 900).astype(np.int64)
+    seq_pool = rng.integers(0, 4, (4096, 75))
+    seq_pool = ((1 << seq_pool) << 4 | (1 << rng.integers(0, 4, (4096, 75)))).astype(np.uint8)
+    qual_pool = np.array([2, 11, 25, 37], np.uint8)[rng.choice(4, (4096, 150), p=[0.02, 0.08, 0.2, 0.7])]
+    seqs = [seq_pool[i].tobytes() for i in range(4096)]
+    quals = [qual_pool[i].tobytes() for i in range(4096)]
+    mqs = [0, 20, 37, 60, 60, 60, 60]
+    split = rng.random(n_pairs) < 0.02
+    pick = rng.integers(0, 4096, (n_pairs, 2, 2))
+    mq = rng.integers(0, len(mqs), (n_pairs, 2))
+    nm = rng.integers(0, 3, (n_pairs, 2))
+    recs = []
+    for k in range(n_pairs):
+        p1 = int(starts[k])
+        p2 = p1 + int(isz[k]) - 150
+        name = "r%08d" % k
+        for mate, (p, mp, rev) in enumerate(((p1, p2, False), (p2, p1, True))):
+            flag = 0x1 | 0x2 | (0x40 if mate == 0 else 0x80) | (0x10 if rev else 0x20)
+            cigar = "150M" if not split[k] else ("100M50S" if mate == 0 else "50S100M")
+            recs.append(dict(name=name, flag=flag, tid=0, pos=p, mapq=mqs[int(mq[k, mate])], cigar=cigar, mtid=0, mpos=mp,
+                             tlen=(int(isz[k]) if mate == 0 else -int(isz[k])), tags=[("NM", "C", int(nm[k, mate])), ("RG", "Z", "rg")],
+                             seq4=seqs[int(pick[k, mate, 0])], qual=quals[int(pick[k, mate, 1])]))
+    recs.sort(key=lambda r: r["pos"])
+    bw.write_bam(path, header, [("1", genome)], recs, block_bytes=65280)
+    hist = {str(k): int(1000 * np.exp(-((k - 400) / 85.0) ** 2)) + 1 for k in range(160, 900)}
+    info = {"smp": {"mapped": len(recs), "unmapped": 0, "bam": path, "sample_name": "smp", "libraryArray": [
+        {"library_name": "lib", "readgroups": ["rg"], "read_length": 150, "histogram": hist, "mean": 400.0, "sd": 60.0, "prevalence": 1.0}]}}
+    sites = []
+    for pos in range(20_000, genome - 20_000, spacing):
+        L = int(rng.integers(500, 3000))
+        sites.append({"id": "d%d" % pos, "svtype": "DEL", "var_length": L,
+                      "A": {"chrom": "1", "pos": pos, "ci": [-10, 10], "is_reverse": False},
+                      "B": {"chrom": "1", "pos": pos + L + 1, "ci": [-10, 10], "is_reverse": True}})
+    return info, sites, len(recs)
+
+
+def real_data_leg(device: int) -> dict:
+    """The f-rows end to end on real BAM bytes, reader="native", geometry="device": BGZF inflate + fetch +
+    fragment summaries in C++ threads (svt_bam_summarise), 128-byte summaries over PCIe, the geometry kernel, the genotype
+    pass, result records back, sample columns formatted (svt_format_results).  Replaces svtyper/classic.py:54-100,
+    singlesample.py:187-205 + the per-variant loop.  Two inputs: the reference's fixture BAM (211 sites, repeated: every
+    block is in the page cache and the same blocks are inflated again and again) and a bounded WGS-like BAM written here
+    (every site touches blocks nobody has inflated before)."""
+    import io
+    import tempfile
+    from svtyper_amd import bam as pybam, hip, library, pipeline, singlesample
+    from svtyper_amd import native_reads as nr
+    from svtyper_amd import evidence as ev
+    from svtyper_amd.vcf import Variant, Vcf
+
+    data = os.path.join(ROOT, "tests", "data")
+    out = {"what": "reader=native, geometry=device: svt_bam_summarise (inflate + fetch + 128-byte fragment summaries, C++ threads) -> H2D -> "
+                   "svt_geometry_kernel -> svt_stream_kernel -> D2H -> svt_format_results; stage times in ms, whole-run rates in sites/s",
+           "bytes_per_fragment_over_pcie": 128, "canonical_record_bytes": 16}
+
+    class Timed:
+        """the HIP engine with a stopwatch on every stage behind the reader"""
+        supports_site_qual = False
+
+        def __init__(self):
+            self.t = {"create_h2d_geometry": 0.0, "pass": 0.0, "results_d2h": 0.0}
+            self.fragments = self.units = 0
+
+        def genotype_fragments(self, fb, flags=0, site_qual=None):
+            t0 = time.perf_counter()
+            d = hip.DeviceBatch.from_fragments(fb, device, flags)
+            t1 = time.perf_counter()
+            d.genotype(sync=True)
+            t2 = time.perf_counter()
+            r = d.results()
+            t3 = time.perf_counter()
+            d.close()
+            self.t["create_h2d_geometry"] += t1 - t0
+            self.t["pass"] += t2 - t1
+            self.t["results_d2h"] += t3 - t2
+            self.fragments += fb.n_fragments
+            self.units += fb.n_units
+            return hip.host_sq(r)
+
+    def run(sample, nbam, sites, repeat, threads=0):
+        best = None
+        for _ in range(2):     # (the first run pays the pooled device buffers; keep the better one)
+            eng = Timed()
+            coll = pipeline.NativeUnitCollector([sample], [nbam], 1.0, 1.0, 20, nr.COUNT_SSO, 1000, n_threads=threads)
+            for _r in range(repeat):
+                for bp in sites:
+                    coll.add_site(bp)
+            t0 = time.perf_counter()
+            res = coll.run(eng, ev.FLAG_SSO_ASSOCIATION)
+            t1 = time.perf_counter()
+            cols = hip.format_results(res, list(pipeline.SVTYPER_FORMAT_KEYS), False)
+            t2 = time.perf_counter()
+            dev = sum(eng.t.values())
+            leg = {"sites": len(sites) * repeat, "fragments": eng.fragments, "wall_ms": (t2 - t0) * 1e3,
+                   "sites_per_s": len(sites) * repeat / (t2 - t0),
+                   "stage_ms": {"inflate_fetch_summarise_host": (t1 - t0 - dev) * 1e3,
+                                "h2d_plus_geometry_kernel": eng.t["create_h2d_geometry"] * 1e3, "genotype_pass": eng.t["pass"] * 1e3,
+                                "results_d2h": eng.t["results_d2h"] * 1e3, "format_columns_host": (t2 - t1) * 1e3},
+                   "h2d_bytes": int(eng.fragments * 128), "fragments_per_site": eng.fragments / max(1, len(sites) * repeat),
+                   "gt_histogram": {str(k): int(v) for k, v in zip(*np.unique(res.gt, return_counts=True))}, "columns": len(cols)}
+            if best is None or leg["wall_ms"] < best["wall_ms"]:
+                best = leg
+        return best
+
+    # ---- (1) the reference's fixture: breakpoints of tests/data/example.vcf, the driver itself first (byte check), then x R
+    in_vcf, bam_path = os.path.join(data, "example.vcf"), os.path.join(data, "NA12878.target_loci.sorted.bam")
+    lib_json = os.path.join(data, "NA12878.bam.json")
+    t0 = time.perf_counter()
+    buf = io.StringIO()
+    with open(in_vcf) as inf, open(os.devnull, "w") as null:
+        old, sys.stderr = sys.stderr, null
+        try:
+            singlesample.sso_genotype(bam_path, inf, buf, 20, 1, 1, 1000000, lib_json, False, None, False, 1000, 1e10, None, 1000,
+                                      geometry="device", reader="native")
+        finally:
+            sys.stderr = old
+    drv = time.perf_counter() - t0
+    strip = lambda text: [l for l in text.splitlines() if not l.startswith("##fileDate")]
+    with open(os.path.join(data, "example.gt.vcf")) as f:
+        same = strip(buf.getvalue()) == strip(f.read())
+    out["fixture_driver"] = {"what": "singlesample.sso_genotype(reader='native', geometry='device') over tests/data (211 breakpoints), VCF in -> VCF out",
+                             "wall_ms": drv * 1e3, "output_equals_example_gt_vcf": bool(same)}
+    vcf = Vcf()
+    bps = []
+    with open(in_vcf) as f:
+        lines = f.readlines()
+    vcf.add_header([l for l in lines if l.startswith("##")])
+    for line in lines:
+        if line.startswith("#"):
+            continue
+        v = Variant(line.rstrip().split("\t"), vcf)
+        if not v.has_svtype() or not v.is_valid_svtype():
+            continue
+        bp = vcf.get_variant_breakpoints(v, 1e10)
+        if bp is not None:
+            bps.append(bp)
+    with open(lib_json) as f:
+        sample = library.Sample.from_lib_info(pybam.AlignmentFile(bam_path), json.load(f), 1e-3)
+    nbam = nr.NativeBam(bam_path)
+    out["fixture_x100"] = dict(run(sample, nbam, bps, 100), what="the %d fixture breakpoints x 100 (cached blocks, repeated sites)" % len(bps))
+    nbam.close()
+    # ---- (2) a bounded WGS-like BAM: 1.2 Mbp at 30x, a DEL every 4 kb
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "wgs_like.bam")
+        t0 = time.perf_counter()
+        info, sites, n_rec = _wgs_like_bam(path)
+        wrote = time.perf_counter() - t0
+        sample = library.Sample.from_lib_info(pybam.AlignmentFile(path), info, 1e-3)
+        nbam = nr.NativeBam(path)
+        out["wgs_like_30x"] = dict(run(sample, nbam, sites, 1), bam_records=n_rec, bam_bytes=os.path.getsize(path), bam_written_s=wrote,
+                                   what="1.2 Mbp at 30x (150-bp pairs, random bases, binned qualities), %d DEL sites 4 kb apart: every "
+                                        "site inflates blocks of its own" % len(sites))
+        nbam.close()
+    return out
+
+
 def main():
     json_out = claim_stdout()
     # the host driver only supports dmabuf IPC: RCCL across processes fails without this (already exported on the GPU boxes)
@@ -227,6 +411,9 @@ def main():
     ap.add_argument("--legs", default="all", help="comma list of the extra N=1 legs to run: " + ",".join(LEGS) + " [all]")
     ap.add_argument("--no-dense-leg", action="store_true", help="(kept for old command lines) = --no-extra-legs")
     ap.add_argument("--large-units", type=int, default=4_000_000)
+    ap.add_argument("--c5-units", type=int, default=None,
+                    help="(site, sample) units of the c5_multisample leg [2 x --units: at the default that is configs[4]'s own per-GPU "
+                         "share, 500 k sites x 32 samples over 8 GPUs = 62 500 sites x 32 = 2 M units x ~100 records]")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--spinup-ms", type=float, default=SPINUP_MS,
                     help="untimed passes for this many ms before the warm-up steps (device clocks; 0 = none)")
@@ -274,10 +461,16 @@ def main():
     gen_s = time.time() - t0
     if world != 1 or args.workload != "c3_mixed_1m" or args.scaling != "weak":
         legs = set()
-    more = c5_batch = None
+    more = c5_batch = c5_sample_major = None
     if "c5" in legs:
-        # the configs[4] shape at the headline's size: sites x 32 samples with per-sample libraries (svt_unit.libs hints)
-        c5_batch = generate("c5_multisample", batch.n_units, rank, workers)
+        # the configs[4] shape at ITS per-GPU size (500 k sites x 32 samples over 8 GPUs = 62 500 sites x 32 = 2 M units of
+        # ~100 records, 3.2 GB): sites x 32 samples with per-sample libraries (svt_unit.libs hints), generated sample-major --
+        # the order a producer that reads BAM by BAM emits -- and, for the comparison launches, site-major as well
+        c5_n = args.c5_units if args.c5_units else 2 * batch.n_units
+        if "c5x" in legs:
+            c5_batch, c5_sample_major = generate("c5_multisample", c5_n, rank, workers, layout="both")
+        else:
+            c5_sample_major = generate("c5_multisample", c5_n, rank, workers, layout="sample")
     if "large" in legs and args.large_units > batch.n_units:
         # the rest of the `large_batch` leg's workload (also generated before any GPU context exists)
         more = generate(args.workload, args.large_units - batch.n_units, rank, workers,
@@ -330,6 +523,10 @@ def main():
         if use_dist:
             dist.barrier()
 
+    # the same launches WITHOUT the spin-up, for the record (a device coming out of idle: DESIGN.md 5): one untimed pass,
+    # then `steps` passes between HIP events -- reported as `roofline.no_spinup_*`, never as `value`
+    dbatch.genotype(sync=True)
+    cold_ms = dbatch.genotype_timed(args.steps) / args.steps
     spun = spin_up(dbatch, args.spinup_ms)
     for _ in range(args.warmup):
         dbatch.genotype(sync=False)
@@ -430,8 +627,10 @@ def main():
                 "kernel_ms_max_over_ranks": kern_ms_max,
                 "kernel_ms_note": "HIP events around the `steps` back-to-back launches of the timed region, divided by `steps`: "
                                   "includes the ~5-10 us between consecutive dispatches that rocprofv3's per-kernel duration leaves out",
+                "no_spinup_kernel_ms": cold_ms, "no_spinup_frac": alg_bytes / (cold_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "library_sha16": library_stamp(),
                 "source_sha16": source_stamp(),
+                "compiler": compiler_stamp(),
                 "note": "`achieved` = ALGORITHMIC bytes (16 B per fragment record + 112 B per unit) over the time of the ONE "
                         "kernel that does all the work from the canonical input: <= peak by construction",
             }),
@@ -516,6 +715,12 @@ def main():
                         packed.free()
                 pack_ms = min(pack_times)
                 pack_med = sorted(pack_times[1:] or pack_times)[len(pack_times[1:] or pack_times) // 2]
+                back_to_back = []
+                for _ in range(5 if packed is not None else 0):   # the encoder called back to back, no pauses (what a producer loop sees)
+                    t0 = time.perf_counter()
+                    p3 = hip.PackedEvidence.try_pack(batch)
+                    back_to_back.append((time.perf_counter() - t0) * 1e3)
+                    p3.free()
                 if packed is None:
                     out["one_shot_packed"] = {"skipped": "this batch cannot be expressed as packed evidence (several libraries)"}
                 else:
@@ -565,6 +770,7 @@ def main():
                         "from_records_wall_ms": min(route), "from_records_wall_ms_median": sorted(route)[len(route) // 2],
                         "from_records_breakpoints_per_s": n / (min(route) * 1e-3),
                         "pack_ms_median": pack_med,
+                        "pack_ms_median_back_to_back": sorted(back_to_back)[len(back_to_back) // 2],
                         "wall_ms": best * 1e3, "serial_wall_ms": serial * 1e3, "serial_create_ms": parts[0] * 1e3,
                         "serial_pass_ms": parts[1] * 1e3, "serial_results_d2h_ms": parts[2] * 1e3, "pack_ms": pack_ms,
                         "pack_inclusive_wall_ms": pack_ms + best * 1e3,
@@ -652,14 +858,13 @@ def main():
             except Exception as e:
                 out["sso"] = {"error": repr(e)}
 
-        if c5_batch is not None:
-            # ---- BASELINE.json configs[4] shape at the headline's size: (site, sample) units, 32 samples, per-sample libraries.
+        if c5_sample_major is not None:
+            # ---- BASELINE.json configs[4] shape at its per-GPU size: (site, sample) units, 32 samples, per-sample libraries.
             # The producer hands the units over SAMPLE-MAJOR (it reads BAM by BAM; a sample's units, which share its library
             # window, are then contiguous in HBM) and svt_batch_result_order makes the pass write the records SITE-MAJOR, the
             # order QUAL, the shard rule and the VCF writer use.  `site_major_input`: the same units handed over site-major.
             try:
-                from svtyper_amd import synth
-                sm_batch, _ = synth.to_sample_major(c5_batch, N_SAMPLES_C5)
+                sm_batch, c5_sample_major = c5_sample_major, None
                 with hip.DeviceBatch(sm_batch, device=local_rank, flags=sso) as dc:
                     dc.result_order(N_SAMPLES_C5)
                     dc.genotype(sync=True)
@@ -672,12 +877,12 @@ def main():
                 leg.update(what="configs[4] shape: %d sites x %d samples, %d libraries, every unit carries its sample's library window "
                                 "(svt_unit.libs); units handed over sample-major, result records written site-major "
                                 "(svt_batch_result_order); one launch of the library-window kernel"
-                                % (c5_batch.n_units // N_SAMPLES_C5, N_SAMPLES_C5, len(c5_batch.libs)),
+                                % (sm_batch.n_units // N_SAMPLES_C5, N_SAMPLES_C5, len(sm_batch.libs)),
                            kernel="svt_stream_kernel<windows>", table_mode=c_mode, units=sm_batch.n_units, records=sm_batch.n_records,
                            units_per_s=sm_batch.n_units / (c_ms * 1e-3), sites_per_s=sm_batch.n_units / N_SAMPLES_C5 / (c_ms * 1e-3))
                 del sm_batch
                 out["c5_multisample"] = leg
-                if "c5x" not in legs:
+                if c5_batch is None:
                     raise StopIteration
                 with hip.DeviceBatch(c5_batch, device=local_rank, flags=sso) as dc:
                     dc.genotype(sync=True)
@@ -739,6 +944,13 @@ def main():
                 }
             except Exception as e:
                 out["shard_of_8"] = {"error": repr(e)}
+
+        if "real" in legs:
+            # ---- the rows either side of the path on real BAM bytes (f1 geometry on device, f3 native reader, f4 pipeline)
+            try:
+                out["real_data"] = real_data_leg(local_rank)
+            except Exception as e:
+                out["real_data"] = {"error": repr(e)}
 
         if more is not None:
             # ---- the same step at 4 M units per GPU: 6.5 GB of records, far beyond the 256 MiB Infinity Cache

@@ -25,6 +25,9 @@ namespace svt {
 constexpr uint32_t kBlockRecords = 8;                         // records per 128-byte block
 constexpr uint32_t kStageBytes = kWave * 128;                 // one block per lane
 constexpr uint32_t kRingBytes = kStageBytes;                  // per wave: one stage
+#ifndef SVT_READ_ADDR_RECOMPUTE
+#define SVT_READ_ADDR_RECOMPUTE 1
+#endif
 #ifndef SVT_STREAM_DEPTH
 #define SVT_STREAM_DEPTH 1   // stages per wave in svt_stream_kernel (2: block k + 2 is in flight while block k is summed)
 #endif
@@ -52,8 +55,16 @@ __device__ __forceinline__ void read_block(const uint32_t lane_block, const uint
 {
     // logical record j of the lane's block sits in slot j ^ swz: lane_block + ((j << 4) ^ sw16)
     uint32_t addr[8];
+#if SVT_READ_ADDR_RECOMPUTE
+    // (the eight addresses are loop invariants the compiler would keep in eight VGPRs across the block loop; formed anew
+    // per block -- one v_xad_u32 each -- they live for the duration of the burst only)
+    uint32_t sw = sw16;
+    asm volatile("" : "+v"(sw));
+#else
+    const uint32_t sw = sw16;
+#endif
 #pragma unroll
-    for (int j = 0; j < 8; ++j) addr[j] = lane_block + (((uint32_t)j << 4) ^ sw16);
+    for (int j = 0; j < 8; ++j) addr[j] = lane_block + (((uint32_t)j << 4) ^ sw);
     asm volatile("s_waitcnt vmcnt(%16)\n\t"
                  "ds_read_b128 %0, %8 offset:%17\n\t"
                  "ds_read_b128 %1, %9 offset:%17\n\t"

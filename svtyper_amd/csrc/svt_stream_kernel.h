@@ -73,6 +73,10 @@
 #define SVT_STREAM_WAVES 3 // waves per SIMD the register allocation must allow (three workgroups per CU)
 #endif
 
+#ifndef SVT_CONSUME_LAUNDER
+#define SVT_CONSUME_LAUNDER 1 // the record consumers' common address arithmetic stays inside each consumer (see consume)
+#endif
+
 #ifndef SVT_PROBE_LDS_PAD
 #define SVT_PROBE_LDS_PAD 0 // timing only: unused LDS added to every streaming workgroup (fewer resident workgroups per CU)
 #endif
@@ -521,7 +525,14 @@ __global__ __launch_bounds__(kBlock, MODE == kSingleLds ? SVT_STREAM_WAVES : MOD
         Acc acc = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
 
         // EDGE = false: every lane's eight records of this block are its own
-        auto consume = [&](const u32x4 (&w)[8], const uint32_t k, auto edge, auto window_kind, auto continuations) {
+        auto consume = [&](const u32x4 (&w_in)[8], const uint32_t k, auto edge, auto window_kind, auto continuations) {
+#if SVT_CONSUME_LAUNDER
+            // The block's records through an empty asm: the four instances of this body (edge / interior x continuation
+            // records or not) start with the same address arithmetic for all eight records, which the compiler otherwise
+            // hoists in front of the branch that selects the instance -- 32 VGPRs of temporaries alive across the whole
+            // block, the difference between three and four waves per SIMD.
+#endif
+            const u32x4 (&w)[8] = w_in;
             constexpr bool EDGE = decltype(edge)::value;
             constexpr bool CONT = decltype(continuations)::value;   // sso: some record of the block may continue a fragment
             constexpr int KIND = decltype(window_kind)::value;   // kMultiLds: 1 = the window holds one library, 0 = several
@@ -535,17 +546,21 @@ __global__ __launch_bounds__(kBlock, MODE == kSingleLds ? SVT_STREAM_WAVES : MOD
                 // records' worth of live table values would not fit the register budget of three waves per SIMD
                 if (j == SVT_STREAM_SPLIT) __builtin_amdgcn_sched_barrier(0);
                 const bool mine = is_mine(j);
-                if (mine) check.see(w[j], lib_key);     // (slots that are not this lane's were not fetched)
+                u32x4 wj = w[j];
+#if SVT_CONSUME_LAUNDER
+                if (MODE != kGeneral) asm volatile("" : "+v"(wj));
+#endif
+                if (mine) check.see(wj, lib_key);     // (slots that are not this lane's were not fetched)
                 if (MODE == kSingleLds) {
-                    record_single<SSO, EDGE, CONT>(w[j], mine, sc, acc);
+                    record_single<SSO, EDGE, CONT>(wj, mine, sc, acc);
                 } else if (MODE == kMultiLds) {
-                    if (KIND == 1) record_single<SSO, EDGE, CONT>(w[j], mine, sc, acc);
-                    else record_window<SSO, EDGE, CONT>(w[j], mine, wc, acc, check);
+                    if (KIND == 1) record_single<SSO, EDGE, CONT>(wj, mine, sc, acc);
+                    else record_window<SSO, EDGE, CONT>(wj, mine, wc, acc, check);
                 } else {
-                    const uint32_t wy = mine ? w[j].y : 0u, wz = mine ? w[j].z : 0u;   // MAPQ 0 everywhere: adds +0.0
-                    weight_evidence<SSO>(wy >> 16 | (wz << 16), wz >> 16, (w[j].w & SVT_REC_CONTINUATION) != 0, t, acc);
+                    const uint32_t wy = mine ? wj.y : 0u, wz = mine ? wj.z : 0u;   // MAPQ 0 everywhere: adds +0.0
+                    weight_evidence<SSO>(wy >> 16 | (wz << 16), wz >> 16, (wj.w & SVT_REC_CONTINUATION) != 0, t, acc);
                     // (a library index beyond the batch's is reported through *err)
-                    pair_evidence(w[j].x, wy & 0xffffu, w[j].w & 7u, min(SVT_REC_LIB(w[j].w), a.n_libs - 1u), t, c, acc);
+                    pair_evidence(wj.x, wy & 0xffffu, wj.w & 7u, min(SVT_REC_LIB(wj.w), a.n_libs - 1u), t, c, acc);
                 }
             }
         };

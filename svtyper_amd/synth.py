@@ -211,10 +211,12 @@ def _multisample_part(args):
 
 
 def make_multisample(n_sites: int, n_samples: int, seed: int, libs_per_sample=(1, 3), mean_frags: float = 100.0,
-                     sd_frags: float = 25.0, min_frags: int = 18, max_frags: int = 183, pool_map=map) -> EvidenceBatch:
+                     sd_frags: float = 25.0, min_frags: int = 18, max_frags: int = 183, pool_map=map, layout: str = "site"):
     """BASELINE.json configs[4] shape: (site, sample) units, site-major, every sample with its own 1..3
     libraries (rounded-normal insert-size histograms) and genotypes drawn per sample from a site allele
-    frequency ~ Beta(0.5, 2).  `pool_map` may be a multiprocessing Pool.map to generate samples in parallel."""
+    frequency ~ Beta(0.5, 2).  `pool_map` may be a multiprocessing Pool.map to generate samples in parallel.
+    layout: "site" = the site-major batch; "sample" = the same units sample-major (== to_sample_major(site-major batch)[0],
+    which is how they are generated); "both" = (site-major, sample-major)."""
     rng = np.random.default_rng(seed)
     libs: List[LibraryTable] = []
     sample_libs = []
@@ -237,10 +239,14 @@ def make_multisample(n_sites: int, n_samples: int, seed: int, libs_per_sample=(1
     for s, p in enumerate(parts):      # every unit says which libraries its sample owns (svt_unit.libs)
         p.units["libs"] = ev.unit_libs(sample_libs[s][0], len(sample_libs[s]))
     allb = ev.concat_batches(parts)
+    del parts
+    allb.libs = libs
+    if layout == "sample":
+        return allb
     order = (np.arange(n_sites)[:, None] + n_sites * np.arange(n_samples)[None, :]).reshape(-1)
     out = permute_units(allb, order)
     out.libs = libs
-    return out
+    return (out, allb) if layout == "both" else out
 
 
 def make_edge_cases(libs: Sequence[LibraryTable], seed: int = 1) -> EvidenceBatch:

@@ -38,7 +38,9 @@ def test_bench_line_has_the_contract_keys(hip_device):
     assert "nothing pre-digested" in d["config"]["step"]
     # a traffic figure is only reported when it was measured on this very build
     assert roof["traffic"] is None or "these kernel sources" in roof["traffic_source"]
-    assert len(roof["source_sha16"]) == 16 and len(roof["library_sha16"]) == 16
+    assert len(roof["source_sha16"]) == 16 and len(roof["library_sha16"]) == 16 and roof["compiler"]
+    # the same launches without the untimed spin-up are in the record too
+    assert roof["no_spinup_kernel_ms"] > 0 and 0 < roof["no_spinup_frac"] <= 1.0
     # the labelled extra legs
     assert d["one_shot"]["pcie_inclusive_breakpoints_per_s"] > 0 and d["one_shot"]["wall_ms"] > 0
     assert d["large_batch"]["units"] == 70000 and d["large_batch"]["first_units_equal_headline"] is True
@@ -49,10 +51,22 @@ def test_bench_line_has_the_contract_keys(hip_device):
     # the singlesample association, the configs[4] shape and the 8-GPU shard: own fractions, own (or no) traffic figures
     assert 0 < d["sso"]["frac"] <= 1.0 and d["sso"]["units"] == 30000
     c5 = d["c5_multisample"]
+    assert c5["units"] == 60000 - 60000 % 32          # configs[4]'s per-GPU share is twice the headline's units
     assert 0 < c5["frac"] <= 1.0 and c5["table_mode"] == 1 and c5["units"] % 32 == 0 and c5["hintless"]["table_mode"] == 1 and c5["hintless"]["results_equal"] and c5["general_tables"]["table_mode"] == 2
     assert c5["site_major_input"]["results_and_site_qual_equal"] is True
     for leg in (d["sso"], c5):
         assert leg["traffic"] is None or "these kernel sources" in leg["traffic_source"]
+    assert d["one_shot_packed"]["pack_ms_median_back_to_back"] > 0
+    # the rows either side of the path on real BAM bytes: the driver itself reproduces the expected VCF, stage times are there
+    real = d["real_data"]
+    assert "error" not in real, real
+    assert real["fixture_driver"]["output_equals_example_gt_vcf"] is True
+    for key in ("fixture_x100", "wgs_like_30x"):
+        leg = real[key]
+        assert leg["sites"] > 0 and leg["fragments"] > 0 and leg["sites_per_s"] > 0 and leg["columns"] == leg["sites"]
+        assert set(leg["stage_ms"]) == {"inflate_fetch_summarise_host", "h2d_plus_geometry_kernel", "genotype_pass", "results_d2h", "format_columns_host"}
+        assert all(v >= 0 for v in leg["stage_ms"].values()) and leg["h2d_bytes"] == 128 * leg["fragments"]
+    assert real["fixture_x100"]["sites"] == 21100
     sh = d["shard_of_8"]
     assert sh["results_equal_headline"] is True and 0 < sh["units"] < 30000 and sh["speedup_vs_headline"] > 0
 

@@ -607,15 +607,15 @@ def test_sum_of_likelihoods_across_the_underflow_band(hip_device, fixture_librar
 
 
 # ------------------------------------------------------------------------------------------
-# BASELINE.json configs[4] at full per-GPU size: 65 536 sites x 32 samples = 2.1 M units, 66 libraries
-# (per-sample insert-size tables: the streaming kernel's general mode) through size-independent properties
+# BASELINE.json configs[4] at its own per-GPU size: 500 k sites x 32 samples over 8 GPUs = 62 500 sites x 32 samples
+# = 2 M units of ~100 fragment records (200 M records, 3.2 GB), ~66 libraries (per-sample library windows), through
+# size-independent properties (the shape classic.py:279 iterates with the per-sample libraries of parsers.py:432-447)
 # ------------------------------------------------------------------------------------------
 @pytest.fixture(scope="module")
 def full_c5():
     import multiprocessing as mp
     with mp.get_context("fork").Pool(16) as pool:
-        return synth.make_multisample(65_536, 32, synth.BASE_SEED + 5, mean_frags=40.0, sd_frags=12.0, min_frags=8,
-                                      max_frags=80, pool_map=pool.map)
+        return synth.make_multisample(62_500, 32, synth.BASE_SEED + 5, pool_map=pool.map)
 
 
 def test_full_size_multisample_properties(hip_device, full_c5):
@@ -623,7 +623,7 @@ def test_full_size_multisample_properties(hip_device, full_c5):
     from svtyper_amd import hip
     batch = full_c5
     n, S = batch.n_units, 32
-    assert n == 65_536 * S and len(batch.libs) >= 32 and batch.n_records > 60_000_000
+    assert n == 62_500 * S == 2_000_000 and len(batch.libs) >= 32 and batch.n_records > 190_000_000
     assert (batch.units["sample"][: 2 * S] == np.tile(np.arange(S), 2)).all()      # site-major
     with hip.DeviceBatch(batch, device=hip_device) as d:
         assert d.layout_name() == "stream"
@@ -637,7 +637,7 @@ def test_full_size_multisample_properties(hip_device, full_c5):
     # QUAL over a site's samples: device kernel == the running host sum (classic.py:485,498), bit for bit
     assert np.array_equal(qual_dev.view(np.uint64), hip.site_qual_host(first, S).view(np.uint64))
     # split invariance at a site boundary, and the multi-device entry with group = samples per site
-    cut = 21_845 * S
+    cut = 20_833 * S
     lo = hip.genotype_batch(batch.slice(0, cut), device=hip_device)
     hi = hip.genotype_batch(batch.slice(cut, n), device=hip_device)
     assert np.array_equal(np.concatenate([_digest(lo), _digest(hi)]), base)
@@ -660,7 +660,7 @@ def test_full_size_multisample_properties(hip_device, full_c5):
         assert np.array_equal(d.results().rec, first.rec)
     # the oracle on a bounded random sample of whole sites
     rng = np.random.default_rng(7)
-    sites = np.sort(rng.choice(65_536, 700, replace=False))
+    sites = np.sort(rng.choice(62_500, 700, replace=False))
     pick = (sites[:, None] * S + np.arange(S)[None, :]).reshape(-1)
     want = c_oracle.genotype_batch(synth.permute_units(batch, pick), flags=0)
     assert_parity(ev.Results(first.rec[pick].copy()), want)
