@@ -42,7 +42,7 @@ __global__ __launch_bounds__(kBlock) void svt_counts_kernel(const double* __rest
     const double* t = counts + 5 * i;   // SVT_TAL_* order: ref_seq, alt_seq, alt_clip, ref_span, alt_span
     const Acc acc = {t[0], t[1], t[2], t[3], t[4], 0.0, 0.0, 0.0};
     uint4 piece[8];
-    unit_epilogue<false, false>(acc, is_dup[i] ? SVT_SVTYPE_DUP : SVT_SVTYPE_DEL, 0u, c, l10, l10, false, piece);
+    unit_epilogue<false, false>(acc, is_dup[i] ? SVT_SVTYPE_DUP : SVT_SVTYPE_DEL, 0u, c, l10, l10, 0u, piece);
     uint4* dst = reinterpret_cast<uint4*>(out + i);
 #pragma unroll
     for (int k = 0; k < 8; ++k) dst[k] = piece[k];

@@ -50,10 +50,11 @@ struct DevicePool {
     std::vector<std::pair<void*, uint64_t>> mapped;   // chunked buffers: virtual base, mapped bytes (guarded by `lock`)
     std::atomic<bool> chunked_available{true};                    // false once alloc_chunked has failed (guarded by `lock` where it matters)
     // `bytes` of device memory as one virtual range over 256 MB physical chunks; false: not available, nothing left behind
-    bool alloc_chunked(int device, uint64_t bytes, void** out, uint64_t* cap)
+    bool alloc_chunked(int device, uint64_t bytes, void** out, uint64_t* cap, uint64_t chunk_bytes = 0)
     {
         static const bool enabled = [] { const char* e = std::getenv("SVT_CHUNKED_BUFFERS"); return !(e && std::atoi(e) == 0); }();
-        if (!enabled) return false;   // (measurements)
+        if (!enabled && !chunk_bytes) return false;   // (measurements)
+        const uint64_t kChunk = chunk_bytes ? chunk_bytes : DevicePool::kChunk;   // (measurement hooks choose their own chunk size)
         hipMemAllocationProp prop = {};
         prop.type = hipMemAllocationTypePinned;
         prop.location.type = hipMemLocationTypeDevice;

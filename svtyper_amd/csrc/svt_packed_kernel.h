@@ -169,7 +169,7 @@ __global__ __launch_bounds__(kBlock, 3) void svt_packed_kernel(const PackedArgs 
         }
         uint4 piece[8];
         unit_epilogue(acc, (uint32_t)U.svtype, (uint32_t)U.flags, a.c, reinterpret_cast<const double*>(smem + a.lds_l10), a.l10,
-                      a.l10_where == kL10Shared, piece);
+                      a.l10_where == kL10Shared ? a.n_l10 : 0u, piece);
         store_results_through_ring(ring, piece, unit, lane, a.out);
     }
 }

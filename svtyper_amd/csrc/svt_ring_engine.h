@@ -26,7 +26,7 @@ constexpr uint32_t kBlockRecords = 8;                         // records per 128
 constexpr uint32_t kStageBytes = kWave * 128;                 // one block per lane
 constexpr uint32_t kRingBytes = kStageBytes;                  // per wave: one stage
 #ifndef SVT_READ_ADDR_RECOMPUTE
-#define SVT_READ_ADDR_RECOMPUTE 1
+#define SVT_READ_ADDR_RECOMPUTE 0   // (in-process A/B: the recomputation costs 0.8 % of the one-library pass and 4 % of the window pass)
 #endif
 #ifndef SVT_STREAM_DEPTH
 #define SVT_STREAM_DEPTH 1   // stages per wave in svt_stream_kernel (2: block k + 2 is in flight while block k is summed)

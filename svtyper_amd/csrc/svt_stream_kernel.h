@@ -73,8 +73,10 @@
 #define SVT_STREAM_WAVES 3 // waves per SIMD the register allocation must allow (three workgroups per CU)
 #endif
 
-#ifndef SVT_CONSUME_LAUNDER
-#define SVT_CONSUME_LAUNDER 1 // the record consumers' common address arithmetic stays inside each consumer (see consume)
+#ifndef SVT_SANITIZE_EDGE
+#define SVT_SANITIZE_EDGE 1 // edge blocks: the slots that are not the lane's become neutral (all-zero) records and the block takes the
+                            // interior consumer -- ONE consumer instance per kernel instead of an edge / interior pair whose common
+                            // address arithmetic the compiler hoists in front of the selecting branch (32 VGPRs alive across the block)
 #endif
 
 #ifndef SVT_PROBE_LDS_PAD
@@ -119,6 +121,8 @@ struct StreamArgs {
     uint32_t lds_rings;          // byte offset of wave 0's ring (128-byte aligned)
     uint32_t l10_where;          // kL10Shared / kL10Ring / kL10Global
     uint32_t lds_l10;            // kL10Shared: byte offset of the workgroup's copy of the log10 table
+    uint32_t l10_lds_entries;    // entries of the table the epilogue finds in LDS (kL10Shared: all; kL10Ring: what one ring stage holds --
+                                 // a unit whose read count reaches beyond takes the table through L2; kL10Global: 0)
     uint64_t n_units;
     svt_result* out;
     uint32_t* err;
@@ -525,14 +529,7 @@ __global__ __launch_bounds__(kBlock, MODE == kSingleLds ? SVT_STREAM_WAVES : MOD
         Acc acc = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
 
         // EDGE = false: every lane's eight records of this block are its own
-        auto consume = [&](const u32x4 (&w_in)[8], const uint32_t k, auto edge, auto window_kind, auto continuations) {
-#if SVT_CONSUME_LAUNDER
-            // The block's records through an empty asm: the four instances of this body (edge / interior x continuation
-            // records or not) start with the same address arithmetic for all eight records, which the compiler otherwise
-            // hoists in front of the branch that selects the instance -- 32 VGPRs of temporaries alive across the whole
-            // block, the difference between three and four waves per SIMD.
-#endif
-            const u32x4 (&w)[8] = w_in;
+        auto consume = [&](const u32x4 (&w)[8], const uint32_t k, auto edge, auto window_kind, auto continuations) {
             constexpr bool EDGE = decltype(edge)::value;
             constexpr bool CONT = decltype(continuations)::value;   // sso: some record of the block may continue a fragment
             constexpr int KIND = decltype(window_kind)::value;   // kMultiLds: 1 = the window holds one library, 0 = several
@@ -546,10 +543,7 @@ __global__ __launch_bounds__(kBlock, MODE == kSingleLds ? SVT_STREAM_WAVES : MOD
                 // records' worth of live table values would not fit the register budget of three waves per SIMD
                 if (j == SVT_STREAM_SPLIT) __builtin_amdgcn_sched_barrier(0);
                 const bool mine = is_mine(j);
-                u32x4 wj = w[j];
-#if SVT_CONSUME_LAUNDER
-                if (MODE != kGeneral) asm volatile("" : "+v"(wj));
-#endif
+                const u32x4 wj = w[j];
                 if (mine) check.see(wj, lib_key);     // (slots that are not this lane's were not fetched)
                 if (MODE == kSingleLds) {
                     record_single<SSO, EDGE, CONT>(wj, mine, sc, acc);
@@ -568,7 +562,7 @@ __global__ __launch_bounds__(kBlock, MODE == kSingleLds ? SVT_STREAM_WAVES : MOD
         // kL10Ring: the log10 table of the epilogue goes through the wave's ring once the tile's last block has left it
         auto l10_into_ring = [&]() {
             const char* l10_bytes = reinterpret_cast<const char*>(a.l10);
-            for (uint32_t off = 0; off < a.n_l10 * 8u; off += 1024u)
+            for (uint32_t off = 0; off < a.l10_lds_entries * 8u; off += 1024u)
                 __builtin_amdgcn_global_load_lds(l10_bytes + off + lane * 16u, (lds_void_ptr)(ring + off), 16, 0, 0);
         };
         if (max_blk) {
@@ -578,6 +572,7 @@ __global__ __launch_bounds__(kBlock, MODE == kSingleLds ? SVT_STREAM_WAVES : MOD
             if (kStreamDepth == 2 && max_blk > 1) exact_behind = fetch(1, 1);
 #pragma unroll 1
             for (uint32_t k = 0; k < max_blk; ++k) {
+                const uint32_t stage_off = kStreamDepth == 2 ? (k & 1u) * kStageBytes : 0u;
                 if (kStreamDepth == 2) {
                     // block k sits in stage k & 1; the group behind it (block k + 1) may stay in flight
                     const bool pend = k + 1 < max_blk && exact_behind;
@@ -588,36 +583,83 @@ __global__ __launch_bounds__(kBlock, MODE == kSingleLds ? SVT_STREAM_WAVES : MOD
                         if (pend) read_block<0, 8>(lane_block, sw16, w);
                         else read_block<0, 0>(lane_block, sw16, w);
                     }
-                    if (SVT_STREAM_PROBE != 2 && k + 2 < max_blk) exact_behind = fetch(k + 2, k & 1u);
                 } else {
                     read_block(lane_block, sw16, w);
-                    if (SVT_STREAM_PROBE != 2 && k + 1 < max_blk) fetch(k + 1);
-                    else if (a.l10_where == kL10Ring) l10_into_ring();   // the tile's last block has left the ring: the copy lands while it is summed
                 }
+                // the block has left its stage for VGPRs: the next fetch into that stage can go out
+                auto refill = [&]() {
+                    if (SVT_STREAM_PROBE == 2) return;
+                    if (kStreamDepth == 2) {
+                        if (k + 2 < max_blk) exact_behind = fetch(k + 2, k & 1u);
+                    } else if (k + 1 < max_blk) fetch(k + 1);
+                    else if (a.l10_where == kL10Ring) l10_into_ring();   // the tile's last block has left the ring: the copy lands while it is summed
+                };
                 const uint32_t k8 = k * kBlockRecords;
                 if (SVT_STREAM_PROBE == 1) {
+                    refill();
 #pragma unroll
                     for (int j = 0; j < 8; ++j) acc.ref_seq += (double)(w[j].x ^ w[j].y ^ w[j].z ^ w[j].w);
-                } else {
-                    const bool edge = __any(k8 < head || k8 + kBlockRecords > last);
-                    // sso: a block in which no lane holds a continuation record (nearly all of them: a fragment
-                    // with a second split candidate is rare) takes the select-free form of the fragment-local sums.
-                    // Slots that were not fetched hold older records: at worst they send the block the general way.
-                    bool has_cont = false;
-                    if (SSO && MODE != kGeneral)
-                        has_cont = __any(((w[0].w | w[1].w | w[2].w | w[3].w | w[4].w | w[5].w | w[6].w | w[7].w) & SVT_REC_CONTINUATION) != 0u);
-                    using kind_any = std::integral_constant<int, 0>;
-                    using kind_one = std::integral_constant<int, 1>;
-                    auto run = [&](auto edge_tag, auto kind_tag) {
-                        if (!SSO || MODE == kGeneral || has_cont) consume(w, k, edge_tag, kind_tag, std::true_type{});
-                        else consume(w, k, edge_tag, kind_tag, std::false_type{});
-                    };
-                    if (MODE == kMultiLds && SVT_WINDOW_SINGLE_PATH && (wd.lib_cnt == 1u || SVT_STREAM_PROBE == 5)) {       // (workgroup-uniform; probe 5: timing only)
-                        if (edge) run(std::true_type{}, kind_one{});
-                        else run(std::false_type{}, kind_one{});
-                    } else if (edge) run(std::true_type{}, kind_any{});
-                    else run(std::false_type{}, kind_any{});
+                    continue;
                 }
+                const uint32_t neutral_w = MODE == kMultiLds ? wd.lib_lo << SVT_REC_LIB_SHIFT : 0u;
+                bool edge = __any(k8 < head || k8 + kBlockRecords > last);
+#if SVT_SANITIZE_EDGE
+                if (edge) {
+                    // A slot outside the unit (the neighbours' records in its first / last line, everything past the end of a
+                    // shorter unit; not fetched: it holds older bytes) becomes the neutral record: MAPQ 0 everywhere adds +0.0
+                    // to every sum (prob_mapq(0) == +0.0), no flag, span 0, the window's first library -- it passes the record
+                    // contract and, for the fragment-local sums of the singlesample association, only ever sits in front of the
+                    // unit's first record (all sums still 0) or behind its last one (it does the final flush early).
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const bool mine = k8 + (uint32_t)j - head < n_rec;   // head <= idx < last, unsigned
+                        w[j].x = mine ? w[j].x : 0u;
+                        w[j].y = mine ? w[j].y : 0u;
+                        w[j].z = mine ? w[j].z : 0u;
+                        w[j].w = mine ? w[j].w : neutral_w;
+                    }
+                    edge = false;
+                }
+#endif
+                // sso: a block in which no lane holds a continuation record (nearly all of them: a fragment with a second
+                // split candidate of one kind is rare) takes the select-free form of the fragment-local sums.
+                bool has_cont = false;
+                if (SSO && MODE != kGeneral)
+                    has_cont = __any(((w[0].w | w[1].w | w[2].w | w[3].w | w[4].w | w[5].w | w[6].w | w[7].w) & SVT_REC_CONTINUATION) != 0u);
+#if SVT_SANITIZE_EDGE
+                if (SSO && MODE != kGeneral && has_cont) {
+                    // The rare block with a continuation record goes through ONE rolled-up general consumer that takes its records
+                    // from the ring again, one at a time (the next fetch waits for it).  An unrolled second consumer beside the
+                    // fast one is what made the compiler hoist both consumers' common address arithmetic in front of the branch:
+                    // 32 VGPRs alive across every block, three waves per SIMD instead of four.
+#pragma unroll 1
+                    for (uint32_t j = 0; j < 8u; ++j) {
+                        u32x4 wj = *reinterpret_cast<lds_cu32x4*>((size_t)(lane_block + stage_off + ((j << 4) ^ sw16)));
+                        const bool mine = k8 + j - head < n_rec;
+                        wj.x = mine ? wj.x : 0u;
+                        wj.y = mine ? wj.y : 0u;
+                        wj.z = mine ? wj.z : 0u;
+                        wj.w = mine ? wj.w : neutral_w;
+                        check.see(wj, lib_key);
+                        if (MODE == kSingleLds || (SVT_WINDOW_SINGLE_PATH && wd.lib_cnt == 1u)) record_single<SSO, false, true>(wj, true, sc, acc);
+                        else record_window<SSO, false, true>(wj, true, wc, acc, check);
+                    }
+                    refill();
+                    continue;
+                }
+#endif
+                refill();
+                using kind_any = std::integral_constant<int, 0>;
+                using kind_one = std::integral_constant<int, 1>;
+                auto run = [&](auto edge_tag, auto kind_tag) {
+                    if (!SSO || MODE == kGeneral || has_cont) consume(w, k, edge_tag, kind_tag, std::true_type{});
+                    else consume(w, k, edge_tag, kind_tag, std::false_type{});
+                };
+                if (MODE == kMultiLds && SVT_WINDOW_SINGLE_PATH && (wd.lib_cnt == 1u || SVT_STREAM_PROBE == 5)) {       // (workgroup-uniform; probe 5: timing only)
+                    if (!SVT_SANITIZE_EDGE && edge) run(std::true_type{}, kind_one{});
+                    else run(std::false_type{}, kind_one{});
+                } else if (!SVT_SANITIZE_EDGE && edge) run(std::true_type{}, kind_any{});
+                else run(std::false_type{}, kind_any{});
             }
         }
         if (SSO) {  // flush the last fragment (singlesample.py:370-372)
@@ -641,7 +683,7 @@ __global__ __launch_bounds__(kBlock, MODE == kSingleLds ? SVT_STREAM_WAVES : MOD
             piece[1] = pack2d(acc.alt_clip, acc.ref_span);
             piece[2] = pack2d(acc.alt_span, (double)U.svtype);
         } else
-        unit_epilogue(acc, (uint32_t)U.svtype, (uint32_t)U.flags, a.c, lds_l10, a.l10, a.l10_where != kL10Global, piece);
+        unit_epilogue(acc, (uint32_t)U.svtype, (uint32_t)U.flags, a.c, lds_l10, a.l10, a.l10_lds_entries, piece);
 
         // where the record goes: the unit's own index, or (svt_batch_result_order) the site-major index of a sample-major unit
         uint32_t unit_out = unit;

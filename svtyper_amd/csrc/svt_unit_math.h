@@ -276,13 +276,13 @@ __device__ __forceinline__ uint4 pack2d(double x, double y)
 // ------------------------------------------------------------------------------------------
 // per-unit epilogue: zeroing rules -> QR/QA -> bayes_gt -> GT/GQ/SQ -> the eight 16-byte pieces of the
 // 128-byte result record (classic.py:425-513).  Shared by every genotype kernel, so all device layouts
-// produce the same bits.  The host-built log(i)/log(10) table is read from LDS (l10_lds) or through L2 (l10_global).
+// produce the same bits.  The host-built log(i)/log(10) table is read from LDS (l10_lds: its first l10_lds_entries entries) or through L2 (l10_global).
 // RULES = false / BLANKS = false: the seam form bayesian_genotype(counts) (singlesample.py:406-473), which takes the
 // counts as they are -- its callers apply the zeroing rules and pick the blank result before calling it.
 // ------------------------------------------------------------------------------------------
 template <bool RULES = true, bool BLANKS = true>
 __device__ __forceinline__ void unit_epilogue(const Acc& acc, const uint32_t svtype, const uint32_t uflags, const GtConsts& c,
-                                              const double* l10_lds, const double* __restrict__ l10_global, const bool l10_in_lds,
+                                              const double* l10_lds, const double* __restrict__ l10_global, const uint32_t l10_lds_entries,
                                               uint4 (&piece)[8])
 {
     double ref_seq = acc.ref_seq, alt_seq = acc.alt_seq, alt_clip = acc.alt_clip,
@@ -319,7 +319,9 @@ __device__ __forceinline__ void unit_epilogue(const Acc& acc, const uint32_t svt
         // bayes_gt (statistics.py:23-37)
         const int32_t total = QR + QA;
         double log_combo;
-        if (l10_in_lds) log_combo = log_choose_dev(l10_lds, total, QA);   // two call sites: ds_read vs global_load
+        // two call sites, ds_read vs global_load: log_choose reads l10[1..k] and l10[n-k+1..n], so `total` is the largest index it
+        // touches -- a unit whose counts stay below the part of the table that sits in LDS never leaves it
+        if ((uint32_t)total < l10_lds_entries) log_combo = log_choose_dev(l10_lds, total, QA);
         else log_combo = log_choose_dev(l10_global, total, QA);
 #pragma unroll
         for (int g = 0; g < 3; ++g)

@@ -103,6 +103,7 @@ struct svt_batch {
     uint64_t cap_perm = 0;
     uint32_t n_chunks = 0;
     int window_tiles = 1;            // kMultiLds: 64-unit tiles per wave (chunks hold up to 256 * window_tiles units)
+    int wgs_per_cu = 3;              // workgroups per CU the pass's kernel was budgeted for (registers -> LDS per workgroup)
     StreamArgs sargs{};
     // kLayoutPacked: packed evidence as uploaded (svt_packed_kernel.h); d_records holds the slots, d_soff the 3n+1 offsets
     uint32_t* d_soff = nullptr;
@@ -198,6 +199,10 @@ int tiles_per_wave(const svt_batch* b, uint64_t units)
 }
 
 // one launch of the streaming kernel over units [a.unit_begin, a.unit_end) (not the library-window mode)
+#ifndef SVT_L10_THROUGH_RING
+#define SVT_L10_THROUGH_RING 1   // a log10 table that does not fit beside the tables: 1 = its head through the wave's ring before each epilogue, 0 = all of it through L2
+#endif
+
 int launch_stream(svt_batch* b, StreamArgs& a, hipStream_t stream)
 {
     const uint64_t units = (uint64_t)a.unit_end - a.unit_begin;
@@ -454,7 +459,7 @@ int create_stream(const svt_evidence_batch* in, svt_batch* b, void* d_records_re
 
     // one library whose tables fit beside the rings: tables in LDS, 32-bit index math; anything else reads
     // the tables through L2 with exact 64-bit geometry
-    constexpr size_t kStreamLdsPerWg = (160 * 1024 / 3) & ~size_t(127);   // three workgroups per CU
+    size_t kStreamLdsPerWg = (160 * 1024 / 3) & ~size_t(127);   // three workgroups per CU (refined below: what the kernel's registers allow)
     constexpr size_t kStreamLdsPerWg2 = (160 * 1024 / 2) & ~size_t(127);  // two
     constexpr size_t kLdsBin = 2 * sizeof(uint16_t);   // thr + hist of one bin in LDS: 16-bit ranks
     const size_t single_lds = kSBins + T.bins.size() * kLdsBin;
@@ -508,17 +513,42 @@ int create_stream(const svt_evidence_batch* in, svt_batch* b, void* d_records_re
     a.lds_winlibs = (uint32_t)(kSBins + (((size_t)a.lds_bins * kLdsBin + 15) & ~size_t(15)));   // (WinLib is read as 16-byte halves)
     size_t tables = a.lds_winlibs + (size_t)a.lds_libs * sizeof(LibDesc) + (windowed ? (size_t)max_win_libs * sizeof(WinLib) : 0);
     tables = (tables + 127) & ~size_t(127);
-    // the log10 table of the epilogue: beside the tables while three workgroups still fit a CU's 160 KB,
-    // else through the wave's ring, else through L2
+    // How many workgroups of this batch's kernel a CU can hold is decided by its registers (512 per SIMD lane: <= 128 VGPRs
+    // = four waves per SIMD = four 256-thread workgroups per CU); the LDS budget per workgroup follows from that, so that
+    // the tables never cost a workgroup the registers would allow.
+    {
+        int wgs = 3;
+        hipFuncAttributes fa{};
+        if (hipFuncGetAttributes(&fa, stream_kernel_of(b, b->mode == kMultiLds ? b->window_tiles : tiles_per_wave(b, n))) == hipSuccess && fa.numRegs > 0)
+            wgs = std::max(1, std::min(8, 512 / ((fa.numRegs + 7) / 8 * 8)));
+        else
+            (void)hipGetLastError();
+        if (const char* e = std::getenv("SVT_STREAM_WGS_PER_CU")) wgs = std::max(1, std::atoi(e));   // (measurements)
+#ifdef SVT_FORCE_WGS
+        wgs = SVT_FORCE_WGS;
+#endif
+        kStreamLdsPerWg = (160 * 1024 / (size_t)wgs) & ~size_t(127);
+        b->wgs_per_cu = wgs;
+    }
+    // the log10 table of the epilogue: beside the tables when it costs no workgroup -- `fit` = what registers AND the
+    // tables + rings allow --, else its first ring-stageful of entries through the wave's ring before each epilogue (a unit
+    // whose read count reaches beyond them takes the table through L2), else through L2
     const size_t l10_bytes = ((size_t)n_l10 * 8 + 127) & ~size_t(127);
-    const size_t with_l10 = tables + l10_bytes + kWavesPerBlock * kStreamRingBytes;
-    // (a window that already costs the third workgroup keeps the table too as long as two still fit)
-    if (with_l10 <= kStreamLdsPerWg || (tables + kWavesPerBlock * kStreamRingBytes > kStreamLdsPerWg && with_l10 <= kStreamLdsPerWg2)) {
+    const size_t base_lds = tables + kWavesPerBlock * kStreamRingBytes;
+    const size_t fit = std::max<size_t>(1, std::min<size_t>((size_t)b->wgs_per_cu, (160 * 1024) / base_lds));
+    const size_t budget = ((160 * 1024) / fit) & ~size_t(127);
+    (void)kStreamLdsPerWg;
+    if (base_lds + l10_bytes <= budget) {
         a.l10_where = kL10Shared;
         a.lds_l10 = (uint32_t)tables;
+        a.l10_lds_entries = n_l10;
         tables += l10_bytes;
+    } else if (kStreamDepth == 1 && SVT_L10_THROUGH_RING) {
+        a.l10_where = kL10Ring;
+        a.l10_lds_entries = (uint32_t)std::min<uint64_t>((n_l10 + 127u) / 128u * 128u, kStreamRingBytes / 8);   // (whole KiB move)
     } else {
-        a.l10_where = (uint64_t)n_l10 * 8 <= kStreamRingBytes ? kL10Ring : kL10Global;
+        a.l10_where = kL10Global;
+        a.l10_lds_entries = 0;
     }
     a.lds_rings = (uint32_t)tables;
     a.n_units = n;
@@ -531,6 +561,10 @@ int create_stream(const svt_evidence_batch* in, svt_batch* b, void* d_records_re
     b->out_dev = b->d_out;   // svt_batch_device_results / svt_batch_bind_device_results / svt_batch_site_qual
     b->lds_bytes = tables + kWavesPerBlock * kStreamRingBytes + SVT_PROBE_LDS_PAD;
     if (b->lds_bytes > 160 * 1024) return fail(SVT_ERR_INVALID, "LDS budget exceeded");
+    if (tm.on)
+        std::fprintf(stderr, "[svt] kernel budget: %d workgroups/CU by registers, LDS %zu B/workgroup (%zu fit), log10 table (%u entries) %s (%u entries)\n",
+                     b->wgs_per_cu, b->lds_bytes, (size_t)(160 * 1024) / std::max<size_t>(b->lds_bytes, 1), n_l10,
+                     a.l10_where == kL10Shared ? "in LDS" : a.l10_where == kL10Ring ? "through the ring" : "through L2", a.l10_lds_entries);
     if (b->lds_bytes > 64 * 1024)
         for (int tiles = 1; tiles <= 2; ++tiles)
             if (b->mode != kGeneral || tiles == 1)
@@ -782,6 +816,10 @@ int create_packed(const svt_packed_evidence* in, svt_batch* b, bool defer_slots 
     b->out_dev = b->d_out;
     b->lds_bytes = tables + kWavesPerBlock * kRingBytes;
     if (b->lds_bytes > 160 * 1024) return fail(SVT_ERR_INVALID, "LDS budget exceeded");
+    if (tm.on)
+        std::fprintf(stderr, "[svt] kernel budget: %d workgroups/CU by registers, LDS %zu B/workgroup (%zu fit), log10 table %s\n", b->wgs_per_cu,
+                     b->lds_bytes, (size_t)(160 * 1024) / std::max<size_t>(b->lds_bytes, 1),
+                     a.l10_where == kL10Shared ? "in LDS" : a.l10_where == kL10Ring ? "through the ring" : "through L2");
     if (b->lds_bytes > 64 * 1024) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&svt_packed_kernel<true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_bytes));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&svt_packed_kernel<false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_bytes));
@@ -1428,6 +1466,76 @@ int svt_genotype_packed(const svt_packed_evidence* in, svt_result* out, int devi
 void* svt_batch_stream(svt_batch* b) { return b ? (void*)b->stream : nullptr; }
 
 void svt_batch_destroy(svt_batch* b) { free_batch(b); }
+
+// ---- measurement hooks (tools/placement_sweep.py; not part of include/svtyper_hip.h): where a batch's records and result
+// records lie in HBM decides a few per cent of the pass; these let a tool place them itself.
+// `chunk_bytes` = 0: one hipMalloc; else one virtual range over physical chunks of that size (hipMemCreate / hipMemMap).
+extern "C" int svt_debug_device_alloc(int device, uint64_t bytes, uint64_t chunk_bytes, void** out)
+{
+    return guarded([&]() -> int {
+        if (!out) return fail(SVT_ERR_INVALID, "null argument");
+        HIP_TRY(hipSetDevice(device));
+        if (chunk_bytes) {
+            uint64_t cap = 0;
+            if (!g_pool.alloc_chunked(device, bytes, out, &cap, chunk_bytes)) return fail(SVT_ERR_HIP, "virtual-memory allocation failed");
+            return SVT_OK;
+        }
+        HIP_TRY(hipMalloc(out, bytes));
+        return SVT_OK;
+    });
+}
+
+extern "C" int svt_debug_device_free(int device, void* p)
+{
+    return guarded([&]() -> int {
+        if (p) g_pool.release(p, device);
+        return SVT_OK;
+    });
+}
+
+extern "C" int svt_debug_memset(int device, void* p, int value, uint64_t bytes)
+{
+    return guarded([&]() -> int {
+        HIP_TRY(hipSetDevice(device));
+        HIP_TRY(hipMemset(p, value, bytes));
+        HIP_TRY(hipDeviceSynchronize());
+        return SVT_OK;
+    });
+}
+
+// the batch streams its records from `dev` (they are copied there; the buffer must hold svt_debug_record_bytes(b) bytes, 128-byte aligned)
+extern "C" uint64_t svt_debug_record_bytes(const svt_batch* b)
+{
+    return b && b->layout == kLayoutStream ? ((uint64_t)b->sargs.last_blk + 1) * 128 : 0;
+}
+
+extern "C" void* svt_debug_records_ptr(const svt_batch* b) { return b ? const_cast<void*>(static_cast<const void*>(b->sargs.records)) : nullptr; }
+
+extern "C" int svt_debug_bind_records(svt_batch* b, void* dev)
+{
+    return guarded([&]() -> int {
+        if (!b || b->layout != kLayoutStream) return fail(SVT_ERR_INVALID, "canonical records only");
+        if (dev && (reinterpret_cast<uintptr_t>(dev) & 127u)) return fail(SVT_ERR_INVALID, "record buffer must be 128-byte aligned");
+        HIP_TRY(hipSetDevice(b->device));
+        HIP_TRY(hipStreamSynchronize(b->stream));
+        if (dev) {
+            HIP_TRY(hipMemcpyAsync(dev, b->d_records, svt_debug_record_bytes(b), hipMemcpyDeviceToDevice, b->stream));
+            HIP_TRY(hipStreamSynchronize(b->stream));
+            // (the copy is checked at both ends: a mapping that silently did not take would otherwise look like bad records)
+            const uint64_t total = svt_debug_record_bytes(b), probe = std::min<uint64_t>(total, 4096);
+            std::vector<unsigned char> x(probe), y(probe);
+            for (uint64_t at : {uint64_t(0), total - probe}) {
+                HIP_TRY(hipMemcpy(x.data(), static_cast<const char*>(b->d_records) + at, probe, hipMemcpyDeviceToHost));
+                HIP_TRY(hipMemcpy(y.data(), static_cast<const char*>(dev) + at, probe, hipMemcpyDeviceToHost));
+                if (std::memcmp(x.data(), y.data(), probe) != 0) return fail(SVT_ERR_HIP, "svt_debug_bind_records: the copy did not arrive");
+            }
+        }
+        HIP_TRY(hipStreamSynchronize(b->stream));
+        b->sargs.records = static_cast<const uint4*>(dev ? dev : b->d_records);
+        b->have_results = false;
+        return SVT_OK;
+    });
+}
 
 void svt_trim(void)
 {
