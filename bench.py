@@ -191,7 +191,7 @@ def cpu_model() -> str:
     return "unknown"
 
 
-LEGS = ("sso", "c5", "c5x", "shard", "one_shot", "packed", "large", "real")   # c5x: the c5 leg's comparison launches (site-major input, no hints)
+LEGS = ("sso", "r96", "c5", "c5x", "shard", "one_shot", "packed", "large", "real")   # c5x: the c5 leg's comparison launches (site-major input, no hints)
 
 
 def roofline_of(kernel_ms: float, alg_bytes: int, key: str, n_units: int, n_records: int) -> dict:
@@ -200,6 +200,7 @@ def roofline_of(kernel_ms: float, alg_bytes: int, key: str, n_units: int, n_reco
     traffic, note = measured_traffic(key, n_units, n_records)
     return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
             "traffic_unit": "bytes per launch", "traffic_source": note,
+            "traffic_kind": "committed PMC profile of these kernel sources (rocprofv3 cannot wrap this run from inside), not a measurement of this run",
             "traffic_over_algorithmic": (traffic / alg_bytes) if traffic else None,
             "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": kernel_ms}
 
@@ -406,6 +407,10 @@ def main():
     ap.add_argument("--workload", default="c3_mixed_1m", choices=["c3_mixed_1m", "c2_del_100k", "c5_multisample"])
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--sso", action="store_true", help="singlesample.py floating-point association")
+    ap.add_argument("--result-bytes", type=int, default=128, choices=[96, 128],
+                    help="device result record: 128 = svt_result, one full cache line per unit; 96 = SVT_FLAG_RESULT96, the record of SURVEY "
+                         "8(d) (the host restores the counts that follow from the tallies: same svt_result records on the host) -- a quarter "
+                         "fewer bytes written and gathered, but part-line writes: the pass itself is 3-4 %% SLOWER (`result96` leg) [128]")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true", help="headline only (N=1: no sso / c5 / shard / one_shot / packed / large legs)")
     ap.add_argument("--legs", default="all", help="comma list of the extra N=1 legs to run: " + ",".join(LEGS) + " [all]")
@@ -504,7 +509,8 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
     coll_device = "cuda" if backend == "nccl" else "cpu"   # where the collectives' tensors live
 
-    sso = ev.FLAG_SSO_ASSOCIATION if args.sso else 0
+    r96 = ev.FLAG_RESULT96 if args.result_bytes == 96 else 0
+    sso = (ev.FLAG_SSO_ASSOCIATION if args.sso else 0) | r96      # (every leg's create flags carry the record form)
     flags = sso
     t0 = time.time()
     dbatch = hip.DeviceBatch(batch, device=local_rank, flags=flags)
@@ -516,8 +522,9 @@ def main():
     # the batch's own result buffer as a torch tensor (zero-copy view): the final RCCL gather needs no extra copy, and the
     # result records stay where svt_batch_create put them (binding a tensor torch allocated costs 3-6 % of the pass: DESIGN.md 3.1)
     res_buf = dbatch.device_results_tensor()
-    assert res_buf.data_ptr() % 128 == 0 and res_buf.numel() >= n * ev.RESULT_DTYPE.itemsize
-    cur = n * ev.RESULT_DTYPE.itemsize
+    rec_bytes = dbatch.result_bytes()
+    assert rec_bytes == args.result_bytes and res_buf.data_ptr() % 128 == 0 and res_buf.numel() >= n * rec_bytes
+    cur = n * rec_bytes
 
     def barrier():
         if use_dist:
@@ -558,14 +565,14 @@ def main():
         torch.cuda.synchronize()
         g0 = time.perf_counter()
         # (ranks sharing a device: the records come down to the host first and travel over gloo)
-        gathered = D.gather_result_records(res_buf[:cur] if backend == "nccl" else res_buf[:cur].cpu(), counts, dst=0)
+        gathered = D.gather_result_records(res_buf[:cur] if backend == "nccl" else res_buf[:cur].cpu(), counts, dst=0, rec_bytes=rec_bytes)
         torch.cuda.synchronize()
         barrier()
         g_s = time.perf_counter() - g0
         if rank == 0:
-            assert gathered.numel() == sum(counts) * ev.RESULT_DTYPE.itemsize
-        gather = {"bytes_per_rank": int(cur), "ms": g_s * 1e3,
-                  "GB/s_into_root": sum(counts[1:] or counts) * ev.RESULT_DTYPE.itemsize / g_s / 1e9,
+            assert gathered.numel() == sum(counts) * rec_bytes
+        gather = {"bytes_per_rank": int(cur), "record_bytes": rec_bytes, "ms": g_s * 1e3,
+                  "GB/s_into_root": sum(counts[1:] or counts) * rec_bytes / g_s / 1e9,
                   "collective": "rccl gather" if backend == "nccl" else "gloo gather (ranks share %d device(s))" % n_dev,
                   "backend": backend, "units_per_rank": counts,
                   # how many ranks the RCCL communicator of this run actually spanned (0: no RCCL in this run)
@@ -575,7 +582,7 @@ def main():
             with hip.DeviceBatch(total, device=local_rank, flags=flags) as d_all:
                 d_all.genotype(sync=True)
                 alone = d_all.results().rec
-            same = bool(np.array_equal(D.results_from_bytes(gathered).rec, alone))
+            same = bool(np.array_equal(D.results_from_bytes(gathered, rec_bytes).rec, alone))
             gather["equals_single_rank_pass"] = same
             assert same, "the gathered result records differ from the single-rank pass over the same workload"
             del alone
@@ -615,6 +622,7 @@ def main():
                 "records_per_gpu": batch.n_records,
                 "total_units": total_units,
                 "association": "sso" if args.sso else "classic",
+                "device_result_record_bytes": rec_bytes,
                 "step": "one launch of svt_stream_kernel over the canonical CSR records resident in HBM -> result records "
                         "in HBM (whole hot path; nothing pre-digested outside the timed region)",
                 "device_layout": "the canonical CSR records as uploaded, streamed by the pass itself",
@@ -690,7 +698,7 @@ def main():
                     "serial_wall_ms": serial * 1e3,
                     "serial_create_ms": parts[0] * 1e3, "serial_pass_ms": parts[1] * 1e3, "serial_results_d2h_ms": parts[2] * 1e3,
                     "pcie_inclusive_breakpoints_per_s": n / best,
-                    "h2d_bytes": int(16 * batch.n_records + 24 * n + 8), "d2h_bytes": int(128 * n),
+                    "h2d_bytes": int(16 * batch.n_records + 24 * n + 8), "d2h_bytes": int(rec_bytes * n),
                 }
                 assert np.array_equal(r1.rec, got.rec), "one-shot results differ from the resident batch's"
                 dbatch = hip.DeviceBatch(batch, device=local_rank, flags=flags)
@@ -776,7 +784,7 @@ def main():
                         "pack_inclusive_wall_ms": pack_ms + best * 1e3,
                         "pack_inclusive_breakpoints_per_s": n / (pack_ms * 1e-3 + best),
                         "pcie_inclusive_breakpoints_per_s": n / best,
-                        "h2d_bytes": packed.nbytes, "d2h_bytes": int(128 * n),
+                        "h2d_bytes": packed.nbytes, "d2h_bytes": int(rec_bytes * n),
                         "bytes_per_fragment_record": packed.nbytes / max(1, batch.n_records),
                         "resident_pass_ms": p_ms, "resident_breakpoints_per_s_pass_only": n / (p_ms * 1e-3),
                         "results_equal_headline": bool(np.array_equal(rp.rec, got.rec)),
@@ -792,20 +800,21 @@ def main():
             sample_n = n
             sample = batch.slice(0, sample_n)
             threads = min(c_oracle.max_threads(), n_cpu)   # more threads than the CPU quota only get throttled
-            want = c_oracle.genotype_batch(sample, flags=sso, n_threads=threads)   # warm-up + parity reference
+            o_flags = sso & ev.FLAG_SSO_ASSOCIATION
+            want = c_oracle.genotype_batch(sample, flags=o_flags, n_threads=threads)   # warm-up + parity reference
             t0 = time.perf_counter()
             reps = 0
             while True:
-                c_oracle.genotype_batch(sample, flags=sso, n_threads=threads, out=want)
+                c_oracle.genotype_batch(sample, flags=o_flags, n_threads=threads, out=want)
                 reps += 1
                 if time.perf_counter() - t0 >= args.cpu_seconds or reps >= 50:
                     break
             cpu_s = time.perf_counter() - t0
             n1 = min(sample_n, 200_000)               # the same restatement on one thread, bounded slice
             one = batch.slice(0, n1)
-            c_oracle.genotype_batch(one, flags=sso, n_threads=1)
+            c_oracle.genotype_batch(one, flags=o_flags, n_threads=1)
             t0 = time.perf_counter()
-            c_oracle.genotype_batch(one, flags=sso, n_threads=1)
+            c_oracle.genotype_batch(one, flags=o_flags, n_threads=1)
             one_thread = n1 / (time.perf_counter() - t0)
             out["cpu_baseline"] = {
                 "value": sample_n * reps / cpu_s,
@@ -825,11 +834,11 @@ def main():
                 from oracle import py_oracle
                 n1 = min(n, 6000)
                 t0 = time.perf_counter()
-                py_oracle.genotype_batch(batch.slice(0, n1), sso)
+                py_oracle.genotype_batch(batch.slice(0, n1), o_flags)
                 one = n1 / (time.perf_counter() - t0)
                 npool = min(n, 2000 * threads)
                 t0 = time.perf_counter()
-                py_oracle.genotype_batch_pool(batch.slice(0, npool), sso, processes=threads, batch_size=1000)
+                py_oracle.genotype_batch_pool(batch.slice(0, npool), o_flags, processes=threads, batch_size=1000)
                 pool = npool / (time.perf_counter() - t0)
                 out["cpu_baseline_python"] = {
                     "kind": "port", "unit": "breakpoints/s", "one_process": one, "pool": pool, "cores": threads,
@@ -848,7 +857,7 @@ def main():
         if "sso" in legs and not args.sso:
             # ---- the same launch with the singlesample association of the split-read sums (svtyper/singlesample.py:246-276,367-372)
             try:
-                with hip.DeviceBatch(batch, device=local_rank, flags=ev.FLAG_SSO_ASSOCIATION) as ds:
+                with hip.DeviceBatch(batch, device=local_rank, flags=ev.FLAG_SSO_ASSOCIATION | r96) as ds:
                     ds.genotype(sync=True)
                     s_ms = time_passes(ds, args.steps)
                     s_alg, _ = ds.bytes()
@@ -857,6 +866,22 @@ def main():
                                   kernel="svt_stream_kernel<sso>", units=n, breakpoints_per_s=n / (s_ms * 1e-3))
             except Exception as e:
                 out["sso"] = {"error": repr(e)}
+
+        if "r96" in legs and not r96:
+            # ---- the same launch writing the 96-byte record of SURVEY 8(d) (SVT_FLAG_RESULT96): 25 % fewer bytes written, but a
+            # unit's record is then three 32-byte sectors of a line it shares with its neighbours, which other waves write at other times
+            try:
+                with hip.DeviceBatch(batch, device=local_rank, flags=flags | ev.FLAG_RESULT96) as d9:
+                    d9.genotype(sync=True)
+                    same = bool(np.array_equal(d9.results().rec, got.rec))
+                    r_ms = time_passes(d9, args.steps)
+                out["result96"] = {"what": "the headline's launch with SVT_FLAG_RESULT96: 96-byte device records, host results restored by svt_results_expand96",
+                                   "kernel_ms": r_ms, "frac": alg_bytes / (r_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "device_record_bytes": 96,
+                                   "bytes_written_per_launch": 96 * n, "host_results_equal_headline": same,
+                                   "note": "fewer bytes, slower pass (part-line writes): in-process A/B over the same buffers 0.3353 vs 0.3211 ms "
+                                           "(profiles/r04_ab_inproc_result96.txt); the flag pays where the records cross PCIe or xGMI, not in the pass"}
+            except Exception as e:
+                out["result96"] = {"error": repr(e)}
 
         if c5_sample_major is not None:
             # ---- BASELINE.json configs[4] shape at its per-GPU size: (site, sample) units, 32 samples, per-sample libraries.

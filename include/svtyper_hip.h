@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SVT_ABI_VERSION 12
+#define SVT_ABI_VERSION 13
 
 /* ---- error codes (0 = ok, <0 = error; text via svt_last_error()) ---------- */
 #define SVT_OK 0
@@ -65,6 +65,13 @@ extern "C" {
  * arithmetic) even where a workgroup could stage its libraries' histograms in LDS -- one library or many: for
  * measurements and for tests that compare the table paths.  Results are the same.                              */
 #define SVT_FLAG_GENERAL_TABLES 0x10u
+/* the pass writes 96-byte result records on the device (svt_result96: the record of SURVEY.md section 8(d) -- GL, SQ, the
+ * five tallies, QR / QA / GQ, GT) instead of 128-byte ones: a quarter fewer bytes written per unit and moved by the final
+ * gather.  The eight counts it leaves out are truncations of sums of the tallies (classic.py:455-469) and are restored
+ * on the host: svt_batch_results / svt_genotype still fill svt_result[n_units], bit for bit the same; only a caller that
+ * reads the DEVICE records itself (svt_batch_device_results, svt_batch_bind_device_results, the RCCL gather) sees the
+ * 96-byte form -- svt_batch_result_bytes tells which -- and expands gathered records with svt_results_expand96.   */
+#define SVT_FLAG_RESULT96 0x20u
 /* (bits 1..3 selected round 1's tiled device layouts, which are gone: they are rejected as unknown bits.)
  * Device layout of a resident batch: nothing is re-tiled or re-encoded -- the CSR arrays go to HBM as the
  * caller packed them and ONE kernel (svt_stream_kernel) takes them to the result records, streaming every
@@ -274,6 +281,17 @@ typedef struct svt_result {
     uint8_t pad[11];              /* zero                                                      */
 } svt_result;
 
+/* ---- the same record without the counts that follow from the tallies, 96 B (SVT_FLAG_RESULT96): bytes 0..83 are
+ * bytes 0..83 of svt_result (gl, sq, tallies, QR, QA, GQ), byte 84 is gt ------------------------------------------ */
+typedef struct svt_result96 {
+    double gl[3];
+    double sq;
+    double tallies[SVT_N_TALLIES];
+    int32_t qr, qa, gq;           /* counts[SVT_CNT_QR], counts[SVT_CNT_QA], counts[SVT_CNT_GQ] */
+    int8_t gt;
+    uint8_t pad[11];              /* zero                                                      */
+} svt_result96;
+
 typedef struct svt_batch svt_batch; /* opaque: device-resident packed batch */
 
 /* ---- entry points ---------------------------------------------------------- */
@@ -318,10 +336,19 @@ int svt_batch_results(svt_batch* b, svt_result* out, uint64_t n_units);
 int svt_batch_device_results(svt_batch* b, svt_result** dev_ptr);
 
 /* Make the kernel write its result records straight into a caller-owned DEVICE buffer of
- * n_units * sizeof(svt_result) bytes, 128-byte aligned (e.g. a torch tensor that is then
+ * n_units * svt_batch_result_bytes(b) bytes, 128-byte aligned (e.g. a torch tensor that is then
  * gathered over RCCL).  The buffer must stay alive until svt_batch_destroy or the next bind;
  * pass NULL to return to the library's own buffer.                                         */
 int svt_batch_bind_device_results(svt_batch* b, svt_result* dev_ptr);
+
+/* Bytes of one DEVICE result record of this batch: sizeof(svt_result), or sizeof(svt_result96) under SVT_FLAG_RESULT96
+ * (what svt_batch_device_results points at, what a buffer for svt_batch_bind_device_results must hold per unit). */
+uint32_t svt_batch_result_bytes(const svt_batch* b);
+
+/* 96-byte records (host memory; e.g. gathered from several devices) -> svt_result[n]: DP, RO, AO, RS, AS, ASC, RP, AP are
+ * the reference's own expressions over the tallies (classic.py:455-469: int() of the sums, in its order of additions),
+ * zero for blank / skipped units as the 128-byte path leaves them.  Host only, no device needed.  `in` and `out` may not overlap. */
+int svt_results_expand96(const svt_result96* in, uint64_t n_units, svt_result* out);
 
 /* Result order for a SAMPLE-MAJOR batch.  A joint run over several samples has one unit per (site, sample).  The
  * reference walks them site-major (classic.py:279: for every variant, for every sample), and that is the order

@@ -53,18 +53,20 @@ __global__ __launch_bounds__(kBlock) void svt_counts_kernel(const double* __rest
 // order, reset to 0 by a sample without evidence, untouched by a skipped or './.' sample.  One site
 // per thread, samples in order; units are site-major (unit = site * n_samples + sample).
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void svt_site_qual_kernel(const svt_result* __restrict__ res, uint32_t n_samples,
-                                                               const double* __restrict__ initial,
+// `res`: result records of `stride` bytes (svt_result, or svt_result96 under SVT_FLAG_RESULT96: SQ sits at the same offset in both,
+// GT at `gt_at`)
+__global__ __launch_bounds__(kBlock) void svt_site_qual_kernel(const unsigned char* __restrict__ res, uint32_t stride, uint32_t gt_at,
+                                                               uint32_t n_samples, const double* __restrict__ initial,
                                                                double* __restrict__ qual, uint64_t n_sites)
 {
     const uint64_t site = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
     if (site >= n_sites) return;
     double q = initial ? initial[site] : 0.0;
-    const svt_result* r = res + site * n_samples;
-    for (uint32_t s = 0; s < n_samples; ++s) {
-        const int gt = r[s].gt;
-        if (gt >= 0) q += r[s].sq;                   // classic.py:485
-        else if (gt == SVT_GT_BLANK) q = 0.0;        // classic.py:498
+    const unsigned char* r = res + site * n_samples * stride;
+    for (uint32_t s = 0; s < n_samples; ++s, r += stride) {
+        const int gt = *reinterpret_cast<const int8_t*>(r + gt_at);
+        if (gt >= 0) q += *reinterpret_cast<const double*>(r + offsetof(svt_result, sq));   // classic.py:485
+        else if (gt == SVT_GT_BLANK) q = 0.0;                                               // classic.py:498
     }
     qual[site] = q;
 }

@@ -261,6 +261,42 @@ __device__ __forceinline__ void store_results_through_ring(unsigned char* ring, 
     }
 }
 
+#ifndef SVT_STORE_UNROLL
+#define SVT_STORE_UNROLL 2
+#endif
+#ifndef SVT_STORE_BARRIER
+#define SVT_STORE_BARRIER 0
+#endif
+// One routine for both result record forms -- 128-byte svt_result (P = 8 sixteen-byte pieces) and the 96-byte svt_result96 of
+// SVT_FLAG_RESULT96 (P = 6: GL, SQ, the five tallies, QR / QA / GQ, GT; the other counts follow from the tallies on the host,
+// svt_results_expand96) -- with P a wave-uniform run-time value: two specialised routines behind a branch made the compiler
+// hoist their common parts in front of it and cost the kernel 30 VGPRs.  The P pieces of a unit leave through P consecutive
+// lanes, 64 units in P store instructions; a 96-byte record starts on a 32-byte boundary, so whole 32-byte sectors are written.
+__device__ __forceinline__ void store_result_records_through_ring(unsigned char* ring, const uint4 (&piece)[8], const uint32_t unit,
+                                                                  const uint32_t lane, unsigned char* __restrict__ out, const uint32_t P)
+{
+    const uint32_t sw = (lane >> 1) & 7u;
+    uint4* st = reinterpret_cast<uint4*>(ring + lane * 128u);
+#pragma unroll
+    for (int p = 0; p < 8; ++p) st[(uint32_t)p ^ sw] = piece[p];
+    const uint32_t stride = P * 16u;
+#if SVT_STORE_UNROLL == 8
+#pragma unroll
+#elif SVT_STORE_UNROLL == 1
+#pragma unroll 1
+#else
+#pragma unroll 2
+#endif
+    for (int i = 0; i < 8; ++i) {
+        if ((uint32_t)i >= P) break;                       // (wave-uniform)
+        if (SVT_STORE_BARRIER) __builtin_amdgcn_sched_barrier(0);
+        const uint32_t idx = (uint32_t)i * kWave + lane, u = P == 8u ? idx >> 3 : idx / 6u, p = idx - u * P;
+        const uint32_t dst_unit = (uint32_t)__shfl((int)unit, (int)u, kWave);
+        const uint4 v = *reinterpret_cast<const uint4*>(ring + u * 128u + ((p ^ ((u >> 1) & 7u)) << 4));
+        if (dst_unit != kPadUnit) store_piece(reinterpret_cast<uint4*>(out + (uint64_t)dst_unit * stride) + p, v);
+    }
+}
+
 }  // namespace svt
 
 #endif  // SVT_RING_ENGINE_H

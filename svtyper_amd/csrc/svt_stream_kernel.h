@@ -73,6 +73,9 @@
 #define SVT_STREAM_WAVES 3 // waves per SIMD the register allocation must allow (three workgroups per CU)
 #endif
 
+#ifndef SVT_STORE_SPECIAL128
+#define SVT_STORE_SPECIAL128 0 // (1 costs the one-library kernel its fourth wave: 129 VGPRs) 1: 128-byte records leave through the unrolled routine with precomputed columns, 96-byte ones through the rolled-up general one
+#endif
 #ifndef SVT_SANITIZE_EDGE
 #define SVT_SANITIZE_EDGE 1 // edge blocks: the slots that are not the lane's become neutral (all-zero) records and the block takes the
                             // interior consumer -- ONE consumer instance per kernel instead of an edge / interior pair whose common
@@ -133,6 +136,7 @@ struct StreamArgs {
     uint32_t lds_winlibs;        // byte offset of the WinLib descriptors (after the bins)
     uint32_t unit_begin;         // this launch covers units [unit_begin, unit_end) (the pipelined one-shot launches
     uint32_t unit_end;           // one range per uploaded piece; a pass over a resident batch: [0, n_units))
+    uint32_t result96;           // SVT_FLAG_RESULT96: `out` holds 96-byte records (svt_result96)
     uint32_t out_samples;        // svt_batch_result_order: > 1 = the units are sample-major (unit = sample * out_sites + site) and the
     uint32_t out_sites;          // result record of a unit goes to index site * out_samples + sample (site-major); 0 = unit order
     LibDesc lib0;
@@ -691,8 +695,22 @@ __global__ __launch_bounds__(kBlock, MODE == kSingleLds ? SVT_STREAM_WAVES : MOD
             const uint32_t sample = unit / a.out_sites;
             unit_out = (unit - sample * a.out_sites) * a.out_samples + sample;
         }
-        if (!(SVT_PROBE_SKIP & 2)) store_results_through_ring(ring, piece, unit_out, lane, a.out);
-        else if (piece[0].x == 0x12345u && piece[2].y == 77u) a.out[unit].sq = 1.0;
+        if (!(SVT_PROBE_SKIP & 2)) {
+#if SVT_STORE_DIRECT
+            store_results_through_ring(ring, piece, unit_out, lane, a.out);
+#else
+            // svt_result96: GL, SQ, tallies, QR, QA | GQ, GT -- pieces 0-4 as they are, piece 5 = {GQ, GT, 0, 0}
+#if SVT_STORE_SPECIAL128
+            if (a.result96) {
+                piece[5] = make_uint4(piece[5].x, piece[7].y, 0u, 0u);
+                store_result_records_through_ring(ring, piece, unit_out, lane, reinterpret_cast<unsigned char*>(a.out), 6u);
+            } else store_results_through_ring(ring, piece, unit_out, lane, a.out);
+#else
+            if (a.result96) piece[5] = make_uint4(piece[5].x, piece[7].y, 0u, 0u);
+            store_result_records_through_ring(ring, piece, unit_out, lane, reinterpret_cast<unsigned char*>(a.out), a.result96 ? 6u : 8u);
+#endif
+#endif
+        } else if (piece[0].x == 0x12345u && piece[2].y == 77u) a.out[unit].sq = 1.0;
     }
     const uint32_t bad = check.bits(MODE == kMultiLds ? wd.lib_cnt : a.n_libs);
     if (bad && SVT_STREAM_PROBE != 2) atomicOr(a.err, bad);   // (probe 2 consumes whatever the ring holds)

@@ -71,7 +71,7 @@ using namespace svt;
 // ------------------------------------------------------------------------------------------
 // batch object
 // ------------------------------------------------------------------------------------------
-constexpr unsigned kKnownFlags = SVT_FLAG_SSO_ASSOCIATION | SVT_FLAG_GENERAL_TABLES;
+constexpr unsigned kKnownFlags = SVT_FLAG_SSO_ASSOCIATION | SVT_FLAG_GENERAL_TABLES | SVT_FLAG_RESULT96;
 
 struct svt_batch {
     int device = 0;
@@ -200,7 +200,8 @@ int tiles_per_wave(const svt_batch* b, uint64_t units)
 
 // one launch of the streaming kernel over units [a.unit_begin, a.unit_end) (not the library-window mode)
 #ifndef SVT_L10_THROUGH_RING
-#define SVT_L10_THROUGH_RING 1   // a log10 table that does not fit beside the tables: 1 = its head through the wave's ring before each epilogue, 0 = all of it through L2
+#define SVT_L10_THROUGH_RING 0   // (in-process A/B, one-library pass with four workgroups per CU: through L2 0.3181 ms, head through the ring 0.3281)
+//  a log10 table that does not fit beside the tables: 1 = its head through the wave's ring before each epilogue, 0 = all of it through L2
 #endif
 
 int launch_stream(svt_batch* b, StreamArgs& a, hipStream_t stream)
@@ -555,6 +556,7 @@ int create_stream(const svt_evidence_batch* in, svt_batch* b, void* d_records_re
     a.unit_begin = 0;
     a.unit_end = (uint32_t)n;
     a.out = b->d_out;
+    a.result96 = (b->flags & SVT_FLAG_RESULT96) ? 1u : 0u;
     a.err = b->d_err;
     a.lib0 = T.libs[0];
     fill_gt_consts(a.c, in->split_weight, in->disc_weight);
@@ -811,6 +813,7 @@ int create_packed(const svt_packed_evidence* in, svt_batch* b, bool defer_slots 
     a.unit_begin = 0;
     a.unit_end = (uint32_t)n;
     a.out = b->d_out;
+    a.result96 = (b->flags & SVT_FLAG_RESULT96) ? 1u : 0u;
     a.lib0 = T.libs[0];
     fill_gt_consts(a.c, in->split_weight, in->disc_weight);
     b->out_dev = b->d_out;
@@ -854,6 +857,87 @@ struct PipeStreams {
     }
 };
 
+
+// ---- SVT_FLAG_RESULT96: 96-byte device records -> the caller's svt_result[] -----------------------------------------
+static_assert(sizeof(svt_result96) == 96 && sizeof(svt_result) == 128, "result record sizes");
+static_assert(offsetof(svt_result96, qr) == offsetof(svt_result, counts) && offsetof(svt_result96, gt) == 84, "svt_result96 is a prefix of svt_result + gt");
+
+inline uint32_t result_bytes(const svt_batch* b) { return (b->flags & SVT_FLAG_RESULT96) ? (uint32_t)sizeof(svt_result96) : (uint32_t)sizeof(svt_result); }
+
+// one record: the counts that are not in the 96-byte form are the reference's truncations of sums of the tallies
+// (classic.py:455-469; the additions in its order, -ffp-contract=off on the host as on the device), 0 for blank / skipped units
+inline void expand96_one(const svt_result96& r, svt_result& o)
+{
+    std::memcpy(&o, &r, 84);                     // gl, sq, tallies, QR, QA, GQ
+    const double ref_seq = r.tallies[SVT_TAL_REF_SEQ], alt_seq = r.tallies[SVT_TAL_ALT_SEQ], alt_clip = r.tallies[SVT_TAL_ALT_CLIP],
+                 ref_span = r.tallies[SVT_TAL_REF_SPAN], alt_span = r.tallies[SVT_TAL_ALT_SPAN];
+    const bool counted = r.gt >= 0 || r.gt == SVT_GT_MISSING;   // (a blank or skipped unit leaves every count 0)
+    o.counts[SVT_CNT_DP] = counted ? (int32_t)(ref_seq + alt_seq + alt_clip + ref_span + alt_span) : 0;
+    o.counts[SVT_CNT_RO] = counted ? (int32_t)(ref_seq + ref_span) : 0;
+    o.counts[SVT_CNT_AO] = counted ? (int32_t)(alt_seq + alt_clip + alt_span) : 0;
+    o.counts[SVT_CNT_RS] = counted ? (int32_t)ref_seq : 0;
+    o.counts[SVT_CNT_AS] = counted ? (int32_t)alt_seq : 0;
+    o.counts[SVT_CNT_ASC] = counted ? (int32_t)alt_clip : 0;
+    o.counts[SVT_CNT_RP] = counted ? (int32_t)ref_span : 0;
+    o.counts[SVT_CNT_AP] = counted ? (int32_t)alt_span : 0;
+    o.gt = r.gt;
+    std::memset(o.pad, 0, sizeof(o.pad));
+}
+
+// n records, `in` and `out` disjoint: split over the host threads
+inline void expand96(const svt_result96* in, uint64_t n, svt_result* out)
+{
+    const uint64_t kChunk = 8192;
+    const uint64_t chunks = (n + kChunk - 1) / kChunk;
+    if (chunks <= 1) {
+        for (uint64_t i = 0; i < n; ++i) expand96_one(in[i], out[i]);
+        return;
+    }
+    parallel_for(chunks, [&](uint64_t c) {
+        const uint64_t hi = std::min(n, (c + 1) * kChunk);
+        for (uint64_t i = c * kChunk; i < hi; ++i) expand96_one(in[i], out[i]);
+    });
+}
+
+// the batch's device result records -> out[n_units] (svt_result), whichever form the device holds
+int d2h_results(svt_batch* b, svt_result* out)
+{
+    const uint64_t n = b->n_units;
+    if (!n) return SVT_OK;
+    if (!(b->flags & SVT_FLAG_RESULT96)) {
+        if (g_pinned.is_pinned(out, n * sizeof(svt_result))) {   // svt_pinned_alloc'ed: straight DMA
+            HIP_TRY(hipMemcpyAsync(out, b->out_dev, n * sizeof(svt_result), hipMemcpyDeviceToHost, b->stream));
+            HIP_TRY(hipStreamSynchronize(b->stream));
+            return SVT_OK;
+        }
+        return d2h_staged(out, b->out_dev, n * sizeof(svt_result), b->stream);
+    }
+    // 96-byte records: down through the pinned ring in pieces of whole records, expanded out of the ring slot (that copy
+    // out of the slot is there for pageable memory anyway; piece k is expanded while piece k + 1 is on the wire)
+    StagingRing& ring = current_ring();
+    std::lock_guard<std::mutex> guard(ring.lock);
+    SVT_TRY(ring.ensure());
+    const uint64_t per_piece = StagingRing::kPiece / sizeof(svt_result96);
+    const unsigned char* src = reinterpret_cast<const unsigned char*>(b->out_dev);
+    uint64_t u = 0, prev_u = 0, prev_n = 0;
+    int slot = 0, prev_slot = -1;
+    while (u < n || prev_slot >= 0) {
+        uint64_t cnt = 0;
+        if (u < n) {
+            cnt = std::min(per_piece, n - u);
+            HIP_TRY(hipMemcpyAsync(ring.buf[slot], src + u * sizeof(svt_result96), cnt * sizeof(svt_result96), hipMemcpyDeviceToHost, b->stream));
+        }
+        if (prev_slot >= 0) expand96(static_cast<const svt_result96*>(ring.buf[prev_slot]), prev_n, out + prev_u);
+        HIP_TRY(hipStreamSynchronize(b->stream));
+        prev_slot = cnt ? slot : -1;
+        prev_u = u;
+        prev_n = cnt;
+        u += cnt;
+        slot = (slot + 1) % 2;
+    }
+    return SVT_OK;
+}
+
 // payload_of(u) = first payload item (16 bytes each) of unit u; upload(i0, i1) enqueues items [i0, i1) on b->stream
 template <typename PayloadOf, typename Upload>
 int run_pipelined(svt_batch* b, svt_result* out, bool* download_left, PayloadOf&& payload_of, Upload&& upload)
@@ -864,7 +948,17 @@ int run_pipelined(svt_batch* b, svt_result* out, bool* download_left, PayloadOf&
     PipeStreams ps;
     SVT_TRY(g_handles.get_stream(&ps.compute));
     SVT_TRY(g_handles.get_stream(&ps.down));
-    const bool out_pinned = n && g_pinned.is_pinned(out, n * sizeof(svt_result));
+    const bool r96 = (b->flags & SVT_FLAG_RESULT96) != 0;
+    const bool out_pinned = n && !r96 && g_pinned.is_pinned(out, n * sizeof(svt_result));
+    // 96-byte device records: every piece comes down into a page-locked scratch as soon as its launch is through and is
+    // expanded into the caller's array while the later pieces are still on their way
+    struct Scratch { void* p = nullptr; ~Scratch() { g_pinned.put(p); } } scratch;
+    struct Piece { uint64_t u0, u1; hipEvent_t down; };
+    std::vector<Piece> pieces;
+    if (r96 && n) {
+        scratch.p = g_pinned.get(n * sizeof(svt_result96));
+        if (!scratch.p) return fail(SVT_ERR_NOMEM, "page-locked scratch for the result records");
+    }
     StageTimer tm;
     static const uint64_t piece_mb = std::getenv("SVT_PIPE_MB") ? std::strtoull(std::getenv("SVT_PIPE_MB"), nullptr, 10) : 64;
     const uint64_t kPieceItems = (std::max<uint64_t>(piece_mb, 1) << 20) / 16;   // payload per piece (the staging ring's piece size)
@@ -889,17 +983,35 @@ int run_pipelined(svt_batch* b, svt_result* out, bool* download_left, PayloadOf&
             HIP_TRY(hipEventRecord(done, ps.compute));
             HIP_TRY(hipStreamWaitEvent(ps.down, done, 0));
             HIP_TRY(hipMemcpyAsync(out + u0, b->out_dev + u0, (u1 - u0) * sizeof(svt_result), hipMemcpyDeviceToHost, ps.down));
+        } else if (r96) {
+            SVT_TRY(ps.event(&done));
+            HIP_TRY(hipEventRecord(done, ps.compute));
+            HIP_TRY(hipStreamWaitEvent(ps.down, done, 0));
+            HIP_TRY(hipMemcpyAsync(static_cast<unsigned char*>(scratch.p) + u0 * sizeof(svt_result96),
+                                   reinterpret_cast<const unsigned char*>(b->out_dev) + u0 * sizeof(svt_result96),
+                                   (u1 - u0) * sizeof(svt_result96), hipMemcpyDeviceToHost, ps.down));
+            hipEvent_t down;
+            SVT_TRY(ps.event(&down));
+            HIP_TRY(hipEventRecord(down, ps.down));
+            pieces.push_back(Piece{u0, u1, down});
         }
         u0 = u1;
     }
     tm.mark("pipeline: pieces enqueued");
+    // (96-byte records: piece k is expanded as soon as it is down, while the later pieces are still going up; should the pass
+    // report a contract violation below, what was expanded is discarded with the error)
+    for (const Piece& pc : pieces) {
+        HIP_TRY(hipEventSynchronize(pc.down));
+        expand96(static_cast<const svt_result96*>(scratch.p) + pc.u0, pc.u1 - pc.u0, out + pc.u0);
+    }
     HIP_TRY(hipStreamSynchronize(b->stream));
     tm.mark("pipeline: uploads done");
     HIP_TRY(hipStreamSynchronize(ps.compute));
     b->have_results = true;
     SVT_TRY(check_stream_errors(b));
     tm.mark("pipeline: passes done");
-    if (out_pinned) {
+    if (r96) {
+    } else if (out_pinned) {
         HIP_TRY(hipStreamSynchronize(ps.down));
     } else {
         *download_left = true;   // pageable output: the caller downloads through the staging ring once it is free
@@ -1162,17 +1274,23 @@ static int svt_batch_results_impl(svt_batch* b, svt_result* out, uint64_t n_unit
     HIP_TRY(hipSetDevice(b->device));
     HIP_TRY(hipStreamSynchronize(b->stream));   // the pass that produced the records
     SVT_TRY(check_stream_errors(b));
-    if (b->n_units && g_pinned.is_pinned(out, b->n_units * sizeof(svt_result))) {   // svt_pinned_alloc'ed: straight DMA
-        HIP_TRY(hipMemcpyAsync(out, b->out_dev, b->n_units * sizeof(svt_result), hipMemcpyDeviceToHost, b->stream));
-        HIP_TRY(hipStreamSynchronize(b->stream));
-        return SVT_OK;
-    }
-    return d2h_staged(out, b->out_dev, b->n_units * sizeof(svt_result), b->stream);
+    return d2h_results(b, out);
 }
 
 int svt_batch_results(svt_batch* b, svt_result* out, uint64_t n_units)
 {
     return guarded([&] { return svt_batch_results_impl(b, out, n_units); });
+}
+
+uint32_t svt_batch_result_bytes(const svt_batch* b) { return b ? result_bytes(b) : 0u; }
+
+int svt_results_expand96(const svt_result96* in, uint64_t n_units, svt_result* out)
+{
+    return guarded([&]() -> int {
+        if (n_units && (!in || !out)) return fail(SVT_ERR_INVALID, "null argument");
+        expand96(in, n_units, out);
+        return SVT_OK;
+    });
 }
 
 int svt_batch_result_order(svt_batch* b, uint32_t n_samples)
@@ -1254,7 +1372,9 @@ static int svt_batch_site_qual_impl(svt_batch* b, uint32_t n_samples, const doub
         SVT_TRY(st.finish());
     }
     hipLaunchKernelGGL(svt_site_qual_kernel, dim3((unsigned)((n_sites + kBlock - 1) / kBlock)), dim3(kBlock), 0, b->stream,
-                       b->out_dev, n_samples, initial ? d_init.as<double>() : nullptr, d_qual.as<double>(), n_sites);
+                       reinterpret_cast<const unsigned char*>(b->out_dev), result_bytes(b),
+                       (uint32_t)((b->flags & SVT_FLAG_RESULT96) ? offsetof(svt_result96, gt) : offsetof(svt_result, gt)), n_samples,
+                       initial ? d_init.as<double>() : nullptr, d_qual.as<double>(), n_sites);
     HIP_TRY(hipGetLastError());
     return d2h_staged(qual_out, d_qual.p, n_sites * sizeof(double), b->stream);
 }
@@ -1383,7 +1503,7 @@ static int svt_batch_create_packed_impl(const svt_packed_evidence* in, int devic
 {
     if (!in || !out) return fail(SVT_ERR_INVALID, "null argument");
     *out = nullptr;
-    if (flags & ~SVT_FLAG_SSO_ASSOCIATION) return fail(SVT_ERR_INVALID, "packed evidence takes SVT_FLAG_SSO_ASSOCIATION only");
+    if (flags & ~(SVT_FLAG_SSO_ASSOCIATION | SVT_FLAG_RESULT96)) return fail(SVT_ERR_INVALID, "packed evidence takes SVT_FLAG_SSO_ASSOCIATION and SVT_FLAG_RESULT96 only");
     if (in->n_units >= 0x55555550ull) return fail(SVT_ERR_INVALID, "too many units in one batch");
     const int ndev = svt_device_count();
     if (ndev <= 0) return fail(SVT_ERR_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
@@ -1414,7 +1534,7 @@ int svt_batch_create_packed(const svt_packed_evidence* in, int device, unsigned 
 
 static int svt_genotype_packed_impl(const svt_packed_evidence* in, svt_result* out, int device, unsigned flags)
 {
-    if (in && out && !(flags & ~SVT_FLAG_SSO_ASSOCIATION) && in->n_units >= kPipelineMinUnits && in->n_units < 0x55555550ull &&
+    if (in && out && !(flags & ~(SVT_FLAG_SSO_ASSOCIATION | SVT_FLAG_RESULT96)) && in->n_units >= kPipelineMinUnits && in->n_units < 0x55555550ull &&
         in->slot_offset && in->slots) {
         const int ndev = svt_device_count();
         if (ndev <= 0) return fail(SVT_ERR_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
@@ -1441,7 +1561,7 @@ static int svt_genotype_packed_impl(const svt_packed_evidence* in, svt_result* o
                                    return st.copy(dst, src, (i1 - i0) * 16);
                                });
             }
-            if (rc == SVT_OK && download_left) rc = d2h_staged(out, b->out_dev, in->n_units * sizeof(svt_result), b->stream);
+            if (rc == SVT_OK && download_left) rc = d2h_results(b, out);
         }
         const std::string keep = g_err;
         free_batch(b);
@@ -1582,7 +1702,7 @@ static int svt_genotype_impl(const svt_evidence_batch* in, svt_result* out, int 
                                    return st.copy(dst, src, (i1 - i0) * 16);
                                });
             }
-            if (rc == SVT_OK && download_left) rc = d2h_staged(out, b->out_dev, in->n_units * sizeof(svt_result), b->stream);
+            if (rc == SVT_OK && download_left) rc = d2h_results(b, out);
         }
         const std::string keep = g_err;
         StageTimer tm;

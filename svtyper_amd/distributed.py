@@ -64,14 +64,18 @@ def gather_bytes(local, sizes: List[int], dst: int = 0):
     return torch.cat([o[:c] for o, c in zip(out, sizes)])
 
 
-def gather_result_records(local, counts: List[int], dst: int = 0):
-    """Gather every rank's result records (a uint8 torch tensor of n_local * 128 bytes, on the
-    backend's device) onto `dst`; `counts` are records per rank."""
-    rec = ev.RESULT_DTYPE.itemsize
-    return gather_bytes(local, [c * rec for c in counts], dst)
+def gather_result_records(local, counts: List[int], dst: int = 0, rec_bytes: int = ev.RESULT_DTYPE.itemsize):
+    """Gather every rank's result records (a uint8 torch tensor of n_local * rec_bytes bytes, on the
+    backend's device) onto `dst`; `counts` are records per rank.  rec_bytes: 128 (svt_result) or 96
+    (svt_result96, batches created with FLAG_RESULT96: a quarter fewer bytes through the collective)."""
+    return gather_bytes(local, [c * rec_bytes for c in counts], dst)
 
 
-def results_from_bytes(t) -> Results:
-    """uint8 tensor of result records (any device) -> Results on the host."""
+def results_from_bytes(t, rec_bytes: int = ev.RESULT_DTYPE.itemsize) -> Results:
+    """uint8 tensor of result records (any device) -> Results on the host (96-byte records are expanded:
+    svt_results_expand96 restores the counts that follow from the tallies)."""
     a = t.cpu().numpy()
+    if rec_bytes == ev.RESULT96_DTYPE.itemsize:
+        from . import hip
+        return hip.expand96(a)
     return Results(a.view(ev.RESULT_DTYPE).copy())

@@ -20,6 +20,7 @@ SVTYPE_NAME = {v: k for k, v in SVTYPE_CODE.items()}
 
 FLAG_SSO_ASSOCIATION = 0x1
 FLAG_GENERAL_TABLES = 0x10     # keep every table in L2 (the general mode): measurements, table-path comparisons
+FLAG_RESULT96 = 0x20           # 96-byte result records on the device (svt_result96); the host API still returns 128-byte records
 
 REC_ALT_STRADDLE = 1 << 0
 REC_REF_STRADDLE_A = 1 << 1
@@ -94,6 +95,10 @@ RESULT_DTYPE = np.dtype(
     align=False,
 )
 assert RESULT_DTYPE.itemsize == 128
+# the device record under FLAG_RESULT96 (svt_result96): svt_result without the counts that follow from the tallies
+RESULT96_DTYPE = np.dtype([("gl", "<f8", (3,)), ("sq", "<f8"), ("tallies", "<f8", (5,)), ("qr", "<i4"), ("qa", "<i4"), ("gq", "<i4"),
+                           ("gt", "i1"), ("pad", "u1", (11,))])
+assert RESULT96_DTYPE.itemsize == 96
 
 
 # --------------------------------------------------------------------------- ctypes structs

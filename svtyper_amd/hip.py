@@ -16,7 +16,7 @@ from .evidence import GT_BLANK, CEvidenceBatch, CPackedEvidence, EvidenceBatch, 
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SVTYPER_HIP_LIB") or os.path.join(_HERE, "csrc", "libsvtyper_hip.so")
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 EXPORTS = (
     "svt_version", "svt_device_count", "svt_last_error", "svt_batch_create", "svt_batch_create_from_fragments",
@@ -25,7 +25,7 @@ EXPORTS = (
     "svt_batch_bind_device_results", "svt_batch_result_order", "svt_batch_bytes", "svt_batch_layout", "svt_batch_site_qual",
     "svt_batch_stream", "svt_batch_destroy", "svt_trim", "svt_bayes_gt", "svt_genotype_counts", "svt_genotype", "svt_genotype_multi", "svt_shard_bounds",
     "svt_pinned_alloc", "svt_pinned_free", "svt_pack_evidence", "svt_packed_free", "svt_batch_create_packed", "svt_genotype_packed",
-    "svt_format_results", "svt_format_free", "svt_results_host_sq",
+    "svt_format_results", "svt_format_free", "svt_results_host_sq", "svt_batch_result_bytes", "svt_results_expand96",
 )
 
 _lib: Optional[C.CDLL] = None
@@ -84,6 +84,10 @@ def load() -> C.CDLL:
     L.svt_format_free.argtypes = [C.c_void_p, C.c_void_p]
     L.svt_batch_site_qual.restype = C.c_int
     L.svt_batch_site_qual.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64]
+    L.svt_batch_result_bytes.restype = C.c_uint32
+    L.svt_batch_result_bytes.argtypes = [C.c_void_p]
+    L.svt_results_expand96.restype = C.c_int
+    L.svt_results_expand96.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p]
     L.svt_batch_layout.restype = C.c_int
     L.svt_batch_layout.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.svt_batch_bytes.restype = C.c_int
@@ -329,6 +333,10 @@ class DeviceBatch:
         records site-major (index site * n_samples + sample).  0 / 1 = unit order."""
         _check(self._lib.svt_batch_result_order(self._h, int(n_samples)))
 
+    def result_bytes(self) -> int:
+        """bytes of one DEVICE result record: 128 (svt_result), or 96 under FLAG_RESULT96 (svt_result96)"""
+        return int(self._lib.svt_batch_result_bytes(self._h))
+
     def device_results_ptr(self) -> int:
         """Device address of the svt_result[n_units] array the kernel writes to."""
         p = C.c_void_p()
@@ -354,7 +362,7 @@ class DeviceBatch:
         class _View:
             pass
         v = _View()
-        v.__cuda_array_interface__ = {"shape": (max(self.n_units, 1) * RESULT_DTYPE.itemsize,), "typestr": "|u1",
+        v.__cuda_array_interface__ = {"shape": (max(self.n_units, 1) * self.result_bytes(),), "typestr": "|u1",
                                       "data": (self.device_results_ptr(), False), "version": 2}
         v._svt_batch = self          # storage -> v -> batch
         t = torch.as_tensor(v, device=torch.device("cuda", getattr(self, "device", 0)))
@@ -420,6 +428,19 @@ class DeviceBatch:
 
     def __exit__(self, *exc):
         self.close(force=exc[0] is not None)   # (never mask the exception that is leaving the block)
+
+
+def expand96(records) -> Results:
+    """svt_results_expand96: 96-byte device records (a uint8 / RESULT96_DTYPE array in host memory, e.g. gathered from
+    several ranks) -> Results with the eight derived counts restored (classic.py:455-469)."""
+    from .evidence import RESULT96_DTYPE
+    a = np.ascontiguousarray(records).view(np.uint8).reshape(-1)
+    if a.size % RESULT96_DTYPE.itemsize:
+        raise ValueError("not a whole number of 96-byte result records")
+    n = a.size // RESULT96_DTYPE.itemsize
+    out = Results.empty(n)
+    _check(load().svt_results_expand96(C.c_void_p(a.ctypes.data), n, C.c_void_p(out.ptr())))
+    return out
 
 
 def host_sq(results: Results) -> Results:

@@ -48,7 +48,7 @@ def run_both(batch, flags=0, device=0):
     return got, want
 
 
-ALL_FLAGS = [0, ev.FLAG_SSO_ASSOCIATION]
+ALL_FLAGS = [0, ev.FLAG_SSO_ASSOCIATION, ev.FLAG_RESULT96, ev.FLAG_SSO_ASSOCIATION | ev.FLAG_RESULT96]   # (96-byte device records: same host results)
 
 
 def oracle_flags(flags):

@@ -125,7 +125,9 @@ def _rank(rank, world, port, out_path, scenario="c3"):
     dist.init_process_group("nccl" if rccl else "gloo", rank=rank, world_size=world,
                             **({"device_id": torch.device("cuda", device)} if rccl else {}))
     group = 1
-    if scenario == "c3":            # configs[3]: one library, mixed SV types
+    flags = ev.FLAG_RESULT96 if scenario == "c3_r96" else 0    # c3_r96: 96-byte device records through the gather
+    rec_bytes = 96 if flags else 128
+    if scenario in ("c3", "c3_r96"):   # configs[3]: one library, mixed SV types
         lib = synth.normal_library(n=50000)
         batch = synth.make_units(30_001, 77, [lib], svtype_mix=(0.6, 0.2, 0.1, 0.1), mean_frags=40, sd_frags=20, min_frags=0)
     elif scenario == "c5":          # configs[4]: 32 samples with their own libraries (library windows), a site's samples on one rank
@@ -139,17 +141,19 @@ def _rank(rank, world, port, out_path, scenario="c3"):
     if scenario == "empty":
         assert any(hi == lo for lo, hi in bounds) and any(hi > lo for lo, hi in bounds)
     shard, (lo, hi) = D.local_shard(batch, rank, world, group)
-    with hip.DeviceBatch(shard, device=device) as d:
+    with hip.DeviceBatch(shard, device=device, flags=flags) as d:
         if scenario == "c5":
             assert d.table_mode() == 1
-        buf = torch.zeros(max(1, shard.n_units) * 128, dtype=torch.uint8, device="cuda")
+        assert d.result_bytes() == rec_bytes
+        buf = torch.zeros(max(1, shard.n_units) * rec_bytes, dtype=torch.uint8, device="cuda")
         d.bind_device_results(buf.data_ptr())        # the kernel writes straight into the tensor that is gathered
         d.genotype(sync=True)
-        local = buf[: shard.n_units * 128] if rccl else buf[: shard.n_units * 128].cpu()
-        gathered = D.gather_result_records(local, [b[1] - b[0] for b in bounds], dst=0)
+        local = buf[: shard.n_units * rec_bytes] if rccl else buf[: shard.n_units * rec_bytes].cpu()
+        gathered = D.gather_result_records(local, [b[1] - b[0] for b in bounds], dst=0, rec_bytes=rec_bytes)
     if rank == 0:
         from oracle import c_oracle
-        got = D.results_from_bytes(gathered)
+        assert gathered.numel() == batch.n_units * rec_bytes
+        got = D.results_from_bytes(gathered, rec_bytes)
         single = hip.genotype_batch(batch, device=device)
         want = c_oracle.genotype_batch(batch)
         if group > 1:     # QUAL over a site's samples from the gathered (site-major) records == the single-rank device pass
@@ -168,7 +172,7 @@ def _rank(rank, world, port, out_path, scenario="c3"):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("scenario", ["c3", "c5", "empty"])
+@pytest.mark.parametrize("scenario", ["c3", "c3_r96", "c5", "empty"])
 def test_two_ranks_shard_hip_gather(hip_device, tmp_path, scenario):
     """world 2: shard_bounds -> the HIP path on every rank -> ONE gather of the 128-byte records; byte-equal to the
     single-rank result and parity-equal to the oracle (RCCL when two devices are visible, gloo on one).  c3: one

@@ -1,0 +1,93 @@
+"""SVT_FLAG_RESULT96 (ABI 13): the pass writes the 96-byte result record of SURVEY.md 8(d) -- GL, SQ, the five tallies,
+QR / QA / GQ, GT -- and the host restores DP, RO, AO, RS, AS, ASC, RP, AP from the tallies as the reference computes them
+(svtyper/classic.py:455-469: int() of the sums).  The host-side results must be the same bytes as the 128-byte path's."""
+import numpy as np
+import pytest
+
+from svtyper_amd import evidence as ev, synth
+
+
+def _to96(rec128):
+    r = np.zeros(len(rec128), ev.RESULT96_DTYPE)
+    for f in ("gl", "sq", "tallies", "gt"):
+        r[f] = rec128[f]
+    r["qr"], r["qa"], r["gq"] = rec128["counts"][:, 0], rec128["counts"][:, 1], rec128["counts"][:, 2]
+    return r
+
+
+@pytest.mark.parametrize("sso", [0, ev.FLAG_SSO_ASSOCIATION])
+def test_expansion_restores_the_oracles_counts(fixture_library, sso):
+    """host only: the oracle's 128-byte records, cut down to the 96-byte form, come back bit for bit from
+    svt_results_expand96 -- blank, skipped, './.' and called units alike (the derivation rule against the reference's
+    restatement on every kind of unit)."""
+    from oracle import c_oracle
+    from svtyper_amd import hip
+    parts = [synth.make_edge_cases([fixture_library], seed=5),
+             synth.make_units(6000, 17, [fixture_library], svtype_mix=(0.5, 0.2, 0.2, 0.1), mean_frags=40, sd_frags=30, min_frags=0,
+                              frac_empty=0.05, frac_skip=0.03)]
+    for batch in parts:
+        want = c_oracle.genotype_batch(batch, flags=sso)
+        assert {ev.GT_BLANK, ev.GT_SKIPPED} <= set(np.unique(want.gt).tolist())
+        got = hip.expand96(_to96(want.rec))
+        assert got.rec.tobytes() == want.rec.tobytes()
+    assert hip.expand96(np.zeros(0, ev.RESULT96_DTYPE)).n_units == 0
+    with pytest.raises(ValueError):
+        hip.expand96(np.zeros(100, np.uint8))
+
+
+@pytest.mark.gpu
+def test_device_records_are_the_96_byte_form(hip_device, fixture_library):
+    """what the kernel leaves in HBM under the flag: svt_result96 records whose fields equal the 128-byte pass's; the host
+    entry points (resident batch, pageable and page-locked one-shot, packed evidence, several devices) return the 128-byte
+    records unchanged"""
+    import ctypes as C
+    from svtyper_amd import hip
+    batch = synth.make_units(70_000, 23, [fixture_library], svtype_mix=(0.5, 0.2, 0.2, 0.1), mean_frags=30, sd_frags=20, min_frags=0,
+                             frac_empty=0.03, frac_skip=0.02)
+    for sso in (0, ev.FLAG_SSO_ASSOCIATION):
+        want = hip.genotype_batch(batch, hip_device, sso)
+        flags = sso | ev.FLAG_RESULT96
+        with hip.DeviceBatch(batch, hip_device, flags) as d:
+            assert d.result_bytes() == 96
+            d.genotype(sync=True)
+            assert d.results().rec.tobytes() == want.rec.tobytes()
+            raw = np.zeros(batch.n_units, ev.RESULT96_DTYPE)
+            lib = hip.load()
+            hip_rt = C.CDLL("libamdhip64.so")
+            assert hip_rt.hipMemcpy(C.c_void_p(raw.ctypes.data), C.c_void_p(d.device_results_ptr()), C.c_size_t(raw.nbytes), 2) == 0
+            assert raw.tobytes() == _to96(want.rec).tobytes()
+        with hip.DeviceBatch(batch, hip_device, sso) as d:
+            assert d.result_bytes() == 128
+        # one shot (upload || pass || download by unit ranges), output in pageable and in page-locked memory
+        assert hip.genotype_batch(batch, hip_device, flags).rec.tobytes() == want.rec.tobytes()
+        pinned = hip.pinned_results(batch.n_units)
+        assert hip.genotype_batch(batch, hip_device, flags, out=pinned).rec.tobytes() == want.rec.tobytes()
+        with hip.PackedEvidence(batch) as p:
+            assert hip.genotype_packed(p, hip_device, flags).rec.tobytes() == want.rec.tobytes()
+            assert hip.genotype_packed(p, hip_device, flags, out=pinned).rec.tobytes() == want.rec.tobytes()
+            with hip.DeviceBatch.from_packed(p, hip_device, flags) as dp:
+                assert dp.result_bytes() == 96
+                dp.genotype(sync=True)
+                assert dp.results().rec.tobytes() == want.rec.tobytes()
+        assert hip.genotype_multi(batch, [hip_device, hip_device, hip_device], flags=flags).rec.tobytes() == want.rec.tobytes()
+
+
+@pytest.mark.gpu
+def test_site_qual_and_result_order_on_96_byte_records(hip_device):
+    """QUAL over a site's samples reads SQ / GT out of the 96-byte records; sample-major units land site-major"""
+    from svtyper_amd import hip
+    multi = synth.make_multisample(300, 8, seed=13, mean_frags=30, sd_frags=10, min_frags=0, max_frags=70)
+    by_sample, _ = synth.to_sample_major(multi, 8)
+    with hip.DeviceBatch(multi, hip_device, 0) as d:
+        d.genotype(sync=True)
+        want, q_want = d.results().rec.tobytes(), d.site_qual(8)
+    init = np.linspace(0.0, 5.0, 300)
+    with hip.DeviceBatch(multi, hip_device, ev.FLAG_RESULT96) as d:
+        d.genotype(sync=True)
+        assert d.results().rec.tobytes() == want and d.site_qual(8).tobytes() == q_want.tobytes()
+        q_init = d.site_qual(8, initial=init)
+    with hip.DeviceBatch(by_sample, hip_device, ev.FLAG_RESULT96) as d:
+        d.result_order(8)
+        d.genotype(sync=True)
+        assert d.results().rec.tobytes() == want and d.site_qual(8).tobytes() == q_want.tobytes()
+        assert d.site_qual(8, initial=init).tobytes() == q_init.tobytes()

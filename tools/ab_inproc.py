@@ -19,9 +19,12 @@ import bench
 from svtyper_amd import evidence as ev, hip, synth
 
 wl = sys.argv[1] if len(sys.argv) > 1 else "c3"
+r96 = wl.endswith("96")          # c396 / sso96 / c596: SVT_FLAG_RESULT96 (builds that do not know the flag are left out)
+both = wl.endswith("both")       # c3both / ...: every build with 128-byte AND with 96-byte device records, over the same buffers
+wl = wl[:-2] if r96 else wl[:-4] if both else wl
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 1_000_000
 only = sys.argv[3:]
-flags = ev.FLAG_SSO_ASSOCIATION if wl == "sso" else 0
+flags = (ev.FLAG_SSO_ASSOCIATION if wl == "sso" else 0) | (ev.FLAG_RESULT96 if r96 else 0)
 if wl in ("c3", "sso"):
     batch = bench.generate("c3_mixed_1m", n, 0, bench.usable_cpus())
     order = 0
@@ -37,8 +40,9 @@ if only:
 
 
 class Build:
-    def __init__(self, path):
-        self.name = os.path.basename(path)
+    def __init__(self, path, flags=None):
+        flags = globals()["flags"] if flags is None else flags
+        self.name = os.path.basename(path) + (" r96" if flags & ev.FLAG_RESULT96 else "")
         L = self.L = C.CDLL(path)
         L.svt_last_error.restype = C.c_char_p
         L.svt_batch_create.argtypes = [C.POINTER(hip.CEvidenceBatch), C.c_int, C.c_uint, C.POINTER(C.c_void_p)]
@@ -77,12 +81,19 @@ class Build:
 
     def digest(self):
         self.check(self.L.svt_batch_genotype(self.h, 1))
+        # (every build shares ONE result buffer: run this build's pass again right before reading it)
         r = ev.Results.empty(batch.n_units)
         self.check(self.L.svt_batch_results(self.h, C.c_void_p(r.ptr()), batch.n_units))
         return hashlib.sha1(r.rec.tobytes()).hexdigest()[:12]
 
 
-builds = [Build(p) for p in libs]
+builds = []
+for p in libs:
+    for fl in ([flags, flags | ev.FLAG_RESULT96] if both else [flags]):
+        try:
+            builds.append(Build(p, fl))
+        except RuntimeError as e:
+            print("left out: %s" % e)
 rec, out = builds[0].buffers()
 for b in builds[1:]:
     b.bind(rec, out)
@@ -94,7 +105,7 @@ times = {b.name: [] for b in builds}
 for _ in range(int(os.environ.get("AB_ROUNDS", "8"))):
     for b in builds:
         times[b.name].append(b.timed(20))
-print("%s: %d units, %d records, every build over the record / result buffers of %s" % (wl, batch.n_units, batch.n_records, builds[0].name))
+print("%s%s: %d units, %d records, every build over the record / result buffers of %s" % (wl, " (96-byte result records)" if r96 else "", batch.n_units, batch.n_records, builds[0].name))
 for b in builds:
     t = sorted(times[b.name])
     print("%-34s best %.4f ms  median %.4f  frac(best) %.3f  digest %s" % (b.name, t[0], t[len(t) // 2], alg / t[0] / 1e6 / 8000, b.digest()), flush=True)
