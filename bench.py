@@ -191,7 +191,7 @@ def cpu_model() -> str:
     return "unknown"
 
 
-LEGS = ("sso", "r96", "c5", "c5x", "shard", "one_shot", "packed", "large", "real")   # c5x: the c5 leg's comparison launches (site-major input, no hints)
+LEGS = ("place", "sso", "r96", "c5", "c5x", "shard", "one_shot", "packed", "large", "real")   # c5x: the c5 leg's comparison launches (site-major input, no hints)
 
 
 def roofline_of(kernel_ms: float, alg_bytes: int, key: str, n_units: int, n_records: int) -> dict:
@@ -755,20 +755,33 @@ def main():
                         rp = hip.genotype_packed(packed, device=local_rank, flags=sso, out=host_out)
                         pipe.append(time.perf_counter() - t0)
                     best = min(pipe)
-                    # the whole route from records in host memory as ONE timed sequence: encode, then upload || pass || download
-                    route = []
+                    # the whole route from records in host memory as ONE call: svt_genotype_packed_from_records encodes the batch in
+                    # ranges of whole units and uploads / genotypes / downloads every finished range while the host threads encode
+                    # the next one (`serial`: svt_pack_evidence, then svt_genotype_packed, timed as one sequence -- round 3's route)
+                    route, route_serial, route_b2b = [], [], []
+                    for _ in range(6):
+                        time.sleep(0.3)     # (the cgroup's CPU quota is per 100 ms: a burst right behind another one is throttled)
+                        t0 = time.perf_counter()
+                        rp = hip.genotype_packed_from_records(batch, device=local_rank, flags=sso, out=host_out)
+                        route.append((time.perf_counter() - t0) * 1e3)
+                    route_equal = bool(np.array_equal(rp.rec, got.rec))
+                    for _ in range(5):      # the same called back to back, no pauses (what a producer loop sees under the CPU quota)
+                        t0 = time.perf_counter()
+                        rp = hip.genotype_packed_from_records(batch, device=local_rank, flags=sso, out=host_out)
+                        route_b2b.append((time.perf_counter() - t0) * 1e3)
                     for _ in range(4):
                         time.sleep(0.3)
                         t0 = time.perf_counter()
                         p2 = hip.PackedEvidence.try_pack(batch)
                         rp = hip.genotype_packed(p2, device=local_rank, flags=sso, out=host_out)
-                        route.append((time.perf_counter() - t0) * 1e3)
+                        route_serial.append((time.perf_counter() - t0) * 1e3)
                         p2.free()
                     out["one_shot_packed"] = {
                         "what": "svt_genotype_packed: packed slots (page-locked, written by svt_pack_evidence) -> result records in a "
                                 "page-locked output array, upload || svt_packed_kernel || download by unit ranges, best of 4.  The "
-                                "leg's headline is `from_records_*`: svt_pack_evidence + svt_genotype_packed timed as one sequence over "
-                                "records that already exist in host memory (best / median of 4) -- the encoder's time belongs to the "
+                                "leg's headline is `from_records_*`: svt_genotype_packed_from_records over records that already exist in host "
+                                "memory (best / median of 6; `from_records_serial_*`: svt_pack_evidence + svt_genotype_packed as one timed "
+                                "sequence) -- the encoder's time belongs to the "
                                 "route; compare with `one_shot.wall_ms`, the same records through the canonical upload.  `pack_ms`: "
                                 "the encoder alone (best of 6, `pack_ms_median` over calls 2-6; host threads: %s); "
                                 "`pcie_inclusive_breakpoints_per_s` alone is what a producer that emits slots directly would "
@@ -777,6 +790,11 @@ def main():
                                    "whose CPU time fits the cgroup's allowance of one accounting period, else the quota's %d" % n_cpu),
                         "from_records_wall_ms": min(route), "from_records_wall_ms_median": sorted(route)[len(route) // 2],
                         "from_records_breakpoints_per_s": n / (min(route) * 1e-3),
+                        "from_records_breakpoints_per_s_median": n / (sorted(route)[len(route) // 2] * 1e-3),
+                        "from_records_wall_ms_median_back_to_back": sorted(route_b2b)[len(route_b2b) // 2],
+                        "from_records_serial_wall_ms": min(route_serial), "from_records_serial_wall_ms_median": sorted(route_serial)[len(route_serial) // 2],
+                        "from_records_results_equal_headline": route_equal,
+                        "from_records_what": "svt_genotype_packed_from_records: encode || upload || pass || download by unit ranges in one call",
                         "pack_ms_median": pack_med,
                         "pack_ms_median_back_to_back": sorted(back_to_back)[len(back_to_back) // 2],
                         "wall_ms": best * 1e3, "serial_wall_ms": serial * 1e3, "serial_create_ms": parts[0] * 1e3,
@@ -867,6 +885,30 @@ def main():
             except Exception as e:
                 out["sso"] = {"error": repr(e)}
 
+        if "place" in legs:
+            # ---- where svt_batch_create's allocations land in HBM moves this pass by up to 8 % (a property of the physical blocks, not
+            # of the offsets inside them, and on some boxes of no block at all: profiles/r04_placement_*.txt).  The headline above is ONE
+            # draw; here are K more, each a batch made resident afresh while the earlier ones stay allocated.
+            try:
+                held, times = [], []
+                for _ in range(6):
+                    dk = hip.DeviceBatch(batch, device=local_rank, flags=flags)
+                    held.append(dk)
+                    dk.genotype(sync=True)
+                    spin_up(dk, 15)
+                    times.append(min(dk.genotype_timed(10) / 10 for _ in range(3)))
+                for dk in held:
+                    dk.close()
+                hip.trim()
+                ts = sorted(times)
+                out["roofline"]["placement"] = {
+                    "what": "the headline's pass over 6 more fresh allocations of the same batch (best of 3 x 10 launches each), in allocation order",
+                    "kernel_ms": times, "min": ts[0], "median": ts[len(ts) // 2], "max": ts[-1],
+                    "frac_min_median_max": [alg_bytes / (t * 1e-3) / 1e9 / HBM_PEAK_GBS for t in (ts[-1], ts[len(ts) // 2], ts[0])],
+                    "spread_pct": (ts[-1] / ts[0] - 1.0) * 100.0, "headline_kernel_ms": kern_ms}
+            except Exception as e:
+                out["roofline"]["placement"] = {"error": repr(e)}
+
         if "r96" in legs and not r96:
             # ---- the same launch writing the 96-byte record of SURVEY 8(d) (SVT_FLAG_RESULT96): 25 % fewer bytes written, but a
             # unit's record is then three 32-byte sectors of a line it shares with its neighbours, which other waves write at other times
@@ -938,6 +980,21 @@ def main():
                     leg["general_tables"] = {"table_mode": dn.table_mode(), "kernel_ms": g_ms, "frac": c_alg / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                              "create_ms": create_gen * 1e3}
                 leg["hintless"]["create_scan_ms"] = (create_nh - create_gen) * 1e3
+                # the one-shot of the same batch (svt_genotype, PCIe included), with and without the hints: both upload in one piece and
+                # take the window kernel (the hint-less one after reading the windows off the records; it used to take the general mode)
+                c5_out = hip.pinned_results(c5_batch.n_units)
+                shots = {}
+                for name, bb in (("hinted", c5_batch), ("hintless", nh)):
+                    ts = []
+                    for _ in range(3):
+                        t0 = time.perf_counter()
+                        r_os = hip.genotype_batch(bb, device=local_rank, flags=sso, out=c5_out)
+                        ts.append((time.perf_counter() - t0) * 1e3)
+                    shots[name + "_wall_ms"] = min(ts)
+                    shots[name + "_results_equal"] = bool(np.array_equal(r_os.rec, c_res_site))
+                shots["hintless_over_hinted"] = shots["hintless_wall_ms"] / shots["hinted_wall_ms"]
+                leg["one_shot"] = shots
+                del c5_out, r_os
                 del nh, nh_units, c_res_site
             except StopIteration:
                 pass

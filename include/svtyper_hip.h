@@ -501,6 +501,14 @@ int svt_batch_create_packed(const svt_packed_evidence* in, int device, unsigned 
 /* create_packed + genotype + results + destroy.                                                              */
 int svt_genotype_packed(const svt_packed_evidence* in, svt_result* out, int device, unsigned flags);
 
+/* The same from canonical records in HOST memory, with the encoder running ahead of the wire: the batch is encoded in
+ * ranges of whole units, and every finished range is uploaded, genotyped by its own launch and downloaded while the host
+ * threads encode the next one -- the wall time of the route is the longer of encoding and transfer, not their sum.  Same
+ * result bytes as svt_pack_evidence + svt_genotype_packed (and as svt_genotype over the same records).  One library per
+ * batch (the packed format's limit, SVT_ERR_UNSUPPORTED otherwise); small batches take the plain sequence.
+ * Replaces, for a producer that holds a batch of fragments in host memory, the hand-over at singlesample.py:355.      */
+int svt_genotype_packed_from_records(const svt_evidence_batch* in, svt_result* out, int device, unsigned flags);
+
 /* ---- several GPUs of one node from ONE process (no torch, no MPI) -------------------------------------
  * The multi-device form of svt_genotype: the replacement for the multiprocessing.Pool of
  * svtyper/singlesample.py:723-751 (`svtyper-sso --cores N`) for a C caller.  The units are cut into

@@ -527,16 +527,22 @@ std::string record_error_text(uint32_t err_bits)
 }
 
 namespace {
-// first(t) on `nt` threads (t = 0: the caller), then between() on the caller once every first() has returned, then -- if
-// that said SVT_OK -- second(t) on the same threads: one round of thread creation for both phases (sixty-four threads cost
-// ~1.5 ms to start).  A thread that cannot be started is simply missing: both phases hand out their work through atomic
-// counters.  Waiting threads back off to short sleeps (between() may take a page-locked allocation's tens of ms the first
-// time).  An exception in any thread is rethrown on the caller after the join, like run_threads does.
-template <typename First, typename Between, typename Second>
-int run_two_phases(unsigned nt, First&& first, Between&& between, Second&& second)
+// The encoder's threads, started once per call (sixty-four threads cost ~1.5 ms to start) and taken through the ranges of the
+// batch: for range r every thread runs first(r, t) (t = 0: the caller); when all of them are through, the caller runs
+// between(r) alone; if that says SVT_OK every thread runs second(r, t); the caller then waits until second(r, .) has
+// returned everywhere, runs after(r) alone -- the hand-over of the range -- and follows the others, who have gone on to
+// first(r + 1, .) in the meantime.  A thread that cannot be started is simply missing: the phases hand out their work
+// through atomic counters.  Waiting threads back off to short sleeps (between() may take a page-locked allocation's tens
+// of ms the first time).  An exception in any thread is rethrown on the caller after the join, like run_threads does.
+template <typename First, typename Between, typename Second, typename After>
+int run_ranged_phases(unsigned nt, uint64_t n_ranges, First&& first, Between&& between, Second&& second, After&& after)
 {
-    std::atomic<unsigned> arrived{0}, expected{~0u};
-    std::atomic<int> go{0};                  // 1: second phase, -1: stop
+    struct Gate {
+        std::atomic<unsigned> arrived{0}, finished{0};
+        std::atomic<int> go{0};              // 1: second phase, -1: stop
+    };
+    std::vector<Gate> gates(n_ranges);
+    std::atomic<unsigned> expected{~0u};
     std::exception_ptr thrown;
     std::mutex lock;
     int rc = SVT_OK;
@@ -547,6 +553,10 @@ int run_two_phases(unsigned nt, First&& first, Between&& between, Second&& secon
             std::lock_guard<std::mutex> g(lock);
             if (!thrown) thrown = std::current_exception();
         }
+    };
+    auto failed = [&]() -> bool {
+        std::lock_guard<std::mutex> g(lock);
+        return (bool)thrown;
     };
     auto wait_until = [](auto&& done) {
         for (unsigned spins = 0; !done(); ++spins) {
@@ -560,25 +570,30 @@ int run_two_phases(unsigned nt, First&& first, Between&& between, Second&& secon
         }
     };
     auto body = [&](unsigned t) {
-        guarded_call([&] { first(t); });
-        arrived.fetch_add(1, std::memory_order_acq_rel);
-        if (t == 0) {
-            wait_until([&] { return arrived.load(std::memory_order_acquire) == expected.load(std::memory_order_acquire); });
-            bool failed;
-            {
-                std::lock_guard<std::mutex> g(lock);
-                failed = (bool)thrown;
+        for (uint64_t r = 0; r < n_ranges; ++r) {
+            Gate& G = gates[r];
+            guarded_call([&] { first(r, t); });
+            G.arrived.fetch_add(1, std::memory_order_acq_rel);
+            if (t == 0) {
+                wait_until([&] { return G.arrived.load(std::memory_order_acquire) == expected.load(std::memory_order_acquire); });
+                if (!failed()) guarded_call([&] { rc = between(r); });
+                G.go.store(!failed() && rc == SVT_OK ? 1 : -1, std::memory_order_release);
+            } else {
+                wait_until([&] { return G.go.load(std::memory_order_acquire) != 0; });
             }
-            if (!failed) guarded_call([&] { rc = between(); });
-            {
-                std::lock_guard<std::mutex> g(lock);
-                failed = (bool)thrown;
+            if (G.go.load(std::memory_order_acquire) != 1) return;
+            guarded_call([&] { second(r, t); });
+            G.finished.fetch_add(1, std::memory_order_acq_rel);
+            if (t == 0) {
+                wait_until([&] { return G.finished.load(std::memory_order_acquire) == expected.load(std::memory_order_acquire); });
+                if (!failed()) guarded_call([&] { rc = after(r); });
+                if (failed() || rc != SVT_OK) {
+                    // (the others are in first(r + 1, .) or waiting at its gate: stop them there)
+                    for (uint64_t q = r + 1; q < n_ranges; ++q) gates[q].go.store(-1, std::memory_order_release);
+                    return;
+                }
             }
-            go.store(!failed && rc == SVT_OK ? 1 : -1, std::memory_order_release);
-        } else {
-            wait_until([&] { return go.load(std::memory_order_acquire) != 0; });
         }
-        if (go.load(std::memory_order_acquire) == 1) guarded_call([&] { second(t); });
     };
     std::vector<std::thread> pool;
     pool.reserve(nt ? nt - 1 : 0);
@@ -598,7 +613,7 @@ int run_two_phases(unsigned nt, First&& first, Between&& between, Second&& secon
 }
 }  // namespace
 
-int encode_packed(const svt_evidence_batch* in, const PackAlloc& A, PackedArrays* out)
+int encode_packed(const svt_evidence_batch* in, const PackAlloc& A, PackedArrays* out, const PackSink* sink)
 {
     if (!in || !out) return fail(SVT_ERR_INVALID, "null argument");
     *out = PackedArrays{};
@@ -647,6 +662,14 @@ int encode_packed(const svt_evidence_batch* in, const PackAlloc& A, PackedArrays
     out->common = common;
     mark("tables + allocations");
     const uint64_t n_chunks = (n + kChunkUnits - 1) / kChunkUnits;
+    // ranges of whole chunks: one for the plain call, several when a sink takes the evidence over as it is produced
+    const uint64_t chunks_per_range = sink && sink->range_units ? std::max<uint64_t>(1, (sink->range_units + kChunkUnits - 1) / kChunkUnits)
+                                                                 : std::max<uint64_t>(n_chunks, 1);
+    const uint64_t n_ranges = std::max<uint64_t>(1, (n_chunks + chunks_per_range - 1) / chunks_per_range);
+    if (sink) {   // the consumer copies ranges out of the slot array while later ones are written: it cannot move
+        out->slots = A.get(std::max<uint64_t>(sink->slots_cap, 1) * 16);
+        if (!out->slots) return fail(SVT_ERR_NOMEM, "out of host memory");
+    }
     const bool read_only_probe = std::getenv("SVT_PACK_PROBE") != nullptr;
     bool use_avx512 = false;
 #if SVT_PACK_AVX512
@@ -694,11 +717,16 @@ int encode_packed(const svt_evidence_batch* in, const PackAlloc& A, PackedArrays
     if (trace) std::fprintf(stderr, "[svt] pack: %u workers\n", nt);
     // ---- the one pass over the records: contract check + the three streams of every unit (record order).  Chunks are
     // claimed, not dealt: a worker that shares its core or loses its CPU for a while just takes fewer.
-    std::atomic<uint64_t> next_chunk{0};
-    auto encode_phase = [&](unsigned t) {
+    std::vector<std::atomic<uint64_t>> next_chunk(n_ranges), next_copy(n_ranges);
+    for (uint64_t r = 0; r < n_ranges; ++r) {
+        next_chunk[r].store(r * chunks_per_range, std::memory_order_relaxed);
+        next_copy[r].store(r * chunks_per_range, std::memory_order_relaxed);
+    }
+    auto encode_phase = [&](uint64_t range, unsigned t) {
+        const uint64_t range_end = std::min(n_chunks, (range + 1) * chunks_per_range);
         const auto w_t0 = std::chrono::steady_clock::now();
         // (worker 0 is the calling thread: its placement is the caller's business)
-        if (spread && t > 0 && home.size() > 1) {
+        if (range == 0 && spread && t > 0 && home.size() > 1) {
             const size_t n_groups = home.size();
             const cpu_set_t& g = home[t % n_groups]->cpus;
             cpu_set_t one = g;
@@ -714,9 +742,11 @@ int encode_packed(const svt_evidence_batch* in, const PackAlloc& A, PackedArrays
         }
         Worker& W = workers[t];
         // a guess at this worker's share (3.2 bytes per record is typical): growing later is only a copy
-        W.arena = g_arenas.get();
-        W.arena.reserve((size_t)(n_rec_claimed / nt / 4 * 3 / 2 + 4096));   // (chunks are claimed: shares differ)
-        for (uint64_t ch; (ch = next_chunk.fetch_add(1, std::memory_order_relaxed)) < n_chunks;) {
+        if (range == 0) {
+            W.arena = g_arenas.get();
+            W.arena.reserve((size_t)(n_rec_claimed / nt / 4 * 3 / 2 + 4096));   // (chunks are claimed: shares differ)
+        }
+        for (uint64_t ch; (ch = next_chunk[range].fetch_add(1, std::memory_order_relaxed)) < range_end;) {
             ChunkOut& C = chunks[ch];
             C.worker = t;
             C.arena_at = W.arena.size;
@@ -782,19 +812,20 @@ int encode_packed(const svt_evidence_batch* in, const PackAlloc& A, PackedArrays
             }
             C.n_slots = W.arena.size - C.arena_at;
         }
-        W.ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w_t0).count();
+        W.ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w_t0).count();
     };
     // ---- between the phases, on the calling thread (svt_last_error is thread-local): verdict on the batch, slot counts
     // -> chunk bases, the output array
-    uint64_t total = 0;
+    uint64_t total = 0, range_first_slot = 0;
     Slot* slots = nullptr;
-    auto between_phases = [&]() -> int {
-        if (trace) {
+    auto between_phases = [&](uint64_t range) -> int {
+        const uint64_t c0 = range * chunks_per_range, c1 = std::min(n_chunks, c0 + chunks_per_range);
+        if (trace && range + 1 == n_ranges) {
             std::fprintf(stderr, "[svt] pack: worker ms:");
             for (const Worker& W : workers) std::fprintf(stderr, " %.1f", W.ms);
             std::fprintf(stderr, "\n");
         }
-        mark("encode (one pass)");
+        if (range + 1 == n_ranges) mark("encode (one pass)");
         uint32_t bad = 0;
         int unit_error = kUnitOk;
         for (const Worker& W : workers) {
@@ -813,20 +844,26 @@ int encode_packed(const svt_evidence_batch* in, const PackAlloc& A, PackedArrays
         if (bad) return fail(SVT_ERR_INVALID, record_error_text(bad));
 
         // slot counts -> slot offsets: chunk bases serially, inside a chunk in parallel (second phase)
-        for (ChunkOut& C : chunks) {
+        range_first_slot = total;
+        for (uint64_t ch = c0; ch < c1; ++ch) {
+            ChunkOut& C = chunks[ch];
             C.base = total;
             total += C.n_slots;
             if (total >= 0xFFFFFFF0ull) return fail(SVT_ERR_UNSUPPORTED, "too many slots for 32-bit slot offsets");
         }
-        out->slots = A.get(std::max<uint64_t>(total, 1) * 16);
-        if (!out->slots) return fail(SVT_ERR_NOMEM, "out of host memory");
+        if (sink) {
+            if (total > sink->slots_cap) return SVT_ERR_PACK_OVERFLOW;   // (the caller repeats the call without a sink)
+        } else {
+            out->slots = A.get(std::max<uint64_t>(total, 1) * 16);
+            if (!out->slots) return fail(SVT_ERR_NOMEM, "out of host memory");
+            mark("allocate slots");
+        }
         slots = static_cast<Slot*>(out->slots);
-        mark("allocate slots");
         return SVT_OK;
     };
-    std::atomic<uint64_t> next_copy{0};
-    auto copy_phase = [&](unsigned) {
-        for (uint64_t ch; (ch = next_copy.fetch_add(1, std::memory_order_relaxed)) < n_chunks;) {
+    auto copy_phase = [&](uint64_t range, unsigned) {
+        const uint64_t range_end = std::min(n_chunks, (range + 1) * chunks_per_range);
+        for (uint64_t ch; (ch = next_copy[range].fetch_add(1, std::memory_order_relaxed)) < range_end;) {
             const ChunkOut& C = chunks[ch];
             const uint64_t u0 = ch * kChunkUnits, u1 = std::min(n, u0 + kChunkUnits);
             uint64_t run = C.base;
@@ -842,7 +879,12 @@ int encode_packed(const svt_evidence_batch* in, const PackAlloc& A, PackedArrays
             std::memcpy(slots + C.base, workers[C.worker].arena.p + C.arena_at, (size_t)C.n_slots * 16);
         }
     };
-    SVT_TRY(run_two_phases(nt, encode_phase, between_phases, copy_phase));
+    auto hand_over = [&](uint64_t range) -> int {
+        if (!sink || !sink->ready) return SVT_OK;
+        const uint64_t u0 = std::min(n, range * chunks_per_range * kChunkUnits), u1 = std::min(n, (range + 1) * chunks_per_range * kChunkUnits);
+        return sink->ready(sink->ctx, out, u0, u1, range_first_slot, total);
+    };
+    SVT_TRY(run_ranged_phases(nt, n_ranges, encode_phase, between_phases, copy_phase, hand_over));
     mark("offsets + final copy");
     out->n_slots = total;
     out->n_records = n_rec_claimed;

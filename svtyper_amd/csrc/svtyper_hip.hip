@@ -103,6 +103,7 @@ struct svt_batch {
     uint64_t cap_perm = 0;
     uint32_t n_chunks = 0;
     int window_tiles = 1;            // kMultiLds: 64-unit tiles per wave (chunks hold up to 256 * window_tiles units)
+    bool records_resident = true;    // false: create_stream left the record upload to its caller (pipelined one-shot)
     int wgs_per_cu = 3;              // workgroups per CU the pass's kernel was budgeted for (registers -> LDS per workgroup)
     StreamArgs sargs{};
     // kLayoutPacked: packed evidence as uploaded (svt_packed_kernel.h); d_records holds the slots, d_soff the 3n+1 offsets
@@ -358,7 +359,12 @@ int create_stream(const svt_evidence_batch* in, svt_batch* b, void* d_records_re
     bool windowed = may_window && (all_hinted || whole_batch_window);
     // No hints and too many libraries for one window: the windows are read off the records themselves, on the device,
     // right after the upload (svt_window_scan_kernel.h) -- not when the caller uploads the records later (pipelined one-shot)
-    const bool derive_windows = may_window && !windowed && n > 0 && in->n_libs <= 255 && T.narrow_bins && !defer_records;
+    const bool derive_windows = may_window && !windowed && n > 0 && in->n_libs <= 255 && T.narrow_bins;
+    // (the pipelined one-shot of such a batch: its pass is a few tenths of a millisecond beside tens of milliseconds of upload, so
+    // nothing is lost by uploading first and reading the windows -- the general mode it used to take instead runs at a third of
+    // the window kernel's speed)
+    if (derive_windows) defer_records = false;
+    b->records_resident = !defer_records;
     // group the units by window key (a counting sort: stable, original order inside a group) and cut the groups into chunks
     auto group_units = [&](auto&& key_of) {
         std::vector<uint32_t> start(65537, 0u);
@@ -671,6 +677,22 @@ int pack_evidence(const svt_evidence_batch* in, svt_packed_evidence** out)
     *out = nullptr;
     const PackAlloc pool{[](uint64_t bytes) { return g_pinned.get(bytes); }, [](void* p) { g_pinned.put(p); }};
     PackedArrays arr;
+    if (const char* e = std::getenv("SVT_PACK_TEST_RANGES")) {
+        // (tests: the ranged form of the encoder -- what svt_genotype_packed_from_records drives -- without a consumer; the
+        // arrays must be the plain call's)
+        PackSink sink;
+        sink.range_units = std::max<uint64_t>(1, std::strtoull(e, nullptr, 10));
+        sink.slots_cap = (in->n_units ? in->rec_offset[in->n_units] : 0) + 3 * in->n_units + 64;
+        static thread_local uint64_t last_u1;
+        last_u1 = 0;
+        sink.ready = [](void*, const PackedArrays* a, uint64_t u0, uint64_t u1, uint64_t s0, uint64_t s1) -> int {
+            if (u0 != last_u1 || u1 < u0 || s1 < s0 || (u1 > u0 && (a->off[3 * u0] != s0 || a->off[3 * u1] != s1))) return fail(SVT_ERR_INTERNAL, "ranged encoder: ranges out of order");
+            last_u1 = u1;
+            return SVT_OK;
+        };
+        SVT_TRY(encode_packed(in, pool, &arr, &sink));
+        if (last_u1 != in->n_units) { g_pinned.put(arr.off); g_pinned.put(arr.units); g_pinned.put(arr.slots); return fail(SVT_ERR_INTERNAL, "ranged encoder: units missing"); }
+    } else
     SVT_TRY(encode_packed(in, pool, &arr));
     auto owner = std::make_unique<PackedOwner>();
     owner->off = arr.off;
@@ -696,15 +718,20 @@ int pack_evidence(const svt_evidence_batch* in, svt_packed_evidence** out)
 }
 
 // svt_batch_create_packed: upload the slots as they are + tables
-int create_packed(const svt_packed_evidence* in, svt_batch* b, bool defer_slots = false)
+// defer_all (svt_genotype_packed_from_records: the encoder is still running): `in` carries the library, the weights, the unit
+// count and in n_slots the CAPACITY to allocate; slot offsets, unit headers and slots arrive later, range by range;
+// max_f_known = the most records any unit has
+int create_packed(const svt_packed_evidence* in, svt_batch* b, bool defer_slots = false, bool defer_all = false, uint64_t max_f_known = 0)
 {
     const uint64_t n = in->n_units;
     StageTimer tm;
     if (in->n_libs != 1 || !in->libs) return fail(SVT_ERR_INVALID, "packed evidence holds one library");
+    if (!defer_all) {
     if (n && (!in->slot_offset || !in->units)) return fail(SVT_ERR_INVALID, "null unit arrays");
     if (n && in->slot_offset[0] != 0) return fail(SVT_ERR_INVALID, "slot_offset[0] must be 0");
     if (n && in->slot_offset[3 * n] != in->n_slots) return fail(SVT_ERR_INVALID, "slot_offset does not end at n_slots");
     if (in->n_slots && !in->slots) return fail(SVT_ERR_INVALID, "null slots");
+    }
     if (in->common_mapq > 0xffffu) return fail(SVT_ERR_INVALID, "common_mapq is two bytes");
     if (!(in->split_weight >= 0.0) || !(in->disc_weight >= 0.0) || !std::isfinite(in->split_weight) || !std::isfinite(in->disc_weight))
         return fail(SVT_ERR_INVALID, "weights must be finite and >= 0");
@@ -723,16 +750,16 @@ int create_packed(const svt_packed_evidence* in, svt_batch* b, bool defer_slots 
     b->d_units = static_cast<svt_unit*>(p);
     SVT_TRY(g_pool.get(b->device, std::max<uint64_t>(n, 1) * sizeof(svt_result), &p, &b->cap_out));
     b->d_out = static_cast<svt_result*>(p);
-    const bool slots_pinned = in->n_slots && g_pinned.is_pinned(in->slots, in->n_slots * 16);
-    const bool off_pinned = n && g_pinned.is_pinned(in->slot_offset, (3 * n + 1) * sizeof(uint32_t));
-    const bool units_pinned = n && g_pinned.is_pinned(in->units, n * sizeof(svt_unit));
+    const bool slots_pinned = !defer_all && in->n_slots && g_pinned.is_pinned(in->slots, in->n_slots * 16);
+    const bool off_pinned = !defer_all && n && g_pinned.is_pinned(in->slot_offset, (3 * n + 1) * sizeof(uint32_t));
+    const bool units_pinned = !defer_all && n && g_pinned.is_pinned(in->units, n * sizeof(svt_unit));
     if (slots_pinned && !defer_slots) HIP_TRY(hipMemcpyAsync(b->d_records, in->slots, in->n_slots * 16, hipMemcpyHostToDevice, b->stream));
     if (off_pinned) HIP_TRY(hipMemcpyAsync(b->d_soff, in->slot_offset, (3 * n + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, b->stream));
     if (units_pinned) HIP_TRY(hipMemcpyAsync(b->d_units, in->units, n * sizeof(svt_unit), hipMemcpyHostToDevice, b->stream));
     tm.mark("allocations + DMA enqueued");
 
-    uint64_t max_f = 0;   // bound of the records behind a unit: 8 pair entries, 7 weight entries per slot
-    {
+    uint64_t max_f = max_f_known;   // bound of the records behind a unit: 8 pair entries, 7 weight entries per slot
+    if (!defer_all) {
         const uint64_t kChunk = 16384, n_chunks = (n + kChunk - 1) / kChunk;
         std::vector<uint64_t> chunk_max(std::max<uint64_t>(n_chunks, 1), 0);
         std::vector<int> chunk_bad(std::max<uint64_t>(n_chunks, 1), 0);
@@ -775,8 +802,8 @@ int create_packed(const svt_packed_evidence* in, svt_batch* b, bool defer_slots 
     {
         Stager st(b->stream);
         if (in->n_slots && !slots_pinned && !defer_slots) SVT_TRY(st.copy(b->d_records, in->slots, in->n_slots * 16));
-        if (n && !off_pinned) SVT_TRY(st.copy(b->d_soff, in->slot_offset, (3 * n + 1) * sizeof(uint32_t)));
-        if (n && !units_pinned) SVT_TRY(st.copy(b->d_units, in->units, n * sizeof(svt_unit)));
+        if (n && !off_pinned && !defer_all) SVT_TRY(st.copy(b->d_soff, in->slot_offset, (3 * n + 1) * sizeof(uint32_t)));
+        if (n && !units_pinned && !defer_all) SVT_TRY(st.copy(b->d_units, in->units, n * sizeof(svt_unit)));
         SVT_TRY(upload(&b->d_pm, T.pm, st));
         SVT_TRY(upload(&b->d_l10, T.l10, st));
         SVT_TRY(upload(&b->d_bins, T.bins, st));
@@ -1583,6 +1610,162 @@ int svt_genotype_packed(const svt_packed_evidence* in, svt_result* out, int devi
     return guarded([&] { return svt_genotype_packed_impl(in, out, device, flags); });
 }
 
+// svt_genotype_packed_from_records: canonical records in host memory -> result records, through packed evidence, with the
+// host encoder running AHEAD of the wire: the batch is encoded in ranges of whole units and every finished range goes up
+// (slots, slot offsets, unit headers: page-locked, straight DMA), is genotyped by its own launch of svt_packed_kernel and
+// comes down while the encoder's threads are already on the next range.  The bytes are those of svt_pack_evidence +
+// svt_genotype_packed; the wall time is the longer of encoding and transfer instead of their sum.
+// (The producer's side of svtyper/singlesample.py:355: `sam_fragments` handed over, tallies back.)
+static int svt_genotype_packed_from_records_impl(const svt_evidence_batch* in, svt_result* out, int device, unsigned flags)
+{
+    if (!in || (!out && in->n_units)) return fail(SVT_ERR_INVALID, "null argument");
+    if (flags & ~(SVT_FLAG_SSO_ASSOCIATION | SVT_FLAG_RESULT96)) return fail(SVT_ERR_INVALID, "packed evidence takes SVT_FLAG_SSO_ASSOCIATION and SVT_FLAG_RESULT96 only");
+    const uint64_t n = in->n_units;
+    const bool overlap = n >= kPipelineMinUnits && n < 0x55555550ull && in->n_libs == 1 && in->libs && in->rec_offset && in->units && in->records &&
+                         in->rec_offset[0] == 0 && in->split_weight >= 0.0 && in->disc_weight >= 0.0 && std::isfinite(in->split_weight) &&
+                         std::isfinite(in->disc_weight) && !std::getenv("SVT_PACKED_SERIAL");
+    auto serial = [&]() -> int {   // small batches, and whatever the overlapped form declines: encode, then the packed one shot
+        svt_packed_evidence* p = nullptr;
+        SVT_TRY(pack_evidence(in, &p));
+        const int rc = svt_genotype_packed(p, out, device, flags);
+        const std::string keep = g_err;
+        svt_packed_free(p);
+        g_err = keep;
+        return rc;
+    };
+    if (!overlap) return serial();
+    const int ndev = svt_device_count();
+    if (ndev <= 0) return fail(SVT_ERR_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(SVT_ERR_NO_DEVICE, "device index out of range");
+    HIP_TRY(hipSetDevice(device));
+    // the most records of any unit (the log10 table's bound) -- the encoder itself checks the offsets' monotony
+    uint64_t max_f = 0;
+    {
+        const uint64_t kChunk = 65536, n_chunks = (n + kChunk - 1) / kChunk;
+        std::vector<uint64_t> part(n_chunks, 0);
+        parallel_for(n_chunks, [&](uint64_t ch) {
+            uint64_t m = 0;
+            for (uint64_t u = ch * kChunk; u < std::min(n, (ch + 1) * kChunk); ++u)
+                if (in->rec_offset[u + 1] >= in->rec_offset[u]) m = std::max(m, in->rec_offset[u + 1] - in->rec_offset[u]);
+            part[ch] = m;
+        });
+        for (uint64_t m : part) max_f = std::max(max_f, m);
+    }
+    if (max_f > 0x3FFFFFFFull) return fail(SVT_ERR_INVALID, "unit with too many records");
+    const uint64_t n_rec = in->rec_offset[n];
+    const uint64_t slots_cap = n_rec / 16 * 5 + 3 * n + 4096;   // 5 bytes per record (3.1 is typical) + a slot per stream and unit
+    if (slots_cap >= 0xFFFFFFF0ull) return serial();
+
+    svt_batch* b = new (std::nothrow) svt_batch();
+    if (!b) return fail(SVT_ERR_NOMEM, "out of host memory");
+    b->device = device;
+    b->flags = flags;
+    b->layout = kLayoutPacked;
+    b->n_units = n;
+    b->n_records = n_rec;
+    svt_packed_evidence shell{};
+    shell.n_units = n;
+    shell.n_slots = slots_cap;
+    shell.n_records = n_rec;
+    shell.n_libs = 1;
+    shell.libs = in->libs;
+    shell.split_weight = in->split_weight;
+    shell.disc_weight = in->disc_weight;
+    int rc = create_packed(&shell, b, /*defer_slots=*/true, /*defer_all=*/true, max_f);
+
+    struct Piece { uint64_t u0, u1; hipEvent_t down; };
+    struct Ctx {
+        svt_batch* b;
+        svt_result* out;
+        PipeStreams ps;
+        bool out_pinned = false, r96 = false;
+        void* scratch = nullptr;
+        std::vector<Piece> pieces;
+        ~Ctx() { g_pinned.put(scratch); }
+    } ctx;
+    ctx.b = b;
+    ctx.out = out;
+    PackedArrays arr;
+    bool overflow = false;
+    if (rc == SVT_OK) rc = g_handles.get_stream(&ctx.ps.compute);
+    if (rc == SVT_OK) rc = g_handles.get_stream(&ctx.ps.down);
+    if (rc == SVT_OK) {
+        ctx.r96 = (flags & SVT_FLAG_RESULT96) != 0;
+        ctx.out_pinned = !ctx.r96 && g_pinned.is_pinned(out, n * sizeof(svt_result));
+        if (ctx.r96) {
+            ctx.scratch = g_pinned.get(n * sizeof(svt_result96));
+            if (!ctx.scratch) rc = fail(SVT_ERR_NOMEM, "page-locked scratch for the result records");
+        }
+    }
+    if (rc == SVT_OK) {
+        PackSink sink;
+        // four ranges: the last one's transfer is what stays exposed, and every range costs the encoder's threads three meetings
+        // (measured, 1 M units: 1 / 2 / 4 / 8 / 12 ranges -> 21.2 / 18.1 / 14.2 / 17.0 / 19.3 ms best, profiles/r04_packed_ranges.txt)
+        sink.range_units = std::max<uint64_t>(32768, (n + 3) / 4);
+        if (const char* e = std::getenv("SVT_PACK_RANGE_UNITS")) sink.range_units = std::max<uint64_t>(256, std::strtoull(e, nullptr, 10));
+        sink.slots_cap = slots_cap;
+        sink.ctx = &ctx;
+        sink.ready = [](void* vctx, const PackedArrays* a, uint64_t u0, uint64_t u1, uint64_t s0, uint64_t s1) -> int {
+            Ctx& c = *static_cast<Ctx*>(vctx);
+            svt_batch* b = c.b;
+            if (u1 <= u0) return SVT_OK;
+            b->pargs.common_mq = a->common;
+            if (s1 > s0)
+                HIP_TRY(hipMemcpyAsync(static_cast<char*>(b->d_records) + s0 * 16, static_cast<const char*>(a->slots) + s0 * 16, (s1 - s0) * 16,
+                                       hipMemcpyHostToDevice, b->stream));
+            HIP_TRY(hipMemcpyAsync(b->d_soff + 3 * u0, a->off + 3 * u0, (3 * (u1 - u0) + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, b->stream));
+            HIP_TRY(hipMemcpyAsync(b->d_units + u0, a->units + u0, (u1 - u0) * sizeof(svt_unit), hipMemcpyHostToDevice, b->stream));
+            hipEvent_t landed, done, down;
+            SVT_TRY(c.ps.event(&landed));
+            HIP_TRY(hipEventRecord(landed, b->stream));
+            HIP_TRY(hipStreamWaitEvent(c.ps.compute, landed, 0));
+            SVT_TRY(launch_range(b, u0, u1, c.ps.compute));
+            if (c.out_pinned || c.r96) {
+                SVT_TRY(c.ps.event(&done));
+                HIP_TRY(hipEventRecord(done, c.ps.compute));
+                HIP_TRY(hipStreamWaitEvent(c.ps.down, done, 0));
+                if (c.out_pinned)
+                    HIP_TRY(hipMemcpyAsync(c.out + u0, b->out_dev + u0, (u1 - u0) * sizeof(svt_result), hipMemcpyDeviceToHost, c.ps.down));
+                else {
+                    HIP_TRY(hipMemcpyAsync(static_cast<unsigned char*>(c.scratch) + u0 * sizeof(svt_result96),
+                                           reinterpret_cast<const unsigned char*>(b->out_dev) + u0 * sizeof(svt_result96),
+                                           (u1 - u0) * sizeof(svt_result96), hipMemcpyDeviceToHost, c.ps.down));
+                    SVT_TRY(c.ps.event(&down));
+                    HIP_TRY(hipEventRecord(down, c.ps.down));
+                    c.pieces.push_back(Piece{u0, u1, down});
+                }
+            }
+            return SVT_OK;
+        };
+        const PackAlloc pool{[](uint64_t bytes) { return g_pinned.get(bytes); }, [](void* p) { g_pinned.put(p); }};
+        rc = encode_packed(in, pool, &arr, &sink);
+        overflow = rc == SVT_ERR_PACK_OVERFLOW;
+    }
+    // whatever was enqueued has to be through before anything is released
+    if (b->stream) (void)hipStreamSynchronize(b->stream);
+    if (ctx.ps.compute) (void)hipStreamSynchronize(ctx.ps.compute);
+    if (ctx.ps.down) (void)hipStreamSynchronize(ctx.ps.down);
+    if (rc == SVT_OK) {
+        b->n_slots = arr.n_slots;
+        b->have_results = true;
+        for (const Piece& pc : ctx.pieces) expand96(static_cast<const svt_result96*>(ctx.scratch) + pc.u0, pc.u1 - pc.u0, out + pc.u0);
+        if (!ctx.out_pinned && !ctx.r96) rc = d2h_results(b, out);
+    }
+    g_pinned.put(arr.off);
+    g_pinned.put(arr.units);
+    g_pinned.put(arr.slots);
+    const std::string keep = g_err;
+    free_batch(b);
+    g_err = keep;
+    if (overflow) return serial();   // (more slots than estimated: the plain route sizes the array exactly)
+    return rc;
+}
+
+int svt_genotype_packed_from_records(const svt_evidence_batch* in, svt_result* out, int device, unsigned flags)
+{
+    return guarded([&] { return svt_genotype_packed_from_records_impl(in, out, device, flags); });
+}
+
 void* svt_batch_stream(svt_batch* b) { return b ? (void*)b->stream : nullptr; }
 
 void svt_batch_destroy(svt_batch* b) { free_batch(b); }
@@ -1609,6 +1792,16 @@ extern "C" int svt_debug_device_free(int device, void* p)
 {
     return guarded([&]() -> int {
         if (p) g_pool.release(p, device);
+        return SVT_OK;
+    });
+}
+
+extern "C" int svt_debug_copy_to_host(int device, void* host, const void* dev, uint64_t bytes)
+{
+    return guarded([&]() -> int {
+        HIP_TRY(hipSetDevice(device));
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemcpy(host, dev, bytes, hipMemcpyDeviceToHost));
         return SVT_OK;
     });
 }
@@ -1684,9 +1877,10 @@ static int svt_genotype_impl(const svt_evidence_batch* in, svt_result* out, int 
         b->n_units = in->n_units;
         b->n_records = in->rec_offset[in->n_units];
         int rc = create_stream(in, b, nullptr, 0, /*defer_records=*/true);
-        if (rc == SVT_OK && b->mode == kMultiLds) {
-            // library windows: the launch walks window chunks, not unit ranges -- upload in one piece, one launch
-            rc = h2d_staged(b->d_records, in->records, b->n_records * sizeof(uint4), b->stream);
+        if (rc == SVT_OK && (b->mode == kMultiLds || b->records_resident)) {
+            // library windows: the launch walks window chunks, not unit ranges -- upload in one piece (a batch without window
+            // hints was uploaded by create_stream, which read the windows off the records), one launch
+            if (!b->records_resident) rc = h2d_staged(b->d_records, in->records, b->n_records * sizeof(uint4), b->stream);
             if (rc == SVT_OK) rc = svt_batch_genotype(b, 1);
             if (rc == SVT_OK) rc = svt_batch_results(b, out, in->n_units);
         } else if (rc == SVT_OK) {

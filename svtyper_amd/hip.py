@@ -26,6 +26,7 @@ EXPORTS = (
     "svt_batch_stream", "svt_batch_destroy", "svt_trim", "svt_bayes_gt", "svt_genotype_counts", "svt_genotype", "svt_genotype_multi", "svt_shard_bounds",
     "svt_pinned_alloc", "svt_pinned_free", "svt_pack_evidence", "svt_packed_free", "svt_batch_create_packed", "svt_genotype_packed",
     "svt_format_results", "svt_format_free", "svt_results_host_sq", "svt_batch_result_bytes", "svt_results_expand96",
+    "svt_genotype_packed_from_records",
 )
 
 _lib: Optional[C.CDLL] = None
@@ -115,6 +116,8 @@ def load() -> C.CDLL:
     L.svt_batch_create_packed.argtypes = [C.POINTER(CPackedEvidence), C.c_int, C.c_uint, C.POINTER(C.c_void_p)]
     L.svt_genotype_packed.restype = C.c_int
     L.svt_genotype_packed.argtypes = [C.POINTER(CPackedEvidence), C.c_void_p, C.c_int, C.c_uint]
+    L.svt_genotype_packed_from_records.restype = C.c_int
+    L.svt_genotype_packed_from_records.argtypes = [C.POINTER(CEvidenceBatch), C.c_void_p, C.c_int, C.c_uint]
     L.svt_results_host_sq.restype = C.c_int
     L.svt_results_host_sq.argtypes = [C.c_void_p, C.c_uint64]
     L.svt_genotype_counts.restype = C.c_int
@@ -258,6 +261,15 @@ def genotype_packed(packed: PackedEvidence, device: int = 0, flags: int = 0, out
     ranges.  `out`: a Results to fill (pinned_results(n): the records then come down by DMA while later pieces go up)."""
     out = Results.empty(packed.n_units) if out is None else _check_out(out, packed.n_units)
     _check(load().svt_genotype_packed(packed._p, C.c_void_p(out.ptr()), int(device), int(flags)))
+    return out
+
+
+def genotype_packed_from_records(batch: EvidenceBatch, device: int = 0, flags: int = 0, out: Optional[Results] = None) -> Results:
+    """svt_genotype_packed_from_records: canonical records in host memory -> results through packed evidence, the host
+    encoder running ahead of the upload by unit ranges (encode || upload || pass || download).  One library per batch."""
+    out = Results.empty(batch.n_units) if out is None else _check_out(out, batch.n_units)
+    cb = batch.as_c()
+    _check(load().svt_genotype_packed_from_records(C.byref(cb), C.c_void_p(out.ptr()), int(device), int(flags)))
     return out
 
 

@@ -21,6 +21,32 @@ int main() {
     svt_library lib{}; lib.hist = hist.data(); lib.key_min = 50; lib.n_bins = (uint32_t)hist.size(); lib.mean = 350.37; lib.sd = 80.71;
     svt_evidence_batch in{}; in.n_units = n; in.rec_offset = off.data(); in.units = units.data(); in.records = recs.data(); in.n_libs = 1; in.libs = &lib; in.split_weight = 1; in.disc_weight = 1;
     PackAlloc A{[](uint64_t b) { return std::malloc(b); }, [](void* p) { std::free(p); }};
+    // the ranged form (svt_genotype_packed_from_records): ranges of 2048 units handed over on the calling thread while the other
+    // threads are already encoding the next range; rep 1 refuses the third range (the stop path through the later gates)
+    for (int rep = 0; rep < 2; ++rep) {
+        struct Seen { uint64_t units = 0, slots = 0, calls = 0; int fail_at; } seen;
+        seen.fail_at = rep == 1 ? 2 : -1;
+        PackSink sink;
+        sink.range_units = 2048;
+        sink.slots_cap = off[n] + 3 * n + 64;
+        sink.ctx = &seen;
+        sink.ready = [](void* ctx, const PackedArrays* a, uint64_t u0, uint64_t u1, uint64_t s0, uint64_t s1) -> int {
+            Seen& s = *static_cast<Seen*>(ctx);
+            if ((int)s.calls == s.fail_at) return -7;
+            uint64_t x = 0;                                        // read what was handed over, as the consumer's DMA would
+            for (uint64_t i = s0; i < s1; ++i) x += static_cast<const uint32_t*>(a->slots)[4 * i];
+            for (uint64_t u = u0; u < u1; ++u) x += a->off[3 * u + 3] + (uint64_t)a->units[u].var_length;
+            s.units += u1 - u0;
+            s.slots += s1 - s0 + (x == 1 ? 0 : 0);
+            ++s.calls;
+            return 0;
+        };
+        PackedArrays out;
+        int rc = encode_packed(&in, A, &out, &sink);
+        std::printf("ranged %d rc %d units %llu slots %llu of %llu calls %llu\n", rep, rc, (unsigned long long)seen.units, (unsigned long long)seen.slots,
+                    (unsigned long long)out.n_slots, (unsigned long long)seen.calls);
+        if (rc == 0) { A.put(out.off); A.put(out.units); A.put(out.slots); }
+    }
     for (int rep = 0; rep < 5; ++rep) {
         PackedArrays out;
         int rc = encode_packed(&in, A, &out);

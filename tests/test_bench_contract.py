@@ -41,13 +41,16 @@ def test_bench_line_has_the_contract_keys(hip_device):
     assert len(roof["source_sha16"]) == 16 and len(roof["library_sha16"]) == 16 and roof["compiler"]
     # the same launches without the untimed spin-up are in the record too
     assert roof["no_spinup_kernel_ms"] > 0 and 0 < roof["no_spinup_frac"] <= 1.0
+    pl = roof["placement"]
+    assert len(pl["kernel_ms"]) == 6 and pl["min"] <= pl["median"] <= pl["max"] and pl["spread_pct"] >= 0
     # the labelled extra legs
     assert d["one_shot"]["pcie_inclusive_breakpoints_per_s"] > 0 and d["one_shot"]["wall_ms"] > 0
     assert d["large_batch"]["units"] == 70000 and d["large_batch"]["first_units_equal_headline"] is True
     assert 0 < d["large_batch"]["frac"] <= 1.0
     assert d["one_shot_packed"]["results_equal_headline"] is True and d["one_shot_packed"]["bytes_per_fragment_record"] < 5
     assert d["one_shot_packed"]["pack_inclusive_wall_ms"] > d["one_shot_packed"]["wall_ms"]
-    assert d["one_shot_packed"]["from_records_wall_ms"] > d["one_shot_packed"]["wall_ms"]
+    assert d["one_shot_packed"]["from_records_wall_ms"] > 0 and d["one_shot_packed"]["from_records_results_equal_headline"] is True
+    assert d["one_shot_packed"]["from_records_serial_wall_ms"] > d["one_shot_packed"]["wall_ms"]
     # the singlesample association, the configs[4] shape and the 8-GPU shard: own fractions, own (or no) traffic figures
     assert 0 < d["sso"]["frac"] <= 1.0 and d["sso"]["units"] == 30000
     assert d["result96"]["host_results_equal_headline"] is True and 0 < d["result96"]["frac"] <= 1.0 and d["config"]["device_result_record_bytes"] == 128
@@ -55,6 +58,7 @@ def test_bench_line_has_the_contract_keys(hip_device):
     assert c5["units"] == 60000 - 60000 % 32          # configs[4]'s per-GPU share is twice the headline's units
     assert 0 < c5["frac"] <= 1.0 and c5["table_mode"] == 1 and c5["units"] % 32 == 0 and c5["hintless"]["table_mode"] == 1 and c5["hintless"]["results_equal"] and c5["general_tables"]["table_mode"] == 2
     assert c5["site_major_input"]["results_and_site_qual_equal"] is True
+    assert c5["one_shot"]["hinted_results_equal"] and c5["one_shot"]["hintless_results_equal"] and c5["one_shot"]["hintless_over_hinted"] < 1.5
     for leg in (d["sso"], c5):
         assert leg["traffic"] is None or "these kernel sources" in leg["traffic_source"]
     assert d["one_shot_packed"]["pack_ms_median_back_to_back"] > 0

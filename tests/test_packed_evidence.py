@@ -218,3 +218,69 @@ def test_worker_count_does_not_change_the_slots(fixture_library):
             else:
                 os.environ["SVT_PACK_THREADS"] = keep
         assert all(g == got[0] for g in got[1:])
+
+
+def test_ranged_encoder_writes_the_same_arrays(fixture_library, monkeypatch):
+    """host only: the encoder taken through ranges of whole units with a hand-over after each (what
+    svt_genotype_packed_from_records drives, SVT_PACK_TEST_RANGES) leaves the arrays of the plain call -- ranges in order,
+    every unit handed over once, offsets final at the hand-over."""
+    from svtyper_amd import hip
+    batch = synth.make_units(40_000, 11, [fixture_library], svtype_mix=(0.5, 0.2, 0.2, 0.1), mean_frags=25, sd_frags=20, min_frags=0,
+                             frac_empty=0.03, frac_skip=0.02)
+    with hip.PackedEvidence(batch) as plain:
+        want = (plain.slots().tobytes(), plain.slot_offset().tobytes(), plain.nbytes)
+    for ranges in ("256", "1000", "7000", "40000", "1000000"):
+        monkeypatch.setenv("SVT_PACK_TEST_RANGES", ranges)
+        with hip.PackedEvidence(batch) as p:
+            assert (p.slots().tobytes(), p.slot_offset().tobytes(), p.nbytes) == want, ranges
+    monkeypatch.setenv("SVT_PACK_TEST_RANGES", "512")
+    monkeypatch.setenv("SVT_PACK_THREADS", "5")
+    with hip.PackedEvidence(batch) as p:
+        assert p.slots().tobytes() == want[0]
+    bad = synth.make_units(9000, 3, [fixture_library])
+    bad.records["flags"][bad.n_records - 5] |= 1 << 20     # an undefined flag bit in the LAST range: reported, nothing leaks
+    with pytest.raises(hip.SvtyperHipError) as e:
+        hip.PackedEvidence(bad)
+    assert "reserved/undefined bits" in str(e.value)
+
+
+@pytest.mark.gpu
+def test_from_records_route_overlaps_and_equals_the_canonical_pass(hip_device, fixture_library, monkeypatch):
+    """svt_genotype_packed_from_records (encode || upload || pass || download by unit ranges) returns the bytes of svt_genotype over the
+    same records: both associations, 96-byte device records, page-locked and pageable output, many small ranges, the serial
+    fallbacks (a small batch; more slots than estimated), and its error paths."""
+    from svtyper_amd import hip
+    batch = synth.make_units(150_000, 19, [fixture_library], svtype_mix=(0.5, 0.2, 0.2, 0.1), mean_frags=30, sd_frags=20, min_frags=0,
+                             frac_empty=0.03, frac_skip=0.02)
+    pinned = hip.pinned_results(batch.n_units)
+    for flags in (0, ev.FLAG_SSO_ASSOCIATION, ev.FLAG_RESULT96, ev.FLAG_SSO_ASSOCIATION | ev.FLAG_RESULT96):
+        want = hip.genotype_batch(batch, hip_device, flags & ev.FLAG_SSO_ASSOCIATION).rec.tobytes()
+        assert hip.genotype_packed_from_records(batch, hip_device, flags).rec.tobytes() == want
+        assert hip.genotype_packed_from_records(batch, hip_device, flags, out=pinned).rec.tobytes() == want
+    want = hip.genotype_batch(batch, hip_device, 0).rec.tobytes()
+    monkeypatch.setenv("SVT_PACK_RANGE_UNITS", "4096")          # ~37 ranges
+    assert hip.genotype_packed_from_records(batch, hip_device, 0, out=pinned).rec.tobytes() == want
+    monkeypatch.delenv("SVT_PACK_RANGE_UNITS")
+    monkeypatch.setenv("SVT_PACKED_SERIAL", "1")                # the plain sequence
+    assert hip.genotype_packed_from_records(batch, hip_device, 0).rec.tobytes() == want
+    monkeypatch.delenv("SVT_PACKED_SERIAL")
+    small = batch.slice(0, 5000)                                # below the pipeline's minimum: the plain sequence
+    assert hip.genotype_packed_from_records(small, hip_device, 0).rec.tobytes() == hip.genotype_batch(small, hip_device, 0).rec.tobytes()
+    assert hip.genotype_packed_from_records(batch.slice(0, 0), hip_device, 0).n_units == 0
+    # records that pack badly (every pair entry wide, every record with candidates): more slots than the estimate -> the plain route
+    dense = synth.make_units(40_000, 5, [fixture_library], mean_frags=30, sd_frags=5, min_frags=10)
+    rng = np.random.default_rng(1)
+    for f in ("mapq_a", "mapq_b", "rs_a", "rs_b", "seq_l", "seq_r", "clip_l", "clip_r"):
+        dense.records[f] = rng.integers(1, 60, dense.n_records).astype(np.uint8)
+    assert hip.genotype_packed_from_records(dense, hip_device, 0).rec.tobytes() == hip.genotype_batch(dense, hip_device, 0).rec.tobytes()
+    # a contract violation in a late range is an error of the call; several libraries are not packable
+    bad = synth.make_units(60_000, 3, [fixture_library])
+    bad.records["flags"][bad.n_records - 5] |= 1 << 20
+    with pytest.raises(hip.SvtyperHipError) as e:
+        hip.genotype_packed_from_records(bad, hip_device, 0)
+    assert "reserved/undefined bits" in str(e.value)
+    two = synth.make_units(40_000, 3, [fixture_library, synth.normal_library(400.0, 60.0, seed=2)])
+    with pytest.raises(hip.SvtyperHipError):
+        hip.genotype_packed_from_records(two, hip_device, 0)
+    # the device is still fine afterwards
+    assert hip.genotype_packed_from_records(batch, hip_device, 0).rec.tobytes() == want

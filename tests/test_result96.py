@@ -53,8 +53,8 @@ def test_device_records_are_the_96_byte_form(hip_device, fixture_library):
             assert d.results().rec.tobytes() == want.rec.tobytes()
             raw = np.zeros(batch.n_units, ev.RESULT96_DTYPE)
             lib = hip.load()
-            hip_rt = C.CDLL("libamdhip64.so")
-            assert hip_rt.hipMemcpy(C.c_void_p(raw.ctypes.data), C.c_void_p(d.device_results_ptr()), C.c_size_t(raw.nbytes), 2) == 0
+            lib.svt_debug_copy_to_host.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_uint64]
+            hip._check(lib.svt_debug_copy_to_host(hip_device, C.c_void_p(raw.ctypes.data), C.c_void_p(d.device_results_ptr()), raw.nbytes))
             assert raw.tobytes() == _to96(want.rec).tobytes()
         with hip.DeviceBatch(batch, hip_device, sso) as d:
             assert d.result_bytes() == 128

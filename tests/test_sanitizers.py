@@ -76,4 +76,10 @@ def test_packed_encoder_under_thread_sanitizer(tmp_path):
                        text=True, timeout=600)
     assert r.returncode == 0 and "ThreadSanitizer" not in r.stderr, (r.stdout[-1000:], r.stderr[-3000:])
     lines = r.stdout.strip().splitlines()
+    ranged, lines = lines[:2], lines[2:]
+    # the ranged form: every unit and slot handed over exactly once, in ten ranges; a refused range stops the call with its code
+    assert ranged[0].startswith("ranged 0 rc 0 units 20000 ") and ranged[0].endswith("calls 10"), ranged
+    slots, of = (int(x) for x in ranged[0].split(" slots ")[1].split(" calls ")[0].split(" of "))
+    assert slots == of > 0
+    assert ranged[1].startswith("ranged 1 rc -7 units 4096 "), ranged
     assert len(lines) == 5 and all(" rc 0 " in l for l in lines[:3]) and all("rec_offset not monotone" in l for l in lines[3:]), lines
