@@ -271,7 +271,8 @@ struct WindowCtx {
     uint32_t vl_or_never;  // DEL ? var_length : 0x80000000 - key_min is added per library
     uint32_t wt0, wt1;
     uint32_t wh0;          // LDS address of w_alt_hi[del16]
-    double pos_delta_d;
+    uint32_t gated;        // bit l: the small-deletion gate of classic.py:339,383 is closed for the window's l-th library (DEL and
+                           // pos_delta < 2 sd of that library) -- per unit and library, so it is formed once per unit, not per record
     bool is_del;
 };
 
@@ -290,8 +291,7 @@ __device__ __forceinline__ void record_window(const u32x4 w, const bool mine, co
     const uint32_t la = c.winlibs_at + min(SVT_REC_LIB(w.w) - c.lib_lo, c.lib_last) * (uint32_t)sizeof(WinLib);
 #endif
     const u32x4 d = *reinterpret_cast<lds_cu32x4*>((size_t)la);          // kmin, nb, thr_at, hist_at
-    const double sd2 = lds_f64(la + 16u);
-    const bool small_del = c.is_del && (c.pos_delta_d < sd2);             // classic.py:339,383
+    const bool small_del = ((c.gated >> min(SVT_REC_LIB(w.w) - c.lib_lo, c.lib_last)) & 1u) != 0u;   // classic.py:339,383
     const uint32_t f3 = small_del ? 0u : (w.w & 7u);
     const uint32_t sub2 = c.is_del ? c.vl_or_never + d.x : 0x80000000u;
     const uint32_t i1 = min(w.x - d.x, d.y), i2 = min(w.x - sub2, d.y);
@@ -528,8 +528,12 @@ __global__ __launch_bounds__(kBlock, MODE == kSingleLds ? SVT_STREAM_WAVES : MOD
         wc.wt0 = sc.wt0;
         wc.wt1 = sc.wt1;
         wc.wh0 = sc.wh0;
-        wc.pos_delta_d = c.pos_delta_d;
         wc.is_del = c.is_del;
+        wc.gated = 0u;
+        if (MODE == kMultiLds && c.is_del) {   // (the host keeps windows of more than 32 libraries out of this mode)
+            for (uint32_t l = 0; l < wd.lib_cnt; ++l)
+                wc.gated |= (c.pos_delta_d < reinterpret_cast<const WinLib*>(smem + a.lds_winlibs)[l].sd2 ? 1u : 0u) << l;
+        }
         Acc acc = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
 
         // EDGE = false: every lane's eight records of this block are its own

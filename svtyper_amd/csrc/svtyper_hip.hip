@@ -473,7 +473,8 @@ int create_stream(const svt_evidence_batch* in, svt_batch* b, void* d_records_re
     const bool single = in->n_libs == 1 && T.fast_geometry && T.narrow_bins && single_lds + kWavesPerBlock * kStreamRingBytes <= 96 * 1024 &&
                         !(b->flags & SVT_FLAG_GENERAL_TABLES);
     const size_t window_lds = kSBins + (((size_t)max_win_bins * kLdsBin + 15) & ~size_t(15)) + (size_t)max_win_libs * sizeof(WinLib);
-    windowed = windowed && T.narrow_bins && window_lds + kWavesPerBlock * kStreamRingBytes <= kStreamLdsPerWg2;
+    // (a window of more than 32 libraries: the kernel keeps one small-deletion gate bit per library of the window in a register)
+    windowed = windowed && T.narrow_bins && max_win_libs <= 32 && window_lds + kWavesPerBlock * kStreamRingBytes <= kStreamLdsPerWg2;
     b->mode = single ? kSingleLds : windowed ? kMultiLds : kGeneral;
     // units that already come grouped by window (a sample-major batch, a one-window batch) need no permutation:
     // the kernel then walks the units themselves (no index loads in front of every unit header)
