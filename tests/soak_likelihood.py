@@ -100,8 +100,14 @@ while time.time() - t0 < budget:
         with packed:
             n_packed += 1
             for flags in (0, ev.FLAG_SSO_ASSOCIATION):
-                if hip.genotype_packed(packed, 0, flags).rec.tobytes() != hip.genotype_batch(b, 0, flags).rec.tobytes():
+                ref_bytes = hip.genotype_batch(b, 0, flags).rec.tobytes()
+                if hip.genotype_packed(packed, 0, flags).rec.tobytes() != ref_bytes:
                     print("PACKED MISMATCH at iteration %d (kind %d, %d libs, flags %d)" % (it, kind, n_libs, flags))
+                    sys.exit(1)
+                # the route that encodes ahead of the wire (ranges of whole units; small batches take the plain sequence)
+                os.environ["SVT_PACK_RANGE_UNITS"] = str(int(rng.choice([256, 4096, 33000, 70000])))
+                if hip.genotype_packed_from_records(b, 0, flags | (ev.FLAG_RESULT96 if it % 2 else 0)).rec.tobytes() != ref_bytes:
+                    print("PACKED-FROM-RECORDS MISMATCH at iteration %d (kind %d, flags %d, ranges of %s units)" % (it, kind, flags, os.environ["SVT_PACK_RANGE_UNITS"]))
                     sys.exit(1)
     it += 1
     units += b.n_units
