@@ -407,10 +407,11 @@ def main():
     ap.add_argument("--workload", default="c3_mixed_1m", choices=["c3_mixed_1m", "c2_del_100k", "c5_multisample"])
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--sso", action="store_true", help="singlesample.py floating-point association")
-    ap.add_argument("--result-bytes", type=int, default=128, choices=[96, 128],
-                    help="device result record: 128 = svt_result, one full cache line per unit; 96 = SVT_FLAG_RESULT96, the record of SURVEY "
-                         "8(d) (the host restores the counts that follow from the tallies: same svt_result records on the host) -- a quarter "
-                         "fewer bytes written and gathered, but part-line writes: the pass itself is 3-4 %% SLOWER (`result96` leg) [128]")
+    ap.add_argument("--result-bytes", type=int, default=96, choices=[96, 128],
+                    help="device result record: 96 = SVT_FLAG_RESULT96, the record of SURVEY 8(d) plus the index of its unit, written in "
+                         "the order the kernel finishes the units (a wave's 64 records = 6 KB of whole lines; the host puts every record "
+                         "where its tag says and restores the counts that follow from the tallies: the same svt_result records); "
+                         "128 = svt_result in unit order, one cache line per unit (`result128` leg) [96]")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true", help="headline only (N=1: no sso / c5 / shard / one_shot / packed / large legs)")
     ap.add_argument("--legs", default="all", help="comma list of the extra N=1 legs to run: " + ",".join(LEGS) + " [all]")
@@ -524,7 +525,7 @@ def main():
     res_buf = dbatch.device_results_tensor()
     rec_bytes = dbatch.result_bytes()
     assert rec_bytes == args.result_bytes and res_buf.data_ptr() % 128 == 0 and res_buf.numel() >= n * rec_bytes
-    cur = n * rec_bytes
+    cur = dbatch.result_slots() * rec_bytes        # (96-byte records: whole workgroups' worth of tagged slots, >= n)
 
     def barrier():
         if use_dist:
@@ -565,14 +566,18 @@ def main():
         torch.cuda.synchronize()
         g0 = time.perf_counter()
         # (ranks sharing a device: the records come down to the host first and travel over gloo)
-        gathered = D.gather_result_records(res_buf[:cur] if backend == "nccl" else res_buf[:cur].cpu(), counts, dst=0, rec_bytes=rec_bytes)
+        local_buf = res_buf[:cur] if backend == "nccl" else res_buf[:cur].cpu()
+        if rec_bytes == 96:
+            gathered, g_sizes = D.gather_tagged_records(local_buf, dst=0)
+        else:
+            gathered, g_sizes = D.gather_result_records(local_buf, counts, dst=0), [c * rec_bytes for c in counts]
         torch.cuda.synchronize()
         barrier()
         g_s = time.perf_counter() - g0
         if rank == 0:
-            assert gathered.numel() == sum(counts) * rec_bytes
+            assert gathered.numel() == sum(g_sizes) >= sum(counts) * rec_bytes
         gather = {"bytes_per_rank": int(cur), "record_bytes": rec_bytes, "ms": g_s * 1e3,
-                  "GB/s_into_root": sum(counts[1:] or counts) * rec_bytes / g_s / 1e9,
+                  "GB/s_into_root": sum(g_sizes[1:] or g_sizes) / g_s / 1e9,
                   "collective": "rccl gather" if backend == "nccl" else "gloo gather (ranks share %d device(s))" % n_dev,
                   "backend": backend, "units_per_rank": counts,
                   # how many ranks the RCCL communicator of this run actually spanned (0: no RCCL in this run)
@@ -582,7 +587,9 @@ def main():
             with hip.DeviceBatch(total, device=local_rank, flags=flags) as d_all:
                 d_all.genotype(sync=True)
                 alone = d_all.results().rec
-            same = bool(np.array_equal(D.results_from_bytes(gathered, rec_bytes).rec, alone))
+            joined = D.results_from_tagged(gathered, g_sizes, counts) if rec_bytes == 96 else D.results_from_bytes(gathered)
+            same = bool(np.array_equal(joined.rec, alone))
+            del joined
             gather["equals_single_rank_pass"] = same
             assert same, "the gathered result records differ from the single-rank pass over the same workload"
             del alone
@@ -623,6 +630,9 @@ def main():
                 "total_units": total_units,
                 "association": "sso" if args.sso else "classic",
                 "device_result_record_bytes": rec_bytes,
+                "device_result_records": ("SVT_FLAG_RESULT96: the 96-byte record of SURVEY 8(d) + the unit's index, in the order the kernel "
+                                          "finishes the units; svt_batch_results returns svt_result[n] in unit order" if rec_bytes == 96
+                                          else "svt_result, 128 bytes, unit order"),
                 "step": "one launch of svt_stream_kernel over the canonical CSR records resident in HBM -> result records "
                         "in HBM (whole hot path; nothing pre-digested outside the timed region)",
                 "device_layout": "the canonical CSR records as uploaded, streamed by the pass itself",
@@ -909,21 +919,23 @@ def main():
             except Exception as e:
                 out["roofline"]["placement"] = {"error": repr(e)}
 
-        if "r96" in legs and not r96:
-            # ---- the same launch writing the 96-byte record of SURVEY 8(d) (SVT_FLAG_RESULT96): 25 % fewer bytes written, but a
-            # unit's record is then three 32-byte sectors of a line it shares with its neighbours, which other waves write at other times
+        if "r96" in legs:
+            # ---- the same launch with the other form of device result record (headline: 96-byte tagged records in the kernel's order
+            # unless --result-bytes 128; here: the other one)
+            other = 128 if r96 else 96
+            key = "result%d" % other
             try:
-                with hip.DeviceBatch(batch, device=local_rank, flags=flags | ev.FLAG_RESULT96) as d9:
+                with hip.DeviceBatch(batch, device=local_rank, flags=(flags & ~ev.FLAG_RESULT96) | (0 if r96 else ev.FLAG_RESULT96)) as d9:
                     d9.genotype(sync=True)
                     same = bool(np.array_equal(d9.results().rec, got.rec))
                     r_ms = time_passes(d9, args.steps)
-                out["result96"] = {"what": "the headline's launch with SVT_FLAG_RESULT96: 96-byte device records, host results restored by svt_results_expand96",
-                                   "kernel_ms": r_ms, "frac": alg_bytes / (r_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "device_record_bytes": 96,
-                                   "bytes_written_per_launch": 96 * n, "host_results_equal_headline": same,
-                                   "note": "fewer bytes, slower pass (part-line writes): in-process A/B over the same buffers 0.3353 vs 0.3211 ms "
-                                           "(profiles/r04_ab_inproc_result96.txt); the flag pays where the records cross PCIe or xGMI, not in the pass"}
+                    slots9 = d9.result_slots()
+                out[key] = {"what": "the headline's launch writing %d-byte device result records (%s)" % (
+                                other, "svt_result, unit order, one line per unit" if other == 128 else "SVT_FLAG_RESULT96: tagged, in the kernel's order"),
+                            "kernel_ms": r_ms, "frac": alg_bytes / (r_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "device_record_bytes": other,
+                            "bytes_written_per_launch": other * slots9, "host_results_equal_headline": same}
             except Exception as e:
-                out["result96"] = {"error": repr(e)}
+                out[key] = {"error": repr(e)}
 
         if c5_sample_major is not None:
             # ---- BASELINE.json configs[4] shape at its per-GPU size: (site, sample) units, 32 samples, per-sample libraries.

@@ -66,11 +66,15 @@ extern "C" {
  * measurements and for tests that compare the table paths.  Results are the same.                              */
 #define SVT_FLAG_GENERAL_TABLES 0x10u
 /* the pass writes 96-byte result records on the device (svt_result96: the record of SURVEY.md section 8(d) -- GL, SQ, the
- * five tallies, QR / QA / GQ, GT) instead of 128-byte ones: a quarter fewer bytes written per unit and moved by the final
- * gather.  The eight counts it leaves out are truncations of sums of the tallies (classic.py:455-469) and are restored
- * on the host: svt_batch_results / svt_genotype still fill svt_result[n_units], bit for bit the same; only a caller that
- * reads the DEVICE records itself (svt_batch_device_results, svt_batch_bind_device_results, the RCCL gather) sees the
- * 96-byte form -- svt_batch_result_bytes tells which -- and expands gathered records with svt_results_expand96.   */
+ * five tallies, QR / QA / GQ, GT -- plus the index of the unit it belongs to) instead of 128-byte ones, IN THE ORDER THE KERNEL
+ * FINISHES THEM: a workgroup sorts its units by length, and a wave's 64 records leave as 6 KB of whole cache lines, tagged,
+ * instead of as 64 part-line writes at their units' positions (96-byte records in unit order were measured 4 % SLOWER than
+ * 128-byte ones; in the kernel's order they are 2-4 % faster and a quarter fewer bytes).  The eight counts the record leaves
+ * out are truncations of sums of the tallies (classic.py:455-469).  svt_batch_results / svt_genotype still fill
+ * svt_result[n_units] in unit order, bit for bit the same: they put every record where its tag says and restore the counts.
+ * Only a caller that reads the DEVICE records itself (svt_batch_device_results, svt_batch_bind_device_results, the RCCL
+ * gather) sees this form: svt_batch_result_slots() records of svt_batch_result_bytes() bytes, some of them padding
+ * (unit == SVT_NO_UNIT); svt_results_expand96 turns gathered records into svt_result[].                                */
 #define SVT_FLAG_RESULT96 0x20u
 /* (bits 1..3 selected round 1's tiled device layouts, which are gone: they are rejected as unknown bits.)
  * Device layout of a resident batch: nothing is re-tiled or re-encoded -- the CSR arrays go to HBM as the
@@ -283,13 +287,17 @@ typedef struct svt_result {
 
 /* ---- the same record without the counts that follow from the tallies, 96 B (SVT_FLAG_RESULT96): bytes 0..83 are
  * bytes 0..83 of svt_result (gl, sq, tallies, QR, QA, GQ), byte 84 is gt ------------------------------------------ */
+#define SVT_NO_UNIT 0xFFFFFFFFu    /* svt_result96.unit of a padding record */
 typedef struct svt_result96 {
     double gl[3];
     double sq;
     double tallies[SVT_N_TALLIES];
     int32_t qr, qa, gq;           /* counts[SVT_CNT_QR], counts[SVT_CNT_QA], counts[SVT_CNT_GQ] */
     int8_t gt;
-    uint8_t pad[11];              /* zero                                                      */
+    uint8_t pad[3];               /* zero                                                      */
+    uint32_t unit;                /* where the record belongs: index into the results in unit order (with
+                                     svt_batch_result_order: the site-major index), SVT_NO_UNIT = padding   */
+    uint32_t pad2;                /* zero                                                      */
 } svt_result96;
 
 typedef struct svt_batch svt_batch; /* opaque: device-resident packed batch */
@@ -345,10 +353,17 @@ int svt_batch_bind_device_results(svt_batch* b, svt_result* dev_ptr);
  * (what svt_batch_device_results points at, what a buffer for svt_batch_bind_device_results must hold per unit). */
 uint32_t svt_batch_result_bytes(const svt_batch* b);
 
-/* 96-byte records (host memory; e.g. gathered from several devices) -> svt_result[n]: DP, RO, AO, RS, AS, ASC, RP, AP are
- * the reference's own expressions over the tallies (classic.py:455-469: int() of the sums, in its order of additions),
- * zero for blank / skipped units as the 128-byte path leaves them.  Host only, no device needed.  `in` and `out` may not overlap. */
-int svt_results_expand96(const svt_result96* in, uint64_t n_units, svt_result* out);
+/* Records in the device result buffer of this batch: n_units, or under SVT_FLAG_RESULT96 the slots the pass's workgroups
+ * write (whole workgroups: >= n_units, padding records included).  A buffer for svt_batch_bind_device_results holds
+ * svt_batch_result_slots(b) * svt_batch_result_bytes(b) bytes.                                                       */
+uint64_t svt_batch_result_slots(const svt_batch* b);
+
+/* 96-byte records (host memory; e.g. gathered from several devices) -> svt_result[n_units]: record i goes to out[in[i].unit]
+ * (padding records are skipped); DP, RO, AO, RS, AS, ASC, RP, AP are the reference's own expressions over the tallies
+ * (classic.py:455-469: int() of the sums, in its order of additions), zero for blank / skipped units as the 128-byte path
+ * leaves them.  SVT_ERR_INVALID when a tag is >= n_units or the records do not cover every unit exactly once.
+ * Host only, no device needed.  `in` and `out` may not overlap.                                                      */
+int svt_results_expand96(const svt_result96* in, uint64_t n_records, svt_result* out, uint64_t n_units);
 
 /* Result order for a SAMPLE-MAJOR batch.  A joint run over several samples has one unit per (site, sample).  The
  * reference walks them site-major (classic.py:279: for every variant, for every sample), and that is the order

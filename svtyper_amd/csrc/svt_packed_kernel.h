@@ -36,7 +36,8 @@ struct PackedArgs {
     uint32_t unit_end;
     uint64_t n_units;
     svt_result* out;
-    uint32_t result96;            // SVT_FLAG_RESULT96: `out` holds 96-byte records
+    uint32_t result96;            // SVT_FLAG_RESULT96: `out` holds tagged 96-byte records in the workgroups' order
+    uint32_t slot_begin;          // ... the first of them this launch writes
     LibDesc lib0;
     GtConsts c;
 };
@@ -171,8 +172,13 @@ __global__ __launch_bounds__(kBlock, 3) void svt_packed_kernel(const PackedArgs 
         uint4 piece[8];
         unit_epilogue(acc, (uint32_t)U.svtype, (uint32_t)U.flags, a.c, reinterpret_cast<const double*>(smem + a.lds_l10), a.l10,
                       a.l10_where == kL10Shared ? a.n_l10 : 0u, piece);
-        if (a.result96) piece[5] = make_uint4(piece[5].x, piece[7].y, 0u, 0u);   // svt_result96: {GQ, GT} behind QR / QA
-        store_result_records_through_ring(ring, piece, unit, lane, reinterpret_cast<unsigned char*>(a.out), a.result96 ? 6u : 8u);
+        // svt_result96: {GQ, GT, unit} behind QR / QA; the tile's records leave in the tile's own order (svt_stream_kernel.h)
+        uint32_t tile_slot = 0xFFFFFFFFu;
+        if (a.result96) {
+            piece[5] = make_uint4(piece[5].x, piece[7].y, unit, 0u);
+            tile_slot = a.slot_begin + blockIdx.x * (uint32_t)(kBlock * R) + ((uint32_t)r * kWavesPerBlock + ((r & 1) ? (uint32_t)kWavesPerBlock - 1u - wave : wave)) * kWave;
+        }
+        store_result_records_through_ring(ring, piece, unit, lane, reinterpret_cast<unsigned char*>(a.out), a.result96 ? 6u : 8u, tile_slot);
     }
 }
 

@@ -273,7 +273,8 @@ __device__ __forceinline__ void store_results_through_ring(unsigned char* ring, 
 // hoist their common parts in front of it and cost the kernel 30 VGPRs.  The P pieces of a unit leave through P consecutive
 // lanes, 64 units in P store instructions; a 96-byte record starts on a 32-byte boundary, so whole 32-byte sectors are written.
 __device__ __forceinline__ void store_result_records_through_ring(unsigned char* ring, const uint4 (&piece)[8], const uint32_t unit,
-                                                                  const uint32_t lane, unsigned char* __restrict__ out, const uint32_t P)
+                                                                  const uint32_t lane, unsigned char* __restrict__ out, const uint32_t P,
+                                                                  const uint32_t sorted_base = 0xFFFFFFFFu)
 {
     const uint32_t sw = (lane >> 1) & 7u;
     uint4* st = reinterpret_cast<uint4*>(ring + lane * 128u);
@@ -293,6 +294,11 @@ __device__ __forceinline__ void store_result_records_through_ring(unsigned char*
         const uint32_t idx = (uint32_t)i * kWave + lane, u = P == 8u ? idx >> 3 : idx / 6u, p = idx - u * P;
         const uint32_t dst_unit = (uint32_t)__shfl((int)unit, (int)u, kWave);
         const uint4 v = *reinterpret_cast<const uint4*>(ring + u * 128u + ((p ^ ((u >> 1) & 7u)) << 4));
+        if (sorted_base != 0xFFFFFFFFu) {
+            // the tile's 64 records in the tile's own (length-sorted) order: one store instruction writes 1 KB of whole lines
+            store_piece(reinterpret_cast<uint4*>(out + (uint64_t)sorted_base * stride) + idx, v);
+            continue;
+        }
         if (dst_unit != kPadUnit) store_piece(reinterpret_cast<uint4*>(out + (uint64_t)dst_unit * stride) + p, v);
     }
 }

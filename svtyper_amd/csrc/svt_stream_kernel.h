@@ -136,7 +136,8 @@ struct StreamArgs {
     uint32_t lds_winlibs;        // byte offset of the WinLib descriptors (after the bins)
     uint32_t unit_begin;         // this launch covers units [unit_begin, unit_end) (the pipelined one-shot launches
     uint32_t unit_end;           // one range per uploaded piece; a pass over a resident batch: [0, n_units))
-    uint32_t result96;           // SVT_FLAG_RESULT96: `out` holds 96-byte records (svt_result96)
+    uint32_t result96;           // SVT_FLAG_RESULT96: `out` holds 96-byte records (svt_result96) in the workgroups' own order, tagged with their unit
+    uint32_t slot_begin;         // ... the first of them this launch writes (workgroup w of the launch: slot_begin + w * 256 * R)
     uint32_t out_samples;        // svt_batch_result_order: > 1 = the units are sample-major (unit = sample * out_sites + site) and the
     uint32_t out_sites;          // result record of a unit goes to index site * out_samples + sample (site-major); 0 = unit order
     LibDesc lib0;
@@ -703,16 +704,14 @@ __global__ __launch_bounds__(kBlock, MODE == kSingleLds ? SVT_STREAM_WAVES : MOD
 #if SVT_STORE_DIRECT
             store_results_through_ring(ring, piece, unit_out, lane, a.out);
 #else
-            // svt_result96: GL, SQ, tallies, QR, QA | GQ, GT -- pieces 0-4 as they are, piece 5 = {GQ, GT, 0, 0}
-#if SVT_STORE_SPECIAL128
+            // svt_result96: GL, SQ, tallies, QR, QA | GQ, GT, unit -- pieces 0-4 as they are, piece 5 = {GQ, GT, unit, 0}; the tile's 64
+            // records go to the tile's own 6 KB of the result buffer, in the tile's (length-sorted) order
+            uint32_t tile_slot = 0xFFFFFFFFu;
             if (a.result96) {
-                piece[5] = make_uint4(piece[5].x, piece[7].y, 0u, 0u);
-                store_result_records_through_ring(ring, piece, unit_out, lane, reinterpret_cast<unsigned char*>(a.out), 6u);
-            } else store_results_through_ring(ring, piece, unit_out, lane, a.out);
-#else
-            if (a.result96) piece[5] = make_uint4(piece[5].x, piece[7].y, 0u, 0u);
-            store_result_records_through_ring(ring, piece, unit_out, lane, reinterpret_cast<unsigned char*>(a.out), a.result96 ? 6u : 8u);
-#endif
+                piece[5] = make_uint4(piece[5].x, piece[7].y, unit_out, 0u);   // (a padding lane: unit_out == kPadUnit == SVT_NO_UNIT)
+                tile_slot = a.slot_begin + blockIdx.x * kUnitsPerWg + ((uint32_t)r * kWavesPerBlock + ((r & 1) ? (uint32_t)kWavesPerBlock - 1u - wave : wave)) * kWave;
+            }
+            store_result_records_through_ring(ring, piece, unit_out, lane, reinterpret_cast<unsigned char*>(a.out), a.result96 ? 6u : 8u, tile_slot);
 #endif
         } else if (piece[0].x == 0x12345u && piece[2].y == 77u) a.out[unit].sq = 1.0;
     }

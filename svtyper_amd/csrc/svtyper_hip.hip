@@ -103,6 +103,8 @@ struct svt_batch {
     uint64_t cap_perm = 0;
     uint32_t n_chunks = 0;
     int window_tiles = 1;            // kMultiLds: 64-unit tiles per wave (chunks hold up to 256 * window_tiles units)
+    uint64_t out_slots = 0;          // records in the device result buffer after a pass: n_units, or (SVT_FLAG_RESULT96) the slots of
+                                     // the pass's workgroups -- tagged records in the kernel's order, padding included
     bool records_resident = true;    // false: create_stream left the record upload to its caller (pipelined one-shot)
     int wgs_per_cu = 3;              // workgroups per CU the pass's kernel was budgeted for (registers -> LDS per workgroup)
     StreamArgs sargs{};
@@ -205,6 +207,15 @@ int tiles_per_wave(const svt_batch* b, uint64_t units)
 //  a log10 table that does not fit beside the tables: 1 = its head through the wave's ring before each epilogue, 0 = all of it through L2
 #endif
 
+// result slots (SVT_FLAG_RESULT96: whole workgroups of tagged records) a launch over `units` units of this batch writes;
+// not the library-window mode, whose launch covers b->n_chunks window chunks
+uint64_t slots_of_launch(const svt_batch* b, uint64_t units)
+{
+    if (units == 0) return 0;
+    const uint64_t per_wg = b->layout == kLayoutPacked ? (uint64_t)kBlock : (uint64_t)kBlock * (uint64_t)tiles_per_wave(b, units);
+    return (units + per_wg - 1) / per_wg * per_wg;
+}
+
 int launch_stream(svt_batch* b, StreamArgs& a, hipStream_t stream)
 {
     const uint64_t units = (uint64_t)a.unit_end - a.unit_begin;
@@ -216,14 +227,16 @@ int launch_stream(svt_batch* b, StreamArgs& a, hipStream_t stream)
     return SVT_OK;
 }
 
-// units [u0, u1) of a streamed layout (stream: not the library-window mode, whose launch covers window chunks)
-int launch_range(svt_batch* b, uint64_t u0, uint64_t u1, hipStream_t stream)
+// units [u0, u1) of a streamed layout (stream: not the library-window mode, whose launch covers window chunks);
+// slot_begin: where this launch's tagged result records start (SVT_FLAG_RESULT96; slots_of_launch(b, u1 - u0) of them)
+int launch_range(svt_batch* b, uint64_t u0, uint64_t u1, hipStream_t stream, uint64_t slot_begin = 0)
 {
     if (u1 <= u0) return SVT_OK;
     if (b->layout == kLayoutPacked) {
         PackedArgs a = b->pargs;
         a.unit_begin = (uint32_t)u0;
         a.unit_end = (uint32_t)u1;
+        a.slot_begin = (uint32_t)slot_begin;
         const dim3 grid((unsigned)((u1 - u0 + kBlock - 1) / kBlock)), block(kBlock);
         void* params[] = {&a};
         const void* k = (b->flags & SVT_FLAG_SSO_ASSOCIATION) ? reinterpret_cast<const void*>(&svt_packed_kernel<true, 1>)
@@ -234,6 +247,7 @@ int launch_range(svt_batch* b, uint64_t u0, uint64_t u1, hipStream_t stream)
     StreamArgs a = b->sargs;
     a.unit_begin = (uint32_t)u0;
     a.unit_end = (uint32_t)u1;
+    a.slot_begin = (uint32_t)slot_begin;
     return launch_stream(b, a, stream);
 }
 
@@ -283,6 +297,28 @@ int check_stream_errors(svt_batch* b)
     HIP_TRY(hipMemcpyAsync(&bits, b->d_err, sizeof(uint32_t), hipMemcpyDeviceToHost, b->stream));
     HIP_TRY(hipStreamSynchronize(b->stream));
     return bits ? record_error(bits) : SVT_OK;
+}
+
+// the result buffer must hold `slots` device records of this batch's form (SVT_FLAG_RESULT96: whole workgroups of 96-byte
+// records, which for many small window chunks or many small launches can be more than n_units * 128 bytes)
+int ensure_result_slots(svt_batch* b, uint64_t slots)
+{
+    const uint64_t bytes = std::max<uint64_t>(slots, 1) * ((b->flags & SVT_FLAG_RESULT96) ? sizeof(svt_result96) : sizeof(svt_result));
+    if (bytes <= b->cap_out) return SVT_OK;
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    const bool bound = b->out_dev != b->d_out;
+    g_pool.put(b->device, b->d_out, b->cap_out);
+    b->d_out = nullptr;
+    b->cap_out = 0;
+    void* p = nullptr;
+    SVT_TRY(g_pool.get(b->device, bytes, &p, &b->cap_out));
+    b->d_out = static_cast<svt_result*>(p);
+    if (!bound) {
+        b->out_dev = b->d_out;
+        b->sargs.out = b->d_out;
+        b->pargs.out = b->d_out;
+    }
+    return SVT_OK;
 }
 
 // svt_batch_create for the streaming layout: validate the unit arrays, build the tables, put the canonical
@@ -562,8 +598,12 @@ int create_stream(const svt_evidence_batch* in, svt_batch* b, void* d_records_re
     a.n_units = n;
     a.unit_begin = 0;
     a.unit_end = (uint32_t)n;
-    a.out = b->d_out;
     a.result96 = (b->flags & SVT_FLAG_RESULT96) ? 1u : 0u;
+    a.slot_begin = 0;
+    b->out_dev = b->d_out;
+    b->out_slots = !a.result96 ? n : b->mode == kMultiLds ? (uint64_t)b->n_chunks * kBlock * (uint64_t)b->window_tiles : slots_of_launch(b, n);
+    SVT_TRY(ensure_result_slots(b, b->out_slots));
+    a.out = b->d_out;
     a.err = b->d_err;
     a.lib0 = T.libs[0];
     fill_gt_consts(a.c, in->split_weight, in->disc_weight);
@@ -840,8 +880,12 @@ int create_packed(const svt_packed_evidence* in, svt_batch* b, bool defer_slots 
     a.n_units = n;
     a.unit_begin = 0;
     a.unit_end = (uint32_t)n;
-    a.out = b->d_out;
     a.result96 = (b->flags & SVT_FLAG_RESULT96) ? 1u : 0u;
+    a.slot_begin = 0;
+    b->out_dev = b->d_out;
+    b->out_slots = a.result96 ? slots_of_launch(b, n) : n;
+    SVT_TRY(ensure_result_slots(b, b->out_slots));
+    a.out = b->d_out;
     a.lib0 = T.libs[0];
     fill_gt_consts(a.c, in->split_weight, in->disc_weight);
     b->out_dev = b->d_out;
@@ -896,7 +940,7 @@ inline uint32_t result_bytes(const svt_batch* b) { return (b->flags & SVT_FLAG_R
 // (classic.py:455-469; the additions in its order, -ffp-contract=off on the host as on the device), 0 for blank / skipped units
 inline void expand96_one(const svt_result96& r, svt_result& o)
 {
-    std::memcpy(&o, &r, 84);                     // gl, sq, tallies, QR, QA, GQ
+    std::memcpy(&o, &r, 84);                     // gl, sq, tallies, QR, QA, GQ (the tag is not part of svt_result)
     const double ref_seq = r.tallies[SVT_TAL_REF_SEQ], alt_seq = r.tallies[SVT_TAL_ALT_SEQ], alt_clip = r.tallies[SVT_TAL_ALT_CLIP],
                  ref_span = r.tallies[SVT_TAL_REF_SPAN], alt_span = r.tallies[SVT_TAL_ALT_SPAN];
     const bool counted = r.gt >= 0 || r.gt == SVT_GT_MISSING;   // (a blank or skipped unit leaves every count 0)
@@ -912,19 +956,44 @@ inline void expand96_one(const svt_result96& r, svt_result& o)
     std::memset(o.pad, 0, sizeof(o.pad));
 }
 
-// n records, `in` and `out` disjoint: split over the host threads
-inline void expand96(const svt_result96* in, uint64_t n, svt_result* out)
+// `n` tagged records -> out[tag] for the records that carry a unit (tags are taken relative to `out`, which holds `n_units`
+// records); `in` and `out` disjoint; split over the host threads.  What was placed is summed up so that the caller can tell
+// whether every unit was covered exactly once: the count and the sum of the tags must be those of 0 .. n_units - 1 (a missing
+// unit or one written twice changes one of them; a tag out of range is refused on the spot).
+struct Placed {
+    uint64_t count = 0, tag_sum = 0;
+    bool bad = false;
+    void add(const Placed& o) { count += o.count; tag_sum += o.tag_sum; bad = bad || o.bad; }
+    bool covers(uint64_t n_units) const { return !bad && count == n_units && tag_sum == (n_units ? n_units * (n_units - 1) / 2 : 0); }
+};
+
+inline Placed expand96(const svt_result96* in, uint64_t n, svt_result* out, uint64_t n_units)
 {
     const uint64_t kChunk = 8192;
     const uint64_t chunks = (n + kChunk - 1) / kChunk;
-    if (chunks <= 1) {
-        for (uint64_t i = 0; i < n; ++i) expand96_one(in[i], out[i]);
-        return;
-    }
-    parallel_for(chunks, [&](uint64_t c) {
+    std::atomic<uint64_t> count{0}, tag_sum{0};
+    std::atomic<bool> bad{false};
+    auto run = [&](uint64_t c) {
         const uint64_t hi = std::min(n, (c + 1) * kChunk);
-        for (uint64_t i = c * kChunk; i < hi; ++i) expand96_one(in[i], out[i]);
-    });
+        uint64_t mine = 0, sum = 0;
+        for (uint64_t i = c * kChunk; i < hi; ++i) {
+            const uint32_t u = in[i].unit;
+            if (u == SVT_NO_UNIT) continue;
+            if (u >= n_units) { bad.store(true, std::memory_order_relaxed); continue; }
+            expand96_one(in[i], out[u]);
+            ++mine;
+            sum += u;
+        }
+        count.fetch_add(mine, std::memory_order_relaxed);
+        tag_sum.fetch_add(sum, std::memory_order_relaxed);
+    };
+    if (chunks <= 1) { if (chunks) run(0); }
+    else parallel_for(chunks, run);
+    Placed p;
+    p.count = count.load();
+    p.tag_sum = tag_sum.load();
+    p.bad = bad.load();
+    return p;
 }
 
 // the batch's device result records -> out[n_units] (svt_result), whichever form the device holds
@@ -940,29 +1009,30 @@ int d2h_results(svt_batch* b, svt_result* out)
         }
         return d2h_staged(out, b->out_dev, n * sizeof(svt_result), b->stream);
     }
-    // 96-byte records: down through the pinned ring in pieces of whole records, expanded out of the ring slot (that copy
-    // out of the slot is there for pageable memory anyway; piece k is expanded while piece k + 1 is on the wire)
+    // tagged 96-byte records: down through the pinned ring in pieces of whole records, every record put where its tag says
+    // while the next piece is on the wire (that copy out of the ring slot is there for pageable memory anyway)
     StagingRing& ring = current_ring();
     std::lock_guard<std::mutex> guard(ring.lock);
     SVT_TRY(ring.ensure());
-    const uint64_t per_piece = StagingRing::kPiece / sizeof(svt_result96);
+    const uint64_t per_piece = StagingRing::kPiece / sizeof(svt_result96), total = b->out_slots;
     const unsigned char* src = reinterpret_cast<const unsigned char*>(b->out_dev);
-    uint64_t u = 0, prev_u = 0, prev_n = 0;
+    uint64_t s0 = 0, prev_n = 0;
     int slot = 0, prev_slot = -1;
-    while (u < n || prev_slot >= 0) {
+    Placed placed;
+    while (s0 < total || prev_slot >= 0) {
         uint64_t cnt = 0;
-        if (u < n) {
-            cnt = std::min(per_piece, n - u);
-            HIP_TRY(hipMemcpyAsync(ring.buf[slot], src + u * sizeof(svt_result96), cnt * sizeof(svt_result96), hipMemcpyDeviceToHost, b->stream));
+        if (s0 < total) {
+            cnt = std::min(per_piece, total - s0);
+            HIP_TRY(hipMemcpyAsync(ring.buf[slot], src + s0 * sizeof(svt_result96), cnt * sizeof(svt_result96), hipMemcpyDeviceToHost, b->stream));
         }
-        if (prev_slot >= 0) expand96(static_cast<const svt_result96*>(ring.buf[prev_slot]), prev_n, out + prev_u);
+        if (prev_slot >= 0) placed.add(expand96(static_cast<const svt_result96*>(ring.buf[prev_slot]), prev_n, out, n));
         HIP_TRY(hipStreamSynchronize(b->stream));
         prev_slot = cnt ? slot : -1;
-        prev_u = u;
         prev_n = cnt;
-        u += cnt;
+        s0 += cnt;
         slot = (slot + 1) % 2;
     }
+    if (!placed.covers(n)) return fail(SVT_ERR_INTERNAL, "the device result records do not cover every unit exactly once");
     return SVT_OK;
 }
 
@@ -981,31 +1051,41 @@ int run_pipelined(svt_batch* b, svt_result* out, bool* download_left, PayloadOf&
     // 96-byte device records: every piece comes down into a page-locked scratch as soon as its launch is through and is
     // expanded into the caller's array while the later pieces are still on their way
     struct Scratch { void* p = nullptr; ~Scratch() { g_pinned.put(p); } } scratch;
-    struct Piece { uint64_t u0, u1; hipEvent_t down; };
+    struct Piece { uint64_t u0, u1, s0, s1; hipEvent_t down; };
     std::vector<Piece> pieces;
-    if (r96 && n) {
-        scratch.p = g_pinned.get(n * sizeof(svt_result96));
-        if (!scratch.p) return fail(SVT_ERR_NOMEM, "page-locked scratch for the result records");
-    }
     StageTimer tm;
     static const uint64_t piece_mb = std::getenv("SVT_PIPE_MB") ? std::strtoull(std::getenv("SVT_PIPE_MB"), nullptr, 10) : 64;
     const uint64_t kPieceItems = (std::max<uint64_t>(piece_mb, 1) << 20) / 16;   // payload per piece (the staging ring's piece size)
-    uint64_t u0 = 0;
-    while (u0 < n) {
-        // the next piece: whole units up to kPieceItems of payload (at least one unit)
+    // the pieces: whole units up to kPieceItems of payload each (at least one unit); their tagged result records
+    // (SVT_FLAG_RESULT96) take whole workgroups' worth of slots per launch
+    uint64_t total_slots = 0;
+    for (uint64_t u0 = 0; u0 < n;) {
         uint64_t lo = u0 + 1, hi = n;
         const uint64_t want = payload_of(u0) + kPieceItems;
         while (lo < hi) {   // largest u1 with payload_of(u1) <= want
             const uint64_t mid = lo + (hi - lo + 1) / 2;
             if (payload_of(mid) <= want) lo = mid; else hi = mid - 1;
         }
-        const uint64_t u1 = lo;
+        const uint64_t slots = r96 ? slots_of_launch(b, lo - u0) : lo - u0;
+        pieces.push_back(Piece{u0, lo, total_slots, total_slots + slots, nullptr});
+        total_slots += slots;
+        u0 = lo;
+    }
+    if (r96 && n) {
+        if (total_slots >= 0xFFFFFFF0ull) return fail(SVT_ERR_INVALID, "too many result slots in one batch");
+        SVT_TRY(ensure_result_slots(b, total_slots));
+        b->out_slots = total_slots;
+        scratch.p = g_pinned.get(total_slots * sizeof(svt_result96));
+        if (!scratch.p) return fail(SVT_ERR_NOMEM, "page-locked scratch for the result records");
+    }
+    for (Piece& pc : pieces) {
+        const uint64_t u0 = pc.u0, u1 = pc.u1;
         SVT_TRY(upload(payload_of(u0), payload_of(u1)));
         hipEvent_t landed, done;
         SVT_TRY(ps.event(&landed));
         HIP_TRY(hipEventRecord(landed, b->stream));
         HIP_TRY(hipStreamWaitEvent(ps.compute, landed, 0));
-        SVT_TRY(launch_range(b, u0, u1, ps.compute));
+        SVT_TRY(launch_range(b, u0, u1, ps.compute, pc.s0));
         if (out_pinned) {
             SVT_TRY(ps.event(&done));
             HIP_TRY(hipEventRecord(done, ps.compute));
@@ -1015,23 +1095,22 @@ int run_pipelined(svt_batch* b, svt_result* out, bool* download_left, PayloadOf&
             SVT_TRY(ps.event(&done));
             HIP_TRY(hipEventRecord(done, ps.compute));
             HIP_TRY(hipStreamWaitEvent(ps.down, done, 0));
-            HIP_TRY(hipMemcpyAsync(static_cast<unsigned char*>(scratch.p) + u0 * sizeof(svt_result96),
-                                   reinterpret_cast<const unsigned char*>(b->out_dev) + u0 * sizeof(svt_result96),
-                                   (u1 - u0) * sizeof(svt_result96), hipMemcpyDeviceToHost, ps.down));
-            hipEvent_t down;
-            SVT_TRY(ps.event(&down));
-            HIP_TRY(hipEventRecord(down, ps.down));
-            pieces.push_back(Piece{u0, u1, down});
+            HIP_TRY(hipMemcpyAsync(static_cast<unsigned char*>(scratch.p) + pc.s0 * sizeof(svt_result96),
+                                   reinterpret_cast<const unsigned char*>(b->out_dev) + pc.s0 * sizeof(svt_result96),
+                                   (pc.s1 - pc.s0) * sizeof(svt_result96), hipMemcpyDeviceToHost, ps.down));
+            SVT_TRY(ps.event(&pc.down));
+            HIP_TRY(hipEventRecord(pc.down, ps.down));
         }
-        u0 = u1;
     }
     tm.mark("pipeline: pieces enqueued");
     // (96-byte records: piece k is expanded as soon as it is down, while the later pieces are still going up; should the pass
     // report a contract violation below, what was expanded is discarded with the error)
-    for (const Piece& pc : pieces) {
-        HIP_TRY(hipEventSynchronize(pc.down));
-        expand96(static_cast<const svt_result96*>(scratch.p) + pc.u0, pc.u1 - pc.u0, out + pc.u0);
-    }
+    Placed placed;
+    if (r96)
+        for (const Piece& pc : pieces) {
+            HIP_TRY(hipEventSynchronize(pc.down));
+            placed.add(expand96(static_cast<const svt_result96*>(scratch.p) + pc.s0, pc.s1 - pc.s0, out, n));
+        }
     HIP_TRY(hipStreamSynchronize(b->stream));
     tm.mark("pipeline: uploads done");
     HIP_TRY(hipStreamSynchronize(ps.compute));
@@ -1039,6 +1118,7 @@ int run_pipelined(svt_batch* b, svt_result* out, bool* download_left, PayloadOf&
     SVT_TRY(check_stream_errors(b));
     tm.mark("pipeline: passes done");
     if (r96) {
+        if (!placed.covers(n)) return fail(SVT_ERR_INTERNAL, "the device result records do not cover every unit exactly once");
     } else if (out_pinned) {
         HIP_TRY(hipStreamSynchronize(ps.down));
     } else {
@@ -1312,11 +1392,15 @@ int svt_batch_results(svt_batch* b, svt_result* out, uint64_t n_units)
 
 uint32_t svt_batch_result_bytes(const svt_batch* b) { return b ? result_bytes(b) : 0u; }
 
-int svt_results_expand96(const svt_result96* in, uint64_t n_units, svt_result* out)
+uint64_t svt_batch_result_slots(const svt_batch* b) { return b ? b->out_slots : 0; }
+
+int svt_results_expand96(const svt_result96* in, uint64_t n_records, svt_result* out, uint64_t n_units)
 {
     return guarded([&]() -> int {
-        if (n_units && (!in || !out)) return fail(SVT_ERR_INVALID, "null argument");
-        expand96(in, n_units, out);
+        if ((n_records && !in) || (n_units && !out)) return fail(SVT_ERR_INVALID, "null argument");
+        const Placed placed = expand96(in, n_records, out, n_units);
+        if (placed.bad) return fail(SVT_ERR_INVALID, "svt_results_expand96: a record's unit is beyond n_units");
+        if (!placed.covers(n_units)) return fail(SVT_ERR_INVALID, "svt_results_expand96: the records do not cover every unit exactly once");
         return SVT_OK;
     });
 }
@@ -1391,6 +1475,25 @@ static int svt_batch_site_qual_impl(svt_batch* b, uint32_t n_samples, const doub
     if (n_sites == 0) return SVT_OK;
     HIP_TRY(hipSetDevice(b->device));
     SVT_TRY(check_stream_errors(b));   // (after svt_batch_genotype(b, 0) / _n nobody has looked at the contract word yet)
+    if (b->flags & SVT_FLAG_RESULT96) {
+        // tagged records lie in the kernel's order, not site by site: QUAL is the same running sum (classic.py:485,498) over the
+        // records brought down and put in order
+        std::vector<svt_result> res(b->n_units);
+        HIP_TRY(hipStreamSynchronize(b->stream));
+        SVT_TRY(d2h_results(b, res.data()));
+        parallel_for((n_sites + 4095) / 4096, [&](uint64_t c) {
+            for (uint64_t site = c * 4096; site < std::min(n_sites, (c + 1) * 4096); ++site) {
+                double q = initial ? initial[site] : 0.0;
+                const svt_result* r = res.data() + site * n_samples;
+                for (uint32_t k = 0; k < n_samples; ++k) {
+                    if (r[k].gt >= 0) q += r[k].sq;
+                    else if (r[k].gt == SVT_GT_BLANK) q = 0.0;
+                }
+                qual_out[site] = q;
+            }
+        });
+        return SVT_OK;
+    }
     DevScratch d_init, d_qual;
     SVT_TRY(d_qual.alloc(n_sites * sizeof(double)));
     if (initial) {
@@ -1400,8 +1503,7 @@ static int svt_batch_site_qual_impl(svt_batch* b, uint32_t n_samples, const doub
         SVT_TRY(st.finish());
     }
     hipLaunchKernelGGL(svt_site_qual_kernel, dim3((unsigned)((n_sites + kBlock - 1) / kBlock)), dim3(kBlock), 0, b->stream,
-                       reinterpret_cast<const unsigned char*>(b->out_dev), result_bytes(b),
-                       (uint32_t)((b->flags & SVT_FLAG_RESULT96) ? offsetof(svt_result96, gt) : offsetof(svt_result, gt)), n_samples,
+                       reinterpret_cast<const unsigned char*>(b->out_dev), (uint32_t)sizeof(svt_result), (uint32_t)offsetof(svt_result, gt), n_samples,
                        initial ? d_init.as<double>() : nullptr, d_qual.as<double>(), n_sites);
     HIP_TRY(hipGetLastError());
     return d2h_staged(qual_out, d_qual.p, n_sites * sizeof(double), b->stream);
@@ -1674,13 +1776,14 @@ static int svt_genotype_packed_from_records_impl(const svt_evidence_batch* in, s
     shell.disc_weight = in->disc_weight;
     int rc = create_packed(&shell, b, /*defer_slots=*/true, /*defer_all=*/true, max_f);
 
-    struct Piece { uint64_t u0, u1; hipEvent_t down; };
+    struct Piece { uint64_t s0, s1; hipEvent_t down; };
     struct Ctx {
         svt_batch* b;
         svt_result* out;
         PipeStreams ps;
         bool out_pinned = false, r96 = false;
         void* scratch = nullptr;
+        uint64_t next_slot = 0, slot_cap = 0;
         std::vector<Piece> pieces;
         ~Ctx() { g_pinned.put(scratch); }
     } ctx;
@@ -1688,22 +1791,27 @@ static int svt_genotype_packed_from_records_impl(const svt_evidence_batch* in, s
     ctx.out = out;
     PackedArrays arr;
     bool overflow = false;
+    PackSink sink;
+    // four ranges: the last one's transfer is what stays exposed, and every range costs the encoder's threads three meetings
+    // (measured, 1 M units: 1 / 2 / 4 / 8 / 12 ranges -> 21.2 / 18.1 / 14.2 / 17.0 / 19.3 ms best, profiles/r04_packed_ranges.txt)
+    sink.range_units = std::max<uint64_t>(32768, (n + 3) / 4);
+    if (const char* e = std::getenv("SVT_PACK_RANGE_UNITS")) sink.range_units = std::max<uint64_t>(256, std::strtoull(e, nullptr, 10));
+    sink.range_units = (sink.range_units + 255) / 256 * 256;      // (the encoder's chunks)
     if (rc == SVT_OK) rc = g_handles.get_stream(&ctx.ps.compute);
     if (rc == SVT_OK) rc = g_handles.get_stream(&ctx.ps.down);
     if (rc == SVT_OK) {
         ctx.r96 = (flags & SVT_FLAG_RESULT96) != 0;
         ctx.out_pinned = !ctx.r96 && g_pinned.is_pinned(out, n * sizeof(svt_result));
-        if (ctx.r96) {
-            ctx.scratch = g_pinned.get(n * sizeof(svt_result96));
-            if (!ctx.scratch) rc = fail(SVT_ERR_NOMEM, "page-locked scratch for the result records");
+        if (ctx.r96) {   // tagged records: every launch writes whole workgroups' worth of slots
+            ctx.slot_cap = n + ((n + sink.range_units - 1) / sink.range_units + 1) * kBlock;
+            rc = ensure_result_slots(b, ctx.slot_cap);
+            if (rc == SVT_OK) {
+                ctx.scratch = g_pinned.get(ctx.slot_cap * sizeof(svt_result96));
+                if (!ctx.scratch) rc = fail(SVT_ERR_NOMEM, "page-locked scratch for the result records");
+            }
         }
     }
     if (rc == SVT_OK) {
-        PackSink sink;
-        // four ranges: the last one's transfer is what stays exposed, and every range costs the encoder's threads three meetings
-        // (measured, 1 M units: 1 / 2 / 4 / 8 / 12 ranges -> 21.2 / 18.1 / 14.2 / 17.0 / 19.3 ms best, profiles/r04_packed_ranges.txt)
-        sink.range_units = std::max<uint64_t>(32768, (n + 3) / 4);
-        if (const char* e = std::getenv("SVT_PACK_RANGE_UNITS")) sink.range_units = std::max<uint64_t>(256, std::strtoull(e, nullptr, 10));
         sink.slots_cap = slots_cap;
         sink.ctx = &ctx;
         sink.ready = [](void* vctx, const PackedArrays* a, uint64_t u0, uint64_t u1, uint64_t s0, uint64_t s1) -> int {
@@ -1720,7 +1828,10 @@ static int svt_genotype_packed_from_records_impl(const svt_evidence_batch* in, s
             SVT_TRY(c.ps.event(&landed));
             HIP_TRY(hipEventRecord(landed, b->stream));
             HIP_TRY(hipStreamWaitEvent(c.ps.compute, landed, 0));
-            SVT_TRY(launch_range(b, u0, u1, c.ps.compute));
+            const uint64_t r0 = c.next_slot, r1 = r0 + (c.r96 ? slots_of_launch(b, u1 - u0) : 0);
+            if (c.r96 && r1 > c.slot_cap) return fail(SVT_ERR_INTERNAL, "result slots of the ranges exceed their bound");
+            c.next_slot = r1;
+            SVT_TRY(launch_range(b, u0, u1, c.ps.compute, r0));
             if (c.out_pinned || c.r96) {
                 SVT_TRY(c.ps.event(&done));
                 HIP_TRY(hipEventRecord(done, c.ps.compute));
@@ -1728,12 +1839,12 @@ static int svt_genotype_packed_from_records_impl(const svt_evidence_batch* in, s
                 if (c.out_pinned)
                     HIP_TRY(hipMemcpyAsync(c.out + u0, b->out_dev + u0, (u1 - u0) * sizeof(svt_result), hipMemcpyDeviceToHost, c.ps.down));
                 else {
-                    HIP_TRY(hipMemcpyAsync(static_cast<unsigned char*>(c.scratch) + u0 * sizeof(svt_result96),
-                                           reinterpret_cast<const unsigned char*>(b->out_dev) + u0 * sizeof(svt_result96),
-                                           (u1 - u0) * sizeof(svt_result96), hipMemcpyDeviceToHost, c.ps.down));
+                    HIP_TRY(hipMemcpyAsync(static_cast<unsigned char*>(c.scratch) + r0 * sizeof(svt_result96),
+                                           reinterpret_cast<const unsigned char*>(b->out_dev) + r0 * sizeof(svt_result96),
+                                           (r1 - r0) * sizeof(svt_result96), hipMemcpyDeviceToHost, c.ps.down));
                     SVT_TRY(c.ps.event(&down));
                     HIP_TRY(hipEventRecord(down, c.ps.down));
-                    c.pieces.push_back(Piece{u0, u1, down});
+                    c.pieces.push_back(Piece{r0, r1, down});
                 }
             }
             return SVT_OK;
@@ -1749,7 +1860,10 @@ static int svt_genotype_packed_from_records_impl(const svt_evidence_batch* in, s
     if (rc == SVT_OK) {
         b->n_slots = arr.n_slots;
         b->have_results = true;
-        for (const Piece& pc : ctx.pieces) expand96(static_cast<const svt_result96*>(ctx.scratch) + pc.u0, pc.u1 - pc.u0, out + pc.u0);
+        b->out_slots = ctx.r96 ? ctx.next_slot : n;
+        Placed placed;
+        for (const Piece& pc : ctx.pieces) placed.add(expand96(static_cast<const svt_result96*>(ctx.scratch) + pc.s0, pc.s1 - pc.s0, out, n));
+        if (ctx.r96 && !placed.covers(n)) rc = fail(SVT_ERR_INTERNAL, "the device result records do not cover every unit exactly once");
         if (!ctx.out_pinned && !ctx.r96) rc = d2h_results(b, out);
     }
     g_pinned.put(arr.off);

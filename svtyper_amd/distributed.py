@@ -64,18 +64,44 @@ def gather_bytes(local, sizes: List[int], dst: int = 0):
     return torch.cat([o[:c] for o, c in zip(out, sizes)])
 
 
-def gather_result_records(local, counts: List[int], dst: int = 0, rec_bytes: int = ev.RESULT_DTYPE.itemsize):
-    """Gather every rank's result records (a uint8 torch tensor of n_local * rec_bytes bytes, on the
-    backend's device) onto `dst`; `counts` are records per rank.  rec_bytes: 128 (svt_result) or 96
-    (svt_result96, batches created with FLAG_RESULT96: a quarter fewer bytes through the collective)."""
-    return gather_bytes(local, [c * rec_bytes for c in counts], dst)
+def gather_result_records(local, counts: List[int], dst: int = 0):
+    """Gather every rank's result records (a uint8 torch tensor of n_local * 128 bytes, on the
+    backend's device) onto `dst`; `counts` are records per rank."""
+    rec = ev.RESULT_DTYPE.itemsize
+    return gather_bytes(local, [c * rec for c in counts], dst)
 
 
-def results_from_bytes(t, rec_bytes: int = ev.RESULT_DTYPE.itemsize) -> Results:
-    """uint8 tensor of result records (any device) -> Results on the host (96-byte records are expanded:
-    svt_results_expand96 restores the counts that follow from the tallies)."""
+def gather_tagged_records(local, dst: int = 0):
+    """The same for batches created with FLAG_RESULT96: a rank's device buffer holds result_slots() tagged 96-byte records in
+    the order its kernel finished them (a quarter fewer bytes through the collective).  How many each rank holds is only known
+    to that rank, so the sizes travel first (one tiny all_gather).  Returns (uint8 tensor, bytes per rank) on `dst`,
+    (None, sizes) elsewhere."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size()
+    mine = torch.tensor([local.numel()], dtype=torch.int64, device=local.device)
+    sizes = [torch.zeros(1, dtype=torch.int64, device=local.device) for _ in range(world)]
+    dist.all_gather(sizes, mine)
+    sizes = [int(x.item()) for x in sizes]
+    return gather_bytes(local, sizes, dst), sizes
+
+
+def results_from_bytes(t) -> Results:
+    """uint8 tensor of 128-byte result records (any device) -> Results on the host."""
     a = t.cpu().numpy()
-    if rec_bytes == ev.RESULT96_DTYPE.itemsize:
-        from . import hip
-        return hip.expand96(a)
     return Results(a.view(ev.RESULT_DTYPE).copy())
+
+
+def results_from_tagged(t, sizes: List[int], counts: List[int]) -> Results:
+    """The gathered tagged 96-byte records of all ranks (sizes[r] bytes from rank r, whose shard holds counts[r] units) ->
+    Results in unit order: every rank's records are put where their tags say, behind the units of the ranks before it."""
+    from . import hip
+    a = t.cpu().numpy()
+    out = Results.empty(sum(counts))
+    at = base = 0
+    for nbytes, n in zip(sizes, counts):
+        hip.expand96(a[at:at + nbytes], n, out.rec[base:base + n])
+        at += nbytes
+        base += n
+    return out

@@ -96,9 +96,11 @@ RESULT_DTYPE = np.dtype(
 )
 assert RESULT_DTYPE.itemsize == 128
 # the device record under FLAG_RESULT96 (svt_result96): svt_result without the counts that follow from the tallies
+# + the index of the unit it belongs to: the records lie in the order the kernel finishes them (whole cache lines per wave)
 RESULT96_DTYPE = np.dtype([("gl", "<f8", (3,)), ("sq", "<f8"), ("tallies", "<f8", (5,)), ("qr", "<i4"), ("qa", "<i4"), ("gq", "<i4"),
-                           ("gt", "i1"), ("pad", "u1", (11,))])
+                           ("gt", "i1"), ("pad", "u1", (3,)), ("unit", "<u4"), ("pad2", "<u4")])
 assert RESULT96_DTYPE.itemsize == 96
+NO_UNIT = 0xFFFFFFFF           # svt_result96.unit of a padding record
 
 
 # --------------------------------------------------------------------------- ctypes structs

@@ -25,7 +25,7 @@ EXPORTS = (
     "svt_batch_bind_device_results", "svt_batch_result_order", "svt_batch_bytes", "svt_batch_layout", "svt_batch_site_qual",
     "svt_batch_stream", "svt_batch_destroy", "svt_trim", "svt_bayes_gt", "svt_genotype_counts", "svt_genotype", "svt_genotype_multi", "svt_shard_bounds",
     "svt_pinned_alloc", "svt_pinned_free", "svt_pack_evidence", "svt_packed_free", "svt_batch_create_packed", "svt_genotype_packed",
-    "svt_format_results", "svt_format_free", "svt_results_host_sq", "svt_batch_result_bytes", "svt_results_expand96",
+    "svt_format_results", "svt_format_free", "svt_results_host_sq", "svt_batch_result_bytes", "svt_batch_result_slots", "svt_results_expand96",
     "svt_genotype_packed_from_records",
 )
 
@@ -88,7 +88,9 @@ def load() -> C.CDLL:
     L.svt_batch_result_bytes.restype = C.c_uint32
     L.svt_batch_result_bytes.argtypes = [C.c_void_p]
     L.svt_results_expand96.restype = C.c_int
-    L.svt_results_expand96.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p]
+    L.svt_results_expand96.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64]
+    L.svt_batch_result_slots.restype = C.c_uint64
+    L.svt_batch_result_slots.argtypes = [C.c_void_p]
     L.svt_batch_layout.restype = C.c_int
     L.svt_batch_layout.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.svt_batch_bytes.restype = C.c_int
@@ -349,6 +351,11 @@ class DeviceBatch:
         """bytes of one DEVICE result record: 128 (svt_result), or 96 under FLAG_RESULT96 (svt_result96)"""
         return int(self._lib.svt_batch_result_bytes(self._h))
 
+    def result_slots(self) -> int:
+        """records in the device result buffer: n_units, or under FLAG_RESULT96 the slots of the pass's workgroups (tagged
+        records in the kernel's order, padding records included)"""
+        return int(self._lib.svt_batch_result_slots(self._h))
+
     def device_results_ptr(self) -> int:
         """Device address of the svt_result[n_units] array the kernel writes to."""
         p = C.c_void_p()
@@ -374,7 +381,7 @@ class DeviceBatch:
         class _View:
             pass
         v = _View()
-        v.__cuda_array_interface__ = {"shape": (max(self.n_units, 1) * self.result_bytes(),), "typestr": "|u1",
+        v.__cuda_array_interface__ = {"shape": (max(self.result_slots(), 1) * self.result_bytes(),), "typestr": "|u1",
                                       "data": (self.device_results_ptr(), False), "version": 2}
         v._svt_batch = self          # storage -> v -> batch
         t = torch.as_tensor(v, device=torch.device("cuda", getattr(self, "device", 0)))
@@ -442,17 +449,24 @@ class DeviceBatch:
         self.close(force=exc[0] is not None)   # (never mask the exception that is leaving the block)
 
 
-def expand96(records) -> Results:
-    """svt_results_expand96: 96-byte device records (a uint8 / RESULT96_DTYPE array in host memory, e.g. gathered from
-    several ranks) -> Results with the eight derived counts restored (classic.py:455-469)."""
-    from .evidence import RESULT96_DTYPE
+def expand96(records, n_units: int, out_rec=None) -> Results:
+    """svt_results_expand96: tagged 96-byte device records (a uint8 / RESULT96_DTYPE array in host memory, e.g. one rank's part
+    of a gather) -> `n_units` results in unit order, the eight derived counts restored (classic.py:455-469).  `out_rec`: a
+    RESULT_DTYPE array (view) of n_units records to fill instead of a fresh Results."""
+    from .evidence import RESULT96_DTYPE, RESULT_DTYPE
     a = np.ascontiguousarray(records).view(np.uint8).reshape(-1)
     if a.size % RESULT96_DTYPE.itemsize:
         raise ValueError("not a whole number of 96-byte result records")
-    n = a.size // RESULT96_DTYPE.itemsize
-    out = Results.empty(n)
-    _check(load().svt_results_expand96(C.c_void_p(a.ctypes.data), n, C.c_void_p(out.ptr())))
-    return out
+    n_rec = a.size // RESULT96_DTYPE.itemsize
+    if out_rec is None:
+        res = Results.empty(n_units)
+        out_rec = res.rec
+    else:
+        res = None
+        if out_rec.dtype != RESULT_DTYPE or out_rec.shape != (n_units,) or not out_rec.flags.c_contiguous:
+            raise ValueError("out_rec must be a contiguous RESULT_DTYPE array of n_units records")
+    _check(load().svt_results_expand96(C.c_void_p(a.ctypes.data), n_rec, C.c_void_p(out_rec.ctypes.data), int(n_units)))
+    return res if res is not None else Results(out_rec)
 
 
 def host_sq(results: Results) -> Results:

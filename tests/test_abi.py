@@ -90,14 +90,14 @@ def test_struct_layouts_match_the_header(tmp_path):
         "svt_fragment_batch": ["n_units", "frag_offset", "breakpoints", "fragments", "n_libs", "libs", "split_weight",
                                "disc_weight", "min_aligned", "split_slop"],
         "svt_result": ["gl", "sq", "tallies", "counts", "gt", "pad"],
-        "svt_result96": ["gl", "sq", "tallies", "qr", "qa", "gq", "gt", "pad"],
+        "svt_result96": ["gl", "sq", "tallies", "qr", "qa", "gq", "gt", "pad", "unit", "pad2"],
     }
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "svtyper_hip.h"', 'int main(void) {']
     for name, fields in structs.items():
         lines.append('printf("%s %%zu\\n", sizeof(%s));' % (name, name))
         for f in fields:
             lines.append('printf("%s.%s %%zu\\n", offsetof(%s, %s));' % (name, f, name, f))
-    for macro in ("SVT_ABI_VERSION", "SVT_FLAG_SSO_ASSOCIATION", "SVT_FLAG_GENERAL_TABLES", "SVT_FLAG_RESULT96", "SVT_REC_LIB_SHIFT", "SVT_REC_CONTINUATION", "SVT_REC_HAS_PAIR"):
+    for macro in ("SVT_ABI_VERSION", "SVT_FLAG_SSO_ASSOCIATION", "SVT_FLAG_GENERAL_TABLES", "SVT_FLAG_RESULT96", "SVT_NO_UNIT", "SVT_REC_LIB_SHIFT", "SVT_REC_CONTINUATION", "SVT_REC_HAS_PAIR"):
         lines.append('printf("%s %%d\\n", (int)%s);' % (macro, macro))
     lines += ['return 0; }']
     src = tmp_path / "probe.c"
@@ -114,6 +114,7 @@ def test_struct_layouts_match_the_header(tmp_path):
     assert c["SVT_FLAG_RESULT96"] == ev.FLAG_RESULT96 and c["svt_result96"] == 96
     # the 96-byte record is svt_result's first 84 bytes + gt: what svt_results_expand96 and the kernel's store rely on
     assert c["svt_result96.qr"] == c["svt_result.counts"] == 72 and c["svt_result96.gt"] == 84 and c["svt_result.gt"] == 116
+    assert c["svt_result96.unit"] == 88 and c["SVT_NO_UNIT"] == ev.NO_UNIT - (1 << 32)
     dtypes = {"svt_record": ev.RECORD_DTYPE, "svt_unit": ev.UNIT_DTYPE, "svt_result": ev.RESULT_DTYPE, "svt_result96": ev.RESULT96_DTYPE,
               "svt_read_summary": geo.READ_DTYPE, "svt_piece_summary": geo.PIECE_DTYPE, "svt_fragment": geo.FRAGMENT_DTYPE,
               "svt_breakpoint": geo.BREAKPOINT_DTYPE}

@@ -53,7 +53,7 @@ def test_bench_line_has_the_contract_keys(hip_device):
     assert d["one_shot_packed"]["from_records_serial_wall_ms"] > d["one_shot_packed"]["wall_ms"]
     # the singlesample association, the configs[4] shape and the 8-GPU shard: own fractions, own (or no) traffic figures
     assert 0 < d["sso"]["frac"] <= 1.0 and d["sso"]["units"] == 30000
-    assert d["result96"]["host_results_equal_headline"] is True and 0 < d["result96"]["frac"] <= 1.0 and d["config"]["device_result_record_bytes"] == 128
+    assert d["result128"]["host_results_equal_headline"] is True and 0 < d["result128"]["frac"] <= 1.0 and d["config"]["device_result_record_bytes"] == 96
     c5 = d["c5_multisample"]
     assert c5["units"] == 60000 - 60000 % 32          # configs[4]'s per-GPU share is twice the headline's units
     assert 0 < c5["frac"] <= 1.0 and c5["table_mode"] == 1 and c5["units"] % 32 == 0 and c5["hintless"]["table_mode"] == 1 and c5["hintless"]["results_equal"] and c5["general_tables"]["table_mode"] == 2

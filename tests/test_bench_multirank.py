@@ -42,7 +42,7 @@ def _common(d, n, total_units):
     g = d["gather"]
     assert len(g["units_per_rank"]) == n and sum(g["units_per_rank"]) == total_units == d["config"]["total_units"]
     rb = d["config"]["device_result_record_bytes"]
-    assert g["record_bytes"] == rb and g["bytes_per_rank"] == rb * g["units_per_rank"][0]
+    assert g["record_bytes"] == rb and g["bytes_per_rank"] >= rb * g["units_per_rank"][0]      # (96: whole workgroups of tagged slots)
     shared = hip.device_count() < n
     assert d["shared_devices"] is shared
     assert g["backend"] == ("gloo" if shared else "nccl") and d["rccl_ranks"] == (0 if shared else n) == g["rccl_ranks"]
@@ -64,10 +64,10 @@ def test_weak_scaling_line(hip_device, n):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n,rec", [(2, 128), (8, 128), (2, 96)])
+@pytest.mark.parametrize("n,rec", [(2, 96), (8, 96), (2, 128)])
 def test_strong_scaling_gathers_the_single_rank_bytes(hip_device, n, rec):
     """configs[3] literally: ONE workload cut by distributed.shard_bounds; rank 0 runs it alone afterwards and compares the bytes
-    (rec = 96: SVT_FLAG_RESULT96 records through the gather, expanded on rank 0)"""
+    (rec = 96, the default: tagged SVT_FLAG_RESULT96 records through the gather, put in order and expanded on rank 0)"""
     d = _launch(n, ["--units", "40000", "--scaling", "strong", "--result-bytes", str(rec)])
     _common(d, n, 40000)
     assert d["gather"]["record_bytes"] == rec

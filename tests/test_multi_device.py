@@ -145,15 +145,20 @@ def _rank(rank, world, port, out_path, scenario="c3"):
         if scenario == "c5":
             assert d.table_mode() == 1
         assert d.result_bytes() == rec_bytes
-        buf = torch.zeros(max(1, shard.n_units) * rec_bytes, dtype=torch.uint8, device="cuda")
+        buf = torch.zeros(max(1, d.result_slots()) * rec_bytes, dtype=torch.uint8, device="cuda")
         d.bind_device_results(buf.data_ptr())        # the kernel writes straight into the tensor that is gathered
         d.genotype(sync=True)
         local = buf[: shard.n_units * rec_bytes] if rccl else buf[: shard.n_units * rec_bytes].cpu()
-        gathered = D.gather_result_records(local, [b[1] - b[0] for b in bounds], dst=0, rec_bytes=rec_bytes)
+        counts = [b[1] - b[0] for b in bounds]
+        if flags:     # tagged 96-byte records: a rank's buffer holds whole workgroups' worth of slots, sizes travel first
+            assert d.result_slots() >= shard.n_units
+            local = buf[: d.result_slots() * 96] if rccl else buf[: d.result_slots() * 96].cpu()
+            gathered, sizes = D.gather_tagged_records(local, dst=0)
+        else:
+            gathered = D.gather_result_records(local, counts, dst=0)
     if rank == 0:
         from oracle import c_oracle
-        assert gathered.numel() == batch.n_units * rec_bytes
-        got = D.results_from_bytes(gathered, rec_bytes)
+        got = D.results_from_tagged(gathered, sizes, counts) if flags else D.results_from_bytes(gathered)
         single = hip.genotype_batch(batch, device=device)
         want = c_oracle.genotype_batch(batch)
         if group > 1:     # QUAL over a site's samples from the gathered (site-major) records == the single-rank device pass

@@ -1,17 +1,20 @@
 """SVT_FLAG_RESULT96 (ABI 13): the pass writes the 96-byte result record of SURVEY.md 8(d) -- GL, SQ, the five tallies,
-QR / QA / GQ, GT -- and the host restores DP, RO, AO, RS, AS, ASC, RP, AP from the tallies as the reference computes them
-(svtyper/classic.py:455-469: int() of the sums).  The host-side results must be the same bytes as the 128-byte path's."""
+QR / QA / GQ, GT -- tagged with its unit and in the order the kernel finishes the units (whole cache lines per wave); the
+host puts every record where its tag says and restores DP, RO, AO, RS, AS, ASC, RP, AP from the tallies as the reference
+computes them (svtyper/classic.py:455-469: int() of the sums).  The host-side results must be the same bytes as the
+128-byte path's."""
 import numpy as np
 import pytest
 
 from svtyper_amd import evidence as ev, synth
 
 
-def _to96(rec128):
+def _to96(rec128, units=None):
     r = np.zeros(len(rec128), ev.RESULT96_DTYPE)
     for f in ("gl", "sq", "tallies", "gt"):
         r[f] = rec128[f]
     r["qr"], r["qa"], r["gq"] = rec128["counts"][:, 0], rec128["counts"][:, 1], rec128["counts"][:, 2]
+    r["unit"] = np.arange(len(rec128)) if units is None else units
     return r
 
 
@@ -28,18 +31,42 @@ def test_expansion_restores_the_oracles_counts(fixture_library, sso):
     for batch in parts:
         want = c_oracle.genotype_batch(batch, flags=sso)
         assert {ev.GT_BLANK, ev.GT_SKIPPED} <= set(np.unique(want.gt).tolist())
-        got = hip.expand96(_to96(want.rec))
+        n = want.n_units
+        got = hip.expand96(_to96(want.rec), n)
         assert got.rec.tobytes() == want.rec.tobytes()
-    assert hip.expand96(np.zeros(0, ev.RESULT96_DTYPE)).n_units == 0
+        # the records in any order, padding records between them: every one lands where its tag says
+        rng = np.random.default_rng(3)
+        order = rng.permutation(n)
+        shuffled = _to96(want.rec[order], units=order)
+        padded = np.zeros(n + 300, ev.RESULT96_DTYPE)
+        padded["unit"] = ev.NO_UNIT
+        at = np.sort(rng.choice(n + 300, n, replace=False))
+        padded[at] = shuffled
+        assert hip.expand96(padded, n).rec.tobytes() == want.rec.tobytes()
+        into = np.zeros(n, ev.RESULT_DTYPE)
+        hip.expand96(padded, n, into)
+        assert into.tobytes() == want.rec.tobytes()
+        # a unit missing, a unit twice, a tag beyond the units: refused
+        for breaker in ("missing", "twice", "beyond"):
+            x = padded.copy()
+            if breaker == "missing":
+                x["unit"][at[5]] = ev.NO_UNIT
+            elif breaker == "twice":
+                x["unit"][at[5]] = x["unit"][at[6]]
+            else:
+                x["unit"][at[5]] = n
+            with pytest.raises(hip.SvtyperHipError):
+                hip.expand96(x, n)
+    assert hip.expand96(np.zeros(0, ev.RESULT96_DTYPE), 0).n_units == 0
     with pytest.raises(ValueError):
-        hip.expand96(np.zeros(100, np.uint8))
+        hip.expand96(np.zeros(100, np.uint8), 1)
 
 
 @pytest.mark.gpu
 def test_device_records_are_the_96_byte_form(hip_device, fixture_library):
-    """what the kernel leaves in HBM under the flag: svt_result96 records whose fields equal the 128-byte pass's; the host
-    entry points (resident batch, pageable and page-locked one-shot, packed evidence, several devices) return the 128-byte
-    records unchanged"""
+    """what the kernel leaves in HBM under the flag: result_slots() tagged svt_result96 records -- every unit exactly once, whole
+    workgroups (padding tagged NO_UNIT), fields equal to the 128-byte pass's; the host entry points (resident batch, pageable
+    and page-locked one-shot, packed evidence, several devices) return the 128-byte records unchanged"""
     import ctypes as C
     from svtyper_amd import hip
     batch = synth.make_units(70_000, 23, [fixture_library], svtype_mix=(0.5, 0.2, 0.2, 0.1), mean_frags=30, sd_frags=20, min_frags=0,
@@ -51,11 +78,18 @@ def test_device_records_are_the_96_byte_form(hip_device, fixture_library):
             assert d.result_bytes() == 96
             d.genotype(sync=True)
             assert d.results().rec.tobytes() == want.rec.tobytes()
-            raw = np.zeros(batch.n_units, ev.RESULT96_DTYPE)
+            slots = d.result_slots()
+            assert batch.n_units <= slots < batch.n_units + 512 and slots % 256 == 0
+            raw = np.zeros(slots, ev.RESULT96_DTYPE)
             lib = hip.load()
             lib.svt_debug_copy_to_host.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_uint64]
             hip._check(lib.svt_debug_copy_to_host(hip_device, C.c_void_p(raw.ctypes.data), C.c_void_p(d.device_results_ptr()), raw.nbytes))
-            assert raw.tobytes() == _to96(want.rec).tobytes()
+            real = raw[raw["unit"] != ev.NO_UNIT]
+            assert len(real) == batch.n_units and np.array_equal(np.sort(real["unit"]), np.arange(batch.n_units))
+            assert not raw["pad"].any() and not raw["pad2"].any()
+            assert real[np.argsort(real["unit"])].tobytes() == _to96(want.rec).tobytes()
+            # the kernel's order: a wave's 64 records are units of similar length (the workgroup's length sort), not neighbours
+            assert (np.diff(real["unit"][:64].astype(np.int64)) != 1).any()
         with hip.DeviceBatch(batch, hip_device, sso) as d:
             assert d.result_bytes() == 128
         # one shot (upload || pass || download by unit ranges), output in pageable and in page-locked memory
