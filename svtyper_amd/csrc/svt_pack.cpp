@@ -13,6 +13,7 @@
 // serially: 113-125 ms per million units on 16 threads; this one: see DESIGN.md 3.2.)
 #include <algorithm>
 #include <atomic>
+#include <functional>
 #include <cmath>
 #include <chrono>
 #include <cstdio>
@@ -350,8 +351,7 @@ constexpr uint64_t kChunkUnits = 256;
 static_assert(SVT_REC_CONTINUATION == (1u << 3) && SVT_REC_HAS_PAIR == (1u << 4), "bit positions used by the encoder's loop");
 
 struct ChunkOut {          // where a chunk's slots wait for the final copy
-    unsigned worker = 0;
-    uint64_t arena_at = 0; // first slot in the worker's arena
+    const Slot* src = nullptr; // in the arena of the worker that encoded it: the memory never moves (segments)
     uint64_t n_slots = 0;
     uint64_t base = 0;     // first slot in the final array
 };
@@ -359,17 +359,56 @@ struct ChunkOut {          // where a chunk's slots wait for the final copy
 // A worker's arena: plain memory that is neither zero-filled when it grows nor handed back between calls.  Fresh pages
 // cost a page fault each and concurrent faults of one process serialise in the kernel: with arenas allocated per call
 // sixteen threads ran at half the per-thread speed of one.
+// It is a list of SEGMENTS that never move: a finished chunk is copied to the final array by whichever thread gets to it,
+// possibly while its owner is already appending the next chunks -- growing by realloc would pull the memory away under that
+// reader.  A chunk is contiguous: when the current segment cannot take its next unit, what the chunk has so far moves on to
+// a larger segment (only the unfinished chunk, which nobody else can see yet).
 struct Arena {
-    Slot* p = nullptr;
-    size_t size = 0, cap = 0;
-    void reserve(const size_t want)
+    struct Seg { Slot* p; size_t size, cap; };
+    static constexpr size_t kSegSlots = size_t(1) << 18;   // 4 MB
+    std::vector<Seg> segs;
+    size_t cur = 0, chunk_at = 0;
+    size_t capacity() const { size_t c = 0; for (const Seg& g : segs) c += g.cap; return c; }
+    void add(const size_t cap)
     {
-        if (want <= cap) return;
-        const size_t ncap = std::max(want, cap + cap / 2 + 4096);
-        Slot* q = static_cast<Slot*>(std::realloc(p, ncap * sizeof(Slot)));
+        Slot* q = static_cast<Slot*>(std::malloc(cap * sizeof(Slot)));
         if (!q) throw std::bad_alloc();
-        p = q;
-        cap = ncap;
+        segs.push_back(Seg{q, 0, cap});
+    }
+    void reset()
+    {
+        for (Seg& g : segs) g.size = 0;
+        cur = chunk_at = 0;
+    }
+    void reserve_first(const size_t want) { if (segs.empty()) add(std::max(want, kSegSlots)); }
+    void begin_chunk()
+    {
+        if (segs.empty()) add(kSegSlots);
+        chunk_at = segs[cur].size;
+    }
+    Slot* append(const size_t n)   // room for n more slots of the chunk being written
+    {
+        if (segs[cur].size + n > segs[cur].cap) {
+            const size_t have = segs[cur].size - chunk_at;
+            size_t nxt = cur + 1;
+            while (nxt < segs.size() && segs[nxt].cap < have + n) ++nxt;     // (segments too small for this chunk stay unused this call)
+            if (nxt == segs.size()) add(std::max(kSegSlots, 2 * (have + n)));
+            if (have) std::memcpy(segs[nxt].p, segs[cur].p + chunk_at, have * sizeof(Slot));
+            segs[cur].size = chunk_at;
+            cur = nxt;
+            segs[cur].size = have;
+            chunk_at = 0;
+        }
+        Slot* w = segs[cur].p + segs[cur].size;
+        segs[cur].size += n;
+        return w;
+    }
+    const Slot* chunk_begin() const { return segs[cur].p + chunk_at; }
+    size_t chunk_size() const { return segs[cur].size - chunk_at; }
+    void release()
+    {
+        for (Seg& g : segs) std::free(g.p);
+        segs.clear();
     }
 };
 struct ArenaPool {       // arenas wait here for the next svt_pack_evidence call (released by svt_pack_trim)
@@ -381,23 +420,23 @@ struct ArenaPool {       // arenas wait here for the next svt_pack_evidence call
         if (idle.empty()) return Arena{};
         size_t best = 0;
         for (size_t i = 1; i < idle.size(); ++i)
-            if (idle[i].cap > idle[best].cap) best = i;
-        Arena a = idle[best];
+            if (idle[i].capacity() > idle[best].capacity()) best = i;
+        Arena a = std::move(idle[best]);
         idle.erase(idle.begin() + (long)best);
-        a.size = 0;
+        a.reset();
         return a;
     }
     void put(Arena a)
     {
-        if (!a.p) return;
+        if (a.segs.empty()) return;
         std::lock_guard<std::mutex> g(lock);
-        if (idle.size() >= 64) { std::free(a.p); return; }
-        idle.push_back(a);
+        if (idle.size() >= 64) { a.release(); return; }
+        idle.push_back(std::move(a));
     }
     void trim()
     {
         std::lock_guard<std::mutex> g(lock);
-        for (Arena& a : idle) std::free(a.p);
+        for (Arena& a : idle) a.release();
         idle.clear();
     }
 };
@@ -406,10 +445,10 @@ ArenaPool g_arenas;
 struct Worker {
     Arena arena;                   // the slots of this worker's chunks, chunk after chunk
     double ms = 0.0;               // SVT_TRACE: how long this worker ran
-    ~Worker() { g_arenas.put(arena); }
+    ~Worker() { g_arenas.put(std::move(arena)); }
     std::vector<uint16_t> scratch; // one unit's three streams at worst-case size, as half-words
-    uint32_t bad = 0;              // record-contract bits (kErr*)
-    int unit_error = 0;            // first unit-array violation (1-based code below), 0 = none
+    std::atomic<uint32_t> bad{0};  // record-contract bits (kErr*); read by other threads while the owner still encodes (streamed form)
+    std::atomic<int> unit_error{0};// first unit-array violation (1-based code below), 0 = none
 };
 
 enum UnitError { kUnitOk = 0, kUnitOffsets, kUnitTooLong, kUnitSvtype, kUnitReserved, kUnitVarLength, kUnitNegativeDel };
@@ -529,9 +568,8 @@ std::string record_error_text(uint32_t err_bits)
 namespace {
 // The encoder's threads, started once per call (sixty-four threads cost ~1.5 ms to start) and taken through the ranges of the
 // batch: for range r every thread runs first(r, t) (t = 0: the caller); when all of them are through, the caller runs
-// between(r) alone; if that says SVT_OK every thread runs second(r, t); the caller then waits until second(r, .) has
-// returned everywhere, runs after(r) alone -- the hand-over of the range -- and follows the others, who have gone on to
-// first(r + 1, .) in the meantime.  A thread that cannot be started is simply missing: the phases hand out their work
+// between(r) alone; if that says SVT_OK every thread runs second(r, t); when second(r, .) has returned everywhere the caller
+// runs after(r) alone -- the hand-over of the range -- and follows the others, who go on to first(r + 1, .) in the meantime.  A thread that cannot be started is simply missing: the phases hand out their work
 // through atomic counters.  Waiting threads back off to short sleeps (between() may take a page-locked allocation's tens
 // of ms the first time).  An exception in any thread is rethrown on the caller after the join, like run_threads does.
 template <typename First, typename Between, typename Second, typename After>
@@ -584,6 +622,8 @@ int run_ranged_phases(unsigned nt, uint64_t n_ranges, First&& first, Between&& b
             if (G.go.load(std::memory_order_acquire) != 1) return;
             guarded_call([&] { second(r, t); });
             G.finished.fetch_add(1, std::memory_order_acq_rel);
+            // (second(r, .) of one thread reads what first(r, .) of the others left in THEIR arenas while those may already be
+            // appending range r + 1: the arenas are segments that never move)
             if (t == 0) {
                 wait_until([&] { return G.finished.load(std::memory_order_acquire) == expected.load(std::memory_order_acquire); });
                 if (!failed()) guarded_call([&] { rc = after(r); });
@@ -722,6 +762,7 @@ int encode_packed(const svt_evidence_batch* in, const PackAlloc& A, PackedArrays
         next_chunk[r].store(r * chunks_per_range, std::memory_order_relaxed);
         next_copy[r].store(r * chunks_per_range, std::memory_order_relaxed);
     }
+    std::function<void(Worker&, uint64_t)> encode_chunk;
     auto encode_phase = [&](uint64_t range, unsigned t) {
         const uint64_t range_end = std::min(n_chunks, (range + 1) * chunks_per_range);
         const auto w_t0 = std::chrono::steady_clock::now();
@@ -744,12 +785,16 @@ int encode_packed(const svt_evidence_batch* in, const PackAlloc& A, PackedArrays
         // a guess at this worker's share (3.2 bytes per record is typical): growing later is only a copy
         if (range == 0) {
             W.arena = g_arenas.get();
-            W.arena.reserve((size_t)(n_rec_claimed / nt / 4 * 3 / 2 + 4096));   // (chunks are claimed: shares differ)
+            W.arena.reserve_first((size_t)(n_rec_claimed / nt / 4 * 3 / 2 + 4096));   // (chunks are claimed: shares differ; more comes in segments)
         }
-        for (uint64_t ch; (ch = next_chunk[range].fetch_add(1, std::memory_order_relaxed)) < range_end;) {
+        for (uint64_t ch; (ch = next_chunk[range].fetch_add(1, std::memory_order_relaxed)) < range_end;) encode_chunk(W, ch);
+        W.ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w_t0).count();
+    };
+    // one chunk of 256 units: contract check + the three streams of every unit (record order), appended to the worker's arena
+    encode_chunk = [&](Worker& W, const uint64_t ch) {
+        {
             ChunkOut& C = chunks[ch];
-            C.worker = t;
-            C.arena_at = W.arena.size;
+            W.arena.begin_chunk();
             const uint64_t u0 = ch * kChunkUnits, u1 = std::min(n, u0 + kChunkUnits);
             std::memcpy(out->units + u0, in->units + u0, (u1 - u0) * sizeof(svt_unit));
             for (uint64_t u = u0; u < u1; ++u) {
@@ -763,7 +808,7 @@ int encode_packed(const svt_evidence_batch* in, const PackAlloc& A, PackedArrays
                 else if (U.var_length < -(1 << 30) || U.var_length > (1 << 30)) ue = kUnitVarLength;
                 else if (U.svtype == SVT_SVTYPE_DEL && U.var_length < 0) ue = kUnitNegativeDel;
                 if (ue != kUnitOk) {
-                    if (!W.unit_error) W.unit_error = ue;
+                    if (!W.unit_error.load(std::memory_order_relaxed)) W.unit_error.store(ue, std::memory_order_relaxed);
                     off[3 * u + 1] = off[3 * u + 2] = off[3 * u + 3] = 0u;
                     continue;                      // (the batch is rejected; nothing of this unit is read)
                 }
@@ -797,22 +842,21 @@ int encode_packed(const svt_evidence_batch* in, const PackAlloc& A, PackedArrays
 #endif
                 encode_records(recs, r0, r1, c, st, S, R, X);
                 const uint32_t lone = st.lone, or_flags = st.or_flags, or_span = st.or_span;
-                W.bad |= (lone ? kErrStraddleNoPair : 0u) | ((or_flags & 0xff00u) ? kErrLibIndex : 0u) |
-                         ((or_flags & ~SVT_REC_FLAG_MASK) ? kErrReservedBits : 0u) | ((int32_t)or_span < 0 ? kErrNegativeSpan : 0u);
+                const uint32_t bad_bits = (lone ? kErrStraddleNoPair : 0u) | ((or_flags & 0xff00u) ? kErrLibIndex : 0u) |
+                                          ((or_flags & ~SVT_REC_FLAG_MASK) ? kErrReservedBits : 0u) | ((int32_t)or_span < 0 ? kErrNegativeSpan : 0u);
+                if (bad_bits) W.bad.fetch_or(bad_bits, std::memory_order_relaxed);
                 const uint32_t ns = S.finish(), nr = R.finish(), nx = X.finish();
                 off[3 * u + 1] = ns;
                 off[3 * u + 2] = nr;
                 off[3 * u + 3] = nx;
-                const size_t at = W.arena.size;
-                W.arena.reserve(at + ns + nr + nx);
-                W.arena.size = at + ns + nr + nx;
-                std::memcpy(W.arena.p + at, W.scratch.data(), (size_t)ns * 16);
-                std::memcpy(W.arena.p + at + ns, W.scratch.data() + cap_s * 8, (size_t)nr * 16);
-                std::memcpy(W.arena.p + at + ns + nr, W.scratch.data() + (cap_s + cap_r) * 8, (size_t)nx * 16);
+                Slot* dst = W.arena.append((size_t)ns + nr + nx);
+                std::memcpy(dst, W.scratch.data(), (size_t)ns * 16);
+                std::memcpy(dst + ns, W.scratch.data() + cap_s * 8, (size_t)nr * 16);
+                std::memcpy(dst + ns + nr, W.scratch.data() + (cap_s + cap_r) * 8, (size_t)nx * 16);
             }
-            C.n_slots = W.arena.size - C.arena_at;
+            C.src = W.arena.chunk_begin();
+            C.n_slots = W.arena.chunk_size();
         }
-        W.ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w_t0).count();
     };
     // ---- between the phases, on the calling thread (svt_last_error is thread-local): verdict on the batch, slot counts
     // -> chunk bases, the output array
@@ -829,8 +873,8 @@ int encode_packed(const svt_evidence_batch* in, const PackAlloc& A, PackedArrays
         uint32_t bad = 0;
         int unit_error = kUnitOk;
         for (const Worker& W : workers) {
-            bad |= W.bad;
-            if (W.unit_error && !unit_error) unit_error = W.unit_error;
+            bad |= W.bad.load(std::memory_order_relaxed);
+            if (W.unit_error.load(std::memory_order_relaxed) && !unit_error) unit_error = W.unit_error.load(std::memory_order_relaxed);
         }
         switch (unit_error) {
         case kUnitOffsets: return fail(SVT_ERR_INVALID, "rec_offset not monotone");
@@ -873,10 +917,10 @@ int encode_packed(const svt_evidence_batch* in, const PackAlloc& A, PackedArrays
             }
             if (!C.n_slots) continue;
 #if SVT_PACK_AVX512
-            if (use_avx512) copy_streaming(slots + C.base, workers[C.worker].arena.p + C.arena_at, (size_t)C.n_slots * 16);
+            if (use_avx512) copy_streaming(slots + C.base, C.src, (size_t)C.n_slots * 16);
             else
 #endif
-            std::memcpy(slots + C.base, workers[C.worker].arena.p + C.arena_at, (size_t)C.n_slots * 16);
+            std::memcpy(slots + C.base, C.src, (size_t)C.n_slots * 16);
         }
     };
     auto hand_over = [&](uint64_t range) -> int {
