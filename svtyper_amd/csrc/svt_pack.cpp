@@ -928,6 +928,155 @@ int encode_packed(const svt_evidence_batch* in, const PackAlloc& A, PackedArrays
         const uint64_t u0 = std::min(n, range * chunks_per_range * kChunkUnits), u1 = std::min(n, (range + 1) * chunks_per_range * kChunkUnits);
         return sink->ready(sink->ctx, out, u0, u1, range_first_slot, total);
     };
+    if (sink && sink->ready && n_chunks > 0 && !std::getenv("SVT_PACK_MEETINGS")) {
+        // ---- the streamed form: no meetings.  Workers claim chunks from ONE counter, in order; whoever encodes the last chunk of a
+        // range becomes its finisher -- waits for the range before it to have its slot bases, fixes this range's, and copies the
+        // range into the final arrays (helped by whoever has nothing left to encode); the calling thread does not encode at
+        // all: it hands finished ranges over, in order, while the workers are far ahead.  (With meetings every range cost the
+        // threads three rendezvous, each as slow as the slowest -- possibly throttled -- thread.)
+        struct Range {
+            std::atomic<uint32_t> encoded{0}, next_copy{0}, copied{0};
+            std::atomic<int> state{0};          // 0 pending, 1 bases fixed (copy open), 2 copied, -1 failed
+            uint64_t first_slot = 0, end_slot = 0;
+        };
+        std::vector<Range> ranges(n_ranges);
+        auto chunks_in = [&](uint64_t r) { return (uint32_t)(std::min(n_chunks, (r + 1) * chunks_per_range) - r * chunks_per_range); };
+        std::atomic<uint64_t> claim{0};
+        std::atomic<int> failed{0};             // 0 none, else the code below
+        enum { kFailVerdict = 1, kFailOverflow, kFailTooMany, kFailException };
+        std::exception_ptr thrown;
+        std::mutex lock;
+        slots = static_cast<Slot*>(out->slots);
+        auto nap = [](unsigned& spins) {
+            if (++spins < 2048) {
+#if defined(__x86_64__)
+                __builtin_ia32_pause();
+#endif
+            } else std::this_thread::sleep_for(std::chrono::microseconds(20));
+        };
+        auto copy_some = [&](uint64_t r) -> bool {     // one chunk of range r into the final arrays; false: nothing left to claim
+            Range& G = ranges[r];
+            const uint32_t k = G.next_copy.fetch_add(1, std::memory_order_relaxed), total_k = chunks_in(r);
+            if (k >= total_k) return false;
+            const uint64_t ch = r * chunks_per_range + k;
+            const ChunkOut& C = chunks[ch];
+            const uint64_t u0 = ch * kChunkUnits, u1 = std::min(n, u0 + kChunkUnits);
+            uint64_t run = C.base;
+            for (uint64_t i = 3 * u0 + 1; i <= 3 * u1; ++i) {
+                run += off[i];
+                off[i] = (uint32_t)run;
+            }
+            if (C.n_slots) {
+#if SVT_PACK_AVX512
+                if (use_avx512) copy_streaming(slots + C.base, C.src, (size_t)C.n_slots * 16);
+                else
+#endif
+                std::memcpy(slots + C.base, C.src, (size_t)C.n_slots * 16);
+            }
+            if (G.copied.fetch_add(1, std::memory_order_acq_rel) + 1 == total_k) G.state.store(2, std::memory_order_release);
+            return true;
+        };
+        auto finish = [&](uint64_t r) {                // the range's last chunk has been encoded (by this thread)
+            unsigned spins = 0;
+            while (r > 0 && ranges[r - 1].state.load(std::memory_order_acquire) == 0 && !failed.load(std::memory_order_relaxed)) nap(spins);
+            if (failed.load(std::memory_order_relaxed) || (r > 0 && ranges[r - 1].state.load(std::memory_order_acquire) < 0)) {
+                ranges[r].state.store(-1, std::memory_order_release);
+                return;
+            }
+            int why = 0;
+            for (const Worker& W : workers)
+                if (W.bad.load(std::memory_order_relaxed) || W.unit_error.load(std::memory_order_relaxed)) why = kFailVerdict;
+            uint64_t at = r ? ranges[r - 1].end_slot : 0;
+            ranges[r].first_slot = at;
+            const uint64_t c0 = r * chunks_per_range, c1 = c0 + chunks_in(r);
+            for (uint64_t ch = c0; ch < c1 && !why; ++ch) {
+                chunks[ch].base = at;
+                at += chunks[ch].n_slots;
+                if (at >= 0xFFFFFFF0ull) why = kFailTooMany;
+            }
+            if (!why && at > sink->slots_cap) why = kFailOverflow;
+            if (why) {
+                int none = 0;
+                failed.compare_exchange_strong(none, why);
+                ranges[r].state.store(-1, std::memory_order_release);
+                return;
+            }
+            ranges[r].end_slot = at;
+            ranges[r].state.store(1, std::memory_order_release);
+            while (copy_some(r)) {}
+        };
+        auto worker = [&](unsigned t) {
+            try {
+                const auto w_t0 = std::chrono::steady_clock::now();
+                Worker& W = workers[t];
+                W.arena = g_arenas.get();
+                W.arena.reserve_first((size_t)(n_rec_claimed / nt / 4 * 3 / 2 + 4096));
+                for (uint64_t ch; !failed.load(std::memory_order_relaxed) && (ch = claim.fetch_add(1, std::memory_order_relaxed)) < n_chunks;) {
+                    encode_chunk(W, ch);
+                    const uint64_t r = ch / chunks_per_range;
+                    if (ranges[r].encoded.fetch_add(1, std::memory_order_acq_rel) + 1 == chunks_in(r)) finish(r);
+                }
+                // nothing left to encode: help with the copies of the ranges that are open, oldest first, until all are through
+                for (uint64_t r = 0; r < n_ranges && !failed.load(std::memory_order_relaxed);) {
+                    const int st = ranges[r].state.load(std::memory_order_acquire);
+                    if (st < 0) break;
+                    if (st == 2) { ++r; continue; }
+                    if (st == 1 && copy_some(r)) continue;
+                    unsigned sp = 2048;          // bases not fixed yet, or every copy of the range is claimed and some are still running
+                    nap(sp);
+                }
+                W.ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w_t0).count();
+            } catch (...) {
+                {
+                    std::lock_guard<std::mutex> g(lock);
+                    if (!thrown) thrown = std::current_exception();
+                }
+                int none = 0;
+                failed.compare_exchange_strong(none, kFailException);
+            }
+        };
+        std::vector<std::thread> pool;
+        pool.reserve(nt);
+        for (unsigned t = 0; t < nt; ++t) {
+            try {
+                pool.emplace_back(worker, t);
+            } catch (const std::system_error&) {
+                break;
+            }
+        }
+        int rc = SVT_OK;
+        if (pool.empty()) worker(0);             // (no thread could be started: the caller encodes, then hands over)
+        for (uint64_t r = 0; r < n_ranges && rc == SVT_OK; ++r) {
+            unsigned spins = 0;
+            int st;
+            while ((st = ranges[r].state.load(std::memory_order_acquire)) != 2 && st >= 0 && !failed.load(std::memory_order_relaxed)) nap(spins);
+            if (ranges[r].state.load(std::memory_order_acquire) != 2) break;
+            const uint64_t u0 = std::min(n, r * chunks_per_range * kChunkUnits), u1 = std::min(n, (r + 1) * chunks_per_range * kChunkUnits);
+            rc = sink->ready(sink->ctx, out, u0, u1, ranges[r].first_slot, ranges[r].end_slot);
+            if (rc != SVT_OK) {
+                int none = 0;
+                failed.compare_exchange_strong(none, kFailException + 1);   // (the consumer declined: stop the workers)
+            }
+        }
+        for (auto& th : pool) th.join();
+        if (thrown) std::rethrow_exception(thrown);
+        if (rc != SVT_OK) return rc;
+        switch (failed.load()) {
+        case 0: break;
+        case kFailOverflow: return SVT_ERR_PACK_OVERFLOW;
+        case kFailTooMany: return fail(SVT_ERR_UNSUPPORTED, "too many slots for 32-bit slot offsets");
+        default: {
+            const int v = between_phases(n_ranges - 1);          // the verdict's text, on the calling thread (svt_last_error is thread-local)
+            return v != SVT_OK ? v : fail(SVT_ERR_INTERNAL, "the encoder stopped without a verdict");
+        }
+        }
+        total = ranges[n_ranges - 1].end_slot;
+        mark("encode + copy (streamed)");
+        out->n_slots = total;
+        out->n_records = n_rec_claimed;
+        release.armed = false;
+        return SVT_OK;
+    }
     SVT_TRY(run_ranged_phases(nt, n_ranges, encode_phase, between_phases, copy_phase, hand_over));
     mark("offsets + final copy");
     out->n_slots = total;

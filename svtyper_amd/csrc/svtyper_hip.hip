@@ -1792,9 +1792,11 @@ static int svt_genotype_packed_from_records_impl(const svt_evidence_batch* in, s
     PackedArrays arr;
     bool overflow = false;
     PackSink sink;
-    // four ranges: the last one's transfer is what stays exposed, and every range costs the encoder's threads three meetings
-    // (measured, 1 M units: 1 / 2 / 4 / 8 / 12 ranges -> 21.2 / 18.1 / 14.2 / 17.0 / 19.3 ms best, profiles/r04_packed_ranges.txt)
-    sink.range_units = std::max<uint64_t>(32768, (n + 3) / 4);
+    // about 64 ranges: the encoder's workers never wait for one another (svt_pack.cpp, the streamed form), so small ranges only
+    // cost the calling thread a hand-over each (four DMA enqueues and a launch) and leave little of the transfer exposed at the end
+    // (measured, 1 M units: ranges of 250 k / 125 k / 63 k / 31 k / 16 k units -> 15.4 / 15.7 / 15.6 / 14.8 / 14.0 ms median beside
+    // 17.4 for the plain sequence; with the meeting-based encoder 15.4 / 14.5 / 16.7 / 17.9 / 22.2: profiles/r04_packed_ranges.txt)
+    sink.range_units = std::max<uint64_t>(8192, (n + 63) / 64);
     if (const char* e = std::getenv("SVT_PACK_RANGE_UNITS")) sink.range_units = std::max<uint64_t>(256, std::strtoull(e, nullptr, 10));
     sink.range_units = (sink.range_units + 255) / 256 * 256;      // (the encoder's chunks)
     if (rc == SVT_OK) rc = g_handles.get_stream(&ctx.ps.compute);
