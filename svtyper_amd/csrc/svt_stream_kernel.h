@@ -53,9 +53,12 @@
 #define SVT_FETCH_FAST_INTERIOR 1 // steps in which every unit of the tile is inside its record range fetch without range tests
 #endif
 #ifndef SVT_WINDOW_SINGLE_PATH
-#define SVT_WINDOW_SINGLE_PATH 0 // 1: library windows of ONE library take the one-library consumer (record_single) -- 7 % fewer
-                                 // instructions for those windows, but with both consumers in one kernel the two-tile build spills
-                                 // 25 registers (41 MB of scratch per launch); with record_window alone it spills none and runs 2-9 % faster
+#define SVT_WINDOW_SINGLE_PATH 1 // library windows of ONE library (the usual sample of a joint run) take the one-library consumer
+                                 // (record_single, 7 % fewer instructions per record); classic association only -- the singlesample
+                                 // window kernel spills 14 registers with both consumers.  In-process A/B on the configs[4] shape
+                                 // (profiles/r04_ab_inproc_variants.txt): every sample one library +3.7 %, 1-3 libraries +1 %, 2-3 +-0.
+                                 // (Round 3 measured the same switch as a loss: its kernel then spilled 25 registers; this round's
+                                 // classic window kernel has 161 VGPRs and none with both consumers.)
 #endif
 #ifndef SVT_LAST_TILE_TAIL_NT
 #define SVT_LAST_TILE_TAIL_NT 1 // two tiles per wave: the last lines of the second tile's units are read for the last time
@@ -650,7 +653,7 @@ __global__ __launch_bounds__(kBlock, MODE == kSingleLds ? SVT_STREAM_WAVES : MOD
                         wj.z = mine ? wj.z : 0u;
                         wj.w = mine ? wj.w : neutral_w;
                         check.see(wj, lib_key);
-                        if (MODE == kSingleLds || (SVT_WINDOW_SINGLE_PATH && wd.lib_cnt == 1u)) record_single<SSO, false, true>(wj, true, sc, acc);
+                        if (MODE == kSingleLds || (SVT_WINDOW_SINGLE_PATH && !SSO && wd.lib_cnt == 1u)) record_single<SSO, false, true>(wj, true, sc, acc);
                         else record_window<SSO, false, true>(wj, true, wc, acc, check);
                     }
                     refill();
@@ -664,7 +667,7 @@ __global__ __launch_bounds__(kBlock, MODE == kSingleLds ? SVT_STREAM_WAVES : MOD
                     if (!SSO || MODE == kGeneral || has_cont) consume(w, k, edge_tag, kind_tag, std::true_type{});
                     else consume(w, k, edge_tag, kind_tag, std::false_type{});
                 };
-                if (MODE == kMultiLds && SVT_WINDOW_SINGLE_PATH && (wd.lib_cnt == 1u || SVT_STREAM_PROBE == 5)) {       // (workgroup-uniform; probe 5: timing only)
+                if (MODE == kMultiLds && SVT_WINDOW_SINGLE_PATH && !SSO && (wd.lib_cnt == 1u || SVT_STREAM_PROBE == 5)) {       // (workgroup-uniform; probe 5: timing only)
                     if (!SVT_SANITIZE_EDGE && edge) run(std::true_type{}, kind_one{});
                     else run(std::false_type{}, kind_one{});
                 } else if (!SVT_SANITIZE_EDGE && edge) run(std::true_type{}, kind_any{});
