@@ -743,7 +743,7 @@ def main():
                     back_to_back.append((time.perf_counter() - t0) * 1e3)
                     p3.free()
                 if packed is None:
-                    out["one_shot_packed"] = {"skipped": "this batch cannot be expressed as packed evidence (several libraries)"}
+                    out["one_shot_packed"] = {"skipped": "this batch cannot be expressed as packed evidence (a histogram wider than 2047 bins, a geometry outside the format's range)"}
                 else:
                     walls, parts = [], None
                     for _ in range(4):
@@ -1009,6 +1009,31 @@ def main():
                     shots[name + "_results_equal"] = bool(np.array_equal(r_os.rec, c_res_site))
                 shots["hintless_over_hinted"] = shots["hintless_wall_ms"] / shots["hinted_wall_ms"]
                 leg["one_shot"] = shots
+                # the same batch as PACKED evidence (several libraries: library switches in the pair streams, the pass reads the
+                # histogram tables through L2): the route from records in host memory in one call, and the pass alone over the
+                # resident slots
+                try:
+                    ts = []
+                    for _ in range(3):
+                        t0 = time.perf_counter()
+                        r_pk = hip.genotype_packed_from_records(c5_batch, device=local_rank, flags=sso & ~ev.FLAG_RESULT96, out=c5_out)
+                        ts.append((time.perf_counter() - t0) * 1e3)
+                    pk = {"from_records_wall_ms": min(ts), "from_records_wall_ms_median": sorted(ts)[1],
+                          "from_records_units_per_s": c5_batch.n_units / (min(ts) * 1e-3),
+                          "results_equal": bool(np.array_equal(r_pk.rec, c_res_site)),
+                          "over_canonical_one_shot": min(ts) / shots["hinted_wall_ms"]}
+                    del r_pk
+                    t0 = time.perf_counter()
+                    with hip.PackedEvidence(c5_batch) as pe:
+                        pk["encode_ms"] = (time.perf_counter() - t0) * 1e3
+                        pk["bytes_per_record"] = pe.nbytes / max(c5_batch.n_records, 1)
+                        with hip.DeviceBatch.from_packed(pe, device=local_rank, flags=sso) as dp:
+                            dp.genotype(sync=True)
+                            pk["pass_ms"] = time_passes(dp, max(3, args.steps // 2))
+                            pk["pass_kernel"] = "svt_packed_kernel<several libraries>"
+                    leg["packed"] = pk
+                except Exception as e:
+                    leg["packed"] = {"error": repr(e)}
                 del c5_out, r_os
                 del nh, nh_units, c_res_site
             except StopIteration:

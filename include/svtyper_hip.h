@@ -476,8 +476,13 @@ int svt_genotype(const svt_evidence_batch* in, svt_result* out, int device,
  * the order inside every stream is the record order, so every tally receives the reference's additions in the
  * reference's order and the results are bit-identical to those of the canonical records.  About 3.2 bytes per
  * fragment record on BASELINE.json's workloads instead of 16.
- * Limits: one library of at most 2047 histogram bins, DEL lengths >= 0, |var_length| <= 2^30, |key_min| <= 2^29,
- * mean + 3 sd of the library not within 4e-6 of an integer (svt_pack_evidence returns SVT_ERR_UNSUPPORTED
+ * Several libraries (a multi-sample batch, a sample sequenced more than once): the pair entries of a unit stay in
+ * ONE stream in record order -- the sums are order-dependent -- and a library-switch half-word stands in front of
+ * the first entry coded against another library than the one before (a sample with one library: one switch per
+ * unit, 2 bytes; interleaved libraries: ~4.5 bytes per record).  The pass then reads the histogram tables through
+ * L2 instead of LDS (svt_packed_kernel<several libraries>); results bit-identical as before.
+ * Limits: libraries of at most 2047 histogram bins, DEL lengths >= 0, |var_length| <= 2^30, |key_min| <= 2^29,
+ * mean + 3 sd of a library not within 4e-6 of an integer (svt_pack_evidence returns SVT_ERR_UNSUPPORTED
  * otherwise and the caller keeps the canonical records).                                                     */
 typedef struct svt_packed_evidence {
     uint64_t n_units;
@@ -488,7 +493,9 @@ typedef struct svt_packed_evidence {
     const svt_unit* units;       /* n_units                                                                 */
     const void* slots;           /* n_slots * 16 bytes                                                      */
     uint32_t common_mapq;        /* mapq_a | mapq_b << 8 of the one-half-word pair entries                  */
-    uint32_t n_libs;             /* 1                                                                       */
+    uint32_t n_libs;             /* 1..256; several: a unit's pair stream starts in the context of libs[0] and
+                                    carries a library-switch half-word (l + 1) << 3 in front of the first entry
+                                    coded against libs[l]; every n_bins <= 2047                             */
     const svt_library* libs;
     double split_weight;
     double disc_weight;
@@ -519,8 +526,9 @@ int svt_genotype_packed(const svt_packed_evidence* in, svt_result* out, int devi
 /* The same from canonical records in HOST memory, with the encoder running ahead of the wire: the batch is encoded in
  * ranges of whole units, and every finished range is uploaded, genotyped by its own launch and downloaded while the host
  * threads encode the next one -- the wall time of the route is the longer of encoding and transfer, not their sum.  Same
- * result bytes as svt_pack_evidence + svt_genotype_packed (and as svt_genotype over the same records).  One library per
- * batch (the packed format's limit, SVT_ERR_UNSUPPORTED otherwise); small batches take the plain sequence.
+ * result bytes as svt_pack_evidence + svt_genotype_packed (and as svt_genotype over the same records).  Any number of
+ * libraries (histograms wider than 2047 bins: SVT_ERR_UNSUPPORTED, the packed format's limit); small batches take the
+ * plain sequence.
  * Replaces, for a producer that holds a batch of fragments in host memory, the hand-over at singlesample.py:355.      */
 int svt_genotype_packed_from_records(const svt_evidence_batch* in, svt_result* out, int device, unsigned flags);
 

@@ -1,6 +1,6 @@
 """TEST INFRASTRUCTURE -- CPU decoder of packed evidence (include/svtyper_hip.h: svt_packed_evidence).
 
-An independent, plain-Python reading of the slot formats documented in svtyper_amd/csrc/svt_prepare_kernels.h:
+An independent, plain-Python reading of the slot formats documented in svtyper_amd/csrc/svt_entry_formats.h:
 slots -> the five tallies of every unit (after the zeroing rules), with the arithmetic of the reference
 (svtyper/classic.py:296-435, singlesample.py:246-404; p_concordant parsers.py:861-882) restated in
 oracle/py_oracle.py.  tests/test_packed_evidence.py compares it with the oracle on the canonical records the slots
@@ -24,16 +24,17 @@ def _pair_weights(f3: int, p_conc: bool, is_del: bool):
     return w_alt, w_ref
 
 
-def tally_packed(slots: np.ndarray, slot_offset: np.ndarray, units: np.ndarray, lib: ev.LibraryTable, common_mapq: int,
+def tally_packed(slots: np.ndarray, slot_offset: np.ndarray, units: np.ndarray, lib, common_mapq: int,
                  sso: bool) -> np.ndarray:
-    """float64 [n_units, 5] tallies in ev.TALLY_NAMES order, zeroing rules applied."""
-    L = po._Lib(lib)
-    key_min, n_bins = int(lib.key_min), int(len(lib.hist))
+    """float64 [n_units, 5] tallies in ev.TALLY_NAMES order, zeroing rules applied.
+    lib: the batch's library, or the list of its libraries (several: library switches in the pair streams)."""
+    libs = list(lib) if isinstance(lib, (list, tuple)) else [lib]
+    Ls = [po._Lib(x) for x in libs]
     out = np.zeros((len(units), 5))
     for u in range(len(units)):
         is_del = int(units["svtype"][u]) == 0
         var_length = int(units["var_length"][u])
-        off2 = min(var_length, n_bins)
+        cur = 0                                  # every unit's pair stream starts in the context of library 0
         o0, o1, o2, o3 = (int(x) for x in slot_offset[3 * u:3 * u + 4])
         ref_seq = alt_seq = alt_clip = ref_span = alt_span = 0
         l_ref = l_seq = l_clip = 0
@@ -51,9 +52,14 @@ def tally_packed(slots: np.ndarray, slot_offset: np.ndarray, units: np.ndarray, 
             k += 1
             f3, code = h & 7, (h >> 3) & 0xfff
             if f3 == 0:
-                continue                         # no-op half-word (padding)
+                if h != 0:                       # library switch (l + 1) << 3: the entries behind it belong to library l
+                    assert not (h & 0x8000) and len(libs) > 1 and code - 1 < len(libs), "library switch out of place"
+                    cur = code - 1
+                continue                         # (zero: a no-op half-word, padding)
+            L, key_min, n_bins = Ls[cur], int(libs[cur].key_min), int(len(libs[cur].hist))
+            off2 = min(var_length, n_bins)
             # code -> the two histogram keys: bins[code] and, for a DEL, bins[code - min(var_length, n_bins)];
-            # codes >= n_bins name the second window only / neither (svt_prepare_kernels.h)
+            # codes >= n_bins name the second window only / neither (svt_entry_formats.h)
             k1 = key_min + code if code < n_bins else None
             i2 = code - off2 if is_del else None
             k2 = key_min + i2 if (i2 is not None and 0 <= i2 < n_bins) else None

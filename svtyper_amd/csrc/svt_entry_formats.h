@@ -14,10 +14,15 @@ namespace svt {
 // The five tallies are independent sums, so evidence for different tallies can live in different streams
 // without changing any of them.
 //
-//   pair entries (alt_span, ref_span), one library with n_bins <= 2047, in half-words:
+//   pair entries (alt_span, ref_span), every library with n_bins <= 2047, in half-words:
 //     an entry with the batch's most common MAPQ pair (60, 60 for bwa) is ONE half-word f3 | code << 3; any other
 //     entry is a 4-byte-aligned pair of half-words, f3 | code << 3 | 0x8000 then mapq_a | mapq_b << 8.  A zero
 //     half-word is a no-op (f3 = 0: both weights 0) and pads a wide entry to its alignment.
+//     Several libraries (ABI 13+: svt_packed_evidence.n_libs > 1): a unit's pair stream starts in the context of library 0
+//     of the batch; the half-word (l + 1) << 3 -- no straddle bit, not wide, not zero: nothing an entry can be -- is a
+//     LIBRARY SWITCH: the entries behind it were coded against the tables of library l, until the next switch or the end
+//     of the unit.  Entries stay in record order whatever their library (the sums are order-dependent), the gate of
+//     classic.py:339,383 is the entry's own library's.  A batch of one library never holds a switch.
 //     f3   = alt | refA << 1 | refB << 2 straddle bits
 //     code = ospan_len translated into the index space of the library's histogram tables: with
 //            r = ospan_len - key_min, the kernel needs thr[r] (parsers.py:870-872) and, for a

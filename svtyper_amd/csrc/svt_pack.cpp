@@ -88,9 +88,20 @@ struct WeightStream {
 struct PairStream {
     uint16_t* begin;
     uint32_t n = 0;       // half-words so far
+    // several libraries (svt_entry_formats.h): the library the decoder's context holds at this point of the stream, and the
+    // library of the records being encoded -- the switch half-word goes out in front of the next entry that is really stored
+    uint32_t cur_lib = 0, want_lib = 0;
     explicit PairStream(uint16_t* p) : begin(p) {}
+    inline void sync_lib()
+    {
+        if (want_lib != cur_lib) {
+            begin[n++] = (uint16_t)((want_lib + 1u) << 3);
+            cur_lib = want_lib;
+        }
+    }
     inline void put(const uint32_t lo16, const uint32_t mq, const uint32_t common)
     {
+        sync_lib();
         if (mq == common) {
             begin[n++] = (uint16_t)lo16;
         } else {
@@ -169,6 +180,63 @@ inline void encode_records(const Slot* recs, const uint64_t r0, const uint64_t r
     }
 }
 
+// Several libraries (svt_entry_formats.h: library switches): what the record loops know about the unit -- its constants
+// against each library a record names, kept for a window of sixteen consecutive libraries (a sample's libraries are
+// neighbours in the batch) and filled when a record first names one.
+struct MultiUnit {
+    const LibDesc* libs;
+    uint32_t n_libs, common;
+    bool is_del;
+    int64_t vl;
+    double pos_delta;
+    bool bad_lib = false;            // a record names a library the batch does not have (the batch is rejected)
+    uint32_t lo = 0, have = 0;       // the window [lo, lo + 16), bit k: entry k of the tables below is filled
+    alignas(64) int32_t t_kmin[16], t_nb[16], t_lim1[16], t_lim2[16], t_out[16], t_gated[16];
+    inline UnitCtx ctx_of(uint32_t L)
+    {
+        if (L >= n_libs) { bad_lib = true; L = 0; }
+        const LibDesc& lib = libs[L];
+        UnitCtx c;
+        const int64_t nb = lib.n_bins;
+        c.gated = is_del && pos_delta < lib.sd2;                  // classic.py:339,383
+        c.key_min = lib.key_min;
+        c.nb = nb;
+        c.vl = vl;
+        c.lim1 = !is_del ? (uint64_t)nb : vl < nb ? (uint64_t)(vl + nb) : (uint64_t)nb;
+        c.lim2 = is_del && vl >= nb ? (uint64_t)nb : 0u;
+        c.code_out = (uint32_t)(2 * nb);
+        c.common = common;
+        return c;
+    }
+    inline void fill(const uint32_t k)
+    {
+        const UnitCtx c = ctx_of(lo + k);
+        t_kmin[k] = (int32_t)c.key_min;
+        t_nb[k] = (int32_t)c.nb;
+        t_lim1[k] = (int32_t)(uint32_t)c.lim1;
+        t_lim2[k] = (int32_t)(uint32_t)c.lim2;
+        t_out[k] = (int32_t)c.code_out;
+        t_gated[k] = c.gated ? -1 : 0;
+        have |= 1u << k;
+    }
+};
+
+// records [r0, r1) of a unit of a batch of several libraries, as runs of one library each; the switch half-word goes out in
+// front of the first entry a run really stores (PairStream::sync_lib)
+inline void encode_records_runs(const Slot* recs, const uint64_t r0, const uint64_t r1, MultiUnit& M, UnitState& st,
+                                PairStream& S, WeightStream& R, WeightStream& X)
+{
+    for (uint64_t j = r0; j < r1;) {
+        const uint32_t L = SVT_REC_LIB(recs[j].w);
+        uint64_t e = j + 1;
+        while (e < r1 && SVT_REC_LIB(recs[e].w) == L) ++e;
+        const UnitCtx c = M.ctx_of(L);
+        S.want_lib = L < M.n_libs ? L : 0u;
+        encode_records(recs, j, e, c, st, S, R, X);
+        j = e;
+    }
+}
+
 #ifndef SVT_PACK_PREFETCH
 #define SVT_PACK_PREFETCH 128   // records (16 bytes each) the vector loop prefetches ahead; 0 = none
 #endif
@@ -181,8 +249,41 @@ inline void encode_records(const Slot* recs, const uint64_t r0, const uint64_t r
 // are then emitted in record order: runs of one-half-word pair entries by a compressing store, the few wide ones and
 // the weight entries from the set bits of the masks.  A group that holds a continuation record (a fragment with a
 // second record: the first-of-fragment bits then depend on the records before it) is left to encode_records.
-__attribute__((target("avx512f,avx512bw,avx512vl")))
-inline void encode_records_avx512(const Slot* recs, const uint64_t r0, const uint64_t r1, const UnitCtx& c, UnitState& st,
+// one-half-word pair entries `ent` of the lanes in `run`, of libraries `libv`: compressed to the front; a switch half-word goes
+// in front of every entry whose library differs from the entry before it (the first one: from the stream's current library).
+// Switches and entries interleaved lane by lane (s0 e0 s1 e1 ...), the lanes that exist compressed once more and stored.
+__attribute__((target("avx512f,avx512bw,avx512vl,bmi2")))
+inline void emit_mixed_run(PairStream& S, const __m512i ent, const __m512i libv, const __mmask16 run, const uint32_t n_libs)
+{
+    const unsigned k = (unsigned)__builtin_popcount(run);
+    const __mmask16 kmask = (__mmask16)((1u << k) - 1u);
+    const __m512i ec = _mm512_maskz_compress_epi32(run, ent), lc = _mm512_maskz_compress_epi32(run, libv);
+    const __m512i prev = _mm512_alignr_epi32(lc, _mm512_set1_epi32((int32_t)S.cur_lib), 15);    // lane i: library of entry i - 1
+    const __mmask16 changed = _mm512_mask_cmpneq_epi32_mask(kmask, lc, prev);
+    const __m512i sw = _mm512_slli_epi32(_mm512_add_epi32(lc, _mm512_set1_epi32(1)), 3);
+    const __m512i ia = _mm512_setr_epi32(0, 16, 1, 17, 2, 18, 3, 19, 4, 20, 5, 21, 6, 22, 7, 23);
+    const __m512i ib = _mm512_setr_epi32(8, 24, 9, 25, 10, 26, 11, 27, 12, 28, 13, 29, 14, 30, 15, 31);
+    const __mmask16 ma = (__mmask16)(_pdep_u32(changed & 0xffu, 0x5555u) | _pdep_u32(kmask & 0xffu, 0xAAAAu));
+    const __mmask16 mb = (__mmask16)(_pdep_u32((unsigned)changed >> 8, 0x5555u) | _pdep_u32((unsigned)kmask >> 8, 0xAAAAu));
+    _mm256_storeu_si256(reinterpret_cast<__m256i*>(S.begin + S.n),
+                        _mm512_cvtepi32_epi16(_mm512_maskz_compress_epi32(ma, _mm512_permutex2var_epi32(sw, ia, ec))));
+    S.n += (uint32_t)__builtin_popcount(ma);
+    if (mb) {
+        _mm256_storeu_si256(reinterpret_cast<__m256i*>(S.begin + S.n),
+                            _mm512_cvtepi32_epi16(_mm512_maskz_compress_epi32(mb, _mm512_permutex2var_epi32(sw, ib, ec))));
+        S.n += (uint32_t)__builtin_popcount(mb);
+    }
+    const uint32_t last_lib = (uint32_t)_mm_cvtsi128_si32(_mm512_castsi512_si128(_mm512_maskz_compress_epi32((__mmask16)(1u << (k - 1u)), lc)));
+    S.cur_lib = S.want_lib = last_lib < n_libs ? last_lib : 0u;
+}
+
+// MULTI (a batch of several libraries; c is not used, M is the unit): the unit's constants come per record from M's
+// window tables by a lane permutation; a group whose kept pair entries are all of one library is emitted as before (behind
+// a switch if that library is not the stream's current one), a mixed group entry by entry from the vector's lanes -- the
+// arithmetic stays in vectors either way.  A group that names libraries more than sixteen apart goes record by record.
+template <bool MULTI>
+__attribute__((target("avx512f,avx512bw,avx512vl,bmi2")))
+inline void encode_records_avx512(const Slot* recs, const uint64_t r0, const uint64_t r1, const UnitCtx& c, MultiUnit* M, UnitState& st,
                                   PairStream& S, WeightStream& R, WeightStream& X)
 {
     // the gated unit keeps no pair entry at all; negative codes cannot happen for it either way
@@ -191,10 +292,10 @@ inline void encode_records_avx512(const Slot* recs, const uint64_t r0, const uin
     const __m512i one = _mm512_set1_epi32(1);
     const __m256i iota16 = _mm256_setr_epi16(0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
     __m512i acc_flags = _mm512_setzero_si512(), acc_span = _mm512_setzero_si512(), acc_lone = _mm512_setzero_si512();
-    const __m512i v_kmin = _mm512_set1_epi32((int32_t)c.key_min), v_vl = _mm512_set1_epi32((int32_t)c.vl);
-    const __m512i v_nb = _mm512_set1_epi32((int32_t)c.nb), v_out = _mm512_set1_epi32((int32_t)c.code_out);
-    const __m512i v_lim1 = _mm512_set1_epi32((int32_t)(uint32_t)c.lim1), v_lim2 = _mm512_set1_epi32((int32_t)(uint32_t)c.lim2);
-    const __m512i v_common = _mm512_set1_epi32((int32_t)c.common);
+    const __m512i v_vl = _mm512_set1_epi32((int32_t)(MULTI ? M->vl : c.vl));
+    __m512i v_kmin = _mm512_set1_epi32((int32_t)c.key_min), v_nb = _mm512_set1_epi32((int32_t)c.nb), v_out = _mm512_set1_epi32((int32_t)c.code_out);
+    __m512i v_lim1 = _mm512_set1_epi32((int32_t)(uint32_t)c.lim1), v_lim2 = _mm512_set1_epi32((int32_t)(uint32_t)c.lim2);
+    const __m512i v_common = _mm512_set1_epi32((int32_t)(MULTI ? M->common : c.common));
     uint64_t j = r0;
     for (; j < r1; j += 16) {
         const unsigned n_here = (unsigned)std::min<uint64_t>(16, r1 - j);   // < 16: the unit's last records, the lanes behind them read as all-zero records
@@ -227,8 +328,40 @@ inline void encode_records_avx512(const Slot* recs, const uint64_t r0, const uin
                             _mm512_permutex2var_epi32(d, _mm512_add_epi32(idx_hi, _mm512_set1_epi32(K)), e))
         const __m512i fw = SVT_FIELD(3);
         if (_mm512_test_epi32_mask(fw, _mm512_set1_epi32((int32_t)SVT_REC_CONTINUATION))) {   // (rare) a fragment goes on: record by record
-            encode_records(recs, j, j + n_here, c, st, S, R, X);
+            if (MULTI) encode_records_runs(recs, j, j + n_here, *M, st, S, R, X);
+            else encode_records(recs, j, j + n_here, c, st, S, R, X);
             continue;
+        }
+        __m512i libv = _mm512_setzero_si512();
+        __mmask16 gated_lanes = 0;
+        if (MULTI) {
+            // every record's library as an index into the unit's window of sixteen; the window moves to the group's libraries
+            // when a record falls outside it, its entries are filled when first named
+            const __mmask16 valid = (__mmask16)((1u << n_here) - 1u);
+            libv = _mm512_and_si512(_mm512_srli_epi32(fw, SVT_REC_LIB_SHIFT), _mm512_set1_epi32(0xff));
+            __m512i idx = _mm512_sub_epi32(libv, _mm512_set1_epi32((int32_t)M->lo));
+            if (_mm512_mask_cmpge_epu32_mask(valid, idx, _mm512_set1_epi32(16))) {
+                const uint32_t gmin = _mm512_mask_reduce_min_epu32(valid, libv), gmax = _mm512_mask_reduce_max_epu32(valid, libv);
+                if (gmax - gmin >= 16u) {
+                    encode_records_runs(recs, j, j + n_here, *M, st, S, R, X);
+                    continue;
+                }
+                M->lo = gmin;
+                M->have = 0;
+                idx = _mm512_sub_epi32(libv, _mm512_set1_epi32((int32_t)gmin));
+            }
+            const __m512i bit = _mm512_sllv_epi32(one, idx);
+            if (_mm512_mask_testn_epi32_mask(valid, bit, _mm512_set1_epi32((int32_t)M->have))) {     // a library named for the first time
+                const uint32_t present = (uint32_t)_mm512_mask_reduce_or_epi32(valid, bit);
+                for (uint32_t miss = present & ~M->have; miss; miss &= miss - 1u) M->fill((uint32_t)__builtin_ctz(miss));
+            }
+            v_kmin = _mm512_permutexvar_epi32(idx, _mm512_load_si512(M->t_kmin));
+            v_nb = _mm512_permutexvar_epi32(idx, _mm512_load_si512(M->t_nb));
+            v_lim1 = _mm512_permutexvar_epi32(idx, _mm512_load_si512(M->t_lim1));
+            v_lim2 = _mm512_permutexvar_epi32(idx, _mm512_load_si512(M->t_lim2));
+            v_out = _mm512_permutexvar_epi32(idx, _mm512_load_si512(M->t_out));
+            const __m512i g = _mm512_permutexvar_epi32(idx, _mm512_load_si512(M->t_gated));
+            gated_lanes = _mm512_test_epi32_mask(g, g);
         }
         const __m512i fx = SVT_FIELD(0), fy = SVT_FIELD(1), fz = SVT_FIELD(2);
 #undef SVT_FIELD
@@ -239,10 +372,18 @@ inline void encode_records_avx512(const Slot* recs, const uint64_t r0, const uin
                                                               _mm512_sub_epi32(_mm512_and_si512(_mm512_srli_epi32(fw, 4), one), one)));
         // ---- pair entries
         __mmask16 keep = 0;
-        if (!c.gated)
+        if (MULTI || !c.gated)
             keep = _mm512_test_epi32_mask(fw, _mm512_set1_epi32(7)) & _mm512_test_epi32_mask(fy, _mm512_set1_epi32(0xff)) &
                    _mm512_test_epi32_mask(fy, _mm512_set1_epi32(0xff00));
+        if (MULTI) keep &= (__mmask16)~gated_lanes;
+        bool mixed = false;      // several libraries among the kept entries of this group
+        if (MULTI && keep) {
+            const uint32_t first_lib = (uint32_t)_mm_cvtsi128_si32(_mm512_castsi512_si128(_mm512_maskz_compress_epi32(keep, libv)));
+            mixed = _mm512_mask_cmpneq_epi32_mask(keep, libv, _mm512_set1_epi32((int32_t)first_lib)) != 0;
+            S.want_lib = first_lib < M->n_libs ? first_lib : 0u;
+        }
         if (keep) {
+            if (!mixed) S.sync_lib();
             // r = ospan_len - key_min as the 32-bit value it is under the format's limits (|key_min| <= 2^29, ospan_len >= 0
             // or rejected): a negative r is a huge unsigned number and fails both range tests, like the 64-bit form
             const __m512i r = _mm512_sub_epi32(fx, v_kmin), r2 = _mm512_sub_epi32(r, v_vl);
@@ -252,7 +393,26 @@ inline void encode_records_avx512(const Slot* recs, const uint64_t r0, const uin
             const __m512i mq = _mm512_and_si512(fy, _mm512_set1_epi32(0xffff));
             const __m512i ent = _mm512_or_si512(_mm512_and_si512(fw, _mm512_set1_epi32(7)), _mm512_slli_epi32(code, 3));
             __mmask16 wide = keep & _mm512_cmpneq_epi32_mask(mq, v_common);
-            if (!wide) {
+            if (MULTI && mixed) {
+                // one-half-word entries in runs between the (few) wide ones, each run with its switches (emit_mixed_run)
+                alignas(64) uint32_t e32[16], m32[16], l32[16];
+                if (wide) {
+                    _mm512_store_si512(e32, ent);
+                    _mm512_store_si512(m32, mq);
+                    _mm512_store_si512(l32, libv);
+                }
+                unsigned from = 0;
+                while (true) {
+                    const unsigned i = wide ? (unsigned)__builtin_ctz(wide) : 16u;
+                    const __mmask16 run = (__mmask16)(keep & ((1u << i) - 1u) & ~((1u << from) - 1u));
+                    if (run) emit_mixed_run(S, ent, libv, run, M->n_libs);
+                    if (i == 16u) break;
+                    S.want_lib = l32[i] < M->n_libs ? l32[i] : 0u;
+                    S.put(e32[i], m32[i], M->common);
+                    from = i + 1u;
+                    wide = (__mmask16)(wide & (wide - 1u));
+                }
+            } else if (!wide) {
                 // all of them one half-word: compress the kept entries and store them as sixteen half-words (the
                 // scratch has room; what lies behind the kept ones is overwritten by whatever comes next)
                 _mm256_storeu_si256(reinterpret_cast<__m256i*>(S.begin + S.n), _mm512_cvtepi32_epi16(_mm512_maskz_compress_epi32(keep, ent)));
@@ -342,7 +502,8 @@ inline void copy_streaming(void* dst, const void* src, size_t bytes)
 
 inline bool cpu_has_avx512()
 {
-    static const bool yes = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512bw") && __builtin_cpu_supports("avx512vl");
+    static const bool yes = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512bw") && __builtin_cpu_supports("avx512vl") &&
+                            __builtin_cpu_supports("bmi2");
     return yes;
 }
 #endif
@@ -676,11 +837,12 @@ int encode_packed(const svt_evidence_batch* in, const PackAlloc& A, PackedArrays
     };
     HostTables T;
     SVT_TRY(build_tables(in, 0, T));
-    if (in->n_libs != 1) return fail(SVT_ERR_UNSUPPORTED, "packed evidence holds one library");
-    if (T.libs[0].n_bins > kMaxShortBins) return fail(SVT_ERR_UNSUPPORTED, "histogram too wide for the packed pair entries");
+    for (const LibDesc& L : T.libs)
+        if (L.n_bins > kMaxShortBins) return fail(SVT_ERR_UNSUPPORTED, "histogram too wide for the packed pair entries");
     if (!T.fast_geometry) return fail(SVT_ERR_UNSUPPORTED, "library geometry outside the packed format's range");
-    const LibDesc lib = T.libs[0];
-    const int64_t key_min = lib.key_min, nb = lib.n_bins;
+    const LibDesc* libs = T.libs.data();
+    const uint32_t n_libs = in->n_libs;
+    const bool multi = n_libs > 1;     // several libraries: library switches in the pair stream (svt_entry_formats.h)
     const Slot* recs = reinterpret_cast<const Slot*>(in->records);
     const uint64_t n_rec_claimed = n ? in->rec_offset[n] : 0;
     if (n_rec_claimed && !in->records) return fail(SVT_ERR_INVALID, "null records");
@@ -812,20 +974,20 @@ int encode_packed(const svt_evidence_batch* in, const PackAlloc& A, PackedArrays
                     off[3 * u + 1] = off[3 * u + 2] = off[3 * u + 3] = 0u;
                     continue;                      // (the batch is rejected; nothing of this unit is read)
                 }
-                const bool is_del = U.svtype == SVT_SVTYPE_DEL;
-                UnitCtx c;
-                c.gated = is_del && (double)U.pos_delta < lib.sd2;                  // classic.py:339,383
-                c.key_min = key_min;
-                c.nb = nb;
-                c.vl = U.var_length;
-                c.lim1 = !is_del ? (uint64_t)nb : c.vl < nb ? (uint64_t)(c.vl + nb) : (uint64_t)nb;
-                c.lim2 = is_del && c.vl >= nb ? (uint64_t)nb : 0u;
-                c.code_out = (uint32_t)(2 * nb);
-                c.common = common;
+                // the unit's constants against a library's tables
+                MultiUnit M;
+                M.libs = libs;
+                M.n_libs = n_libs;
+                M.common = common;
+                M.is_del = U.svtype == SVT_SVTYPE_DEL;
+                M.vl = U.var_length;
+                M.pos_delta = (double)U.pos_delta;
+                if (multi && (U.libs & 0xffu) < n_libs) M.lo = U.libs & 0xffu;     // (the hint, where there is one: the sample's first library)
                 const uint64_t f = r1 - r0;
-                // worst case per stream: every record a wide pair entry behind a pad half-word (3 half-words), one
-                // reference-read entry, two candidate entries; + two or three slots: the vector form stores sixteen half-words at once
-                const uint64_t cap_s = (3 * f + 8 + 7) / 8 + 3, cap_r = f / 7 + 4, cap_x = 2 * f / 7 + 2;
+                // worst case per stream: every record a wide pair entry behind a pad half-word (3 half-words; several libraries:
+                // and a library switch in front of it), one reference-read entry, two candidate entries; + two or three slots:
+                // the vector form stores sixteen half-words at once
+                const uint64_t cap_s = ((multi ? 4 : 3) * f + 8 + 7) / 8 + 3, cap_r = f / 7 + 4, cap_x = 2 * f / 7 + 2;
                 if (W.scratch.size() < (cap_s + cap_r + cap_x) * 8) W.scratch.resize((cap_s + cap_r + cap_x) * 8);
                 PairStream S(W.scratch.data());
                 WeightStream R(W.scratch.data() + cap_s * 8), X(W.scratch.data() + (cap_s + cap_r) * 8);
@@ -835,14 +997,24 @@ int encode_packed(const svt_evidence_batch* in, const PackAlloc& A, PackedArrays
                     for (uint64_t j = r0; j < r1; ++j) x ^= recs[j].x ^ recs[j].w;
                     st.or_span = x & 0x7fffffffu;
                     st.or_flags = 0;
-                } else
+                } else if (!multi) {
+                    const UnitCtx c = M.ctx_of(0);
 #if SVT_PACK_AVX512
-                if (use_avx512) encode_records_avx512(recs, r0, r1, c, st, S, R, X);
-                else
+                    if (use_avx512) encode_records_avx512<false>(recs, r0, r1, c, nullptr, st, S, R, X);
+                    else
 #endif
-                encode_records(recs, r0, r1, c, st, S, R, X);
+                    encode_records(recs, r0, r1, c, st, S, R, X);
+                } else {
+                    // several libraries: a sample's reads come from one library as a rule, from two or three interleaved when it
+                    // was sequenced more than once
+#if SVT_PACK_AVX512
+                    if (use_avx512) encode_records_avx512<true>(recs, r0, r1, M.ctx_of(0), &M, st, S, R, X);
+                    else
+#endif
+                    encode_records_runs(recs, r0, r1, M, st, S, R, X);
+                }
                 const uint32_t lone = st.lone, or_flags = st.or_flags, or_span = st.or_span;
-                const uint32_t bad_bits = (lone ? kErrStraddleNoPair : 0u) | ((or_flags & 0xff00u) ? kErrLibIndex : 0u) |
+                const uint32_t bad_bits = (lone ? kErrStraddleNoPair : 0u) | ((multi ? M.bad_lib : (or_flags & 0xff00u) != 0u) ? kErrLibIndex : 0u) |
                                           ((or_flags & ~SVT_REC_FLAG_MASK) ? kErrReservedBits : 0u) | ((int32_t)or_span < 0 ? kErrNegativeSpan : 0u);
                 if (bad_bits) W.bad.fetch_or(bad_bits, std::memory_order_relaxed);
                 const uint32_t ns = S.finish(), nr = R.finish(), nx = X.finish();

@@ -24,7 +24,9 @@ struct PackedArgs {
     const svt_unit* units;
     const double* pm;             // 256
     const double* l10;            // n_l10
-    const Bin* bins;              // n_bins + 1
+    const Bin* bins;              // every library's n_bins + 1
+    const LibDesc* libs;          // n_libs (several libraries: staged in LDS; their tables are read from bins[] through L2)
+    uint32_t n_libs;
     const PairWeights* wtab;      // 32
     uint32_t n_l10;
     uint32_t total_bins;
@@ -42,7 +44,8 @@ struct PackedArgs {
     GtConsts c;
 };
 
-template <bool SSO, int R>
+// MULTI: packed evidence of several libraries (library switches in the pair stream, svt_entry_formats.h)
+template <bool SSO, int R, bool MULTI>
 __global__ __launch_bounds__(kBlock, 3) void svt_packed_kernel(const PackedArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -78,7 +81,10 @@ __global__ __launch_bounds__(kBlock, 3) void svt_packed_kernel(const PackedArgs 
         reinterpret_cast<double*>(smem + kLdsWcolC)[tid] = pp0 * w.w_alt;
         reinterpret_cast<double*>(smem + kLdsWcolC + kWcolRef)[tid] = pp0 * w.w_ref;
     }
-    {
+    if (MULTI) {     // the library descriptors, where the one-library form keeps its bins
+        for (uint32_t i = tid; i < a.n_libs * (uint32_t)(sizeof(LibDesc) / 8); i += kBlock)
+            reinterpret_cast<uint64_t*>(smem + kLdsBins)[i] = reinterpret_cast<const uint64_t*>(a.libs)[i];
+    } else {
         int32_t* s_thr = reinterpret_cast<int32_t*>(smem + kLdsBins);
         uint32_t* s_hist = reinterpret_cast<uint32_t*>(smem + kLdsBins) + a.total_bins;
         for (uint32_t i = tid; i < a.total_bins; i += kBlock) {
@@ -133,6 +139,10 @@ __global__ __launch_bounds__(kBlock, 3) void svt_packed_kernel(const PackedArgs 
         c.off2_4 = c.is_del ? min((uint32_t)U.var_length, a.lib0.n_bins) * 4u : 0x80000000u;
         c.hist_at = kLdsBins + a.total_bins * 4u;
         c.common_mq = a.common_mq;
+        c.var_length = U.var_length;
+        c.tab8 = a.lib0.tab_off * (uint32_t)sizeof(Bin);      // several libraries: every unit's stream starts in library 0's context
+        c.libs_at = kLdsBins;
+        c.lib_last = a.n_libs - 1u;
         Acc acc = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
 
         if (max_blk) {
@@ -152,10 +162,10 @@ __global__ __launch_bounds__(kBlock, 3) void svt_packed_kernel(const PackedArgs 
                     if (__any(is_pair)) {
                         const uint32_t x = is_pair ? w[j].x : 0u, y = is_pair ? w[j].y : 0u, z = is_pair ? w[j].z : 0u,
                                        v = is_pair ? w[j].w : 0u;
-                        short_pair_dword(x, c, acc);
-                        short_pair_dword(y, c, acc);
-                        short_pair_dword(z, c, acc);
-                        short_pair_dword(v, c, acc);
+                        short_pair_dword<MULTI>(x, c, acc, a.bins);
+                        short_pair_dword<MULTI>(y, c, acc, a.bins);
+                        short_pair_dword<MULTI>(z, c, acc, a.bins);
+                        short_pair_dword<MULTI>(v, c, acc, a.bins);
                     }
                     if (__any(is_ref))
                         ref_read_row<SSO>(is_ref ? make_uint4(w[j].x, w[j].y, w[j].z, w[j].w) : make_uint4(0, 0, 0, 0), acc);

@@ -67,6 +67,10 @@ struct LaneCtx {
     uint32_t common_mq;   // mapq_a | mapq_b << 8 of the one-half-word pair entries
     uint32_t nb4, off2_4; // n_bins * 4 (byte offset of the sentinel bin); DEL ? min(var_length, n_bins) * 4 : 0x80000000
     uint32_t hist_at;     // LDS address of hist[0]
+    // packed entries of several libraries (library switches, svt_entry_formats.h): the tables are read through L2
+    uint32_t tab8;        // byte offset of the current library's first Bin in bins[]
+    uint32_t libs_at;     // LDS address of the batch's LibDesc[n_libs]
+    uint32_t lib_last;    // n_libs - 1
 };
 
 // ---- one canonical 16-byte record, any geometry (svt_stream_kernel.h: kGeneral) --------------------
@@ -150,11 +154,43 @@ __device__ __forceinline__ void pair_evidence(const uint32_t o, const uint32_t m
 // Pair slot (one library): a 16-byte slot is four dwords, each either two one-half-word entries that carry
 // the batch's common MAPQ pair, or one wide entry (low half f3 | code << 3 | 0x8000, high half its two MAPQs).
 // code4 = byte offset of thr[code] / hist[code], f3x8 = f3 << 3 (byte offset inside a decision-table column), pp = pmA * pmB.
-__device__ __forceinline__ void pair_eval_single(const uint32_t code4, const uint32_t f3x8, const double pp,
-                                                 const LaneCtx& c, Acc& a)
+// MULTI (several libraries): thr / hist of the entry's library come from bins[] in device memory (every library's
+// n_bins + 1 Bin{thr, hist}, a few hundred KB at most: L2) -- the libraries of a batch do not fit LDS together, and a launch
+// over unit ranges (the route encodes ahead of the wire) cannot group its workgroups by library window the way the
+// canonical route does.  The pass over packed evidence is a few per cent of its route either way.
+template <bool MULTI>
+__device__ __forceinline__ void pair_tables(const uint32_t code4, const LaneCtx& c, const Bin* bins, int32_t& thr1, uint32_t& h2)
 {
-    const int32_t thr1 = lds_i32(kLdsBins + min(code4, c.nb4));
-    const uint32_t h2 = lds_u32(c.hist_at + min(code4 - c.off2_4, c.nb4));
+    if (MULTI) {
+        const char* base = reinterpret_cast<const char*>(bins) + c.tab8;
+        thr1 = *reinterpret_cast<const int32_t*>(base + 2u * min(code4, c.nb4));
+        h2 = *reinterpret_cast<const uint32_t*>(base + 2u * min(code4 - c.off2_4, c.nb4) + 4u);
+    } else {
+        thr1 = lds_i32(kLdsBins + min(code4, c.nb4));
+        h2 = lds_u32(c.hist_at + min(code4 - c.off2_4, c.nb4));
+    }
+}
+
+// a half-word of the pair stream that is not the MAPQ half of a wide entry: a library switch (l + 1) << 3 moves the lane's
+// table context to library l (clamped to the batch's libraries: slots a caller wrote itself are not trusted with addresses)
+__device__ __forceinline__ void switch_library(const uint32_t h, LaneCtx& c)
+{
+    if ((h & 0x8007u) == 0u && h != 0u) {
+        const uint32_t at = c.libs_at + min((h >> 3) - 1u, c.lib_last) * (uint32_t)sizeof(LibDesc);
+        const uint32_t n_bins = lds_u32(at + 8u);
+        c.tab8 = lds_u32(at) * (uint32_t)sizeof(Bin);
+        c.nb4 = n_bins * 4u;
+        c.off2_4 = c.is_del ? min((uint32_t)c.var_length, n_bins) * 4u : 0x80000000u;
+    }
+}
+
+template <bool MULTI>
+__device__ __forceinline__ void pair_eval_single(const uint32_t code4, const uint32_t f3x8, const double pp,
+                                                 const LaneCtx& c, Acc& a, const Bin* bins)
+{
+    int32_t thr1;
+    uint32_t h2;
+    pair_tables<MULTI>(code4, c, bins, thr1, h2);
     const bool p_conc = (int32_t)h2 <= thr1;
     const uint32_t wa = (p_conc ? c.wt1 : c.wt0) | f3x8;
     const double w_alt = lds_f64(wa), w_ref = lds_f64(wa + kWcolRef);
@@ -162,20 +198,25 @@ __device__ __forceinline__ void pair_eval_single(const uint32_t code4, const uin
     a.ref_span += pp * w_ref;
 }
 
-__device__ __forceinline__ void short_pair_dword(const uint32_t e, const LaneCtx& c, Acc& a)
+template <bool MULTI>
+__device__ __forceinline__ void short_pair_dword(const uint32_t e, LaneCtx& c, Acc& a, const Bin* bins)
 {
     const bool wide = (e & 0x8000u) != 0u;
     const uint32_t hi = e >> 16;
     const uint32_t mq = wide ? hi : c.common_mq;
     const double pm_a = lds_f64(kLdsPm + byte0_x8(mq)), pm_b = lds_f64(kLdsPm + byte1_x8(mq));
-    pair_eval_single((e >> 1) & 0x3ffcu, (e << 3) & 0x38u, pm_a * pm_b, c, a);
+    // (a library switch is then also evaluated as the entry it is not: no straddle bit, both weights 0, the sums receive +0.0)
+    if (MULTI) switch_library(e & 0xffffu, c);
+    pair_eval_single<MULTI>((e >> 1) & 0x3ffcu, (e << 3) & 0x38u, pm_a * pm_b, c, a, bins);
+    if (MULTI && !wide) switch_library(hi, c);
     // the high half: a second entry with the common MAPQs -- its products pmA * pmB * {w_alt, w_ref} come ready from the
     // second decision table -- or the MAPQ bytes of the wide entry just added: then the straddle bits read as 0,
     // both table values are 0 and the sums receive +0.0
     {
         const uint32_t code4 = (e >> 17) & 0x3ffcu;
-        const int32_t thr1 = lds_i32(kLdsBins + min(code4, c.nb4));
-        const uint32_t h2 = lds_u32(c.hist_at + min(code4 - c.off2_4, c.nb4));
+        int32_t thr1;
+        uint32_t h2;
+        pair_tables<MULTI>(code4, c, bins, thr1, h2);
         const bool p_conc = (int32_t)h2 <= thr1;
         const uint32_t wa = ((p_conc ? c.wt1 : c.wt0) + (kLdsWcolC - kLdsWcol)) | (wide ? 0u : (e >> 13) & 0x38u);
         a.alt_span += lds_f64(wa);

@@ -227,6 +227,14 @@ int launch_stream(svt_batch* b, StreamArgs& a, hipStream_t stream)
     return SVT_OK;
 }
 
+// the pass over packed evidence: one library (tables in LDS) / several (library switches, tables through L2)
+const void* packed_kernel_of(const svt_batch* b)
+{
+    const bool sso = (b->flags & SVT_FLAG_SSO_ASSOCIATION) != 0, multi = b->pargs.n_libs > 1;
+    return sso ? (multi ? reinterpret_cast<const void*>(&svt_packed_kernel<true, 1, true>) : reinterpret_cast<const void*>(&svt_packed_kernel<true, 1, false>))
+               : (multi ? reinterpret_cast<const void*>(&svt_packed_kernel<false, 1, true>) : reinterpret_cast<const void*>(&svt_packed_kernel<false, 1, false>));
+}
+
 // units [u0, u1) of a streamed layout (stream: not the library-window mode, whose launch covers window chunks);
 // slot_begin: where this launch's tagged result records start (SVT_FLAG_RESULT96; slots_of_launch(b, u1 - u0) of them)
 int launch_range(svt_batch* b, uint64_t u0, uint64_t u1, hipStream_t stream, uint64_t slot_begin = 0)
@@ -239,9 +247,7 @@ int launch_range(svt_batch* b, uint64_t u0, uint64_t u1, hipStream_t stream, uin
         a.slot_begin = (uint32_t)slot_begin;
         const dim3 grid((unsigned)((u1 - u0 + kBlock - 1) / kBlock)), block(kBlock);
         void* params[] = {&a};
-        const void* k = (b->flags & SVT_FLAG_SSO_ASSOCIATION) ? reinterpret_cast<const void*>(&svt_packed_kernel<true, 1>)
-                                                             : reinterpret_cast<const void*>(&svt_packed_kernel<false, 1>);
-        HIP_TRY(hipLaunchKernel(k, grid, block, params, b->lds_bytes, stream));
+        HIP_TRY(hipLaunchKernel(packed_kernel_of(b), grid, block, params, b->lds_bytes, stream));
         return SVT_OK;
     }
     StreamArgs a = b->sargs;
@@ -257,9 +263,7 @@ int launch_genotype(svt_batch* b)
         if (b->n_units == 0) return SVT_OK;
         const dim3 grid((unsigned)((b->n_units + kBlock - 1) / kBlock)), block(kBlock);
         void* params[] = {&b->pargs};
-        const void* k = (b->flags & SVT_FLAG_SSO_ASSOCIATION) ? reinterpret_cast<const void*>(&svt_packed_kernel<true, 1>)
-                                                             : reinterpret_cast<const void*>(&svt_packed_kernel<false, 1>);
-        HIP_TRY(hipLaunchKernel(k, grid, block, params, b->lds_bytes, b->stream));
+        HIP_TRY(hipLaunchKernel(packed_kernel_of(b), grid, block, params, b->lds_bytes, b->stream));
         return SVT_OK;
     }
     if (b->n_units == 0) return SVT_OK;
@@ -701,8 +705,8 @@ struct PackedOwner {             // what svt_pack_evidence returns: the public s
     uint32_t* off = nullptr;     // the three arrays that cross PCIe live in page-locked memory (g_pinned)
     svt_unit* units = nullptr;
     void* slots = nullptr;
-    std::vector<uint32_t> hist;
-    svt_library lib{};
+    std::vector<std::vector<uint32_t>> hists;    // the libraries, copied: the evidence outlives the caller's batch
+    std::vector<svt_library> libs;
     ~PackedOwner()
     {
         g_pinned.put(off);
@@ -739,9 +743,12 @@ int pack_evidence(const svt_evidence_batch* in, svt_packed_evidence** out)
     owner->off = arr.off;
     owner->units = arr.units;
     owner->slots = arr.slots;
-    owner->hist.assign(in->libs[0].hist, in->libs[0].hist + in->libs[0].n_bins);
-    owner->lib = in->libs[0];
-    owner->lib.hist = owner->hist.data();
+    owner->hists.resize(in->n_libs);
+    owner->libs.assign(in->libs, in->libs + in->n_libs);
+    for (uint32_t l = 0; l < in->n_libs; ++l) {
+        owner->hists[l].assign(in->libs[l].hist, in->libs[l].hist + in->libs[l].n_bins);
+        owner->libs[l].hist = owner->hists[l].data();
+    }
     svt_packed_evidence& P = owner->pub;
     P.n_units = in->n_units;
     P.n_slots = arr.n_slots;
@@ -750,8 +757,8 @@ int pack_evidence(const svt_evidence_batch* in, svt_packed_evidence** out)
     P.units = owner->units;
     P.slots = owner->slots;
     P.common_mapq = arr.common;
-    P.n_libs = 1;
-    P.libs = &owner->lib;
+    P.n_libs = in->n_libs;
+    P.libs = owner->libs.data();
     P.split_weight = in->split_weight;
     P.disc_weight = in->disc_weight;
     *out = &owner.release()->pub;
@@ -766,7 +773,7 @@ int create_packed(const svt_packed_evidence* in, svt_batch* b, bool defer_slots 
 {
     const uint64_t n = in->n_units;
     StageTimer tm;
-    if (in->n_libs != 1 || !in->libs) return fail(SVT_ERR_INVALID, "packed evidence holds one library");
+    if (in->n_libs == 0 || in->n_libs > 256 || !in->libs) return fail(SVT_ERR_INVALID, "n_libs must be 1..256");
     if (!defer_all) {
     if (n && (!in->slot_offset || !in->units)) return fail(SVT_ERR_INVALID, "null unit arrays");
     if (n && in->slot_offset[0] != 0) return fail(SVT_ERR_INVALID, "slot_offset[0] must be 0");
@@ -830,14 +837,15 @@ int create_packed(const svt_packed_evidence* in, svt_batch* b, bool defer_slots 
     }
     svt_evidence_batch shell{};   // what build_tables looks at
     shell.n_units = 0;
-    shell.n_libs = 1;
+    shell.n_libs = in->n_libs;
     shell.libs = in->libs;
     shell.split_weight = in->split_weight;
     shell.disc_weight = in->disc_weight;
     HostTables T;
     SVT_TRY(build_tables(&shell, max_f, T));
     // the limits of the packed format (include/svtyper_hip.h), library side; the unit side was checked above
-    if (T.libs[0].n_bins > kMaxShortBins) return fail(SVT_ERR_UNSUPPORTED, "histogram too wide for the packed pair entries");
+    for (const LibDesc& L : T.libs)
+        if (L.n_bins > kMaxShortBins) return fail(SVT_ERR_UNSUPPORTED, "histogram too wide for the packed pair entries");
     if (!T.fast_geometry) return fail(SVT_ERR_UNSUPPORTED, "library geometry outside the packed format's range");
     tm.mark("validate + tables");
     {
@@ -848,11 +856,13 @@ int create_packed(const svt_packed_evidence* in, svt_batch* b, bool defer_slots 
         SVT_TRY(upload(&b->d_pm, T.pm, st));
         SVT_TRY(upload(&b->d_l10, T.l10, st));
         SVT_TRY(upload(&b->d_bins, T.bins, st));
+        SVT_TRY(upload(&b->d_libs, T.libs, st));
         SVT_TRY(upload(&b->d_wtab, T.wtab, st));
         SVT_TRY(st.finish());
     }
     tm.mark("H2D slots + unit arrays + tables");
-    b->mode = kSingleLds;
+    const bool multi = in->n_libs > 1;     // library switches in the pair streams: descriptors in LDS, tables through L2
+    b->mode = multi ? kGeneral : kSingleLds;
     b->n_slots = in->n_slots;
     PackedArgs& a = b->pargs;
     a.slots = static_cast<const uint4*>(b->d_records);
@@ -861,11 +871,13 @@ int create_packed(const svt_packed_evidence* in, svt_batch* b, bool defer_slots 
     a.pm = b->d_pm;
     a.l10 = b->d_l10;
     a.bins = b->d_bins;
+    a.libs = b->d_libs;
+    a.n_libs = in->n_libs;
     a.wtab = b->d_wtab;
     a.n_l10 = (uint32_t)T.l10.size();
     a.total_bins = (uint32_t)T.bins.size();
     a.common_mq = in->common_mapq;
-    size_t tables = kLdsBins + (size_t)a.total_bins * sizeof(Bin);
+    size_t tables = kLdsBins + (multi ? (size_t)in->n_libs * sizeof(LibDesc) : (size_t)a.total_bins * sizeof(Bin));
     tables = (tables + 127) & ~size_t(127);
     constexpr size_t kLdsPerWg = (160 * 1024 / 3) & ~size_t(127);   // three workgroups per CU
     const size_t l10_bytes = ((size_t)a.n_l10 * 8 + 127) & ~size_t(127);
@@ -896,8 +908,7 @@ int create_packed(const svt_packed_evidence* in, svt_batch* b, bool defer_slots 
                      b->lds_bytes, (size_t)(160 * 1024) / std::max<size_t>(b->lds_bytes, 1),
                      a.l10_where == kL10Shared ? "in LDS" : a.l10_where == kL10Ring ? "through the ring" : "through L2");
     if (b->lds_bytes > 64 * 1024) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&svt_packed_kernel<true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_bytes));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&svt_packed_kernel<false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_bytes));
+        HIP_TRY(hipFuncSetAttribute(packed_kernel_of(b), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_bytes));
     }
     return SVT_OK;
 }
@@ -1724,7 +1735,7 @@ static int svt_genotype_packed_from_records_impl(const svt_evidence_batch* in, s
     if (!in || (!out && in->n_units)) return fail(SVT_ERR_INVALID, "null argument");
     if (flags & ~(SVT_FLAG_SSO_ASSOCIATION | SVT_FLAG_RESULT96)) return fail(SVT_ERR_INVALID, "packed evidence takes SVT_FLAG_SSO_ASSOCIATION and SVT_FLAG_RESULT96 only");
     const uint64_t n = in->n_units;
-    const bool overlap = n >= kPipelineMinUnits && n < 0x55555550ull && in->n_libs == 1 && in->libs && in->rec_offset && in->units && in->records &&
+    const bool overlap = n >= kPipelineMinUnits && n < 0x55555550ull && in->n_libs >= 1 && in->n_libs <= 256 && in->libs && in->rec_offset && in->units && in->records &&
                          in->rec_offset[0] == 0 && in->split_weight >= 0.0 && in->disc_weight >= 0.0 && std::isfinite(in->split_weight) &&
                          std::isfinite(in->disc_weight) && !std::getenv("SVT_PACKED_SERIAL");
     auto serial = [&]() -> int {   // small batches, and whatever the overlapped form declines: encode, then the packed one shot
@@ -1756,7 +1767,9 @@ static int svt_genotype_packed_from_records_impl(const svt_evidence_batch* in, s
     }
     if (max_f > 0x3FFFFFFFull) return fail(SVT_ERR_INVALID, "unit with too many records");
     const uint64_t n_rec = in->rec_offset[n];
-    const uint64_t slots_cap = n_rec / 16 * 5 + 3 * n + 4096;   // 5 bytes per record (3.1 is typical) + a slot per stream and unit
+    // 5 bytes per record (3.1 is typical; several libraries: 6, a switch in front of most pair entries of a sample sequenced more
+    // than once) + a slot per stream and unit
+    const uint64_t slots_cap = n_rec / 16 * (in->n_libs > 1 ? 6 : 5) + 3 * n + 4096;
     if (slots_cap >= 0xFFFFFFF0ull) return serial();
 
     svt_batch* b = new (std::nothrow) svt_batch();
@@ -1770,7 +1783,7 @@ static int svt_genotype_packed_from_records_impl(const svt_evidence_batch* in, s
     shell.n_units = n;
     shell.n_slots = slots_cap;
     shell.n_records = n_rec;
-    shell.n_libs = 1;
+    shell.n_libs = in->n_libs;
     shell.libs = in->libs;
     shell.split_weight = in->split_weight;
     shell.disc_weight = in->disc_weight;

@@ -163,7 +163,7 @@ class PackedEvidence:
 
     @classmethod
     def try_pack(cls, batch: EvidenceBatch):
-        """None when the batch cannot be expressed as packed evidence (several libraries, ...)."""
+        """None when the batch cannot be expressed as packed evidence (a histogram of more than 2047 bins, ...)."""
         try:
             return cls(batch)
         except SvtyperHipError as e:
@@ -268,7 +268,7 @@ def genotype_packed(packed: PackedEvidence, device: int = 0, flags: int = 0, out
 
 def genotype_packed_from_records(batch: EvidenceBatch, device: int = 0, flags: int = 0, out: Optional[Results] = None) -> Results:
     """svt_genotype_packed_from_records: canonical records in host memory -> results through packed evidence, the host
-    encoder running ahead of the upload by unit ranges (encode || upload || pass || download).  One library per batch."""
+    encoder running ahead of the upload by unit ranges (encode || upload || pass || download)."""
     out = Results.empty(batch.n_units) if out is None else _check_out(out, batch.n_units)
     cb = batch.as_c()
     _check(load().svt_genotype_packed_from_records(C.byref(cb), C.c_void_p(out.ptr()), int(device), int(flags)))

@@ -12,36 +12,59 @@ def _tallies_bits(x):
     return np.ascontiguousarray(x).view(np.uint64)
 
 
+def _three_libraries(fixture_library):
+    return [fixture_library, synth.normal_library(420.0, 95.0, seed=3), synth.normal_library(270.0, 40.0, seed=5)]
+
+
+@pytest.mark.parametrize("n_libs", [1, 3])
 @pytest.mark.parametrize("sso", [0, ev.FLAG_SSO_ASSOCIATION])
-def test_encoder_against_an_independent_decoder(fixture_library, sso):
-    """CPU only: decode the slots the encoder wrote and redo the reference's arithmetic on them."""
+def test_encoder_against_an_independent_decoder(fixture_library, sso, n_libs):
+    """CPU only: decode the slots the encoder wrote and redo the reference's arithmetic on them.  n_libs = 3: records of three
+    libraries interleaved inside every unit (library switches in the pair stream, the small-deletion gate per library), and
+    the configs[4] shape -- every sample's units with that sample's one to three libraries."""
     from oracle import c_oracle, py_packed
     from svtyper_amd import hip
-    batches = [synth.make_edge_cases([fixture_library], seed=11).slice(0, 300),
-               synth.make_units(400, 7, [fixture_library], svtype_mix=(0.5, 0.2, 0.2, 0.1), min_frags=0, mean_frags=25, sd_frags=20)]
-    b = synth.make_units(300, 8, [fixture_library], svtype_mix=(0.6, 0.2, 0.1, 0.1), mean_frags=30, sd_frags=10)
+    libs = _three_libraries(fixture_library)[:n_libs]
+    batches = [synth.make_edge_cases(libs, seed=11).slice(0, 300),
+               synth.make_units(400, 7, libs, svtype_mix=(0.5, 0.2, 0.2, 0.1), min_frags=0, mean_frags=25, sd_frags=20)]
+    b = synth.make_units(300, 8, libs, svtype_mix=(0.6, 0.2, 0.1, 0.1), mean_frags=30, sd_frags=10)
     b.records["mapq_a"][::3] = 37                      # wide entries, every alignment case
     b.records["mapq_b"][::7] = 0
     b.units["var_length"][::5] = 3                      # below the small-deletion gate
     b.units["pos_delta"][::5] = 3
     batches.append(b)
+    if n_libs > 1:
+        batches.append(synth.make_multisample(40, 6, seed=3, mean_frags=40, sd_frags=20, min_frags=0, max_frags=120))
+        g = synth.make_units(200, 9, libs, svtype_mix=(1.0, 0, 0, 0), mean_frags=30, sd_frags=10)
+        g.units["pos_delta"][:] = 150                  # gated against library 0 (2 sd = 160) and 1 (190), not against library 2 (80)
+        g.units["var_length"][:] = 150
+        batches.append(g)
     for batch in batches:
         want = c_oracle.genotype_batch(batch, flags=sso).tallies
         with hip.PackedEvidence(batch) as p:
-            assert p.n_units == batch.n_units and p.n_records == batch.n_records
+            assert p.n_units == batch.n_units and p.n_records == batch.n_records and p.c.n_libs == len(batch.libs)
             so = p.slot_offset()
             assert so[0] == 0 and so[-1] == p.c.n_slots and np.all(np.diff(so.astype(np.int64)) >= 0)
-            got = py_packed.tally_packed(p.slots(), so, batch.units, fixture_library, int(p.c.common_mapq), bool(sso))
+            got = py_packed.tally_packed(p.slots(), so, batch.units, list(batch.libs), int(p.c.common_mapq), bool(sso))
+            if n_libs > 1:   # the switches are there, and only where a library really changes hands
+                half = p.slots().view(np.uint16).reshape(-1)
+                switches = int((((half & 0x8007) == 0) & (half != 0)).sum())
+                assert 0 < switches <= batch.n_records
         skip = (batch.units["flags"] & ev.UNIT_SKIP) != 0       # (the oracle blanks skipped units; the decoder has no epilogue)
         assert np.array_equal(_tallies_bits(got[~skip]), _tallies_bits(want[~skip]))
 
 
 def test_pack_rejects_what_the_format_cannot_hold(fixture_library):
     from svtyper_amd import hip
-    two = synth.make_units(50, 3, [fixture_library, synth.normal_library(420.0, 95.0, seed=3)])
-    assert hip.PackedEvidence.try_pack(two) is None
     wide = synth.make_units(50, 3, [synth.normal_library(3000.0, 900.0, seed=5)])
     assert hip.PackedEvidence.try_pack(wide) is None
+    wide2 = synth.make_units(50, 3, [fixture_library, synth.normal_library(3000.0, 900.0, seed=5)])    # ... any of its libraries
+    assert hip.PackedEvidence.try_pack(wide2) is None
+    two = synth.make_units(50, 3, [fixture_library, synth.normal_library(420.0, 95.0, seed=3)])
+    two.records["flags"][9] |= 2 << ev.REC_LIB_SHIFT       # a library the batch does not have
+    with pytest.raises(hip.SvtyperHipError) as e:
+        hip.PackedEvidence(two)
+    assert "lib index" in str(e.value)
     neg = synth.make_units(50, 3, [fixture_library], svtype_mix=(1.0, 0, 0, 0))
     neg.units["var_length"][3] = -7
     assert hip.PackedEvidence.try_pack(neg) is None
@@ -88,6 +111,13 @@ def test_packed_pass_parity(hip_device, fixture_library, sso):
     for n in (1, 63, 64, 65, 255, 257, 4097):
         batches["tiny%d" % n] = synth.make_units(n, n, [fixture_library], svtype_mix=(0.5, 0.2, 0.2, 0.1), min_frags=0,
                                                  mean_frags=30, sd_frags=30)
+    # several libraries: interleaved inside the units, and per sample (the configs[4] shape, site-major and sample-major)
+    libs = _three_libraries(fixture_library)
+    batches["edge3"] = synth.make_edge_cases(libs, seed=11)
+    batches["mixed3"] = synth.make_units(30_000, 23, libs, svtype_mix=(0.5, 0.2, 0.2, 0.1), mean_frags=40, sd_frags=30, min_frags=0,
+                                         frac_empty=0.03, frac_skip=0.02)
+    batches["c5"] = synth.make_multisample(600, 32, seed=13, mean_frags=40, sd_frags=20, min_frags=0, max_frags=150)
+    batches["c5_by_sample"] = synth.to_sample_major(batches["c5"], 32)[0]
     for name, batch in batches.items():
         got, want = _both(batch, sso)
         assert_parity(got, want)
@@ -167,9 +197,23 @@ def test_vector_and_scalar_encoders_write_the_same_slots(fixture_library):
     import os
     from svtyper_amd import hip
     rng = np.random.default_rng(2026)
-    for trial in range(6):
-        batch = synth.make_units(3000, 100 + trial, [fixture_library], svtype_mix=(0.6, 0.2, 0.1, 0.1),
-                                 mean_frags=(5, 17, 33, 64, 100, 180)[trial], sd_frags=(4, 9, 16, 20, 30, 60)[trial], min_frags=0)
+    for trial in range(11):
+        # (trials 6-8: three libraries -- interleaved record by record, then in runs of a dozen and of forty records; 9: forty
+        # libraries, a unit's records all over them (more than the vector form's window of sixteen: record by record); 10: the
+        # configs[4] shape without the units' window hints (the window moves to each sample's libraries))
+        libs = [fixture_library] if trial < 6 else _three_libraries(fixture_library)
+        if trial == 9:
+            libs = [synth.normal_library(250.0 + 7 * k, 40.0 + k, n=50_000, seed=k) for k in range(40)]
+        mean = (5, 17, 33, 64, 100, 180, 33, 100, 180, 64, 50)[trial]
+        if trial == 10:
+            batch = synth.make_multisample(120, 24, seed=41, mean_frags=50, sd_frags=30, min_frags=0, max_frags=200)
+            batch.units["libs"] = 0
+        else:
+            batch = synth.make_units(3000, 100 + trial, libs, svtype_mix=(0.6, 0.2, 0.1, 0.1), mean_frags=mean,
+                                     sd_frags=(4, 9, 16, 20, 30, 60, 16, 30, 60, 20, 0)[trial], min_frags=0)
+        if trial in (7, 8):
+            run = (np.arange(batch.n_records) // (12 if trial == 7 else 40)) % 3
+            batch.records["flags"] = (batch.records["flags"] & ~np.uint32(0xff00)) | (run.astype(np.uint32) << np.uint32(ev.REC_LIB_SHIFT))
         rec = batch.records
         n = batch.n_records
         firsts = set(int(x) for x in batch.rec_offset[:-1])
@@ -203,8 +247,9 @@ def test_worker_count_does_not_change_the_slots(fixture_library):
     must write the same slots and offsets -- also when there are fewer chunks than workers."""
     import os
     from svtyper_amd import hip
-    for n_units in (100, 5000):
-        batch = synth.make_units(n_units, 77, [fixture_library], svtype_mix=(0.6, 0.2, 0.1, 0.1), mean_frags=40, sd_frags=30, min_frags=0)
+    for n_units in (100, 5000, 5001):
+        libs = [fixture_library] if n_units != 5001 else _three_libraries(fixture_library)
+        batch = synth.make_units(n_units, 77, libs, svtype_mix=(0.6, 0.2, 0.1, 0.1), mean_frags=40, sd_frags=30, min_frags=0)
         got = []
         keep = os.environ.get("SVT_PACK_THREADS")
         try:
@@ -242,13 +287,22 @@ def test_ranged_encoder_writes_the_same_arrays(fixture_library, monkeypatch):
     with pytest.raises(hip.SvtyperHipError) as e:
         hip.PackedEvidence(bad)
     assert "reserved/undefined bits" in str(e.value)
+    monkeypatch.delenv("SVT_PACK_TEST_RANGES")
+    monkeypatch.delenv("SVT_PACK_THREADS")
+    multi = synth.make_multisample(900, 16, seed=5, mean_frags=25, sd_frags=15, min_frags=0, max_frags=90)     # several libraries
+    with hip.PackedEvidence(multi) as plain:
+        want = (plain.slots().tobytes(), plain.slot_offset().tobytes(), plain.nbytes)
+    for ranges in ("256", "3000"):
+        monkeypatch.setenv("SVT_PACK_TEST_RANGES", ranges)
+        with hip.PackedEvidence(multi) as p:
+            assert (p.slots().tobytes(), p.slot_offset().tobytes(), p.nbytes) == want, ranges
 
 
 @pytest.mark.gpu
 def test_from_records_route_overlaps_and_equals_the_canonical_pass(hip_device, fixture_library, monkeypatch):
     """svt_genotype_packed_from_records (encode || upload || pass || download by unit ranges) returns the bytes of svt_genotype over the
     same records: both associations, 96-byte device records, page-locked and pageable output, many small ranges, the serial
-    fallbacks (a small batch; more slots than estimated), and its error paths."""
+    fallbacks (a small batch; more slots than estimated), its error paths, and batches of several libraries."""
     from svtyper_amd import hip
     batch = synth.make_units(150_000, 19, [fixture_library], svtype_mix=(0.5, 0.2, 0.2, 0.1), mean_frags=30, sd_frags=20, min_frags=0,
                              frac_empty=0.03, frac_skip=0.02)
@@ -279,8 +333,16 @@ def test_from_records_route_overlaps_and_equals_the_canonical_pass(hip_device, f
     with pytest.raises(hip.SvtyperHipError) as e:
         hip.genotype_packed_from_records(bad, hip_device, 0)
     assert "reserved/undefined bits" in str(e.value)
-    two = synth.make_units(40_000, 3, [fixture_library, synth.normal_library(400.0, 60.0, seed=2)])
-    with pytest.raises(hip.SvtyperHipError):
-        hip.genotype_packed_from_records(two, hip_device, 0)
     # the device is still fine afterwards
     assert hip.genotype_packed_from_records(batch, hip_device, 0).rec.tobytes() == want
+    # several libraries: interleaved inside the units, and the configs[4] shape sample-major (library switches; tables through L2)
+    two = synth.make_units(60_000, 3, [fixture_library, synth.normal_library(400.0, 60.0, seed=2)], svtype_mix=(0.5, 0.2, 0.2, 0.1),
+                           mean_frags=30, sd_frags=20, min_frags=0)
+    c5 = synth.to_sample_major(synth.make_multisample(2500, 32, seed=7, mean_frags=30, sd_frags=15, min_frags=0, max_frags=120), 32)[0]
+    for multi in (two, c5):
+        for flags in (0, ev.FLAG_SSO_ASSOCIATION | ev.FLAG_RESULT96):
+            want_m = hip.genotype_batch(multi, hip_device, flags & ev.FLAG_SSO_ASSOCIATION).rec.tobytes()
+            assert hip.genotype_packed_from_records(multi, hip_device, flags).rec.tobytes() == want_m
+            monkeypatch.setenv("SVT_PACK_RANGE_UNITS", "4096")
+            assert hip.genotype_packed_from_records(multi, hip_device, flags).rec.tobytes() == want_m
+            monkeypatch.delenv("SVT_PACK_RANGE_UNITS")
