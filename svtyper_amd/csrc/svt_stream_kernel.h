@@ -139,6 +139,8 @@ struct StreamArgs {
     uint32_t lds_winlibs;        // byte offset of the WinLib descriptors (after the bins)
     uint32_t unit_begin;         // this launch covers units [unit_begin, unit_end) (the pipelined one-shot launches
     uint32_t unit_end;           // one range per uploaded piece; a pass over a resident batch: [0, n_units))
+    uint32_t units_per_wg;       // (not the window mode) consecutive units of one workgroup, <= 256 * R: the host cuts a launch into
+                                 // EQUAL workgroups that fill whole rounds of the chip's resident workgroups (svtyper_hip.hip: wg_plan)
     uint32_t result96;           // SVT_FLAG_RESULT96: `out` holds 96-byte records (svt_result96) in the workgroups' own order, tagged with their unit
     uint32_t slot_begin;         // ... the first of them this launch writes (workgroup w of the launch: slot_begin + w * 256 * R)
     uint32_t out_samples;        // svt_batch_result_order: > 1 = the units are sample-major (unit = sample * out_sites + site) and the
@@ -334,7 +336,7 @@ __global__ __launch_bounds__(kBlock, MODE == kSingleLds ? SVT_STREAM_WAVES : MOD
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid / kWave));   // wave-uniform: ring addresses stay in SGPRs
     // this workgroup's units: 256 * R consecutive ones, or (library windows) a chunk of the permutation that groups
     // the units by the libraries of their sample
-    uint32_t wg_base = a.unit_begin + blockIdx.x * kUnitsPerWg, n_here;
+    uint32_t wg_base = a.unit_begin + blockIdx.x * a.units_per_wg, n_here;
     WgDesc wd{};
     if (MODE == kMultiLds) {
         const uint2 ch = a.chunks[blockIdx.x];
@@ -342,7 +344,7 @@ __global__ __launch_bounds__(kBlock, MODE == kSingleLds ? SVT_STREAM_WAVES : MOD
         n_here = ch.y;
         wd = a.windows[blockIdx.x];
     } else {
-        n_here = min(kUnitsPerWg, a.unit_end - wg_base);
+        n_here = min(a.units_per_wg, a.unit_end - wg_base);
     }
     // (library windows: a.perm == nullptr when the units already come grouped by window)
     auto unit_at = [&](const uint32_t local) -> uint32_t { return MODE == kMultiLds && a.perm ? a.perm[wg_base + local] : wg_base + local; };

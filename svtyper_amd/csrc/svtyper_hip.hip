@@ -107,6 +107,7 @@ struct svt_batch {
                                      // the pass's workgroups -- tagged records in the kernel's order, padding included
     bool records_resident = true;    // false: create_stream left the record upload to its caller (pipelined one-shot)
     int wgs_per_cu = 3;              // workgroups per CU the pass's kernel was budgeted for (registers -> LDS per workgroup)
+    uint32_t resident_wgs = 0;       // workgroups of the pass's kernel the device holds at once (registers, LDS, CUs); 0 = unknown
     StreamArgs sargs{};
     // kLayoutPacked: packed evidence as uploaded (svt_packed_kernel.h); d_records holds the slots, d_soff the 3n+1 offsets
     uint32_t* d_soff = nullptr;
@@ -209,21 +210,78 @@ int tiles_per_wave(const svt_batch* b, uint64_t units)
 
 // result slots (SVT_FLAG_RESULT96: whole workgroups of tagged records) a launch over `units` units of this batch writes;
 // not the library-window mode, whose launch covers b->n_chunks window chunks
+// compute units of a device (the chip's resident workgroups = workgroups per CU x this)
+inline uint32_t cu_count(int device)
+{
+    static std::mutex lock;
+    static std::vector<int> known;
+    std::lock_guard<std::mutex> g(lock);
+    if ((size_t)device >= known.size()) known.resize((size_t)device + 1, 0);
+    if (known[(size_t)device] == 0) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || v <= 0) { (void)hipGetLastError(); v = 256; }
+        known[(size_t)device] = v;
+    }
+    return (uint32_t)known[(size_t)device];
+}
+
+// How a launch over `units` units is cut into workgroups.  The pass is memory-bound and its workgroups run in near lockstep:
+// the chip holds `resident_wgs` of them, a launch takes as many ROUNDS of that as its workgroups need, and a last round of a few
+// workgroups costs a third of a full one whatever it holds (measured over the same buffers, 512-unit workgroups, 1 024 resident:
+// 1 024 workgroups 0.165 ms, 1 094 -> 0.211; 2 048 -> 0.322, 2 090 -> 0.359; profiles/r04_wg_rounds.txt).  So the units of
+// a launch of more than one round are dealt out as EQUAL workgroups that fill whole rounds -- 1 M units: 2 045 workgroups of
+// 489 instead of 1 954 of 512 -- unless that would leave more than a quarter of a workgroup's lanes (and tagged result slots) empty.
+#ifndef SVT_WG_BALANCE
+#define SVT_WG_BALANCE 1
+#endif
+#ifndef SVT_WG_MIN_FILL
+#define SVT_WG_MIN_FILL 50   // per cent: the emptiest workgroup the rule may make (more than one round: never below 50)
+#endif
+struct WgPlan { int tiles; uint32_t per_wg, n_wg; };
+static std::atomic<int> g_wg_balance{SVT_WG_BALANCE && !std::getenv("SVT_NO_WG_BALANCE") ? SVT_WG_MIN_FILL : 0};   // (svt_debug_wg_balance: measurements)
+extern "C" int svt_debug_wg_balance(int min_fill_percent) { return g_wg_balance.exchange(std::max(0, std::min(100, min_fill_percent))); }
+inline uint32_t balanced_units_per_wg(uint64_t units, uint64_t n_min, uint32_t full, uint32_t resident)
+{
+    const int min_fill = g_wg_balance.load(std::memory_order_relaxed);     // per cent of a full workgroup
+    if (!min_fill || !resident || n_min <= resident) return full;
+    const uint64_t rounds = (n_min + resident - 1) / resident;
+    const uint64_t want = (units + rounds * resident - 1) / (rounds * resident);
+    return want * 100 >= (uint64_t)full * (uint64_t)min_fill ? (uint32_t)want : full;
+}
+static std::atomic<uint32_t> g_force_per_wg{0}, g_force_tiles{0};     // (svt_debug_force_wg: measurements)
+extern "C" void svt_debug_force_wg(uint32_t per_wg, uint32_t tiles) { g_force_per_wg = per_wg; g_force_tiles = tiles; }
+WgPlan wg_plan(const svt_batch* b, uint64_t units)
+{
+    WgPlan p;
+    if (const uint32_t f = g_force_per_wg.load(std::memory_order_relaxed)) {
+        p.tiles = b->mode == kSingleLds ? (int)g_force_tiles.load(std::memory_order_relaxed) : SVT_STREAM_R;
+        p.per_wg = std::min<uint32_t>(f, (uint32_t)kBlock * (uint32_t)p.tiles);
+        p.n_wg = (uint32_t)((units + p.per_wg - 1) / p.per_wg);
+        return p;
+    }
+    p.tiles = tiles_per_wave(b, units);
+    const uint32_t full = (uint32_t)kBlock * (uint32_t)p.tiles;
+    p.per_wg = balanced_units_per_wg(units, (units + full - 1) / full, full, b->resident_wgs);
+    p.n_wg = (uint32_t)((units + p.per_wg - 1) / p.per_wg);
+    return p;
+}
+
 uint64_t slots_of_launch(const svt_batch* b, uint64_t units)
 {
     if (units == 0) return 0;
-    const uint64_t per_wg = b->layout == kLayoutPacked ? (uint64_t)kBlock : (uint64_t)kBlock * (uint64_t)tiles_per_wave(b, units);
-    return (units + per_wg - 1) / per_wg * per_wg;
+    if (b->layout == kLayoutPacked) return (units + kBlock - 1) / kBlock * kBlock;
+    const WgPlan p = wg_plan(b, units);
+    return (uint64_t)p.n_wg * (uint64_t)kBlock * (uint64_t)p.tiles;
 }
 
 int launch_stream(svt_batch* b, StreamArgs& a, hipStream_t stream)
 {
     const uint64_t units = (uint64_t)a.unit_end - a.unit_begin;
-    const int tiles = tiles_per_wave(b, units);
-    const uint64_t per_wg = (uint64_t)kBlock * (uint64_t)tiles;
-    const dim3 grid((unsigned)((units + per_wg - 1) / per_wg)), block(kBlock);
+    const WgPlan p = wg_plan(b, units);
+    a.units_per_wg = p.per_wg;
+    const dim3 grid(p.n_wg), block(kBlock);
     void* params[] = {&a};
-    HIP_TRY(hipLaunchKernel(stream_kernel_of(b, tiles), grid, block, params, b->lds_bytes, stream));
+    HIP_TRY(hipLaunchKernel(stream_kernel_of(b, p.tiles), grid, block, params, b->lds_bytes, stream));
     return SVT_OK;
 }
 
@@ -386,6 +444,8 @@ int create_stream(const svt_evidence_batch* in, svt_batch* b, void* d_records_re
     std::vector<uint32_t> perm;
     std::vector<uint2> chunks;
     std::vector<WgDesc> windows;
+    struct Group { uint32_t begin, end; WgDesc w; };   // positions [begin, end) of perm: the units of one library window
+    std::vector<Group> groups;
     uint32_t max_win_bins = 0, max_win_libs = 0;
     // Without hints (on every unit) the only window that is known to hold every record's library is the whole batch:
     // a run with a handful of libraries (one sample with 2-3 read-group libraries) still fits LDS that way; a joint
@@ -411,6 +471,7 @@ int create_stream(const svt_evidence_batch* in, svt_batch* b, void* d_records_re
         for (uint64_t u = 0; u < n; ++u) ++start[key_of(u) + 1];
         for (uint32_t k = 0; k < 65536u; ++k) start[k + 1] += start[k];
         perm.resize(n);
+        groups.clear();
         {
             std::vector<uint32_t> at(start.begin(), start.end() - 1);
             for (uint64_t u = 0; u < n; ++u) perm[at[key_of(u)]++] = (uint32_t)u;
@@ -425,9 +486,19 @@ int create_stream(const svt_evidence_batch* in, svt_batch* b, void* d_records_re
             w.bin_cnt = T.libs[lo + cnt - 1].tab_off + T.libs[lo + cnt - 1].n_bins + 1 - w.bin_lo;
             max_win_bins = std::max(max_win_bins, w.bin_cnt);
             max_win_libs = std::max(max_win_libs, w.lib_cnt);
-            for (uint32_t p0 = start[k]; p0 < start[k + 1]; p0 += kUnitsPerWg) {
-                chunks.push_back(make_uint2(p0, std::min(kUnitsPerWg, start[k + 1] - p0)));
-                windows.push_back(w);
+            groups.push_back(Group{start[k], start[k + 1], w});
+        }
+    };
+    // ... and the groups into workgroup chunks of at most `per_chunk` units, the chunks of a group of (nearly) equal size
+    auto cut_chunks = [&](const uint32_t per_chunk) {
+        chunks.clear();
+        windows.clear();
+        for (const Group& g : groups) {
+            const uint32_t units = g.end - g.begin, pieces = (units + per_chunk - 1) / per_chunk;
+            for (uint32_t i = 0; i < pieces; ++i) {
+                const uint32_t p0 = g.begin + (uint32_t)((uint64_t)units * i / pieces), p1 = g.begin + (uint32_t)((uint64_t)units * (i + 1) / pieces);
+                chunks.push_back(make_uint2(p0, p1 - p0));
+                windows.push_back(g.w);
             }
         }
     };
@@ -520,6 +591,21 @@ int create_stream(const svt_evidence_batch* in, svt_batch* b, void* d_records_re
     // the kernel then walks the units themselves (no index loads in front of every unit header)
     bool identity = true;
     if (windowed) {
+        // the chunks: whole rounds of equal workgroups (wg_plan's rule; what the window kernel's registers and this batch's
+        // window tables + rings let a CU hold)
+        uint32_t per_chunk = kUnitsPerWg;
+        {
+            int wgs = 3;
+            hipFuncAttributes fa{};
+            if (hipFuncGetAttributes(&fa, stream_kernel_of(b, b->window_tiles)) == hipSuccess && fa.numRegs > 0) wgs = std::max(1, std::min(8, 512 / ((fa.numRegs + 7) / 8 * 8)));
+            else (void)hipGetLastError();
+            const size_t lds = ((window_lds + 127) & ~size_t(127)) + kWavesPerBlock * kStreamRingBytes;
+            const uint32_t resident = (uint32_t)std::min<size_t>((size_t)wgs, (160 * 1024) / lds) * cu_count(b->device);
+            uint64_t n_min = 0;
+            for (const Group& g : groups) n_min += (g.end - g.begin + kUnitsPerWg - 1) / kUnitsPerWg;
+            per_chunk = balanced_units_per_wg(n, n_min, kUnitsPerWg, resident);
+        }
+        cut_chunks(per_chunk);
         Stager st(b->stream);
         void* pp = nullptr;
         for (uint64_t u = 0; u < n && identity; ++u) identity = perm[u] == (uint32_t)u;
@@ -602,8 +688,11 @@ int create_stream(const svt_evidence_batch* in, svt_batch* b, void* d_records_re
     a.n_units = n;
     a.unit_begin = 0;
     a.unit_end = (uint32_t)n;
+    a.units_per_wg = (uint32_t)kBlock * (uint32_t)tiles_per_wave(b, n);
     a.result96 = (b->flags & SVT_FLAG_RESULT96) ? 1u : 0u;
     a.slot_begin = 0;
+    b->resident_wgs = (uint32_t)std::min<size_t>((size_t)b->wgs_per_cu, (160 * 1024) / (tables + kWavesPerBlock * kStreamRingBytes + SVT_PROBE_LDS_PAD)) *
+                      cu_count(b->device);
     b->out_dev = b->d_out;
     b->out_slots = !a.result96 ? n : b->mode == kMultiLds ? (uint64_t)b->n_chunks * kBlock * (uint64_t)b->window_tiles : slots_of_launch(b, n);
     SVT_TRY(ensure_result_slots(b, b->out_slots));
