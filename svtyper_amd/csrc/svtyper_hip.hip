@@ -254,7 +254,8 @@ WgPlan wg_plan(const svt_batch* b, uint64_t units)
 {
     WgPlan p;
     if (const uint32_t f = g_force_per_wg.load(std::memory_order_relaxed)) {
-        p.tiles = b->mode == kSingleLds ? (int)g_force_tiles.load(std::memory_order_relaxed) : SVT_STREAM_R;
+        const int ft = (int)g_force_tiles.load(std::memory_order_relaxed);
+        p.tiles = b->mode == kSingleLds && (ft == 1 || ft == 2) ? ft : tiles_per_wave(b, units);
         p.per_wg = std::min<uint32_t>(f, (uint32_t)kBlock * (uint32_t)p.tiles);
         p.n_wg = (uint32_t)((units + p.per_wg - 1) / p.per_wg);
         return p;
@@ -604,6 +605,12 @@ int create_stream(const svt_evidence_batch* in, svt_batch* b, void* d_records_re
             uint64_t n_min = 0;
             for (const Group& g : groups) n_min += (g.end - g.begin + kUnitsPerWg - 1) / kUnitsPerWg;
             per_chunk = balanced_units_per_wg(n, n_min, kUnitsPerWg, resident);
+            // every group rounds its chunk count up: keep the total inside the rounds the rule aimed at
+            if (per_chunk < kUnitsPerWg && resident) {
+                const uint64_t rounds = (n_min + resident - 1) / resident;
+                auto count = [&](uint32_t per) { uint64_t c = 0; for (const Group& g : groups) c += (g.end - g.begin + per - 1) / per; return c; };
+                while (per_chunk < kUnitsPerWg && count(per_chunk) > rounds * resident) ++per_chunk;
+            }
         }
         cut_chunks(per_chunk);
         Stager st(b->stream);
