@@ -125,3 +125,50 @@ def test_site_qual_and_result_order_on_96_byte_records(hip_device):
         d.genotype(sync=True)
         assert d.results().rec.tobytes() == want and d.site_qual(8).tobytes() == q_want.tobytes()
         assert d.site_qual(8, initial=init).tobytes() == q_init.tobytes()
+
+
+@pytest.mark.gpu
+def test_workgroup_plan_does_not_change_the_results(hip_device, fixture_library):
+    """A launch of more than one round of the chip's resident workgroups is cut into EQUAL workgroups that fill whole rounds
+    (svtyper_hip.hip: wg_plan; StreamArgs.units_per_wg), the window mode cuts its chunks by the same rule: the bytes are those of
+    full workgroups -- both record forms, both associations, library windows -- and of any other cut (odd workgroup sizes forced
+    through the debug hook); the tagged records grow by the emptier workgroups' padding slots and still hold every unit once."""
+    import ctypes as C
+    from svtyper_amd import hip
+    lib = hip.load()
+    lib.svt_debug_wg_balance.argtypes = [C.c_int]
+    lib.svt_debug_force_wg.argtypes = [C.c_uint32, C.c_uint32]
+    one = synth.make_units(700_000, 31, [fixture_library], svtype_mix=(0.5, 0.2, 0.2, 0.1), mean_frags=12, sd_frags=8, min_frags=0,
+                           frac_empty=0.02, frac_skip=0.01)
+    c5 = synth.to_sample_major(synth.make_multisample(16_000, 32, seed=17, mean_frags=10, sd_frags=6, min_frags=0, max_frags=40), 32)[0]
+
+    def run(batch, flags, order):
+        with hip.DeviceBatch(batch, hip_device, flags) as d:
+            if order:
+                d.result_order(order)
+            d.genotype(sync=True)
+            return d.results().rec.tobytes(), d.result_slots()
+
+    prev = lib.svt_debug_wg_balance(0)
+    try:
+        for batch, order in ((one, 0), (c5, 32)):
+            for flags in (0, ev.FLAG_RESULT96, ev.FLAG_SSO_ASSOCIATION | ev.FLAG_RESULT96):
+                lib.svt_debug_wg_balance(0)
+                want, slots_full = run(batch, flags, order)
+                lib.svt_debug_wg_balance(50)
+                got, slots = run(batch, flags, order)
+                assert got == want
+                assert slots % 256 == 0 and slots >= batch.n_units
+                if flags & ev.FLAG_RESULT96:
+                    assert slots > slots_full           # (both batches need more than one round: the plan really cut them differently)
+                else:
+                    assert slots == batch.n_units
+                if order == 0:
+                    for per_wg, tiles in ((489, 2), (257, 2), (65, 1), (200, 1)):
+                        lib.svt_debug_force_wg(per_wg, tiles)
+                        try:
+                            assert run(batch, flags, order)[0] == want, (per_wg, tiles)
+                        finally:
+                            lib.svt_debug_force_wg(0, 0)
+    finally:
+        lib.svt_debug_wg_balance(prev)
