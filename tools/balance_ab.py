@@ -1,6 +1,7 @@
 """equal workgroups in whole rounds (wg_plan) vs full workgroups, over the SAME record / result buffers"""
-import ctypes as C, sys, numpy as np
-sys.path.insert(0, '/root/repo')
+import ctypes as C, os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from svtyper_amd import hip, evidence as ev, synth
 lib = hip.load()

@@ -1,6 +1,7 @@
 """pass time vs number of units over the SAME record / result buffers (those of a 1.6 M-unit batch): round quantisation without the placement lottery"""
-import ctypes as C, sys, numpy as np
-sys.path.insert(0, '/root/repo')
+import ctypes as C, os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from svtyper_amd import hip, evidence as ev
 lib = hip.load()
