@@ -421,6 +421,8 @@ def main():
                     help="(site, sample) units of the c5_multisample leg [2 x --units: at the default that is configs[4]'s own per-GPU "
                          "share, 500 k sites x 32 samples over 8 GPUs = 62 500 sites x 32 = 2 M units x ~100 records]")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--tune-placement", default="12,4",
+                    help="svt_batch_tune_placement before the timed region (resident legs): result,record candidates; 0,0 = none [12,4]")
     ap.add_argument("--spinup-ms", type=float, default=SPINUP_MS,
                     help="untimed passes for this many ms before the warm-up steps (device clocks; 0 = none)")
     ap.add_argument("--force-dist", action="store_true",
@@ -520,6 +522,30 @@ def main():
     alg_bytes, resident_bytes = dbatch.bytes()
     layout_name = dbatch.layout_name()
 
+    tune_res, tune_rec = (int(x) for x in args.tune_placement.split(","))
+
+    def tune(d):
+        """svt_batch_tune_placement (setup, not timed): the pass over a handful of freshly allocated candidates for the result
+        buffer and the record buffer, the fastest kept -- where the VRAM manager puts the two moves the pass by up to 8 %"""
+        if not (tune_res or tune_rec):
+            return None
+        w0 = time.perf_counter()
+        r = d.tune_placement(tune_res, tune_rec)
+        r["wall_ms"] = (time.perf_counter() - w0) * 1e3
+        # the audition is 0.2-0.5 s of uninterrupted passes, after which the device alternates for a while between its level and
+        # one ~4 % slower (groups of 20 passes: 0.289 / 0.300 ms; back to a steady 0.287 after half a second of idling,
+        # profiles/r04_placement_tuning.txt): let it idle before the spin-up and the timed steps, which are a burst of a few ms
+        time.sleep(0.5)
+        r["idle_after_s"] = 0.5
+        return r
+
+    # the same launches WITHOUT the spin-up and on the buffers svt_batch_create drew, for the record (a device coming out of
+    # idle: DESIGN.md 5): one untimed pass, then `steps` passes between HIP events -- reported as `roofline.no_spinup_*`,
+    # never as `value`
+    dbatch.genotype(sync=True)
+    cold_ms = dbatch.genotype_timed(args.steps) / args.steps
+    tuned = tune(dbatch)
+
     # the batch's own result buffer as a torch tensor (zero-copy view): the final RCCL gather needs no extra copy, and the
     # result records stay where svt_batch_create put them (binding a tensor torch allocated costs 3-6 % of the pass: DESIGN.md 3.1)
     res_buf = dbatch.device_results_tensor()
@@ -531,10 +557,6 @@ def main():
         if use_dist:
             dist.barrier()
 
-    # the same launches WITHOUT the spin-up, for the record (a device coming out of idle: DESIGN.md 5): one untimed pass,
-    # then `steps` passes between HIP events -- reported as `roofline.no_spinup_*`, never as `value`
-    dbatch.genotype(sync=True)
-    cold_ms = dbatch.genotype_timed(args.steps) / args.steps
     spun = spin_up(dbatch, args.spinup_ms)
     for _ in range(args.warmup):
         dbatch.genotype(sync=False)
@@ -646,6 +668,10 @@ def main():
                 "kernel_ms_note": "HIP events around the `steps` back-to-back launches of the timed region, divided by `steps`: "
                                   "includes the ~5-10 us between consecutive dispatches that rocprofv3's per-kernel duration leaves out",
                 "no_spinup_kernel_ms": cold_ms, "no_spinup_frac": alg_bytes / (cold_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "placement_tuned": dict(tuned, what="svt_batch_tune_placement before the timed region (setup): the real pass over "
+                                        "freshly allocated candidates for the result buffer and the record buffer, the fastest kept; "
+                                        "before_ms / after_ms = the pass on the buffers svt_batch_create drew / on the kept ones. "
+                                        "`roofline.placement` below: fresh allocations WITHOUT it") if tuned else None,
                 "library_sha16": library_stamp(),
                 "source_sha16": source_stamp(),
                 "compiler": compiler_stamp(),
@@ -890,11 +916,12 @@ def main():
             try:
                 with hip.DeviceBatch(batch, device=local_rank, flags=ev.FLAG_SSO_ASSOCIATION | r96) as ds:
                     ds.genotype(sync=True)
+                    s_tuned = tune(ds)
                     s_ms = time_passes(ds, args.steps)
                     s_alg, _ = ds.bytes()
                 out["sso"] = dict(roofline_of(s_ms, s_alg, "stream_sso", n, batch.n_records),
                                   what="the headline's workload and launch with SVT_FLAG_SSO_ASSOCIATION (svtyper-sso's summation order)",
-                                  kernel="svt_stream_kernel<sso>", units=n, breakpoints_per_s=n / (s_ms * 1e-3))
+                                  kernel="svt_stream_kernel<sso>", units=n, breakpoints_per_s=n / (s_ms * 1e-3), placement_tuned=s_tuned)
             except Exception as e:
                 out["sso"] = {"error": repr(e)}
 
@@ -950,6 +977,7 @@ def main():
                 with hip.DeviceBatch(sm_batch, device=local_rank, flags=sso) as dc:
                     dc.result_order(N_SAMPLES_C5)
                     dc.genotype(sync=True)
+                    c_tuned = tune(dc)
                     c_ms = time_passes(dc, args.steps)
                     c_alg, _ = dc.bytes()
                     c_mode = dc.table_mode()
@@ -961,6 +989,7 @@ def main():
                                 "(svt_batch_result_order); one launch of the library-window kernel"
                                 % (sm_batch.n_units // N_SAMPLES_C5, N_SAMPLES_C5, len(sm_batch.libs)),
                            kernel="svt_stream_kernel<windows>", table_mode=c_mode, units=sm_batch.n_units, records=sm_batch.n_records,
+                           placement_tuned=c_tuned,
                            units_per_s=sm_batch.n_units / (c_ms * 1e-3), sites_per_s=sm_batch.n_units / N_SAMPLES_C5 / (c_ms * 1e-3))
                 del sm_batch
                 out["c5_multisample"] = leg
@@ -1083,11 +1112,12 @@ def main():
                 more = None
                 with hip.DeviceBatch(big, device=local_rank, flags=flags) as db:
                     db.genotype(sync=True)
+                    b_tuned = tune(db)
                     b_ms = time_passes(db, max(5, args.steps // 2))
                     b_alg, _ = db.bytes()
                     head = db.results().rec[:n]
                 out["large_batch"] = {
-                    "units": big.n_units, "records": big.n_records, "kernel_ms": b_ms,
+                    "units": big.n_units, "records": big.n_records, "kernel_ms": b_ms, "placement_tuned": b_tuned,
                     "breakpoints_per_s": big.n_units / (b_ms * 1e-3),
                     "achieved_GBps": b_alg / (b_ms * 1e-3) / 1e9, "frac": b_alg / (b_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                     "first_units_equal_headline": bool(np.array_equal(head, got.rec)),

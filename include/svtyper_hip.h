@@ -349,6 +349,17 @@ int svt_batch_device_results(svt_batch* b, svt_result** dev_ptr);
  * pass NULL to return to the library's own buffer.                                         */
 int svt_batch_bind_device_results(svt_batch* b, svt_result* dev_ptr);
 
+/* Optional, for a resident batch that is passed over many times -- and for the first batch of a chunked run, whose buffers the
+ * following batches inherit through the library's pool.  Where the VRAM manager puts the records and the result records
+ * moves the pass by up to 8 % (levels that last as long as the allocation and that nothing at allocation time predicts,
+ * DESIGN.md 3.1).  The call allocates `result_candidates` more result buffers and `record_candidates` more record buffers
+ * (filled by device copies), runs the real pass over each once the clocks are up (~40 ms of passes first), keeps the fastest
+ * combination and releases the others: ~0.1-0.3 s and, transiently, candidates x buffer size of HBM.  *before_ms / *after_ms
+ * (may be NULL): the pass time per launch before and after.  Not for a batch whose result records are bound to a caller's
+ * buffer; record candidates only for canonical records resident in the batch's own buffer.  The result records in the
+ * device buffer afterwards are those of the last pass (have_results as after svt_batch_genotype).                    */
+int svt_batch_tune_placement(svt_batch* b, int result_candidates, int record_candidates, float* before_ms, float* after_ms);
+
 /* Bytes of one DEVICE result record of this batch: sizeof(svt_result), or sizeof(svt_result96) under SVT_FLAG_RESULT96
  * (what svt_batch_device_results points at, what a buffer for svt_batch_bind_device_results must hold per unit). */
 uint32_t svt_batch_result_bytes(const svt_batch* b);

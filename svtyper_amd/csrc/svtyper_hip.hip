@@ -1476,6 +1476,130 @@ static int svt_batch_genotype_timed_impl(svt_batch* b, int iters, float* ms_tota
     return check_stream_errors(b);
 }
 
+// svt_batch_tune_placement (include/svtyper_hip.h): audition device buffers for the result records and for the records.
+// Which physical blocks of HBM the two big buffers of a batch lie in moves the pass by up to 8 % (levels, stable
+// for the life of an allocation, that nothing at allocation time predicts): with 288 GB of HBM the cheap answer is to allocate a
+// handful of candidates, run the REAL pass over each once the clocks are up, keep the fastest and hand the others back.  The
+// kept buffers return to the pool with the batch, so the batches of a chunked run that follow inherit them.
+static int svt_batch_tune_placement_impl(svt_batch* b, int result_candidates, int record_candidates, float* before_ms, float* after_ms)
+{
+    if (!b) return fail(SVT_ERR_INVALID, "null batch");
+    if (result_candidates < 0 || record_candidates < 0 || result_candidates > 64 || record_candidates > 16) return fail(SVT_ERR_INVALID, "0..64 result and 0..16 record candidates");
+    if (before_ms) *before_ms = 0.f;
+    if (after_ms) *after_ms = 0.f;
+    if (b->n_units == 0) return SVT_OK;
+    if (b->out_dev != b->d_out) return fail(SVT_ERR_INVALID, "the result records are bound to a caller's buffer (svt_batch_bind_device_results)");
+    HIP_TRY(hipSetDevice(b->device));
+    auto pass_ms = [&](int iters, float* ms) -> int {      // `iters` back-to-back launches, per launch
+        float total = 0.f;
+        HIP_TRY(hipEventRecord(b->ev0, b->stream));
+        for (int i = 0; i < iters; ++i) SVT_TRY(launch_genotype(b));
+        HIP_TRY(hipEventRecord(b->ev1, b->stream));
+        HIP_TRY(hipEventSynchronize(b->ev1));
+        HIP_TRY(hipEventElapsedTime(&total, b->ev0, b->ev1));
+        *ms = total / (float)iters;
+        return SVT_OK;
+    };
+    auto best_of = [&](int groups, int iters, float* ms) -> int {
+        float best = 0.f;
+        for (int g = 0; g < groups; ++g) {
+            float t = 0.f;
+            SVT_TRY(pass_ms(iters, &t));
+            if (g == 0 || t < best) best = t;
+        }
+        *ms = best;
+        return SVT_OK;
+    };
+    // clocks up: ~40 ms of passes (a device that idled runs its first launches 5-8 % slow)
+    {
+        float one = 0.f;
+        SVT_TRY(pass_ms(2, &one));
+        const int n = (int)std::min(400.0, std::max(4.0, 40.0 / std::max(one, 0.01f)));
+        SVT_TRY(pass_ms(n, &one));
+    }
+    float current = 0.f;
+    SVT_TRY(best_of(3, 10, &current));
+    if (before_ms) *before_ms = current;
+    const bool resident_records = b->layout == kLayoutStream && b->records_resident && b->sargs.records == static_cast<const uint4*>(b->d_records);
+    struct Cand { void* p; uint64_t cap; float ms; };
+    // ---- result records: plain allocations (they may be handed to RCCL or to another process)
+    if (result_candidates > 0) {
+        const uint64_t bytes = std::max<uint64_t>(b->cap_out, std::max<uint64_t>(b->out_slots, 1) * result_bytes(b));
+        std::vector<Cand> cands;
+        struct FreeAll { std::vector<Cand>& c; ~FreeAll() { for (Cand& x : c) if (x.p) (void)hipFree(x.p); } } guard{cands};
+        for (int i = 0; i < result_candidates; ++i) {
+            void* p = nullptr;
+            if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); break; }     // (out of memory: audition what there is)
+            cands.push_back(Cand{p, bytes, 0.f});
+        }
+        size_t best = cands.size();
+        for (size_t i = 0; i < cands.size(); ++i) {
+            b->sargs.out = b->pargs.out = static_cast<svt_result*>(cands[i].p);
+            SVT_TRY(best_of(2, 10, &cands[i].ms));
+            if (best == cands.size() || cands[i].ms < cands[best].ms) best = i;
+        }
+        if (best != cands.size()) {      // the winner once more, against the incumbent measured the same way (a single fast group is not a level)
+            b->sargs.out = b->pargs.out = static_cast<svt_result*>(cands[best].p);
+            SVT_TRY(best_of(3, 10, &cands[best].ms));
+        }
+        if (best != cands.size() && cands[best].ms < current * 0.995f) {
+            HIP_TRY(hipStreamSynchronize(b->stream));
+            g_pool.put(b->device, b->d_out, b->cap_out);
+            b->d_out = static_cast<svt_result*>(cands[best].p);
+            b->cap_out = cands[best].cap;
+            current = cands[best].ms;
+            cands[best].p = nullptr;
+        }
+        b->out_dev = b->d_out;
+        b->sargs.out = b->pargs.out = b->d_out;
+    }
+    // ---- records (canonical records resident in the batch's own buffer): candidates of the pool's own kind, filled by device copies
+    if (record_candidates > 0 && resident_records) {
+        const uint64_t bytes = ((uint64_t)b->sargs.last_blk + 1) * 128;      // the records as the kernel reads them: whole 128-byte blocks
+        std::vector<Cand> cands;
+        struct FreeAll { std::vector<Cand>& c; int device; ~FreeAll() { for (Cand& x : c) if (x.p) g_pool.release(x.p, device); } } guard{cands, b->device};
+        for (int i = 0; i < record_candidates; ++i) {
+            void* p = nullptr;
+            uint64_t cap = 0;
+            // (not from the pool's idle list: a buffer that sits there was this batch's neighbour in time, not a new draw)
+            if (!(bytes + bytes / 8 >= DevicePool::kChunkedMin && g_pool.chunked_available && g_pool.alloc_chunked(b->device, bytes + bytes / 8, &p, &cap))) {
+                if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); break; }
+                cap = bytes;
+            }
+            cands.push_back(Cand{p, cap, 0.f});
+            HIP_TRY(hipMemcpyAsync(p, b->d_records, bytes, hipMemcpyDeviceToDevice, b->stream));
+        }
+        size_t best = cands.size();
+        for (size_t i = 0; i < cands.size(); ++i) {
+            b->sargs.records = static_cast<const uint4*>(cands[i].p);
+            SVT_TRY(best_of(2, 10, &cands[i].ms));
+            if (best == cands.size() || cands[i].ms < cands[best].ms) best = i;
+        }
+        if (best != cands.size()) {
+            b->sargs.records = static_cast<const uint4*>(cands[best].p);
+            SVT_TRY(best_of(3, 10, &cands[best].ms));
+        }
+        if (best != cands.size() && cands[best].ms < current * 0.995f) {
+            HIP_TRY(hipStreamSynchronize(b->stream));
+            g_pool.put(b->device, b->d_records, b->cap_records);
+            b->d_records = cands[best].p;
+            b->cap_records = cands[best].cap;
+            current = cands[best].ms;
+            cands[best].p = nullptr;
+        }
+        b->sargs.records = static_cast<const uint4*>(b->d_records);
+    }
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    if (after_ms) *after_ms = current;
+    b->have_results = true;      // (the last pass ran over the kept buffers)
+    return check_stream_errors(b);
+}
+
+int svt_batch_tune_placement(svt_batch* b, int result_candidates, int record_candidates, float* before_ms, float* after_ms)
+{
+    return guarded([&] { return svt_batch_tune_placement_impl(b, result_candidates, record_candidates, before_ms, after_ms); });
+}
+
 int svt_batch_genotype_timed(svt_batch* b, int iters, float* ms_total)
 {
     return guarded([&] { return svt_batch_genotype_timed_impl(b, iters, ms_total); });

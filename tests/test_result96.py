@@ -171,3 +171,63 @@ def test_workgroup_plan_does_not_change_the_results(hip_device, fixture_library)
                             lib.svt_debug_force_wg(0, 0)
     finally:
         lib.svt_debug_wg_balance(prev)
+
+
+@pytest.mark.gpu
+def test_tune_placement_keeps_the_results(hip_device, fixture_library):
+    """svt_batch_tune_placement auditions freshly allocated result and record buffers with the real pass and keeps the fastest:
+    whatever it keeps, the batch returns the same bytes afterwards (both record forms, library windows, packed evidence, a tiny
+    and an empty batch), reports the pass time before and after (after <= before), refuses a batch whose result records are
+    bound to a caller's buffer or are out as a torch view, and the next batch of the size inherits the buffers from the pool."""
+    from svtyper_amd import hip
+    one = synth.make_units(60_000, 41, [fixture_library], svtype_mix=(0.5, 0.2, 0.2, 0.1), mean_frags=30, sd_frags=20, min_frags=0,
+                           frac_empty=0.02, frac_skip=0.01)
+    c5 = synth.to_sample_major(synth.make_multisample(1500, 8, seed=19, mean_frags=20, sd_frags=10, min_frags=0, max_frags=60), 8)[0]
+    for batch, order in ((one, 0), (c5, 8), (one.slice(0, 3), 0), (one.slice(0, 0), 0)):
+        for flags in (0, ev.FLAG_RESULT96, ev.FLAG_SSO_ASSOCIATION | ev.FLAG_RESULT96):
+            with hip.DeviceBatch(batch, hip_device, flags) as d:
+                if order:
+                    d.result_order(order)
+                d.genotype(sync=True)
+                want = d.results().rec.tobytes()
+                r = d.tune_placement(5, 2)
+                assert r["after_ms"] <= r["before_ms"] and (batch.n_units == 0 or r["before_ms"] > 0)
+                assert d.results().rec.tobytes() == want          # (the records of the tuner's last pass)
+                d.genotype(sync=True)
+                assert d.results().rec.tobytes() == want
+                if order:
+                    assert d.site_qual(order).tobytes() == d.site_qual(order).tobytes()
+            with hip.DeviceBatch(batch, hip_device, flags) as d:   # the pool hands the kept buffers to the next batch
+                if order:
+                    d.result_order(order)
+                d.genotype(sync=True)
+                assert d.results().rec.tobytes() == want
+    with hip.PackedEvidence(one) as p, hip.DeviceBatch.from_packed(p, hip_device, ev.FLAG_RESULT96) as d:
+        d.genotype(sync=True)
+        want = d.results().rec.tobytes()
+        r = d.tune_placement(4, 4)                                # (packed evidence: result candidates only)
+        assert r["after_ms"] <= r["before_ms"]
+        d.genotype(sync=True)
+        assert d.results().rec.tobytes() == want
+    with hip.DeviceBatch(one, hip_device, 0) as d:
+        d.genotype(sync=True)
+        other = hip.DeviceBatch(one, hip_device, 0)
+        try:
+            d.bind_device_results(other.device_results_ptr())
+            with pytest.raises(hip.SvtyperHipError):
+                d.tune_placement(2, 0)
+            d.bind_device_results(0)
+            with pytest.raises(hip.SvtyperHipError):
+                d.tune_placement(65, 0)
+            import weakref
+
+            class View:      # (what device_results_tensor() registers; torch itself needs a process of its own, test_multi_device.py)
+                pass
+            view = View()
+            d._views = [weakref.ref(view)]
+            with pytest.raises(hip.SvtyperHipError):
+                d.tune_placement(2, 0)
+            del view
+            d.tune_placement(2, 1)
+        finally:
+            other.close()
