@@ -670,7 +670,10 @@ def main():
                 "resident_bytes_per_launch": resident_bytes,
                 "kernel_ms_max_over_ranks": kern_ms_max,
                 "kernel_ms_note": "HIP events around the `steps` back-to-back launches of the timed region, divided by `steps`: "
-                                  "includes the ~5-10 us between consecutive dispatches that rocprofv3's per-kernel duration leaves out",
+                                  "includes the ~5-10 us between consecutive dispatches that rocprofv3's per-kernel duration leaves out; "
+                                  "rocprofv3's per-kernel AVERAGE covers every call in the process (cold passes, the placement audition's "
+                                  "candidates, spin-up, the untuned `placement` leg): the statistic of a kernel trace that corresponds to "
+                                  "this number is the fastest run of `steps` consecutive dispatches (tools/summarize_prof.py prints both)",
                 "no_spinup_kernel_ms": cold_ms, "no_spinup_frac": alg_bytes / (cold_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "placement_tuned": dict(tuned, what="svt_batch_tune_placement before the timed region (setup): the real pass over "
                                         "freshly allocated candidates for the result buffer and the record buffer, the fastest kept; "

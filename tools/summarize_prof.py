@@ -20,6 +20,35 @@ for f in dbs("stats"):
     for r in c.execute("select name,total_calls,total_duration,average,percentage from top_kernels"):
         print(",".join(str(x) for x in r))
 
+# The same trace dispatch by dispatch: `top_kernels` averages EVERY call of a kernel in the process -- the cold passes right after
+# svt_batch_create, the placement audition's candidate buffers (svt_batch_tune_placement), spin-up, the untuned `placement` leg --,
+# the bench line's kernel_ms is the `steps` launches of the timed region.  The fastest run of `steps` consecutive dispatches is
+# the statistic of the trace that corresponds to it (kernel_ms also holds the few microseconds between consecutive dispatches).
+try:
+    _steps = json_steps = None
+    import json as _json
+    _line = [l for l in open(os.path.join(out, "stats_bench.json")) if l.startswith("{")][-1]
+    _steps = int(_json.loads(_line)["steps"])
+except Exception:
+    _steps = 10
+for f in dbs("stats"):
+    c = sqlite3.connect(f)
+    try:
+        rows = list(c.execute("select name, start, duration from kernels where name like '%svt_%' order by start"))
+    except sqlite3.Error:
+        rows = []
+    if rows:
+        print("# kernel trace by dispatch: median, and the fastest run of %d consecutive dispatches of the kernel (the bench's timed region is %d launches)" % (_steps, _steps))
+        print("name,calls,median_us,fastest_%d_consecutive_avg_us" % _steps)
+        by = {}
+        for name, start, dur in rows:
+            by.setdefault(name, []).append(dur / 1e3)
+        for name, d in sorted(by.items(), key=lambda kv: -sum(kv[1])):
+            if len(d) < _steps:
+                continue
+            best = min(sum(d[i:i + _steps]) / _steps for i in range(len(d) - _steps + 1))
+            print("%s,%d,%.3f,%.3f" % (name, len(d), sorted(d)[len(d) // 2], best))
+
 for sub in ("pmc_sq1", "pmc_sq2", "pmc_fetch", "pmc_write"):
     for f in dbs(sub):
         c = sqlite3.connect(f)
