@@ -83,6 +83,12 @@ while time.time() - t0 < budget:
                     if d.results().rec.tobytes() != ref_bytes:
                         print("TABLE-PATH MISMATCH at iteration %d (kind %d, %d libs, flags %#x, mode %d)" % (it, kind, n_libs, fl, d.table_mode()))
                         sys.exit(1)
+                    if it % 7 == 0:   # the placement audition swaps the batch's result / record buffers: the bytes stay
+                        d.tune_placement(3, 2)
+                        d.genotype(sync=True)
+                        if d.results().rec.tobytes() != ref_bytes:
+                            print("TUNE-PLACEMENT MISMATCH at iteration %d (kind %d, %d libs, flags %#x)" % (it, kind, n_libs, fl))
+                            sys.exit(1)
     if by_sample > 1:   # the same units handed over sample-major, result records written site-major (svt_batch_result_order)
         sm, _ = synth.to_sample_major(b, by_sample)
         for flags in (0, ev.FLAG_SSO_ASSOCIATION):
