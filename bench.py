@@ -425,8 +425,8 @@ def main():
                     help="(site, sample) units of the c5_multisample leg [2 x --units: at the default that is configs[4]'s own per-GPU "
                          "share, 500 k sites x 32 samples over 8 GPUs = 62 500 sites x 32 = 2 M units x ~100 records]")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
-    ap.add_argument("--tune-placement", default="12,4",
-                    help="svt_batch_tune_placement before the timed region (resident legs): result,record candidates; 0,0 = none [12,4]")
+    ap.add_argument("--tune-placement", default="32,8",
+                    help="svt_batch_tune_placement before the timed region (resident legs): result,record candidates; 0,0 = none [32,8]")
     ap.add_argument("--spinup-ms", type=float, default=SPINUP_MS,
                     help="untimed passes for this many ms before the warm-up steps (device clocks; 0 = none)")
     ap.add_argument("--force-dist", action="store_true",

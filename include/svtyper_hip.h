@@ -354,7 +354,9 @@ int svt_batch_bind_device_results(svt_batch* b, svt_result* dev_ptr);
  * moves the pass by up to 8 % (levels that last as long as the allocation and that nothing at allocation time predicts,
  * DESIGN.md 3.1).  The call allocates `result_candidates` more result buffers and `record_candidates` more record buffers
  * (filled by device copies), runs the real pass over each once the clocks are up (~40 ms of passes first), keeps the fastest
- * combination and releases the others: ~0.1-0.3 s and, transiently, candidates x buffer size of HBM.  *before_ms / *after_ms
+ * combination and releases the others: ~0.1-0.4 s (the launches per candidate are chosen so that the audition stays a short
+ * burst: a device under seconds of uninterrupted load is measured in another state) and, transiently, candidates x buffer size
+ * of HBM; 32 and 8 are good values (a dozen candidates miss the fastest blocks about every other time).  *before_ms / *after_ms
  * (may be NULL): the pass time per launch before and after.  Not for a batch whose result records are bound to a caller's
  * buffer; record candidates only for canonical records resident in the batch's own buffer.  The result records in the
  * device buffer afterwards are those of the last pass (have_results as after svt_batch_genotype).                    */

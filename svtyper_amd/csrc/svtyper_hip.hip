@@ -1522,6 +1522,12 @@ static int svt_batch_tune_placement_impl(svt_batch* b, int result_candidates, in
     if (before_ms) *before_ms = current;
     const bool resident_records = b->layout == kLayoutStream && b->records_resident && b->sargs.records == static_cast<const uint4*>(b->d_records);
     struct Cand { void* p; uint64_t cap; float ms; };
+    // The whole audition stays within ~0.3 s of uninterrupted passes: beyond that the device alternates between its level and one
+    // ~4 % slower until it has idled (profiles/r04_placement_tuning.txt), and candidates measured in that state are ranked by the
+    // state, not by their placement (an audition of 48 + 12 candidates at ten launches each kept a 0.301 ms pair where 32 + 8 found
+    // 0.285 twice).  So the launches per measurement follow from the pass time and the number of candidates.
+    const int n_cand = result_candidates + (resident_records ? record_candidates : 0);
+    const int iters = std::max(3, std::min(10, (int)(250.0f / (float)std::max(n_cand, 1) / (2.0f * std::max(current, 1e-3f)))));
     // ---- result records: plain allocations (they may be handed to RCCL or to another process)
     if (result_candidates > 0) {
         const uint64_t bytes = std::max<uint64_t>(b->cap_out, std::max<uint64_t>(b->out_slots, 1) * result_bytes(b));
@@ -1535,12 +1541,12 @@ static int svt_batch_tune_placement_impl(svt_batch* b, int result_candidates, in
         size_t best = cands.size();
         for (size_t i = 0; i < cands.size(); ++i) {
             b->sargs.out = b->pargs.out = static_cast<svt_result*>(cands[i].p);
-            SVT_TRY(best_of(2, 10, &cands[i].ms));
+            SVT_TRY(best_of(2, iters, &cands[i].ms));
             if (best == cands.size() || cands[i].ms < cands[best].ms) best = i;
         }
         if (best != cands.size()) {      // the winner once more, against the incumbent measured the same way (a single fast group is not a level)
             b->sargs.out = b->pargs.out = static_cast<svt_result*>(cands[best].p);
-            SVT_TRY(best_of(3, 10, &cands[best].ms));
+            SVT_TRY(best_of(3, iters, &cands[best].ms));
         }
         if (best != cands.size() && cands[best].ms < current * 0.995f) {
             HIP_TRY(hipStreamSynchronize(b->stream));
@@ -1572,12 +1578,12 @@ static int svt_batch_tune_placement_impl(svt_batch* b, int result_candidates, in
         size_t best = cands.size();
         for (size_t i = 0; i < cands.size(); ++i) {
             b->sargs.records = static_cast<const uint4*>(cands[i].p);
-            SVT_TRY(best_of(2, 10, &cands[i].ms));
+            SVT_TRY(best_of(2, iters, &cands[i].ms));
             if (best == cands.size() || cands[i].ms < cands[best].ms) best = i;
         }
         if (best != cands.size()) {
             b->sargs.records = static_cast<const uint4*>(cands[best].p);
-            SVT_TRY(best_of(3, 10, &cands[best].ms));
+            SVT_TRY(best_of(3, iters, &cands[best].ms));
         }
         if (best != cands.size() && cands[best].ms < current * 0.995f) {
             HIP_TRY(hipStreamSynchronize(b->stream));

@@ -337,7 +337,7 @@ class DeviceBatch:
         _check(self._lib.svt_batch_genotype_timed(self._h, int(iters), C.byref(ms)))
         return float(ms.value)
 
-    def tune_placement(self, result_candidates: int = 12, record_candidates: int = 4) -> dict:
+    def tune_placement(self, result_candidates: int = 32, record_candidates: int = 8) -> dict:
         """svt_batch_tune_placement: audition freshly allocated device buffers for the result records and the records with
         the real pass, keep the fastest (where a buffer lies in HBM moves the pass by up to 8 %).  Returns the pass time per
         launch before and after, in ms."""
