@@ -536,11 +536,12 @@ def main():
         w0 = time.perf_counter()
         r = d.tune_placement(tune_res, tune_rec)
         r["wall_ms"] = (time.perf_counter() - w0) * 1e3
-        # the audition is 0.2-0.5 s of uninterrupted passes, after which the device alternates for a while between its level and
-        # one ~4 % slower (groups of 20 passes: 0.289 / 0.300 ms; back to a steady 0.287 after half a second of idling,
+        # the audition is 0.3-0.4 s of uninterrupted passes, after which the device runs for a while at a level 4-7 % slower (1 M
+        # units: groups of 20 passes alternate 0.289 / 0.300 ms, a steady 0.287 again after half a second of idling; 4 M units:
+        # 1.20 instead of 1.127 ms through 1.5 s of idling and spin-ups, 1.127 again after two more seconds,
         # profiles/r04_placement_tuning.txt): let it idle before the spin-up and the timed steps, which are a burst of a few ms
-        time.sleep(0.5)
-        r["idle_after_s"] = 0.5
+        time.sleep(2.0)
+        r["idle_after_s"] = 2.0
         return r
 
     # the same launches WITHOUT the spin-up and on the buffers svt_batch_create drew, for the record (a device coming out of
