@@ -540,8 +540,8 @@ def main():
         # units: groups of 20 passes alternate 0.289 / 0.300 ms, a steady 0.287 again after half a second of idling; 4 M units:
         # 1.20 instead of 1.127 ms through 1.5 s of idling and spin-ups, 1.127 again after two more seconds,
         # profiles/r04_placement_tuning.txt): let it idle before the spin-up and the timed steps, which are a burst of a few ms
-        time.sleep(2.0)
-        r["idle_after_s"] = 2.0
+        r["idle_after_s"] = max(2.0, 8.0 * r["wall_ms"] * 1e-3)
+        time.sleep(r["idle_after_s"])
         return r
 
     # the same launches WITHOUT the spin-up and on the buffers svt_batch_create drew, for the record (a device coming out of
