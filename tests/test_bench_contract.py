@@ -41,6 +41,10 @@ def test_bench_line_has_the_contract_keys(hip_device):
     assert len(roof["source_sha16"]) == 16 and len(roof["library_sha16"]) == 16 and roof["compiler"]
     # the same launches without the untimed spin-up are in the record too
     assert roof["no_spinup_kernel_ms"] > 0 and 0 < roof["no_spinup_frac"] <= 1.0
+    # the placement audition before the timed steps is setup and says what it did; the six fresh allocations below are without it
+    pt = roof["placement_tuned"]
+    assert 0 < pt["after_ms"] <= pt["before_ms"] and pt["result_candidates"] == 32 and pt["record_candidates"] == 8 and pt["idle_after_s"] >= 2.0
+    assert d["sso"]["placement_tuned"]["after_ms"] <= d["sso"]["placement_tuned"]["before_ms"]
     pl = roof["placement"]
     assert len(pl["kernel_ms"]) == 6 and pl["min"] <= pl["median"] <= pl["max"] and pl["spread_pct"] >= 0
     # the labelled extra legs
@@ -58,6 +62,9 @@ def test_bench_line_has_the_contract_keys(hip_device):
     assert c5["units"] == 60000 - 60000 % 32          # configs[4]'s per-GPU share is twice the headline's units
     assert 0 < c5["frac"] <= 1.0 and c5["table_mode"] == 1 and c5["units"] % 32 == 0 and c5["hintless"]["table_mode"] == 1 and c5["hintless"]["results_equal"] and c5["general_tables"]["table_mode"] == 2
     assert c5["site_major_input"]["results_and_site_qual_equal"] is True
+    # ... and the same batch as packed evidence of several libraries (library switches in the pair streams)
+    assert c5["packed"]["results_equal"] is True and c5["packed"]["bytes_per_record"] < 6 and c5["packed"]["pass_ms"] > 0
+    assert c5["placement_tuned"]["after_ms"] <= c5["placement_tuned"]["before_ms"]
     assert c5["one_shot"]["hinted_results_equal"] and c5["one_shot"]["hintless_results_equal"] and c5["one_shot"]["hintless_over_hinted"] < 1.5
     for leg in (d["sso"], c5):
         assert leg["traffic"] is None or "these kernel sources" in leg["traffic_source"]
