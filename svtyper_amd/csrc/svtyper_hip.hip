@@ -60,6 +60,7 @@
 #include "svt_pack.h"
 #include "svt_stream_kernel.h"
 #include "svt_packed_kernel.h"
+#include "svt_coop_kernel.h"
 #include "svt_window_scan_kernel.h"
 #include "svt_geometry_kernel.h"
 #include "svt_bayes_kernel.h"
@@ -108,6 +109,10 @@ struct svt_batch {
     bool records_resident = true;    // false: create_stream left the record upload to its caller (pipelined one-shot)
     int wgs_per_cu = 3;              // workgroups per CU the pass's kernel was budgeted for (registers -> LDS per workgroup)
     uint32_t resident_wgs = 0;       // workgroups of the pass's kernel the device holds at once (registers, LDS, CUs); 0 = unknown
+    // the cooperative kernel for launches of less than one round (svt_coop_kernel.h); 0 bytes = not for this batch
+    size_t coop_lds_bytes = 0;
+    uint32_t coop_region = 0, coop_l10_where = kL10Global, coop_lds_l10 = 0, coop_l10_entries = 0;
+    uint32_t coop_resident = 0;      // workgroups of it the device holds at once
     StreamArgs sargs{};
     // kLayoutPacked: packed evidence as uploaded (svt_packed_kernel.h); d_records holds the slots, d_soff the 3n+1 offsets
     uint32_t* d_soff = nullptr;
@@ -187,6 +192,12 @@ const void* stream_kernel_of(const svt_batch* b, int tiles = SVT_STREAM_R)
     return (b->flags & SVT_FLAG_SSO_ASSOCIATION) ? stream_kernel_for<true>(b->mode, tiles) : stream_kernel_for<false>(b->mode, tiles);
 }
 
+const void* coop_kernel_of(const svt_batch* b)
+{
+    return (b->flags & SVT_FLAG_SSO_ASSOCIATION) ? reinterpret_cast<const void*>(&svt_coop_kernel<true, kSingleLds>)
+                                                  : reinterpret_cast<const void*>(&svt_coop_kernel<false, kSingleLds>);
+}
+
 // 64-unit tiles per wave for a launch over `units` units.  One tile per wave leaves a third of a workgroup's
 // wave-time waiting for the wave that holds its longest units; two tiles in snake order even that out (DESIGN.md
 // 3.1) but make a workgroup run longer, which pays once the one-tile launch would need more than one round of
@@ -237,7 +248,7 @@ inline uint32_t cu_count(int device)
 #ifndef SVT_WG_MIN_FILL
 #define SVT_WG_MIN_FILL 50   // per cent: the emptiest workgroup the rule may make (more than one round: never below 50)
 #endif
-struct WgPlan { int tiles; uint32_t per_wg, n_wg; };
+struct WgPlan { int tiles; uint32_t per_wg, n_wg; bool coop; };
 static std::atomic<int> g_wg_balance{SVT_WG_BALANCE && !std::getenv("SVT_NO_WG_BALANCE") ? SVT_WG_MIN_FILL : 0};   // (svt_debug_wg_balance: measurements)
 extern "C" int svt_debug_wg_balance(int min_fill_percent) { return g_wg_balance.exchange(std::max(0, std::min(100, min_fill_percent))); }
 inline uint32_t balanced_units_per_wg(uint64_t units, uint64_t n_min, uint32_t full, uint32_t resident)
@@ -250,9 +261,30 @@ inline uint32_t balanced_units_per_wg(uint64_t units, uint64_t n_min, uint32_t f
 }
 static std::atomic<uint32_t> g_force_per_wg{0}, g_force_tiles{0};     // (svt_debug_force_wg: measurements)
 extern "C" void svt_debug_force_wg(uint32_t per_wg, uint32_t tiles) { g_force_per_wg = per_wg; g_force_tiles = tiles; }
+// Launches of less than one round: five-wave workgroups whose producers look up and whose consumer sums (svt_coop_kernel.h).
+// A workgroup takes 64 ... 256 units -- as few as keep the launch inside ONE round of the resident cooperative workgroups, so
+// that a launch of a few thousand units still spreads over the chip.
+#ifndef SVT_COOP_MAX_UNITS
+#define SVT_COOP_MAX_UNITS 65536
+#endif
+static std::atomic<uint64_t> g_coop_max_units{std::getenv("SVT_NO_COOP") ? uint64_t(0) : uint64_t(SVT_COOP_MAX_UNITS)};
+static std::atomic<uint32_t> g_coop_per_wg{0};
+extern "C" void svt_debug_coop(uint64_t max_units, uint32_t per_wg) { g_coop_max_units = max_units; g_coop_per_wg = per_wg; }   // (measurements)
 WgPlan wg_plan(const svt_batch* b, uint64_t units)
 {
     WgPlan p;
+    p.coop = false;
+    if (b->coop_lds_bytes && units && units <= g_coop_max_units.load(std::memory_order_relaxed) && !g_force_per_wg.load(std::memory_order_relaxed)) {
+        p.coop = true;
+        p.per_wg = (uint32_t)kBlock;
+        if (const uint32_t f = g_coop_per_wg.load(std::memory_order_relaxed)) p.per_wg = std::min<uint32_t>((f + 63u) / 64u * 64u, (uint32_t)kBlock);
+        else
+            for (uint32_t per = 64; per < (uint32_t)kBlock; per += 64)
+                if ((units + per - 1) / per <= std::max<uint32_t>(b->coop_resident, 1)) { p.per_wg = per; break; }
+        p.tiles = (int)(p.per_wg / 64u);     // (slots_of_launch: n_wg * tiles * 64 result slots)
+        p.n_wg = (uint32_t)((units + p.per_wg - 1) / p.per_wg);
+        return p;
+    }
     if (const uint32_t f = g_force_per_wg.load(std::memory_order_relaxed)) {
         const int ft = (int)g_force_tiles.load(std::memory_order_relaxed);
         p.tiles = b->mode == kSingleLds && (ft == 1 || ft == 2) ? ft : tiles_per_wave(b, units);
@@ -272,6 +304,7 @@ uint64_t slots_of_launch(const svt_batch* b, uint64_t units)
     if (units == 0) return 0;
     if (b->layout == kLayoutPacked) return (units + kBlock - 1) / kBlock * kBlock;
     const WgPlan p = wg_plan(b, units);
+    if (p.coop) return (uint64_t)p.n_wg * (uint64_t)p.tiles * (uint64_t)kWave;
     return (uint64_t)p.n_wg * (uint64_t)kBlock * (uint64_t)p.tiles;
 }
 
@@ -280,6 +313,17 @@ int launch_stream(svt_batch* b, StreamArgs& a, hipStream_t stream)
     const uint64_t units = (uint64_t)a.unit_end - a.unit_begin;
     const WgPlan p = wg_plan(b, units);
     a.units_per_wg = p.per_wg;
+    if (p.coop) {
+        StreamArgs c = a;
+        c.lds_rings = b->coop_region;
+        c.l10_where = b->coop_l10_where;
+        c.lds_l10 = b->coop_lds_l10;
+        c.l10_lds_entries = b->coop_l10_entries;
+        const dim3 grid(p.n_wg), block(kCoopBlock);
+        void* params[] = {&c};
+        HIP_TRY(hipLaunchKernel(coop_kernel_of(b), grid, block, params, b->coop_lds_bytes, stream));
+        return SVT_OK;
+    }
     const dim3 grid(p.n_wg), block(kBlock);
     void* params[] = {&a};
     HIP_TRY(hipLaunchKernel(stream_kernel_of(b, p.tiles), grid, block, params, b->lds_bytes, stream));
@@ -692,6 +736,29 @@ int create_stream(const svt_evidence_batch* in, svt_batch* b, void* d_records_re
         a.l10_lds_entries = 0;
     }
     a.lds_rings = (uint32_t)tables;
+    // the cooperative kernel (one library): its own region behind the tables, two workgroups per CU
+    if (b->mode == kSingleLds && a.l10_where != kL10Ring) {
+        size_t ctab = (a.lds_winlibs + 127) & ~size_t(127);     // the tables without the log10 table
+        b->coop_l10_where = kL10Global;
+        b->coop_lds_l10 = 0;
+        b->coop_l10_entries = 0;
+        if (ctab + l10_bytes + kCoopRegionBytes <= (160 * 1024 / 2)) {
+            b->coop_l10_where = kL10Shared;
+            b->coop_lds_l10 = (uint32_t)ctab;
+            b->coop_l10_entries = n_l10;
+            ctab += l10_bytes;
+        }
+        if (ctab + kCoopRegionBytes <= 160 * 1024) {
+            b->coop_region = (uint32_t)ctab;
+            b->coop_lds_bytes = ctab + kCoopRegionBytes;
+            int wgs = 2;
+            hipFuncAttributes fa{};
+            if (hipFuncGetAttributes(&fa, coop_kernel_of(b)) == hipSuccess && fa.numRegs > 0) wgs = std::max(1, std::min(4, 512 / ((fa.numRegs + 7) / 8 * 8) * 4 / kCoopWaves));
+            else (void)hipGetLastError();
+            b->coop_resident = (uint32_t)std::min<size_t>((size_t)wgs, (160 * 1024) / b->coop_lds_bytes) * cu_count(b->device);
+            if (b->coop_lds_bytes > 64 * 1024) HIP_TRY(hipFuncSetAttribute(coop_kernel_of(b), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->coop_lds_bytes));
+        }
+    }
     a.n_units = n;
     a.unit_begin = 0;
     a.unit_end = (uint32_t)n;
