@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SVT_ABI_VERSION 13
+#define SVT_ABI_VERSION 14
 
 /* ---- error codes (0 = ok, <0 = error; text via svt_last_error()) ---------- */
 #define SVT_OK 0
@@ -343,11 +343,17 @@ int svt_batch_results(svt_batch* b, svt_result* out, uint64_t n_units);
  * records runs one of them -- svt_batch_genotype(b, 1) is enough -- before trusting them.     */
 int svt_batch_device_results(svt_batch* b, svt_result** dev_ptr);
 
-/* Make the kernel write its result records straight into a caller-owned DEVICE buffer of
- * n_units * svt_batch_result_bytes(b) bytes, 128-byte aligned (e.g. a torch tensor that is then
- * gathered over RCCL).  The buffer must stay alive until svt_batch_destroy or the next bind;
- * pass NULL to return to the library's own buffer.                                         */
+/* Make the kernel write its result records straight into a caller-owned DEVICE buffer, 128-byte aligned (e.g. a torch
+ * tensor that is then gathered over RCCL).  ONE size holds for both record forms:
+ *     svt_batch_result_slots(b) * svt_batch_result_bytes(b)   bytes
+ * -- n_units * 128 for svt_result records; under SVT_FLAG_RESULT96 the slots are whole workgroups of tagged 96-byte records
+ * (padding included), which for many small window chunks can be up to about twice n_units.  The buffer must stay alive until
+ * svt_batch_destroy or the next bind; pass NULL to return to the library's own buffer.
+ * svt_batch_bind_device_results2 (ABI 14) takes the buffer's capacity and refuses one that is too small (SVT_ERR_INVALID);
+ * the form without a capacity trusts the caller.  Either way a pass whose workgroup plan needs more slots than the bound
+ * buffer was sized for fails with SVT_ERR_STATE instead of writing beyond it.                                              */
 int svt_batch_bind_device_results(svt_batch* b, svt_result* dev_ptr);
+int svt_batch_bind_device_results2(svt_batch* b, void* dev_ptr, uint64_t capacity_bytes);
 
 /* Optional, for a resident batch that is passed over many times -- and for the first batch of a chunked run, whose buffers the
  * following batches inherit through the library's pool.  Where the VRAM manager puts the records and the result records
@@ -541,7 +547,8 @@ int svt_genotype_packed(const svt_packed_evidence* in, svt_result* out, int devi
  * threads encode the next one -- the wall time of the route is the longer of encoding and transfer, not their sum.  Same
  * result bytes as svt_pack_evidence + svt_genotype_packed (and as svt_genotype over the same records).  Any number of
  * libraries (histograms wider than 2047 bins: SVT_ERR_UNSUPPORTED, the packed format's limit); small batches take the
- * plain sequence.
+ * plain sequence.  On any error `out` is UNDEFINED: ranges in front of a range that breaks the record contract have been
+ * genotyped and written by then.
  * Replaces, for a producer that holds a batch of fragments in host memory, the hand-over at singlesample.py:355.      */
 int svt_genotype_packed_from_records(const svt_evidence_batch* in, svt_result* out, int device, unsigned flags);
 

@@ -459,9 +459,9 @@ __global__ __launch_bounds__(kCoopBlock, SVT_COOP_WAVES_PER_SIMD) void svt_coop_
     }
     const uint32_t bad = check.bits(a.n_libs);
     if (bad) atomicOr(a.err, bad);
-    if (SVT_COOP_TRACE && blockIdx.x == 0 && lane == 0) {
+    if (SVT_COOP_TRACE && (blockIdx.x % 61u) == 0 && lane == 0 && (wave == 0 || wave == 5)) {
         const uint64_t trace_t3 = clock64();
-        printf("coop wg0 wave %u: steps %u (tiles %u %u %u %u) prologue %llu loop %llu (%.0f per step) epilogue %llu cycles\n", wave, steps, tmax[0], tmax[1], tmax[2], tmax[3],
+        printf("coop wg %u wave %u (realtime %llu): steps %u (tiles %u %u %u %u) prologue %llu loop %llu (%.0f per step) epilogue %llu cycles\n", blockIdx.x, wave, (unsigned long long)wall_clock64(), steps, tmax[0], tmax[1], tmax[2], tmax[3],
                (unsigned long long)(trace_t1 - trace_t0), (unsigned long long)(trace_t2 - trace_t1), (double)(trace_t2 - trace_t1) / (double)max(steps, 1u),
                (unsigned long long)(trace_t3 - trace_t2));
     }

@@ -850,9 +850,16 @@ int encode_packed(const svt_evidence_batch* in, const PackAlloc& A, PackedArrays
     struct Release {
         const PackAlloc& A;
         PackedArrays* p;
+        const PackSink* sink;
         bool armed = true;
-        ~Release() { if (armed) { A.put(p->off); A.put(p->units); A.put(p->slots); *p = PackedArrays{}; } }
-    } release{A, out};
+        ~Release()
+        {
+            if (!armed) return;
+            if (sink && sink->drain) sink->drain(sink->ctx);   // (ranges already handed over may still be on their way out of these arrays)
+            A.put(p->off); A.put(p->units); A.put(p->slots);
+            *p = PackedArrays{};
+        }
+    } release{A, out, sink};
     out->off = static_cast<uint32_t*>(A.get((3 * n + 1) * sizeof(uint32_t)));
     out->units = static_cast<svt_unit*>(A.get(std::max<uint64_t>(n, 1) * sizeof(svt_unit)));
     if (!out->off || !out->units) return fail(SVT_ERR_NOMEM, "out of host memory");

@@ -41,6 +41,9 @@ struct PackSink {
     // units [u0, u1) are final in out->off (entries 3 u0 .. 3 u1), out->units and out->slots [s0, s1); called on the calling
     // thread of encode_packed, ranges in order; a non-zero return stops the encoder and becomes its return value
     int (*ready)(void* ctx, const struct PackedArrays* out, uint64_t u0, uint64_t u1, uint64_t s0, uint64_t s1) = nullptr;
+    // called before a FAILING encoder gives the output arrays back to the allocator: ranges handed over earlier may still be
+    // read by the consumer (DMA out of the page-locked arrays) -- it has to be through with them first
+    void (*drain)(void* ctx) = nullptr;
 };
 constexpr int SVT_ERR_PACK_OVERFLOW = -1000;   // internal: never leaves the library
 

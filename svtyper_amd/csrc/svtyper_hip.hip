@@ -104,6 +104,7 @@ struct svt_batch {
     uint64_t cap_perm = 0;
     uint32_t n_chunks = 0;
     int window_tiles = 1;            // kMultiLds: 64-unit tiles per wave (chunks hold up to 256 * window_tiles units)
+    uint64_t bound_slots = 0;        // svt_batch_bind_device_results: result records the caller's buffer holds (0 = the library's own buffer)
     uint64_t out_slots = 0;          // records in the device result buffer after a pass: n_units, or (SVT_FLAG_RESULT96) the slots of
                                      // the pass's workgroups -- tagged records in the kernel's order, padding included
     bool records_resident = true;    // false: create_stream left the record upload to its caller (pipelined one-shot)
@@ -360,6 +361,8 @@ int launch_range(svt_batch* b, uint64_t u0, uint64_t u1, hipStream_t stream, uin
     return launch_stream(b, a, stream);
 }
 
+int ensure_result_slots(svt_batch* b, uint64_t slots);
+
 int launch_genotype(svt_batch* b)
 {
     if (b->layout == kLayoutPacked) {
@@ -370,7 +373,22 @@ int launch_genotype(svt_batch* b)
         return SVT_OK;
     }
     if (b->n_units == 0) return SVT_OK;
-    if (b->mode != kMultiLds) return launch_stream(b, b->sargs, b->stream);
+    if (b->mode != kMultiLds) {
+        // The workgroup plan is looked up per launch (the debug hooks can move it between svt_batch_create and a pass): the tagged
+        // records of THIS launch must fit what the result buffer was sized for -- the library's own buffer grows, a caller's does not.
+        if (b->sargs.result96) {
+            const uint64_t need = slots_of_launch(b, b->n_units);
+            if (need != b->out_slots) {
+                if (b->out_dev != b->d_out) {
+                    if (need > b->bound_slots) return fail(SVT_ERR_STATE, "the pass needs more result slots than the bound device buffer holds");
+                } else {
+                    SVT_TRY(ensure_result_slots(b, need));
+                }
+                b->out_slots = need;
+            }
+        }
+        return launch_stream(b, b->sargs, b->stream);
+    }
     const dim3 grid(b->n_chunks), block(kBlock);   // library windows: one workgroup per chunk of a window's units
     void* params[] = {&b->sargs};
     HIP_TRY(hipLaunchKernel(stream_kernel_of(b, b->window_tiles), grid, block, params, b->lds_bytes, b->stream));
@@ -1130,44 +1148,43 @@ inline void expand96_one(const svt_result96& r, svt_result& o)
     std::memset(o.pad, 0, sizeof(o.pad));
 }
 
-// `n` tagged records -> out[tag] for the records that carry a unit (tags are taken relative to `out`, which holds `n_units`
-// records); `in` and `out` disjoint; split over the host threads.  What was placed is summed up so that the caller can tell
-// whether every unit was covered exactly once: the count and the sum of the tags must be those of 0 .. n_units - 1 (a missing
-// unit or one written twice changes one of them; a tag out of range is refused on the spot).
+// Tagged 96-byte records (SVT_FLAG_RESULT96: the kernel's order, padding tagged SVT_NO_UNIT) -> out[tag] as svt_result
+// records; `in` and `out` disjoint; split over the host threads.  Whether every unit is covered EXACTLY once is tracked per
+// unit (one byte each, claimed with an atomic exchange before the record is written): a tag out of range, or a second record
+// for a unit, is refused on the spot -- nothing is written for it, no two threads ever write one out[] element -- and a
+// unit nobody claimed shows in the count.  (A count and a sum of the tags, the first form, let {1, 1, 2, 2} pass for {0, 1, 2, 3}.)
 struct Placed {
-    uint64_t count = 0, tag_sum = 0;
-    bool bad = false;
-    void add(const Placed& o) { count += o.count; tag_sum += o.tag_sum; bad = bad || o.bad; }
-    bool covers(uint64_t n_units) const { return !bad && count == n_units && tag_sum == (n_units ? n_units * (n_units - 1) / 2 : 0); }
+    uint64_t n_units = 0;
+    std::unique_ptr<std::atomic<unsigned char>[]> seen;
+    std::atomic<uint64_t> count{0};
+    std::atomic<bool> bad{false};
+    explicit Placed(uint64_t n) : n_units(n), seen(n ? new std::atomic<unsigned char>[n]() : nullptr) {}
+    // true: the caller may write out[u]
+    bool claim(uint32_t u)
+    {
+        if (u >= n_units || seen[u].exchange(1, std::memory_order_relaxed)) { bad.store(true, std::memory_order_relaxed); return false; }
+        return true;
+    }
+    bool covers(uint64_t n) const { return n == n_units && !bad.load() && count.load() == n_units; }
 };
 
-inline Placed expand96(const svt_result96* in, uint64_t n, svt_result* out, uint64_t n_units)
+inline void expand96(const svt_result96* in, uint64_t n, svt_result* out, Placed& placed)
 {
     const uint64_t kChunk = 8192;
     const uint64_t chunks = (n + kChunk - 1) / kChunk;
-    std::atomic<uint64_t> count{0}, tag_sum{0};
-    std::atomic<bool> bad{false};
     auto run = [&](uint64_t c) {
         const uint64_t hi = std::min(n, (c + 1) * kChunk);
-        uint64_t mine = 0, sum = 0;
+        uint64_t mine = 0;
         for (uint64_t i = c * kChunk; i < hi; ++i) {
             const uint32_t u = in[i].unit;
-            if (u == SVT_NO_UNIT) continue;
-            if (u >= n_units) { bad.store(true, std::memory_order_relaxed); continue; }
+            if (u == SVT_NO_UNIT || !placed.claim(u)) continue;
             expand96_one(in[i], out[u]);
             ++mine;
-            sum += u;
         }
-        count.fetch_add(mine, std::memory_order_relaxed);
-        tag_sum.fetch_add(sum, std::memory_order_relaxed);
+        placed.count.fetch_add(mine, std::memory_order_relaxed);
     };
     if (chunks <= 1) { if (chunks) run(0); }
     else parallel_for(chunks, run);
-    Placed p;
-    p.count = count.load();
-    p.tag_sum = tag_sum.load();
-    p.bad = bad.load();
-    return p;
 }
 
 // the batch's device result records -> out[n_units] (svt_result), whichever form the device holds
@@ -1192,14 +1209,14 @@ int d2h_results(svt_batch* b, svt_result* out)
     const unsigned char* src = reinterpret_cast<const unsigned char*>(b->out_dev);
     uint64_t s0 = 0, prev_n = 0;
     int slot = 0, prev_slot = -1;
-    Placed placed;
+    Placed placed(n);
     while (s0 < total || prev_slot >= 0) {
         uint64_t cnt = 0;
         if (s0 < total) {
             cnt = std::min(per_piece, total - s0);
             HIP_TRY(hipMemcpyAsync(ring.buf[slot], src + s0 * sizeof(svt_result96), cnt * sizeof(svt_result96), hipMemcpyDeviceToHost, b->stream));
         }
-        if (prev_slot >= 0) placed.add(expand96(static_cast<const svt_result96*>(ring.buf[prev_slot]), prev_n, out, n));
+        if (prev_slot >= 0) expand96(static_cast<const svt_result96*>(ring.buf[prev_slot]), prev_n, out, placed);
         HIP_TRY(hipStreamSynchronize(b->stream));
         prev_slot = cnt ? slot : -1;
         prev_n = cnt;
@@ -1279,11 +1296,11 @@ int run_pipelined(svt_batch* b, svt_result* out, bool* download_left, PayloadOf&
     tm.mark("pipeline: pieces enqueued");
     // (96-byte records: piece k is expanded as soon as it is down, while the later pieces are still going up; should the pass
     // report a contract violation below, what was expanded is discarded with the error)
-    Placed placed;
+    Placed placed(n);
     if (r96)
         for (const Piece& pc : pieces) {
             HIP_TRY(hipEventSynchronize(pc.down));
-            placed.add(expand96(static_cast<const svt_result96*>(scratch.p) + pc.s0, pc.s1 - pc.s0, out, n));
+            expand96(static_cast<const svt_result96*>(scratch.p) + pc.s0, pc.s1 - pc.s0, out, placed);
         }
     HIP_TRY(hipStreamSynchronize(b->stream));
     tm.mark("pipeline: uploads done");
@@ -1557,6 +1574,23 @@ static int svt_batch_tune_placement_impl(svt_batch* b, int result_candidates, in
     if (b->n_units == 0) return SVT_OK;
     if (b->out_dev != b->d_out) return fail(SVT_ERR_INVALID, "the result records are bound to a caller's buffer (svt_batch_bind_device_results)");
     HIP_TRY(hipSetDevice(b->device));
+    // Whatever way this function is left -- an audition cut short by a failing launch or copy included -- the pass's arguments
+    // point at the batch's OWN buffers again (the candidate guards below synchronise the stream before they release anything),
+    // and a batch left half way has no results.
+    struct Restore {
+        svt_batch* b;
+        bool done = false;
+        ~Restore()
+        {
+            if (!done) {
+                (void)hipStreamSynchronize(b->stream);
+                b->have_results = false;
+            }
+            b->out_dev = b->d_out;
+            b->sargs.out = b->pargs.out = b->d_out;
+            if (b->layout == kLayoutStream && b->records_resident) b->sargs.records = static_cast<const uint4*>(b->d_records);
+        }
+    } restore{b};
     auto pass_ms = [&](int iters, float* ms) -> int {      // `iters` back-to-back launches, per launch
         float total = 0.f;
         HIP_TRY(hipEventRecord(b->ev0, b->stream));
@@ -1599,7 +1633,7 @@ static int svt_batch_tune_placement_impl(svt_batch* b, int result_candidates, in
     if (result_candidates > 0) {
         const uint64_t bytes = std::max<uint64_t>(b->cap_out, std::max<uint64_t>(b->out_slots, 1) * result_bytes(b));
         std::vector<Cand> cands;
-        struct FreeAll { std::vector<Cand>& c; ~FreeAll() { for (Cand& x : c) if (x.p) (void)hipFree(x.p); } } guard{cands};
+        struct FreeAll { std::vector<Cand>& c; hipStream_t s; ~FreeAll() { (void)hipStreamSynchronize(s); for (Cand& x : c) if (x.p) (void)hipFree(x.p); } } guard{cands, b->stream};
         for (int i = 0; i < result_candidates; ++i) {
             void* p = nullptr;
             if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); break; }     // (out of memory: audition what there is)
@@ -1630,7 +1664,7 @@ static int svt_batch_tune_placement_impl(svt_batch* b, int result_candidates, in
     if (record_candidates > 0 && resident_records) {
         const uint64_t bytes = ((uint64_t)b->sargs.last_blk + 1) * 128;      // the records as the kernel reads them: whole 128-byte blocks
         std::vector<Cand> cands;
-        struct FreeAll { std::vector<Cand>& c; int device; ~FreeAll() { for (Cand& x : c) if (x.p) g_pool.release(x.p, device); } } guard{cands, b->device};
+        struct FreeAll { std::vector<Cand>& c; int device; hipStream_t s; ~FreeAll() { (void)hipStreamSynchronize(s); for (Cand& x : c) if (x.p) g_pool.release(x.p, device); } } guard{cands, b->device, b->stream};
         for (int i = 0; i < record_candidates; ++i) {
             void* p = nullptr;
             uint64_t cap = 0;
@@ -1665,6 +1699,7 @@ static int svt_batch_tune_placement_impl(svt_batch* b, int result_candidates, in
     HIP_TRY(hipStreamSynchronize(b->stream));
     if (after_ms) *after_ms = current;
     b->have_results = true;      // (the last pass ran over the kept buffers)
+    restore.done = true;
     return check_stream_errors(b);
 }
 
@@ -1702,7 +1737,8 @@ int svt_results_expand96(const svt_result96* in, uint64_t n_records, svt_result*
 {
     return guarded([&]() -> int {
         if ((n_records && !in) || (n_units && !out)) return fail(SVT_ERR_INVALID, "null argument");
-        const Placed placed = expand96(in, n_records, out, n_units);
+        Placed placed(n_units);
+        expand96(in, n_records, out, placed);
         if (placed.bad) return fail(SVT_ERR_INVALID, "svt_results_expand96: a record's unit is beyond n_units");
         if (!placed.covers(n_units)) return fail(SVT_ERR_INVALID, "svt_results_expand96: the records do not cover every unit exactly once");
         return SVT_OK;
@@ -1733,13 +1769,17 @@ int svt_batch_device_results(svt_batch* b, svt_result** dev)
     return SVT_OK;
 }
 
-static int svt_batch_bind_device_results_impl(svt_batch* b, svt_result* dev)
+static int svt_batch_bind_device_results_impl(svt_batch* b, svt_result* dev, uint64_t capacity_bytes, bool have_capacity)
 {
     if (!b) return fail(SVT_ERR_INVALID, "null batch");
     if (dev && (reinterpret_cast<uintptr_t>(dev) & 127u)) return fail(SVT_ERR_INVALID, "result buffer must be 128-byte aligned");
+    const uint64_t need = std::max<uint64_t>(b->out_slots, 1) * result_bytes(b);
+    if (dev && have_capacity && capacity_bytes < need)
+        return fail(SVT_ERR_INVALID, "result buffer too small: svt_batch_result_slots(b) * svt_batch_result_bytes(b) = " + std::to_string(need) + " bytes");
     b->out_dev = dev ? dev : b->d_out;
     b->sargs.out = b->out_dev;
     b->pargs.out = b->out_dev;
+    b->bound_slots = dev ? (have_capacity ? capacity_bytes / result_bytes(b) : b->out_slots) : 0;   // what a later pass may write
     b->have_results = false;
 
     return SVT_OK;
@@ -1747,7 +1787,12 @@ static int svt_batch_bind_device_results_impl(svt_batch* b, svt_result* dev)
 
 int svt_batch_bind_device_results(svt_batch* b, svt_result* dev)
 {
-    return guarded([&] { return svt_batch_bind_device_results_impl(b, dev); });
+    return guarded([&] { return svt_batch_bind_device_results_impl(b, dev, 0, false); });
+}
+
+int svt_batch_bind_device_results2(svt_batch* b, void* dev, uint64_t capacity_bytes)
+{
+    return guarded([&] { return svt_batch_bind_device_results_impl(b, static_cast<svt_result*>(dev), capacity_bytes, true); });
 }
 
 int svt_batch_bytes(const svt_batch* b, uint64_t* algorithmic, uint64_t* resident)
@@ -2157,6 +2202,12 @@ static int svt_genotype_packed_from_records_impl(const svt_evidence_batch* in, s
             }
             return SVT_OK;
         };
+        sink.drain = [](void* vctx) {
+            Ctx& c = *static_cast<Ctx*>(vctx);
+            if (c.b->stream) (void)hipStreamSynchronize(c.b->stream);
+            if (c.ps.compute) (void)hipStreamSynchronize(c.ps.compute);
+            if (c.ps.down) (void)hipStreamSynchronize(c.ps.down);
+        };
         const PackAlloc pool{[](uint64_t bytes) { return g_pinned.get(bytes); }, [](void* p) { g_pinned.put(p); }};
         rc = encode_packed(in, pool, &arr, &sink);
         overflow = rc == SVT_ERR_PACK_OVERFLOW;
@@ -2169,8 +2220,8 @@ static int svt_genotype_packed_from_records_impl(const svt_evidence_batch* in, s
         b->n_slots = arr.n_slots;
         b->have_results = true;
         b->out_slots = ctx.r96 ? ctx.next_slot : n;
-        Placed placed;
-        for (const Piece& pc : ctx.pieces) placed.add(expand96(static_cast<const svt_result96*>(ctx.scratch) + pc.s0, pc.s1 - pc.s0, out, n));
+        Placed placed(n);
+        for (const Piece& pc : ctx.pieces) expand96(static_cast<const svt_result96*>(ctx.scratch) + pc.s0, pc.s1 - pc.s0, out, placed);
         if (ctx.r96 && !placed.covers(n)) rc = fail(SVT_ERR_INTERNAL, "the device result records do not cover every unit exactly once");
         if (!ctx.out_pinned && !ctx.r96) rc = d2h_results(b, out);
     }

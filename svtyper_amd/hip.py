@@ -16,13 +16,13 @@ from .evidence import GT_BLANK, CEvidenceBatch, CPackedEvidence, EvidenceBatch, 
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SVTYPER_HIP_LIB") or os.path.join(_HERE, "csrc", "libsvtyper_hip.so")
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 EXPORTS = (
     "svt_version", "svt_device_count", "svt_last_error", "svt_batch_create", "svt_batch_create_from_fragments",
     "svt_batch_genotype",
     "svt_batch_genotype_n", "svt_batch_genotype_timed", "svt_batch_tune_placement", "svt_batch_results", "svt_batch_device_results",
-    "svt_batch_bind_device_results", "svt_batch_result_order", "svt_batch_bytes", "svt_batch_layout", "svt_batch_site_qual",
+    "svt_batch_bind_device_results", "svt_batch_bind_device_results2", "svt_batch_result_order", "svt_batch_bytes", "svt_batch_layout", "svt_batch_site_qual",
     "svt_batch_stream", "svt_batch_destroy", "svt_trim", "svt_bayes_gt", "svt_genotype_counts", "svt_genotype", "svt_genotype_multi", "svt_shard_bounds",
     "svt_pinned_alloc", "svt_pinned_free", "svt_pack_evidence", "svt_packed_free", "svt_batch_create_packed", "svt_genotype_packed",
     "svt_format_results", "svt_format_free", "svt_results_host_sq", "svt_batch_result_bytes", "svt_batch_result_slots", "svt_results_expand96",
@@ -80,6 +80,8 @@ def load() -> C.CDLL:
     L.svt_batch_device_results.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
     L.svt_batch_bind_device_results.restype = C.c_int
     L.svt_batch_bind_device_results.argtypes = [C.c_void_p, C.c_void_p]
+    L.svt_batch_bind_device_results2.restype = C.c_int
+    L.svt_batch_bind_device_results2.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
     L.svt_format_results.restype = C.c_int
     L.svt_format_results.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_int, C.POINTER(C.c_void_p),
                                      C.POINTER(C.c_void_p)]
@@ -404,10 +406,14 @@ class DeviceBatch:
         del v
         return t
 
-    def bind_device_results(self, dev_ptr: int):
-        """Caller-owned device buffer (n_units * 128 bytes, 128-byte aligned), e.g. a torch
-        tensor's data_ptr(); 0 returns to the library's own buffer."""
-        _check(self._lib.svt_batch_bind_device_results(self._h, C.c_void_p(int(dev_ptr) or None)))
+    def bind_device_results(self, dev_ptr: int, capacity_bytes: Optional[int] = None):
+        """Caller-owned device buffer of result_slots() * result_bytes() bytes, 128-byte aligned (n_units * 128 for 128-byte
+        records; whole workgroups of tagged records under FLAG_RESULT96), e.g. a torch tensor's data_ptr(); 0 returns to the
+        library's own buffer.  With `capacity_bytes` the library refuses a buffer that is too small."""
+        if capacity_bytes is None or not dev_ptr:
+            _check(self._lib.svt_batch_bind_device_results(self._h, C.c_void_p(int(dev_ptr) or None)))
+        else:
+            _check(self._lib.svt_batch_bind_device_results2(self._h, C.c_void_p(int(dev_ptr)), C.c_uint64(int(capacity_bytes))))
 
     def bytes(self):
         a, r = C.c_uint64(), C.c_uint64()

@@ -1,0 +1,101 @@
+"""Launches of less than one round of resident workgroups take svt_coop_kernel (svtyper_amd/csrc/svt_coop_kernel.h): eight
+producer waves per workgroup do the table look-ups of the records, three consumer waves add the addends in record order.  Same
+operands, same operations, same order per accumulator as the streaming kernel's one lane per unit -- so the same BYTES, which
+is what these tests demand: against the streaming kernel (the debug hook switches the cooperative one off) and against the
+oracle, both associations, both device record forms, every workgroup size, ragged / empty / skipped units, long units."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from svtyper_amd import evidence as ev
+from svtyper_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+FLAGS = [0, ev.FLAG_SSO_ASSOCIATION, ev.FLAG_RESULT96, ev.FLAG_SSO_ASSOCIATION | ev.FLAG_RESULT96]
+DEFAULT_MAX = 65536
+
+
+def _hook():
+    from svtyper_amd import hip
+    lib = hip.load()
+    lib.svt_debug_coop.argtypes = [C.c_uint64, C.c_uint32]
+    lib.svt_debug_coop.restype = None
+    return lib
+
+
+def _resident(batch, device, flags, order=0):
+    from svtyper_amd import hip
+    with hip.DeviceBatch(batch, device, flags) as d:
+        if order:
+            d.result_order(order)
+        d.genotype(sync=True)
+        return d.results().rec.tobytes(), d.result_slots()
+
+
+def test_same_bytes_as_the_streaming_kernel_and_the_oracle(hip_device, fixture_library):
+    from oracle import c_oracle
+    from svtyper_amd import hip
+    lib = _hook()
+    batches = [
+        synth.make_edge_cases([fixture_library], seed=23),                                   # empty / skipped / continuation records / 1 300-record units
+        synth.make_units(9_000, 5, [fixture_library], svtype_mix=(0.5, 0.2, 0.2, 0.1), mean_frags=60, sd_frags=50, min_frags=0, max_frags=400,
+                         frac_empty=0.04, frac_skip=0.02),
+        synth.make_units(20_011, 6, [fixture_library], svtype_mix=(0.7, 0.15, 0.15, 0.0)),  # the configs[2] shape, a last workgroup that is not full
+        synth.make_units(1, 7, [fixture_library]),
+        synth.make_units(65, 8, [fixture_library], mean_frags=3, sd_frags=2, min_frags=0, max_frags=9),
+    ]
+    try:
+        for batch in batches:
+            for flags in FLAGS:
+                lib.svt_debug_coop(0, 0)
+                want, slots_stream = _resident(batch, hip_device, flags)
+                oracle = c_oracle.genotype_batch(batch, flags=flags & ev.FLAG_SSO_ASSOCIATION)
+                assert np.array_equal(np.frombuffer(want, ev.RESULT_DTYPE)["gt"], oracle.gt)
+                for per_wg in (0, 64, 128, 192, 256):
+                    lib.svt_debug_coop(1 << 40, per_wg)
+                    got, slots = _resident(batch, hip_device, flags)
+                    assert got == want, (batch.n_units, flags, per_wg)
+                    if flags & ev.FLAG_RESULT96:
+                        assert slots % 64 == 0 and batch.n_units <= slots <= batch.n_units + 255 + 256 * (per_wg == 0)
+                    else:
+                        assert slots == batch.n_units
+                    # the one-shot entry (upload || pass || download by unit ranges: every range its own cooperative launch)
+                    assert hip.genotype_batch(batch, hip_device, flags).rec.tobytes() == want
+    finally:
+        lib.svt_debug_coop(DEFAULT_MAX, 0)
+
+
+def test_the_default_rule_picks_it_for_small_launches_only(hip_device, fixture_library):
+    """<= 65 536 units of one library: cooperative (tagged records in whole 64-unit tiles); above: the streaming kernel's whole
+    256-unit workgroups; several libraries: the streaming kernel (library windows)."""
+    small = synth.make_units(10_000, 9, [fixture_library], mean_frags=8, sd_frags=4, min_frags=0, max_frags=20)
+    large = synth.make_units(70_000, 10, [fixture_library], mean_frags=8, sd_frags=4, min_frags=0, max_frags=20)
+    two = synth.make_units(10_000, 11, [fixture_library, synth.normal_library(420.0, 95.0, seed=3)], mean_frags=8, sd_frags=4, min_frags=0, max_frags=20)
+    _, s_small = _resident(small, hip_device, ev.FLAG_RESULT96)
+    _, s_large = _resident(large, hip_device, ev.FLAG_RESULT96)
+    _, s_two = _resident(two, hip_device, ev.FLAG_RESULT96)
+    assert s_small == (10_000 + 63) // 64 * 64          # 64 units per workgroup: 157 workgroups, one 64-unit tile each
+    assert s_large == (70_000 + 255) // 256 * 256
+    assert s_two % 256 == 0
+
+
+def test_sample_major_units_site_major_records(hip_device, fixture_library):
+    """svt_batch_result_order through the cooperative kernel: one library, units sample-major, records (and tags) site-major"""
+    lib = _hook()
+    n_sites, n_samples = 900, 8
+    batch = synth.make_units(n_sites * n_samples, 12, [fixture_library], svtype_mix=(0.6, 0.2, 0.2, 0.0), mean_frags=25, sd_frags=10, min_frags=0)
+    try:
+        for flags in (0, ev.FLAG_RESULT96):
+            lib.svt_debug_coop(0, 0)
+            want, _ = _resident(batch, hip_device, flags, order=n_samples)
+            lib.svt_debug_coop(1 << 40, 0)
+            got, _ = _resident(batch, hip_device, flags, order=n_samples)
+            assert got == want
+            plain, _ = _resident(batch, hip_device, flags)
+            a = np.frombuffer(plain, ev.RESULT_DTYPE).reshape(n_samples, n_sites)
+            b = np.frombuffer(got, ev.RESULT_DTYPE).reshape(n_sites, n_samples)
+            assert a.T.tobytes() == b.tobytes()
+    finally:
+        lib.svt_debug_coop(DEFAULT_MAX, 0)

@@ -47,12 +47,17 @@ def test_expansion_restores_the_oracles_counts(fixture_library, sso):
         hip.expand96(padded, n, into)
         assert into.tobytes() == want.rec.tobytes()
         # a unit missing, a unit twice, a tag beyond the units: refused
-        for breaker in ("missing", "twice", "beyond"):
+        # ("pair": one unit twice AND another one missing at once -- {1, 1, 2, 2} for {0, 1, 2, 3} keeps both the count and the
+        # sum of the tags, which was all the first form of the check looked at)
+        for breaker in ("missing", "twice", "beyond", "pair"):
             x = padded.copy()
             if breaker == "missing":
                 x["unit"][at[5]] = ev.NO_UNIT
             elif breaker == "twice":
                 x["unit"][at[5]] = x["unit"][at[6]]
+            elif breaker == "pair":
+                lo, hi = np.nonzero(x["unit"] == 0)[0][0], np.nonzero(x["unit"] == 3)[0][0]
+                x["unit"][lo], x["unit"][hi] = 1, 2
             else:
                 x["unit"][at[5]] = n
             with pytest.raises(hip.SvtyperHipError):
@@ -233,3 +238,34 @@ def test_tune_placement_keeps_the_results(hip_device, fixture_library):
             d.tune_placement(2, 1)
         finally:
             other.close()
+
+
+@pytest.mark.gpu
+def test_bind_with_a_capacity_refuses_a_short_buffer(hip_device, fixture_library):
+    """svt_batch_bind_device_results2: the buffer for the device records is result_slots() * result_bytes() bytes for both
+    record forms; a shorter one is refused instead of being overrun by the pass."""
+    import ctypes as C
+    from svtyper_amd import hip
+    lib = hip.load()
+    lib.svt_debug_device_alloc.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.POINTER(C.c_void_p)]
+    lib.svt_debug_device_free.argtypes = [C.c_int, C.c_void_p]
+    batch = synth.make_units(3000, 77, [fixture_library], svtype_mix=(0.5, 0.2, 0.2, 0.1), mean_frags=20, sd_frags=10, min_frags=0)
+    want = hip.genotype_batch(batch, hip_device, 0)
+    for flags in (0, ev.FLAG_RESULT96):
+        with hip.DeviceBatch(batch, hip_device, flags) as d:
+            need = d.result_slots() * d.result_bytes()
+            assert need >= batch.n_units * d.result_bytes()
+            buf = C.c_void_p()
+            hip._check(lib.svt_debug_device_alloc(hip_device, need + 256, 0, C.byref(buf)))
+            try:
+                base = (buf.value + 127) // 128 * 128
+                with pytest.raises(hip.SvtyperHipError):
+                    d.bind_device_results(base, need - 1)
+                d.bind_device_results(base, need)
+                d.genotype(sync=True)
+                assert d.results().rec.tobytes() == want.rec.tobytes()
+                d.bind_device_results(0)
+                d.genotype(sync=True)
+                assert d.results().rec.tobytes() == want.rec.tobytes()
+            finally:
+                hip._check(lib.svt_debug_device_free(hip_device, buf))
