@@ -111,6 +111,173 @@ def generate(name: str, n_units: int, rank: int, workers: int, first_chunk: int 
     return parts[0] if len(parts) == 1 else ev.concat_batches(parts)
 
 
+def _count_chunk(args):
+    name, n, idx, rank = args
+    from svtyper_amd import synth
+    cfg = synth.CONFIGS[name]
+    return synth.make_units(n, synth.BASE_SEED + cfg["config_no"] + 1000 * idx + 7919 * rank,
+                            [fixture_library()], svtype_mix=cfg["svtype_mix"], counts_only=True)
+
+
+def generate_shard(name: str, n_units: int, world: int, r: int, workers: int, group: int = 1):
+    """Shard r of `world` of the workload generate(name, n_units, rank=0) under the shard rule (distributed.shard_bounds),
+    without building the rest of it: the records per unit of every chunk are the first few draws of its generator
+    (synth.make_units(counts_only=True)), the bounds follow from them, and only the chunks the shard overlaps are generated.
+    Returns (the shard, the bounds of all ranks)."""
+    from svtyper_amd import distributed as D
+    from svtyper_amd import evidence as ev
+    chunk = 50_000
+    jobs = [(name, min(chunk, n_units - i), i // chunk, 0) for i in range(0, n_units, chunk)]
+    counts = np.concatenate([_count_chunk(j) for j in jobs]) if jobs else np.zeros(0, np.int64)
+    rec_offset = np.zeros(n_units + 1, np.uint64)
+    np.cumsum(counts, out=rec_offset[1:])
+    bounds = D.shard_bounds(rec_offset, world, group)
+    lo, hi = bounds[r]
+    if hi <= lo:
+        return _gen_chunk(jobs[0]).slice(0, 0), bounds
+    first, last = lo // chunk, (hi - 1) // chunk
+    mine = jobs[first:last + 1]
+    if workers > 1 and len(mine) > 1:
+        import multiprocessing as mp
+        with mp.get_context("fork").Pool(min(workers, len(mine))) as pool:
+            parts = pool.map(_gen_chunk, mine)
+    else:
+        parts = [_gen_chunk(j) for j in mine]
+    b = parts[0] if len(parts) == 1 else ev.concat_batches(parts)
+    return b.slice(lo - first * chunk, hi - first * chunk), bounds
+
+
+def pipelined_passes(dbatch, sizes, batches, backend, compact=False):
+    """`batches` passes of the resident batch, each followed by the gather of ITS result records onto rank 0 -- with the gather
+    of batch k running under the pass of batch k + 1: two result buffers per rank, the pass writes one while the collective
+    reads the other (RCCL on its own stream; ranks that share a device: gloo from a host copy).  Every rank calls this between
+    barriers; returns the seconds for all of it on this rank (the caller takes the maximum over the ranks)."""
+    import torch
+    from svtyper_amd import distributed as D
+    cur = dbatch.result_slots() * dbatch.result_bytes()
+    bufs = [torch.empty(cur + 128, dtype=torch.uint8, device="cuda") for _ in range(2)]
+    base = [(b.data_ptr() + 127) // 128 * 128 - b.data_ptr() for b in bufs]
+    try:
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(batches + 1):
+            if k < batches:
+                dbatch.bind_device_results(bufs[k % 2].data_ptr() + base[k % 2], cur)
+                dbatch.genotype(sync=False)
+            if k >= 1:
+                src = bufs[(k - 1) % 2][base[(k - 1) % 2]: base[(k - 1) % 2] + cur]
+                if compact:
+                    src = D.compact_tagged_records(src)
+                D.gather_bytes(src if backend == "nccl" else src.cpu(), sizes, dst=0)
+            if k < batches:
+                dbatch.synchronize()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+    finally:
+        dbatch.bind_device_results(0)
+
+
+def dist_leg(what, dbatch, counts, total_units, steps, warmup, rank, world, backend, coll_device, n_dev, order=0, alone=None, sites_per_unit=None):
+    """One workload through the N-rank job, every rank calling this with ITS resident shard: the passes alone (barrier + device
+    sync on both sides, maximum over the ranks), the single gather of the result records onto rank 0, the same with compact
+    48-byte records, and the pipelined steady state (pipelined_passes).  Rank 0 returns the leg's dict; `alone` (rank 0): the
+    result records of one rank's pass over the WHOLE workload -- what the gathered records must equal."""
+    import torch
+    import torch.distributed as dist
+    from svtyper_amd import distributed as D
+    from svtyper_amd import evidence as ev
+    rec_bytes = dbatch.result_bytes()
+    if order:
+        dbatch.result_order(order)
+    dbatch.genotype(sync=True)
+    spin_up(dbatch, 20.0)
+    for _ in range(warmup):
+        dbatch.genotype(sync=False)
+    dbatch.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    kern_ms = dbatch.genotype_timed(steps) / steps
+    torch.cuda.synchronize()
+    dist.barrier()
+    elapsed = time.perf_counter() - t0
+    mine = torch.tensor([elapsed, kern_ms], dtype=torch.float64, device=coll_device)
+    every = [torch.zeros(2, dtype=torch.float64, device=coll_device) for _ in range(world)]
+    dist.all_gather(every, mine)
+    elapsed = max(float(t[0].item()) for t in every)
+    kern_all = [float(t[1].item()) for t in every]
+
+    res = dbatch.device_results_tensor()
+    cur = dbatch.result_slots() * rec_bytes
+
+    def one_gather(compact):
+        dist.barrier()
+        torch.cuda.synchronize()
+        g0 = time.perf_counter()
+        src = res[:cur]
+        if compact:
+            src = D.compact_tagged_records(src)
+        src = src if backend == "nccl" else src.cpu()
+        if rec_bytes == 96:
+            gathered, sizes = D.gather_tagged_records(src, dst=0)
+        else:
+            sizes = [c * rec_bytes for c in counts]
+            gathered = D.gather_result_records(src, counts, dst=0)
+        torch.cuda.synchronize()
+        dist.barrier()
+        return gathered, sizes, time.perf_counter() - g0
+
+    gathered, sizes, g_s = one_gather(False)
+    same = None
+    if rank == 0 and alone is not None:
+        joined = D.results_from_tagged(gathered, sizes, counts) if rec_bytes == 96 else D.results_from_bytes(gathered)
+        same = bool(np.array_equal(joined.rec, alone))
+        del joined
+    gathered = None
+    compact = None
+    if rec_bytes == 96:
+        c_gathered, c_sizes, c_s = one_gather(True)
+        c_same = None
+        if rank == 0 and alone is not None:
+            j = D.results_from_compact(c_gathered, c_sizes, counts).rec
+            c_same = bool(np.array_equal(j["gl"], alone["gl"]) and np.array_equal(j["sq"], alone["sq"]) and np.array_equal(j["gt"], alone["gt"])
+                          and np.array_equal(j["counts"][:, :3], alone["counts"][:, :3]))
+        c_gathered = None
+        compact = {"record_bytes": 48, "ms": c_s * 1e3, "GB/s_into_root": sum(c_sizes[1:] or c_sizes) / c_s / 1e9,
+                   "fields": "GL, SQ, QR, QA, GQ, GT + the unit tag (what parsers.py:375-399 prints of a genotype; DP / RO / AO / RS / AS / ASC / RP / AP "
+                             "need the 40 bytes of tallies)", "genotype_fields_equal_single_rank_pass": c_same}
+    res = None
+    # ---- steady state: pass of batch k+1 over the gather of batch k
+    batches = max(8, steps)
+    pipe = {}
+    for key, comp in (("value_pipelined", False),) + ((("value_pipelined_compact", True),) if rec_bytes == 96 else ()):
+        use_sizes = (c_sizes if comp else sizes)
+        dist.barrier()
+        p_s = pipelined_passes(dbatch, use_sizes, batches, backend, compact=comp)
+        dist.barrier()
+        t = torch.tensor([p_s], dtype=torch.float64, device=coll_device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        pipe[key] = total_units * batches / float(t[0].item())
+        pipe[key.replace("value_", "ms_per_batch_")] = float(t[0].item()) / batches * 1e3
+    if rank != 0:
+        return None
+    value = total_units * steps / elapsed
+    leg = {"what": what, "total_units": int(total_units), "units_per_rank": [int(c) for c in counts], "steps": steps,
+           "kernel_ms_per_rank": kern_all, "ms_per_step": elapsed / steps * 1e3, "value": value, "unit": "breakpoints/s",
+           "gather": {"record_bytes": rec_bytes, "bytes_per_rank": int(cur), "ms": g_s * 1e3, "GB/s_into_root": sum(sizes[1:] or sizes) / g_s / 1e9,
+                      "collective": "rccl gather" if backend == "nccl" else "gloo gather (ranks share %d device(s))" % n_dev},
+           "gather_compact": compact,
+           "value_with_gather": total_units / (elapsed / steps + g_s),
+           "batches_pipelined": batches,
+           "pipelined_note": "two result buffers per rank; the gather of batch k runs under the pass of batch k + 1 (steady state over "
+                             "`batches_pipelined` batches, barrier on both sides, maximum over the ranks): the N-GPU throughput of pass + gather",
+           "equals_single_rank_pass": same, "rccl_ranks": world if backend == "nccl" else 0}
+    leg.update(pipe)
+    if sites_per_unit:
+        leg["sites_per_s"] = value / sites_per_unit
+    return leg
+
+
 def claim_stdout():
     """The contract is ONE JSON line on stdout, but libraries below us write there too (RCCL prints its version
     banner on stdout through C stdio, flushed at exit).  Keep the real stdout for the JSON line and point file
@@ -431,6 +598,10 @@ def main():
                     help="untimed passes for this many ms before the warm-up steps (device clocks; 0 = none)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (RCCL) and run the gather even with one rank")
+    ap.add_argument("--no-dist-legs", action="store_true",
+                    help="N > 1 (or --force-dist): the headline only -- no `strong` (configs[3]) / `c5` (configs[4]) legs, no pipelined steady state")
+    ap.add_argument("--c5-units-per-rank", type=int, default=None,
+                    help="(site, sample) units per rank of the N-rank `c5` leg [configs[4] literally: 16 M / N, at most 2 x --units]")
     args = ap.parse_args()
     if args.no_dense_leg:
         args.no_extra_legs = True
@@ -483,6 +654,17 @@ def main():
             c5_batch, c5_sample_major = generate("c5_multisample", c5_n, rank, workers, layout="both")
         else:
             c5_sample_major = generate("c5_multisample", c5_n, rank, workers, layout="sample")
+    # the N-rank legs (one invocation answers BASELINE.json: configs[3] = the SAME --units workload cut N ways, configs[4] = 500 k
+    # sites x 32 samples over the ranks), generated like everything else before a GPU context exists
+    dist_legs_on = (world > 1 or args.force_dist) and not args.no_dist_legs and args.workload == "c3_mixed_1m" and args.scaling == "weak"
+    strong_shard = strong_bounds = c5_shard = None
+    if dist_legs_on:
+        t0 = time.time()
+        strong_shard, strong_bounds = generate_shard(args.workload, args.units, world, rank, workers)
+        c5_per_rank = args.c5_units_per_rank if args.c5_units_per_rank else min(2 * args.units, 16_000_000 // world)
+        c5_per_rank = max(N_SAMPLES_C5, c5_per_rank // N_SAMPLES_C5 * N_SAMPLES_C5)
+        c5_shard = generate("c5_multisample", c5_per_rank, rank, workers, layout="sample")
+        gen_s += time.time() - t0
     if "large" in legs and args.large_units > batch.n_units:
         # the rest of the `large_batch` leg's workload (also generated before any GPU context exists)
         more = generate(args.workload, args.large_units - batch.n_units, rank, workers,
@@ -623,8 +805,63 @@ def main():
             total = None
 
     res_buf = None   # (the view keeps the batch alive; the legs below close and re-create it)
+    got = dbatch.results() if rank == 0 else None
+    # ---- the N-rank legs: every rank takes part, rank 0 keeps the dicts
+    dist_out = {}
+    if use_dist and dist_legs_on:
+        try:
+            # the headline's steady state: pass k+1 over the gather of batch k
+            sizes = [0] * world
+            mine = torch.tensor([cur], dtype=torch.int64, device=coll_device)
+            every = [torch.zeros(1, dtype=torch.int64, device=coll_device) for _ in range(world)]
+            dist.all_gather(every, mine)
+            sizes = [int(x.item()) for x in every]
+            batches = max(8, args.steps)
+            barrier()
+            p_s = pipelined_passes(dbatch, sizes, batches, backend)
+            barrier()
+            t = torch.tensor([p_s], dtype=torch.float64, device=coll_device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dist_out["value_pipelined"] = total_units * batches / float(t[0].item())
+            dist_out["value_pipelined_note"] = ("pass of batch k+1 over the RCCL gather of batch k, two result buffers per rank, %d batches, "
+                                                "barrier on both sides, maximum over the ranks: units / s of pass + gather in steady state" % batches)
+        except Exception as e:
+            dist_out["value_pipelined"] = None
+            dist_out["value_pipelined_error"] = repr(e)
+        # configs[3]: the headline's own workload (rank 0's batch: same seeds) cut by the shard rule; rank 0 holds the whole of it
+        # and its single-rank result records
+        counts_s = [b[1] - b[0] for b in strong_bounds]
+        with hip.DeviceBatch(strong_shard, device=local_rank, flags=flags) as ds:
+            leg = dist_leg("BASELINE.json configs[3] literally: the %d-unit workload of the headline sharded over %d rank(s) by bytes "
+                           "(distributed.shard_bounds), every rank one launch per step, ONE gather of the result records onto rank 0"
+                           % (args.units, world), ds, counts_s, sum(counts_s), args.steps, args.warmup, rank, world, backend, coll_device, n_dev,
+                           alone=got.rec if rank == 0 and batch.n_units == sum(counts_s) else None)
+        if rank == 0:
+            leg["speedup_vs_one_rank_pass"] = kern_ms / (leg["ms_per_step"]) if leg["ms_per_step"] else None
+            leg["speedup_note"] = "the headline's kernel_ms (one rank, the whole workload) / this leg's ms_per_step (N ranks, passes alone)"
+            dist_out["strong"] = leg
+        strong_shard = None
+        # configs[4]: sites x 32 samples, sample-major units with per-sample library windows, site-major result records; a site's
+        # samples stay on one rank (group = 32), QUAL is local
+        counts_c = [c5_shard.n_units] * world
+        with hip.DeviceBatch(c5_shard, device=local_rank, flags=flags) as dc:
+            leg = dist_leg("BASELINE.json configs[4]: %d sites x %d samples = %d (site, sample) units per rank x %d rank(s)%s, per-sample "
+                           "libraries, sample-major units -> site-major records (svt_batch_result_order), QUAL on the device per rank"
+                           % (c5_shard.n_units // N_SAMPLES_C5, N_SAMPLES_C5, c5_shard.n_units, world,
+                              "" if c5_shard.n_units * world == 16_000_000 else " (configs[4] literally is 16 M units over 8 ranks = 2 M per rank)"),
+                           dc, counts_c, c5_shard.n_units * world, max(5, args.steps // 2), args.warmup, rank, world, backend, coll_device, n_dev,
+                           order=N_SAMPLES_C5, sites_per_unit=N_SAMPLES_C5)
+            dc.genotype(sync=True)      # (the pipelined passes wrote into bound buffers: the records in the batch's own buffer again)
+            q0 = time.perf_counter()
+            qual = dc.site_qual(N_SAMPLES_C5)
+            q_ms = (time.perf_counter() - q0) * 1e3
+        if rank == 0:
+            leg["site_qual_ms"] = q_ms
+            leg["site_qual_sites"] = int(len(qual))
+            leg["frac"] = (16 * c5_shard.n_records + 112 * c5_shard.n_units) / (leg["kernel_ms_per_rank"][0] * 1e-3) / 1e9 / HBM_PEAK_GBS
+            dist_out["c5"] = leg
+        c5_shard = None
     if rank == 0:
-        got = dbatch.results()
         value = total_units * args.steps / elapsed
         traffic_key = "c5_windows" if args.workload == "c5_multisample" else "stream_sso" if args.sso else "stream"
         roof = roofline_of(kern_ms, alg_bytes, traffic_key, n, batch.n_records)
@@ -691,6 +928,7 @@ def main():
                        "note": "untimed passes before the warm-up steps so that the timed steps run at a loaded GPU's clocks; "
                                "not steps, not warm-up steps (spin_up in bench.py)"},
         }
+        out.update(dist_out)
         if gather:
             out["gather"] = gather
             out["rccl_ranks"] = gather["rccl_ranks"]
@@ -911,6 +1149,17 @@ def main():
                               "(multiprocessing.Pool(%d), batch_size=1000)" % (n1, npool, threads)}
             except Exception as e:  # never let the extra baseline break the bench line
                 out["cpu_baseline_python"] = {"error": repr(e)}
+            # north_star: >= 100 x the svtyper-sso CPU path's breakpoints/s on one MI355X.  BASELINE.md publishes no number, so
+            # `vs_baseline` stays null (the contract); the ratios against the two CPU restatements timed on THIS box's host cores:
+            py = out["cpu_baseline_python"]
+            out["vs_cpu"] = {
+                "python_restatement_pool": value / py["pool"] if py.get("pool") else None,
+                "c_port": value / out["cpu_baseline"]["value"],
+                "cores": threads,
+                "note": "value / cpu_baseline_python.pool (SURVEY 8d-ii's denominator: the reference's own structure -- a multiprocessing.Pool "
+                        "of pure-Python workers, singlesample.py:723-751 -- restated in oracle/py_oracle.py) and value / cpu_baseline.value "
+                        "(the same algorithm in C with OpenMP on the same cores); target >= 100",
+            }
             ints_bad = int((got.counts[:sample_n] != want.counts).sum() + (got.gt[:sample_n] != want.gt).sum())
             out["parity"] = {
                 "units_checked": sample_n,

@@ -329,6 +329,11 @@ int svt_batch_genotype(svt_batch* b, int sync);
  * synchronises); equivalent to `iters` calls of svt_batch_genotype(b, 0).                  */
 int svt_batch_genotype_n(svt_batch* b, int iters);
 
+/* (ABI 14) Wait for the passes enqueued so far and report what they found (the record contract): what
+ * svt_batch_genotype(b, 1) does after its launch, without a launch -- for a caller that overlaps an asynchronous pass with
+ * other work (the gather of the previous batch's result records, bench.py `value_pipelined`).                        */
+int svt_batch_sync(svt_batch* b);
+
 /* Run `iters` back-to-back passes bracketed by HIP events on the batch's stream;
  * *ms_total receives the elapsed milliseconds of all `iters` launches.          */
 int svt_batch_genotype_timed(svt_batch* b, int iters, float* ms_total);

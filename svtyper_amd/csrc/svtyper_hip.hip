@@ -1547,6 +1547,16 @@ int svt_batch_genotype_n(svt_batch* b, int iters)
     return guarded([&] { return svt_batch_genotype_n_impl(b, iters); });
 }
 
+int svt_batch_sync(svt_batch* b)
+{
+    return guarded([&]() -> int {
+        if (!b) return fail(SVT_ERR_INVALID, "null batch");
+        HIP_TRY(hipSetDevice(b->device));
+        HIP_TRY(hipStreamSynchronize(b->stream));
+        return check_stream_errors(b);
+    });
+}
+
 static int svt_batch_genotype_timed_impl(svt_batch* b, int iters, float* ms_total)
 {
     if (!b || !ms_total || iters <= 0) return fail(SVT_ERR_INVALID, "bad arguments");

@@ -105,3 +105,54 @@ def results_from_tagged(t, sizes: List[int], counts: List[int]) -> Results:
         at += nbytes
         base += n
     return out
+
+
+# ---- the compact gather record ------------------------------------------------------------------------------------------------
+# What a consumer of GENOTYPES reads of a result record (parsers.py:375-399 prints GT, GQ, SQ, GL and, of the counts, QR / QA;
+# the other counts are int() of sums of the tallies): 48 bytes instead of 96 through the collective, i.e. half the bytes the root
+# has to take in -- the one gather onto rank 0 is bound by the root's xGMI ingest, not by the passes.
+COMPACT_DTYPE = np.dtype([("gl", "<f8", (3,)), ("sq", "<f8"), ("qr", "<i4"), ("qa", "<i4"), ("gq", "<i2"), ("gt", "i1"), ("pad", "u1"),
+                          ("unit", "<u4")])
+assert COMPACT_DTYPE.itemsize == 48
+
+
+def compact_tagged_records(t):
+    """Tagged 96-byte device records (uint8 tensor, any device, slots * 96 bytes) -> slots * 48 bytes of COMPACT_DTYPE records
+    (GL, SQ, QR, QA, GQ, GT, the unit tag) on the same device: four strided copies."""
+    import torch
+    x = t.view(-1, 96)
+    out = torch.zeros((x.shape[0], 48), dtype=torch.uint8, device=t.device)
+    out[:, 0:32] = x[:, 0:32]        # gl[3], sq
+    out[:, 32:40] = x[:, 72:80]      # qr, qa
+    out[:, 40:42] = x[:, 80:82]      # gq: the low half of an int32 in [-1, 200]
+    out[:, 42] = x[:, 84]            # gt
+    out[:, 44:48] = x[:, 88:92]      # unit
+    return out.view(-1)
+
+
+def results_from_compact(t, sizes: List[int], counts: List[int]) -> Results:
+    """The gathered compact records of all ranks -> Results in unit order with GL, SQ, GT and the QR / QA / GQ counts filled
+    (tallies and the other counts are not part of the compact record: zero)."""
+    a = t.cpu().numpy()
+    out = Results.empty(sum(counts))
+    out.rec[:] = np.zeros((), ev.RESULT_DTYPE)
+    seen = np.zeros(sum(counts), bool)
+    at = base = 0
+    for nbytes, n in zip(sizes, counts):
+        c = a[at:at + nbytes].view(COMPACT_DTYPE)
+        c = c[c["unit"] != ev.NO_UNIT]
+        if len(c) != n or (n and (c["unit"].max() >= n or len(np.unique(c["unit"])) != n)):
+            raise ValueError("compact records of a rank do not cover its units exactly once")
+        u = c["unit"].astype(np.int64) + base
+        r = out.rec
+        r["gl"][u] = c["gl"]
+        r["sq"][u] = c["sq"]
+        r["counts"][u, ev.COUNT_NAMES.index("QR")] = c["qr"]
+        r["counts"][u, ev.COUNT_NAMES.index("QA")] = c["qa"]
+        r["counts"][u, ev.COUNT_NAMES.index("GQ")] = c["gq"]
+        r["gt"][u] = c["gt"]
+        seen[u] = True
+        at += nbytes
+        base += n
+    assert seen.all()
+    return out

@@ -21,7 +21,7 @@ ABI_VERSION = 14
 EXPORTS = (
     "svt_version", "svt_device_count", "svt_last_error", "svt_batch_create", "svt_batch_create_from_fragments",
     "svt_batch_genotype",
-    "svt_batch_genotype_n", "svt_batch_genotype_timed", "svt_batch_tune_placement", "svt_batch_results", "svt_batch_device_results",
+    "svt_batch_genotype_n", "svt_batch_sync", "svt_batch_genotype_timed", "svt_batch_tune_placement", "svt_batch_results", "svt_batch_device_results",
     "svt_batch_bind_device_results", "svt_batch_bind_device_results2", "svt_batch_result_order", "svt_batch_bytes", "svt_batch_layout", "svt_batch_site_qual",
     "svt_batch_stream", "svt_batch_destroy", "svt_trim", "svt_bayes_gt", "svt_genotype_counts", "svt_genotype", "svt_genotype_multi", "svt_shard_bounds",
     "svt_pinned_alloc", "svt_pinned_free", "svt_pack_evidence", "svt_packed_free", "svt_batch_create_packed", "svt_genotype_packed",
@@ -68,6 +68,8 @@ def load() -> C.CDLL:
     L.svt_batch_genotype.argtypes = [C.c_void_p, C.c_int]
     L.svt_batch_genotype_n.restype = C.c_int
     L.svt_batch_genotype_n.argtypes = [C.c_void_p, C.c_int]
+    L.svt_batch_sync.restype = C.c_int
+    L.svt_batch_sync.argtypes = [C.c_void_p]
     L.svt_batch_genotype_timed.restype = C.c_int
     L.svt_batch_genotype_timed.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float)]
     L.svt_batch_tune_placement.restype = C.c_int
@@ -328,6 +330,10 @@ class DeviceBatch:
 
     def genotype(self, sync: bool = True):
         _check(self._lib.svt_batch_genotype(self._h, int(sync)))
+
+    def synchronize(self):
+        """svt_batch_sync: wait for the passes enqueued with genotype(sync=False) / genotype_n and report what they found."""
+        _check(self._lib.svt_batch_sync(self._h))
 
     def genotype_n(self, iters: int):
         """Enqueue `iters` passes on the batch stream without waiting."""

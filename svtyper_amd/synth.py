@@ -57,8 +57,11 @@ def make_units(n_units: int, seed: int, libs: Sequence[LibraryTable], svtype_mix
                mean_frags: float = 100.0, sd_frags: float = 25.0, min_frags: int = 18,
                max_frags: int = 183, sample: int = 0, lib_choices: Optional[Sequence[int]] = None,
                alt_af: Optional[np.ndarray] = None, split_weight: float = 1.0,
-               disc_weight: float = 1.0, frac_empty: float = 0.0, frac_skip: float = 0.0) -> EvidenceBatch:
-    """One chunk of synthetic units.  svtype_mix = probabilities of (DEL, DUP, INV, BND)."""
+               disc_weight: float = 1.0, frac_empty: float = 0.0, frac_skip: float = 0.0,
+               counts_only: bool = False) -> EvidenceBatch:
+    """One chunk of synthetic units.  svtype_mix = probabilities of (DEL, DUP, INV, BND).
+    counts_only: return just the records per unit (int64[n_units]) this seed would produce -- the first few draws of the
+    generator, none of the per-record work -- so that a rank can find its shard of a workload without building all of it."""
     rng = np.random.default_rng(seed)
     libs = list(libs)
     if lib_choices is None:
@@ -77,6 +80,8 @@ def make_units(n_units: int, seed: int, libs: Sequence[LibraryTable], svtype_mix
     empty = rng.random(n_units) < frac_empty
     skip = rng.random(n_units) < frac_skip
     F[empty | skip] = 0
+    if counts_only:
+        return F
     units = np.zeros(n_units, UNIT_DTYPE)
     units["svtype"] = svtype
     units["var_length"] = np.where(svtype == 0, var_len, 0)

@@ -61,6 +61,25 @@ def test_weak_scaling_line(hip_device, n):
     _common(d, n, 12000 * n)
     assert d["scaling"] == "weak" and d["gather"]["units_per_rank"] == [12000] * n
     assert d["config"]["units_per_gpu"] == 12000 and "equals_single_rank_pass" not in d["gather"]
+    # ... and the SAME invocation answers BASELINE.json's multi-GPU configs: `strong` = configs[3] (the --units workload cut N
+    # ways, gathered bytes equal to rank 0's own pass over all of it), `c5` = configs[4] (sites x 32 samples per rank, whole
+    # sites per rank), each with the passes alone, the single gather (96-byte and compact 48-byte records) and the pipelined
+    # steady state (pass of batch k+1 over the gather of batch k)
+    assert d["value_pipelined"] > 0
+    for key, total in (("strong", 12000), ("c5", None)):
+        leg = d[key]
+        per = leg["units_per_rank"]
+        assert len(per) == n == len(leg["kernel_ms_per_rank"]) and sum(per) == leg["total_units"] and min(per) > 0
+        assert leg["value"] > leg["value_with_gather"] > 0 and leg["value_pipelined"] > 0 and leg["value_pipelined_compact"] > 0
+        assert leg["batches_pipelined"] >= 8 and leg["gather"]["record_bytes"] == 96 and leg["gather_compact"]["record_bytes"] == 48
+        assert leg["rccl_ranks"] == d["rccl_ranks"]
+        if total is not None:
+            assert leg["total_units"] == total and leg["equals_single_rank_pass"] is True
+            assert leg["gather_compact"]["genotype_fields_equal_single_rank_pass"] is True
+            assert max(per) - min(per) < 0.2 * total / n + 64
+        else:
+            assert all(c % 32 == 0 for c in per) and len(set(per)) == 1 and leg["site_qual_sites"] == per[0] // 32
+            assert abs(leg["sites_per_s"] * 32 - leg["value"]) < 1e-6 * leg["value"]
 
 
 @pytest.mark.gpu

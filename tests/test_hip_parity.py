@@ -75,6 +75,21 @@ def test_c2_slice(hip_device, fixture_library, flags):
     assert_parity(got, want)
 
 
+def test_c2_at_its_full_size(hip_device, fixture_library):
+    """BASELINE.json configs[1] literally: all 100 000 DEL sites (10 M records) against the oracle, classic association, both
+    device record forms (0.2 s of GPU; the C oracle takes a second)."""
+    from oracle import c_oracle
+    from svtyper_amd import hip
+    batch = synth.make_config("c2_del_100k", [fixture_library])
+    assert batch.n_units == 100_000 and (batch.units["svtype"] == 0).all()
+    want = c_oracle.genotype_batch(batch, flags=0)
+    for flags in (0, ev.FLAG_RESULT96):
+        assert_parity(hip.genotype_batch(batch, device=hip_device, flags=flags), want)
+        with hip.DeviceBatch(batch, hip_device, flags) as d:
+            d.genotype(sync=True)
+            assert_parity(d.results(), want)
+
+
 @pytest.mark.parametrize("flags", ALL_FLAGS)
 def test_c3_slice_mixed(hip_device, fixture_library, flags):
     """configs[2]: mixed DEL/DUP/INV."""

@@ -269,3 +269,38 @@ def test_bind_with_a_capacity_refuses_a_short_buffer(hip_device, fixture_library
                 assert d.results().rec.tobytes() == want.rec.tobytes()
             finally:
                 hip._check(lib.svt_debug_device_free(hip_device, buf))
+
+
+def test_compact_gather_records_carry_the_genotype_fields(fixture_library):
+    """host only: distributed.compact_tagged_records cuts tagged 96-byte records down to the 48 bytes a consumer of genotypes
+    reads (GL, SQ, QR, QA, GQ, GT + the tag); results_from_compact puts two ranks' records -- any order, padding between them --
+    back in unit order with exactly those fields of the oracle's records, and refuses a rank whose records do not cover it."""
+    import torch
+    from oracle import c_oracle
+    from svtyper_amd import distributed as D
+    batch = synth.make_edge_cases([fixture_library], seed=9)
+    want = c_oracle.genotype_batch(batch, flags=0).rec
+    n = len(want)
+    cut = n // 3
+    rng = np.random.default_rng(1)
+    parts, sizes, counts = [], [], []
+    for lo, hi in ((0, cut), (cut, n)):
+        order = rng.permutation(hi - lo)
+        tagged = _to96(want[lo:hi][order], units=order)
+        padded = np.zeros(hi - lo + 70, ev.RESULT96_DTYPE)
+        padded["unit"] = ev.NO_UNIT
+        padded[np.sort(rng.choice(len(padded), hi - lo, replace=False))] = tagged
+        c = D.compact_tagged_records(torch.from_numpy(padded.view(np.uint8).copy()))
+        assert c.numel() == 48 * len(padded)
+        parts.append(c)
+        sizes.append(int(c.numel()))
+        counts.append(hi - lo)
+    got = D.results_from_compact(torch.cat(parts), sizes, counts).rec
+    for f in ("gl", "sq", "gt"):
+        assert np.array_equal(got[f], want[f])
+    assert np.array_equal(got["counts"][:, :3], want["counts"][:, :3])
+    assert not got["tallies"].any() and not got["counts"][:, 3:].any()
+    broken = parts[0].clone()
+    broken.view(-1, 48)[np.nonzero(parts[0].view(-1, 48)[:, 44:48].numpy().view(np.uint32).ravel() == 0)[0][0], 44:48] = 0xFF   # unit 0 -> padding
+    with pytest.raises(ValueError):
+        D.results_from_compact(torch.cat([broken, parts[1]]), sizes, counts)
