@@ -362,7 +362,7 @@ def cpu_model() -> str:
     return "unknown"
 
 
-LEGS = ("place", "sso", "r96", "c5", "c5x", "shard", "one_shot", "packed", "large", "real")   # c5x: the c5 leg's comparison launches (site-major input, no hints)
+LEGS = ("place", "sso", "r96", "c5", "c5x", "c5f", "shard", "one_shot", "packed", "large", "real")   # c5x: the c5 leg's comparison launches (site-major input, no hints)
 
 
 def roofline_of(kernel_ms: float, alg_bytes: int, key: str, n_units: int, n_records: int) -> dict:
@@ -511,6 +511,41 @@ def real_data_leg(device: int) -> dict:
                    "gt_histogram": {str(k): int(v) for k, v in zip(*np.unique(res.gt, return_counts=True))}, "columns": len(cols)}
             if best is None or leg["wall_ms"] < best["wall_ms"]:
                 best = leg
+        # ---- the same sites in CHUNKS through the drivers' double buffering (pipeline.ChunkPipeline, what sso_genotype / sv_genotype
+        # run): chunk k's reader + device stages on a worker thread (C++ and HIP calls: outside the GIL) while the caller's thread
+        # formats the sample columns of chunk k-1 -- the wall time is the longer chain, not the sum of the stages
+        try:
+            all_sites = [bp for _r in range(repeat) for bp in sites]
+            per = max(256, -(-len(all_sites) // 12))
+            over = None
+            for _ in range(2):
+                eng = Timed()
+                pipe = pipeline.ChunkPipeline(True)
+                n_cols = [0]
+                fmt_s = [0.0]
+
+                def on_done(res):
+                    f0 = time.perf_counter()
+                    n_cols[0] += len(hip.format_results(res, list(pipeline.SVTYPER_FORMAT_KEYS), False))
+                    fmt_s[0] += time.perf_counter() - f0
+                t0 = time.perf_counter()
+                for lo in range(0, len(all_sites), per):
+                    coll = pipeline.NativeUnitCollector([sample], [nbam], 1.0, 1.0, 20, nr.COUNT_SSO, 1000, n_threads=threads)
+                    for bp in all_sites[lo:lo + per]:
+                        coll.add_site(bp)
+                    pipe.submit(coll.take(eng, ev.FLAG_SSO_ASSOCIATION), on_done)
+                pipe.close()
+                wall = time.perf_counter() - t0
+                if over is None or wall < over["overlapped_wall_ms"] * 1e-3:
+                    over = {"overlapped_wall_ms": wall * 1e3, "overlapped_sites_per_s": len(all_sites) / wall, "chunks": -(-len(all_sites) // per),
+                            "sites_per_chunk": per, "format_columns_host_ms": fmt_s[0] * 1e3, "device_stages_ms": sum(eng.t.values()) * 1e3,
+                            "columns": n_cols[0]}
+            assert over["columns"] == best["columns"]
+            best.update(over)
+            best["overlap_note"] = ("`stage_ms` / `wall_ms`: one chunk, the stages one after the other; `overlapped_*`: the same sites in %d chunks through "
+                                    "pipeline.ChunkPipeline (reader + device stages of chunk k on a worker thread, text of chunk k-1 on the caller's)" % over["chunks"])
+        except Exception as e:
+            best["overlapped_error"] = repr(e)
         return best
 
     # ---- (1) the reference's fixture: breakpoints of tests/data/example.vcf, the driver itself first (byte check), then x R
@@ -674,6 +709,7 @@ def main():
     import torch.distributed as dist
     from svtyper_amd import evidence as ev
     from svtyper_amd import hip
+    from svtyper_amd import synth
 
     hip.load()
     n_dev = hip.device_count()
@@ -748,6 +784,10 @@ def main():
     for _ in range(args.warmup):
         dbatch.genotype(sync=False)
     torch.cuda.synchronize()
+    # which dispatches of the headline kernel the timed region is, counted from the process's first one: 1 (the pass after
+    # create) + `steps` (the cold measurement) + the spin-up + the warm-up come first -- known exactly when no audition ran (its
+    # launch count depends on the pass time).  tools/summarize_prof.py averages the kernel trace and the PMC passes over exactly these.
+    first_timed_dispatch = (1 + args.steps + spun + args.warmup) if not tuned else None
 
     # ---- the timed region: EXACTLY `steps` passes, barrier + device sync on both sides
     barrier()
@@ -913,6 +953,15 @@ def main():
                                   "candidates, spin-up, the untuned `placement` leg): the statistic of a kernel trace that corresponds to "
                                   "this number is the fastest run of `steps` consecutive dispatches (tools/summarize_prof.py prints both)",
                 "no_spinup_kernel_ms": cold_ms, "no_spinup_frac": alg_bytes / (cold_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                # the three numbers side by side: `frac` above = this run's timed steps (after svt_batch_tune_placement unless
+                # --tune-placement 0,0, and after the spin-up); frac_cold = the same launches on the buffers svt_batch_create drew, device
+                # out of idle; frac_untuned_median = median over six more fresh allocations without the audition (`placement` leg, N = 1)
+                "frac_tuned": roof["frac"] if tuned else None,
+                "frac_cold": alg_bytes / (cold_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "frac_untuned_median": None,
+                "timed_region_dispatches": {"first": first_timed_dispatch, "count": args.steps,
+                                            "note": "0-based index, among this process's dispatches of the headline kernel, of the timed region's first "
+                                                    "launch (null after a placement audition, whose launch count is not fixed)"},
                 "placement_tuned": dict(tuned, what="svt_batch_tune_placement before the timed region (setup): the real pass over "
                                         "freshly allocated candidates for the result buffer and the record buffer, the fastest kept; "
                                         "before_ms / after_ms = the pass on the buffers svt_batch_create drew / on the kept ones. "
@@ -1203,6 +1252,7 @@ def main():
                     "kernel_ms": times, "min": ts[0], "median": ts[len(ts) // 2], "max": ts[-1],
                     "frac_min_median_max": [alg_bytes / (t * 1e-3) / 1e9 / HBM_PEAK_GBS for t in (ts[-1], ts[len(ts) // 2], ts[0])],
                     "spread_pct": (ts[-1] / ts[0] - 1.0) * 100.0, "headline_kernel_ms": kern_ms}
+                out["roofline"]["frac_untuned_median"] = alg_bytes / (ts[len(ts) // 2] * 1e-3) / 1e9 / HBM_PEAK_GBS
             except Exception as e:
                 out["roofline"]["placement"] = {"error": repr(e)}
 
@@ -1248,8 +1298,54 @@ def main():
                            kernel="svt_stream_kernel<windows>", table_mode=c_mode, units=sm_batch.n_units, records=sm_batch.n_records,
                            placement_tuned=c_tuned,
                            units_per_s=sm_batch.n_units / (c_ms * 1e-3), sites_per_s=sm_batch.n_units / N_SAMPLES_C5 / (c_ms * 1e-3))
-                del sm_batch
                 out["c5_multisample"] = leg
+                if "c5f" in legs:
+                    # ---- configs[4] at ITS size on this one device: 16 M units = the leg's batch replicated along the sites (sample-major
+                    # stays sample-major; the copies carry the same evidence, so the whole pass must repeat the 2 M-unit pass block by
+                    # block): ~1.6 G records = 37 % of the 32-bit record index space, ~26 GB of HBM, ~31 k window chunks
+                    try:
+                        copies = max(1, 16_000_000 // sm_batch.n_units)
+                        avail = 0.0
+                        for line in open("/proc/meminfo"):
+                            if line.startswith("MemAvailable:"):
+                                avail = int(line.split()[1]) / 1e6
+                        need_gb = (16 * sm_batch.n_records + 40 * sm_batch.n_units) * copies / 1e9 * 1.15 + 4
+                        if avail and avail < need_gb:
+                            raise MemoryError("host has %.0f GB available, the replicated batch needs %.0f" % (avail, need_gb))
+                        t0 = time.perf_counter()
+                        full = synth.replicate_sample_major(sm_batch, N_SAMPLES_C5, copies)
+                        rep_s = time.perf_counter() - t0
+                        t0 = time.perf_counter()
+                        with hip.DeviceBatch(full, device=local_rank, flags=sso) as df:
+                            create_s = time.perf_counter() - t0
+                            df.result_order(N_SAMPLES_C5)
+                            df.genotype(sync=True)
+                            f_ms = time_passes(df, max(3, args.steps // 4))
+                            f_alg, f_res = df.bytes()
+                            t0 = time.perf_counter()
+                            f_qual = df.site_qual(N_SAMPLES_C5)
+                            q_ms = (time.perf_counter() - t0) * 1e3
+                            f_rec = df.results().rec
+                            f_slots = df.result_slots()
+                        blocks = f_rec.reshape(copies, -1)
+                        same = all(blocks[c].tobytes() == c_res.tobytes() for c in range(copies))
+                        same_q = bool(np.array_equal(f_qual.reshape(copies, -1), np.broadcast_to(c_qual, (copies, len(c_qual)))))
+                        out["c5_full"] = {
+                            "what": "BASELINE.json configs[4] at its full size on ONE device: %d sites x %d samples = %d units, %d records (%.1f GB "
+                                    "resident), sample-major units -> site-major tagged records, QUAL on the device; the batch is the "
+                                    "c5_multisample leg's replicated %d x along the sites" % (
+                                        full.n_units // N_SAMPLES_C5, N_SAMPLES_C5, full.n_units, full.n_records, f_res / 1e9, copies),
+                            "units": full.n_units, "records": full.n_records, "kernel_ms": f_ms,
+                            "frac": f_alg / (f_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "units_per_s": full.n_units / (f_ms * 1e-3),
+                            "sites_per_s": full.n_units / N_SAMPLES_C5 / (f_ms * 1e-3), "result_slots": f_slots,
+                            "record_index_space_used": full.n_records / 2.0**32,
+                            "site_qual_ms": q_ms, "replicate_host_s": rep_s, "create_s": create_s,
+                            "every_site_block_equals_the_2M_unit_pass": bool(same), "site_qual_equals": same_q,
+                        }
+                        del full, f_rec, blocks, f_qual
+                    except Exception as e:
+                        out["c5_full"] = {"error": repr(e)}
+                del sm_batch
                 if c5_batch is None:
                     raise StopIteration
                 with hip.DeviceBatch(c5_batch, device=local_rank, flags=sso) as dc:

@@ -141,6 +141,7 @@ struct StreamArgs {
     uint32_t unit_end;           // one range per uploaded piece; a pass over a resident batch: [0, n_units))
     uint32_t units_per_wg;       // (not the window mode) consecutive units of one workgroup, <= 256 * R: the host cuts a launch into
                                  // EQUAL workgroups that fill whole rounds of the chip's resident workgroups (svtyper_hip.hip: wg_plan)
+    uint32_t chunk_begin;        // (library windows) this launch covers the chunks from this one on
     uint32_t result96;           // SVT_FLAG_RESULT96: `out` holds 96-byte records (svt_result96) in the workgroups' own order, tagged with their unit
     uint32_t slot_begin;         // ... the first of them this launch writes (workgroup w of the launch: slot_begin + w * 256 * R)
     uint32_t out_samples;        // svt_batch_result_order: > 1 = the units are sample-major (unit = sample * out_sites + site) and the
@@ -321,9 +322,14 @@ __device__ __forceinline__ void record_window(const u32x4 w, const bool mine, co
 #endif
 }
 
-template <bool SSO, int MODE, int R>
-__global__ __launch_bounds__(kBlock, MODE == kSingleLds ? SVT_STREAM_WAVES : MODE == kMultiLds ? SVT_WINDOW_WAVES : 2) void svt_stream_kernel(const StreamArgs a)
+// WK (library windows only): 0 = a launch over windows of any size -- both record consumers in one kernel, 161 VGPRs, three
+// workgroups per CU; 1 = every window of the launch holds ONE library (record_single only), 2 = every window holds several
+// (record_window only): one consumer each, 126 VGPRs, four workgroups per CU.  The host launches the chunks of a batch as
+// two ranges (chunks come ordered by the size of their window), StreamArgs::chunk_begin = the range's first chunk.
+template <bool SSO, int MODE, int R, int WK = 0>
+__global__ __launch_bounds__(kBlock, MODE == kSingleLds ? SVT_STREAM_WAVES : MODE == kMultiLds ? (WK ? 4 : SVT_WINDOW_WAVES) : 2) void svt_stream_kernel(const StreamArgs a)
 {
+    static_assert(WK == 0 || (MODE == kMultiLds && !SSO), "window kinds: classic library-window kernels only");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // (lds_rings is 128-byte aligned)
     constexpr uint32_t kUnitsPerWg = kBlock * R;
     double* s_pm = reinterpret_cast<double*>(smem + kSPm);
@@ -338,11 +344,12 @@ __global__ __launch_bounds__(kBlock, MODE == kSingleLds ? SVT_STREAM_WAVES : MOD
     // the units by the libraries of their sample
     uint32_t wg_base = a.unit_begin + blockIdx.x * a.units_per_wg, n_here;
     WgDesc wd{};
+    const uint32_t wg_index = MODE == kMultiLds ? blockIdx.x + a.chunk_begin : blockIdx.x;   // (the launch's chunk range / workgroup)
     if (MODE == kMultiLds) {
-        const uint2 ch = a.chunks[blockIdx.x];
+        const uint2 ch = a.chunks[wg_index];
         wg_base = ch.x;
         n_here = ch.y;
-        wd = a.windows[blockIdx.x];
+        wd = a.windows[wg_index];
     } else {
         n_here = min(a.units_per_wg, a.unit_end - wg_base);
     }
@@ -655,7 +662,7 @@ __global__ __launch_bounds__(kBlock, MODE == kSingleLds ? SVT_STREAM_WAVES : MOD
                         wj.z = mine ? wj.z : 0u;
                         wj.w = mine ? wj.w : neutral_w;
                         check.see(wj, lib_key);
-                        if (MODE == kSingleLds || (SVT_WINDOW_SINGLE_PATH && !SSO && wd.lib_cnt == 1u)) record_single<SSO, false, true>(wj, true, sc, acc);
+                        if (MODE == kSingleLds || WK == 1 || (WK == 0 && SVT_WINDOW_SINGLE_PATH && !SSO && wd.lib_cnt == 1u)) record_single<SSO, false, true>(wj, true, sc, acc);
                         else record_window<SSO, false, true>(wj, true, wc, acc, check);
                     }
                     refill();
@@ -669,7 +676,7 @@ __global__ __launch_bounds__(kBlock, MODE == kSingleLds ? SVT_STREAM_WAVES : MOD
                     if (!SSO || MODE == kGeneral || has_cont) consume(w, k, edge_tag, kind_tag, std::true_type{});
                     else consume(w, k, edge_tag, kind_tag, std::false_type{});
                 };
-                if (MODE == kMultiLds && SVT_WINDOW_SINGLE_PATH && !SSO && (wd.lib_cnt == 1u || SVT_STREAM_PROBE == 5)) {       // (workgroup-uniform; probe 5: timing only)
+                if (MODE == kMultiLds && WK != 2 && (WK == 1 || (SVT_WINDOW_SINGLE_PATH && !SSO && (wd.lib_cnt == 1u || SVT_STREAM_PROBE == 5)))) {       // (workgroup-uniform; probe 5: timing only)
                     if (!SVT_SANITIZE_EDGE && edge) run(std::true_type{}, kind_one{});
                     else run(std::false_type{}, kind_one{});
                 } else if (!SVT_SANITIZE_EDGE && edge) run(std::true_type{}, kind_any{});
@@ -714,7 +721,7 @@ __global__ __launch_bounds__(kBlock, MODE == kSingleLds ? SVT_STREAM_WAVES : MOD
             uint32_t tile_slot = 0xFFFFFFFFu;
             if (a.result96) {
                 piece[5] = make_uint4(piece[5].x, piece[7].y, unit_out, 0u);   // (a padding lane: unit_out == kPadUnit == SVT_NO_UNIT)
-                tile_slot = a.slot_begin + blockIdx.x * kUnitsPerWg + ((uint32_t)r * kWavesPerBlock + ((r & 1) ? (uint32_t)kWavesPerBlock - 1u - wave : wave)) * kWave;
+                tile_slot = a.slot_begin + wg_index * kUnitsPerWg + ((uint32_t)r * kWavesPerBlock + ((r & 1) ? (uint32_t)kWavesPerBlock - 1u - wave : wave)) * kWave;
             }
             store_result_records_through_ring(ring, piece, unit_out, lane, reinterpret_cast<unsigned char*>(a.out), a.result96 ? 6u : 8u, tile_slot);
 #endif

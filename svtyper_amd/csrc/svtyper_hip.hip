@@ -69,6 +69,16 @@
 
 using namespace svt;
 
+// the one-tile-per-wave instantiations of the streaming kernel live in svt_small_kernels.hip (their own scheduling strategy)
+#if SVT_STREAM_R == 1 && !defined(SVT_NO_SMALL_TU)
+namespace svt {
+extern template __global__ void svt_stream_kernel<false, kSingleLds, 1>(const StreamArgs);
+extern template __global__ void svt_stream_kernel<true, kSingleLds, 1>(const StreamArgs);
+extern template __global__ void svt_stream_kernel<false, kMultiLds, 1>(const StreamArgs);
+extern template __global__ void svt_stream_kernel<true, kMultiLds, 1>(const StreamArgs);
+}  // namespace svt
+#endif
+
 // ------------------------------------------------------------------------------------------
 // batch object
 // ------------------------------------------------------------------------------------------
@@ -103,6 +113,8 @@ struct svt_batch {
     WgDesc* d_windows = nullptr;
     uint64_t cap_perm = 0;
     uint32_t n_chunks = 0;
+    uint32_t n_chunks_one = 0;       // ... of which the first ones have windows of ONE library
+    bool split_window_kinds = false; // the pass is two launches: one-library windows, then the others (a kernel per kind)
     int window_tiles = 1;            // kMultiLds: 64-unit tiles per wave (chunks hold up to 256 * window_tiles units)
     uint64_t bound_slots = 0;        // svt_batch_bind_device_results: result records the caller's buffer holds (0 = the library's own buffer)
     uint64_t out_slots = 0;          // records in the device result buffer after a pass: n_units, or (SVT_FLAG_RESULT96) the slots of
@@ -186,6 +198,13 @@ const void* stream_kernel_for(int mode, int tiles)
     return mode == kSingleLds  ? reinterpret_cast<const void*>(&svt_stream_kernel<SSO, kSingleLds, SVT_STREAM_R>)
            : mode == kMultiLds ? reinterpret_cast<const void*>(&svt_stream_kernel<SSO, kMultiLds, SVT_STREAM_R>)
                                : reinterpret_cast<const void*>(&svt_stream_kernel<SSO, kGeneral, SVT_STREAM_R>);
+}
+
+// library windows, classic association, two tiles per wave: a kernel per kind of window (1 = one library, 2 = several)
+const void* window_kernel_of_kind(int kind)
+{
+    return kind == 1 ? reinterpret_cast<const void*>(&svt_stream_kernel<false, kMultiLds, 2, 1>)
+                     : reinterpret_cast<const void*>(&svt_stream_kernel<false, kMultiLds, 2, 2>);
 }
 
 const void* stream_kernel_of(const svt_batch* b, int tiles = SVT_STREAM_R)
@@ -373,6 +392,24 @@ int launch_genotype(svt_batch* b)
         return SVT_OK;
     }
     if (b->n_units == 0) return SVT_OK;
+    if (b->mode == kMultiLds && b->split_window_kinds) {
+        // two launches, one per kind of window: each kernel holds ONE record consumer (126 VGPRs: four workgroups per CU; the
+        // kernel with both consumers has 161: three).  The chunks are ordered by the size of their window.
+        const dim3 block(kBlock);
+        if (b->n_chunks_one) {
+            StreamArgs a = b->sargs;
+            a.chunk_begin = 0;
+            void* params[] = {&a};
+            HIP_TRY(hipLaunchKernel(window_kernel_of_kind(1), dim3(b->n_chunks_one), block, params, b->lds_bytes, b->stream));
+        }
+        if (b->n_chunks > b->n_chunks_one) {
+            StreamArgs a = b->sargs;
+            a.chunk_begin = b->n_chunks_one;
+            void* params[] = {&a};
+            HIP_TRY(hipLaunchKernel(window_kernel_of_kind(2), dim3(b->n_chunks - b->n_chunks_one), block, params, b->lds_bytes, b->stream));
+        }
+        return SVT_OK;
+    }
     if (b->mode != kMultiLds) {
         // The workgroup plan is looked up per launch (the debug hooks can move it between svt_batch_create and a pass): the tagged
         // records of THIS launch must fit what the result buffer was sized for -- the library's own buffer grows, a caller's does not.
@@ -503,6 +540,16 @@ int create_stream(const svt_evidence_batch* in, svt_batch* b, void* d_records_re
     // library windows: two tiles per wave for launches that need more than one round of resident workgroups anyway
     // (the same rule and the same reason as tiles_per_wave for one library)
     b->window_tiles = (SVT_STREAM_R == 1 && SVT_WINDOW_TILES == 2 && n >= kTwoTilesMinUnits) ? 2 : SVT_STREAM_R;
+    // classic association, two tiles per wave: the pass over library windows as two launches, a kernel per kind of window (one
+    // record consumer each: 126 VGPRs, four workgroups per CU, against 161 / three for the kernel that holds both).  Measured on
+    // the configs[4] batch at 2 M units, same memory (profiles/r05_window_split_ab.txt): 0.713 against 0.655 ms with one to three
+    // libraries per sample -- two launches one after the other pay two ramp-downs --, 0.6144 against 0.6147 when every sample has
+    // one library (one launch either way: the fourth workgroup per CU buys nothing here).  Off.
+#ifndef SVT_WINDOW_SPLIT
+#define SVT_WINDOW_SPLIT 0
+#endif
+    const bool split_kinds = SVT_WINDOW_SPLIT && b->window_tiles == 2 && !(b->flags & SVT_FLAG_SSO_ASSOCIATION) && !std::getenv("SVT_NO_WINDOW_SPLIT");
+    auto window_budget_kernel = [&]() { return split_kinds ? window_kernel_of_kind(2) : stream_kernel_of(b, b->window_tiles); };
     const uint32_t kUnitsPerWg = (uint32_t)kBlock * (uint32_t)b->window_tiles;
     std::vector<uint32_t> perm;
     std::vector<uint2> chunks;
@@ -660,7 +707,7 @@ int create_stream(const svt_evidence_batch* in, svt_batch* b, void* d_records_re
         {
             int wgs = 3;
             hipFuncAttributes fa{};
-            if (hipFuncGetAttributes(&fa, stream_kernel_of(b, b->window_tiles)) == hipSuccess && fa.numRegs > 0) wgs = std::max(1, std::min(8, 512 / ((fa.numRegs + 7) / 8 * 8)));
+            if (hipFuncGetAttributes(&fa, window_budget_kernel()) == hipSuccess && fa.numRegs > 0) wgs = std::max(1, std::min(8, 512 / ((fa.numRegs + 7) / 8 * 8)));
             else (void)hipGetLastError();
             const size_t lds = ((window_lds + 127) & ~size_t(127)) + kWavesPerBlock * kStreamRingBytes;
             const uint32_t resident = (uint32_t)std::min<size_t>((size_t)wgs, (160 * 1024) / lds) * cu_count(b->device);
@@ -689,6 +736,13 @@ int create_stream(const svt_evidence_batch* in, svt_batch* b, void* d_records_re
         SVT_TRY(upload(&b->d_windows, windows, st));
         SVT_TRY(st.finish());
         b->n_chunks = (uint32_t)chunks.size();
+        // the chunks come ordered by window key = first library | libraries << 8: windows of one library first
+        uint32_t n_one = 0;
+        while (n_one < b->n_chunks && windows[n_one].lib_cnt == 1u) ++n_one;
+        bool ordered = true;
+        for (uint32_t i = n_one; i < b->n_chunks && ordered; ++i) ordered = windows[i].lib_cnt != 1u;
+        b->n_chunks_one = n_one;
+        b->split_window_kinds = split_kinds && ordered;
     }
     if (b->d_perm && (!windowed || identity)) {   // (the scan's buffer when no permutation came of it)
         g_pool.put(b->device, b->d_perm, b->cap_perm);
@@ -722,7 +776,7 @@ int create_stream(const svt_evidence_batch* in, svt_batch* b, void* d_records_re
     {
         int wgs = 3;
         hipFuncAttributes fa{};
-        if (hipFuncGetAttributes(&fa, stream_kernel_of(b, b->mode == kMultiLds ? b->window_tiles : tiles_per_wave(b, n))) == hipSuccess && fa.numRegs > 0)
+        if (hipFuncGetAttributes(&fa, b->mode == kMultiLds ? window_budget_kernel() : stream_kernel_of(b, tiles_per_wave(b, n))) == hipSuccess && fa.numRegs > 0)
             wgs = std::max(1, std::min(8, 512 / ((fa.numRegs + 7) / 8 * 8)));
         else
             (void)hipGetLastError();
@@ -803,6 +857,9 @@ int create_stream(const svt_evidence_batch* in, svt_batch* b, void* d_records_re
         for (int tiles = 1; tiles <= 2; ++tiles)
             if (b->mode != kGeneral || tiles == 1)
                 HIP_TRY(hipFuncSetAttribute(stream_kernel_of(b, tiles), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_bytes));
+    if (b->lds_bytes > 64 * 1024 && b->split_window_kinds)
+        for (int kind = 1; kind <= 2; ++kind)
+            HIP_TRY(hipFuncSetAttribute(window_kernel_of_kind(kind), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_bytes));
     return SVT_OK;
 }
 

@@ -314,3 +314,34 @@ def to_sample_major(batch, n_samples: int):
     new_off[1:] = np.cumsum(cnt)
     src = np.repeat(off[:-1][order] - new_off[:-1].astype(np.int64), cnt) + np.arange(int(new_off[-1]), dtype=np.int64)
     return ev.EvidenceBatch(new_off, batch.units[order], batch.records[src], batch.libs, batch.split_weight, batch.disc_weight), order
+
+
+def replicate_sample_major(batch, n_samples: int, copies: int):
+    """`copies` x the sites of a SAMPLE-MAJOR batch (unit = sample * n_sites + site), still sample-major: the sites of copy c
+    follow those of copy c - 1 inside every sample's block.  One concatenation of contiguous slices -- the way to reach
+    configs[4]'s full size (500 k sites x 32 samples = 16 M units, 1.6 G records, 26 GB) from a batch a host generates in
+    seconds; the copies carry the same evidence (the pass does not care; results repeat with period n_sites)."""
+    n = batch.n_units
+    if n % n_samples:
+        raise ValueError("n_units must be a multiple of n_samples")
+    n_sites = n // n_samples
+    off = batch.rec_offset.astype(np.int64)
+    per_sample_recs = off[n_sites::n_sites] - off[:-1:n_sites][:n_samples]       # records of every sample's block
+    total_recs = int(per_sample_recs.sum()) * copies
+    units = np.empty(n * copies, batch.units.dtype)
+    records = np.empty(total_recs, batch.records.dtype)
+    counts = np.empty(n * copies, np.int64)
+    u = r = 0
+    cnt = off[1:] - off[:-1]
+    for s in range(n_samples):
+        lo, hi = s * n_sites, (s + 1) * n_sites
+        r0, r1 = int(off[lo]), int(off[hi])
+        for _ in range(copies):
+            units[u:u + n_sites] = batch.units[lo:hi]
+            counts[u:u + n_sites] = cnt[lo:hi]
+            records[r:r + (r1 - r0)] = batch.records[r0:r1]
+            u += n_sites
+            r += r1 - r0
+    new_off = np.zeros(n * copies + 1, np.uint64)
+    np.cumsum(counts, out=new_off[1:])
+    return ev.EvidenceBatch(new_off, units, records, batch.libs, batch.split_weight, batch.disc_weight)

@@ -22,6 +22,13 @@ run_pass() {   # run_pass <subdir> <stdout file> <bench command> -- <rocprofv3 o
     done
     return 1
 }
+# A process of its own for the HEADLINE's timed region: no audition, no other leg -- every dispatch of the headline kernel is
+# accounted for (1 after create + steps cold + spin-up + warm-up, then the timed steps: roofline.timed_region_dispatches), so the
+# trace and the counter passes are averaged over exactly the launches bench.py times (tools/summarize_prof.py, "timed region")
+HEAD="python bench.py --steps ${HEAD_STEPS:-50} --warmup 3 --no-cpu-baseline --no-extra-legs --tune-placement 0,0 ${BENCH_ARGS:-}"
+run_pass headstats $OUT/stats_headline.json "$HEAD" -- --kernel-trace --stats
+run_pass headfetch $OUT/fetch_headline.json "$HEAD" -- --pmc FETCH_SIZE
+run_pass headwrite $OUT/write_headline.json "$HEAD" -- --pmc WRITE_SIZE
 run_pass stats $OUT/stats_bench.json "$BENCH" -- --kernel-trace --stats
 run_pass pmc_sq1 /dev/null "$BENCH_SHORT" -- --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS
 run_pass pmc_sq2 /dev/null "$BENCH_SHORT" -- --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_VMEM_RD
@@ -29,3 +36,5 @@ run_pass pmc_fetch /dev/null "$BENCH_SHORT" -- --pmc FETCH_SIZE
 run_pass pmc_write /dev/null "$BENCH_SHORT" -- --pmc WRITE_SIZE
 python tools/summarize_prof.py $OUT > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt
+# the raw rocpd databases are tens of MB (gpurun copies at most 64 MiB back): keep the summary, the bench lines and the logs
+[ -n "${KEEP_DBS:-}" ] || find $OUT -mindepth 1 -maxdepth 1 -type d -exec rm -rf {} +

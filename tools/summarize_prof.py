@@ -13,6 +13,56 @@ def dbs(sub):
     return sorted(glob.glob(os.path.join(out, sub, "**", "*.db"), recursive=True))
 
 
+# ---- the headline's timed region, isolated: a process without audition or other legs, whose bench line says which dispatches of
+# the headline kernel its timed region was (roofline.timed_region_dispatches)
+def _headline_line(name):
+    try:
+        import json as _j
+        return _j.loads([l for l in open(os.path.join(out, name)) if l.startswith("{")][-1])
+    except Exception:
+        return None
+
+
+def _timed_rows(sub, line, query):
+    """rows of the headline kernel's dispatches in start order, cut to the timed region of `line`"""
+    tr = line["roofline"]["timed_region_dispatches"]
+    pat = "svt_stream_kernel<%s, 0, " % ("true" if line["config"]["association"] == "sso" else "false")
+    rows = []
+    for f in dbs(sub):
+        c = sqlite3.connect(f)
+        rows += [r for r in c.execute(query) if pat in r[0]]
+    return rows, tr
+
+
+_hl = _headline_line("stats_headline.json")
+if _hl and _hl["roofline"]["timed_region_dispatches"]["first"] is not None:
+    rows, tr = _timed_rows("headstats", _hl, "select name, start, duration from kernels order by start")
+    d = [r[2] / 1e3 for r in rows]
+    a, k = tr["first"], tr["count"]
+    if len(d) >= a + k:
+        timed = d[a:a + k]
+        avg = sum(timed) / k
+        print("# TIMED REGION of the headline (own process: no audition, no other leg; `bench.py %s`)" % "--steps %d --tune-placement 0,0 --no-extra-legs" % k)
+        print("# dispatches %d..%d of %d of the headline kernel = the %d launches between bench.py's HIP events" % (a, a + k - 1, len(d), k))
+        print("timed_region_avg_us,%.3f" % avg)
+        print("timed_region_min_us,%.3f" % min(timed))
+        print("timed_region_max_us,%.3f" % max(timed))
+        print("bench_kernel_ms_same_run,%.5f   (HIP events / steps: includes the gaps between consecutive dispatches)" % _hl["roofline"]["kernel_ms"])
+        print("timed_region_avg_over_bench_kernel_ms,%.4f" % (avg / 1e3 / _hl["roofline"]["kernel_ms"]))
+        alg = 16 * _hl["config"]["records_per_gpu"] + 112 * _hl["config"]["units_per_gpu"]
+        print("frac_from_trace_avg,%.4f   frac_of_the_bench_line,%.4f   frac_cold_of_the_bench_line,%.4f" % (
+            alg / (avg * 1e-6) / 8e12, _hl["roofline"]["frac"], _hl["roofline"]["frac_cold"]))
+        print("all_dispatches_avg_us,%.3f   (cold passes + spin-up + warm-up + timed: what `top_kernels.average` shows)" % (sum(d) / len(d)))
+    for sub, counter, fname in (("headfetch", "FETCH_SIZE", "fetch_headline.json"), ("headwrite", "WRITE_SIZE", "write_headline.json")):
+        line = _headline_line(fname)
+        if not line or line["roofline"]["timed_region_dispatches"]["first"] is None:
+            continue
+        rows, tr = _timed_rows(sub, line, "select kernel_name, dispatch_id, value from counters_collection where counter_name = '%s' order by dispatch_id" % counter)
+        v = [r[2] for r in rows]
+        a, k = tr["first"], tr["count"]
+        if len(v) >= a + k:
+            print("timed_region_%s_KB_mean,%.1f   (dispatches %d..%d; all %d dispatches: %.1f)" % (counter, sum(v[a:a + k]) / k, a, a + k - 1, len(v), sum(v) / len(v)))
+
 for f in dbs("stats"):
     c = sqlite3.connect(f)
     print("# rocprofv3 --kernel-trace --stats   (%s)" % os.path.relpath(f, out))
