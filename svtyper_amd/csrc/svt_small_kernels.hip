@@ -18,10 +18,16 @@
 #include "svt_device_types.h"
 #include "svt_unit_math.h"
 #include "svt_stream_kernel.h"
+#include "svt_split_kernel.h"
 
 namespace svt {
 template __global__ void svt_stream_kernel<false, kSingleLds, 1>(const StreamArgs);
 template __global__ void svt_stream_kernel<true, kSingleLds, 1>(const StreamArgs);
 template __global__ void svt_stream_kernel<false, kMultiLds, 1>(const StreamArgs);
 template __global__ void svt_stream_kernel<true, kMultiLds, 1>(const StreamArgs);
+// K lanes per unit (svt_split_kernel.h)
+template __global__ void svt_split_kernel<false, kSingleLds, 2>(const StreamArgs);
+template __global__ void svt_split_kernel<true, kSingleLds, 2>(const StreamArgs);
+template __global__ void svt_split_kernel<false, kSingleLds, 4>(const StreamArgs);
+template __global__ void svt_split_kernel<true, kSingleLds, 4>(const StreamArgs);
 }  // namespace svt

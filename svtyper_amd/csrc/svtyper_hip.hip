@@ -61,6 +61,7 @@
 #include "svt_stream_kernel.h"
 #include "svt_packed_kernel.h"
 #include "svt_coop_kernel.h"
+#include "svt_split_kernel.h"
 #include "svt_window_scan_kernel.h"
 #include "svt_geometry_kernel.h"
 #include "svt_bayes_kernel.h"
@@ -76,6 +77,10 @@ extern template __global__ void svt_stream_kernel<false, kSingleLds, 1>(const St
 extern template __global__ void svt_stream_kernel<true, kSingleLds, 1>(const StreamArgs);
 extern template __global__ void svt_stream_kernel<false, kMultiLds, 1>(const StreamArgs);
 extern template __global__ void svt_stream_kernel<true, kMultiLds, 1>(const StreamArgs);
+extern template __global__ void svt_split_kernel<false, kSingleLds, 2>(const StreamArgs);
+extern template __global__ void svt_split_kernel<true, kSingleLds, 2>(const StreamArgs);
+extern template __global__ void svt_split_kernel<false, kSingleLds, 4>(const StreamArgs);
+extern template __global__ void svt_split_kernel<true, kSingleLds, 4>(const StreamArgs);
 }  // namespace svt
 #endif
 
@@ -122,10 +127,14 @@ struct svt_batch {
     bool records_resident = true;    // false: create_stream left the record upload to its caller (pipelined one-shot)
     int wgs_per_cu = 3;              // workgroups per CU the pass's kernel was budgeted for (registers -> LDS per workgroup)
     uint32_t resident_wgs = 0;       // workgroups of the pass's kernel the device holds at once (registers, LDS, CUs); 0 = unknown
+    uint64_t one_tile_round_units = 0;   // units ONE round of the one-tile-per-wave kernel's resident workgroups holds (one library); 0 = unknown
     // the cooperative kernel for launches of less than one round (svt_coop_kernel.h); 0 bytes = not for this batch
     size_t coop_lds_bytes = 0;
     uint32_t coop_region = 0, coop_l10_where = kL10Global, coop_lds_l10 = 0, coop_l10_entries = 0;
     uint32_t coop_resident = 0;      // workgroups of it the device holds at once
+    // K lanes per unit (svt_split_kernel.h): the same for its region
+    size_t split_lds_bytes = 0;
+    uint32_t split_region = 0, split_l10_where = kL10Global, split_lds_l10 = 0, split_l10_entries = 0;
     StreamArgs sargs{};
     // kLayoutPacked: packed evidence as uploaded (svt_packed_kernel.h); d_records holds the slots, d_soff the 3n+1 offsets
     uint32_t* d_soff = nullptr;
@@ -218,16 +227,26 @@ const void* coop_kernel_of(const svt_batch* b)
                                                   : reinterpret_cast<const void*>(&svt_coop_kernel<false, kSingleLds>);
 }
 
+const void* split_kernel_of(const svt_batch* b, int lanes)
+{
+    const bool sso = (b->flags & SVT_FLAG_SSO_ASSOCIATION) != 0;
+    if (lanes == 2) return sso ? reinterpret_cast<const void*>(&svt_split_kernel<true, kSingleLds, 2>) : reinterpret_cast<const void*>(&svt_split_kernel<false, kSingleLds, 2>);
+    return sso ? reinterpret_cast<const void*>(&svt_split_kernel<true, kSingleLds, 4>) : reinterpret_cast<const void*>(&svt_split_kernel<false, kSingleLds, 4>);
+}
+
 // 64-unit tiles per wave for a launch over `units` units.  One tile per wave leaves a third of a workgroup's
 // wave-time waiting for the wave that holds its longest units; two tiles in snake order even that out (DESIGN.md
 // 3.1) but make a workgroup run longer, which pays once the one-tile launch would need more than one round of
 // resident workgroups: measured -17 % at 250 k units, +-1 % at 500 k, -9 % at 1 M, -6 % at 2 M; +10 % at exactly
 // one round (196 608), no difference below.  One library only (the other modes are register-bound).
-constexpr uint64_t kTwoTilesMinUnits = 768ull * kBlock * 9 / 8;   // a little more than the chip's resident workgroups hold
+// (This round the one-tile kernels are compiled for instruction-level parallelism -- svt_small_kernels.hip: 149 VGPRs, three
+// workgroups per CU --, so one round of them is 768 workgroups = 196 608 units: a launch beyond it, which would take a second
+// round of one-tile workgroups, takes two tiles per wave: 200 k units 0.106 -> 0.087 ms.)
+constexpr uint64_t kTwoTilesMinUnits = 768ull * kBlock * 9 / 8;   // library windows: a little more than the chip's resident workgroups hold
 int tiles_per_wave(const svt_batch* b, uint64_t units)
 {
 #if SVT_STREAM_R == 1 && !defined(SVT_STREAM_ONE_TILE)
-    if (b->mode == kSingleLds && units >= kTwoTilesMinUnits) return 2;
+    if (b->mode == kSingleLds && units > (b->one_tile_round_units ? b->one_tile_round_units : kTwoTilesMinUnits)) return 2;
 #endif
     (void)b; (void)units;
     return SVT_STREAM_R;
@@ -268,7 +287,7 @@ inline uint32_t cu_count(int device)
 #ifndef SVT_WG_MIN_FILL
 #define SVT_WG_MIN_FILL 50   // per cent: the emptiest workgroup the rule may make (more than one round: never below 50)
 #endif
-struct WgPlan { int tiles; uint32_t per_wg, n_wg; bool coop; };
+struct WgPlan { int tiles; uint32_t per_wg, n_wg; bool coop; int split; };   // split: lanes per unit of svt_split_kernel (0 = not that kernel)
 static std::atomic<int> g_wg_balance{SVT_WG_BALANCE && !std::getenv("SVT_NO_WG_BALANCE") ? SVT_WG_MIN_FILL : 0};   // (svt_debug_wg_balance: measurements)
 extern "C" int svt_debug_wg_balance(int min_fill_percent) { return g_wg_balance.exchange(std::max(0, std::min(100, min_fill_percent))); }
 inline uint32_t balanced_units_per_wg(uint64_t units, uint64_t n_min, uint32_t full, uint32_t resident)
@@ -285,16 +304,63 @@ extern "C" void svt_debug_force_wg(uint32_t per_wg, uint32_t tiles) { g_force_pe
 // A workgroup takes 64 ... 256 units -- as few as keep the launch inside ONE round of the resident cooperative workgroups, so
 // that a launch of a few thousand units still spreads over the chip.
 #ifndef SVT_COOP_MAX_UNITS
-#define SVT_COOP_MAX_UNITS 65536
+#define SVT_COOP_MAX_UNITS (1ull << 40)   /* (svt_debug_coop: measurements; the rule is SVT_COOP_CU_UNITS per CU) */
 #endif
 static std::atomic<uint64_t> g_coop_max_units{std::getenv("SVT_NO_COOP") ? uint64_t(0) : uint64_t(SVT_COOP_MAX_UNITS)};
 static std::atomic<uint32_t> g_coop_per_wg{0};
 extern "C" void svt_debug_coop(uint64_t max_units, uint32_t per_wg) { g_coop_max_units = max_units; g_coop_per_wg = per_wg; }   // (measurements)
+// Which kernel a launch of less than one round takes (measurements: SVT_SMALL_KIND at build time, svt_debug_small_kind at run time):
+// 0 = the rule below, 1 = the streaming kernel always, 2 = cooperative, 3 / 4 = two / four lanes per unit.
+#ifndef SVT_SMALL_KIND
+#define SVT_SMALL_KIND 0
+#endif
+// The rule (tools/small_kinds.py over 2 k ... 160 k units, profiles/r05_small_kinds.txt; 256 CUs, 100 records per unit, ms):
+//   units    stream   coop    2 lanes  4 lanes
+//   10 000   0.0358   0.0206  0.0364   0.0253      <= one cooperative workgroup of 64 units per CU: cooperative
+//   30 000   0.0372   0.0296  0.0377   0.0261      <= one 4-lane workgroup of 256 units per CU: four lanes per unit
+//   65 000   0.0387   0.0424  0.0390   0.0273
+//   90 000   0.0490   0.0528  0.0469   0.0493      <= two 2-lane workgroups per CU: two lanes per unit (classic association;
+//  131 000   0.0550   0.0639  0.0528   0.0536         the singlesample one spills at 128 registers: streaming kernel)
+//  160 000   0.0684   0.0954  0.0826   0.0740      beyond: the streaming kernel
+// Units of 400 records: 0.118 / 0.057 / 0.124 / 0.083 at 10 000 units -- the longer the units, the more the shorter chain is worth.
+#ifndef SVT_SPLIT4_CU_UNITS
+#define SVT_SPLIT4_CU_UNITS 256     // units per CU up to which a launch takes four lanes per unit (0 = never)
+#endif
+#ifndef SVT_SPLIT2_CU_UNITS
+#define SVT_SPLIT2_CU_UNITS 512     // ... two lanes per unit
+#endif
+#ifndef SVT_COOP_CU_UNITS
+#define SVT_COOP_CU_UNITS 64        // ... the cooperative kernel
+#endif
+static std::atomic<int> g_small_kind{SVT_SMALL_KIND};
+extern "C" int svt_debug_small_kind(int kind) { return g_small_kind.exchange(kind); }
 WgPlan wg_plan(const svt_batch* b, uint64_t units)
 {
     WgPlan p;
     p.coop = false;
-    if (b->coop_lds_bytes && units && units <= g_coop_max_units.load(std::memory_order_relaxed) && !g_force_per_wg.load(std::memory_order_relaxed)) {
+    p.split = 0;
+    {
+        const int kind = g_small_kind.load(std::memory_order_relaxed);
+        const bool forced = kind == 3 || kind == 4;
+        const uint64_t cus = cu_count(b->device);
+        const bool sso = (b->flags & SVT_FLAG_SSO_ASSOCIATION) != 0;
+        const bool coop_first = b->coop_lds_bytes && units <= std::min<uint64_t>(cus * SVT_COOP_CU_UNITS, g_coop_max_units.load(std::memory_order_relaxed));
+        const int lanes = forced ? (kind == 3 ? 2 : 4)
+                          : kind != 0 || coop_first ? 0
+                          : units <= cus * SVT_SPLIT4_CU_UNITS ? 4 : units <= cus * SVT_SPLIT2_CU_UNITS && !sso ? 2 : 0;
+        if (lanes && b->split_lds_bytes && units && !g_force_per_wg.load(std::memory_order_relaxed)) {
+            p.split = lanes;
+            p.tiles = 1;
+            p.per_wg = (uint32_t)kBlock;
+            p.n_wg = (uint32_t)((units + p.per_wg - 1) / p.per_wg);
+            return p;
+        }
+        if (kind == 1 || kind == 3 || kind == 4) goto stream;
+    }
+    if (b->coop_lds_bytes && units && g_small_kind.load(std::memory_order_relaxed) != 1 &&
+        (units <= std::min<uint64_t>((uint64_t)cu_count(b->device) * SVT_COOP_CU_UNITS, g_coop_max_units.load(std::memory_order_relaxed)) ||
+         g_small_kind.load(std::memory_order_relaxed) == 2) &&
+        !g_force_per_wg.load(std::memory_order_relaxed)) {
         p.coop = true;
         p.per_wg = (uint32_t)kBlock;
         if (const uint32_t f = g_coop_per_wg.load(std::memory_order_relaxed)) p.per_wg = std::min<uint32_t>((f + 63u) / 64u * 64u, (uint32_t)kBlock);
@@ -305,6 +371,7 @@ WgPlan wg_plan(const svt_batch* b, uint64_t units)
         p.n_wg = (uint32_t)((units + p.per_wg - 1) / p.per_wg);
         return p;
     }
+stream:
     if (const uint32_t f = g_force_per_wg.load(std::memory_order_relaxed)) {
         const int ft = (int)g_force_tiles.load(std::memory_order_relaxed);
         p.tiles = b->mode == kSingleLds && (ft == 1 || ft == 2) ? ft : tiles_per_wave(b, units);
@@ -333,6 +400,17 @@ int launch_stream(svt_batch* b, StreamArgs& a, hipStream_t stream)
     const uint64_t units = (uint64_t)a.unit_end - a.unit_begin;
     const WgPlan p = wg_plan(b, units);
     a.units_per_wg = p.per_wg;
+    if (p.split) {
+        StreamArgs c = a;
+        c.lds_rings = b->split_region;
+        c.l10_where = b->split_l10_where;
+        c.lds_l10 = b->split_lds_l10;
+        c.l10_lds_entries = b->split_l10_entries;
+        const dim3 grid(p.n_wg), block(kBlock * p.split);
+        void* params[] = {&c};
+        HIP_TRY(hipLaunchKernel(split_kernel_of(b, p.split), grid, block, params, b->split_lds_bytes, stream));
+        return SVT_OK;
+    }
     if (p.coop) {
         StreamArgs c = a;
         c.lds_rings = b->coop_region;
@@ -770,6 +848,14 @@ int create_stream(const svt_evidence_batch* in, svt_batch* b, void* d_records_re
     a.lds_winlibs = (uint32_t)(kSBins + (((size_t)a.lds_bins * kLdsBin + 15) & ~size_t(15)));   // (WinLib is read as 16-byte halves)
     size_t tables = a.lds_winlibs + (size_t)a.lds_libs * sizeof(LibDesc) + (windowed ? (size_t)max_win_libs * sizeof(WinLib) : 0);
     tables = (tables + 127) & ~size_t(127);
+    if (single) {   // one round of the one-tile kernel: what its registers and (tables + rings, the log10 table at most beside them) allow
+        int wgs = 3;
+        hipFuncAttributes fa{};
+        if (hipFuncGetAttributes(&fa, stream_kernel_of(b, 1)) == hipSuccess && fa.numRegs > 0) wgs = std::max(1, std::min(8, 512 / ((fa.numRegs + 7) / 8 * 8)));
+        else (void)hipGetLastError();
+        const size_t by_lds = (160 * 1024) / (tables + kWavesPerBlock * kStreamRingBytes);
+        b->one_tile_round_units = (uint64_t)std::min<size_t>((size_t)wgs, std::max<size_t>(by_lds, 1)) * cu_count(b->device) * kBlock;
+    }
     // How many workgroups of this batch's kernel a CU can hold is decided by its registers (512 per SIMD lane: <= 128 VGPRs
     // = four waves per SIMD = four 256-thread workgroups per CU); the LDS budget per workgroup follows from that, so that
     // the tables never cost a workgroup the registers would allow.
@@ -829,6 +915,21 @@ int create_stream(const svt_evidence_batch* in, svt_batch* b, void* d_records_re
             else (void)hipGetLastError();
             b->coop_resident = (uint32_t)std::min<size_t>((size_t)wgs, (160 * 1024) / b->coop_lds_bytes) * cu_count(b->device);
             if (b->coop_lds_bytes > 64 * 1024) HIP_TRY(hipFuncSetAttribute(coop_kernel_of(b), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->coop_lds_bytes));
+        }
+        // ... and the kernel with K lanes per unit
+        size_t stab = (a.lds_winlibs + 127) & ~size_t(127);
+        if (stab + l10_bytes + kSplitRegionBytes <= (160 * 1024 / 2)) {
+            b->split_l10_where = kL10Shared;
+            b->split_lds_l10 = (uint32_t)stab;
+            b->split_l10_entries = n_l10;
+            stab += l10_bytes;
+        }
+        if (stab + kSplitRegionBytes <= 160 * 1024) {
+            b->split_region = (uint32_t)stab;
+            b->split_lds_bytes = stab + kSplitRegionBytes;
+            if (b->split_lds_bytes > 64 * 1024)
+                for (int lanes = 2; lanes <= 4; lanes += 2)
+                    HIP_TRY(hipFuncSetAttribute(split_kernel_of(b, lanes), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->split_lds_bytes));
         }
     }
     a.n_units = n;

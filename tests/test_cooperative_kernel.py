@@ -14,7 +14,7 @@ from svtyper_amd import synth
 pytestmark = pytest.mark.gpu
 
 FLAGS = [0, ev.FLAG_SSO_ASSOCIATION, ev.FLAG_RESULT96, ev.FLAG_SSO_ASSOCIATION | ev.FLAG_RESULT96]
-DEFAULT_MAX = 65536
+DEFAULT_MAX = 1 << 40        # (svt_debug_coop: no cap of its own; the rule is per CU, svtyper_hip.hip: wg_plan)
 
 
 def _hook():
@@ -67,9 +67,39 @@ def test_same_bytes_as_the_streaming_kernel_and_the_oracle(hip_device, fixture_l
         lib.svt_debug_coop(DEFAULT_MAX, 0)
 
 
+def test_lanes_per_unit_kernels_same_bytes(hip_device, fixture_library):
+    """svt_split_kernel (svtyper_amd/csrc/svt_split_kernel.h): a unit on 2 or 4 adjacent lanes, the sums handed from lane to lane
+    in record order by DPP row shifts -- the streaming kernel's bytes, both associations, both record forms, ragged / empty /
+    skipped / 1 300-record units, continuation records, a last workgroup that is not full, the one-shot entry."""
+    from svtyper_amd import hip
+    lib = _hook()
+    lib.svt_debug_small_kind.argtypes = [C.c_int]
+    batches = [
+        synth.make_edge_cases([fixture_library], seed=29),
+        synth.make_units(9_000, 15, [fixture_library], svtype_mix=(0.5, 0.2, 0.2, 0.1), mean_frags=60, sd_frags=50, min_frags=0, max_frags=400,
+                         frac_empty=0.04, frac_skip=0.02),
+        synth.make_units(40_011, 16, [fixture_library], svtype_mix=(0.7, 0.15, 0.15, 0.0)),
+        synth.make_units(3, 17, [fixture_library]),
+    ]
+    try:
+        for batch in batches:
+            for flags in FLAGS:
+                lib.svt_debug_small_kind(1)
+                want, slots_stream = _resident(batch, hip_device, flags)
+                for kind in (3, 4):
+                    lib.svt_debug_small_kind(kind)
+                    got, slots = _resident(batch, hip_device, flags)
+                    assert got == want, (batch.n_units, flags, kind)
+                    assert slots == slots_stream
+                    assert hip.genotype_batch(batch, hip_device, flags).rec.tobytes() == want
+    finally:
+        lib.svt_debug_small_kind(0)
+
+
 def test_the_default_rule_picks_it_for_small_launches_only(hip_device, fixture_library):
-    """<= 65 536 units of one library: cooperative (tagged records in whole 64-unit tiles); above: the streaming kernel's whole
-    256-unit workgroups; several libraries: the streaming kernel (library windows)."""
+    """one library, by units per CU (svtyper_hip.hip: wg_plan): <= 64 cooperative (tagged records in whole 64-unit tiles);
+    above: 4 / 2 lanes per unit or the streaming kernel, whole 256-unit workgroups all of them; several libraries: the streaming
+    kernel (library windows)."""
     small = synth.make_units(10_000, 9, [fixture_library], mean_frags=8, sd_frags=4, min_frags=0, max_frags=20)
     large = synth.make_units(70_000, 10, [fixture_library], mean_frags=8, sd_frags=4, min_frags=0, max_frags=20)
     two = synth.make_units(10_000, 11, [fixture_library, synth.normal_library(420.0, 95.0, seed=3)], mean_frags=8, sd_frags=4, min_frags=0, max_frags=20)
