@@ -35,7 +35,9 @@ while time.time() - t0 < budget:
     elif kind == 5:  # one library, enough units for two tiles per wave (launches of >= 221 184 units), ragged lengths
         libs = libs[:1]
         n_libs = 1
-        b = synth.make_units(int(rng.integers(221_184, 300_000)), 3000 + it, libs, svtype_mix=tuple(rng.dirichlet([2, 1, 1, 1])),
+        # (every other time a launch of less than one round: 16 k ... 140 k units take the kernels with four / two lanes per unit)
+        n5 = int(rng.integers(221_184, 300_000)) if rng.random() < 0.5 else int(rng.integers(16_000, 140_000))
+        b = synth.make_units(n5, 3000 + it, libs, svtype_mix=tuple(rng.dirichlet([2, 1, 1, 1])),
                              mean_frags=float(rng.uniform(2, 25)), sd_frags=float(rng.uniform(1, 20)), min_frags=0,
                              max_frags=int(rng.integers(30, 260)), frac_empty=0.02, frac_skip=0.01)
     elif kind == 4:  # several samples with their own libraries: the streaming kernel's library windows (svt_unit.libs)
