@@ -194,6 +194,10 @@ __global__ __launch_bounds__(kBlock * K, 4) void svt_split_kernel(const StreamAr
 #pragma unroll
     for (int d = 1; d < kWave; d <<= 1) max_blk = max(max_blk, (uint32_t)__shfl_xor((int)max_blk, d, kWave));
     max_blk = (uint32_t)__builtin_amdgcn_readfirstlane((int)max_blk);
+    uint32_t min_blk = nblk;
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) min_blk = min(min_blk, (uint32_t)__shfl_xor((int)min_blk, d, kWave));
+    min_blk = (uint32_t)__builtin_amdgcn_readfirstlane((int)min_blk);
     StreamCtx sc;
     sc.fmask = me.w & kSplitFmask;
     sc.kmin = (uint32_t)a.lib0.key_min;
@@ -221,6 +225,14 @@ __global__ __launch_bounds__(kBlock * K, 4) void svt_split_kernel(const StreamAr
     }
     const char* rec_bytes = reinterpret_cast<const char*>(a.records);
     auto fetch = [&](const uint32_t k) {
+        if (k >= 1u && k + 1u < min_blk) {   // an interior block of every unit of the wave: whole lines, nothing to test
+#pragma unroll
+            for (int i = 0; i < kFetches; ++i) {
+                const uint32_t rec = src_base[i] + k * kBlockRecords;
+                __builtin_amdgcn_global_load_lds(rec_bytes + ((uint64_t)rec << 4), (lds_void_ptr)(ring + (uint32_t)i * 1024u), 16, 0, SVT_STREAM_AUX);
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < kFetches; ++i) {
             const uint32_t rec = src_base[i] + k * kBlockRecords;
@@ -244,30 +256,60 @@ __global__ __launch_bounds__(kBlock * K, 4) void svt_split_kernel(const StreamAr
         for (uint32_t j = 0; j < kRecs; ++j) w[j] = *reinterpret_cast<lds_cu32x4_s*>((size_t)rd[j]);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (k + 1 < max_blk) fetch(k + 1);
-        // ---- what this lane's records add; a slot outside the unit is the neutral record (MAPQ 0 everywhere adds +0.0)
+        // ---- what this lane's records add; a slot outside the unit is the neutral record (MAPQ 0 everywhere adds +0.0).
+        // Two records at a time, in three steps with one LDS round trip each -- every look-up that depends on the record alone, the
+        // decision-table look-up that depends on p_concordant, the products -- instead of six round trips per record: a wave
+        // that has its SIMD nearly to itself waits for every one of them.
         SplitAddends x[kRecs];
         bool any_cont = false;
 #pragma unroll
-        for (uint32_t j = 0; j < kRecs; ++j) {
-            const bool mine = k * kBlockRecords + hh * kRecs + j - head < n_rec;   // head <= index < last, unsigned
-            u32x4 wj = w[j];
-            wj.x = mine ? wj.x : 0u;
-            wj.y = mine ? wj.y : 0u;
-            wj.z = mine ? wj.z : 0u;
-            wj.w = mine ? wj.w : 0u;
-            check.see(wj);
-            x[j].rs_a = lds_f64(kSPm + byte2_x8(wj.y));
-            x[j].rs_b = lds_f64(kSPm + byte3_x8(wj.y));
-            x[j].p_seq = lds_f64(kSPmHalf + byte0_x8(wj.z)) + lds_f64(kSPmHalf + byte1_x8(wj.z));
-            x[j].p_clip = lds_f64(kSPmHalf + byte2_x8(wj.z)) + lds_f64(kSPmHalf + byte3_x8(wj.z));
-            const double pp = lds_f64(kSPm + byte0_x8(wj.y)) * lds_f64(kSPm + byte1_x8(wj.y));
-            const uint32_t i1 = min(wj.x - sc.kmin, sc.nb), i2 = min(wj.x - sc.sub2, sc.nb);
-            const bool p_conc = (int32_t)lds_u16(sc.hist_at + (i2 << 1)) <= lds_i16(kSBins + (i1 << 1));
-            const uint32_t wa = (p_conc ? sc.wt1 : sc.wt0) | ((wj.w & sc.fmask) << 3);   // &w_alt[f3 | p_conc << 3 | del16]
-            x[j].alt_w = pp * lds_f64(wa);
-            x[j].ref_w = pp * lds_f64(wa + kSWref);
-            x[j].cont = SSO && (wj.w & SVT_REC_CONTINUATION) != 0u;
-            any_cont = any_cont || x[j].cont;
+        for (uint32_t j0 = 0; j0 < kRecs; j0 += 2u) {
+            u32x4 wj[2];
+            double pm_a[2], pm_b[2], s0[2], s1[2], c0[2], c1[2];
+            int32_t thr1[2];
+            uint32_t h2[2];
+#pragma unroll
+            for (uint32_t q = 0; q < 2u; ++q) {
+                const uint32_t j = j0 + q;
+                const bool mine = k * kBlockRecords + hh * kRecs + j - head < n_rec;   // head <= index < last, unsigned
+                wj[q].x = mine ? w[j].x : 0u;
+                wj[q].y = mine ? w[j].y : 0u;
+                wj[q].z = mine ? w[j].z : 0u;
+                wj[q].w = mine ? w[j].w : 0u;
+                check.see(wj[q]);
+                const uint32_t i1 = min(wj[q].x - sc.kmin, sc.nb), i2 = min(wj[q].x - sc.sub2, sc.nb);
+                thr1[q] = lds_i16(kSBins + (i1 << 1));
+                h2[q] = lds_u16(sc.hist_at + (i2 << 1));
+                pm_a[q] = lds_f64(kSPm + byte0_x8(wj[q].y));
+                pm_b[q] = lds_f64(kSPm + byte1_x8(wj[q].y));
+                x[j].rs_a = lds_f64(kSPm + byte2_x8(wj[q].y));
+                x[j].rs_b = lds_f64(kSPm + byte3_x8(wj[q].y));
+                s0[q] = lds_f64(kSPmHalf + byte0_x8(wj[q].z));
+                s1[q] = lds_f64(kSPmHalf + byte1_x8(wj[q].z));
+                c0[q] = lds_f64(kSPmHalf + byte2_x8(wj[q].z));
+                c1[q] = lds_f64(kSPmHalf + byte3_x8(wj[q].z));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            double w_alt[2], w_ref[2];
+#pragma unroll
+            for (uint32_t q = 0; q < 2u; ++q) {
+                const bool p_conc = (int32_t)h2[q] <= thr1[q];
+                const uint32_t wa = (p_conc ? sc.wt1 : sc.wt0) | ((wj[q].w & sc.fmask) << 3);   // &w_alt[f3 | p_conc << 3 | del16]
+                w_alt[q] = lds_f64(wa);
+                w_ref[q] = lds_f64(wa + kSWref);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (uint32_t q = 0; q < 2u; ++q) {
+                const uint32_t j = j0 + q;
+                const double pp = pm_a[q] * pm_b[q];
+                x[j].p_seq = s0[q] + s1[q];
+                x[j].p_clip = c0[q] + c1[q];
+                x[j].alt_w = pp * w_alt[q];
+                x[j].ref_w = pp * w_ref[q];
+                x[j].cont = SSO && (wj[q].w & SVT_REC_CONTINUATION) != 0u;
+                any_cont = any_cont || x[j].cont;
+            }
         }
         const bool has_cont = SSO && __any(any_cont);
         // ---- the sums, in record order: lane 0 of the group, then lane 1 with what lane 0 hands over, ...

@@ -304,3 +304,24 @@ def test_compact_gather_records_carry_the_genotype_fields(fixture_library):
     broken.view(-1, 48)[np.nonzero(parts[0].view(-1, 48)[:, 44:48].numpy().view(np.uint32).ravel() == 0)[0][0], 44:48] = 0xFF   # unit 0 -> padding
     with pytest.raises(ValueError):
         D.results_from_compact(torch.cat([broken, parts[1]]), sizes, counts)
+
+
+@pytest.mark.gpu
+def test_batch_sync_reports_what_the_enqueued_passes_found(hip_device, fixture_library):
+    """svt_batch_sync (ABI 14): passes enqueued without waiting, then ONE call that waits and reports -- the results are there,
+    and a record that breaks the contract (a straddle bit without HAS_PAIR) comes back as the error svt_batch_genotype(b, 1)
+    would have raised."""
+    from svtyper_amd import hip
+    batch = synth.make_units(5000, 91, [fixture_library], svtype_mix=(0.5, 0.2, 0.2, 0.1), mean_frags=20, sd_frags=10, min_frags=0)
+    want = hip.genotype_batch(batch, hip_device, 0)
+    with hip.DeviceBatch(batch, hip_device, ev.FLAG_RESULT96) as d:
+        d.genotype(sync=False)
+        d.genotype_n(3)
+        d.synchronize()
+        assert d.results().rec.tobytes() == want.rec.tobytes()
+    bad = synth.make_units(5000, 91, [fixture_library], svtype_mix=(0.5, 0.2, 0.2, 0.1), mean_frags=20, sd_frags=10, min_frags=1)
+    bad.records["flags"][7] = (bad.records["flags"][7] | ev.REC_ALT_STRADDLE) & ~np.uint32(ev.REC_HAS_PAIR)
+    with hip.DeviceBatch(bad, hip_device, 0) as d:
+        d.genotype(sync=False)
+        with pytest.raises(hip.SvtyperHipError):
+            d.synchronize()
