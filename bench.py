@@ -516,7 +516,7 @@ def real_data_leg(device: int) -> dict:
         # formats the sample columns of chunk k-1 -- the wall time is the longer chain, not the sum of the stages
         try:
             all_sites = [bp for _r in range(repeat) for bp in sites]
-            per = max(256, -(-len(all_sites) // 12))
+            per = max(256, -(-len(all_sites) // 3))     # (a dozen chunks lost 15 %: every chunk starts the reader's thread pool and a device batch of its own)
             over = None
             for _ in range(2):
                 eng = Timed()
@@ -1304,7 +1304,7 @@ def main():
                     # stays sample-major; the copies carry the same evidence, so the whole pass must repeat the 2 M-unit pass block by
                     # block): ~1.6 G records = 37 % of the 32-bit record index space, ~26 GB of HBM, ~31 k window chunks
                     try:
-                        copies = max(1, 16_000_000 // sm_batch.n_units)
+                        copies = max(1, min(8, 16_000_000 // sm_batch.n_units))     # (8 x the 2 M-unit leg = configs[4]; small --units: 8 x as well)
                         avail = 0.0
                         for line in open("/proc/meminfo"):
                             if line.startswith("MemAvailable:"):

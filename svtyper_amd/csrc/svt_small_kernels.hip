@@ -30,4 +30,7 @@ template __global__ void svt_split_kernel<false, kSingleLds, 2>(const StreamArgs
 template __global__ void svt_split_kernel<true, kSingleLds, 2>(const StreamArgs);
 template __global__ void svt_split_kernel<false, kSingleLds, 4>(const StreamArgs);
 template __global__ void svt_split_kernel<true, kSingleLds, 4>(const StreamArgs);
+template __global__ void svt_split_kernel<false, kMultiLds, 2>(const StreamArgs);
+template __global__ void svt_split_kernel<false, kMultiLds, 4>(const StreamArgs);
+template __global__ void svt_split_kernel<true, kMultiLds, 4>(const StreamArgs);
 }  // namespace svt

@@ -33,7 +33,8 @@ namespace svt {
 // the split region of the workgroup's LDS, byte offsets from StreamArgs::lds_rings (128-byte aligned)
 constexpr uint32_t kSplitTileAt = 0;                                  // uint4[256]  {first record, records, sub2, flags} by sorted position
 constexpr uint32_t kSplitUnitAt = kSplitTileAt + kBlock * 16u;        // uint32[256] unit index (kPadUnit: none)
-constexpr uint32_t kSplitTallyAt = kSplitUnitAt + kBlock * 4u;        // double[5][256] tallies by sorted position
+constexpr uint32_t kSplitGateAt = kSplitUnitAt + kBlock * 4u;         // uint32[256] library windows: bit l = the small-deletion gate of the window's l-th library is closed
+constexpr uint32_t kSplitTallyAt = kSplitGateAt + kBlock * 4u;        // double[5][256] tallies by sorted position
 constexpr uint32_t kSplitRingAt = kSplitTallyAt + 5u * kBlock * 8u;   // per-wave rings: 4 K waves x (64 / K units x 128 bytes) = 32 KB; sort scratch
                                                                       // before the steps, the four result rings after them
 constexpr uint32_t kSplitRegionBytes = kSplitRingAt + (uint32_t)(kBlock / kWave) * kRingBytes;
@@ -90,7 +91,7 @@ struct SplitAddends {
 template <bool SSO, int MODE, int K>
 __global__ __launch_bounds__(kBlock * K, 4) void svt_split_kernel(const StreamArgs a)
 {
-    static_assert(MODE == kSingleLds, "one library");
+    static_assert(MODE == kSingleLds || MODE == kMultiLds, "one library, or library windows (svt_unit.libs)");
     static_assert(K == 2 || K == 4, "two or four lanes per unit");
     constexpr uint32_t kWaves = 4u * K, kThreads = kWaves * kWave, kUnitsPerWave = kWave / K, kRecs = kBlockRecords / K;
     constexpr uint32_t kWaveRing = kUnitsPerWave * 128u;   // one 128-byte block per unit of the wave
@@ -101,21 +102,34 @@ __global__ __launch_bounds__(kBlock * K, 4) void svt_split_kernel(const StreamAr
     unsigned char* region = smem + a.lds_rings;
     uint4* s_tile = reinterpret_cast<uint4*>(region + kSplitTileAt);
     uint32_t* s_unit = reinterpret_cast<uint32_t*>(region + kSplitUnitAt);
+    uint32_t* s_gate = reinterpret_cast<uint32_t*>(region + kSplitGateAt);
     double* s_tally = reinterpret_cast<double*>(region + kSplitTallyAt);
     unsigned char* rings = region + kSplitRingAt;
 
-    const uint32_t wg_base = a.unit_begin + blockIdx.x * a.units_per_wg;
-    const uint32_t n_here = min(a.units_per_wg, a.unit_end - wg_base);
+    // this workgroup's units: 256 consecutive ones, or (library windows) a chunk of at most 256 units of the permutation that groups
+    // the units by the libraries of their sample
+    const uint32_t wg_index = MODE == kMultiLds ? blockIdx.x + a.chunk_begin : blockIdx.x;
+    uint32_t wg_base = a.unit_begin + blockIdx.x * a.units_per_wg, n_here;
+    WgDesc wd{};
+    if (MODE == kMultiLds) {
+        const uint2 ch = a.chunks[wg_index];
+        wg_base = ch.x;
+        n_here = min(ch.y, (uint32_t)kBlock);
+        wd = a.windows[wg_index];
+    } else {
+        n_here = min(a.units_per_wg, a.unit_end - wg_base);
+    }
     const bool sorter = tid < (uint32_t)kBlock;    // the first four waves hold the workgroup's (up to) 256 units
 
     // ---- this thread's unit: record range and header (the loads overlap the table staging below)
-    uint32_t beg = 0u, cnt = 0u;
+    uint32_t beg = 0u, cnt = 0u, my_unit = kPadUnit;
     svt_unit U{};
     if (sorter && tid < n_here) {
-        const uint64_t lo = a.rec_offset[wg_base + tid], hi = a.rec_offset[wg_base + tid + 1];
+        my_unit = MODE == kMultiLds && a.perm ? a.perm[wg_base + tid] : wg_base + tid;
+        const uint64_t lo = a.rec_offset[my_unit], hi = a.rec_offset[my_unit + 1];
         beg = (uint32_t)lo;
         cnt = (uint32_t)(hi - lo);
-        U = a.units[wg_base + tid];
+        U = a.units[my_unit];
     }
     // ---- tables (the layout of svt_stream_kernel: kSPm ...)
     for (uint32_t i = tid; i < 256; i += kThreads) {
@@ -128,13 +142,33 @@ __global__ __launch_bounds__(kBlock * K, 4) void svt_split_kernel(const StreamAr
         reinterpret_cast<double*>(smem + kSWtab)[tid] = pw.w_alt;
         reinterpret_cast<double*>(smem + kSWtab + kSWref)[tid] = pw.w_ref;
     }
-    {
+    if (MODE == kSingleLds) {
         int16_t* s_thr = reinterpret_cast<int16_t*>(smem + kSBins);
         uint16_t* s_hst = reinterpret_cast<uint16_t*>(smem + kSBins) + a.total_bins;
         for (uint32_t i = tid; i < a.total_bins; i += kThreads) {
             const Bin bn = a.bins[i];
             s_thr[i] = (int16_t)bn.thr;
             s_hst[i] = (uint16_t)bn.hist;
+        }
+    } else {
+        // the window's bins as thr[bin_cnt], hist[bin_cnt] and one WinLib per library of the window (svt_stream_kernel.h)
+        int16_t* s_thr = reinterpret_cast<int16_t*>(smem + kSBins);
+        uint16_t* s_hst = reinterpret_cast<uint16_t*>(smem + kSBins) + wd.bin_cnt;
+        for (uint32_t i = tid; i < wd.bin_cnt; i += kThreads) {
+            const Bin bn = a.bins[wd.bin_lo + i];
+            s_thr[i] = (int16_t)bn.thr;
+            s_hst[i] = (uint16_t)bn.hist;
+        }
+        if (tid < wd.lib_cnt) {
+            const LibDesc L = a.libs[wd.lib_lo + tid];
+            WinLib wl;
+            wl.kmin = (uint32_t)L.key_min;
+            wl.nb = L.n_bins;
+            wl.thr_at = kSBins + (L.tab_off - wd.bin_lo) * 2u;
+            wl.hist_at = kSBins + (wd.bin_cnt + L.tab_off - wd.bin_lo) * 2u;
+            wl.sd2 = L.sd2;
+            wl.pad = 0.0;
+            reinterpret_cast<WinLib*>(smem + a.lds_winlibs)[tid] = wl;
         }
     }
     if (a.l10_where == kL10Shared) {
@@ -173,13 +207,21 @@ __global__ __launch_bounds__(kBlock * K, 4) void svt_split_kernel(const StreamAr
         __syncthreads();
         if (sorter) {
             const bool is_del = U.svtype == SVT_SVTYPE_DEL;
-            const bool small_del = is_del && ((double)U.pos_delta < a.lib0.sd2);   // classic.py:339,383
+            const bool small_del = MODE == kSingleLds && is_del && ((double)U.pos_delta < a.lib0.sd2);   // classic.py:339,383
             const uint32_t flags = (small_del ? 0u : kSplitFmask) | (is_del ? kSplitDel16 : 0u) | ((uint32_t)U.svtype << kSplitSvtypeShift) |
                                    ((uint32_t)U.flags << kSplitUflagsShift);
-            const uint32_t sub2 = is_del ? (uint32_t)U.var_length + (uint32_t)a.lib0.key_min : 0x80000000u;
+            // one library: DEL ? var_length + key_min : never in range; windows: DEL ? var_length : never -- the library's key_min is added per record
+            const uint32_t sub2 = is_del ? (uint32_t)U.var_length + (MODE == kSingleLds ? (uint32_t)a.lib0.key_min : 0u) : 0x80000000u;
             const uint32_t pos = s_start[key] + rank;
             s_tile[pos] = make_uint4(beg, cnt, sub2, flags);
-            s_unit[pos] = tid < n_here ? wg_base + tid : kPadUnit;
+            s_unit[pos] = my_unit;
+            if (MODE == kMultiLds) {   // the small-deletion gate per library of the window, formed once per unit (the WinLibs were staged before the sort's barriers)
+                uint32_t gated = 0u;
+                if (is_del)
+                    for (uint32_t l = 0; l < wd.lib_cnt; ++l)
+                        gated |= ((double)U.pos_delta < reinterpret_cast<const WinLib*>(smem + a.lds_winlibs)[l].sd2 ? 1u : 0u) << l;
+                s_gate[pos] = gated;
+            }
         }
         __syncthreads();
     }
@@ -207,6 +249,11 @@ __global__ __launch_bounds__(kBlock * K, 4) void svt_split_kernel(const StreamAr
     sc.wt0 = kSWtab + (me.w & kSplitDel16) * 8u;
     sc.wt1 = sc.wt0 + 8u * 8u;
     sc.wh0 = 0u;
+    const uint32_t gated = MODE == kMultiLds ? s_gate[pos] : 0u;
+    const bool is_del = (me.w & kSplitDel16) != 0u;
+    const uint32_t lib_last = wd.lib_cnt - 1u, winlibs_at = a.lds_winlibs;
+    const uint32_t neutral_w = MODE == kMultiLds ? wd.lib_lo << SVT_REC_LIB_SHIFT : 0u;
+    const uint32_t lib_key = MODE == kMultiLds && wd.lib_cnt == 1u ? wd.lib_lo << SVT_REC_LIB_SHIFT : 0u;
 
     // ---- fetch side: lane (o, rr) of instruction i brings 16 bytes of the block of the wave's unit 8 i + o to ring + (8 i + o) * 128 + rr * 16;
     // the slot rr of unit u holds logical record rr ^ swz(u), swz(u) = (u >> 1) & 7 (svt_ring_engine.h)
@@ -267,7 +314,7 @@ __global__ __launch_bounds__(kBlock * K, 4) void svt_split_kernel(const StreamAr
             u32x4 wj[2];
             double pm_a[2], pm_b[2], s0[2], s1[2], c0[2], c1[2];
             int32_t thr1[2];
-            uint32_t h2[2];
+            uint32_t h2[2], f3[2];
 #pragma unroll
             for (uint32_t q = 0; q < 2u; ++q) {
                 const uint32_t j = j0 + q;
@@ -275,11 +322,25 @@ __global__ __launch_bounds__(kBlock * K, 4) void svt_split_kernel(const StreamAr
                 wj[q].x = mine ? w[j].x : 0u;
                 wj[q].y = mine ? w[j].y : 0u;
                 wj[q].z = mine ? w[j].z : 0u;
-                wj[q].w = mine ? w[j].w : 0u;
-                check.see(wj[q]);
-                const uint32_t i1 = min(wj[q].x - sc.kmin, sc.nb), i2 = min(wj[q].x - sc.sub2, sc.nb);
-                thr1[q] = lds_i16(kSBins + (i1 << 1));
-                h2[q] = lds_u16(sc.hist_at + (i2 << 1));
+                wj[q].w = mine ? w[j].w : neutral_w;
+                check.see(wj[q], lib_key);
+                if (MODE == kMultiLds) {
+                    // the record's library picks one of the window's descriptors (record_window, svt_stream_kernel.h)
+                    const uint32_t rel = SVT_REC_LIB(wj[q].w) - wd.lib_lo;
+                    check.window_lib(rel);
+                    const uint32_t l = min(rel, lib_last);
+                    const u32x4 d = *reinterpret_cast<lds_cu32x4_s*>((size_t)(winlibs_at + l * (uint32_t)sizeof(WinLib)));   // kmin, nb, thr_at, hist_at
+                    f3[q] = ((gated >> l) & 1u) ? 0u : (wj[q].w & 7u);          // classic.py:339,383
+                    const uint32_t sub2 = is_del ? sc.sub2 + d.x : 0x80000000u;
+                    const uint32_t i1 = min(wj[q].x - d.x, d.y), i2 = min(wj[q].x - sub2, d.y);
+                    thr1[q] = lds_i16(d.z + (i1 << 1));
+                    h2[q] = lds_u16(d.w + (i2 << 1));
+                } else {
+                    f3[q] = wj[q].w & sc.fmask;
+                    const uint32_t i1 = min(wj[q].x - sc.kmin, sc.nb), i2 = min(wj[q].x - sc.sub2, sc.nb);
+                    thr1[q] = lds_i16(kSBins + (i1 << 1));
+                    h2[q] = lds_u16(sc.hist_at + (i2 << 1));
+                }
                 pm_a[q] = lds_f64(kSPm + byte0_x8(wj[q].y));
                 pm_b[q] = lds_f64(kSPm + byte1_x8(wj[q].y));
                 x[j].rs_a = lds_f64(kSPm + byte2_x8(wj[q].y));
@@ -294,7 +355,7 @@ __global__ __launch_bounds__(kBlock * K, 4) void svt_split_kernel(const StreamAr
 #pragma unroll
             for (uint32_t q = 0; q < 2u; ++q) {
                 const bool p_conc = (int32_t)h2[q] <= thr1[q];
-                const uint32_t wa = (p_conc ? sc.wt1 : sc.wt0) | ((wj[q].w & sc.fmask) << 3);   // &w_alt[f3 | p_conc << 3 | del16]
+                const uint32_t wa = (p_conc ? sc.wt1 : sc.wt0) | (f3[q] << 3);   // &w_alt[f3 | p_conc << 3 | del16]
                 w_alt[q] = lds_f64(wa);
                 w_ref[q] = lds_f64(wa + kSWref);
             }
@@ -379,11 +440,11 @@ __global__ __launch_bounds__(kBlock * K, 4) void svt_split_kernel(const StreamAr
         uint32_t tile_slot = 0xFFFFFFFFu;
         if (a.result96) {
             piece[5] = make_uint4(piece[5].x, piece[7].y, unit_out, 0u);
-            tile_slot = a.slot_begin + (blockIdx.x * (uint32_t)kWavesPerBlock + wave) * kWave;
+            tile_slot = a.slot_begin + (wg_index * (uint32_t)kWavesPerBlock + wave) * kWave;
         }
         store_result_records_through_ring(rings + wave * kRingBytes, piece, unit_out, lane, reinterpret_cast<unsigned char*>(a.out), a.result96 ? 6u : 8u, tile_slot);
     }
-    const uint32_t bad = check.bits(a.n_libs);
+    const uint32_t bad = check.bits(MODE == kMultiLds ? wd.lib_cnt : a.n_libs);
     if (bad) atomicOr(a.err, bad);
 }
 

@@ -81,6 +81,9 @@ extern template __global__ void svt_split_kernel<false, kSingleLds, 2>(const Str
 extern template __global__ void svt_split_kernel<true, kSingleLds, 2>(const StreamArgs);
 extern template __global__ void svt_split_kernel<false, kSingleLds, 4>(const StreamArgs);
 extern template __global__ void svt_split_kernel<true, kSingleLds, 4>(const StreamArgs);
+extern template __global__ void svt_split_kernel<false, kMultiLds, 2>(const StreamArgs);
+extern template __global__ void svt_split_kernel<false, kMultiLds, 4>(const StreamArgs);
+extern template __global__ void svt_split_kernel<true, kMultiLds, 4>(const StreamArgs);
 }  // namespace svt
 #endif
 
@@ -230,6 +233,10 @@ const void* coop_kernel_of(const svt_batch* b)
 const void* split_kernel_of(const svt_batch* b, int lanes)
 {
     const bool sso = (b->flags & SVT_FLAG_SSO_ASSOCIATION) != 0;
+    if (b->mode == kMultiLds) {   // (singlesample association: four lanes only -- split_lanes_for never asks for two)
+        if (lanes == 2) return reinterpret_cast<const void*>(&svt_split_kernel<false, kMultiLds, 2>);
+        return sso ? reinterpret_cast<const void*>(&svt_split_kernel<true, kMultiLds, 4>) : reinterpret_cast<const void*>(&svt_split_kernel<false, kMultiLds, 4>);
+    }
     if (lanes == 2) return sso ? reinterpret_cast<const void*>(&svt_split_kernel<true, kSingleLds, 2>) : reinterpret_cast<const void*>(&svt_split_kernel<false, kSingleLds, 2>);
     return sso ? reinterpret_cast<const void*>(&svt_split_kernel<true, kSingleLds, 4>) : reinterpret_cast<const void*>(&svt_split_kernel<false, kSingleLds, 4>);
 }
@@ -334,6 +341,21 @@ extern "C" void svt_debug_coop(uint64_t max_units, uint32_t per_wg) { g_coop_max
 #endif
 static std::atomic<int> g_small_kind{SVT_SMALL_KIND};
 extern "C" int svt_debug_small_kind(int kind) { return g_small_kind.exchange(kind); }
+// lanes per unit for a launch over `units` units (0 = not the split kernel)
+int split_lanes_for(const svt_batch* b, uint64_t units)
+{
+    const int kind = g_small_kind.load(std::memory_order_relaxed);
+    const bool sso = (b->flags & SVT_FLAG_SSO_ASSOCIATION) != 0;
+    if (!b->split_lds_bytes || !units) return 0;
+    if (kind == 3) return sso && b->mode == kMultiLds ? 0 : 2;
+    if (kind == 4) return 4;
+    if (kind != 0) return 0;
+    const uint64_t cus = cu_count(b->device);
+    const bool coop_first = b->coop_lds_bytes && units <= std::min<uint64_t>(cus * SVT_COOP_CU_UNITS, g_coop_max_units.load(std::memory_order_relaxed));
+    if (coop_first) return 0;
+    return units <= cus * SVT_SPLIT4_CU_UNITS ? 4 : units <= cus * SVT_SPLIT2_CU_UNITS && !sso ? 2 : 0;
+}
+
 WgPlan wg_plan(const svt_batch* b, uint64_t units)
 {
     WgPlan p;
@@ -341,13 +363,7 @@ WgPlan wg_plan(const svt_batch* b, uint64_t units)
     p.split = 0;
     {
         const int kind = g_small_kind.load(std::memory_order_relaxed);
-        const bool forced = kind == 3 || kind == 4;
-        const uint64_t cus = cu_count(b->device);
-        const bool sso = (b->flags & SVT_FLAG_SSO_ASSOCIATION) != 0;
-        const bool coop_first = b->coop_lds_bytes && units <= std::min<uint64_t>(cus * SVT_COOP_CU_UNITS, g_coop_max_units.load(std::memory_order_relaxed));
-        const int lanes = forced ? (kind == 3 ? 2 : 4)
-                          : kind != 0 || coop_first ? 0
-                          : units <= cus * SVT_SPLIT4_CU_UNITS ? 4 : units <= cus * SVT_SPLIT2_CU_UNITS && !sso ? 2 : 0;
+        const int lanes = split_lanes_for(b, units);
         if (lanes && b->split_lds_bytes && units && !g_force_per_wg.load(std::memory_order_relaxed)) {
             p.split = lanes;
             p.tiles = 1;
@@ -470,6 +486,21 @@ int launch_genotype(svt_batch* b)
         return SVT_OK;
     }
     if (b->n_units == 0) return SVT_OK;
+    if (b->mode == kMultiLds && b->window_tiles == 1) {
+        // a launch of less than one round: K lanes per unit (svt_split_kernel.h; the chunks hold at most 256 units)
+        if (const int lanes = split_lanes_for(b, b->n_units)) {
+            StreamArgs c = b->sargs;
+            c.lds_rings = b->split_region;
+            c.l10_where = b->split_l10_where;
+            c.lds_l10 = b->split_lds_l10;
+            c.l10_lds_entries = b->split_l10_entries;
+            c.chunk_begin = 0;
+            const dim3 grid(b->n_chunks), block(kBlock * lanes);
+            void* params[] = {&c};
+            HIP_TRY(hipLaunchKernel(split_kernel_of(b, lanes), grid, block, params, b->split_lds_bytes, b->stream));
+            return SVT_OK;
+        }
+    }
     if (b->mode == kMultiLds && b->split_window_kinds) {
         // two launches, one per kind of window: each kernel holds ONE record consumer (126 VGPRs: four workgroups per CU; the
         // kernel with both consumers has 161: three).  The chunks are ordered by the size of their window.
@@ -930,6 +961,22 @@ int create_stream(const svt_evidence_batch* in, svt_batch* b, void* d_records_re
             if (b->split_lds_bytes > 64 * 1024)
                 for (int lanes = 2; lanes <= 4; lanes += 2)
                     HIP_TRY(hipFuncSetAttribute(split_kernel_of(b, lanes), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->split_lds_bytes));
+        }
+    }
+    if (b->mode == kMultiLds && a.l10_where != kL10Ring) {
+        // the kernel with K lanes per unit over library windows: its region behind the window tables (and the log10 table where
+        // the streaming kernel keeps it beside them)
+        const size_t stab = (tables + 127) & ~size_t(127);
+        if (stab + kSplitRegionBytes <= 160 * 1024) {
+            b->split_region = (uint32_t)stab;
+            b->split_lds_bytes = stab + kSplitRegionBytes;
+            b->split_l10_where = a.l10_where;
+            b->split_lds_l10 = a.lds_l10;
+            b->split_l10_entries = a.l10_lds_entries;
+            if (b->split_lds_bytes > 64 * 1024)
+                for (int lanes = 2; lanes <= 4; lanes += 2)
+                    if (lanes == 4 || !(b->flags & SVT_FLAG_SSO_ASSOCIATION))
+                        HIP_TRY(hipFuncSetAttribute(split_kernel_of(b, lanes), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->split_lds_bytes));
         }
     }
     a.n_units = n;

@@ -62,6 +62,16 @@ def test_bench_line_has_the_contract_keys(hip_device):
     assert c5["units"] == 60000 - 60000 % 32          # configs[4]'s per-GPU share is twice the headline's units
     assert 0 < c5["frac"] <= 1.0 and c5["table_mode"] == 1 and c5["units"] % 32 == 0 and c5["hintless"]["table_mode"] == 1 and c5["hintless"]["results_equal"] and c5["general_tables"]["table_mode"] == 2
     assert c5["site_major_input"]["results_and_site_qual_equal"] is True
+    # configs[4] at "its full size" (here 8 x the leg's batch): every site block repeats the leg's pass, QUAL too
+    full = d["c5_full"]
+    assert "error" not in full, full
+    assert full["units"] == 8 * c5["units"] and full["every_site_block_equals_the_2M_unit_pass"] is True and full["site_qual_equals"] is True
+    assert 0 < full["frac"] <= 1.0 and full["result_slots"] >= full["units"]
+    # the three placements side by side, the ratios against the CPU restatements, the timed region's dispatches for the profile
+    assert roof["frac_tuned"] == roof["frac"] and 0 < roof["frac_cold"] <= 1.0 and 0 < roof["frac_untuned_median"] <= 1.0
+    assert roof["timed_region_dispatches"]["count"] == 3 and roof["timed_region_dispatches"]["first"] is None      # (an audition ran)
+    assert d["vs_cpu"]["c_port"] > 1 and d["vs_cpu"]["python_restatement_pool"] > d["vs_cpu"]["c_port"]
+    assert d["shard_of_8"]["results_equal_headline"] is True
     # ... and the same batch as packed evidence of several libraries (library switches in the pair streams)
     assert c5["packed"]["results_equal"] is True and c5["packed"]["bytes_per_record"] < 6 and c5["packed"]["pass_ms"] > 0
     assert c5["placement_tuned"]["after_ms"] <= c5["placement_tuned"]["before_ms"]
@@ -95,3 +105,23 @@ def test_one_line_on_stdout_with_the_process_group_up(hip_device):
     d = json.loads(lines[0])
     assert d["gather"]["collective"] == "rccl gather" and d["value"] > 0
     assert d["scaling"] == "strong" and d["config"]["total_units"] == 20000 and d["gather"]["units_per_rank"] == [20000]
+
+
+def test_a_rank_builds_only_its_shard_of_the_strong_workload():
+    """host only: bench.generate_shard (the `strong` leg = configs[3]) returns, for every rank, exactly the units a slice of the
+    whole workload under distributed.shard_bounds would -- without generating the chunks the shard does not touch (the bounds
+    come from synth.make_units(counts_only=True), the first draws of every chunk's generator)."""
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    import bench
+    from svtyper_amd import distributed as D
+    n, world = 120_000, 3
+    whole = bench.generate("c3_mixed_1m", n, 0, 2)
+    bounds = D.shard_bounds(whole.rec_offset, world, 1)
+    assert sum(hi - lo for lo, hi in bounds) == n
+    for r in range(world):
+        shard, b = bench.generate_shard("c3_mixed_1m", n, world, r, 2)
+        assert b == bounds
+        want = whole.slice(*bounds[r])
+        assert np.array_equal(shard.rec_offset, want.rec_offset) and np.array_equal(shard.units, want.units)
+        assert shard.records.tobytes() == want.records.tobytes()

@@ -96,6 +96,40 @@ def test_lanes_per_unit_kernels_same_bytes(hip_device, fixture_library):
         lib.svt_debug_small_kind(0)
 
 
+def test_lanes_per_unit_kernels_over_library_windows(hip_device, fixture_library):
+    """the same kernels over per-sample library windows (svt_unit.libs; windows of 1-3 libraries, a window of 12, units in any
+    order, hint-less batches whose windows are read off the records): the one-tile window kernel's bytes, sample-major units with
+    site-major records included"""
+    from svtyper_amd import hip
+    lib = _hook()
+    lib.svt_debug_small_kind.argtypes = [C.c_int]
+    rng = np.random.default_rng(5)
+    multi = synth.make_multisample(300, 8, seed=21, mean_frags=30, sd_frags=15, min_frags=0, max_frags=90)
+    shuffled = synth.permute_units(multi, rng.permutation(multi.n_units)[: int(multi.n_units * 0.8)])
+    wide = synth.make_units(6_000, 31, [fixture_library] + [synth.normal_library(300.0 + 20 * i, 40.0 + 3 * i, seed=40 + i) for i in range(11)],
+                            svtype_mix=(0.5, 0.2, 0.2, 0.1), mean_frags=25, sd_frags=10, min_frags=0)
+    by_sample, _ = synth.to_sample_major(multi, 8)
+    nohint = ev.EvidenceBatch(multi.rec_offset, multi.units.copy(), multi.records, multi.libs, multi.split_weight, multi.disc_weight)
+    nohint.units["libs"] = 0
+    try:
+        for batch, order in ((multi, 0), (shuffled, 0), (wide, 0), (by_sample, 8), (nohint, 0)):
+            for flags in FLAGS:
+                lib.svt_debug_small_kind(1)
+                want, slots_stream = _resident(batch, hip_device, flags, order)
+                for kind in (3, 4):
+                    if kind == 3 and (flags & ev.FLAG_SSO_ASSOCIATION):
+                        continue        # (two lanes per unit: classic association only)
+                    lib.svt_debug_small_kind(kind)
+                    got, slots = _resident(batch, hip_device, flags, order)
+                    assert got == want, (batch.n_units, flags, kind, order)
+                    assert slots == slots_stream
+                lib.svt_debug_small_kind(0)
+                got, _ = _resident(batch, hip_device, flags, order)
+                assert got == want
+    finally:
+        lib.svt_debug_small_kind(0)
+
+
 def test_the_default_rule_picks_it_for_small_launches_only(hip_device, fixture_library):
     """one library, by units per CU (svtyper_hip.hip: wg_plan): <= 64 cooperative (tagged records in whole 64-unit tiles);
     above: 4 / 2 lanes per unit or the streaming kernel, whole 256-unit workgroups all of them; several libraries: the streaming

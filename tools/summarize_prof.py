@@ -120,14 +120,14 @@ try:
     bj = json.loads(line)
     # leg -> (kernel-name pattern of its launches, units, records, workload text)
     legs = {"stream_sso" if bj["config"]["association"] == "sso" else "stream":
-            (r"svt_stream_kernel<%s, 0, \d>" % ("true" if bj["config"]["association"] == "sso" else "false"),
+            (r"svt_stream_kernel<%s, 0, \d(, \d)?>" % ("true" if bj["config"]["association"] == "sso" else "false"),
              bj["config"]["units_per_gpu"], bj["config"]["records_per_gpu"], bj["config"]["workload"])}
     if bj["config"]["association"] != "sso" and "kernel_ms" in bj.get("sso", {}):
-        legs["stream_sso"] = (r"svt_stream_kernel<true, 0, \d>", bj["sso"]["units"], bj["config"]["records_per_gpu"], bj["sso"]["what"])
+        legs["stream_sso"] = (r"svt_stream_kernel<true, 0, \d(, \d)?>", bj["sso"]["units"], bj["config"]["records_per_gpu"], bj["sso"]["what"])
     if "kernel_ms" in bj.get("c5_multisample", {}):
         c5 = bj["c5_multisample"]
-        legs["c5_windows"] = (r"svt_stream_kernel<(true|false), 1, \d>", c5["units"], c5["records"], c5["what"])
-        legs["c5_hintless"] = (r"svt_stream_kernel<(true|false), 2, \d>", c5["units"], c5["records"], "the same batch without svt_unit.libs hints")
+        legs["c5_windows"] = (r"svt_stream_kernel<(true|false), 1, \d(, \d)?>", c5["units"], c5["records"], c5["what"])
+        legs["c5_hintless"] = (r"svt_stream_kernel<(true|false), 2, \d(, \d)?>", c5["units"], c5["records"], "the same batch without svt_unit.libs hints")
 
     def mean_of(sub, counter, pat):
         tot = cnt = 0
