@@ -18,6 +18,7 @@
 
 #include "../../include/svtyper_hip.h"
 #include "svt_error.h"
+#include "svt_fast_format.h"
 #include "svt_host_cpus.h"
 
 namespace {
@@ -41,6 +42,23 @@ inline void put_fmt(std::string& s, const char* fmt, double v)
     char buf[64];
     const int n = std::snprintf(buf, sizeof buf, fmt, v);
     s.append(buf, (size_t)std::max(0, std::min(n, (int)sizeof buf - 1)));
+}
+
+// '%.0f' / '%0.2f' / '%.2g' through svt_fast_format.h (exact integer arithmetic, the same digits), snprintf outside its range
+inline void put_fixed(std::string& s, double v, int decimals)
+{
+    char buf[64];
+    const int n = svt::format_fixed(buf, v, decimals);
+    if (n > 0) s.append(buf, (size_t)n);
+    else put_fmt(s, decimals == 0 ? "%.0f" : "%0.2f", v);
+}
+
+inline void put_g2(std::string& s, double v)
+{
+    char buf[64];
+    const int n = svt::format_g2(buf, v);
+    if (n > 0) s.append(buf, (size_t)n);
+    else put_fmt(s, "%.2g", v);
 }
 
 // SQ of a called unit from its three log10 likelihoods with the HOST libm -- the very calls CPython makes for
@@ -75,18 +93,18 @@ void put_field(std::string& s, const svt_result& r, uint8_t field, bool skipped_
         if (gt >= 0) put_int(s, r.counts[SVT_CNT_GQ]); else s += '.';
         return;
     case SVT_FMT_SQ:
-        if (gt >= 0) put_fmt(s, "%0.2f", r.sq); else s += '.';
+        if (gt >= 0) put_fixed(s, r.sq, 2); else s += '.';
         return;
     case SVT_FMT_GL:
         if (blank) { s += '.'; return; }
-        put_fmt(s, "%.0f", r.gl[0]); s += ',';
-        put_fmt(s, "%.0f", r.gl[1]); s += ',';
-        put_fmt(s, "%.0f", r.gl[2]);
+        put_fixed(s, r.gl[0], 0); s += ',';
+        put_fixed(s, r.gl[1], 0); s += ',';
+        put_fixed(s, r.gl[2], 0);
         return;
     case SVT_FMT_AB: {
         const int64_t qr = blank ? 0 : r.counts[SVT_CNT_QR], qa = blank ? 0 : r.counts[SVT_CNT_QA];
         if (blank || qr + qa == 0) { s += '.'; return; }
-        put_fmt(s, "%.2g", (double)qa / (double)(qr + qa));            // classic.py:466-469
+        put_g2(s, (double)qa / (double)(qr + qa));            // classic.py:466-469
         return;
     }
     default:
@@ -106,7 +124,7 @@ static int svt_format_results_impl(const svt_result* res, uint64_t n_units, cons
     *offsets_out = nullptr;
     for (uint32_t k = 0; k < n_fields; ++k)
         if (fields[k] >= SVT_N_FORMAT_FIELDS && fields[k] != SVT_FMT_ABSENT) return fail(SVT_ERR_INVALID, "unknown FORMAT field code");
-    const unsigned nt = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(svt::usable_cpus(), n_units / 4096 + 1));
+    const unsigned nt = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(svt::usable_cpus(), n_units / 2048 + 1));
     std::vector<std::string> part(nt);
     std::vector<std::vector<uint32_t>> len(nt);
     auto work = [&](unsigned t) {

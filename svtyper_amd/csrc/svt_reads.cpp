@@ -96,13 +96,62 @@ static const FastInflate& fast_inflate()
     return f;
 }
 
+// One inflated BGZF block: immutable once it is published, so readers on several threads can hold it.
+struct BlockData {
+    std::vector<uint8_t> data;
+    uint64_t next = 0;         // compressed offset of the block behind it (== its own offset: end of data / unusable block)
+};
+typedef std::shared_ptr<const BlockData> BlockRef;
+
+// Inflated blocks shared by the worker threads of ONE svt_bam_summarise call.  Workers take runs of neighbouring units,
+// and a worker that starts a run walks up to its first window through the blocks in front of it (a window is reached from
+// the start of its 16-kb bin: seven 64-KiB blocks at 30x on average) -- blocks the worker of the run before inflates too,
+// for its own last units.  Measured on 290 whole-genome-like sites: 24 % (8 workers) to 54 % (15) of all inflate calls were
+// such repeats, and inflate is three quarters of the reader's time there.  A block is looked up here after the reader's own
+// slots missed and published after it was inflated: one short critical section per 64 KiB of records.  64 shards x 16 ways
+// = 1 024 blocks (64 MiB) at most, first-in-first-out per shard; a block a reader still holds outlives its eviction.
+class SharedBlocks {
+public:
+    BlockRef find(uint64_t coff)
+    {
+        Shard& sh = shard(coff);
+        std::lock_guard<std::mutex> g(sh.lock);
+        for (int i = 0; i < kWays; ++i)
+            if (sh.coff[i] == coff) return sh.block[i];
+        return BlockRef();
+    }
+    void publish(uint64_t coff, const BlockRef& b)
+    {
+        Shard& sh = shard(coff);
+        std::lock_guard<std::mutex> g(sh.lock);
+        for (int i = 0; i < kWays; ++i)
+            if (sh.coff[i] == coff) return;                      // another reader was faster: keep the first copy
+        sh.coff[sh.clock] = coff;
+        sh.block[sh.clock] = b;
+        sh.clock = (sh.clock + 1) % kWays;
+    }
+
+private:
+    static constexpr int kShards = 64, kWays = 16;
+    struct Shard {
+        std::mutex lock;
+        uint64_t coff[kWays];
+        BlockRef block[kWays];
+        int clock = 0;
+        Shard() { for (auto& c : coff) c = ~0ull; }
+    };
+    Shard& shard(uint64_t coff) { return shards_[(coff * 0x9E3779B97F4A7C15ull) >> 58]; }
+    Shard shards_[kShards];
+};
+
 class Bgzf {
 public:
-    explicit Bgzf(const FileMap& file) : file_(file)
+    explicit Bgzf(const FileMap& file, SharedBlocks* shared = nullptr) : file_(file), shared_(shared), empty_(std::make_shared<BlockData>())
     {
         std::memset(&zs_, 0, sizeof zs_);
         if (fast_inflate().usable()) fast_ = fast_inflate().alloc();
         if (!fast_) zs_ok_ = inflateInit2(&zs_, -15) == Z_OK;   // one inflate state per reader, reset per block
+        block_ = empty_.get();
     }
     ~Bgzf()
     {
@@ -134,7 +183,7 @@ public:
             const size_t avail = block_->data.size() - std::min(uoff_, block_->data.size());
             if (avail == 0) {
                 const uint64_t next = block_->next;
-                if (block_ != &empty_ && next == coff_) break;
+                if (block_ != empty_.get() && next == coff_) break;
                 if (!load(next)) break;
                 uoff_ = 0;
                 continue;
@@ -154,7 +203,7 @@ public:
     {
         if (uoff_ >= block_->data.size()) {
             const uint64_t next = block_->next;
-            if (block_ != &empty_ && next == coff_) return nullptr;
+            if (block_ != empty_.get() && next == coff_) return nullptr;
             if (!load(next)) return nullptr;
             uoff_ = 0;
         }
@@ -163,45 +212,55 @@ public:
     void advance(size_t n) { uoff_ += n; }   // over bytes contiguous() has just vouched for
 
 private:
-    struct Block { std::vector<uint8_t> data; uint64_t next = 0; uint64_t coff = ~0ull; };
-    // a few recently inflated blocks: the two windows of a unit and its neighbours walk forward through
-    // the same blocks.  Fixed slots whose buffers are reused -- no allocation once they are warm.
-    static constexpr int kSlots = 32;
-    Block* slot_for(uint64_t coff)
+    // Recently used blocks of this reader: the two windows of a unit and its neighbours walk forward through the same
+    // blocks, and a list of sites often comes back to a region (both ends of a large event, overlapping calls, the same
+    // targets again).  kSlots references, 8 MiB of blocks at most; the offsets sit in an array of their own: a look-up is
+    // one pass over 1 KiB.  (32 slots: a cycle over ~50 blocks -- the fixture's 211 sites, repeated -- missed on every
+    // third site, a third of the reader's time.)
+    static constexpr int kSlots = 128;
+    int slot_for(uint64_t coff) const
     {
-        for (int i = 0; i < kSlots; ++i)
-            if (slots_[i].coff == coff) return &slots_[i];
-        return nullptr;
+        for (int i = 0; i < n_slots_; ++i)
+            if (coffs_[i] == coff) return i;
+        return -1;
     }
-    Block* victim()
+    bool use(uint64_t coff, const BlockRef& b)           // make `b` the current block, remembered under `coff`
     {
-        Block* b = &slots_[clock_];
-        clock_ = (clock_ + 1) % kSlots;
-        b->data.clear();
-        return b;
+        int i;
+        if (n_slots_ < kSlots) i = n_slots_++;
+        else {
+            i = clock_;
+            clock_ = (clock_ + 1) % kSlots;
+        }
+        coffs_[i] = coff;
+        slots_[i] = b;
+        block_ = b.get();
+        coff_ = coff;
+        return !block_->data.empty() || block_->next > coff;
     }
-    bool park(Block* b, uint64_t coff, bool is_bad)
+    bool park(uint64_t coff, bool is_bad)                // end of file / unusable block: an empty block that is its own successor
     {
         if (is_bad) bad_ = true;
-        b->coff = coff;
+        auto b = std::make_shared<BlockData>();
         b->next = coff;
-        block_ = b;
-        coff_ = coff;
+        use(coff, b);
         return false;
     }
     bool load(uint64_t coff)
     {
-        if (Block* hit = slot_for(coff)) {
-            block_ = hit;
+        const int hit = slot_for(coff);
+        if (hit >= 0) {
+            block_ = slots_[hit].get();
             coff_ = coff;
             return !block_->data.empty() || block_->next > coff;
         }
-        Block* b = victim();
-        if (coff + 18 > file_.size) return park(b, coff, false);          // end of file
+        if (shared_)
+            if (BlockRef b = shared_->find(coff)) return use(coff, b);
+        if (coff + 18 > file_.size) return park(coff, false);          // end of file
         const uint8_t* hdr = file_.data + coff;
-        if (hdr[0] != 31 || hdr[1] != 139) return park(b, coff, true);
+        if (hdr[0] != 31 || hdr[1] != 139) return park(coff, true);
         const size_t xlen = hdr[10] | (hdr[11] << 8);
-        if (coff + 12 + xlen > file_.size) return park(b, coff, true);
+        if (coff + 12 + xlen > file_.size) return park(coff, true);
         int bsize = -1;
         for (size_t i = 0; i + 4 <= xlen;) {
             const uint8_t* x = hdr + 12 + i;
@@ -209,42 +268,47 @@ private:
             if (x[0] == 66 && x[1] == 67 && i + 6 <= xlen) bsize = x[4] | (x[5] << 8);
             i += 4 + slen;
         }
-        if (bsize < 0 || coff + (uint64_t)bsize + 1 > file_.size) return park(b, coff, true);
+        if (bsize < 0 || coff + (uint64_t)bsize + 1 > file_.size) return park(coff, true);
         const int clen = bsize - (int)xlen - 19;
-        if (clen < 0) return park(b, coff, true);
+        if (clen < 0) return park(coff, true);
         const uint8_t* cdata = hdr + 12 + xlen;
         const uint8_t* tail = cdata + clen;
         const uint32_t isize = tail[4] | (tail[5] << 8) | (tail[6] << 16) | ((uint32_t)tail[7] << 24);
-        if (isize > 65536u) return park(b, coff, true);     // a BGZF block inflates to at most 64 KiB
+        if (isize > 65536u) return park(coff, true);     // a BGZF block inflates to at most 64 KiB
+        auto b = std::make_shared<BlockData>();
         b->data.resize(isize);
+        bool inflated = true;
         if (isize && fast_) {
             // exactly isize bytes or an error (a null "actual size" pointer makes a short stream a failure)
-            if (fast_inflate().decompress(fast_, cdata, (size_t)clen, b->data.data(), b->data.size(), nullptr) != 0) bad_ = true;
+            if (fast_inflate().decompress(fast_, cdata, (size_t)clen, b->data.data(), b->data.size(), nullptr) != 0) inflated = false;
         } else if (isize) {
-            if (inflateReset(&zs_) != Z_OK) bad_ = true;
+            if (inflateReset(&zs_) != Z_OK) inflated = false;
             else {
                 zs_.next_in = const_cast<Bytef*>(cdata);
                 zs_.avail_in = (uInt)clen;
                 zs_.next_out = b->data.data();
                 zs_.avail_out = (uInt)b->data.size();
-                if (inflate(&zs_, Z_FINISH) != Z_STREAM_END) bad_ = true;
+                if (inflate(&zs_, Z_FINISH) != Z_STREAM_END) inflated = false;
             }
         }
-        b->coff = coff;
+        if (!inflated) bad_ = true;                      // (its bytes stay readable, as before: the caller sees failed())
         b->next = coff + (uint64_t)bsize + 1;
-        block_ = b;
-        coff_ = coff;
+        if (shared_ && inflated) shared_->publish(coff, b);
+        use(coff, b);
         return true;
     }
 
     const FileMap& file_;
+    SharedBlocks* shared_;
     z_stream zs_;
     bool zs_ok_ = false;
     void* fast_ = nullptr;   // libdeflate decompressor of this reader
-    Block slots_[kSlots];
+    BlockRef slots_[kSlots];
+    uint64_t coffs_[kSlots];
+    int n_slots_ = 0;
     int clock_ = 0;
-    Block empty_;
-    Block* block_ = &empty_;
+    std::shared_ptr<BlockData> empty_;
+    const BlockData* block_ = nullptr;
     uint64_t coff_ = 0;
     size_t uoff_ = 0;
     bool bad_ = false;
@@ -1092,15 +1156,30 @@ static int svt_bam_summarise_impl(const svt_bam* bam, const svt_summarise_args* 
     // VCF while this runs: pipeline.ChunkPipeline)
     unsigned nt = args->n_threads > 0 ? (unsigned)args->n_threads : std::max(1u, svt::usable_cpus() - 1u);
     nt = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(nt ? nt : 1, n ? n : 1));
-    // units per grab: 16 keeps neighbours on one worker, fewer when the batch is too small to feed every worker that way
-    const uint64_t kUnitsPerGrab = std::max<uint64_t>(1, std::min<uint64_t>(16, n / (4ull * nt)));
+    // Consecutive units stay on one worker: neighbouring sites share BGZF blocks, and the worker's own slots serve them
+    // without a lock (what a worker re-reads at the start of a run comes from SharedBlocks).  A grab is a long run while
+    // there is plenty left and shrinks towards the end, where balance matters: half of an even share of what remains,
+    // between 4 and 64 units (guided self-scheduling).
     std::atomic<uint64_t> next(0);
+    auto claim = [&](uint64_t& lo, uint64_t& hi) {
+        uint64_t at = next.load(std::memory_order_relaxed);
+        for (;;) {
+            if (at >= n) return false;
+            const uint64_t take = std::min<uint64_t>(n - at, std::max<uint64_t>(4, std::min<uint64_t>(64, (n - at) / (2ull * nt))));
+            if (next.compare_exchange_weak(at, at + take, std::memory_order_relaxed)) {
+                lo = at;
+                hi = at + take;
+                return true;
+            }
+        }
+    };
     std::atomic<int> first_rc(SVT_OK);
     std::mutex err_lock;
     std::string first_err;
     std::vector<std::unique_ptr<SummaryArena>> arenas(nt);
+    const std::unique_ptr<SharedBlocks> shared_blocks(new SharedBlocks());
     auto worker = [&](unsigned t) {
-        Bgzf z(bam->file);
+        Bgzf z(bam->file, shared_blocks.get());
         std::vector<uint8_t> buf;
         UnitOut unit;
         Workspace ws;
@@ -1111,9 +1190,9 @@ static int svt_bam_summarise_impl(const svt_bam* bam, const svt_summarise_args* 
             return;
         }
         for (;;) {   // consecutive units stay on one thread: neighbouring sites share BGZF blocks (and its cache)
-            const uint64_t u0 = next.fetch_add(kUnitsPerGrab);
-            if (u0 >= n) return;
-            for (uint64_t u = u0; u < std::min(n, u0 + kUnitsPerGrab); ++u) {
+            uint64_t u0, u1;
+            if (!claim(u0, u1)) return;
+            for (uint64_t u = u0; u < u1; ++u) {
                 if (first_rc.load(std::memory_order_relaxed) != SVT_OK) return;
                 std::string err;
                 int rc = process_unit(*bam, z, buf, *args, rg_lib, u, ws, unit, err);

@@ -83,3 +83,67 @@ def test_packed_encoder_under_thread_sanitizer(tmp_path):
     assert slots == of > 0
     assert ranged[1].startswith("ranged 1 rc -7 units 4096 "), ranged
     assert len(lines) == 5 and all(" rc 0 " in l for l in lines[:3]) and all("rec_offset not monotone" in l for l in lines[3:]), lines
+
+
+def test_native_reader_under_thread_sanitizer(tmp_path):
+    """svt_reads.cpp: the workers of svt_bam_summarise claim runs of units from one counter and share inflated BGZF blocks
+    (SharedBlocks: a mutex per shard, blocks immutable once published).  tests/native/tsan_reads_main.cpp runs the fixture's
+    sites (x 3, so that every block is wanted by several workers) with 1 and 8 workers under -fsanitize=thread; the summaries
+    must be the same bytes whatever the number of workers."""
+    import json
+    import shutil
+    import numpy as np
+    if not shutil.which("g++"):
+        pytest.skip("no g++")
+    exe = str(tmp_path / "tsan_reads")
+    r = subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=thread", "-I", CSRC, "-I", os.path.join(ROOT, "include"),
+                        os.path.join(ROOT, "tests", "native", "tsan_reads_main.cpp"), os.path.join(CSRC, "svt_reads.cpp"), "-o", exe,
+                        "-lz", "-ldl", "-lpthread"], capture_output=True, text=True, timeout=600)
+    if r.returncode != 0 and "libtsan" in r.stderr.lower():
+        pytest.skip("this g++ has no ThreadSanitizer runtime")
+    assert r.returncode == 0, r.stderr[-3000:]
+    # the units exactly as NativeUnitCollector hands them to the ctypes layer
+    sys.path.insert(0, ROOT)
+    from svtyper_amd import bam as pybam, library, native_reads as nr, pipeline
+    from svtyper_amd.vcf import Variant, Vcf
+    data = os.path.join(ROOT, "tests", "data")
+    bam_path = os.path.join(data, "NA12878.target_loci.sorted.bam")
+    vcf, sites = Vcf(), []
+    with open(os.path.join(data, "example.vcf")) as f:
+        lines = f.readlines()
+    vcf.add_header([l for l in lines if l.startswith("##")])
+    for line in lines:
+        if not line.startswith("#"):
+            v = Variant(line.rstrip().split("\t"), vcf)
+            bp = vcf.get_variant_breakpoints(v, 1e10) if v.has_svtype() and v.is_valid_svtype() else None
+            if bp is not None:
+                sites.append(bp)
+    with open(os.path.join(data, "NA12878.bam.json")) as f:
+        sample = library.Sample.from_lib_info(pybam.AlignmentFile(bam_path), json.load(f), 1e-3)
+
+    class Capture:
+        """stands where nr.NativeBam stands: keeps what summarise() is handed"""
+        filename, lengths = bam_path, pybam.AlignmentFile(bam_path).lengths
+        gettid = staticmethod(pybam.AlignmentFile(bam_path).gettid)
+
+        def summarise(self, win, bps, rgs, idx, max_reads, mode, n_threads):
+            win.tofile(str(tmp_path / "win.bin"))
+            bps.tofile(str(tmp_path / "bps.bin"))
+            self.rgs = ["%s=%d" % (rg, lib) for rg, lib in zip(rgs, idx)]
+            raise StopIteration
+
+    cap = Capture()
+    coll = pipeline.NativeUnitCollector([sample], [cap], 1.0, 1.0, 20, nr.COUNT_SSO, 1000)
+    for _ in range(3):
+        for bp in sites:
+            coll.add_site(bp)
+    engine = type("E", (), {"genotype_fragments": lambda self, *a, **k: None})()
+    with pytest.raises(StopIteration):
+        coll.run(engine, 0)
+    r = subprocess.run([exe, bam_path, str(tmp_path / "win.bin"), str(tmp_path / "bps.bin")] + cap.rgs,
+                       env=dict(os.environ, TSAN_OPTIONS="halt_on_error=1"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "ThreadSanitizer" not in r.stderr, (r.stdout[-1000:], r.stderr[-3000:])
+    lines = r.stdout.strip().splitlines()
+    assert len(lines) == 3 and lines[0].startswith("threads 1 units %d " % (3 * len(sites))), lines
+    assert len({l.split(" units ")[1] for l in lines}) == 1, lines          # same fragments, same bytes
+    assert int(lines[0].split(" fragments ")[1].split()[0]) > 10_000
