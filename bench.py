@@ -497,14 +497,16 @@ def real_data_leg(device: int) -> dict:
                 for bp in sites:
                     coll.add_site(bp)
             t0 = time.perf_counter()
-            res = coll.run(eng, ev.FLAG_SSO_ASSOCIATION)
+            job = coll.take(eng, ev.FLAG_SSO_ASSOCIATION)     # (the sites' fields -> arrays, Python)
+            t_prep = time.perf_counter()
+            res = job()
             t1 = time.perf_counter()
             cols = hip.format_results(res, list(pipeline.SVTYPER_FORMAT_KEYS), False)
             t2 = time.perf_counter()
             dev = sum(eng.t.values())
             leg = {"sites": len(sites) * repeat, "fragments": eng.fragments, "wall_ms": (t2 - t0) * 1e3,
                    "sites_per_s": len(sites) * repeat / (t2 - t0),
-                   "stage_ms": {"inflate_fetch_summarise_host": (t1 - t0 - dev) * 1e3,
+                   "stage_ms": {"site_arrays_python": (t_prep - t0) * 1e3, "inflate_fetch_summarise_host": (t1 - t_prep - dev) * 1e3,
                                 "h2d_plus_geometry_kernel": eng.t["create_h2d_geometry"] * 1e3, "genotype_pass": eng.t["pass"] * 1e3,
                                 "results_d2h": eng.t["results_d2h"] * 1e3, "format_columns_host": (t2 - t1) * 1e3},
                    "h2d_bytes": int(eng.fragments * 128), "fragments_per_site": eng.fragments / max(1, len(sites) * repeat),
@@ -516,7 +518,7 @@ def real_data_leg(device: int) -> dict:
         # formats the sample columns of chunk k-1 -- the wall time is the longer chain, not the sum of the stages
         try:
             all_sites = [bp for _r in range(repeat) for bp in sites]
-            per = max(256, -(-len(all_sites) // 3))     # (a dozen chunks lost 15 %: every chunk starts the reader's thread pool and a device batch of its own)
+            per = max(256, -(-len(all_sites) // 6))     # (every chunk starts the reader's thread pool and a device batch of its own)
             over = None
             for _ in range(2):
                 eng = Timed()
@@ -543,7 +545,8 @@ def real_data_leg(device: int) -> dict:
             assert over["columns"] == best["columns"]
             best.update(over)
             best["overlap_note"] = ("`stage_ms` / `wall_ms`: one chunk, the stages one after the other; `overlapped_*`: the same sites in %d chunks through "
-                                    "pipeline.ChunkPipeline (reader + device stages of chunk k on a worker thread, text of chunk k-1 on the caller's)" % over["chunks"])
+                                    "pipeline.ChunkPipeline (two chunks in flight: the reader of chunk k+1 while chunk k is on the device; the arrays of the next chunk "
+                                    "and the text of an earlier one on the caller's thread)" % over["chunks"])
         except Exception as e:
             best["overlapped_error"] = repr(e)
         return best

@@ -63,8 +63,9 @@ typedef struct svt_summarise_args {
 } svt_summarise_args;
 
 typedef struct svt_summaries {
-    uint64_t* frag_offset;    /* n_units + 1, malloc'ed */
-    svt_fragment* fragments;  /* frag_offset[n_units], malloc'ed */
+    uint64_t* frag_offset;    /* n_units + 1 */
+    svt_fragment* fragments;  /* frag_offset[n_units]; owned by the library (a large one comes from its pool of
+                                 huge-page mappings): release ONLY through svt_summaries_free */
     uint8_t* skipped;         /* n_units: 1 = too many reads (unit has no fragments) */
 } svt_summaries;
 

@@ -878,16 +878,90 @@ struct UnitSpan {                      // where a finished unit's summaries wait
     bool skipped = false;
 };
 
-// Anonymous mapping advised for transparent huge pages: the summaries are written once and read
-// once, so what they cost is page faults -- with 4 KB pages and a few hundred threads those contend
-// in the kernel long before the cores are busy.
-void* map_buffer(size_t bytes)
-{
-    void* p = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
-    if (p == MAP_FAILED) return nullptr;
-    madvise(p, bytes, MADV_HUGEPAGE);
-    return p;
-}
+// Large host buffers of the summariser (the workers' arenas, the flat summary array): anonymous mappings advised for
+// transparent huge pages -- the summaries are written once and read once, so what they cost is page faults and, when they
+// go, the unmapping: on the 2 x EPYC 9575F box 17 ms to unmap the arenas of 2.1 M summaries and as much again for the
+// flat array, a third of the call.  Mappings therefore go back to a process-wide pool (at most SVT_READER_POOL_MB, default
+// 1024, of idle memory; 0 = unmap at once) and the next call starts on pages that are already there.
+class BufferPool {
+public:
+    static BufferPool& get()
+    {
+        static BufferPool* pool = new BufferPool();      // (never destroyed: buffers may be returned during process exit)
+        return *pool;
+    }
+    // a mapping of at least `bytes` (its real size goes to *cap), nullptr when the system has none
+    void* acquire(size_t bytes, size_t* cap)
+    {
+        const size_t want = (std::max<size_t>(bytes, 1) + kGrain - 1) / kGrain * kGrain;
+        {
+            std::lock_guard<std::mutex> g(lock_);
+            size_t best = idle_.size();
+            for (size_t i = 0; i < idle_.size(); ++i)    // smallest idle mapping that fits and is not more than twice too big
+                if (idle_[i].second >= want && idle_[i].second <= 2 * want && (best == idle_.size() || idle_[i].second < idle_[best].second)) best = i;
+            if (best != idle_.size()) {
+                void* p = idle_[best].first;
+                *cap = idle_[best].second;
+                idle_bytes_ -= *cap;
+                idle_.erase(idle_.begin() + (long)best);
+                return p;
+            }
+        }
+        void* p = mmap(nullptr, want, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        if (p == MAP_FAILED) return nullptr;
+        madvise(p, want, MADV_HUGEPAGE);
+        *cap = want;
+        return p;
+    }
+    void release(void* p, size_t cap)
+    {
+        if (!p) return;
+        {
+            std::lock_guard<std::mutex> g(lock_);
+            if (idle_bytes_ + cap <= limit_) {
+                idle_.emplace_back(p, cap);
+                idle_bytes_ += cap;
+                return;
+            }
+        }
+        munmap(p, cap);
+    }
+    // the flat array handed to the caller: its size is remembered here so that svt_summaries_free needs only the pointer
+    void* acquire_tracked(size_t bytes)
+    {
+        size_t cap = 0;
+        void* p = acquire(bytes, &cap);
+        if (p) {
+            std::lock_guard<std::mutex> g(lock_);
+            lent_[p] = cap;
+        }
+        return p;
+    }
+    bool release_tracked(void* p)
+    {
+        size_t cap = 0;
+        {
+            std::lock_guard<std::mutex> g(lock_);
+            auto it = lent_.find(p);
+            if (it == lent_.end()) return false;
+            cap = it->second;
+            lent_.erase(it);
+        }
+        release(p, cap);
+        return true;
+    }
+
+private:
+    BufferPool()
+    {
+        if (const char* e = std::getenv("SVT_READER_POOL_MB")) limit_ = (size_t)std::max(0ll, std::atoll(e)) << 20;
+    }
+    static constexpr size_t kGrain = 16u << 20;          // eight huge pages: arenas are exactly one grain
+    std::mutex lock_;
+    std::vector<std::pair<void*, size_t>> idle_;
+    std::unordered_map<void*, size_t> lent_;
+    size_t idle_bytes_ = 0, limit_ = (size_t)1024 << 20;
+};
 
 // append-only store of one worker: units are copied in whole, never split across chunks
 class SummaryArena {
@@ -895,15 +969,14 @@ public:
     SummaryArena() = default;
     SummaryArena(const SummaryArena&) = delete;
     SummaryArena& operator=(const SummaryArena&) = delete;
-    ~SummaryArena() { for (auto& c : chunks_) munmap(c.first, c.second); }
+    ~SummaryArena() { for (auto& c : chunks_) BufferPool::get().release(c.first, c.second); }
     const svt_fragment* append(const std::vector<svt_fragment>& v)
     {
         const size_t bytes = v.size() * sizeof(svt_fragment);
         if (bytes == 0) return nullptr;
         if (used_ + bytes > cap_) {
-            const size_t want = std::max(bytes, kChunkBytes);
-            const size_t size = (want + kHuge - 1) / kHuge * kHuge;
-            void* p = map_buffer(size);
+            size_t size = 0;
+            void* p = BufferPool::get().acquire(std::max(bytes, kChunkBytes), &size);
             if (!p) return nullptr;
             chunks_.emplace_back(p, size);
             cap_ = size;
@@ -916,7 +989,7 @@ public:
     }
 
 private:
-    static constexpr size_t kHuge = 2u << 20, kChunkBytes = 16u << 20;
+    static constexpr size_t kChunkBytes = 16u << 20;
     std::vector<std::pair<void*, size_t>> chunks_;
     size_t cap_ = 0, used_ = 0;
 };
@@ -1217,12 +1290,9 @@ static int svt_bam_summarise_impl(const svt_bam* bam, const svt_summarise_args* 
     uint64_t total = 0;
     for (const auto& o : outs) total += o.count;
     out->frag_offset = static_cast<uint64_t*>(std::malloc((n + 1) * sizeof(uint64_t)));
-    {   // 2 MB aligned + huge-page advice (still free()-able): 1.4 GB for 10 M summaries
+    {   // from the pool of huge-page mappings when it is large (1.4 GB for 10 M summaries), malloc otherwise
         const size_t bytes = std::max<uint64_t>(total, 1) * sizeof(svt_fragment);
-        void* p = nullptr;
-        if (bytes >= (4u << 20) && posix_memalign(&p, 2u << 20, bytes) == 0) madvise(p, bytes, MADV_HUGEPAGE);
-        else p = std::malloc(bytes);
-        out->fragments = static_cast<svt_fragment*>(p);
+        out->fragments = static_cast<svt_fragment*>(bytes >= (4u << 20) ? BufferPool::get().acquire_tracked(bytes) : std::malloc(bytes));
     }
     out->skipped = static_cast<uint8_t*>(std::malloc(std::max<uint64_t>(n, 1)));
     if (!out->frag_offset || !out->fragments || !out->skipped) {
@@ -1265,7 +1335,7 @@ void svt_summaries_free(svt_summaries* s)
 {
     if (!s) return;
     std::free(s->frag_offset);
-    std::free(s->fragments);
+    if (s->fragments && !BufferPool::get().release_tracked(s->fragments)) std::free(s->fragments);
     std::free(s->skipped);
     s->frag_offset = nullptr;
     s->fragments = nullptr;

@@ -14,6 +14,9 @@ through the same seam.
 from __future__ import annotations
 
 import os
+import sys
+import threading
+import time
 from itertools import chain
 from operator import itemgetter, methodcaller
 
@@ -30,6 +33,7 @@ Engine = Callable[[EvidenceBatch, int], Results]
 Z = 3            # fetch / straddle flank in standard deviations (classic.py:183)
 SPLIT_SLOP = 3   # slop around the breakpoint for split reads (classic.py:184)
 MIN_LIB_PREVALENCE = 1e-3
+_READER_TURN = threading.Lock()   # svt_bam_summarise starts a pool of threads that fills the host: one call at a time
 
 
 class HipEngine:
@@ -184,27 +188,31 @@ class NativeUnitCollector:
         return len(self.sites) * len(self.samples)
 
     def take(self, engine: Engine, flags: int, site_quals=None):
-        """Detach the sites recorded so far as a job (see UnitCollector.take)."""
+        """Detach the sites recorded so far as a job (see UnitCollector.take).  The sites' fields become arrays HERE, on the
+        caller's thread (Python: it holds the GIL) -- under ChunkPipeline that is while the reader and the device work on
+        the chunk before; the job itself is C++ and HIP calls only."""
         sites, self.sites = self.sites, []
         kw = _site_qual_kw(engine, len(self.samples), site_quals)
-        return lambda: self._run_sites(sites, engine, flags, kw)
+        if sites and not hasattr(engine, "genotype_fragments"):
+            raise TypeError("reader='native' needs an engine with genotype_fragments (the HIP engine)")
+        t_begin = time.perf_counter()
+        prepared = self._prepare(sites)
+        prep_s = time.perf_counter() - t_begin
+        return lambda: self._run_prepared(prepared, engine, flags, kw, prep_s)
 
     def run(self, engine: Engine, flags: int) -> Results:
         return self.take(engine, flags)()
 
-    def _run_sites(self, sites: List[dict], engine: Engine, flags: int, kw: dict) -> Results:
+    def _prepare(self, sites: List[dict]):
+        """Per sample the (svt_breakpoint[], svt_fetch_unit[]) arrays of the sites."""
         import numpy as np
-        from .geometry import FragmentBatch, breakpoint_record
+        from .geometry import BREAKPOINT_DTYPE
         from .native_reads import FETCH_DTYPE
-        n_samp = len(self.samples)
         n_sites = len(sites)
         if n_sites == 0:
-            return Results.empty(0)
-        if not hasattr(engine, "genotype_fragments"):
-            raise TypeError("reader='native' needs an engine with genotype_fragments (the HIP engine)")
-        per_sample = []
-        # the sites' fields as arrays: C-level iteration (itemgetter + fromiter) instead of a comprehension per field --
-        # 1.6 us per site the first way, 0.5 this way, and at a few hundred thousand sites per second that is the reader's budget
+            return []
+        # C-level iteration (itemgetter + fromiter) instead of a comprehension per field: 1.6 us per site the first way,
+        # 0.8 this way -- at a few hundred thousand sites per second that is a share of the reader's budget
         get = lambda key, seq: map(itemgetter(key), seq)
         A = list(get("A", sites))
         B = list(get("B", sites))
@@ -216,12 +224,12 @@ class NativeUnitCollector:
             ci[:, col:col + 2] = np.fromiter(chain.from_iterable(get("ci", side)), np.int64, 2 * n_sites).reshape(n_sites, 2)
         rev = np.fromiter(get("is_reverse", A), np.bool_, n_sites).astype(np.uint8)
         rev |= np.fromiter(get("is_reverse", B), np.bool_, n_sites).astype(np.uint8) << 1
-        svtypes = list(get("svtype", sites))
-        svt = np.fromiter(map(ev.SVTYPE_CODE.__getitem__, svtypes), np.uint8, n_sites)
+        svt = np.fromiter(map(ev.SVTYPE_CODE.__getitem__, get("svtype", sites)), np.uint8, n_sites)
         vlen = np.fromiter(map(methodcaller("get", "var_length", 0), sites), np.int64, n_sites)
         vlen[svt != ev.SVTYPE_CODE["DEL"]] = 0
         chrom_a, chrom_b = list(get("chrom", A)), list(get("chrom", B))
         clip = lambda x: np.clip(x, -2**31, 2**31 - 1)
+        prepared = []
         for k, (sample, nbam) in enumerate(zip(self.samples, self.bams)):
             tid_of = {c: nbam.gettid(c) for c in set(chrom_a).union(chrom_b)}.__getitem__
             tid = np.empty((n_sites, 2), np.int64)
@@ -230,7 +238,6 @@ class NativeUnitCollector:
             if (tid < 0).any():
                 bad = sites[int(np.nonzero((tid < 0).any(axis=1))[0][0])]
                 raise KeyError("chromosome of variant %s is not in %s" % (bad.get("id"), nbam.filename))
-            from .geometry import BREAKPOINT_DTYPE
             bps = np.zeros(n_sites, BREAKPOINT_DTYPE)
             bps["tid_a"], bps["tid_b"] = tid[:, 0], tid[:, 1]
             bps["pos_a"], bps["pos_b"] = clip(pos[:, 0]), clip(pos[:, 1])
@@ -248,13 +255,33 @@ class NativeUnitCollector:
             win["tid_a"], win["tid_b"] = tid[:, 0], tid[:, 1]
             win["lo_a"], win["lo_b"] = lo[:, 0].astype(np.int64), lo[:, 1].astype(np.int64)
             win["hi_a"], win["hi_b"] = hi[:, 0].astype(np.int64), hi[:, 1].astype(np.int64)
+            prepared.append((bps, win))
+        return prepared
+
+    def _run_prepared(self, prepared, engine: Engine, flags: int, kw: dict, prep_s: float = 0.0) -> Results:
+        import numpy as np
+        from .geometry import FragmentBatch
+        n_samp = len(self.samples)
+        if not prepared:
+            return Results.empty(0)
+        per_sample = []
+        trace = os.environ.get("SVT_TRACE") is not None
+        t_begin = time.perf_counter()
+        lap = (lambda what: sys.stderr.write("[NativeUnitCollector] %-22s %8.1f ms\n" % (what, (time.perf_counter() - t_begin) * 1e3))) if trace else (lambda what: None)
+        if trace:
+            sys.stderr.write("[NativeUnitCollector] %-22s %8.1f ms (at take(), on the caller's thread)\n" % ("site arrays (python)", prep_s * 1e3))
+        for k, (nbam, (bps, win)) in enumerate(zip(self.bams, prepared)):
             rgs, idx = self.rg_tables[k]
-            off, frags, skipped = nbam.summarise(win, bps, rgs, idx, self.max_reads, self.count_mode, self.n_threads)
+            with _READER_TURN:      # (two chunks in flight under ChunkPipeline: one reads, the other is on the device)
+                off, frags, skipped = nbam.summarise(win, bps, rgs, idx, self.max_reads, self.count_mode, self.n_threads)
+            lap("svt_bam_summarise")
             bps["flags"] |= np.where(skipped != 0, 4, 0).astype(np.uint8)   # SVT_BP_SKIP
             fb = FragmentBatch(off, bps, frags, self.lib_tables, self.split_weight, self.disc_weight, self.min_aligned,
                                SPLIT_SLOP)
             if n_samp == 1:
-                return engine.genotype_fragments(fb, flags, **kw)
+                res = engine.genotype_fragments(fb, flags, **kw)
+                lap("device stages")
+                return res
             # one device batch per sample: the summaries go to the GPU as the reader produced them (no
             # re-interleaving of ~13 KB per unit on the host)
             per_sample.append(engine.genotype_fragments(fb, flags).rec)
@@ -303,32 +330,36 @@ class SampleColumnWriter:
 
 
 class ChunkPipeline:
-    """Chunk-level double buffering of the drivers (svtyper/singlesample.py:710-762 re-cast): the job of
-    chunk k -- C++ fetch/summarise or packing, H2D, kernels, D2H, all outside the GIL -- runs on a worker
-    thread while the host parses the VCF lines of chunk k+1; `on_done(results)` is called on the caller's
-    thread, in submission order (chunk k-1's when chunk k is submitted, the last one at close())."""
+    """Chunk-level pipelining of the drivers (svtyper/singlesample.py:710-762 re-cast).  The job of chunk k -- C++
+    fetch/summarise or packing, H2D, kernels, D2H, all outside the GIL -- runs on a worker thread while the caller's thread
+    parses the VCF lines of chunk k+1, turns them into arrays and formats the columns of an earlier chunk; with two workers
+    the device stages of chunk k also run under the reader of chunk k+1 (the readers themselves take turns:
+    NativeUnitCollector holds a lock around svt_bam_summarise, whose own threads already fill the host).  `on_done(results)`
+    is called on the caller's thread, in submission order: chunk k-depth's when chunk k is submitted, the rest at close()."""
 
-    def __init__(self, overlap: bool = True):
+    def __init__(self, overlap: bool = True, depth: int = 2):
+        from collections import deque
         from concurrent.futures import ThreadPoolExecutor
-        self._pool = ThreadPoolExecutor(1) if overlap else None
-        self._prev = None
+        self._depth = max(1, int(depth))
+        self._pool = ThreadPoolExecutor(self._depth) if overlap else None
+        self._pending = deque()
 
     def submit(self, job, on_done) -> None:
         if self._pool is None:
             on_done(job())
             return
-        fut = self._pool.submit(job)
-        self._drain()
-        self._prev = (fut, on_done)
+        self._pending.append((self._pool.submit(job), on_done))
+        while len(self._pending) > self._depth:
+            self._drain_one()
 
-    def _drain(self) -> None:
-        if self._prev is not None:
-            (fut, on_done), self._prev = self._prev, None
-            on_done(fut.result())
+    def _drain_one(self) -> None:
+        fut, on_done = self._pending.popleft()
+        on_done(fut.result())
 
     def close(self) -> None:
         try:
-            self._drain()
+            while self._pending:
+                self._drain_one()
         finally:
             if self._pool is not None:
                 self._pool.shutdown(wait=True)
