@@ -163,6 +163,8 @@ public:
     bool ok() const { return file_.data != nullptr && (zs_ok_ || fast_); }
     bool failed() const { return bad_; }
     void mark_bad() { bad_ = true; }   // the record stream inside the blocks is corrupt
+    uint64_t n_inflated = 0, n_shared_hits = 0;   // (SVT_TRACE)
+    double inflate_s = 0.0;
 
     void seek(uint64_t voff)
     {
@@ -255,7 +257,7 @@ private:
             return !block_->data.empty() || block_->next > coff;
         }
         if (shared_)
-            if (BlockRef b = shared_->find(coff)) return use(coff, b);
+            if (BlockRef b = shared_->find(coff)) { ++n_shared_hits; return use(coff, b); }
         if (coff + 18 > file_.size) return park(coff, false);          // end of file
         const uint8_t* hdr = file_.data + coff;
         if (hdr[0] != 31 || hdr[1] != 139) return park(coff, true);
@@ -278,6 +280,7 @@ private:
         auto b = std::make_shared<BlockData>();
         b->data.resize(isize);
         bool inflated = true;
+        const auto t_inflate = std::chrono::steady_clock::now();
         if (isize && fast_) {
             // exactly isize bytes or an error (a null "actual size" pointer makes a short stream a failure)
             if (fast_inflate().decompress(fast_, cdata, (size_t)clen, b->data.data(), b->data.size(), nullptr) != 0) inflated = false;
@@ -291,6 +294,8 @@ private:
                 if (inflate(&zs_, Z_FINISH) != Z_STREAM_END) inflated = false;
             }
         }
+        inflate_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_inflate).count();
+        ++n_inflated;
         if (!inflated) bad_ = true;                      // (its bytes stay readable, as before: the caller sees failed())
         b->next = coff + (uint64_t)bsize + 1;
         if (shared_ && inflated) shared_->publish(coff, b);
@@ -809,6 +814,7 @@ struct Workspace {
     std::vector<char> names;
     std::vector<uint32_t> table;       // fragment index + 1, 0 = empty; size is a power of two
     std::vector<uint32_t> order;
+    std::vector<std::pair<uint64_t, uint32_t>> keys;
     std::vector<std::pair<int64_t, int64_t>> intervals;
     std::vector<const SplitOut*> seq, clip;
     std::string last_rg;               // most reads of a unit share their read group
@@ -858,16 +864,37 @@ struct Workspace {
             table[i] = (uint32_t)(k + 1);
         }
     }
-    // live fragments in the order of Python's sorted() over their (ASCII) names
+    // live fragments in the order of Python's sorted() over their (ASCII) names.  Query names of one run share a long
+    // prefix (instrument : run : flowcell : lane ...), so comparing them byte by byte from the start -- a few hundred
+    // times per unit -- reads the same thirty bytes again and again: the common prefix of the unit's names is found once
+    // and the sort runs on the eight bytes behind it as one big-endian integer; equal keys fall back to the whole names.
     const std::vector<uint32_t>& sorted_order()
     {
         order.resize(n_frags);
-        for (size_t k = 0; k < n_frags; ++k) order[k] = (uint32_t)k;
-        std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
-            const Fragment &a = frags[x], &b = frags[y];
+        keys.resize(n_frags);
+        size_t lcp = n_frags ? frags[0].name_len : 0;
+        for (size_t k = 1; k < n_frags && lcp; ++k) {
+            const char *a = name_of(frags[0]), *b = name_of(frags[k]);
+            const size_t n = std::min<size_t>(lcp, frags[k].name_len);
+            size_t i = 0;
+            while (i < n && a[i] == b[i]) ++i;
+            lcp = i;
+        }
+        for (size_t k = 0; k < n_frags; ++k) {
+            const Fragment& f = frags[k];
+            uint64_t key = 0;                                    // bytes past the end count as 0: a shorter name sorts first,
+            const unsigned char* p = reinterpret_cast<const unsigned char*>(name_of(f)) + lcp;   // as it does for memcmp + length
+            const size_t have = f.name_len - lcp;               // (lcp <= every name's length)
+            for (size_t i = 0; i < 8; ++i) key = (key << 8) | (i < have ? p[i] : 0u);
+            keys[k] = std::make_pair(key, (uint32_t)k);
+        }
+        std::sort(keys.begin(), keys.end(), [&](const std::pair<uint64_t, uint32_t>& x, const std::pair<uint64_t, uint32_t>& y) {
+            if (x.first != y.first) return x.first < y.first;
+            const Fragment &a = frags[x.second], &b = frags[y.second];
             const int c = std::memcmp(name_of(a), name_of(b), std::min(a.name_len, b.name_len));
             return c != 0 ? c < 0 : a.name_len < b.name_len;
         });
+        for (size_t k = 0; k < n_frags; ++k) order[k] = keys[k].second;
         return order;
     }
 };
@@ -1251,8 +1278,15 @@ static int svt_bam_summarise_impl(const svt_bam* bam, const svt_summarise_args* 
     std::string first_err;
     std::vector<std::unique_ptr<SummaryArena>> arenas(nt);
     const std::unique_ptr<SharedBlocks> shared_blocks(new SharedBlocks());
+    struct WorkerStat { double busy_s = 0, inflate_s = 0; uint64_t units = 0, grabs = 0, inflated = 0, shared = 0; };
+    std::vector<WorkerStat> stats(nt);
     auto worker = [&](unsigned t) {
+        const auto w_begin = std::chrono::steady_clock::now();
         Bgzf z(bam->file, shared_blocks.get());
+        struct Report {
+            WorkerStat& st; Bgzf& z; std::chrono::steady_clock::time_point t0;
+            ~Report() { st.busy_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); st.inflate_s = z.inflate_s; st.inflated = z.n_inflated; st.shared = z.n_shared_hits; }
+        } report{stats[t], z, w_begin};
         std::vector<uint8_t> buf;
         UnitOut unit;
         Workspace ws;
@@ -1265,6 +1299,8 @@ static int svt_bam_summarise_impl(const svt_bam* bam, const svt_summarise_args* 
         for (;;) {   // consecutive units stay on one thread: neighbouring sites share BGZF blocks (and its cache)
             uint64_t u0, u1;
             if (!claim(u0, u1)) return;
+            stats[t].grabs += 1;
+            stats[t].units += u1 - u0;
             for (uint64_t u = u0; u < u1; ++u) {
                 if (first_rc.load(std::memory_order_relaxed) != SVT_OK) return;
                 std::string err;
@@ -1286,6 +1322,17 @@ static int svt_bam_summarise_impl(const svt_bam* bam, const svt_summarise_args* 
     run_threads(nt, worker);
     if (first_rc.load() != SVT_OK) return fail(first_rc.load(), first_err);
     lap("units");
+    if (trace) {
+        WorkerStat sum, longest;
+        for (const auto& w : stats) {
+            sum.busy_s += w.busy_s; sum.inflate_s += w.inflate_s; sum.inflated += w.inflated; sum.shared += w.shared; sum.grabs += w.grabs;
+            if (w.busy_s > longest.busy_s) longest = w;
+        }
+        std::fprintf(stderr, "[svt_bam_summarise] %u workers: busy %.1f ms in all (longest %.1f ms: %llu units in %llu grabs, %.1f ms inflating), %llu grabs, "
+                             "%llu blocks inflated in %.1f ms, %llu taken from other workers\n", nt, sum.busy_s * 1e3, longest.busy_s * 1e3,
+                     (unsigned long long)longest.units, (unsigned long long)longest.grabs, longest.inflate_s * 1e3, (unsigned long long)sum.grabs,
+                     (unsigned long long)sum.inflated, sum.inflate_s * 1e3, (unsigned long long)sum.shared);
+    }
 
     uint64_t total = 0;
     for (const auto& o : outs) total += o.count;
