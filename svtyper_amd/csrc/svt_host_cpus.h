@@ -12,6 +12,8 @@
 #include <cstdio>
 #include <cstring>
 #include <thread>
+#include <utility>
+#include <vector>
 
 namespace svt {
 
@@ -59,6 +61,46 @@ inline unsigned usable_cpus()
         return n;
     }();
     return cached;
+}
+
+// distinct physical cores among the CPUs this process may run on (SMT siblings counted once); 0 = unknown
+inline unsigned physical_cores()
+{
+    static const unsigned cached = [] {
+        cpu_set_t set;
+        if (sched_getaffinity(0, sizeof set, &set) != 0) return 0u;
+        std::vector<std::pair<long, long>> seen;
+        for (int cpu = 0; cpu < CPU_SETSIZE; ++cpu) {
+            if (!CPU_ISSET(cpu, &set)) continue;
+            long ids[2] = {-1, -1};
+            const char* what[2] = {"physical_package_id", "core_id"};
+            for (int k = 0; k < 2; ++k) {
+                char path[128];
+                std::snprintf(path, sizeof path, "/sys/devices/system/cpu/cpu%d/topology/%s", cpu, what[k]);
+                if (FILE* f = std::fopen(path, "r")) {
+                    if (std::fscanf(f, "%ld", &ids[k]) != 1) ids[k] = -1;
+                    std::fclose(f);
+                }
+            }
+            if (ids[1] < 0) return 0u;
+            const std::pair<long, long> id(ids[0], ids[1]);
+            if (std::find(seen.begin(), seen.end(), id) == seen.end()) seen.push_back(id);
+        }
+        return (unsigned)seen.size();
+    }();
+    return cached;
+}
+
+// Threads for a burst of `est_cpu_s` seconds of CPU work.  A cgroup CPU quota is CPU time per accounting period (16 CPUs =
+// 1.6 s per 100 ms), not a number of threads: a call whose whole work fits well inside one period's allowance may run one
+// worker per physical core (at most `cap`) and be done sooner; a longer one is bound by the quota whatever it starts and
+// keeps to usable_cpus().  Without a quota usable_cpus() is the machine already.
+inline unsigned burst_threads(double est_cpu_s, unsigned cap)
+{
+    const unsigned base = usable_cpus();
+    const CpuQuota q = cpu_quota();
+    if (q.period_s <= 0.0 || est_cpu_s > 0.6 * q.cpu_s) return base;
+    return std::max(base, std::min(physical_cores(), cap));
 }
 
 }  // namespace svt

@@ -1252,20 +1252,24 @@ static int svt_bam_summarise_impl(const svt_bam* bam, const svt_summarise_args* 
                          std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
     };
     std::vector<UnitSpan> outs(n);
-    // by default one usable CPU is left to the caller's other thread (the drivers parse the next chunk of the
-    // VCF while this runs: pipeline.ChunkPipeline)
-    unsigned nt = args->n_threads > 0 ? (unsigned)args->n_threads : std::max(1u, svt::usable_cpus() - 1u);
+    // by default one usable CPU is left to the caller's other thread (the drivers parse the next chunk of the VCF while this
+    // runs: pipeline.ChunkPipeline).  A small call is a burst (svt_host_cpus.h): at 350 us of CPU time per unit -- a window
+    // pair at 30x costs 210 us on the 9575F, mostly inflate -- up to 2 700 units fit well inside one period of a 16-CPU
+    // quota and run on up to 48 physical cores instead (290 whole-genome-like sites: 97 ms of CPU time, 7.9 -> ms).
+    unsigned nt = args->n_threads > 0 ? (unsigned)args->n_threads
+                                      : std::max(1u, svt::burst_threads((double)n * 350e-6, 48u) - 1u);
     nt = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(nt ? nt : 1, n ? n : 1));
     // Consecutive units stay on one worker: neighbouring sites share BGZF blocks, and the worker's own slots serve them
     // without a lock (what a worker re-reads at the start of a run comes from SharedBlocks).  A grab is a long run while
     // there is plenty left and shrinks towards the end, where balance matters: half of an even share of what remains,
-    // between 4 and 64 units (guided self-scheduling).
+    // between 4 (fewer when the call is too small to feed every worker that way) and 64 units (guided self-scheduling).
+    const uint64_t min_grab = std::max<uint64_t>(1, std::min<uint64_t>(4, n / (4ull * nt)));
     std::atomic<uint64_t> next(0);
     auto claim = [&](uint64_t& lo, uint64_t& hi) {
         uint64_t at = next.load(std::memory_order_relaxed);
         for (;;) {
             if (at >= n) return false;
-            const uint64_t take = std::min<uint64_t>(n - at, std::max<uint64_t>(4, std::min<uint64_t>(64, (n - at) / (2ull * nt))));
+            const uint64_t take = std::min<uint64_t>(n - at, std::max<uint64_t>(min_grab, std::min<uint64_t>(64, (n - at) / (2ull * nt))));
             if (next.compare_exchange_weak(at, at + take, std::memory_order_relaxed)) {
                 lo = at;
                 hi = at + take;
