@@ -1092,7 +1092,7 @@ private:
     {
         if (const char* e = std::getenv("SVT_READER_POOL_MB")) limit_ = (size_t)std::max(0ll, std::atoll(e)) << 20;
     }
-    static constexpr size_t kGrain = 16u << 20;          // eight huge pages: arenas are exactly one grain
+    static constexpr size_t kGrain = 2u << 20;           // one huge page
     std::mutex lock_;
     std::vector<std::pair<void*, size_t>> idle_;
     std::unordered_map<void*, size_t> lent_;
@@ -1111,8 +1111,8 @@ public:
         const size_t bytes = v.size() * sizeof(svt_fragment);
         if (bytes == 0) return nullptr;
         if (used_ + bytes > cap_) {
-            size_t size = 0;
-            void* p = BufferPool::get().acquire(std::max(bytes, kChunkBytes), &size);
+            size_t size = 0;     // 2, 4, 8, 16, 16 ... MiB: forty-seven workers of a small call do not map (and return) 16 MiB each
+            void* p = BufferPool::get().acquire(std::max(bytes, std::min(kChunkBytes, (size_t)(2u << 20) << std::min<size_t>(chunks_.size(), 3))), &size);
             if (!p) return nullptr;
             chunks_.emplace_back(p, size);
             cap_ = size;
@@ -1391,10 +1391,11 @@ static int svt_bam_summarise_impl(const svt_bam* bam, const svt_summarise_args* 
     std::string first_err;
     std::vector<std::unique_ptr<SummaryArena>> arenas(nt);
     const std::unique_ptr<SharedBlocks> shared_blocks(new SharedBlocks());
-    struct WorkerStat { double busy_s = 0, inflate_s = 0; uint64_t units = 0, grabs = 0, inflated = 0, shared = 0, ahead = 0; };
+    struct WorkerStat { double start_s = 0, busy_s = 0, inflate_s = 0; uint64_t units = 0, grabs = 0, inflated = 0, shared = 0, ahead = 0; };
     std::vector<WorkerStat> stats(nt);
     auto worker = [&](unsigned t) {
         const auto w_begin = std::chrono::steady_clock::now();
+        stats[t].start_s = std::chrono::duration<double>(w_begin - t_begin).count();
         Bgzf z(bam->file, shared_blocks.get());
         struct Report {
             WorkerStat& st; Bgzf& z; std::chrono::steady_clock::time_point t0;
@@ -1437,10 +1438,14 @@ static int svt_bam_summarise_impl(const svt_bam* bam, const svt_summarise_args* 
     lap("units");
     if (trace) {
         WorkerStat sum, longest;
+        double first_start = 1e9, last_start = 0, first_end = 1e9, last_end = 0;
         for (const auto& w : stats) {
+            first_start = std::min(first_start, w.start_s); last_start = std::max(last_start, w.start_s);
+            first_end = std::min(first_end, w.start_s + w.busy_s); last_end = std::max(last_end, w.start_s + w.busy_s);
             sum.busy_s += w.busy_s; sum.inflate_s += w.inflate_s; sum.inflated += w.inflated; sum.shared += w.shared; sum.grabs += w.grabs; sum.ahead += w.ahead;
             if (w.busy_s > longest.busy_s) longest = w;
         }
+        std::fprintf(stderr, "[svt_bam_summarise] workers started %.2f .. %.2f ms, finished %.2f .. %.2f ms\n", first_start * 1e3, last_start * 1e3, first_end * 1e3, last_end * 1e3);
         std::fprintf(stderr, "[svt_bam_summarise] %u workers: busy %.1f ms in all (longest %.1f ms: %llu units in %llu grabs, %.1f ms inflating), %llu grabs, "
                              "%llu blocks inflated in %.1f ms (%llu of them ahead for others), %llu taken from other workers\n", nt, sum.busy_s * 1e3, longest.busy_s * 1e3,
                      (unsigned long long)longest.units, (unsigned long long)longest.grabs, longest.inflate_s * 1e3, (unsigned long long)sum.grabs,
