@@ -2,6 +2,11 @@
 #ifndef SVT_ERROR_H
 #define SVT_ERROR_H
 
+#include <pthread.h>
+
+#include <atomic>
+#include <condition_variable>
+#include <cstdint>
 #include <exception>
 #include <functional>
 #include <mutex>
@@ -39,7 +44,90 @@ int guarded(F&& f) noexcept
     }
 }
 
-// fn(t) for t in [0, nt): t = 0 on the calling thread, the others on threads of their own.  An exception in any
+// Parked worker threads of the host-side stages.  The calls that use run_threads() are short -- the reader of a chunk,
+// its gather, the text of its sample columns: 1 to 40 ms -- and come one after the other, chunk after chunk.  Starting
+// forty-seven threads took 3.5 ms on the 2 x EPYC 9575F box however they were started (one by one or as a tree: a new
+// thread lands on an idle core that has to wake up first), more than the work of a small call; parked threads are all
+// woken by one notify.  The pool serves one run_threads() at a time: a second caller (another host thread of the drivers'
+// pipeline) finds it busy and starts threads of its own, as before.  Threads are created on demand (at most kMax), never
+// destroyed; after a fork() the child starts with an empty pool.
+class WorkerPool {
+public:
+    static WorkerPool& get()
+    {
+        static std::once_flag once;
+        std::call_once(once, [] {
+            instance().store(new WorkerPool(), std::memory_order_release);
+            pthread_atfork(nullptr, nullptr, [] { instance().store(new WorkerPool(), std::memory_order_release); });   // (the parent's threads are not in the child)
+        });
+        return *instance().load(std::memory_order_acquire);
+    }
+    // body(t) for t in [1, nt) on parked threads and body(0) here; false (nothing has run) when the pool is taken or too small
+    bool try_run(unsigned nt, const std::function<void(unsigned)>& body)
+    {
+        if (nt < 2 || nt - 1 > kMax) return false;
+        if (taken_.exchange(true, std::memory_order_acquire)) return false;      // (also a run_threads() inside a share of another)
+        struct Release {
+            std::atomic<bool>& flag;
+            ~Release() { flag.store(false, std::memory_order_release); }
+        } release{taken_};
+        const unsigned want = nt - 1;
+        {
+            std::lock_guard<std::mutex> g(lock_);
+            while (threads_ < want) {
+                try {
+                    std::thread(&WorkerPool::park, this, threads_, generation_).detach();
+                } catch (const std::system_error&) {
+                    return false;
+                }
+                ++threads_;
+            }
+            job_ = &body;
+            job_threads_ = want;
+            remaining_ = want;
+            ++generation_;
+        }
+        wake_.notify_all();
+        body(0);
+        std::unique_lock<std::mutex> g(lock_);
+        done_.wait(g, [&] { return remaining_ == 0; });
+        job_ = nullptr;
+        job_threads_ = 0;
+        return true;
+    }
+
+private:
+    static constexpr unsigned kMax = 96;
+    static std::atomic<WorkerPool*>& instance()
+    {
+        static std::atomic<WorkerPool*> p{nullptr};
+        return p;
+    }
+    void park(unsigned index, uint64_t seen)
+    {
+        std::unique_lock<std::mutex> g(lock_);
+        for (;;) {
+            wake_.wait(g, [&] { return generation_ != seen; });
+            seen = generation_;
+            if (index < job_threads_) {
+                const std::function<void(unsigned)>* job = job_;
+                g.unlock();
+                (*job)(index + 1);                         // (run_threads' body: it does not throw)
+                g.lock();
+                if (--remaining_ == 0) done_.notify_one();
+            }
+        }
+    }
+    std::atomic<bool> taken_{false};
+    std::mutex lock_;
+    std::condition_variable wake_, done_;
+    const std::function<void(unsigned)>* job_ = nullptr;
+    unsigned threads_ = 0, job_threads_ = 0, remaining_ = 0;
+    uint64_t generation_ = 0;
+};
+
+// fn(t) for t in [0, nt): t = 0 on the calling thread, the others on parked threads of the pool (on threads of their own
+// when the pool is taken).  An exception in any
 // of them is rethrown here once all have finished (so it reaches guarded() instead of terminating the process);
 // the share of a thread that could not be started runs on the calling thread.
 template <typename Fn>
@@ -57,7 +145,7 @@ void run_threads(unsigned nt, Fn&& fn)
     };
     if (nt <= 1) {
         body(0);
-    } else {
+    } else if (!WorkerPool::get().try_run(nt, std::function<void(unsigned)>(std::cref(body)))) {
         // thread t starts threads 2t+1 and 2t+2 before it runs its own share: sixty-four threads started one after the other
         // by the caller cost ~1.5 ms, a sixth of a small call; as a tree they are all running after six generations
         std::function<void(unsigned)> node = [&](unsigned t) {

@@ -1,4 +1,4 @@
-"""svt_error.h: the exception guard of the C ABI and the thread runner -- compiled into a tiny host program with g++
+"""svt_error.h: the exception guard of the C ABI and the thread runner (with its pool of parked threads) -- compiled into a tiny host program with g++
 (no GPU, no HIP) and run."""
 import os
 import subprocess
@@ -7,9 +7,12 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 PROGRAM = r'''
+#include <sys/wait.h>
+#include <unistd.h>
 #include <atomic>
 #include <cstdio>
 #include <stdexcept>
+#include <thread>
 #include "svtyper_amd/csrc/svt_error.h"
 using namespace svt;
 int main()
@@ -36,6 +39,39 @@ int main()
         return 0;
     });
     if (rc != SVT_ERR_INTERNAL || finished != 7 || g_err.find("worker 3") == std::string::npos) return 7;
+    // 4. the parked pool: call after call (growing and shrinking), from two callers at once (one finds the pool taken and
+    //    starts threads of its own), a call inside a share, and in a forked child (which has none of the parent's threads)
+    for (unsigned rep = 0; rep < 300; ++rep) {
+        const unsigned nt = 2 + rep % 40;
+        std::atomic<unsigned> sum(0);
+        run_threads(nt, [&](unsigned t) { sum += t + 1; });
+        if (sum != nt * (nt + 1) / 2) return 8;
+    }
+    std::atomic<unsigned> bad(0);
+    auto caller = [&] {
+        for (unsigned rep = 0; rep < 200; ++rep) {
+            std::atomic<unsigned> sum(0);
+            run_threads(9, [&](unsigned t) { sum += t + 1; });
+            if (sum != 45) ++bad;
+        }
+    };
+    std::thread other(caller);
+    caller();
+    other.join();
+    if (bad) return 9;
+    std::atomic<unsigned> inner(0);
+    run_threads(4, [&](unsigned) { run_threads(3, [&](unsigned t) { inner += t + 1; }); });
+    if (inner != 4 * 6) return 10;
+#ifndef SVT_NO_FORK_CHECK
+    const pid_t child = fork();
+    if (child == 0) {
+        std::atomic<unsigned> sum(0);
+        run_threads(12, [&](unsigned t) { sum += t + 1; });
+        _exit(sum == 78 ? 0 : 1);
+    }
+    int status = 0;
+    if (child < 0 || waitpid(child, &status, 0) != child || !WIFEXITED(status) || WEXITSTATUS(status) != 0) return 11;
+#endif
     std::puts("ok");
     return 0;
 }
@@ -49,6 +85,22 @@ def test_exception_guard_and_thread_runner(tmp_path):
     subprocess.run(["g++", "-std=c++17", "-O1", "-pthread", "-I", ROOT, str(src), "-o", exe], check=True, timeout=120)
     r = subprocess.run([exe], capture_output=True, text=True, timeout=60)
     assert r.returncode == 0 and r.stdout.strip() == "ok", (r.returncode, r.stdout, r.stderr)
+
+
+def test_thread_runner_under_thread_sanitizer(tmp_path):
+    """the same program under -fsanitize=thread (without the fork() check, which that runtime does not support): the hand-over
+    of a job to the parked threads and back is two condition variables and a generation counter"""
+    import pytest
+    src = tmp_path / "helpers.cpp"
+    src.write_text(PROGRAM)
+    exe = str(tmp_path / "helpers_tsan")
+    r = subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=thread", "-DSVT_NO_FORK_CHECK", "-pthread", "-I", ROOT, str(src), "-o", exe],
+                       capture_output=True, text=True, timeout=300)
+    if r.returncode != 0 and "libtsan" in r.stderr.lower():
+        pytest.skip("this g++ has no ThreadSanitizer runtime")
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([exe], env=dict(os.environ, TSAN_OPTIONS="halt_on_error=1"), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip() == "ok" and "ThreadSanitizer" not in r.stderr, (r.returncode, r.stdout, r.stderr[-3000:])
 
 
 FORMAT_PROGRAM = r'''
