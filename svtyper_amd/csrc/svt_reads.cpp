@@ -11,6 +11,7 @@
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
+#include <time.h>
 #include <unistd.h>
 #include <zlib.h>
 
@@ -601,6 +602,8 @@ struct svt_bam {
     };
     std::vector<RefIndex> index;
     bool has_index = false;
+    // CPU seconds per unit of the summariser's last calls on this file (0: none yet): sizes the next call's burst
+    mutable std::atomic<double> cpu_s_per_unit{0.0};
 };
 
 namespace {
@@ -1130,6 +1133,12 @@ private:
     size_t cap_ = 0, used_ = 0;
 };
 
+inline double thread_cpu_seconds()
+{
+    timespec ts;
+    return clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts) == 0 ? (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec : 0.0;
+}
+
 // one unit: gather reads of both windows, assemble fragments, emit summaries
 int process_unit(const svt_bam& bam, Bgzf& z, std::vector<uint8_t>& buf, const svt_summarise_args& A,
                  const std::unordered_map<std::string, int32_t>& rg_lib, uint64_t u, Workspace& ws, UnitOut& out,
@@ -1362,11 +1371,14 @@ static int svt_bam_summarise_impl(const svt_bam* bam, const svt_summarise_args* 
     };
     std::vector<UnitSpan> outs(n);
     // by default one usable CPU is left to the caller's other thread (the drivers parse the next chunk of the VCF while this
-    // runs: pipeline.ChunkPipeline).  A small call is a burst (svt_host_cpus.h): at 350 us of CPU time per unit -- a window
-    // pair at 30x costs 210 us on the 9575F, mostly inflate -- up to 2 700 units fit well inside one period of a 16-CPU
-    // quota and run on up to 48 physical cores instead (290 whole-genome-like sites: 97 ms of CPU time, 7.9 -> ms).
-    unsigned nt = args->n_threads > 0 ? (unsigned)args->n_threads
-                                      : std::max(1u, svt::burst_threads((double)n * 350e-6, 48u) - 1u);
+    // runs: pipeline.ChunkPipeline).  A call whose CPU time fits well inside one period of a cgroup quota is a burst
+    // (svt_host_cpus.h) and runs on up to 48 physical cores instead: its CPU time is what the last calls on this file
+    // measured per unit (+ 30 %), or 350 us per unit when there is none yet -- a window pair at 30x costs 210 us on the
+    // 9575F, mostly inflate.  (290 whole-genome-like sites: 97 ms of CPU time, 7.9 -> 2.4 ms; the fixture's 21 100 units:
+    // 0.45 s, 31 -> ms -- 16 CPUs for a tenth of a second are the same allowance as 48 for a thirtieth.)
+    const double known = bam->cpu_s_per_unit.load(std::memory_order_relaxed);
+    const double est_cpu_s = (double)n * (known > 0.0 ? 1.3 * known : 350e-6);
+    unsigned nt = args->n_threads > 0 ? (unsigned)args->n_threads : std::max(1u, svt::burst_threads(est_cpu_s, 48u) - 1u);
     nt = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(nt ? nt : 1, n ? n : 1));
     // Consecutive units stay on one worker: neighbouring sites share BGZF blocks, and the worker's own slots serve them
     // without a lock (what a worker re-reads at the start of a run comes from SharedBlocks).  A grab is a long run while
@@ -1391,16 +1403,16 @@ static int svt_bam_summarise_impl(const svt_bam* bam, const svt_summarise_args* 
     std::string first_err;
     std::vector<std::unique_ptr<SummaryArena>> arenas(nt);
     const std::unique_ptr<SharedBlocks> shared_blocks(new SharedBlocks());
-    struct WorkerStat { double start_s = 0, busy_s = 0, inflate_s = 0; uint64_t units = 0, grabs = 0, inflated = 0, shared = 0, ahead = 0; };
+    struct WorkerStat { double start_s = 0, busy_s = 0, cpu_s = 0, inflate_s = 0; uint64_t units = 0, grabs = 0, inflated = 0, shared = 0, ahead = 0; };
     std::vector<WorkerStat> stats(nt);
     auto worker = [&](unsigned t) {
         const auto w_begin = std::chrono::steady_clock::now();
         stats[t].start_s = std::chrono::duration<double>(w_begin - t_begin).count();
         Bgzf z(bam->file, shared_blocks.get());
         struct Report {
-            WorkerStat& st; Bgzf& z; std::chrono::steady_clock::time_point t0;
-            ~Report() { st.busy_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); st.inflate_s = z.inflate_s; st.inflated = z.n_inflated; st.shared = z.n_shared_hits; st.ahead = z.n_ahead; }
-        } report{stats[t], z, w_begin};
+            WorkerStat& st; Bgzf& z; std::chrono::steady_clock::time_point t0; double cpu0;
+            ~Report() { st.cpu_s = thread_cpu_seconds() - cpu0; st.busy_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); st.inflate_s = z.inflate_s; st.inflated = z.n_inflated; st.shared = z.n_shared_hits; st.ahead = z.n_ahead; }
+        } report{stats[t], z, w_begin, thread_cpu_seconds()};
         std::vector<uint8_t> buf;
         UnitOut unit;
         Workspace ws;
@@ -1436,18 +1448,26 @@ static int svt_bam_summarise_impl(const svt_bam* bam, const svt_summarise_args* 
     run_threads(nt, worker);
     if (first_rc.load() != SVT_OK) return fail(first_rc.load(), first_err);
     lap("units");
+    {   // what a unit of this file costs: half the last call, half the calls before it
+        double cpu = 0.0;
+        for (const auto& w : stats) cpu += w.cpu_s;
+        if (n && cpu > 0.0) {
+            const double now = cpu / (double)n, before = bam->cpu_s_per_unit.load(std::memory_order_relaxed);
+            bam->cpu_s_per_unit.store(before > 0.0 ? 0.5 * (before + now) : now, std::memory_order_relaxed);
+        }
+    }
     if (trace) {
         WorkerStat sum, longest;
         double first_start = 1e9, last_start = 0, first_end = 1e9, last_end = 0;
         for (const auto& w : stats) {
             first_start = std::min(first_start, w.start_s); last_start = std::max(last_start, w.start_s);
             first_end = std::min(first_end, w.start_s + w.busy_s); last_end = std::max(last_end, w.start_s + w.busy_s);
-            sum.busy_s += w.busy_s; sum.inflate_s += w.inflate_s; sum.inflated += w.inflated; sum.shared += w.shared; sum.grabs += w.grabs; sum.ahead += w.ahead;
+            sum.busy_s += w.busy_s; sum.cpu_s += w.cpu_s; sum.inflate_s += w.inflate_s; sum.inflated += w.inflated; sum.shared += w.shared; sum.grabs += w.grabs; sum.ahead += w.ahead;
             if (w.busy_s > longest.busy_s) longest = w;
         }
         std::fprintf(stderr, "[svt_bam_summarise] workers started %.2f .. %.2f ms, finished %.2f .. %.2f ms\n", first_start * 1e3, last_start * 1e3, first_end * 1e3, last_end * 1e3);
-        std::fprintf(stderr, "[svt_bam_summarise] %u workers: busy %.1f ms in all (longest %.1f ms: %llu units in %llu grabs, %.1f ms inflating), %llu grabs, "
-                             "%llu blocks inflated in %.1f ms (%llu of them ahead for others), %llu taken from other workers\n", nt, sum.busy_s * 1e3, longest.busy_s * 1e3,
+        std::fprintf(stderr, "[svt_bam_summarise] %u workers: CPU %.1f ms, busy %.1f ms in all (longest %.1f ms: %llu units in %llu grabs, %.1f ms inflating), %llu grabs, "
+                             "%llu blocks inflated in %.1f ms (%llu of them ahead for others), %llu taken from other workers\n", nt, sum.cpu_s * 1e3, sum.busy_s * 1e3, longest.busy_s * 1e3,
                      (unsigned long long)longest.units, (unsigned long long)longest.grabs, longest.inflate_s * 1e3, (unsigned long long)sum.grabs,
                      (unsigned long long)sum.inflated, sum.inflate_s * 1e3, (unsigned long long)sum.ahead, (unsigned long long)sum.shared);
     }
