@@ -86,7 +86,7 @@ def test_bench_line_has_the_contract_keys(hip_device):
     for key in ("fixture_x100", "wgs_like_30x"):
         leg = real[key]
         assert leg["sites"] > 0 and leg["fragments"] > 0 and leg["sites_per_s"] > 0 and leg["columns"] == leg["sites"]
-        assert set(leg["stage_ms"]) == {"inflate_fetch_summarise_host", "h2d_plus_geometry_kernel", "genotype_pass", "results_d2h", "format_columns_host"}
+        assert set(leg["stage_ms"]) == {"site_arrays_python", "inflate_fetch_summarise_host", "h2d_plus_geometry_kernel", "genotype_pass", "results_d2h", "format_columns_host"}
         assert all(v >= 0 for v in leg["stage_ms"].values()) and leg["h2d_bytes"] == 128 * leg["fragments"]
     assert real["fixture_x100"]["sites"] == 21100
     sh = d["shard_of_8"]
