@@ -460,9 +460,11 @@ def real_data_leg(device: int) -> dict:
     from svtyper_amd.vcf import Variant, Vcf
 
     data = os.path.join(ROOT, "tests", "data")
-    out = {"what": "reader=native, geometry=device: svt_bam_summarise (inflate + fetch + 128-byte fragment summaries, C++ threads) -> H2D -> "
-                   "svt_geometry_kernel -> svt_stream_kernel -> D2H -> svt_format_results; stage times in ms, whole-run rates in sites/s",
-           "bytes_per_fragment_over_pcie": 128, "canonical_record_bytes": 16}
+    out = {"what": "reader=native, the geometry predicates in the reader's threads: svt_bam_evidence (inflate + fetch + fragment assembly + "
+                   "svt_geometry_math.h -> 16-byte evidence records, C++ threads) -> H2D (svt_batch_create) -> svt_stream_kernel -> D2H -> "
+                   "svt_format_results; stage times in ms, whole-run rates in sites/s.  `device_geometry`: the same sites with 128-byte fragment "
+                   "summaries over PCIe and svt_geometry_kernel on the device (svt_bam_summarise -> svt_batch_create_from_fragments)",
+           "bytes_per_fragment_over_pcie": 16, "bytes_per_fragment_over_pcie_device_geometry": 128, "canonical_record_bytes": 16}
 
     class Timed:
         """the HIP engine with a stopwatch on every stage behind the reader"""
@@ -470,11 +472,11 @@ def real_data_leg(device: int) -> dict:
 
         def __init__(self):
             self.t = {"create_h2d_geometry": 0.0, "pass": 0.0, "results_d2h": 0.0}
-            self.fragments = self.units = 0
+            self.fragments = self.units = self.h2d_bytes = 0
 
-        def genotype_fragments(self, fb, flags=0, site_qual=None):
+        def _timed(self, make, n_fragments, n_units, h2d_bytes):
             t0 = time.perf_counter()
-            d = hip.DeviceBatch.from_fragments(fb, device, flags)
+            d = make()
             t1 = time.perf_counter()
             d.genotype(sync=True)
             t2 = time.perf_counter()
@@ -484,15 +486,24 @@ def real_data_leg(device: int) -> dict:
             self.t["create_h2d_geometry"] += t1 - t0
             self.t["pass"] += t2 - t1
             self.t["results_d2h"] += t3 - t2
-            self.fragments += fb.n_fragments
-            self.units += fb.n_units
+            self.fragments += n_fragments
+            self.units += n_units
+            self.h2d_bytes += h2d_bytes
             return hip.host_sq(r)
 
-    def run(sample, nbam, sites, repeat, threads=0):
+        def __call__(self, batch, flags=0, site_qual=None):          # geometry in the reader: canonical 16-byte records
+            return self._timed(lambda: hip.DeviceBatch(batch, device, flags), batch.n_records, batch.n_units,
+                               16 * batch.n_records + 24 * batch.n_units)
+
+        def genotype_fragments(self, fb, flags=0, site_qual=None):  # geometry on the device: 128-byte summaries
+            return self._timed(lambda: hip.DeviceBatch.from_fragments(fb, device, flags), fb.n_fragments, fb.n_units,
+                               128 * fb.n_fragments + 56 * fb.n_units)
+
+    def run(sample, nbam, sites, repeat, threads=0, geometry="reader"):
         best = None
         for _ in range(2):     # (the first run pays the pooled device buffers; keep the better one)
             eng = Timed()
-            coll = pipeline.NativeUnitCollector([sample], [nbam], 1.0, 1.0, 20, nr.COUNT_SSO, 1000, n_threads=threads)
+            coll = pipeline.NativeUnitCollector([sample], [nbam], 1.0, 1.0, 20, nr.COUNT_SSO, 1000, n_threads=threads, geometry=geometry)
             for _r in range(repeat):
                 for bp in sites:
                     coll.add_site(bp)
@@ -509,7 +520,7 @@ def real_data_leg(device: int) -> dict:
                    "stage_ms": {"site_arrays_python": (t_prep - t0) * 1e3, "inflate_fetch_summarise_host": (t1 - t_prep - dev) * 1e3,
                                 "h2d_plus_geometry_kernel": eng.t["create_h2d_geometry"] * 1e3, "genotype_pass": eng.t["pass"] * 1e3,
                                 "results_d2h": eng.t["results_d2h"] * 1e3, "format_columns_host": (t2 - t1) * 1e3},
-                   "h2d_bytes": int(eng.fragments * 128), "fragments_per_site": eng.fragments / max(1, len(sites) * repeat),
+                   "geometry": geometry, "h2d_bytes": int(eng.h2d_bytes), "fragments_per_site": eng.fragments / max(1, len(sites) * repeat),
                    "gt_histogram": {str(k): int(v) for k, v in zip(*np.unique(res.gt, return_counts=True))}, "columns": len(cols)}
             if best is None or leg["wall_ms"] < best["wall_ms"]:
                 best = leg
@@ -532,7 +543,7 @@ def real_data_leg(device: int) -> dict:
                     fmt_s[0] += time.perf_counter() - f0
                 t0 = time.perf_counter()
                 for lo in range(0, len(all_sites), per):
-                    coll = pipeline.NativeUnitCollector([sample], [nbam], 1.0, 1.0, 20, nr.COUNT_SSO, 1000, n_threads=threads)
+                    coll = pipeline.NativeUnitCollector([sample], [nbam], 1.0, 1.0, 20, nr.COUNT_SSO, 1000, n_threads=threads, geometry=geometry)
                     for bp in all_sites[lo:lo + per]:
                         coll.add_site(bp)
                     pipe.submit(coll.take(eng, ev.FLAG_SSO_ASSOCIATION), on_done)
@@ -587,6 +598,9 @@ def real_data_leg(device: int) -> dict:
         sample = library.Sample.from_lib_info(pybam.AlignmentFile(bam_path), json.load(f), 1e-3)
     nbam = nr.NativeBam(bam_path)
     out["fixture_x100"] = dict(run(sample, nbam, bps, 100), what="the %d fixture breakpoints x 100 (cached blocks, repeated sites)" % len(bps))
+    dg = run(sample, nbam, bps, 100, geometry="device")
+    out["fixture_x100"]["device_geometry"] = {k: dg[k] for k in ("wall_ms", "sites_per_s", "stage_ms", "h2d_bytes", "overlapped_wall_ms", "overlapped_sites_per_s") if k in dg}
+    out["fixture_x100"]["device_geometry"]["same_genotypes"] = dg["gt_histogram"] == out["fixture_x100"]["gt_histogram"]
     nbam.close()
     # ---- (2) a bounded WGS-like BAM: 1.2 Mbp at 30x, a DEL every 4 kb
     with tempfile.TemporaryDirectory() as tmp:
@@ -596,9 +610,12 @@ def real_data_leg(device: int) -> dict:
         wrote = time.perf_counter() - t0
         sample = library.Sample.from_lib_info(pybam.AlignmentFile(path), info, 1e-3)
         nbam = nr.NativeBam(path)
+        dg = run(sample, nbam, sites, 1, geometry="device")
         out["wgs_like_30x"] = dict(run(sample, nbam, sites, 1), bam_records=n_rec, bam_bytes=os.path.getsize(path), bam_written_s=wrote,
                                    what="1.2 Mbp at 30x (150-bp pairs, random bases, binned qualities), %d DEL sites 4 kb apart: every "
                                         "site inflates blocks of its own" % len(sites))
+        out["wgs_like_30x"]["device_geometry"] = {k: dg[k] for k in ("wall_ms", "sites_per_s", "stage_ms", "h2d_bytes") if k in dg}
+        out["wgs_like_30x"]["device_geometry"]["same_genotypes"] = dg["gt_histogram"] == out["wgs_like_30x"]["gt_histogram"]
         nbam.close()
     return out
 

@@ -74,6 +74,31 @@ typedef struct svt_summaries {
 int svt_bam_summarise(const svt_bam* bam, const svt_summarise_args* args, svt_summaries* out);
 void svt_summaries_free(svt_summaries* s);
 
+/* ---- the same units as evidence records ------------------------------------------------------
+ * svt_bam_evidence = svt_bam_summarise + the breakpoint-dependent predicates of the geometry stage
+ * (svtyper/parsers.py:785-857,1122-1215; what svt_batch_create_from_fragments evaluates on the
+ * device) in the reader's own threads: 16-byte svt_records leave the reader instead of 128-byte
+ * summaries, and the batch goes to svt_batch_create / svt_genotype like any other.  The predicates
+ * are ONE piece of source for both places (svtyper_amd/csrc/svt_geometry_math.h); the records are
+ * those of the device stage, byte for byte (tests/test_hip_geometry.py).
+ * Here every field of svt_summarise_args.breakpoints is read.                                      */
+typedef struct svt_evidence_params {
+    uint32_t n_libs;           /* 1..256: size of lib_flank; a fragment of a library beyond it is an error */
+    const double* lib_flank;   /* per library: mean + 3 sd, is_pair_straddle's flank (parsers.py:846-855)   */
+    int32_t min_aligned;       /* -m / --min_aligned (classic.py:34)                                        */
+    int32_t split_slop;        /* 3 (classic.py:184)                                                        */
+} svt_evidence_params;
+
+typedef struct svt_evidence {
+    uint64_t* rec_offset;     /* n_units + 1 */
+    svt_record* records;      /* rec_offset[n_units], in the units' order, sorted(query_name) inside a unit;
+                                 owned by the library: release ONLY through svt_evidence_free               */
+    uint8_t* skipped;         /* n_units: 1 = too many reads (unit has no records; set SVT_UNIT_SKIP)       */
+} svt_evidence;
+
+int svt_bam_evidence(const svt_bam* bam, const svt_summarise_args* args, const svt_evidence_params* geometry, svt_evidence* out);
+void svt_evidence_free(svt_evidence* e);
+
 /* Library statistics straight from the BAM (svtyper/parsers.py:501-576): what Library.from_bam scans
  * for, for ONE library given as its read-group ids, in three passes from the first record each --
  *   read_length : max query length (M/I/S/=/X) over the library's reads until 10 001 of them were seen

@@ -97,9 +97,9 @@ def sv_genotype(bam_string, vcf_in, vcf_out, min_aligned, split_weight, disc_wei
     if engine is None:
         engine = default_engine()
     vcf = Vcf()
-    if reader == "native":      # C++ fetch + summariser, geometry and likelihood on the device
+    if reader == "native":      # C++ fetch + summariser; geometry in the reader's threads ("host") or on the device
         collector = NativeUnitCollector(samples, native, split_weight, disc_weight, min_aligned, COUNT_CLASSIC,
-                                        max_reads)
+                                        max_reads, geometry="device" if geometry == "device" else "reader")
     elif reader == "python":
         collector = UnitCollector(samples, split_weight, disc_weight, min_aligned, geometry)
     else:

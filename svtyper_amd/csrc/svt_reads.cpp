@@ -34,6 +34,7 @@
 
 #include "../../include/svtyper_reads.h"
 #include "svt_error.h"
+#include "svt_geometry_math.h"
 #include "svt_host_cpus.h"
 
 namespace {
@@ -914,6 +915,7 @@ bool fill_piece(svt_piece_summary& d, const PieceOut& p)
 
 struct UnitOut {                       // per worker, reused for every unit it processes
     std::vector<svt_fragment> frags;
+    std::vector<svt_record> recs;      // svt_bam_evidence: the summaries turned into evidence records
     bool skipped = false;
 };
 
@@ -1011,8 +1013,8 @@ struct Workspace {
     }
 };
 
-struct UnitSpan {                      // where a finished unit's summaries wait for the gather
-    const svt_fragment* frags = nullptr;
+struct UnitSpan {                      // where a finished unit's summaries (or evidence records) wait for the gather
+    const void* data = nullptr;
     uint64_t count = 0;
     bool skipped = false;
 };
@@ -1109,9 +1111,8 @@ public:
     SummaryArena(const SummaryArena&) = delete;
     SummaryArena& operator=(const SummaryArena&) = delete;
     ~SummaryArena() { for (auto& c : chunks_) BufferPool::get().release(c.first, c.second); }
-    const svt_fragment* append(const std::vector<svt_fragment>& v)
+    const void* append(const void* data, size_t bytes)
     {
-        const size_t bytes = v.size() * sizeof(svt_fragment);
         if (bytes == 0) return nullptr;
         if (used_ + bytes > cap_) {
             size_t size = 0;     // 2, 4, 8, 16, 16 ... MiB: forty-seven workers of a small call do not map (and return) 16 MiB each
@@ -1122,9 +1123,9 @@ public:
             used_ = 0;
         }
         uint8_t* dst = static_cast<uint8_t*>(chunks_.back().first) + used_;
-        std::memcpy(dst, v.data(), bytes);
+        std::memcpy(dst, data, bytes);
         used_ += bytes;
-        return reinterpret_cast<const svt_fragment*>(dst);
+        return dst;
     }
 
 private:
@@ -1351,12 +1352,33 @@ int32_t svt_bam_tid(const svt_bam* bam, const char* name)
 
 const char* svt_bam_header_text(const svt_bam* bam) { return bam ? bam->text.c_str() : nullptr; }
 
-static int svt_bam_summarise_impl(const svt_bam* bam, const svt_summarise_args* args, svt_summaries* out)
+// What the workers' results are gathered into: the three arrays of svt_summaries (elements: 128-byte summaries) or of
+// svt_evidence (elements: 16-byte records made from the summaries by svt_geometry_math.h, `geometry` != nullptr).
+struct GatherOut {
+    uint64_t** offset;
+    void** elements;
+    uint8_t** skipped;
+    size_t element_bytes;
+};
+
+static void free_gathered(uint64_t*& offset, void*& elements, uint8_t*& skipped)
 {
-    if (!bam || !args || !out) return fail(SVT_ERR_INVALID, "null argument");
-    out->frag_offset = nullptr;
-    out->fragments = nullptr;
-    out->skipped = nullptr;
+    std::free(offset);
+    if (elements && !BufferPool::get().release_tracked(elements)) std::free(elements);
+    std::free(skipped);
+    offset = nullptr;
+    elements = nullptr;
+    skipped = nullptr;
+}
+
+static int summarise_units(const svt_bam* bam, const svt_summarise_args* args, const svt_evidence_params* geometry, GatherOut out)
+{
+    if (!bam || !args) return fail(SVT_ERR_INVALID, "null argument");
+    *out.offset = nullptr;
+    *out.elements = nullptr;
+    *out.skipped = nullptr;
+    if (geometry && (geometry->n_libs == 0 || geometry->n_libs > 256 || !geometry->lib_flank))
+        return fail(SVT_ERR_INVALID, "n_libs must be 1..256 with a flank per library");
     const uint64_t n = args->n_units;
     if (n && (!args->windows || !args->breakpoints)) return fail(SVT_ERR_INVALID, "null unit arrays");
     std::unordered_map<std::string, int32_t> rg_lib;
@@ -1431,11 +1453,27 @@ static int svt_bam_summarise_impl(const svt_bam* bam, const svt_summarise_args* 
                 if (first_rc.load(std::memory_order_relaxed) != SVT_OK) return;
                 std::string err;
                 int rc = process_unit(*bam, z, buf, *args, rg_lib, u, ws, unit, err);
+                if (rc == SVT_OK && geometry) {      // the predicates of the device stage, here: 16 bytes per fragment leave the reader
+                    const svt_breakpoint& bp = args->breakpoints[u];
+                    if (bp.svtype > SVT_SVTYPE_BND) { rc = SVT_ERR_INVALID; err = "bad svtype"; }
+                    unit.recs.resize(unit.frags.size());
+                    for (size_t k = 0; rc == SVT_OK && k < unit.frags.size(); ++k) {
+                        const svt_fragment& f = unit.frags[k];
+                        const uint32_t lib = f.read[0].reserved & 0xffu;
+                        if (lib >= geometry->n_libs) { rc = SVT_ERR_INVALID; err = "library index of a fragment outside the library table"; break; }
+                        const svt::Record4 r = svt::geometry_record(svt::read_of(f.read[0]), svt::read_of(f.read[1]), svt::piece_of(f.seq[0]),
+                                                                    svt::piece_of(f.seq[1]), svt::piece_of(f.clip[0]), svt::piece_of(f.clip[1]), bp,
+                                                                    geometry->lib_flank[lib], geometry->min_aligned, geometry->split_slop);
+                        static_assert(sizeof(svt_record) == sizeof r, "svt_record is four words");
+                        std::memcpy(&unit.recs[k], &r, sizeof r);
+                    }
+                }
                 if (rc == SVT_OK) {
                     outs[u].count = unit.frags.size();
                     outs[u].skipped = unit.skipped;
-                    outs[u].frags = arenas[t]->append(unit.frags);
-                    if (outs[u].count && !outs[u].frags) { rc = SVT_ERR_NOMEM; err = "out of host memory"; }
+                    outs[u].data = geometry ? arenas[t]->append(unit.recs.data(), unit.recs.size() * sizeof(svt_record))
+                                            : arenas[t]->append(unit.frags.data(), unit.frags.size() * sizeof(svt_fragment));
+                    if (outs[u].count && !outs[u].data) { rc = SVT_ERR_NOMEM; err = "out of host memory"; }
                 }
                 if (rc != SVT_OK) {
                     std::lock_guard<std::mutex> g(err_lock);
@@ -1474,23 +1512,24 @@ static int svt_bam_summarise_impl(const svt_bam* bam, const svt_summarise_args* 
 
     uint64_t total = 0;
     for (const auto& o : outs) total += o.count;
-    out->frag_offset = static_cast<uint64_t*>(std::malloc((n + 1) * sizeof(uint64_t)));
+    uint64_t* offsets = static_cast<uint64_t*>(std::malloc((n + 1) * sizeof(uint64_t)));
+    void* elements = nullptr;
     {   // from the pool of huge-page mappings when it is large (1.4 GB for 10 M summaries), malloc otherwise
-        const size_t bytes = std::max<uint64_t>(total, 1) * sizeof(svt_fragment);
-        out->fragments = static_cast<svt_fragment*>(bytes >= (4u << 20) ? BufferPool::get().acquire_tracked(bytes) : std::malloc(bytes));
+        const size_t bytes = std::max<uint64_t>(total, 1) * out.element_bytes;
+        elements = bytes >= (4u << 20) ? BufferPool::get().acquire_tracked(bytes) : std::malloc(bytes);
     }
-    out->skipped = static_cast<uint8_t*>(std::malloc(std::max<uint64_t>(n, 1)));
-    if (!out->frag_offset || !out->fragments || !out->skipped) {
-        svt_summaries_free(out);
+    uint8_t* skipped = static_cast<uint8_t*>(std::malloc(std::max<uint64_t>(n, 1)));
+    if (!offsets || !elements || !skipped) {
+        free_gathered(offsets, elements, skipped);
         return fail(SVT_ERR_NOMEM, "out of host memory");
     }
     uint64_t off = 0;
     for (uint64_t u = 0; u < n; ++u) {
-        out->frag_offset[u] = off;
+        offsets[u] = off;
         off += outs[u].count;
-        out->skipped[u] = outs[u].skipped ? 1 : 0;
+        skipped[u] = outs[u].skipped ? 1 : 0;
     }
-    out->frag_offset[n] = off;
+    offsets[n] = off;
     {   // gather the per-unit vectors into the flat array on the same threads
         std::atomic<uint64_t> nextu(0);
         auto copier = [&]() {
@@ -1499,12 +1538,14 @@ static int svt_bam_summarise_impl(const svt_bam* bam, const svt_summarise_args* 
                 if (u0 >= n) return;
                 for (uint64_t u = u0; u < std::min(n, u0 + 256); ++u)
                     if (outs[u].count)
-                        std::memcpy(out->fragments + out->frag_offset[u], outs[u].frags,
-                                    outs[u].count * sizeof(svt_fragment));
+                        std::memcpy(static_cast<uint8_t*>(elements) + offsets[u] * out.element_bytes, outs[u].data, outs[u].count * out.element_bytes);
             }
         };
         run_threads(std::min(nt, 32u), [&](unsigned) { copier(); });
     }
+    *out.offset = offsets;
+    *out.elements = elements;
+    *out.skipped = skipped;
     lap("gather");
     arenas.clear();
     lap("release");
@@ -1513,18 +1554,40 @@ static int svt_bam_summarise_impl(const svt_bam* bam, const svt_summarise_args* 
 
 int svt_bam_summarise(const svt_bam* bam, const svt_summarise_args* args, svt_summaries* out)
 {
-    return guarded([&] { return svt_bam_summarise_impl(bam, args, out); });
+    return guarded([&] {
+        if (!out) return fail(SVT_ERR_INVALID, "null argument");
+        void* elements = nullptr;
+        const int rc = summarise_units(bam, args, nullptr, GatherOut{&out->frag_offset, &elements, &out->skipped, sizeof(svt_fragment)});
+        out->fragments = static_cast<svt_fragment*>(elements);
+        return rc;
+    });
 }
 
 void svt_summaries_free(svt_summaries* s)
 {
     if (!s) return;
-    std::free(s->frag_offset);
-    if (s->fragments && !BufferPool::get().release_tracked(s->fragments)) std::free(s->fragments);
-    std::free(s->skipped);
-    s->frag_offset = nullptr;
+    void* elements = s->fragments;
+    free_gathered(s->frag_offset, elements, s->skipped);
     s->fragments = nullptr;
-    s->skipped = nullptr;
+}
+
+int svt_bam_evidence(const svt_bam* bam, const svt_summarise_args* args, const svt_evidence_params* geometry, svt_evidence* out)
+{
+    return guarded([&] {
+        if (!out || !geometry) return fail(SVT_ERR_INVALID, "null argument");
+        void* elements = nullptr;
+        const int rc = summarise_units(bam, args, geometry, GatherOut{&out->rec_offset, &elements, &out->skipped, sizeof(svt_record)});
+        out->records = static_cast<svt_record*>(elements);
+        return rc;
+    });
+}
+
+void svt_evidence_free(svt_evidence* e)
+{
+    if (!e) return;
+    void* elements = e->records;
+    free_gathered(e->rec_offset, elements, e->skipped);
+    e->records = nullptr;
 }
 
 static int svt_bam_scan_library_impl(const svt_bam* bam, uint32_t n_read_groups, const char* const* read_groups, int64_t num_samp,

@@ -34,6 +34,14 @@ class _Summaries(C.Structure):
     _fields_ = [("frag_offset", C.POINTER(C.c_uint64)), ("fragments", C.c_void_p), ("skipped", C.POINTER(C.c_uint8))]
 
 
+class _EvidenceParams(C.Structure):
+    _fields_ = [("n_libs", C.c_uint32), ("lib_flank", C.POINTER(C.c_double)), ("min_aligned", C.c_int32), ("split_slop", C.c_int32)]
+
+
+class _Evidence(C.Structure):
+    _fields_ = [("rec_offset", C.POINTER(C.c_uint64)), ("records", C.c_void_p), ("skipped", C.POINTER(C.c_uint8))]
+
+
 class _LibraryScan(C.Structure):
     _fields_ = [("read_length", C.c_int64), ("in_lib", C.c_uint64), ("total", C.c_uint64), ("n_hist", C.c_uint64),
                 ("hist_keys", C.POINTER(C.c_int64)), ("hist_counts", C.POINTER(C.c_uint64))]
@@ -64,6 +72,10 @@ def _lib():
         L.svt_bam_summarise.argtypes = [C.c_void_p, C.POINTER(_Args), C.POINTER(_Summaries)]
         L.svt_summaries_free.restype = None
         L.svt_summaries_free.argtypes = [C.POINTER(_Summaries)]
+        L.svt_bam_evidence.restype = C.c_int
+        L.svt_bam_evidence.argtypes = [C.c_void_p, C.POINTER(_Args), C.POINTER(_EvidenceParams), C.POINTER(_Evidence)]
+        L.svt_evidence_free.restype = None
+        L.svt_evidence_free.argtypes = [C.POINTER(_Evidence)]
         L.svt_bam_scan_library.restype = C.c_int
         L.svt_bam_scan_library.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_char_p), C.c_int64, C.POINTER(_LibraryScan)]
         L.svt_library_scan_free.restype = None
@@ -122,6 +134,38 @@ class NativeBam:
         finally:
             self._L.svt_library_scan_free(C.byref(out))
 
+    def evidence(self, windows: np.ndarray, breakpoints: np.ndarray, read_groups: Sequence[str],
+                 read_group_lib: Sequence[int], max_reads: Optional[int], count_mode: int, lib_flank: Sequence[float],
+                 min_aligned: int, split_slop: int, n_threads: int = 0) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+        """svt_bam_evidence: (rec_offset uint64 [n+1], records RECORD_DTYPE, skipped uint8 [n]) -- the units' 16-byte
+        evidence records, the geometry predicates evaluated in the reader's threads (`lib_flank`: mean + 3 sd of every
+        library of the batch).  What summarise() + the device geometry stage produce, byte for byte."""
+        from .evidence import RECORD_DTYPE
+        windows = np.ascontiguousarray(windows, dtype=FETCH_DTYPE)
+        breakpoints = np.ascontiguousarray(breakpoints, dtype=BREAKPOINT_DTYPE)
+        n = int(windows.shape[0])
+        if breakpoints.shape[0] != n:
+            raise ValueError("windows and breakpoints must have the same length")
+        names = (C.c_char_p * max(1, len(read_groups)))(*[rg.encode() for rg in read_groups])
+        libs = (C.c_int32 * max(1, len(read_groups)))(*[int(x) for x in read_group_lib])
+        flank = (C.c_double * max(1, len(lib_flank)))(*[float(x) for x in lib_flank])
+        a = _Args(n, windows.ctypes.data, breakpoints.ctypes.data, len(read_groups), names, libs,
+                  -1 if max_reads is None else int(max_reads), int(count_mode), int(n_threads))
+        g = _EvidenceParams(len(lib_flank), flank, int(min_aligned), int(split_slop))
+        out = _Evidence()
+        hip._check(self._L.svt_bam_evidence(self._h, C.byref(a), C.byref(g), C.byref(out)))
+        owner = _EvidenceOwner(self._L, out)    # frees the C buffers when the arrays below are gone
+        off = np.ctypeslib.as_array(out.rec_offset, shape=(n + 1,)).copy()
+        total = int(off[-1])
+        skipped = np.ctypeslib.as_array(out.skipped, shape=(max(n, 1),))[:n].copy()
+        if total:
+            raw = (C.c_uint8 * (total * RECORD_DTYPE.itemsize)).from_address(out.records)
+            raw._svt_owner = owner
+            recs = np.frombuffer(raw, dtype=RECORD_DTYPE)
+        else:
+            recs = np.zeros(0, RECORD_DTYPE)
+        return off, recs, skipped
+
     def summarise(self, windows: np.ndarray, breakpoints: np.ndarray, read_groups: Sequence[str],
                   read_group_lib: Sequence[int], max_reads: Optional[int], count_mode: int,
                   n_threads: int = 0) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
@@ -148,6 +192,17 @@ class NativeBam:
         else:
             frags = np.zeros(0, FRAGMENT_DTYPE)
         return off, frags, skipped
+
+
+class _EvidenceOwner:
+    def __init__(self, lib, evidence):
+        self._lib, self._e = lib, evidence
+
+    def __del__(self):
+        try:
+            self._lib.svt_evidence_free(C.byref(self._e))
+        except Exception:
+            pass
 
 
 class _SummariesOwner:

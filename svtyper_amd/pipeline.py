@@ -155,7 +155,14 @@ class NativeUnitCollector:
     every (site, sample) unit and the summaries go straight to the device geometry + likelihood stages."""
 
     def __init__(self, samples: List[Sample], native_bams, split_weight: float, disc_weight: float,
-                 min_aligned: int, count_mode: int, max_reads, n_threads: int = 0):
+                 min_aligned: int, count_mode: int, max_reads, n_threads: int = 0, geometry: str = "reader"):
+        """`geometry`: where the breakpoint-dependent predicates (parsers.py:785-857,1122-1215) are evaluated --
+        "reader" (default): in the C++ reader's threads, which hands over 16-byte evidence records (svt_bam_evidence) for
+        the canonical route of ANY engine; "device": 128-byte fragment summaries go to the device's geometry stage
+        (svt_bam_summarise -> svt_batch_create_from_fragments, the HIP engine only).  Same records either way."""
+        if geometry not in ("reader", "device"):
+            raise ValueError("geometry must be 'reader' or 'device'")
+        self.geometry = geometry
         self.samples = samples
         self.bams = native_bams
         self.min_aligned = min_aligned
@@ -193,8 +200,8 @@ class NativeUnitCollector:
         the chunk before; the job itself is C++ and HIP calls only."""
         sites, self.sites = self.sites, []
         kw = _site_qual_kw(engine, len(self.samples), site_quals)
-        if sites and not hasattr(engine, "genotype_fragments"):
-            raise TypeError("reader='native' needs an engine with genotype_fragments (the HIP engine)")
+        if sites and self.geometry == "device" and not hasattr(engine, "genotype_fragments"):
+            raise TypeError("reader='native' with geometry='device' needs an engine with genotype_fragments (the HIP engine)")
         t_begin = time.perf_counter()
         prepared = self._prepare(sites)
         prep_s = time.perf_counter() - t_begin
@@ -270,6 +277,8 @@ class NativeUnitCollector:
         lap = (lambda what: sys.stderr.write("[NativeUnitCollector] %-22s %8.1f ms\n" % (what, (time.perf_counter() - t_begin) * 1e3))) if trace else (lambda what: None)
         if trace:
             sys.stderr.write("[NativeUnitCollector] %-22s %8.1f ms (at take(), on the caller's thread)\n" % ("site arrays (python)", prep_s * 1e3))
+        if self.geometry == "reader":
+            return self._run_records(prepared, engine, flags, kw, lap)
         for k, (nbam, (bps, win)) in enumerate(zip(self.bams, prepared)):
             rgs, idx = self.rg_tables[k]
             with _READER_TURN:      # (two chunks in flight under ChunkPipeline: one reads, the other is on the device)
@@ -293,6 +302,50 @@ class NativeUnitCollector:
                 gt = rec["gt"]
                 q = np.where(gt >= 0, q + rec["sq"], np.where(gt == ev.GT_BLANK, 0.0, q))
             res.site_qual = q
+        return res
+
+
+    def _run_records(self, prepared, engine: Engine, flags: int, kw: dict, lap) -> Results:
+        """geometry="reader": evidence records straight from the reader, ONE canonical batch over all samples (units
+        site-major, sample-minor: what UnitCollector builds, and what keeps QUAL on the device)."""
+        import numpy as np
+        n_samp = len(self.samples)
+        n_sites = int(prepared[0][0].shape[0])
+        flank = [float(t.mean) + float(t.sd) * 3 for t in self.lib_tables]       # (svt_batch_create_from_fragments' v_nondel)
+        per_sample = []
+        for k, (nbam, (bps, win)) in enumerate(zip(self.bams, prepared)):
+            rgs, idx = self.rg_tables[k]
+            with _READER_TURN:
+                off, recs, skipped = nbam.evidence(win, bps, rgs, idx, self.max_reads, self.count_mode, flank, self.min_aligned,
+                                                   SPLIT_SLOP, self.n_threads)
+            lap("svt_bam_evidence")
+            units = np.zeros(n_sites, ev.UNIT_DTYPE)
+            units["var_length"] = np.where(bps["svtype"] == ev.SVTYPE_CODE["DEL"], bps["var_length"], 0)
+            units["pos_delta"] = np.clip(bps["pos_b"].astype(np.int64) - bps["pos_a"].astype(np.int64), -2**31, 2**31 - 1)   # classic.py:339
+            units["sample"], units["svtype"] = k, bps["svtype"]
+            units["flags"] = np.where(skipped != 0, ev.UNIT_SKIP, 0)
+            units["libs"] = self.sample_libs[k]
+            per_sample.append((off, units, recs))
+        if n_samp == 1:
+            off, units, recs = per_sample[0]
+            batch = EvidenceBatch(off, units, recs, self.lib_tables, self.split_weight, self.disc_weight)
+        else:
+            # site-major, sample-minor: unit (site i, sample k) takes the k-th slice of site i -- counts interleaved, records
+            # copied slice by slice through one fancy index (16 bytes per fragment, not the 128 of a summary)
+            counts = np.stack([np.diff(p[0].astype(np.int64)) for p in per_sample], axis=1)          # [site, sample]
+            off = np.zeros(n_sites * n_samp + 1, np.uint64)
+            np.cumsum(counts.reshape(-1), out=off[1:].view(np.int64))
+            units = np.stack([p[1] for p in per_sample], axis=1).reshape(-1)
+            recs = np.empty(int(off[-1]), ev.RECORD_DTYPE)
+            dst0 = off[:-1].astype(np.int64).reshape(n_sites, n_samp)
+            for k, (soff, _u, srecs) in enumerate(per_sample):
+                n_k = counts[:, k]
+                if int(n_k.sum()):
+                    dst = np.repeat(dst0[:, k] - soff[:-1].astype(np.int64), n_k) + np.arange(int(n_k.sum()), dtype=np.int64)
+                    recs[dst] = srecs
+            batch = EvidenceBatch(off, units, recs, self.lib_tables, self.split_weight, self.disc_weight)
+        res = engine(batch, flags, **kw)
+        lap("engine (canonical batch)")
         return res
 
 

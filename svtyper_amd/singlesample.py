@@ -177,9 +177,10 @@ def sso_genotype(bam_string, vcf_in, vcf_out, min_aligned, split_weight, disc_we
     vcf.write_header(vcf_out)
 
     logit("Genotyping Input VCF (%s Mode)" % ("Serial" if cores is None else "Parallel"))
-    if reader == "native":      # C++ fetch + summariser (cores = its thread count), device geometry
+    if reader == "native":      # C++ fetch + summariser (cores = its thread count); geometry in the reader's threads ("host") or on the device
         collector = NativeUnitCollector([sample], [native], split_weight, disc_weight, min_aligned,
-                                        COUNT_SSO, max_reads, n_threads=cores or 0)
+                                        COUNT_SSO, max_reads, n_threads=cores or 0,
+                                        geometry="device" if geometry == "device" else "reader")
     elif reader == "python":
         collector = UnitCollector([sample], split_weight, disc_weight, min_aligned, geometry)
     else:

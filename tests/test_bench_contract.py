@@ -87,7 +87,8 @@ def test_bench_line_has_the_contract_keys(hip_device):
         leg = real[key]
         assert leg["sites"] > 0 and leg["fragments"] > 0 and leg["sites_per_s"] > 0 and leg["columns"] == leg["sites"]
         assert set(leg["stage_ms"]) == {"site_arrays_python", "inflate_fetch_summarise_host", "h2d_plus_geometry_kernel", "genotype_pass", "results_d2h", "format_columns_host"}
-        assert all(v >= 0 for v in leg["stage_ms"].values()) and leg["h2d_bytes"] == 128 * leg["fragments"]
+        assert all(v >= 0 for v in leg["stage_ms"].values()) and leg["h2d_bytes"] == 16 * leg["fragments"] + 24 * leg["sites"]
+        assert leg["geometry"] == "reader" and leg["device_geometry"]["same_genotypes"] is True and leg["device_geometry"]["h2d_bytes"] > 7 * leg["h2d_bytes"]
     assert real["fixture_x100"]["sites"] == 21100
     sh = d["shard_of_8"]
     assert sh["results_equal_headline"] is True and 0 < sh["units"] < 30000 and sh["speedup_vs_headline"] > 0

@@ -184,7 +184,8 @@ def test_synthetic_bam_all_paths_agree(tmp_path, hip_device, driver):
 
     want = run(str(tmp_path / "oracle.vcf"), engine=T.oracle_engine)
     assert want.count("\n") > 40 and "\t0/1:" in want or "\t1/1:" in want or "\t0/0:" in want
-    for name, kw in (("host", {}), ("device", dict(geometry="device")), ("native", dict(geometry="device", reader="native"))):
+    for name, kw in (("host", {}), ("device", dict(geometry="device")), ("native", dict(geometry="device", reader="native")),
+                     ("native_records", dict(reader="native"))):
         got = run(str(tmp_path / (name + ".vcf")), **kw)
         assert got == want, "%s path differs from the oracle-engine output" % name
 

@@ -233,3 +233,20 @@ def test_classic_two_bams_sum_quals(tmp_path):
     assert len(got) == len(want)
     for i, (x, y) in enumerate(zip(got, want)):
         assert x == y, "line %d\n%s\n%s" % (i + 1, x, y)
+
+
+@pytest.mark.parametrize("driver", ["classic", "sso"])
+def test_native_reader_with_the_oracle_engine(tmp_path, driver, monkeypatch):
+    """reader="native" with the geometry predicates in the reader's threads (svt_bam_evidence) hands canonical evidence
+    batches to ANY engine: here the CPU oracle, in chunks of 17 units -- the expected VCF, byte for byte, without a GPU."""
+    out = str(tmp_path / "out.vcf")
+    with open(IN_VCF) as inf, open(out, "w") as outf:
+        if driver == "classic":
+            monkeypatch.setattr(classic, "CHUNK_UNITS", 17)
+            classic.sv_genotype(IN_BAM, inf, outf, 20, 1, 1, 1000000, LIB_JSON, False, None, None, False, None, 1e10,
+                                engine=oracle_engine, reader="native")
+        else:
+            monkeypatch.setattr(singlesample, "CHUNK_UNITS", 17)
+            singlesample.sso_genotype(IN_BAM, inf, outf, 20, 1, 1, 1000000, LIB_JSON, False, None, False, 1000, 1e10,
+                                      None, 1000, engine=oracle_engine, reader="native")
+    same_vcf(EXPECTED, out)

@@ -73,11 +73,14 @@ def test_three_samples_blank_in_the_middle_oracle_engine(tmp_path, sum_quals):
     assert len(body) == 5 and all(len(r) == 12 for r in body)
     assert sum(r[10].startswith("./.:.:0:0:0") for r in body) == 3       # the middle sample is blank at u1 and the BND pair
     _same(_run(tmp_path, "oracle", sum_quals, engine=T.oracle_engine), want)
+    # ... and with the native reader handing evidence records of the three BAMs to the same engine (units interleaved
+    # site-major over the samples by NativeUnitCollector._run_records)
+    _same(_run(tmp_path, "oracle_native", sum_quals, engine=T.oracle_engine, reader="native"), want)
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("sum_quals", [True, False])
-@pytest.mark.parametrize("kw", [{}, {"geometry": "device"}, {"geometry": "device", "reader": "native"}],
-                         ids=["host", "device-geometry", "native-reader"])
+@pytest.mark.parametrize("kw", [{}, {"geometry": "device"}, {"geometry": "device", "reader": "native"}, {"reader": "native"}],
+                         ids=["host", "device-geometry", "native-reader", "native-reader-own-geometry"])
 def test_three_samples_blank_in_the_middle_hip(tmp_path, hip_device, sum_quals, kw):
     _same(_run(tmp_path, "hip", sum_quals, **kw), _golden(sum_quals))

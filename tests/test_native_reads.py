@@ -290,3 +290,65 @@ def test_odd_records_do_not_end_the_run():
     assert not r.cigar
     f = fr.SamFragment(r, _L())
     assert f.num_primary == 1 and f.split_reads == []
+
+
+def _python_records(sites, sample, mode, max_reads, min_aligned=20, split_slop=3):
+    """the units' evidence records through the Python reader + packer (the reference's predicates restated in packer.py)"""
+    from svtyper_amd import evidence as ev, packer
+    lib_index = {id(lib): i for i, lib in enumerate(sample.lib_dict.values())}
+    offs, recs, skipped = [0], [], []
+    for s in sites:
+        bp = s["breakpoint"]
+        frags, many = (classic.gather_all_reads if mode == nr.COUNT_CLASSIC else singlesample.gather_reads)(sample, bp, max_reads)
+        a = packer.pack_fragments(frags, bp, lib_index, min_aligned, split_slop) if frags and not many else np.zeros(0, ev.RECORD_DTYPE)
+        recs.append(a)
+        offs.append(offs[-1] + len(a))
+        skipped.append(1 if many else 0)
+    return np.asarray(offs, np.uint64), np.concatenate(recs), np.asarray(skipped, np.uint8)
+
+
+def _native_records(sites, sample, nbam, mode, max_reads, threads, min_aligned=20, split_slop=3):
+    tid_of = nbam.gettid
+    bps = np.concatenate([geo.breakpoint_record(s["breakpoint"], tid_of) for s in sites])
+    win = np.zeros(len(sites), nr.FETCH_DTYPE)
+    for k, s in enumerate(sites):
+        bp = s["breakpoint"]
+        for side, (t, lo, hi) in (("A", ("tid_a", "lo_a", "hi_a")), ("B", ("tid_b", "lo_b", "hi_b"))):
+            chrom, a, b = pipeline.fetch_window(sample, bp[side]["chrom"], bp[side]["pos"], bp[side]["ci"],
+                                                as_int=(mode == nr.COUNT_SSO))
+            win[t][k], win[lo][k], win[hi][k] = tid_of(chrom), int(a), int(b)
+    rgs = list(sample.rg_to_lib.keys())
+    libs = list(sample.lib_dict.values())
+    rg_lib = [libs.index(sample.rg_to_lib[rg]) if sample.rg_to_lib[rg].name in sample.active_libs else -1 for rg in rgs]
+    flank = [float(lib.mean) + float(lib.sd) * 3 for lib in libs]
+    return nbam.evidence(win, bps, rgs, rg_lib, max_reads, mode, flank, min_aligned, split_slop, threads)
+
+
+@pytest.mark.parametrize("mode,max_reads,threads,min_aligned", [
+    (nr.COUNT_CLASSIC, None, 3, 20), (nr.COUNT_SSO, 1000, 2, 20), (nr.COUNT_SSO, 120, 1, 20), (nr.COUNT_CLASSIC, None, 2, 34)])
+def test_evidence_records_equal_the_python_packer(setup, mode, max_reads, threads, min_aligned):
+    """svt_bam_evidence (the geometry predicates of svt_geometry_math.h in the reader's threads) against the Python reader +
+    packer.py on the fixture's 211 sites: the 16-byte records, their offsets and the skip flags, byte for byte."""
+    sites, sample, nbam = setup
+    want = _python_records(sites, sample, mode, max_reads, min_aligned)
+    got = _native_records(sites, sample, nbam, mode, max_reads, threads, min_aligned)
+    assert np.array_equal(got[2], want[2]) and np.array_equal(got[0], want[0])
+    assert got[1].tobytes() == want[1].tobytes()
+    assert len(want[1]) > 5000 or want[2].any()
+    assert (want[1]["flags"] & 1).any() and want[1]["seq_l"].any() and want[1]["rs_a"].any()      # (the predicates are exercised)
+
+
+def test_evidence_rejects_a_library_outside_the_table(setup):
+    sites, sample, nbam = setup
+    from svtyper_amd import hip
+    tid_of = nbam.gettid
+    bps = np.concatenate([geo.breakpoint_record(s["breakpoint"], tid_of) for s in sites[:3]])
+    win = np.zeros(3, nr.FETCH_DTYPE)
+    for k, s in enumerate(sites[:3]):
+        bp = s["breakpoint"]
+        win["tid_a"][k] = win["tid_b"][k] = tid_of(bp["A"]["chrom"])
+        win["lo_a"][k], win["hi_a"][k] = max(0, bp["A"]["pos"] - 500), bp["A"]["pos"] + 500
+        win["lo_b"][k], win["hi_b"][k] = max(0, bp["B"]["pos"] - 500), bp["B"]["pos"] + 500
+    rgs = list(sample.rg_to_lib.keys())
+    with pytest.raises(hip.SvtyperHipError):
+        nbam.evidence(win, bps, rgs, [5] * len(rgs), None, nr.COUNT_CLASSIC, [400.0], 20, 3, 1)     # library 5 of a table of 1
