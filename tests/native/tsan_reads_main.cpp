@@ -69,6 +69,29 @@ int main(int argc, char** argv)
         std::printf("threads %d units %zu fragments %llu hash %016llx\n", threads, win.size(), (unsigned long long)total, (unsigned long long)h);
         svt_summaries_free(&s);
     }
+    // the same units as evidence records (svt_bam_evidence: the geometry predicates in the workers)
+    int32_t max_lib = 0;
+    for (int32_t l : libs) max_lib = l > max_lib ? l : max_lib;
+    std::vector<double> flank((size_t)max_lib + 1, 400.0);
+    svt_evidence_params g{};
+    g.n_libs = (uint32_t)flank.size();
+    g.lib_flank = flank.data();
+    g.min_aligned = 20;
+    g.split_slop = 3;
+    for (int threads : {1, 8, 8}) {
+        a.n_threads = threads;
+        svt_evidence e{};
+        const int rc = svt_bam_evidence(bam, &a, &g, &e);
+        if (rc != 0) { std::printf("evidence threads %d rc %d: %s\n", threads, rc, svt_last_error()); return 7; }
+        const uint64_t total = e.rec_offset[win.size()];
+        uint64_t h = 1469598103934665603ull;
+        auto mix = [&](const void* p, size_t n) { for (size_t i = 0; i < n; ++i) h = (h ^ static_cast<const uint8_t*>(p)[i]) * 1099511628211ull; };
+        mix(e.rec_offset, (win.size() + 1) * sizeof(uint64_t));
+        mix(e.skipped, win.size());
+        mix(e.records, total * sizeof(svt_record));
+        std::printf("evidence threads %d units %zu records %llu hash %016llx\n", threads, win.size(), (unsigned long long)total, (unsigned long long)h);
+        svt_evidence_free(&e);
+    }
     svt_bam_close(bam);
     return 0;
 }

@@ -99,7 +99,8 @@ def test_thread_runner_under_thread_sanitizer(tmp_path):
     if r.returncode != 0 and "libtsan" in r.stderr.lower():
         pytest.skip("this g++ has no ThreadSanitizer runtime")
     assert r.returncode == 0, r.stderr[-2000:]
-    r = subprocess.run([exe], env=dict(os.environ, TSAN_OPTIONS="halt_on_error=1"), capture_output=True, text=True, timeout=300)
+    env = {k: v for k, v in os.environ.items() if k != "LD_PRELOAD"}      # (this file also runs under a preloaded ASan runtime)
+    r = subprocess.run([exe], env=dict(env, TSAN_OPTIONS="halt_on_error=1"), capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.strip() == "ok" and "ThreadSanitizer" not in r.stderr, (r.returncode, r.stdout, r.stderr[-3000:])
 
 

@@ -133,7 +133,7 @@ def test_native_reader_under_thread_sanitizer(tmp_path):
             raise StopIteration
 
     cap = Capture()
-    coll = pipeline.NativeUnitCollector([sample], [cap], 1.0, 1.0, 20, nr.COUNT_SSO, 1000)
+    coll = pipeline.NativeUnitCollector([sample], [cap], 1.0, 1.0, 20, nr.COUNT_SSO, 1000, geometry="device")
     for _ in range(3):
         for bp in sites:
             coll.add_site(bp)
@@ -144,6 +144,8 @@ def test_native_reader_under_thread_sanitizer(tmp_path):
                        env=dict(os.environ, TSAN_OPTIONS="halt_on_error=1"), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "ThreadSanitizer" not in r.stderr, (r.stdout[-1000:], r.stderr[-3000:])
     lines = r.stdout.strip().splitlines()
-    assert len(lines) == 3 and lines[0].startswith("threads 1 units %d " % (3 * len(sites))), lines
-    assert len({l.split(" units ")[1] for l in lines}) == 1, lines          # same fragments, same bytes
+    assert len(lines) == 6 and lines[0].startswith("threads 1 units %d " % (3 * len(sites))), lines
+    assert len({l.split(" units ")[1] for l in lines[:3]}) == 1, lines      # summaries: same fragments, same bytes
+    assert len({l.split(" units ")[1] for l in lines[3:]}) == 1, lines      # evidence records (svt_bam_evidence): the same
+    assert all(l.startswith("evidence threads ") for l in lines[3:])
     assert int(lines[0].split(" fragments ")[1].split()[0]) > 10_000
