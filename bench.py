@@ -810,6 +810,9 @@ def main():
     first_timed_dispatch = (1 + args.steps + spun + args.warmup) if not tuned else None
 
     # ---- the timed region: EXACTLY `steps` passes, barrier + device sync on both sides
+    import gc
+    gc.collect()
+    gc.disable()     # (a collection of the interpreter's heap -- the workload's arrays are alive -- is not part of a pass)
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -817,9 +820,17 @@ def main():
     # (kern_ms: the dominant kernel's average launch duration over the timed region itself -- torch.cuda.Event
     # would only see torch's current stream)
     kern_ms = dbatch.genotype_timed(args.steps) / args.steps
+    t_passes = time.perf_counter()
     torch.cuda.synchronize()
+    t_sync = time.perf_counter()
     barrier()
     elapsed = time.perf_counter() - t0
+    gc.enable()
+    # where the host spent the timed region: `steps` launches + the wait for the last one (the HIP events inside measure the
+    # device's share, kernel_ms x steps), the device synchronisation, the barrier
+    timed_region_host = {"launch_and_wait_ms": (t_passes - t0) * 1e3, "device_sync_ms": (t_sync - t_passes) * 1e3,
+                         "barrier_ms": (elapsed - (t_sync - t0)) * 1e3, "device_ms_by_hip_events": kern_ms * args.steps,
+                         "host_ms_outside_the_events": (elapsed * 1e3 - kern_ms * args.steps)}
     if use_dist:
         t = torch.tensor([elapsed, kern_ms], dtype=torch.float64, device=coll_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -979,6 +990,7 @@ def main():
                 "frac_tuned": roof["frac"] if tuned else None,
                 "frac_cold": alg_bytes / (cold_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "frac_untuned_median": None,
+                "timed_region_host": timed_region_host,
                 "timed_region_dispatches": {"first": first_timed_dispatch, "count": args.steps,
                                             "note": "0-based index, among this process's dispatches of the headline kernel, of the timed region's first "
                                                     "launch (null after a placement audition, whose launch count is not fixed)"},

@@ -71,6 +71,42 @@ __global__ __launch_bounds__(kBlock) void svt_site_qual_kernel(const unsigned ch
     qual[site] = q;
 }
 
+// The same over TAGGED 96-byte records (SVT_FLAG_RESULT96): they lie in the order the pass's workgroups finished them, each
+// carrying the index it belongs at (svt_result96.unit; site-major after svt_batch_result_order), so a site's samples are not
+// neighbours.  Two launches instead of 128 bytes per unit over PCIe and a host loop: (1) every slot puts the two fields QUAL
+// needs -- SQ and GT, 16 bytes -- where its tag says (records read as whole lines, one 16-byte store per unit); (2) the running
+// sum of classic.py:485,498 over a site's entries, in sample order: the same operands in the same order as the kernel above.
+struct QualEntry { double sq; int64_t gt; };
+static_assert(sizeof(QualEntry) == 16, "one 16-byte store per unit");
+
+__global__ __launch_bounds__(kBlock) void svt_site_qual_scatter_kernel(const svt_result96* __restrict__ rec, uint64_t n_slots, uint64_t n_units,
+                                                                       QualEntry* __restrict__ entries, uint32_t* __restrict__ err)
+{
+    const uint64_t s = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (s >= n_slots) return;
+    const uint32_t unit = rec[s].unit;
+    if (unit == SVT_NO_UNIT) return;                       // padding of a workgroup's last tile
+    if (unit >= n_units) { atomicOr(err, 1u); return; }    // (not a record this batch's pass wrote)
+    QualEntry e;
+    e.sq = rec[s].sq;
+    e.gt = rec[s].gt;
+    entries[unit] = e;
+}
+
+__global__ __launch_bounds__(kBlock) void svt_site_qual_entries_kernel(const QualEntry* __restrict__ entries, uint32_t n_samples,
+                                                                       const double* __restrict__ initial, double* __restrict__ qual, uint64_t n_sites)
+{
+    const uint64_t site = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (site >= n_sites) return;
+    double q = initial ? initial[site] : 0.0;
+    const QualEntry* e = entries + site * n_samples;
+    for (uint32_t s = 0; s < n_samples; ++s) {
+        const QualEntry x = e[s];
+        if (x.gt >= 0) q += x.sq;                          // classic.py:485
+        else if (x.gt == SVT_GT_BLANK) q = 0.0;            // classic.py:498
+    }
+    qual[site] = q;
+}
 
 }  // namespace svt
 

@@ -2039,32 +2039,31 @@ static int svt_batch_site_qual_impl(svt_batch* b, uint32_t n_samples, const doub
     if (n_sites == 0) return SVT_OK;
     HIP_TRY(hipSetDevice(b->device));
     SVT_TRY(check_stream_errors(b));   // (after svt_batch_genotype(b, 0) / _n nobody has looked at the contract word yet)
-    if (b->flags & SVT_FLAG_RESULT96) {
-        // tagged records lie in the kernel's order, not site by site: QUAL is the same running sum (classic.py:485,498) over the
-        // records brought down and put in order
-        std::vector<svt_result> res(b->n_units);
-        HIP_TRY(hipStreamSynchronize(b->stream));
-        SVT_TRY(d2h_results(b, res.data()));
-        parallel_for((n_sites + 4095) / 4096, [&](uint64_t c) {
-            for (uint64_t site = c * 4096; site < std::min(n_sites, (c + 1) * 4096); ++site) {
-                double q = initial ? initial[site] : 0.0;
-                const svt_result* r = res.data() + site * n_samples;
-                for (uint32_t k = 0; k < n_samples; ++k) {
-                    if (r[k].gt >= 0) q += r[k].sq;
-                    else if (r[k].gt == SVT_GT_BLANK) q = 0.0;
-                }
-                qual_out[site] = q;
-            }
-        });
-        return SVT_OK;
-    }
-    DevScratch d_init, d_qual;
+    DevScratch d_init, d_qual, d_entries, d_flag;
     SVT_TRY(d_qual.alloc(n_sites * sizeof(double)));
     if (initial) {
         SVT_TRY(d_init.alloc(n_sites * sizeof(double)));
         Stager st(b->stream);
         SVT_TRY(st.copy(d_init.p, initial, n_sites * sizeof(double)));
         SVT_TRY(st.finish());
+    }
+    if (b->flags & SVT_FLAG_RESULT96) {
+        // tagged records lie in the kernel's order, not site by site: SQ and GT of every slot go where its tag says (16 bytes per
+        // unit of device scratch), then the same running sum over a site's entries (svt_bayes_kernel.h) -- nothing but the
+        // QUAL values crosses PCIe (this used to bring every record down: 2 GB and 0.6 s for the 16 M units of configs[4])
+        SVT_TRY(d_entries.alloc(b->n_units * sizeof(QualEntry)));
+        SVT_TRY(d_flag.alloc(sizeof(uint32_t)));
+        HIP_TRY(hipMemsetAsync(d_flag.p, 0, sizeof(uint32_t), b->stream));
+        hipLaunchKernelGGL(svt_site_qual_scatter_kernel, dim3((unsigned)((b->out_slots + kBlock - 1) / kBlock)), dim3(kBlock), 0, b->stream,
+                           reinterpret_cast<const svt_result96*>(b->out_dev), b->out_slots, b->n_units, d_entries.as<QualEntry>(), d_flag.as<uint32_t>());
+        HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(svt_site_qual_entries_kernel, dim3((unsigned)((n_sites + kBlock - 1) / kBlock)), dim3(kBlock), 0, b->stream,
+                           d_entries.as<QualEntry>(), n_samples, initial ? d_init.as<double>() : nullptr, d_qual.as<double>(), n_sites);
+        HIP_TRY(hipGetLastError());
+        uint32_t bad = 0;
+        SVT_TRY(d2h_staged(&bad, d_flag.p, sizeof bad, b->stream));
+        if (bad) return fail(SVT_ERR_INTERNAL, "svt_batch_site_qual: a result record carries a unit beyond the batch");
+        return d2h_staged(qual_out, d_qual.p, n_sites * sizeof(double), b->stream);
     }
     hipLaunchKernelGGL(svt_site_qual_kernel, dim3((unsigned)((n_sites + kBlock - 1) / kBlock)), dim3(kBlock), 0, b->stream,
                        reinterpret_cast<const unsigned char*>(b->out_dev), (uint32_t)sizeof(svt_result), (uint32_t)offsetof(svt_result, gt), n_samples,

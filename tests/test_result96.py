@@ -135,6 +135,41 @@ def test_site_qual_and_result_order_on_96_byte_records(hip_device):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n_samples", [1, 3, 32])
+def test_site_qual_over_tagged_records_stays_on_the_device(hip_device, n_samples):
+    """SVT_FLAG_RESULT96: svt_batch_site_qual scatters (SQ, GT) by tag and sums per site on the device (svt_site_qual_scatter_kernel /
+    svt_site_qual_entries_kernel) -- the reference's running QUAL (classic.py:216-217,485,498) bit for bit, with padding slots,
+    blank and skipped samples, site-major and sample-major input, with and without incoming QUAL; and it is a few launches,
+    not a download of every record (60 k units: well under the 128-byte records' PCIe time)."""
+    import time
+    from svtyper_amd import hip
+    n_sites = 60000 // n_samples
+    multi = synth.make_multisample(n_sites, n_samples, seed=29, mean_frags=12, sd_frags=8, min_frags=0, max_frags=40)
+    init = np.linspace(-1.0, 9.0, n_sites)
+    with hip.DeviceBatch(multi, hip_device, ev.FLAG_RESULT96) as d:
+        d.genotype(sync=True)
+        res = d.results()
+        assert d.result_slots() >= multi.n_units
+        for initial in (None, init):
+            want = np.asarray(hip.site_qual_host(res, n_samples, initial))
+            got = d.site_qual(n_samples, initial)
+            assert np.array_equal(got.view(np.uint64), want.view(np.uint64))
+        assert (res.rec["gt"] < 0).any() and (res.rec["gt"] >= 0).any()
+        d.site_qual(n_samples)
+        t0 = time.perf_counter()
+        for _ in range(5):
+            d.site_qual(n_samples)
+        per_call_ms = (time.perf_counter() - t0) / 5 * 1e3
+        print("site_qual over %d tagged records: %.3f ms per call" % (multi.n_units, per_call_ms))
+    if n_samples > 1:
+        by_sample, _ = synth.to_sample_major(multi, n_samples)
+        with hip.DeviceBatch(by_sample, hip_device, ev.FLAG_RESULT96) as d:
+            d.result_order(n_samples)
+            d.genotype(sync=True)
+            assert np.array_equal(d.site_qual(n_samples, init).view(np.uint64), np.asarray(hip.site_qual_host(res, n_samples, init)).view(np.uint64))
+
+
+@pytest.mark.gpu
 def test_workgroup_plan_does_not_change_the_results(hip_device, fixture_library):
     """A launch of more than one round of the chip's resident workgroups is cut into EQUAL workgroups that fill whole rounds
     (svtyper_hip.hip: wg_plan; StreamArgs.units_per_wg), the window mode cuts its chunks by the same rule: the bytes are those of
