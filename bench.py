@@ -504,10 +504,12 @@ def real_data_leg(device: int) -> dict:
         for _ in range(2):     # (the first run pays the pooled device buffers; keep the better one)
             eng = Timed()
             coll = pipeline.NativeUnitCollector([sample], [nbam], 1.0, 1.0, 20, nr.COUNT_SSO, 1000, n_threads=threads, geometry=geometry)
+            a0 = time.perf_counter()
             for _r in range(repeat):
                 for bp in sites:
                     coll.add_site(bp)
             t0 = time.perf_counter()
+            add_ms = (t0 - a0) * 1e3
             job = coll.take(eng, ev.FLAG_SSO_ASSOCIATION)     # (the sites' fields -> arrays, Python)
             t_prep = time.perf_counter()
             res = job()
@@ -520,6 +522,9 @@ def real_data_leg(device: int) -> dict:
                    "stage_ms": {"site_arrays_python": (t_prep - t0) * 1e3, "inflate_fetch_summarise_host": (t1 - t_prep - dev) * 1e3,
                                 "h2d_plus_geometry_kernel": eng.t["create_h2d_geometry"] * 1e3, "genotype_pass": eng.t["pass"] * 1e3,
                                 "results_d2h": eng.t["results_d2h"] * 1e3, "format_columns_host": (t2 - t1) * 1e3},
+                   # (the collector's add_site() per site -- the driver's per-variant loop -- lies in front of `wall_ms`; the chunked run
+                   # below has it inside its wall time, so compare `overlapped_wall_ms` with `wall_incl_add_sites_ms`)
+                   "add_sites_python_ms": add_ms, "wall_incl_add_sites_ms": (t2 - t0) * 1e3 + add_ms,
                    "geometry": geometry, "h2d_bytes": int(eng.h2d_bytes), "fragments_per_site": eng.fragments / max(1, len(sites) * repeat),
                    "gt_histogram": {str(k): int(v) for k, v in zip(*np.unique(res.gt, return_counts=True))}, "columns": len(cols)}
             if best is None or leg["wall_ms"] < best["wall_ms"]:
