@@ -1,0 +1,39 @@
+#!/usr/bin/env python
+"""What state does bench.py's timed region find the device in?  One resident headline batch (tuned like bench.py's), then
+(a) idle 2 s -> spin-up of S ms -> 3 warm-up passes -> 20 timed passes, for S in 0 ... 320, twice; (b) after 2 s of idling,
+groups of 10 passes back to back for ~0.5 s (the pass time as the device comes out of idle and stays loaded).
+   python tools/timed_state_probe.py [result_candidates record_candidates]"""
+import os, sys, time
+sys.path.insert(0, os.getcwd())
+import bench
+from svtyper_amd import evidence as ev, hip
+b = bench.generate("c3_mixed_1m", 1_000_000, 0, bench.usable_cpus())
+rc = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (32, 8)
+with hip.DeviceBatch(b, 0, ev.FLAG_RESULT96) as d:
+    d.genotype(sync=True)
+    cold = d.genotype_timed(20) / 20
+    bench.spin_up(d, 40.0)
+    if rc[0] or rc[1]:
+        r = d.tune_placement(*rc)
+        print("cold %.4f ms; audition %s" % (cold, r), flush=True)
+    for rep in range(2):
+        for spin in (0, 5, 10, 20, 40, 80, 160, 320):
+            time.sleep(2.0)
+            n = bench.spin_up(d, float(spin)) if spin else 0
+            for _ in range(3):
+                d.genotype(sync=False)
+            d.genotype(sync=True)
+            a = d.genotype_timed(20) / 20
+            c = d.genotype_timed(20) / 20
+            print("idle 2 s, spin-up %3d ms (%4d passes): timed 20 -> %.4f ms, the next 20 -> %.4f" % (spin, n, a, c), flush=True)
+    time.sleep(2.0)
+    t0 = time.perf_counter()
+    line = []
+    while time.perf_counter() - t0 < 0.6:
+        line.append("%.0f:%.4f" % ((time.perf_counter() - t0) * 1e3, d.genotype_timed(10) / 10))
+    print("after 2 s idle, groups of 10 (ms since start : pass ms):\n" + " ".join(line), flush=True)
+    for idle in (0.0, 0.1, 0.5, 1.0):
+        bench.spin_up(d, 400.0)
+        time.sleep(idle)
+        bench.spin_up(d, 40.0)
+        print("400 ms of passes, idle %.1f s, spin-up 40 ms: timed 20 -> %.4f ms" % (idle, d.genotype_timed(20) / 20), flush=True)
