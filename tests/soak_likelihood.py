@@ -93,12 +93,18 @@ while time.time() - t0 < budget:
                             sys.exit(1)
     if by_sample > 1:   # the same units handed over sample-major, result records written site-major (svt_batch_result_order)
         sm, _ = synth.to_sample_major(b, by_sample)
-        for flags in (0, ev.FLAG_SSO_ASSOCIATION):
+        for flags in (0, ev.FLAG_SSO_ASSOCIATION, ev.FLAG_RESULT96, ev.FLAG_RESULT96 | ev.FLAG_SSO_ASSOCIATION):
             with hip.DeviceBatch(sm, 0, flags) as d:
                 d.result_order(by_sample)
                 d.genotype(sync=True)
-                if d.results().rec.tobytes() != hip.genotype_batch(b, 0, flags).rec.tobytes():
+                got = d.results()
+                if got.rec.tobytes() != hip.genotype_batch(b, 0, flags & ev.FLAG_SSO_ASSOCIATION).rec.tobytes():
                     print("RESULT-ORDER MISMATCH at iteration %d (kind %d, %d samples, flags %d)" % (it, kind, by_sample, flags))
+                    sys.exit(1)
+                # QUAL on the device (128-byte records site-major; tagged 96-byte records scattered by tag) = the host's running sum
+                init = rng.uniform(-3.0, 40.0, b.n_units // by_sample) if rng.random() < 0.5 else None
+                if d.site_qual(by_sample, init).tobytes() != np.asarray(hip.site_qual_host(got, by_sample, init)).tobytes():
+                    print("SITE-QUAL MISMATCH at iteration %d (kind %d, %d samples, flags %d)" % (it, kind, by_sample, flags))
                     sys.exit(1)
     try:                # the packed evidence format, where it can hold the batch: same bytes as the canonical pass
         packed = hip.PackedEvidence(b)
