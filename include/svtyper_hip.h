@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SVT_ABI_VERSION 15
+#define SVT_ABI_VERSION 16
 
 /* ---- error codes (0 = ok, <0 = error; text via svt_last_error()) ---------- */
 #define SVT_OK 0
@@ -319,6 +319,21 @@ const char* svt_last_error(void);
  * classic.py:279-296 / the `sam_fragments` argument of singlesample.py:355.     */
 int svt_batch_create(const svt_evidence_batch* in, int device, unsigned flags,
                      svt_batch** out);
+
+/* The same with the RECORDS handed over in pieces (ABI 16): `in->records` is ignored; the record array of the batch is the
+ * concatenation of `segments[0 .. n_segments)` (their lengths add up to in->rec_offset[in->n_units]; a segment may be empty,
+ * unit boundaries need not coincide with segment boundaries).  For a joint run over several samples whose evidence comes from
+ * one reader per sample (svt_bam_evidence: one record array per BAM): the units go in SAMPLE-major -- rec_offset / units
+ * concatenated by the caller, 24 bytes per unit -- every sample's records go up from where its reader left them, and
+ * svt_batch_result_order makes the pass write the result records site-major.  Nobody concatenates or interleaves 16 bytes per
+ * fragment on the host (classic.py:279-296 walks samples inside sites; the evidence is produced sample by sample).
+ * Same validation, same errors and the same batch as svt_batch_create over the concatenated array.                         */
+typedef struct svt_record_segment {
+    const svt_record* records;
+    uint64_t n_records;
+} svt_record_segment;
+int svt_batch_create_segments(const svt_evidence_batch* in, const svt_record_segment* segments, uint32_t n_segments,
+                              int device, unsigned flags, svt_batch** out);
 
 /* One pass of the hot path over the resident batch: tally -> zeroing rules ->
  * QR/QA -> bayes_gt -> GT/GQ/SQ, results left in HBM.  Asynchronous on the

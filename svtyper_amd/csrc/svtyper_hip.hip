@@ -1588,6 +1588,90 @@ int svt_batch_create(const svt_evidence_batch* in, int device, unsigned flags, s
     return guarded([&] { return svt_batch_create_impl(in, device, flags, out); });
 }
 
+// svt_batch_create with the records in pieces (include/svtyper_hip.h): create_stream leaves the record upload to this function
+// (as it does for the pipelined one-shot), every segment goes through the staging ring to its place in the device array.  A
+// batch whose library windows have to be read off the records (several libraries, units without hints) needs the records
+// while it is created: its segments are put together in page-locked scratch first -- the rare case.
+static int svt_batch_create_segments_impl(const svt_evidence_batch* in, const svt_record_segment* segments, uint32_t n_segments,
+                                          int device, unsigned flags, svt_batch** out)
+{
+    if (!in || !out || (n_segments && !segments)) return fail(SVT_ERR_INVALID, "null argument");
+    *out = nullptr;
+    const uint64_t n = in->n_units;
+    if (n && !in->rec_offset) return fail(SVT_ERR_INVALID, "null unit arrays");
+    const uint64_t n_rec = n ? in->rec_offset[n] : 0;
+    uint64_t have = 0;
+    for (uint32_t k = 0; k < n_segments; ++k) {
+        if (segments[k].n_records && !segments[k].records) return fail(SVT_ERR_INVALID, "svt_batch_create_segments: null segment");
+        if (segments[k].n_records > n_rec - have) return fail(SVT_ERR_INVALID, "svt_batch_create_segments: the segments hold more records than rec_offset[n_units]");
+        have += segments[k].n_records;
+    }
+    if (have != n_rec) return fail(SVT_ERR_INVALID, "svt_batch_create_segments: the segments hold fewer records than rec_offset[n_units]");
+    svt_evidence_batch eb = *in;
+    eb.records = nullptr;
+    bool hinted = true;      // (create_stream's rule: the windows come from the hints only when every unit has one)
+    if (in->n_libs > 1 && in->units && !(flags & SVT_FLAG_GENERAL_TABLES))
+        for (uint64_t u = 0; u < n && hinted; ++u) hinted = ((in->units[u].libs >> 8) & 0xffu) != 0u;
+    if (!hinted || (flags & ~kKnownFlags) || n_rec == 0) {
+        struct Scratch { void* p = nullptr; ~Scratch() { g_pinned.put(p); } } scratch;
+        if (n_rec) {
+            scratch.p = g_pinned.get(n_rec * sizeof(svt_record));
+            if (!scratch.p) return fail(SVT_ERR_NOMEM, "out of page-locked host memory");
+            char* at = static_cast<char*>(scratch.p);
+            for (uint32_t k = 0; k < n_segments; ++k) {
+                std::memcpy(at, segments[k].records, segments[k].n_records * sizeof(svt_record));
+                at += segments[k].n_records * sizeof(svt_record);
+            }
+            eb.records = static_cast<const svt_record*>(scratch.p);
+        }
+        return svt_batch_create_impl(&eb, device, flags, out);
+    }
+    // the checks of svt_batch_create_impl (the records are not looked at on the host: the pass itself checks their contract)
+    if (n >= 0xFFFFFFF0ull) return fail(SVT_ERR_INVALID, "too many units in one batch (< 2^32)");
+    if (in->n_libs == 0 || in->n_libs > 256 || !in->libs) return fail(SVT_ERR_INVALID, "n_libs must be 1..256");
+    if (n && !in->units) return fail(SVT_ERR_INVALID, "null unit arrays");
+    if (n && in->rec_offset[0] != 0) return fail(SVT_ERR_INVALID, "rec_offset[0] must be 0");
+    if (!(in->split_weight >= 0.0) || !(in->disc_weight >= 0.0) || !std::isfinite(in->split_weight) || !std::isfinite(in->disc_weight))
+        return fail(SVT_ERR_INVALID, "weights must be finite and >= 0");
+    const int ndev = svt_device_count();
+    if (ndev <= 0) return fail(SVT_ERR_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(SVT_ERR_NO_DEVICE, "device index out of range");
+    HIP_TRY(hipSetDevice(device));
+    svt_batch* b = new (std::nothrow) svt_batch();
+    if (!b) return fail(SVT_ERR_NOMEM, "out of host memory");
+    b->device = device;
+    b->flags = flags;
+    b->layout = kLayoutStream;
+    b->n_units = n;
+    b->n_records = n_rec;
+    int rc = create_stream(&eb, b, nullptr, 0, /*defer_records=*/true);
+    if (rc == SVT_OK && b->records_resident) rc = fail(SVT_ERR_INTERNAL, "svt_batch_create_segments: create_stream wanted the records");
+    if (rc == SVT_OK) {
+        Stager st(b->stream);
+        char* at = static_cast<char*>(b->d_records);
+        for (uint32_t k = 0; k < n_segments && rc == SVT_OK; ++k) {
+            rc = st.copy(at, segments[k].records, segments[k].n_records * sizeof(svt_record));
+            at += segments[k].n_records * sizeof(svt_record);
+        }
+        if (rc == SVT_OK) rc = st.finish();
+        if (rc == SVT_OK) b->records_resident = true;
+    }
+    if (rc != SVT_OK) {
+        const std::string keep = g_err;
+        free_batch(b);
+        g_err = keep;
+        return rc;
+    }
+    *out = b;
+    return SVT_OK;
+}
+
+int svt_batch_create_segments(const svt_evidence_batch* in, const svt_record_segment* segments, uint32_t n_segments, int device,
+                              unsigned flags, svt_batch** out)
+{
+    return guarded([&] { return svt_batch_create_segments_impl(in, segments, n_segments, device, flags, out); });
+}
+
 static int svt_batch_create_from_fragments_impl(const svt_fragment_batch* in, int device, unsigned flags,
                                     svt_record* records_out, svt_batch** out)
 {

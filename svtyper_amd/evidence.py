@@ -246,6 +246,37 @@ class EvidenceBatch:
         return cb
 
 
+class SegmentedBatch:
+    """A CSR batch whose RECORD array is handed over in pieces (include/svtyper_hip.h: svt_batch_create_segments): the record
+    array of the batch is the concatenation of `segments`.  What a joint run builds from one reader per sample -- units
+    sample-major, every sample's records where its reader left them."""
+
+    def __init__(self, rec_offset, units, segments, libs, split_weight: float = 1.0, disc_weight: float = 1.0):
+        self.rec_offset = np.ascontiguousarray(rec_offset, dtype=np.uint64)
+        self.units = np.ascontiguousarray(units, dtype=UNIT_DTYPE)
+        self.segments = [np.ascontiguousarray(x, dtype=RECORD_DTYPE) for x in segments]
+        self.libs = libs
+        self.split_weight = split_weight
+        self.disc_weight = disc_weight
+        if self.rec_offset.shape[0] != self.units.shape[0] + 1:
+            raise ValueError("rec_offset must have n_units + 1 entries")
+        if self.units.shape[0] and int(self.rec_offset[-1]) != self.n_records:
+            raise ValueError("rec_offset[-1] must equal the number of records of all segments")
+
+    @property
+    def n_units(self) -> int:
+        return int(self.units.shape[0])
+
+    @property
+    def n_records(self) -> int:
+        return sum(int(x.shape[0]) for x in self.segments)
+
+    def joined(self) -> "EvidenceBatch":
+        """The same batch with its records in one array (a copy of 16 bytes per record)."""
+        recs = np.concatenate(self.segments) if self.segments else np.zeros(0, RECORD_DTYPE)
+        return EvidenceBatch(self.rec_offset, self.units, recs, self.libs, self.split_weight, self.disc_weight)
+
+
 class Results:
     """Result records (include/svtyper_hip.h: svt_result[n_units]), one 128-byte record per unit."""
 

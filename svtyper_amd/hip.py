@@ -16,10 +16,10 @@ from .evidence import GT_BLANK, CEvidenceBatch, CPackedEvidence, EvidenceBatch, 
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SVTYPER_HIP_LIB") or os.path.join(_HERE, "csrc", "libsvtyper_hip.so")
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 EXPORTS = (
-    "svt_version", "svt_device_count", "svt_last_error", "svt_batch_create", "svt_batch_create_from_fragments",
+    "svt_version", "svt_device_count", "svt_last_error", "svt_batch_create", "svt_batch_create_segments", "svt_batch_create_from_fragments",
     "svt_batch_genotype",
     "svt_batch_genotype_n", "svt_batch_sync", "svt_batch_genotype_timed", "svt_batch_tune_placement", "svt_batch_results", "svt_batch_device_results",
     "svt_batch_bind_device_results", "svt_batch_bind_device_results2", "svt_batch_result_order", "svt_batch_bytes", "svt_batch_layout", "svt_batch_site_qual",
@@ -62,6 +62,8 @@ def load() -> C.CDLL:
     L.svt_last_error.restype = C.c_char_p
     L.svt_batch_create.restype = C.c_int
     L.svt_batch_create.argtypes = [C.POINTER(CEvidenceBatch), C.c_int, C.c_uint, C.POINTER(C.c_void_p)]
+    L.svt_batch_create_segments.restype = C.c_int
+    L.svt_batch_create_segments.argtypes = [C.POINTER(CEvidenceBatch), C.c_void_p, C.c_uint32, C.c_int, C.c_uint, C.POINTER(C.c_void_p)]
     L.svt_batch_create_from_fragments.restype = C.c_int
     L.svt_batch_create_from_fragments.argtypes = [C.c_void_p, C.c_int, C.c_uint, C.c_void_p, C.POINTER(C.c_void_p)]
     L.svt_batch_genotype.restype = C.c_int
@@ -293,6 +295,29 @@ class DeviceBatch:
         self.device = int(device)
         cb = batch.as_c()
         _check(L.svt_batch_create(C.byref(cb), int(device), int(flags), C.byref(self._h)))
+
+    @classmethod
+    def from_segments(cls, sbatch, device: int = 0, flags: int = 0):
+        """svt_batch_create_segments: an evidence.SegmentedBatch -- the records go up piece by piece from where they lie
+        (one reader per sample of a joint run), nothing is concatenated on the host.  The same batch as
+        DeviceBatch(sbatch.joined())."""
+        from .evidence import EvidenceBatch, RECORD_DTYPE
+        L = load()
+        self = cls.__new__(cls)
+        self._lib = L
+        self._h = C.c_void_p()
+        self.n_units = sbatch.n_units
+        self.n_records = sbatch.n_records
+        self.device = int(device)
+        head = EvidenceBatch.__new__(EvidenceBatch)      # (the unit arrays and libraries; `records` is ignored by the call)
+        head.rec_offset, head.units, head.records = sbatch.rec_offset, sbatch.units, np.zeros(0, RECORD_DTYPE)
+        head.libs, head.split_weight, head.disc_weight, head._keep = sbatch.libs, sbatch.split_weight, sbatch.disc_weight, []
+        cb = head.as_c()
+        segs = np.zeros(max(1, len(sbatch.segments)), np.dtype([("records", "<u8"), ("n_records", "<u8")]))
+        for k, x in enumerate(sbatch.segments):
+            segs[k] = (x.ctypes.data if x.shape[0] else 0, x.shape[0])
+        _check(L.svt_batch_create_segments(C.byref(cb), segs.ctypes.data, len(sbatch.segments), int(device), int(flags), C.byref(self._h)))
+        return self
 
     @classmethod
     def from_fragments(cls, fbatch, device: int = 0, flags: int = 0, return_records: bool = False):

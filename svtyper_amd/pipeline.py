@@ -50,7 +50,22 @@ class HipEngine:
 
     supports_site_qual = True   # QUAL over a site's samples (classic.py:485,498) can stay on the device
 
-    def __call__(self, batch: EvidenceBatch, flags: int = 0, site_qual=None) -> Results:
+    # a joint run may hand its units over SAMPLE-major (unit = sample * n_sites + site: the order the per-sample readers
+    # produce them in); the pass writes the result records site-major (svt_batch_result_order), so nobody interleaves
+    # 16 bytes per fragment on the host
+    accepts_sample_major = True
+
+    def __call__(self, batch: EvidenceBatch, flags: int = 0, site_qual=None, sample_major: int = 0) -> Results:
+        if sample_major > 1:
+            from .evidence import SegmentedBatch
+            make = self._hip.DeviceBatch.from_segments if isinstance(batch, SegmentedBatch) else self._hip.DeviceBatch
+            with make(batch, self.device, flags) as d:
+                d.result_order(sample_major)
+                d.genotype(sync=True)
+                res = self._hip.host_sq(d.results())
+            if site_qual is not None:      # classic.py:485,498 over the refined SQ, as hip._finish does
+                res.site_qual = self._hip.site_qual_host(res, site_qual[0], site_qual[1])
+            return res
         res = self._hip.genotype_batch(batch, device=self.device, flags=flags, site_qual=site_qual)
         return res if site_qual is not None else self._hip.host_sq(res)   # SQ as the reference's libm gives it from GL
 
@@ -329,6 +344,20 @@ class NativeUnitCollector:
         if n_samp == 1:
             off, units, recs = per_sample[0]
             batch = EvidenceBatch(off, units, recs, self.lib_tables, self.split_weight, self.disc_weight)
+        elif getattr(engine, "accepts_sample_major", False):
+            # the engine takes the units as the readers left them, sample after sample: the unit arrays concatenated (24 bytes
+            # per unit), every sample's records from where its reader left them (evidence.SegmentedBatch ->
+            # svt_batch_create_segments), the result records written site-major by the pass -- no per-record work on the host
+            from .evidence import SegmentedBatch
+            counts = np.concatenate([np.diff(p[0].astype(np.int64)) for p in per_sample])
+            off = np.zeros(n_sites * n_samp + 1, np.uint64)
+            np.cumsum(counts, out=off[1:].view(np.int64))
+            batch = SegmentedBatch(off, np.concatenate([p[1] for p in per_sample]), [p[2] for p in per_sample],
+                                   self.lib_tables, self.split_weight, self.disc_weight)
+            lap("sample-major unit arrays")
+            res = engine(batch, flags, sample_major=n_samp, **kw)
+            lap("engine (canonical batch, sample-major)")
+            return res
         else:
             # site-major, sample-minor: unit (site i, sample k) takes the k-th slice of site i -- counts interleaved, records
             # copied slice by slice through one fancy index (16 bytes per fragment, not the 128 of a summary)
@@ -344,6 +373,7 @@ class NativeUnitCollector:
                     dst = np.repeat(dst0[:, k] - soff[:-1].astype(np.int64), n_k) + np.arange(int(n_k.sum()), dtype=np.int64)
                     recs[dst] = srecs
             batch = EvidenceBatch(off, units, recs, self.lib_tables, self.split_weight, self.disc_weight)
+            lap("site-major interleave")
         res = engine(batch, flags, **kw)
         lap("engine (canonical batch)")
         return res

@@ -522,6 +522,60 @@ def test_pooled_buffers_do_not_leak_state(hip_device, fixture_library):
     assert_parity(hip.genotype_batch(small, device=hip_device), want_small)
 
 
+def _segmented(batch, cuts):
+    """the batch with its record array cut at `cuts` (record indices, any order; duplicates give empty segments)"""
+    edges = [0] + sorted(int(c) for c in cuts) + [batch.n_records]
+    segs = [batch.records[a:b].copy() for a, b in zip(edges[:-1], edges[1:])]
+    return ev.SegmentedBatch(batch.rec_offset, batch.units, segs, batch.libs, batch.split_weight, batch.disc_weight)
+
+
+def test_records_handed_over_in_segments(hip_device, fixture_library):
+    """svt_batch_create_segments (ABI 16): the batch whose record array is the concatenation of the segments -- the same bytes
+    as svt_batch_create over the joined array, for one library, for library windows (hinted, sample-major, site-major result
+    records) and for several libraries without hints (the windows are read off the records: segments joined in scratch);
+    segments cut inside units, empty segments, no segment at all for an empty batch; mismatching lengths are refused."""
+    from svtyper_amd import hip
+    rng = np.random.default_rng(44)
+    one = synth.make_units(30000, 91, [fixture_library], mean_frags=40, sd_frags=25, min_frags=0, max_frags=200, frac_empty=0.02, frac_skip=0.01)
+    multi = synth.make_multisample(700, 8, seed=17, mean_frags=30, sd_frags=12, min_frags=0, max_frags=90)
+    by_sample, _ = synth.to_sample_major(multi, 8)
+    unhinted = ev.EvidenceBatch(multi.rec_offset, multi.units.copy(), multi.records, multi.libs, multi.split_weight, multi.disc_weight)
+    unhinted.units["libs"] = 0
+    for batch, order in ((one, 0), (by_sample, 8), (multi, 0), (unhinted, 0)):
+        for flags in (0, ev.FLAG_SSO_ASSOCIATION | ev.FLAG_RESULT96):
+            with hip.DeviceBatch(batch, hip_device, flags) as d:
+                if order:
+                    d.result_order(order)
+                d.genotype(sync=True)
+                want, mode = d.results().rec.tobytes(), d.table_mode()
+            cut_sets = [[], [batch.n_records // 2], list(rng.integers(0, batch.n_records + 1, 7)), [0, 0, batch.n_records, 5, 5]]
+            if order:      # one segment per sample, as NativeUnitCollector hands them over
+                n_sites = batch.n_units // order
+                cut_sets.append([int(batch.rec_offset[k * n_sites]) for k in range(1, order)])
+            for cuts in cut_sets:
+                with hip.DeviceBatch.from_segments(_segmented(batch, cuts), hip_device, flags) as d:
+                    if order:
+                        d.result_order(order)
+                    d.genotype(sync=True)
+                    assert d.table_mode() == mode
+                    assert d.results().rec.tobytes() == want, (order, flags, cuts)
+    empty = one.slice(0, 0)
+    with hip.DeviceBatch.from_segments(ev.SegmentedBatch(empty.rec_offset, empty.units, [], empty.libs), hip_device, 0) as d:
+        d.genotype(sync=True)
+        assert d.results().n_units == 0
+    L = hip.load()
+    import ctypes as C
+    small = one.slice(0, 100)
+    cb = small.as_c()
+    segs = np.zeros(2, np.dtype([("records", "<u8"), ("n_records", "<u8")]))
+    for lengths in ((small.n_records - 1, 0), (small.n_records, 1), (small.n_records + 5, 0)):
+        segs[0] = (small.records.ctypes.data, lengths[0])
+        segs[1] = (small.records.ctypes.data, lengths[1])
+        h = C.c_void_p()
+        assert L.svt_batch_create_segments(C.byref(cb), segs.ctypes.data, 2, hip_device, 0, C.byref(h)) == -1 and not h.value      # SVT_ERR_INVALID
+        assert b"segments hold" in L.svt_last_error()
+
+
 @pytest.mark.parametrize("n_samples", [1, 3, 32])
 def test_site_qual_on_device(hip_device, fixture_library, n_samples):
     """svt_batch_site_qual == the reference's running QUAL (classic.py:216-217,485,498), bit for bit"""

@@ -77,6 +77,31 @@ def test_three_samples_blank_in_the_middle_oracle_engine(tmp_path, sum_quals):
     # site-major over the samples by NativeUnitCollector._run_records)
     _same(_run(tmp_path, "oracle_native", sum_quals, engine=T.oracle_engine, reader="native"), want)
 
+    # ... and handed over SAMPLE-major, as the HIP engine takes them (accepts_sample_major: the readers' arrays concatenated,
+    # the device writes the result records site-major).  The stand-in puts the units in site-major order itself.
+    class SampleMajorOracle:
+        accepts_sample_major = True
+        supports_site_qual = True
+        calls = 0
+
+        def __call__(self, batch, flags=0, site_qual=None, sample_major=0):
+            import numpy as np
+            from svtyper_amd import hip, synth
+            from svtyper_amd.evidence import SegmentedBatch
+            assert isinstance(batch, SegmentedBatch) and len(batch.segments) == 3
+            batch = batch.joined()
+            assert sample_major == 3 and batch.n_units % 3 == 0
+            assert (batch.units["sample"] == np.repeat(np.arange(3), batch.n_units // 3)).all()
+            n_sites = batch.n_units // 3
+            site_major = synth.permute_units(batch, (np.arange(batch.n_units) % 3) * n_sites + np.arange(batch.n_units) // 3)
+            res = T.oracle_engine(site_major, flags)
+            if site_qual is not None:
+                res.site_qual = hip.site_qual_host(res, site_qual[0], site_qual[1])
+            SampleMajorOracle.calls += 1
+            return res
+    _same(_run(tmp_path, "oracle_native_sample_major", sum_quals, engine=SampleMajorOracle(), reader="native"), want)
+    assert SampleMajorOracle.calls >= 1
+
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("sum_quals", [True, False])
