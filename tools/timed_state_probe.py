@@ -16,7 +16,19 @@ with hip.DeviceBatch(b, 0, ev.FLAG_RESULT96) as d:
     if rc[0] or rc[1]:
         r = d.tune_placement(*rc)
         print("cold %.4f ms; audition %s" % (cold, r), flush=True)
-    for rep in range(2):
+    # the bench's own sequence after the audition (idle 2.5 s, spin-up 40 ms, 3 warm-ups, 20 timed), then the same timed group
+    # again and again with 0.3 s of idling between: does the pass flip between levels over seconds?
+    time.sleep(2.5)
+    series = []
+    for k in range(40):
+        bench.spin_up(d, 40.0)
+        for _ in range(3):
+            d.genotype(sync=False)
+        d.genotype(sync=True)
+        series.append("%.4f" % (d.genotype_timed(20) / 20))
+        time.sleep(0.3)
+    print("after the audition, every 0.35 s: spin-up 40 ms + 3 warm-ups + timed 20 ->\n" + " ".join(series), flush=True)
+    for rep in range(1):
         for spin in (0, 5, 10, 20, 40, 80, 160, 320):
             time.sleep(2.0)
             n = bench.spin_up(d, float(spin)) if spin else 0
