@@ -543,17 +543,24 @@ struct Record {               // one BAM alignment, decoded as far as the path n
     int mapq = 0;
     int64_t l_seq = 0;
     int64_t tlen = 0;         // template_length
-    std::string name;
+    const char* name = "";    // query name: points into the record's bytes (the inflated block, or the caller's gather buffer for a
+    uint32_t name_len = 0;    // record that straddles blocks): valid until the next record is read
     Cigar cigar;
     const uint8_t* tags = nullptr;
     size_t tags_len = 0;
+    std::string name_str() const { return std::string(name, name_len); }
 };
 
-// Z-typed tag value or nullptr; walks the tag area like svtyper_amd/bam.py::_parse_tags
-const char* find_z_tag(const Record& r, char k0, char k1, bool* malformed)
+// Z-typed tag value or nullptr; walks the tag area like svtyper_amd/bam.py::_parse_tags.
+// A kept read is asked for RG and then for SA: the second search need not walk the tags in front of RG again.  `from`: where
+// the walk starts; `resume` (optional): set to the offset behind the found tag; `other` (optional, with o0 o1): the first Z
+// value of that other tag met ON THE WAY to the found one.  First-match semantics and the set of tags validated are those of
+// two full walks: search RG from 0 noting SA, then -- when SA was not met -- search SA from `resume`.
+const char* find_z_tag(const Record& r, char k0, char k1, bool* malformed, size_t from = 0, size_t* resume = nullptr,
+                       char o0 = 0, char o1 = 0, const char** other = nullptr, bool validate_only = false)
 {
     const uint8_t* b = r.tags;
-    size_t i = 0, n = r.tags_len;
+    size_t i = from, n = r.tags_len;
     while (i + 3 <= n) {
         const char a0 = (char)b[i], a1 = (char)b[i + 1], t = (char)b[i + 2];
         i += 3;
@@ -563,10 +570,18 @@ const char* find_z_tag(const Record& r, char k0, char k1, bool* malformed)
         case 's': case 'S': skip = 2; break;
         case 'i': case 'I': case 'f': skip = 4; break;
         case 'Z': case 'H': {
-            const void* z = std::memchr(b + i, 0, n - i);
+            // (the values are short -- RG ids, MD strings of a few characters: a library call per tag costs more than the scan)
+            const uint8_t* q = b + i;
+            const uint8_t* const near_end = b + std::min(n, i + 24);
+            while (q < near_end && *q) ++q;
+            const void* z = (q < near_end) ? q : (q < b + n ? std::memchr(q, 0, (size_t)(b + n - q)) : nullptr);
             if (!z) { *malformed = true; return nullptr; }
-            if (a0 == k0 && a1 == k1 && t == 'Z') return reinterpret_cast<const char*>(b + i);
             skip = (size_t)(static_cast<const uint8_t*>(z) - (b + i)) + 1;
+            if (!validate_only && a0 == k0 && a1 == k1 && t == 'Z') {
+                if (resume) *resume = i + skip;
+                return reinterpret_cast<const char*>(b + i);
+            }
+            if (other && !*other && a0 == o0 && a1 == o1 && t == 'Z') *other = reinterpret_cast<const char*>(b + i);
             break;
         }
         case 'B': {
@@ -676,7 +691,9 @@ bool decode_core(const uint8_t* d, uint32_t size, Record& r, RecordLayout& lay)
 // the variable-length parts a kept record is asked for: query name, CIGAR operations, tag area
 void decode_rest(const uint8_t* d, uint32_t size, const RecordLayout& lay, Record& r)
 {
-    r.name.assign(reinterpret_cast<const char*>(d + 32), lay.l_name ? lay.l_name - 1 : 0);
+    r.name = reinterpret_cast<const char*>(d + 32);
+    r.name_len = lay.l_name ? lay.l_name - 1 : 0;
+
     r.cigar.clear();
     const uint8_t* c0 = d + 32 + lay.l_name;
     for (unsigned k = 0; k < lay.n_cigar; ++k) {
@@ -709,9 +726,12 @@ bool fetch(const svt_bam& bam, Bgzf& z, int32_t tid, int64_t beg, int64_t end, s
     uint64_t min_off = 0;
     const size_t li = (size_t)(beg >> 14);
     if (!ri.linear.empty()) min_off = li < ri.linear.size() ? ri.linear[li] : ri.linear.back();
-    std::vector<uint32_t> bins;
+    // (scratch of the calling thread, reused from fetch to fetch: two fetches per unit, three allocations each)
+    static thread_local std::vector<uint32_t> bins;
+    static thread_local std::vector<std::pair<uint64_t, uint64_t>> chunks, merged;
     reg2bins(beg, end, bins);
-    std::vector<std::pair<uint64_t, uint64_t>> chunks;
+    chunks.clear();
+    merged.clear();
     for (uint32_t b : bins) {
         auto it = ri.bins.find(b);
         if (it == ri.bins.end()) continue;
@@ -720,7 +740,6 @@ bool fetch(const svt_bam& bam, Bgzf& z, int32_t tid, int64_t beg, int64_t end, s
     }
     if (chunks.empty()) return true;
     std::sort(chunks.begin(), chunks.end());
-    std::vector<std::pair<uint64_t, uint64_t>> merged;
     merged.push_back(chunks[0]);
     for (size_t i = 1; i < chunks.size(); ++i) {
         if (chunks[i].first <= merged.back().second) merged.back().second = std::max(merged.back().second, chunks[i].second);
@@ -748,10 +767,14 @@ bool fetch(const svt_bam& bam, Bgzf& z, int32_t tid, int64_t beg, int64_t end, s
 
 // SplitRead.is_valid (parsers.py:959-1058 / fragments.py) -> fills `out` when the candidate is valid
 // returns 1 valid, 0 invalid, -1 malformed input
-int split_candidate(const svt_bam& bam, const Record& r, Split& out)
+// `sa_seen` / `tags_from`: what the caller's search for RG already knows -- an SA value it walked past, else where the tags it
+// has not looked at begin (0: the whole tag area)
+int split_candidate(const svt_bam& bam, const Record& r, Split& out, const char* sa_seen = nullptr, size_t tags_from = 0)
 {
     bool malformed = false;
-    const char* sa = find_z_tag(r, 'S', 'A', &malformed);
+    const char* sa = sa_seen;
+    if (sa_seen) (void)find_z_tag(r, 0, 0, &malformed, tags_from, nullptr, 0, 0, nullptr, /*validate_only=*/true);   // (the full walk looked at every tag)
+    else sa = find_z_tag(r, 'S', 'A', &malformed, tags_from);
     if (malformed) return -1;
     if (r.cigar.empty()) return 0;   // a mapped read without a CIGAR cannot be a split candidate (fragments.py: add_read)
     if (!sa) {   // the common read: no SA tag and no clipped end -> not a candidate, nothing to build
@@ -929,6 +952,7 @@ struct Workspace {
     std::vector<uint32_t> table;       // fragment index + 1, 0 = empty; size is a power of two
     std::vector<uint32_t> order;
     std::vector<std::pair<uint64_t, uint32_t>> keys;
+    std::vector<uint64_t> packed;
     std::vector<std::pair<int64_t, int64_t>> intervals;
     std::vector<const SplitOut*> seq, clip;
     std::string last_rg;               // most reads of a unit share their read group
@@ -944,28 +968,42 @@ struct Workspace {
     }
     static uint64_t hash_name(const char* p, size_t n)
     {
-        uint64_t h = 1469598103934665603ull;                  // FNV-1a
-        for (size_t i = 0; i < n; ++i) h = (h ^ (unsigned char)p[i]) * 1099511628211ull;
+        // eight bytes per step: a byte-wise FNV-1a is a serial chain of one multiply per byte of a 20-50 byte name (a tenth of
+        // what a kept read costs)
+        uint64_t h = 0x9E3779B97F4A7C15ull ^ (uint64_t)n;
+        size_t i = 0;
+        for (; i + 8 <= n; i += 8) {
+            uint64_t w;
+            std::memcpy(&w, p + i, 8);
+            h = (h ^ w) * 0xFF51AFD7ED558CCDull;
+            h ^= h >> 32;
+        }
+        if (i < n) {
+            uint64_t w = 0;
+            std::memcpy(&w, p + i, n - i);
+            h = (h ^ w) * 0xFF51AFD7ED558CCDull;
+            h ^= h >> 32;
+        }
         return h;
     }
     const char* name_of(const Fragment& f) const { return names.data() + f.name_off; }
     // the fragment of this query name; created (with `lib`) when the name is new
-    Fragment& fragment(const std::string& name, int lib)
+    Fragment& fragment(const char* name, const uint32_t len, int lib)
     {
         if ((n_frags + 1) * 2 > table.size()) grow();
         const size_t mask = table.size() - 1;
-        for (size_t i = hash_name(name.data(), name.size()) & mask;; i = (i + 1) & mask) {
+        for (size_t i = hash_name(name, len) & mask;; i = (i + 1) & mask) {
             const uint32_t slot = table[i];
             if (slot == 0u) {
                 if (n_frags == frags.size()) frags.emplace_back();
                 Fragment& f = frags[n_frags];
-                f.reset(lib, (uint32_t)names.size(), (uint32_t)name.size());
-                names.insert(names.end(), name.begin(), name.end());
+                f.reset(lib, (uint32_t)names.size(), len);
+                names.insert(names.end(), name, name + len);
                 table[i] = (uint32_t)++n_frags;
                 return f;
             }
             Fragment& f = frags[slot - 1];
-            if (f.name_len == name.size() && std::memcmp(name_of(f), name.data(), name.size()) == 0) return f;
+            if (f.name_len == len && std::memcmp(name_of(f), name, len) == 0) return f;
         }
     }
     void grow()
@@ -991,22 +1029,51 @@ struct Workspace {
             const char *a = name_of(frags[0]), *b = name_of(frags[k]);
             const size_t n = std::min<size_t>(lcp, frags[k].name_len);
             size_t i = 0;
-            while (i < n && a[i] == b[i]) ++i;
+            for (; i + 8 <= n; i += 8) {      // eight bytes at a time: thirty common bytes times a few hundred names per unit
+                uint64_t x, y;
+                std::memcpy(&x, a + i, 8);
+                std::memcpy(&y, b + i, 8);
+                if (x != y) { i += (size_t)__builtin_ctzll(x ^ y) >> 3; break; }     // (little-endian: the lowest differing byte)
+            }
+            while (i < n && a[i] == b[i]) ++i;      // (the tail; at once over when the words differed)
             lcp = i;
         }
-        for (size_t k = 0; k < n_frags; ++k) {
-            const Fragment& f = frags[k];
+        auto key_of = [&](const Fragment& f) {
             uint64_t key = 0;                                    // bytes past the end count as 0: a shorter name sorts first,
             const unsigned char* p = reinterpret_cast<const unsigned char*>(name_of(f)) + lcp;   // as it does for memcmp + length
             const size_t have = f.name_len - lcp;               // (lcp <= every name's length)
+            if (have >= 8) {
+                std::memcpy(&key, p, 8);
+                return __builtin_bswap64(key);
+            }
             for (size_t i = 0; i < 8; ++i) key = (key << 8) | (i < have ? p[i] : 0u);
-            keys[k] = std::make_pair(key, (uint32_t)k);
-        }
-        std::sort(keys.begin(), keys.end(), [&](const std::pair<uint64_t, uint32_t>& x, const std::pair<uint64_t, uint32_t>& y) {
-            if (x.first != y.first) return x.first < y.first;
-            const Fragment &a = frags[x.second], &b = frags[y.second];
+            return key;
+        };
+        auto by_name = [&](const uint32_t x, const uint32_t y) {
+            const Fragment &a = frags[x], &b = frags[y];
             const int c = std::memcmp(name_of(a), name_of(b), std::min(a.name_len, b.name_len));
             return c != 0 ? c < 0 : a.name_len < b.name_len;
+        };
+        if (n_frags <= 4096) {
+            // the usual unit: the key's leading 52 bits and the fragment's index in ONE integer -- a sort of plain 64-bit words, no
+            // comparator that looks at the names; runs of equal leading bits (rare: they agree in six and a half bytes behind the
+            // common prefix) are put in order by their whole names afterwards
+            packed.resize(n_frags);
+            for (size_t k = 0; k < n_frags; ++k) packed[k] = (key_of(frags[k]) & ~uint64_t(0xfff)) | (uint64_t)k;
+            std::sort(packed.begin(), packed.end());
+            for (size_t k = 0; k < n_frags; ++k) order[k] = (uint32_t)(packed[k] & 0xfffu);
+            for (size_t k = 0; k < n_frags;) {
+                size_t e = k + 1;
+                while (e < n_frags && (packed[e] >> 12) == (packed[k] >> 12)) ++e;
+                if (e - k > 1) std::sort(order.begin() + (ptrdiff_t)k, order.begin() + (ptrdiff_t)e, by_name);
+                k = e;
+            }
+            return order;
+        }
+        for (size_t k = 0; k < n_frags; ++k) keys[k] = std::make_pair(key_of(frags[k]), (uint32_t)k);
+        std::sort(keys.begin(), keys.end(), [&](const std::pair<uint64_t, uint32_t>& x, const std::pair<uint64_t, uint32_t>& y) {
+            if (x.first != y.first) return x.first < y.first;
+            return by_name(x.second, y.second);
         });
         for (size_t k = 0; k < n_frags; ++k) order[k] = keys[k].second;
         return order;
@@ -1141,11 +1208,15 @@ inline double thread_cpu_seconds()
 }
 
 // one unit: gather reads of both windows, assemble fragments, emit summaries
+// `emit(fragment)`: what becomes of a finished summary -- kept as it is (svt_bam_summarise) or turned into its 16-byte evidence
+// record on the spot (svt_bam_evidence: no array of 128-byte summaries in between); returns false with `err` set to stop
+template <typename Emit>
 int process_unit(const svt_bam& bam, Bgzf& z, std::vector<uint8_t>& buf, const svt_summarise_args& A,
                  const std::unordered_map<std::string, int32_t>& rg_lib, uint64_t u, Workspace& ws, UnitOut& out,
-                 std::string& err)
+                 std::string& err, Emit&& emit)
 {
     out.frags.clear();
+    out.recs.clear();
     out.skipped = false;
     const svt_fetch_unit& w = A.windows[u];
     const int32_t tids[2] = {w.tid_a, w.tid_b};
@@ -1169,9 +1240,11 @@ int process_unit(const svt_bam& bam, Bgzf& z, std::vector<uint8_t>& buf, const s
             }
             if (r.flag & (0x4 | 0x400)) return true;                   // unmapped / duplicate
             bool malformed = false;
-            const char* rg = find_z_tag(r, 'R', 'G', &malformed);
+            size_t behind_rg = 0;
+            const char* sa_seen = nullptr;
+            const char* rg = find_z_tag(r, 'R', 'G', &malformed, 0, &behind_rg, 'S', 'A', &sa_seen);
 
-            if (malformed || !rg) { err = "read without a usable RG tag: " + r.name; rc = SVT_ERR_INVALID; return false; }
+            if (malformed || !rg) { err = "read without a usable RG tag: " + r.name_str(); rc = SVT_ERR_INVALID; return false; }
             if (!ws.have_last_rg || ws.last_rg != rg) {
                 auto it = rg_lib.find(rg);
                 if (it == rg_lib.end()) { err = std::string("read group not in the library table: ") + rg; rc = SVT_ERR_INVALID; return false; }
@@ -1181,7 +1254,7 @@ int process_unit(const svt_bam& bam, Bgzf& z, std::vector<uint8_t>& buf, const s
             }
             if (ws.last_lib < 0) return true;                           // library below the prevalence cut
             if (A.count_mode == 0 && A.max_reads >= 0 && i > A.max_reads) { out.skipped = true; return false; }
-            Fragment& f = ws.fragment(r.name, ws.last_lib);             // SamFragment(read, lib) when new
+            Fragment& f = ws.fragment(r.name, r.name_len, ws.last_lib);             // SamFragment(read, lib) when new
             if (std::find(f.seen.begin(), f.seen.end(), r.flag) != f.seen.end()) return true;   // same (name, flag) again
             f.seen.push_back(r.flag);
             if (r.flag & (0x100 | 0x800)) return true;                  // secondary / supplementary
@@ -1195,15 +1268,15 @@ int process_unit(const svt_bam& bam, Bgzf& z, std::vector<uint8_t>& buf, const s
             f.primaries.push_back(ri);
             f.num_primary += 1;
             Split sp;
-            const int v = split_candidate(bam, r, sp);
-            if (v < 0) { err = "malformed SA tag / CIGAR at read " + r.name; rc = SVT_ERR_INVALID; return false; }
+            const int v = split_candidate(bam, r, sp, sa_seen, behind_rg);
+            if (v < 0) { err = "malformed SA tag / CIGAR at read " + r.name_str(); rc = SVT_ERR_INVALID; return false; }
             if (v > 0) f.splits.push_back(SplitOut{sp.soft, piece_out(sp.left), piece_out(sp.right)});
             return true;
         });
         if (rc != SVT_OK) return rc;
         if (!ok) { err = "BAM read error"; return SVT_ERR_INVALID; }
     }
-    if (out.skipped) { out.frags.clear(); return SVT_OK; }
+    if (out.skipped) { out.frags.clear(); out.recs.clear(); return SVT_OK; }
 
     for (const uint32_t fi : ws.sorted_order()) {
         const Fragment& f = ws.frags[fi];
@@ -1226,7 +1299,7 @@ int process_unit(const svt_bam& bam, Bgzf& z, std::vector<uint8_t>& buf, const s
                 err = "MAPQ outside 0..255 in an SA tag of fragment " + std::string(ws.name_of(f), f.name_len);
                 return SVT_ERR_INVALID;
             }
-            out.frags.push_back(fr);
+            if (!emit(fr)) return SVT_ERR_INVALID;
         }
     }
     return SVT_OK;
@@ -1452,24 +1525,26 @@ static int summarise_units(const svt_bam* bam, const svt_summarise_args* args, c
             for (uint64_t u = u0; u < u1; ++u) {
                 if (first_rc.load(std::memory_order_relaxed) != SVT_OK) return;
                 std::string err;
-                int rc = process_unit(*bam, z, buf, *args, rg_lib, u, ws, unit, err);
-                if (rc == SVT_OK && geometry) {      // the predicates of the device stage, here: 16 bytes per fragment leave the reader
+                int rc;
+                if (geometry) {      // the predicates of the device stage, here: 16 bytes per fragment leave the reader
                     const svt_breakpoint& bp = args->breakpoints[u];
                     if (bp.svtype > SVT_SVTYPE_BND) { rc = SVT_ERR_INVALID; err = "bad svtype"; }
-                    unit.recs.resize(unit.frags.size());
-                    for (size_t k = 0; rc == SVT_OK && k < unit.frags.size(); ++k) {
-                        const svt_fragment& f = unit.frags[k];
+                    else rc = process_unit(*bam, z, buf, *args, rg_lib, u, ws, unit, err, [&](const svt_fragment& f) {
                         const uint32_t lib = f.read[0].reserved & 0xffu;
-                        if (lib >= geometry->n_libs) { rc = SVT_ERR_INVALID; err = "library index of a fragment outside the library table"; break; }
+                        if (lib >= geometry->n_libs) { err = "library index of a fragment outside the library table"; return false; }
                         const svt::Record4 r = svt::geometry_record(svt::read_of(f.read[0]), svt::read_of(f.read[1]), svt::piece_of(f.seq[0]),
                                                                     svt::piece_of(f.seq[1]), svt::piece_of(f.clip[0]), svt::piece_of(f.clip[1]), bp,
                                                                     geometry->lib_flank[lib], geometry->min_aligned, geometry->split_slop);
                         static_assert(sizeof(svt_record) == sizeof r, "svt_record is four words");
-                        std::memcpy(&unit.recs[k], &r, sizeof r);
-                    }
+                        unit.recs.emplace_back();
+                        std::memcpy(&unit.recs.back(), &r, sizeof r);
+                        return true;
+                    });
+                } else {
+                    rc = process_unit(*bam, z, buf, *args, rg_lib, u, ws, unit, err, [&](const svt_fragment& f) { unit.frags.push_back(f); return true; });
                 }
                 if (rc == SVT_OK) {
-                    outs[u].count = unit.frags.size();
+                    outs[u].count = geometry ? unit.recs.size() : unit.frags.size();
                     outs[u].skipped = unit.skipped;
                     outs[u].data = geometry ? arenas[t]->append(unit.recs.data(), unit.recs.size() * sizeof(svt_record))
                                             : arenas[t]->append(unit.frags.data(), unit.frags.size() * sizeof(svt_fragment));
@@ -1608,7 +1683,7 @@ static int svt_bam_scan_library_impl(const svt_bam* bam, uint32_t n_read_groups,
         if (malformed || !rg) return -1;
         return rgset.count(rg) ? 1 : 0;
     };
-    auto no_rg = [&](const Record& rec) { return fail(SVT_ERR_INVALID, "read without a usable RG tag: " + rec.name); };
+    auto no_rg = [&](const Record& rec) { return fail(SVT_ERR_INVALID, "read without a usable RG tag: " + rec.name_str()); };
     auto query_length = [](const Record& rec) {
         int64_t n = 0;
         for (const auto& c : rec.cigar) if (c.first == 0 || c.first == 1 || c.first == 4 || c.first == 7 || c.first == 8) n += c.second;

@@ -85,7 +85,7 @@ def test_summaries_equal_python(setup, mode, max_reads, threads):
 # hard clips, insertions, deletions, N gaps, several SA entries, secondary / supplementary /
 # duplicate / unmapped flags, MAPQ 255, B-typed tags in front of the ones that matter
 # ------------------------------------------------------------------------------------------
-def _synthetic_bam(path, seed=11, n_pairs=700, sample="syn", only_sites=None):
+def _synthetic_bam(path, seed=11, n_pairs=700, sample="syn", only_sites=None, sa_first=False, tied_names=False):
     import bamwriter as bw
     rng = np.random.default_rng(seed)
     refs = [("1", 200_000), ("2", 100_000)]
@@ -123,6 +123,8 @@ def _synthetic_bam(path, seed=11, n_pairs=700, sample="syn", only_sites=None):
         mq = [0, 1, 20, 37, 60, 60, 60, 255]
         rg = ("rgA", "rgB")[int(rng.integers(2))]
         name = "q%05d" % int(rng.integers(0, 10 ** 5)) + ("" if rng.random() < 0.9 else "x")
+        if tied_names:    # (no extra random draws) names that agree in the seven bytes behind their common prefix
+            name = "q%03d000%s" % (int(name[1:6]) % 3, name[1:])
         extra = 0x400 if rng.random() < 0.03 else 0
         for mate, (t, p, r, mt, mp, mr) in enumerate(((tid, pos1, rev1, mtid, pos2, rev2), (mtid, pos2, rev2, tid, pos1, rev1))):
             cigar = cigars[int(rng.integers(len(cigars)))]
@@ -140,7 +142,10 @@ def _synthetic_bam(path, seed=11, n_pairs=700, sample="syn", only_sites=None):
                                               mq[int(rng.integers(len(mq)))] % 256, int(rng.integers(4)))
                 if rng.random() < 0.2:
                     sa += "2,777,+,50M50S,10,1;"
-                tags.append(("SA", "Z", sa))
+                if sa_first:      # (no extra random draws: the same reads, SA in front of RG and one more tag behind RG)
+                    tags = [tags[0], ("SA", "Z", sa)] + tags[1:] + [("XT", "Z", "tail")]
+                else:
+                    tags.append(("SA", "Z", sa))
             recs.append(dict(name=name, flag=flag, tid=t, pos=max(0, p), mapq=mq[int(rng.integers(len(mq)))], cigar=cigar,
                              mtid=mt, mpos=max(0, mp), tlen=(mp - p) if t == mt else 0, tags=tags))
             if rng.random() < 0.06:                    # an extra secondary / supplementary record of the same read
@@ -160,8 +165,27 @@ def _synthetic_bam(path, seed=11, n_pairs=700, sample="syn", only_sites=None):
                                                  (13, nr.COUNT_CLASSIC, 90), (14, nr.COUNT_SSO, 200),
                                                  (15, nr.COUNT_CLASSIC, 345), (16, nr.COUNT_SSO, 352)])
 def test_synthetic_bam_native_equals_python(tmp_path, seed, mode, max_reads):
-    path = str(tmp_path / "syn.bam")
-    sites, info = _synthetic_bam(path, seed)
+    _synthetic_native_equals_python(tmp_path, seed, mode, max_reads, False)
+
+
+@pytest.mark.parametrize("seed,mode,max_reads", [(11, nr.COUNT_CLASSIC, None), (12, nr.COUNT_SSO, 1000)])
+def test_tag_order_does_not_matter(tmp_path, seed, mode, max_reads):
+    """the reader looks for RG and SA in ONE walk over a read's tags (SA noted on the way to RG, else searched from behind RG):
+    the same reads with SA in front of RG give the same summaries as the Python reader -- and as with SA behind RG"""
+    a = _synthetic_native_equals_python(tmp_path, seed, mode, max_reads, True)
+    b = _synthetic_native_equals_python(tmp_path, seed, mode, max_reads, False)
+    assert a == b
+
+
+def test_names_that_tie_in_the_sort_key(tmp_path):
+    """sorted(query_name) runs on a few bytes behind the unit's common prefix; names that agree there are ordered by the whole
+    name afterwards -- the Python reader sorts the names themselves"""
+    _synthetic_native_equals_python(tmp_path, 12, nr.COUNT_SSO, 1000, False, tied_names=True)
+
+
+def _synthetic_native_equals_python(tmp_path, seed, mode, max_reads, sa_first, tied_names=False):
+    path = str(tmp_path / ("syn%d%d.bam" % (sa_first, tied_names)))
+    sites, info = _synthetic_bam(path, seed, sa_first=sa_first, tied_names=tied_names)
     pybam = bam.AlignmentFile(path)
     sample = library.Sample.from_lib_info(pybam, info, 1e-3)
     nbam = nr.NativeBam(path)
@@ -174,6 +198,7 @@ def test_synthetic_bam_native_equals_python(tmp_path, seed, mode, max_reads):
     assert len(want[1]) > 100 or want[2].any()
     # the synthetic reads really exercise the split-read path
     assert (want[1]["seq"]["flags"] & 1).any() or (want[1]["clip"]["flags"] & 1).any() or want[2].all()
+    return got[0].tobytes(), got[1].tobytes(), got[2].tobytes()
 
 
 def test_library_statistics_native_equals_python_and_reference(tmp_path):
