@@ -805,6 +805,13 @@ def main():
         if use_dist:
             dist.barrier()
 
+    # the interpreter's collector stays out of the timed region (a collection of the heap is not part of a pass) -- switched
+    # off HERE, in front of the spin-up: a full collection takes tens of milliseconds during which the device idles, and a
+    # device that has idled that long runs the next passes ~10 % slower (this round's lines with the collection between the
+    # warm-up and the timed steps: 0.317-0.325 ms where the audition had just measured 0.287-0.297)
+    import gc
+    gc.collect()
+    gc.disable()
     spun = spin_up(dbatch, args.spinup_ms)
     for _ in range(args.warmup):
         dbatch.genotype(sync=False)
@@ -815,9 +822,6 @@ def main():
     first_timed_dispatch = (1 + args.steps + spun + args.warmup) if not tuned else None
 
     # ---- the timed region: EXACTLY `steps` passes, barrier + device sync on both sides
-    import gc
-    gc.collect()
-    gc.disable()     # (a collection of the interpreter's heap -- the workload's arrays are alive -- is not part of a pass)
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()

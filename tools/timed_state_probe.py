@@ -8,7 +8,14 @@ sys.path.insert(0, os.getcwd())
 import bench
 from svtyper_amd import evidence as ev, hip
 b = bench.generate("c3_mixed_1m", 1_000_000, 0, bench.usable_cpus())
-rc = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (32, 8)
+_num = [a for a in sys.argv[1:] if not a.startswith("--")]
+rc = (int(_num[0]), int(_num[1])) if len(_num) > 1 else (32, 8)
+WITH_TORCH = "--torch" in sys.argv      # as bench.py runs: torch's HIP context alive, the result buffer viewed as a tensor
+SHORT = "--short" in sys.argv           # the series after the audition only
+if WITH_TORCH:
+    import torch
+    torch.cuda.set_device(0)
+    torch.cuda.synchronize()
 with hip.DeviceBatch(b, 0, ev.FLAG_RESULT96) as d:
     d.genotype(sync=True)
     cold = d.genotype_timed(20) / 20
@@ -19,6 +26,9 @@ with hip.DeviceBatch(b, 0, ev.FLAG_RESULT96) as d:
     # the bench's own sequence after the audition (idle 2.5 s, spin-up 40 ms, 3 warm-ups, 20 timed), then the same timed group
     # again and again with 0.3 s of idling between: does the pass flip between levels over seconds?
     time.sleep(2.5)
+    if WITH_TORCH:
+        view = d.device_results_tensor()
+        torch.cuda.synchronize()
     series = []
     for k in range(40):
         bench.spin_up(d, 40.0)
@@ -27,7 +37,11 @@ with hip.DeviceBatch(b, 0, ev.FLAG_RESULT96) as d:
         d.genotype(sync=True)
         series.append("%.4f" % (d.genotype_timed(20) / 20))
         time.sleep(0.3)
-    print("after the audition, every 0.35 s: spin-up 40 ms + 3 warm-ups + timed 20 ->\n" + " ".join(series), flush=True)
+    print("after the audition, every 0.35 s: spin-up 40 ms + 3 warm-ups + timed 20%s ->\n" % (" (torch context alive)" if WITH_TORCH else "") + " ".join(series), flush=True)
+    if WITH_TORCH:
+        del view
+    if SHORT:
+        sys.exit(0)
     for rep in range(1):
         for spin in (0, 5, 10, 20, 40, 80, 160, 320):
             time.sleep(2.0)
