@@ -190,6 +190,7 @@ def dist_leg(what, dbatch, counts, total_units, steps, warmup, rank, world, back
     if order:
         dbatch.result_order(order)
     dbatch.genotype(sync=True)
+    dist.barrier()          # (the ranks meet before they spin up: nobody idles in the barrier in front of the timed passes)
     spin_up(dbatch, 20.0)
     for _ in range(warmup):
         dbatch.genotype(sync=False)
@@ -812,6 +813,11 @@ def main():
     import gc
     gc.collect()
     gc.disable()
+    # N ranks: meet BEFORE the spin-up.  The ranks get here at different times (generation, upload, audition), and the first
+    # collective of a process sets the communicator up: a rank that waited for the others in the barrier of the timed region
+    # itself would start its timed passes on a device that has idled -- the same ~10 % as above.  After this meeting the ranks
+    # spin up together and the barrier in front of the timed steps returns at once.
+    barrier()
     spun = spin_up(dbatch, args.spinup_ms)
     for _ in range(args.warmup):
         dbatch.genotype(sync=False)
