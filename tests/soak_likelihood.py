@@ -101,6 +101,17 @@ while time.time() - t0 < budget:
                 if got.rec.tobytes() != hip.genotype_batch(b, 0, flags & ev.FLAG_SSO_ASSOCIATION).rec.tobytes():
                     print("RESULT-ORDER MISMATCH at iteration %d (kind %d, %d samples, flags %d)" % (it, kind, by_sample, flags))
                     sys.exit(1)
+                # the same batch with its records handed over in pieces (svt_batch_create_segments): same bytes
+                cuts = sorted(int(c) for c in rng.integers(0, sm.n_records + 1, int(rng.integers(0, 6))))
+                edges = [0] + cuts + [sm.n_records]
+                seg = ev.SegmentedBatch(sm.rec_offset, sm.units, [sm.records[a:b] for a, b in zip(edges[:-1], edges[1:])], sm.libs,
+                                        sm.split_weight, sm.disc_weight)
+                with hip.DeviceBatch.from_segments(seg, 0, flags) as ds:
+                    ds.result_order(by_sample)
+                    ds.genotype(sync=True)
+                    if ds.results().rec.tobytes() != got.rec.tobytes():
+                        print("SEGMENTS MISMATCH at iteration %d (kind %d, %d samples, flags %d, cuts %s)" % (it, kind, by_sample, flags, cuts))
+                        sys.exit(1)
                 # QUAL on the device (128-byte records site-major; tagged 96-byte records scattered by tag) = the host's running sum
                 init = rng.uniform(-3.0, 40.0, b.n_units // by_sample) if rng.random() < 0.5 else None
                 if d.site_qual(by_sample, init).tobytes() != np.asarray(hip.site_qual_host(got, by_sample, init)).tobytes():
