@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py -- breakpoints genotyped per second on N x MI355X (BASELINE.json metric).
 
-    python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py                       (= --gpus 1 --steps 100 --warmup 3)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W [--scaling strong]
 
@@ -632,7 +632,9 @@ def main():
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    # (100 passes of ~0.29 ms: the fixed costs of the timed region -- 20 launches' enqueue, the wake-up after the last one, with N
+    # ranks two barriers -- are ~0.13 ms + the barriers, 2 % of a 20-step region and 0.4 % of this one)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--units", type=int, default=None,
                     help="breakpoints per GPU (weak) or in total (strong) [1 000 000; c2_del_100k: 100 000]")
