@@ -39,6 +39,10 @@ def test_bench_line_has_the_contract_keys(hip_device):
     # a traffic figure is only reported when it was measured on this very build
     assert roof["traffic"] is None or "these kernel sources" in roof["traffic_source"]
     assert len(roof["source_sha16"]) == 16 and len(roof["library_sha16"]) == 16 and roof["compiler"]
+    # where the host spent the timed region: the device's share (HIP events) lies inside the launch-and-wait time
+    th = roof["timed_region_host"]
+    assert th["launch_and_wait_ms"] >= th["device_ms_by_hip_events"] > 0 and th["host_ms_outside_the_events"] >= 0 and th["barrier_ms"] >= 0
+    assert abs(th["device_ms_by_hip_events"] - roof["kernel_ms"] * d["steps"]) < 1e-6
     # the same launches without the untimed spin-up are in the record too
     assert roof["no_spinup_kernel_ms"] > 0 and 0 < roof["no_spinup_frac"] <= 1.0
     # the placement audition before the timed steps is setup and says what it did; the six fresh allocations below are without it
@@ -88,6 +92,7 @@ def test_bench_line_has_the_contract_keys(hip_device):
         assert leg["sites"] > 0 and leg["fragments"] > 0 and leg["sites_per_s"] > 0 and leg["columns"] == leg["sites"]
         assert set(leg["stage_ms"]) == {"site_arrays_python", "inflate_fetch_summarise_host", "h2d_plus_geometry_kernel", "genotype_pass", "results_d2h", "format_columns_host"}
         assert all(v >= 0 for v in leg["stage_ms"].values()) and leg["h2d_bytes"] == 16 * leg["fragments"] + 24 * leg["sites"]
+        assert leg["add_sites_python_ms"] >= 0 and leg["wall_incl_add_sites_ms"] >= leg["wall_ms"]      # (what the chunked run compares with)
         assert leg["geometry"] == "reader" and leg["device_geometry"]["same_genotypes"] is True and leg["device_geometry"]["h2d_bytes"] > 7 * leg["h2d_bytes"]
     assert real["fixture_x100"]["sites"] == 21100
     sh = d["shard_of_8"]
