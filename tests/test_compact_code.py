@@ -60,3 +60,21 @@ def test_far_spans_take_the_sentinel():
     for ospan_len in (0, 1, 10**6, 2**31 - 1):
         code = pair_code(ospan_len, 100, 50, True, 10**5)
         assert kernel_indices(code, 50, True, 10**5) == direct_indices(ospan_len, 100, 50, True, 10**5)
+
+
+def test_segmented_batch_is_the_joined_batch():
+    """evidence.SegmentedBatch (what a joint run hands to svt_batch_create_segments): the record array is the concatenation of the
+    segments; lengths that do not add up to rec_offset[-1] are refused on the host already"""
+    import numpy as np
+    import pytest
+    from svtyper_amd import evidence as ev, synth
+    b = synth.make_multisample(40, 3, seed=5, mean_frags=6, sd_frags=3, min_frags=0, max_frags=15)
+    cuts = [0, 7, 7, b.n_records // 2, b.n_records]
+    seg = ev.SegmentedBatch(b.rec_offset, b.units, [b.records[x:y] for x, y in zip(cuts[:-1], cuts[1:])], b.libs, b.split_weight, b.disc_weight)
+    assert seg.n_units == b.n_units and seg.n_records == b.n_records and len(seg.segments) == 4
+    j = seg.joined()
+    assert j.records.tobytes() == b.records.tobytes() and j.rec_offset.tobytes() == b.rec_offset.tobytes() and j.units.tobytes() == b.units.tobytes()
+    with pytest.raises(ValueError):
+        ev.SegmentedBatch(b.rec_offset, b.units, [b.records[:-1]], b.libs)
+    with pytest.raises(ValueError):
+        ev.SegmentedBatch(b.rec_offset[:-1], b.units, [b.records], b.libs)
