@@ -161,6 +161,15 @@ def test_site_qual_over_tagged_records_stays_on_the_device(hip_device, n_samples
             d.site_qual(n_samples)
         per_call_ms = (time.perf_counter() - t0) / 5 * 1e3
         print("site_qual over %d tagged records: %.3f ms per call" % (multi.n_units, per_call_ms))
+    # the same records written by the packed-evidence kernel (tagged the same way)
+    try:
+        packed = hip.PackedEvidence(multi)
+    except hip.SvtyperHipError:
+        packed = None
+    if packed is not None:
+        with packed, hip.DeviceBatch.from_packed(packed, hip_device, ev.FLAG_RESULT96) as d:
+            d.genotype(sync=True)
+            assert np.array_equal(d.site_qual(n_samples, init).view(np.uint64), np.asarray(hip.site_qual_host(res, n_samples, init)).view(np.uint64))
     if n_samples > 1:
         by_sample, _ = synth.to_sample_major(multi, n_samples)
         with hip.DeviceBatch(by_sample, hip_device, ev.FLAG_RESULT96) as d:
