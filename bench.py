@@ -157,18 +157,27 @@ def pipelined_passes(dbatch, sizes, batches, backend, compact=False):
     cur = dbatch.result_slots() * dbatch.result_bytes()
     bufs = [torch.empty(cur + 128, dtype=torch.uint8, device="cuda") for _ in range(2)]
     base = [(b.data_ptr() + 127) // 128 * 128 - b.data_ptr() for b in bufs]
+    # a result buffer is written by pass k and read by the gather of batch k (torch's / the backend's streams); pass k + 2 may
+    # only be launched into it once that gather has finished: an event recorded behind the gather, waited for on the host
+    # before the launch -- inside the timed region, as a pipeline over DIFFERENT batches would have to
+    read_done = [None, None]
     try:
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for k in range(batches + 1):
             if k < batches:
+                if read_done[k % 2] is not None:
+                    read_done[k % 2].synchronize()
                 dbatch.bind_device_results(bufs[k % 2].data_ptr() + base[k % 2], cur)
                 dbatch.genotype(sync=False)
             if k >= 1:
-                src = bufs[(k - 1) % 2][base[(k - 1) % 2]: base[(k - 1) % 2] + cur]
+                j = (k - 1) % 2
+                src = bufs[j][base[j]: base[j] + cur]
                 if compact:
                     src = D.compact_tagged_records(src)
                 D.gather_bytes(src if backend == "nccl" else src.cpu(), sizes, dst=0)
+                read_done[j] = torch.cuda.Event()
+                read_done[j].record()      # (behind the collective: a synchronous c10d call makes the current stream wait for it)
             if k < batches:
                 dbatch.synchronize()
         torch.cuda.synchronize()

@@ -21,8 +21,8 @@ from . import __version__
 from . import evidence as ev
 from .bam import open_alignment_file
 from .library import Sample, setup_sample, write_sample_json
-from .pipeline import (MIN_LIB_PREVALENCE, ChunkPipeline, NativeUnitCollector, SampleColumnWriter, UnitCollector, add_read_to,
-                       default_engine, fetch_window)
+from .pipeline import (MIN_LIB_PREVALENCE, BulkFeeder, ChunkPipeline, NativeUnitCollector, SampleColumnWriter, UnitCollector, add_read_to,
+                       default_engine, fetch_window, resolve_reader, text_blocks)
 from .results import results_to_dicts
 from .vcf import VALID_SVTYPES, Variant, Vcf
 
@@ -66,9 +66,10 @@ def apply_result(var: Variant, sample_name: str, gt: int, res: dict) -> None:
 
 def sv_genotype(bam_string, vcf_in, vcf_out, min_aligned, split_weight, disc_weight, num_samp, lib_info_path,
                 debug, alignment_outpath, ref_fasta, sum_quals, max_reads, max_ci_dist, *, engine=None, geometry="host",
-                reader="python"):
+                reader=None):
     if alignment_outpath is not None:
         raise NotImplementedError("-w/--write_alignment (evidence BAM dump) is outside the MI355X hot path build")
+    reader = resolve_reader(reader)
     bams = []
     for path in bam_string.split(","):
         if not (path.endswith(".bam") or path.endswith(".cram")):
@@ -106,9 +107,9 @@ def sv_genotype(bam_string, vcf_in, vcf_out, min_aligned, split_weight, disc_wei
         raise ValueError("reader must be 'python' or 'native'")
     pending: list = []      # ordered output actions of the current chunk
     header_lines: list = []
-    in_header = True
-
+    n_samp = len(samples)
     pipe = ChunkPipeline()
+    fast: list = []     # SampleColumnWriter, made once the header is known
 
     def flush():
         actions = list(pending)
@@ -116,16 +117,14 @@ def sv_genotype(bam_string, vcf_in, vcf_out, min_aligned, split_weight, disc_wei
         quals = [float(a[1].qual) for a in actions if a[0] == "gt"]      # incoming QUAL (0 unless --sum_quals)
         pipe.submit(collector.take(engine, 0, site_quals=quals), lambda results: write_out(results, actions))
 
-    fast: list = []     # SampleColumnWriter, made once the header is known
-
-    def write_out(results, actions):
+    def render_actions(results, actions):
+        """the output text of every action, one string each (the lines of a variant, of a BND pair, of a line passed through)"""
         gts = results.gt.tolist()
         site_qual = None if results.site_qual is None else results.site_qual.tolist()
-        n_samp = len(samples)
         columns = sqs = dicts = None
         for action in actions:
             if action[0] == "raw":
-                vcf_out.write(action[1].get_var_string() + "\n")
+                yield action[1].get_var_string() + "\n"
                 continue
             _, var, var2, first_unit = action
             unit_gts = gts[first_unit:first_unit + n_samp]
@@ -144,10 +143,11 @@ def sv_genotype(bam_string, vcf_in, vcf_out, min_aligned, split_weight, disc_wei
                         elif g == ev.GT_BLANK:
                             var.qual = 0
                 cols = columns[first_unit:first_unit + n_samp]
-                vcf_out.write(var.get_var_string_with(fast[0].format_string, cols) + "\n")
+                text = var.get_var_string_with(fast[0].format_string, cols) + "\n"
                 if var2 is not None:               # BND: second mate carries the same QUAL and genotypes
                     var2.qual = var.qual
-                    vcf_out.write(var2.get_var_string_with(fast[0].format_string, cols) + "\n")
+                    text += var2.get_var_string_with(fast[0].format_string, cols) + "\n"
+                yield text
                 continue
             if dicts is None:
                 dicts = results_to_dicts(results)
@@ -155,47 +155,48 @@ def sv_genotype(bam_string, vcf_in, vcf_out, min_aligned, split_weight, disc_wei
                 if debug:
                     _debug_print(results.rec[first_unit + k])
                 apply_result(var, sample.name, gts[first_unit + k], dicts[first_unit + k])
-            if site_qual is not None:      # the same running sum, accumulated on the device (svt_batch_site_qual)
-                var.qual = site_qual[first_unit // len(samples)]
-            vcf_out.write(var.get_var_string() + "\n")
+            if site_qual is not None:      # the same running sum, over the refined SQ (hip.site_qual_host)
+                var.qual = site_qual[first_unit // n_samp]
+            text = var.get_var_string() + "\n"
             if var2 is not None:                   # BND: second mate carries the same genotypes
                 var.share_genotypes_with(var2)
-                vcf_out.write(var2.get_var_string() + "\n")
+                text += var2.get_var_string() + "\n"
+            yield text
 
-    for line in vcf_in:
-        if in_header:
-            if line[0] == "#":
-                header_lines.append(line)
-                continue
-            in_header = False
-            vcf.add_header(header_lines)
-            vcf.add_custom_svtyper_headers()
-            for sample in samples:
-                if sample.name not in vcf.sample_list:
-                    vcf.add_sample(sample.name)
-            vcf_out.write(vcf.get_header() + "\n")
-            fast.append(SampleColumnWriter(vcf, [s.name for s in samples], skipped_as_dots=True))
+    def write_out(results, actions):
+        for text in render_actions(results, actions):
+            vcf_out.write(text)
 
+    def start_body():
+        """the first variant line ends the header (classic.py:166-176)"""
+        vcf.add_header(header_lines)
+        vcf.add_custom_svtyper_headers()
+        for sample in samples:
+            if sample.name not in vcf.sample_list:
+                vcf.add_sample(sample.name)
+        vcf_out.write(vcf.get_header() + "\n")
+        fast.append(SampleColumnWriter(vcf, [s.name for s in samples], skipped_as_dots=True))
+
+    def handle_line(line, first_unit_base=0):
+        """One variant line -> its output action (classic.py:219-278), or None for a first BND mate (it waits for its
+        partner, classic.py:256-258); its units go to the collector."""
         var = Variant(line.rstrip().split("\t"), vcf)
         if not sum_quals:
             var.qual = 0
         if not var.has_svtype():
             sys.stderr.write("Warning: SVTYPE missing at variant %s. Skipping.\n" % var.var_id)
-            pending.append(("raw", var))
-            continue
+            return ("raw", var)
         if var.get_svtype() not in VALID_SVTYPES:
             sys.stderr.write("Warning: Unsupported SVTYPE at variant %s (%s). Skipping.\n"
                              % (var.var_id, var.get_svtype()))
-            pending.append(("raw", var))
-            continue
+            return ("raw", var)
         bp = vcf.get_variant_breakpoints(var, max_ci_dist)
-        if bp is None:          # first mate of a BND pair: wait for its partner (classic.py:256-258)
-            continue
+        if bp is None:
+            return None
         var2 = None
         if var.get_svtype() == "BND":
             var2 = var
             var = _take_first_mate(vcf, bp, var2)
-
         if reader == "native":
             first_unit = collector.add_site(bp)
         else:
@@ -203,15 +204,64 @@ def sv_genotype(bam_string, vcf_in, vcf_out, min_aligned, split_weight, disc_wei
             for k, sample in enumerate(samples):
                 fragments, many = gather_all_reads(sample, bp, max_reads)
                 collector.add(bp, k, fragments, skip=many)
-        pending.append(("gt", var, var2, first_unit))
-        if len(collector) >= CHUNK_UNITS:
-            flush()
+        return ("gt", var, var2, first_unit - first_unit_base)
 
-    if in_header and header_lines:   # header-only VCF: the reference writes nothing
-        pass
+    def per_line(lines):
+        """the general route: one Variant object per line, device batches of CHUNK_UNITS units"""
+        for line in lines:
+            action = handle_line(line)
+            if action is not None:
+                pending.append(action)
+            if len(collector) >= CHUNK_UNITS:
+                flush()
+
+    # bulk route (reader="native"): blocks of lines -> breakpoint arrays -> output text in native calls (bulk_vcf.py); lines
+    # it hands back, and everything once it stops in front of a BND line it cannot express, take the per-line route above
+    bulk = None
+    unpaired = False        # first BND mates left in the bulk parser at the end
+    if (reader == "native" and not debug and hasattr(vcf_in, "readline") and hasattr(vcf_in, "read")
+            and os.environ.get("SVT_BULK_VCF", "1") != "0"):
+        from . import bulk_vcf
+        if bulk_vcf.available():
+            bulk = bulk_vcf
+    if bulk is None:
+        in_header = True
+        for line in vcf_in:
+            if in_header:
+                if line[0] == "#":
+                    header_lines.append(line)
+                    continue
+                in_header = False
+                start_body()
+            per_line((line,))
+    else:
+        first = vcf_in.readline()
+        while first and first[0] == "#":
+            header_lines.append(first)
+            first = vcf_in.readline()
+        if first:
+            start_body()
+            if not fast[0].enabled:       # other samples' columns in the VCF: every line keeps its Genotype objects
+                per_line((first,))
+                per_line(vcf_in)
+            else:
+                feeder = BulkFeeder(bulk, vcf, collector, pipe, engine, 0, n_samp, fast[0], bulk.QUAL_CLASSIC, max_ci_dist,
+                                    sum_quals, False, handle_line, render_actions, vcf_out.write)
+                rest = feeder.run(text_blocks(first, vcf_in, n_samp))
+                if rest is not None:      # the per-line route from here on, with the BND mates the parser was holding
+                    for held in feeder.pending_lines():
+                        mate = Variant(held.split("\t"), vcf)
+                        if not sum_quals:
+                            mate.qual = 0
+                        vcf._bnd_pending[mate.var_id] = mate
+                    per_line(rest)
+                    per_line(vcf_in)
+                else:
+                    unpaired = feeder.n_pending() > 0
+
     flush()
     pipe.close()
-    if vcf._bnd_pending:
+    if vcf._bnd_pending or unpaired:
         logging.warning("Unpaired breakends found in file. These will not be present in output.")
     vcf_in.close()
     vcf_out.close()

@@ -44,9 +44,40 @@ def local_shard(batch: EvidenceBatch, rank: int, world: int, group: int = 1) -> 
 
 
 def gather_bytes(local, sizes: List[int], dst: int = 0):
-    """Gather every rank's uint8 tensor (sizes[r] bytes on rank r, on the backend's device) onto `dst`
-    with one collective.  Shards may differ in size, so the payload is padded to the largest one.
-    Returns the concatenated uint8 tensor on `dst`, None elsewhere."""
+    """Every rank's uint8 tensor (sizes[r] bytes on rank r, on the backend's device) onto `dst`: the root posts one receive per
+    rank straight into ITS slice of one preallocated buffer, every other rank one send of exactly its bytes (one batch of
+    point-to-point operations: over RCCL one group, each peer over its own xGMI link) -- no padding to the largest shard and
+    no second pass over the payload on the root.  Returns the uint8 tensor on `dst` (rank order), None elsewhere.
+    SVT_GATHER=collective selects the padded `dist.gather` + concatenation this replaced (same bytes)."""
+    import os
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size()
+    rank = dist.get_rank()
+    if local.numel() != sizes[rank]:
+        raise ValueError("rank %d holds %d bytes, the sizes say %d" % (rank, local.numel(), sizes[rank]))
+    if os.environ.get("SVT_GATHER") == "collective":
+        return _gather_bytes_collective(local, sizes, dst)
+    if rank != dst:
+        if sizes[rank]:
+            for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, local.contiguous(), dst)]):
+                req.wait()
+        return None
+    starts = [0]
+    for c in sizes:
+        starts.append(starts[-1] + c)
+    out = torch.empty(starts[-1], dtype=torch.uint8, device=local.device)
+    ops = [dist.P2POp(dist.irecv, out[starts[r]:starts[r + 1]], r) for r in range(world) if r != dst and sizes[r]]
+    reqs = dist.batch_isend_irecv(ops) if ops else []
+    out[starts[dst]:starts[dst + 1]] = local       # the root's own records: one device copy, under the transfers
+    for req in reqs:
+        req.wait()
+    return out
+
+
+def _gather_bytes_collective(local, sizes: List[int], dst: int = 0):
+    """One `dist.gather` of payloads padded to the largest shard, then a concatenation on the root."""
     import torch
     import torch.distributed as dist
 

@@ -86,6 +86,19 @@ def default_engine() -> Engine:
     return HipEngine(0)
 
 
+def resolve_reader(reader: Optional[str]) -> str:
+    """`reader=None` (the drivers' default, i.e. what a caller with the reference's positional arguments gets): the C++
+    reader of libsvtyper_hip.so when the library is there -- fetch, fragment assembly and the geometry predicates in its
+    threads, VCF lines in bulk --, else the portable Python reader.  Same output bytes either way."""
+    if reader is not None:
+        return reader
+    try:
+        from . import hip
+        return "native" if hasattr(hip.load(), "svt_bam_evidence") else "python"
+    except Exception:
+        return "python"
+
+
 class UnitCollector:
     """Packs (breakpoint, sample) units of one chunk of variants and remembers where each went.
 
@@ -200,66 +213,64 @@ class NativeUnitCollector:
         if len(self.lib_tables) > 256:
             raise ValueError("more than 256 libraries in one run are not supported by the evidence record")
         self.sites: List[dict] = []
+        self.site_arrays: list = []      # bulk_vcf.SiteArrays blocks, in front of the dict sites
 
     def add_site(self, breakpoint: dict) -> int:
         """Returns the index of the site's first unit (its samples follow in order)."""
         self.sites.append(breakpoint)
-        return (len(self.sites) - 1) * len(self.samples)
+        return (self._n_array_sites() + len(self.sites) - 1) * len(self.samples)
+
+    def add_site_arrays(self, arrays) -> int:
+        """The sites of a parsed block as arrays (bulk_vcf.SiteArrays: no dict per site).  They come in front of whatever
+        add_site() adds to the same batch; returns the index of their first unit."""
+        if self.sites:
+            raise ValueError("add_site_arrays() after add_site() in one batch")
+        first = self._n_array_sites() * len(self.samples)
+        self.site_arrays.append(arrays)
+        return first
+
+    def _n_array_sites(self) -> int:
+        return sum(len(a) for a in self.site_arrays)
 
     def __len__(self):
-        return len(self.sites) * len(self.samples)
+        return (self._n_array_sites() + len(self.sites)) * len(self.samples)
 
     def take(self, engine: Engine, flags: int, site_quals=None):
         """Detach the sites recorded so far as a job (see UnitCollector.take).  The sites' fields become arrays HERE, on the
         caller's thread (Python: it holds the GIL) -- under ChunkPipeline that is while the reader and the device work on
         the chunk before; the job itself is C++ and HIP calls only."""
+        from .bulk_vcf import SiteArrays
         sites, self.sites = self.sites, []
+        blocks, self.site_arrays = self.site_arrays, []
         kw = _site_qual_kw(engine, len(self.samples), site_quals)
-        if sites and self.geometry == "device" and not hasattr(engine, "genotype_fragments"):
+        if (sites or blocks) and self.geometry == "device" and not hasattr(engine, "genotype_fragments"):
             raise TypeError("reader='native' with geometry='device' needs an engine with genotype_fragments (the HIP engine)")
         t_begin = time.perf_counter()
-        prepared = self._prepare(sites)
+        prepared = self._prepare(SiteArrays.concat(blocks + [SiteArrays.from_dicts(sites)]))
         prep_s = time.perf_counter() - t_begin
         return lambda: self._run_prepared(prepared, engine, flags, kw, prep_s)
 
     def run(self, engine: Engine, flags: int) -> Results:
         return self.take(engine, flags)()
 
-    def _prepare(self, sites: List[dict]):
-        """Per sample the (svt_breakpoint[], svt_fetch_unit[]) arrays of the sites."""
+    def _prepare(self, sites):
+        """Per sample the (svt_breakpoint[], svt_fetch_unit[]) arrays of the sites (bulk_vcf.SiteArrays)."""
         import numpy as np
         from .geometry import BREAKPOINT_DTYPE
         from .native_reads import FETCH_DTYPE
         n_sites = len(sites)
         if n_sites == 0:
             return []
-        # C-level iteration (itemgetter + fromiter) instead of a comprehension per field: 1.6 us per site the first way,
-        # 0.8 this way -- at a few hundred thousand sites per second that is a share of the reader's budget
-        get = lambda key, seq: map(itemgetter(key), seq)
-        A = list(get("A", sites))
-        B = list(get("B", sites))
-        pos = np.empty((n_sites, 2), np.int64)
-        pos[:, 0] = np.fromiter(get("pos", A), np.int64, n_sites)
-        pos[:, 1] = np.fromiter(get("pos", B), np.int64, n_sites)
-        ci = np.empty((n_sites, 4), np.int64)
-        for col, side in ((0, A), (2, B)):      # (a ci that is not a pair fails here, as it did in the comprehension's index)
-            ci[:, col:col + 2] = np.fromiter(chain.from_iterable(get("ci", side)), np.int64, 2 * n_sites).reshape(n_sites, 2)
-        rev = np.fromiter(get("is_reverse", A), np.bool_, n_sites).astype(np.uint8)
-        rev |= np.fromiter(get("is_reverse", B), np.bool_, n_sites).astype(np.uint8) << 1
-        svt = np.fromiter(map(ev.SVTYPE_CODE.__getitem__, get("svtype", sites)), np.uint8, n_sites)
-        vlen = np.fromiter(map(methodcaller("get", "var_length", 0), sites), np.int64, n_sites)
-        vlen[svt != ev.SVTYPE_CODE["DEL"]] = 0
-        chrom_a, chrom_b = list(get("chrom", A)), list(get("chrom", B))
+        pos, ci, rev, svt = sites.pos, sites.ci, sites.reverse, sites.svtype
+        vlen = np.where(svt == ev.SVTYPE_CODE["DEL"], sites.var_length, 0)
         clip = lambda x: np.clip(x, -2**31, 2**31 - 1)
         prepared = []
         for k, (sample, nbam) in enumerate(zip(self.samples, self.bams)):
-            tid_of = {c: nbam.gettid(c) for c in set(chrom_a).union(chrom_b)}.__getitem__
-            tid = np.empty((n_sites, 2), np.int64)
-            tid[:, 0] = np.fromiter(map(tid_of, chrom_a), np.int64, n_sites)
-            tid[:, 1] = np.fromiter(map(tid_of, chrom_b), np.int64, n_sites)
+            tid = np.array([nbam.gettid(c) for c in sites.names], dtype=np.int64)[sites.chrom]      # [site, side]
             if (tid < 0).any():
-                bad = sites[int(np.nonzero((tid < 0).any(axis=1))[0][0])]
-                raise KeyError("chromosome of variant %s is not in %s" % (bad.get("id"), nbam.filename))
+                i, side = (int(x[0]) for x in np.nonzero(tid < 0))
+                raise KeyError("chromosome %s of variant line %d of the batch is not in %s"
+                               % (sites.names[int(sites.chrom[i, side])], i + 1, nbam.filename))
             bps = np.zeros(n_sites, BREAKPOINT_DTYPE)
             bps["tid_a"], bps["tid_b"] = tid[:, 0], tid[:, 1]
             bps["pos_a"], bps["pos_b"] = clip(pos[:, 0]), clip(pos[:, 1])
@@ -410,6 +421,111 @@ class SampleColumnWriter:
         """one string per unit of `results`"""
         from . import hip
         return hip.format_results(results, self.fields, self._skipped_as_dots)
+
+
+BULK_BLOCK_UNITS = 400_000   # (breakpoint, sample) units per device batch of the bulk route (SVT_BULK_BLOCK_UNITS)
+
+
+def text_blocks(first: str, source, n_samples: int):
+    """Blocks of whole lines from `source` (a text file object) behind `first` (a line already read), each about
+    BULK_BLOCK_UNITS units' worth of lines, judged by the length of the first one."""
+    units = int(os.environ.get("SVT_BULK_BLOCK_UNITS", BULK_BLOCK_UNITS))
+    chars = min(max(units // max(1, n_samples) * max(64, len(first)), 1 << 10), 256 << 20)
+    carry = first
+    while True:
+        data = source.read(chars)
+        if not data:
+            if carry:
+                yield carry
+            return
+        if not data.endswith("\n"):
+            data += source.readline()
+        yield carry + data
+        carry = ""
+
+
+def split_lines(text: str) -> List[str]:
+    """file.readlines() of a text: lines end at '\\n' only (str.splitlines also cuts at \\r, \\x0b, \\x1c, \\u2028 ...)"""
+    import io
+    return io.StringIO(text, newline="\n").readlines()
+
+
+class BulkFeeder:
+    """The drivers' bulk route (reader="native"): a block of variant lines -> breakpoint arrays in one native call
+    (bulk_vcf.VcfParser) -> the reader and the device -> the block's output lines as one text (VcfChunk.emit).  No Variant
+    object, breakpoint dict or join per line: svtyper/classic.py:219-278 / singlesample.py:577-652 for a block at a time.
+    Lines the parser hands back (no / unsupported SVTYPE, sample columns with FORMAT values, numbers it does not read
+    exactly as Python would ...) go through the driver's own per-line code (`handle_line`, `render_actions`) and are written
+    at their place; when the parser stops in front of a BND line it cannot express, run() returns the lines not consumed
+    and the driver carries on per line (pairing is stateful: pending_lines() are the first mates still waiting)."""
+
+    def __init__(self, bulk, vcf, collector, pipe, engine, flags: int, n_samples: int, fast, qual_mode: int, max_ci_dist,
+                 sum_quals: bool, skip_hash_lines: bool, handle_line, render_actions, write):
+        self._bulk = bulk
+        self._parser = bulk.VcfParser(vcf, max_ci_dist, sum_quals, skip_hash_lines)
+        self._collector, self._pipe, self._engine, self._flags = collector, pipe, engine, flags
+        self._n_samp, self._fast, self._qual_mode = n_samples, fast, qual_mode
+        self._handle_line, self._render_actions, self._write = handle_line, render_actions, write
+        self._skipped_as_dots = qual_mode == bulk.QUAL_CLASSIC
+
+    def n_pending(self) -> int:
+        return len(self.pending_lines())
+
+    def pending_lines(self) -> List[str]:
+        return self._parser.pending_lines()
+
+    def run(self, blocks) -> Optional[List[str]]:
+        """Every block of `blocks` (an iterator of texts of whole lines); None, or the lines of the current block the parser
+        did not consume (the iterator then stands behind that block)."""
+        for block in blocks:
+            rest = self._block(block)
+            if rest is not None:
+                return rest
+        return None
+
+    def _block(self, text: str) -> Optional[List[str]]:
+        import numpy as np
+        bulk = self._bulk
+        enc = bulk.TEXT_ENCODING
+        raw = text.encode(*enc)
+        chunk, used = self._parser.parse(raw)
+        n_bulk_units = chunk.n_sites * self._n_samp
+        if chunk.n_sites:
+            self._collector.add_site_arrays(chunk.sites)
+        actions = []          # (line index, action) of the lines handed back, in order
+        begin = chunk.line_begin
+        for i in np.nonzero(chunk.line_kind == bulk.LINE_PYTHON)[0].tolist():
+            action = self._handle_line(raw[begin[i]:begin[i + 1]].decode(*enc), n_bulk_units)
+            if action is not None:
+                actions.append((i, action))
+        job = self._collector.take(self._engine, self._flags)
+        self._pipe.submit(job, lambda results: self._write_block(chunk, actions, results))
+        return None if used == len(raw) else split_lines(raw[used:].decode(*enc))
+
+    def _write_block(self, chunk, actions, results) -> None:
+        import numpy as np
+        bulk = self._bulk
+        enc = bulk.TEXT_ENCODING
+        fast = self._fast
+        text, off = chunk.emit(results, self._n_samp, self._qual_mode, fast.fields, self._skipped_as_dots, fast.format_string)
+        if not actions:
+            if text:
+                self._write(text.decode(*enc))
+            chunk.close()
+            return
+        # lines handed back sit between the sites' lines: sites_before[i] = sites written by lines in front of line i
+        sites_before = np.concatenate([[0], np.cumsum(chunk.line_kind == bulk.LINE_SITE)])
+        own = Results(results.rec[chunk.n_sites * self._n_samp:])          # their units lie behind the parser's
+        cursor = 0
+        for (i, _), rendered in zip(actions, self._render_actions(own, [a for _, a in actions])):
+            s = int(sites_before[i])
+            if s > cursor:
+                self._write(text[off[cursor]:off[s]].decode(*enc))
+                cursor = s
+            self._write(rendered)
+        if cursor < chunk.n_sites:
+            self._write(text[off[cursor]:off[chunk.n_sites]].decode(*enc))
+        chunk.close()
 
 
 class ChunkPipeline:

@@ -86,20 +86,12 @@ def plan_shards(body: Sequence[str], world: int) -> List[List[int]]:
     return plan
 
 
-class _Lines:
-    """What the drivers need of an input file: iteration, readlines(), close(), name."""
+class _Lines(io.StringIO):
+    """What the drivers need of an input file: iteration, read(), readline(), readlines(), close(), name."""
 
     def __init__(self, lines: List[str], name: str):
-        self._lines, self.name = lines, name
-
-    def __iter__(self):
-        return iter(self._lines)
-
-    def readlines(self):
-        return list(self._lines)
-
-    def close(self):
-        pass
+        super().__init__("".join(lines), newline="\n")
+        self.name = name
 
 
 class _Sink(io.StringIO):

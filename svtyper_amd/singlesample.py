@@ -20,8 +20,8 @@ from . import __version__
 from . import evidence as ev
 from .bam import open_alignment_file
 from .library import Sample, setup_sample, write_sample_json
-from .pipeline import (MIN_LIB_PREVALENCE, ChunkPipeline, NativeUnitCollector, SampleColumnWriter, UnitCollector, add_read_to,
-                       default_engine, fetch_window)
+from .pipeline import (BULK_BLOCK_UNITS, MIN_LIB_PREVALENCE, BulkFeeder, ChunkPipeline, NativeUnitCollector, split_lines, SampleColumnWriter, UnitCollector, add_read_to,
+                       default_engine, fetch_window, resolve_reader)
 from .results import results_to_dicts
 from .vcf import Variant, Vcf
 
@@ -128,9 +128,10 @@ def assign_genotype(variant: Variant, sample_name: str, res: dict) -> None:
 
 def sso_genotype(bam_string, vcf_in, vcf_out, min_aligned, split_weight, disc_weight, num_samp, lib_info_path,
                  debug, ref_fasta, sum_quals, max_reads, max_ci_dist, cores, batch_size, *, engine=None, geometry="host",
-                 reader="python"):
+                 reader=None):
     if vcf_in is None:
         return
+    reader = resolve_reader(reader)
     full_bam_path = os.path.abspath(bam_string)
     if not (full_bam_path.endswith(".bam") or full_bam_path.endswith(".cram")):
         sys.exit("Error: %s is not a valid alignment file (*.bam or *.cram)\n" % full_bam_path)
@@ -153,24 +154,45 @@ def sso_genotype(bam_string, vcf_in, vcf_out, min_aligned, split_weight, disc_we
     if engine is None:
         engine = default_engine()
 
+    # bulk route (reader="native"): the body as blocks of text -> breakpoint arrays -> output text in native calls
+    # (bulk_vcf.py); the per-line route below stays the general one (and takes over at a BND line the parser cannot express)
+    bulk = None
+    if reader == "native" and hasattr(vcf_in, "read") and os.environ.get("SVT_BULK_VCF", "1") != "0":
+        from . import bulk_vcf
+        if bulk_vcf.available():
+            bulk = bulk_vcf
+
     # header: only the '##' lines are parsed, so sample columns of the input are not carried over and
     # the BAM's sample becomes the only column (singlesample.py:112-125)
-    lines = vcf_in.readlines()
     header = []
-    for line in lines:
-        if line.startswith("##"):
-            header.append(line)
-        else:
-            break
+    input_samples = []
+    if bulk is None:
+        lines = vcf_in.readlines()
+        for line in lines:
+            if line.startswith("##"):
+                header.append(line)
+            else:
+                break
+        for line in lines:
+            if line.startswith("#CHROM"):
+                input_samples = line.rstrip().split("\t")[9:]
+                break
+    else:
+        text = vcf_in.read()
+        body_at = 0
+        while text.startswith("##", body_at):
+            nl = text.find("\n", body_at)
+            end = len(text) if nl < 0 else nl + 1
+            header.append(text[body_at:end])
+            body_at = end
+        at = 0 if text.startswith("#CHROM") else text.find("\n#CHROM") + 1
+        if at > 0 or text.startswith("#CHROM"):
+            nl = text.find("\n", at)
+            input_samples = text[at:len(text) if nl < 0 else nl].rstrip().split("\t")[9:]
     vcf = Vcf()
     vcf.filename = getattr(vcf_in, "name", "<stdin>")
     vcf.add_header(header)
     vcf.add_custom_svtyper_headers()
-    input_samples = []
-    for line in lines:
-        if line.startswith("#CHROM"):
-            input_samples = line.rstrip().split("\t")[9:]
-            break
     if sample.name not in input_samples:
         logit("Note: Did not find sample name : '%s' in input vcf: '%s' -- adding" % (sample.name, vcf.filename))
     vcf.add_sample(sample.name)
@@ -195,11 +217,12 @@ def sso_genotype(bam_string, vcf_in, vcf_out, min_aligned, split_weight, disc_we
 
     fast = SampleColumnWriter(vcf, [sample.name], skipped_as_dots=False)
 
-    def write_out(results, actions):
+    def render_actions(results, actions):
+        """the output text of every action, one string each"""
         columns = gts = sqs = dicts = None
         for action in actions:
             if action[0] == "raw":
-                action[1].write(vcf_out)
+                yield action[1].get_var_string() + "\n"
                 continue
             _, variant, variant2, unit = action
             if fast.eligible(variant):
@@ -209,36 +232,39 @@ def sso_genotype(bam_string, vcf_in, vcf_out, min_aligned, split_weight, disc_we
                 if gts[unit] >= 0:
                     variant.qual += sqs[unit]          # singlesample.py:544-546
                 cols = columns[unit:unit + 1]
-                print(variant.get_var_string_with(fast.format_string, cols), file=vcf_out)
+                out = variant.get_var_string_with(fast.format_string, cols) + "\n"
                 if variant2 is not None:
                     variant2.qual = variant.qual
-                    print(variant2.get_var_string_with(fast.format_string, cols), file=vcf_out)
+                    out += variant2.get_var_string_with(fast.format_string, cols) + "\n"
+                yield out
                 continue
             if dicts is None:
                 dicts = results_to_dicts(results)   # blank for "no evidence" and "too many reads" alike
             assign_genotype(variant, sample.name, dicts[unit])
-            variant.write(vcf_out)
+            out = variant.get_var_string() + "\n"
             if variant2 is not None:
                 variant.share_genotypes_with(variant2)
-                variant2.write(vcf_out)
+                out += variant2.get_var_string() + "\n"
+            yield out
 
-    for line in lines:
-        if line.startswith("#"):
-            continue
+    def write_out(results, actions):
+        for out in render_actions(results, actions):
+            vcf_out.write(out)
+
+    def handle_line(line, unit_base=0):
+        """One variant line -> its output action (singlesample.py:577-652), None for a first BND mate"""
         variant = Variant(line.rstrip().split("\t"), vcf)
         if not sum_quals:
             variant.qual = 0
         if not variant.has_svtype():
             logit("Warning: SVTYPE missing at variant %s. Skipping.\n" % variant.var_id)
-            pending.append(("raw", variant))
-            continue
+            return ("raw", variant)
         if not variant.is_valid_svtype():
             logit("Warning: Unsupported SVTYPE at variant %s (%s). Skipping.\n" % (variant.var_id, variant.get_svtype()))
-            pending.append(("raw", variant))
-            continue
+            return ("raw", variant)
         bp = vcf.get_variant_breakpoints(variant, max_ci_dist)
         if bp is None:
-            continue
+            return None
         variant2 = None
         if variant.get_svtype() == "BND":
             variant2 = variant
@@ -248,9 +274,44 @@ def sso_genotype(bam_string, vcf_in, vcf_out, min_aligned, split_weight, disc_we
         else:
             fragments, many = gather_reads(sample, bp, max_reads)
             unit = collector.add(bp, 0, fragments, skip=many)
-        pending.append(("gt", variant, variant2, unit))
-        if len(collector) >= CHUNK_UNITS:
-            flush()
+        return ("gt", variant, variant2, unit - unit_base)
+
+    def per_line(lines):
+        for line in lines:
+            if line.startswith("#"):
+                continue
+            action = handle_line(line)
+            if action is not None:
+                pending.append(action)
+            if len(collector) >= CHUNK_UNITS:
+                flush()
+
+    if bulk is None:
+        per_line(lines)
+    else:
+        def blocks():
+            units = int(os.environ.get("SVT_BULK_BLOCK_UNITS", BULK_BLOCK_UNITS))
+            nl = text.find("\n", body_at)
+            chars = min(max(units * max(64, (nl if nl >= 0 else len(text)) - body_at), 1 << 10), 256 << 20)
+            at = body_at
+            while at < len(text):
+                cut = text.find("\n", at + chars)
+                end = len(text) if cut < 0 else cut + 1
+                yield text[at:end]
+                at = end
+        feeder = BulkFeeder(bulk, vcf, collector, pipe, engine, ev.FLAG_SSO_ASSOCIATION, 1, fast, bulk.QUAL_SSO, max_ci_dist,
+                            sum_quals, True, handle_line, render_actions, vcf_out.write)
+        source = blocks()
+        rest = feeder.run(source)
+        if rest is not None:          # the per-line route from here on, with the BND mates the parser was holding
+            for held in feeder.pending_lines():
+                mate = Variant(held.split("\t"), vcf)
+                if not sum_quals:
+                    mate.qual = 0
+                vcf._bnd_pending[mate.var_id] = mate
+            per_line(rest)
+            for block in source:
+                per_line(split_lines(block))
     flush()
     pipe.close()
     sample.close()

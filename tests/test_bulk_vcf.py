@@ -1,0 +1,399 @@
+"""The bulk VCF route (include/svtyper_vcf.h, svtyper_amd/bulk_vcf.py) against the per-line Python code it stands in
+for (svtyper_amd/vcf.py, written after svtyper/parsers.py:11-399 and byte-checked against the reference's
+example.gt.vcf): the same breakpoints for every line it takes, the same output bytes from the same result records,
+and -- through both drivers -- the same VCF for inputs full of the lines it hands back or stops at.  CPU only: the
+likelihood seam is filled by the oracle (test infrastructure), exactly as in test_host_pipeline.py."""
+import io
+import os
+import random
+
+import numpy as np
+import pytest
+
+from svtyper_amd import bulk_vcf, classic, evidence as ev, singlesample
+from svtyper_amd.vcf import Variant, Vcf
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+DATA = os.path.join(HERE, "data")
+IN_VCF = os.path.join(DATA, "example.vcf")
+IN_BAM = os.path.join(DATA, "NA12878.target_loci.sorted.bam")
+LIB_JSON = os.path.join(DATA, "NA12878.bam.json")
+EXPECTED = os.path.join(DATA, "example.gt.vcf")
+FIELDS = ("GT", "GQ", "SQ", "GL", "DP", "RO", "AO", "QR", "QA", "RS", "AS", "ASC", "RP", "AP", "AB")
+
+
+def oracle_engine(batch, flags=0, **kw):
+    from oracle import c_oracle
+    return c_oracle.genotype_batch(batch, flags=flags)
+
+
+def fixture_lines():
+    lines = open(IN_VCF).readlines()
+    return [l for l in lines if l.startswith("#")], [l for l in lines if not l.startswith("#")]
+
+
+def header_vcf(head, sample="NA12878"):
+    vcf = Vcf()
+    vcf.add_header([l for l in head if l.startswith("##")])
+    vcf.add_custom_svtyper_headers()
+    vcf.add_sample(sample)
+    return vcf
+
+
+class Sink(io.StringIO):
+    def close(self):
+        pass
+
+
+def run_driver(driver, text, bulk, monkeypatch, sum_quals=False, max_ci_dist=1e10, block_units=None):
+    monkeypatch.setenv("SVT_BULK_VCF", "1" if bulk else "0")
+    if block_units is not None:
+        monkeypatch.setenv("SVT_BULK_BLOCK_UNITS", str(block_units))
+    out, err = Sink(), io.StringIO()
+    import sys
+    old, sys.stderr = sys.stderr, err
+    try:
+        if driver == "sso":
+            singlesample.sso_genotype(IN_BAM, io.StringIO(text), out, 20, 1, 1, 1000000, LIB_JSON, False, None, sum_quals,
+                                      1000, max_ci_dist, None, 1000, engine=oracle_engine, reader="native")
+        else:
+            classic.sv_genotype(IN_BAM, io.StringIO(text), out, 20, 1, 1, 1000000, LIB_JSON, False, None, None, sum_quals,
+                                None, max_ci_dist, engine=oracle_engine, reader="native")
+    finally:
+        sys.stderr = old
+    strip = lambda t: [l for l in t.split("\n") if not l.startswith("##fileDate=")]
+    warnings = [l for l in err.getvalue().split("\n") if "Warning" in l]
+    return strip(out.getvalue()), warnings
+
+
+# ---------------------------------------------------------------------------------------------- the parser by itself
+def python_breakpoints(vcf, lines, max_ci_dist=1e10, sum_quals=False):
+    """what the per-line code makes of `lines`: (line index of the site's line, breakpoint dict, incoming QUAL) per site"""
+    sites = []
+    for i, line in enumerate(lines):
+        var = Variant(line.rstrip().split("\t"), vcf)
+        if not sum_quals:
+            var.qual = 0
+        if not var.has_svtype() or not var.is_valid_svtype():
+            continue
+        bp = vcf.get_variant_breakpoints(var, max_ci_dist)
+        if bp is None:
+            continue
+        first = vcf._bnd_first.pop(bp["id"]) if var.get_svtype() == "BND" else var
+        sites.append((i, bp, first.qual, first, var if first is not var else None))
+    return sites
+
+
+def assert_sites_equal(chunk, names, want):
+    s = chunk.sites
+    assert len(s) == len(want)
+    site_lines = np.nonzero(chunk.line_kind == bulk_vcf.LINE_SITE)[0].tolist()
+    assert site_lines == [w[0] for w in want]
+    for k, (_, bp, qual, _, _) in enumerate(want):
+        assert s.names[s.chrom[k, 0]] == bp["A"]["chrom"] and s.names[s.chrom[k, 1]] == bp["B"]["chrom"]
+        assert (int(s.pos[k, 0]), int(s.pos[k, 1])) == (bp["A"]["pos"], bp["B"]["pos"])
+        assert s.ci[k].tolist() == list(bp["A"]["ci"]) + list(bp["B"]["ci"])
+        assert int(s.reverse[k]) == int(bp["A"]["is_reverse"]) | (int(bp["B"]["is_reverse"]) << 1)
+        assert int(s.svtype[k]) == ev.SVTYPE_CODE[bp["svtype"]]
+        assert int(s.var_length[k]) == bp.get("var_length", 0)
+        assert float(chunk.qual_in[k]) == float(qual)
+
+
+def test_fixture_breakpoints_equal_the_python_model():
+    head, body = fixture_lines()
+    vcf = header_vcf(head)
+    parser = bulk_vcf.VcfParser(vcf, 1e10, False, True)
+    raw = "".join(body).encode()
+    chunk, used = parser.parse(raw)
+    assert used == len(raw) and chunk.n_lines == len(body)
+    want = python_breakpoints(header_vcf(head), body)
+    assert len(want) == 211
+    assert_sites_equal(chunk, parser.chrom_names(), want)
+    assert parser.pending_lines() == []
+    kinds = chunk.line_kind.tolist()
+    assert kinds.count(bulk_vcf.LINE_HELD) == 1 and kinds.count(bulk_vcf.LINE_PYTHON) == 0   # one BND pair in the fixture
+
+
+def random_results(n, seed, skipped=True):
+    rng = np.random.default_rng(seed)
+    res = ev.Results.empty(n)
+    codes = [0, 1, 2, ev.GT_MISSING, ev.GT_BLANK] + ([ev.GT_SKIPPED] if skipped else [])
+    res.rec["gt"] = rng.choice(codes, n, p=[0.3, 0.25, 0.2, 0.05, 0.1, 0.1] if skipped else [0.3, 0.3, 0.2, 0.1, 0.1])
+    res.rec["gl"] = -rng.random((n, 3)) * 300
+    res.rec["sq"] = rng.random(n) * 2000
+    res.rec["counts"] = rng.integers(0, 300, (n, 11))
+    return res
+
+
+@pytest.mark.parametrize("mode,n_samp", [("sso", 1), ("classic", 1), ("classic", 3)])
+def test_emitted_lines_equal_the_python_rendering(mode, n_samp):
+    """svt_vcf_emit == Variant.get_var_string_with + the drivers' QUAL rules, for every GT code, BND pairs included"""
+    from svtyper_amd import hip
+    head, body = fixture_lines()
+    def mk():
+        vcf = Vcf()
+        vcf.add_header([l for l in head if l.startswith("##")])
+        vcf.add_custom_svtyper_headers()
+        for k in range(n_samp):
+            vcf.add_sample("S%d" % k)
+        return vcf
+
+    vcf = mk()
+    body = body * 3
+    parser = bulk_vcf.VcfParser(vcf, 1e10, True, True)           # --sum_quals: the incoming QUAL counts
+    body = [l.replace("\t0\t.\t", "\t%d.5\t.\t" % (i % 7), 1) if i % 3 == 0 else l for i, l in enumerate(body)]
+    chunk, used = parser.parse("".join(body).encode())
+    want = python_breakpoints(mk(), body, sum_quals=True)
+    assert_sites_equal(chunk, parser.chrom_names(), want)
+    res = random_results(chunk.n_sites * n_samp, 7, skipped=True)
+    if mode == "classic":      # sites whose samples were all skipped (classic.py:282-284)
+        res.rec["gt"][: 4 * n_samp] = ev.GT_SKIPPED
+    classic_mode = mode == "classic"
+    order = sorted(FIELDS, key=lambda k: vcf.format_rank[k])
+    fmt = ":".join(order)
+    text, off = chunk.emit(res, n_samp, bulk_vcf.QUAL_CLASSIC if classic_mode else bulk_vcf.QUAL_SSO, order, classic_mode, fmt)
+    cols = hip.format_results(res, order, classic_mode)
+    gts, sqs = res.gt.tolist(), res.sq.tolist()
+    got = text.decode().split("\n")
+    at = 0
+    for k, (_, bp, qual, first, second) in enumerate(want):
+        unit = k * n_samp
+        q = qual
+        for j in range(n_samp):
+            if gts[unit + j] >= 0:
+                q += sqs[unit + j]
+            elif gts[unit + j] == ev.GT_BLANK and classic_mode:
+                q = 0
+        first.qual = q
+        if classic_mode and all(g == ev.GT_SKIPPED for g in gts[unit:unit + n_samp]):
+            lines = [first.get_var_string_with("GT", ["./."] * n_samp)]
+            if second is not None:
+                second.qual = q
+                lines.append(second.get_var_string_with("GT", ["./."] * n_samp))
+        else:
+            lines = [first.get_var_string_with(fmt, cols[unit:unit + n_samp])]
+            if second is not None:
+                second.qual = q
+                lines.append(second.get_var_string_with(fmt, cols[unit:unit + n_samp]))
+        assert got[at:at + len(lines)] == lines, (k, got[at:at + len(lines)], lines)
+        assert text[off[k]:off[k + 1]].decode() == "".join(l + "\n" for l in lines)
+        at += len(lines)
+    assert got[at:] == [""]
+
+
+ODD_FIELDS = {
+    1: ["+5", " 5", "5 ", "1_000", "", "0x10", "12345678901234567890", "-0", "007", "٣"],
+    5: ["1e2", "nan", "inf", "1_0", " 1", "", "-", ".", "1.", ".5", "0x1p3", "1e400", "+3.25", "1e", "١"],
+}
+
+
+def mutate(line, rng):
+    """a variant line with one thing about it changed -- most of them things only Python reads its own way"""
+    cols = line.rstrip("\n").split("\t")
+    kind = rng.randrange(16)
+    info = cols[7].split(";")
+    if kind == 0:
+        cols[1] = rng.choice(ODD_FIELDS[1])
+    elif kind == 1:
+        cols[5] = rng.choice(ODD_FIELDS[5])
+    elif kind == 2:
+        info = [i for i in info if not i.startswith(rng.choice(["SVTYPE=", "END=", "CIPOS=", "CIEND=", "MATEID="]))]
+    elif kind == 3:
+        info = [i.replace("SVTYPE=DEL", "SVTYPE=" + rng.choice(["INS", "CNV", "del", "DEL2", ""])) for i in info]
+    elif kind == 4:
+        k = rng.randrange(len(info))
+        info.insert(k, rng.choice(["IMPRECISE", "SVTYPE", "END", "FOO=1=2", "END=12=13", "", "CIPOS=1", "CIPOS=-1,2,3",
+                                   "CIEND=-5,+5", "CIPOS= 0,0", "END=1e3", "NEWKEY=7", "PRPOS=0.5,0.5", "SVTYPE=DUP", "END=250000000"]))
+    elif kind == 5:
+        info.append(rng.choice(["SVTYPE=INV", "END=%d" % (int(cols[1]) + 999), "CIPOS=-3,4", "CIPOS95=-1,1", "MATEID=zzz"]))
+    elif kind == 6:
+        cols += rng.choice([["GT"], ["GT", "0/1"], ["GT:SU", "0/1:4"], ["GT", "./.", "1/1"], ["SU", "3"], ["GT", "0/0:7"]])
+    elif kind == 7:
+        cols[-1] += rng.choice([" ", "\r", "\t", "\x0b", " ", "\x1c"])
+    elif kind == 8:
+        cols = cols[:rng.randrange(1, 8)]
+    elif kind == 9:
+        info = [i.replace("CIPOS=", "CIPOS=-%d," % 10 ** rng.randrange(2, 12), 1).replace(",0,0", ",0") if i.startswith("CIPOS=") else i for i in info]
+        info.append(rng.choice(["CIPOS95=-2,2", "CIPOS95=x,2", "CIEND95=0,0", "X=1"]))
+    elif kind == 10:
+        cols[4] = rng.choice(["", "N[2:321[", "]2:321]N", "<DEL>", "N", "["])
+    elif kind == 11:
+        cols[2] = rng.choice(["dup_id", "", "a;b", "id with space"])
+    elif kind == 12:
+        cols[6] = rng.choice(["PASS", ".", "q10;s50", ""])
+    elif kind == 13:
+        info = [i.upper() if rng.random() < 0.2 else i for i in info]
+    elif kind == 14:
+        info = info[::-1]
+    cols[7:8] = [";".join(info)] if len(cols) > 7 else []
+    return "\t".join(cols) + "\n"
+
+
+def test_differential_fuzz_of_the_parser_against_the_python_model():
+    """Mutated fixture lines, one at a time in front of a clean BND pair: every line the parser TAKES gives the breakpoint
+    dict and the output text Python gives; what it hands back or stops at is the per-line code's business.  Python raising
+    on a line (a crash of the reference) must never be a line the parser took."""
+    head, body = fixture_lines()
+    rng = random.Random(20260930)
+    bnd = [l for l in body if "SVTYPE=BND" in l]
+    plain = [l for l in body if "SVTYPE=BND" not in l]
+    vcf = header_vcf(head)
+    order = sorted(FIELDS, key=lambda k: vcf.format_rank[k])
+    fmt = ":".join(order)
+    from svtyper_amd import hip
+    taken = handed_back = stopped = 0
+    for trial in range(1500):
+        src = rng.choice(bnd) if rng.random() < 0.15 else rng.choice(plain)
+        line = mutate(src, rng)
+        sum_quals = rng.random() < 0.5
+        max_ci = rng.choice([1e10, 50, 0])
+        parser = bulk_vcf.VcfParser(vcf, max_ci, sum_quals, False)
+        chunk, used = parser.parse(line.encode("utf-8", "surrogateescape"))
+        model = header_vcf(head)
+        try:
+            want = python_breakpoints(model, [line], max_ci, sum_quals)
+            crashed = False
+        except (SystemExit, Exception):
+            want, crashed = None, True
+        if used == 0:
+            stopped += 1
+            continue
+        kind = int(chunk.line_kind[0])
+        if kind == bulk_vcf.LINE_PYTHON:
+            handed_back += 1
+            continue
+        assert not crashed, line
+        taken += 1
+        if kind == bulk_vcf.LINE_HELD:
+            assert want == [] and list(model._bnd_pending) == [line.split("\t")[2]]
+            assert parser.pending_lines() == [line.rstrip("\n")]
+            continue
+        assert kind == bulk_vcf.LINE_SITE
+        assert_sites_equal(chunk, parser.chrom_names(), want)
+        res = random_results(1, trial, skipped=False)
+        text, _ = chunk.emit(res, 1, bulk_vcf.QUAL_SSO, order, False, fmt)
+        first = want[0][3]
+        if res.gt[0] >= 0:
+            first.qual += float(res.sq[0])
+        assert text.decode("utf-8", "surrogateescape") == first.get_var_string_with(fmt, hip.format_results(res, order, False)) + "\n", line
+    assert taken > 300 and handed_back > 300 and stopped > 20, (taken, handed_back, stopped)
+
+
+# ---------------------------------------------------------------------------------------------- through the drivers
+@pytest.mark.parametrize("driver", ["sso", "classic"])
+def test_fixture_through_the_bulk_route_is_the_expected_vcf(driver, monkeypatch):
+    text = open(IN_VCF).read()
+    got, _ = run_driver(driver, text, True, monkeypatch)
+    want = [l for l in open(EXPECTED).read().split("\n") if not l.startswith("##fileDate=")]
+    assert got == want
+
+
+def odd_vcf(seed, n=260):
+    """the fixture's body with every kind of line the bulk route hands back or stops at mixed in, BND pairs split far
+    apart, repeated, and one left without its partner"""
+    head, body = fixture_lines()
+    rng = random.Random(seed)
+    bnd = [l for l in body if "SVTYPE=BND" in l]
+    plain = [l for l in body if "SVTYPE=BND" not in l]
+    out = []
+    pairs = 0
+    waiting = []
+    for i in range(n):
+        r = rng.random()
+        if r < 0.08:           # a BND pair with ids of its own, the second mate some lines later
+            a, b = bnd
+            tag = "_p%d" % pairs
+            pairs += 1
+            ida, idb = a.split("\t")[2], b.split("\t")[2]
+            a2 = a.replace(ida, ida + tag).replace(idb, idb + tag)
+            b2 = b.replace(ida, ida + tag).replace(idb, idb + tag)
+            out.append(a2)
+            waiting.append((i + rng.randrange(1, 40), b2))
+        elif r < 0.25:
+            line = mutate(rng.choice(plain), rng)
+            cols = line.rstrip("\n").split("\t")
+            if len(cols) >= 8:      # (fewer than eight columns is exit(1) in every implementation: not a comparison)
+                try:                # (and so is what Python cannot read at all: keep the lines the per-line code survives)
+                    python_breakpoints(header_vcf(head), [line])
+                    out.append(line)
+                except (SystemExit, Exception):
+                    pass
+        else:
+            out.append(rng.choice(plain))
+        for w in [w for w in waiting if w[0] <= i]:
+            out.append(w[1])
+            waiting.remove(w)
+    out.append(bnd[0].replace(bnd[0].split("\t")[2], "lonely_mate"))
+    return "".join(head) + "".join(out)
+
+
+@pytest.mark.parametrize("driver", ["sso", "classic"])
+@pytest.mark.parametrize("seed,block_units", [(1, None), (2, 16), (3, 64)])
+def test_odd_lines_and_split_bnd_pairs_bulk_equals_per_line(driver, seed, block_units, monkeypatch):
+    text = odd_vcf(seed)
+    want, want_warn = run_driver(driver, text, False, monkeypatch)
+    got, got_warn = run_driver(driver, text, True, monkeypatch, block_units=block_units)
+    assert got == want
+    assert got_warn == want_warn
+    assert len(want) > 200
+
+
+@pytest.mark.parametrize("driver", ["sso", "classic"])
+def test_a_bnd_line_off_the_fast_route_hands_over_to_the_per_line_code(driver, monkeypatch):
+    """a BND mate with sample columns carrying FORMAT values, in the middle: the parser stops there, the first mates it was
+    holding move into the Vcf model, everything behind is the per-line route -- same bytes as the per-line route alone"""
+    head, body = fixture_lines()
+    bnd = [l for l in body if "SVTYPE=BND" in l]
+    plain = [l for l in body if "SVTYPE=BND" not in l]
+    ida, idb = bnd[0].split("\t")[2], bnd[1].split("\t")[2]
+    early_first = bnd[0].replace(ida, "e1").replace(idb, "e2")
+    early_second = bnd[1].replace(ida, "e1").replace(idb, "e2")
+    odd_first = bnd[0].rstrip("\n") + "\tGT:GQ\t0/1:9\n"
+    lines = plain[:30] + [early_first] + plain[30:60] + [odd_first] + plain[60:90] + [early_second, bnd[1]] + plain[90:120]
+    text = "".join(head) + "".join(lines)
+    want, _ = run_driver(driver, text, False, monkeypatch)
+    got, _ = run_driver(driver, text, True, monkeypatch, block_units=50)
+    assert got == want
+    assert sum(1 for l in got if "\te1\t" in l or "\te2\t" in l) == 2
+
+
+@pytest.mark.parametrize("driver", ["sso", "classic"])
+def test_sum_quals_and_the_95_percent_interval_through_the_bulk_route(driver, monkeypatch):
+    head, body = fixture_lines()
+    rng = random.Random(5)
+    lines = []
+    for i, l in enumerate(body):
+        cols = l.rstrip("\n").split("\t")
+        cols[5] = rng.choice(["0", ".", "12.5", "3", "1e2", "0.125"])
+        cols[7] = cols[7].replace("CIPOS=0,0", "CIPOS=-%d,%d" % (rng.randrange(0, 80), rng.randrange(0, 80))) + ";CIPOS95=-2,3;CIEND95=-1,1"
+        lines.append("\t".join(cols) + "\n")
+    text = "".join(head) + "".join(lines)
+    for max_ci in (1e10, 60):
+        want, _ = run_driver(driver, text, False, monkeypatch, sum_quals=True, max_ci_dist=max_ci)
+        got, _ = run_driver(driver, text, True, monkeypatch, sum_quals=True, max_ci_dist=max_ci)
+        assert got == want
+
+
+def test_unpaired_breakends_are_reported_by_the_classic_driver(monkeypatch, caplog):
+    head, body = fixture_lines()
+    bnd = [l for l in body if "SVTYPE=BND" in l]
+    text = "".join(head) + "".join(body[:20]) + bnd[0].replace(bnd[0].split("\t")[2], "lonely")
+    import logging
+    for bulk in (False, True):
+        caplog.clear()
+        with caplog.at_level(logging.WARNING):
+            run_driver("classic", text, bulk, monkeypatch)
+        assert any("Unpaired breakends" in r.getMessage() for r in caplog.records), bulk
+
+
+def test_the_c_abi_exports_the_bulk_vcf_calls():
+    import ctypes
+    import re
+    from svtyper_amd import hip
+    src = open(os.path.join(os.path.dirname(HERE), "include", "svtyper_vcf.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(svt_vcf_[a-z_0-9]+)\s*\(", src)))
+    lib = ctypes.CDLL(hip.LIB_PATH)
+    assert declared == sorted(bulk_vcf.EXPORTS)
+    for s in declared:
+        assert hasattr(lib, s), s

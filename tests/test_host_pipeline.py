@@ -34,20 +34,20 @@ def same_vcf(a, b):
         assert x == y, "line %d differs:\n%s\n%s" % (i + 1, x, y)
 
 
-def run_classic(out, engine):
+def run_classic(out, engine, **kw):
     with open(IN_VCF) as inf, open(out, "w") as outf:
         classic.sv_genotype(bam_string=IN_BAM, vcf_in=inf, vcf_out=outf, min_aligned=20, split_weight=1,
                             disc_weight=1, num_samp=1000000, lib_info_path=LIB_JSON, debug=False,
                             alignment_outpath=None, ref_fasta=None, sum_quals=False, max_reads=None,
-                            max_ci_dist=1e10, engine=engine)
+                            max_ci_dist=1e10, engine=engine, **kw)
 
 
-def run_sso(out, engine, cores):
+def run_sso(out, engine, cores, **kw):
     with open(IN_VCF) as inf, open(out, "w") as outf:
         singlesample.sso_genotype(bam_string=IN_BAM, vcf_in=inf, vcf_out=outf, min_aligned=20, split_weight=1,
                                   disc_weight=1, num_samp=1000000, lib_info_path=LIB_JSON, debug=False,
                                   ref_fasta=None, sum_quals=False, max_reads=1000, max_ci_dist=1e10, cores=cores,
-                                  batch_size=1000, engine=engine)
+                                  batch_size=1000, engine=engine, **kw)
 
 
 def test_classic_integration_oracle_engine(tmp_path):
@@ -64,35 +64,61 @@ def test_sso_integration_oracle_engine(tmp_path, cores):
 
 
 @pytest.mark.parametrize("driver", ["classic", "sso"])
-def test_small_chunks_through_the_chunk_pipeline(tmp_path, monkeypatch, driver):
+def test_the_reference_signature_takes_the_native_bulk_route(tmp_path, monkeypatch, driver):
+    """A caller with the reference's own arguments (no `reader=`) gets the C++ reader and the bulk VCF route -- no Variant
+    object per line -- and the same bytes as the portable Python reader."""
+    from svtyper_amd import bulk_vcf, native_reads, pipeline, vcf
+    assert pipeline.resolve_reader(None) == "native" and pipeline.resolve_reader("python") == "python"
+    made = {"variant": 0, "evidence": 0, "blocks": 0}
+    init, evidence, parse = vcf.Variant.__init__, native_reads.NativeBam.evidence, bulk_vcf.VcfParser.parse
+    monkeypatch.setattr(vcf.Variant, "__init__", lambda self, *a: (made.__setitem__("variant", made["variant"] + 1), init(self, *a))[1])
+    monkeypatch.setattr(native_reads.NativeBam, "evidence", lambda self, *a: (made.__setitem__("evidence", made["evidence"] + 1), evidence(self, *a))[1])
+    monkeypatch.setattr(bulk_vcf.VcfParser, "parse", lambda self, *a: (made.__setitem__("blocks", made["blocks"] + 1), parse(self, *a))[1])
+    run = (lambda out, **kw: run_classic(out, oracle_engine, **kw)) if driver == "classic" else (lambda out, **kw: run_sso(out, oracle_engine, None, **kw))
+    default = str(tmp_path / "default.vcf")
+    run(default)
+    assert made == {"variant": 0, "evidence": 1, "blocks": 1}
+    same_vcf(EXPECTED, default)
+    portable = str(tmp_path / "python.vcf")
+    run(portable, reader="python")
+    assert made["variant"] == 212 and made["evidence"] == 1
+    same_vcf(default, portable)
+
+
+@pytest.mark.parametrize("driver", ["classic", "sso"])
+@pytest.mark.parametrize("reader", ["python", None])
+def test_small_chunks_through_the_chunk_pipeline(tmp_path, monkeypatch, driver, reader):
     """Many device batches per run: chunk k is genotyped on the worker thread while chunk k+1 is parsed,
-    the output order and bytes stay those of the single-batch run (BND mates straddle chunk borders)."""
+    the output order and bytes stay those of the single-batch run (BND mates straddle chunk borders) -- per line with the
+    Python reader, in blocks of text on the default route."""
     calls = []
 
-    def counting_engine(batch, flags=0):
+    def counting_engine(batch, flags=0, **kw):
         calls.append(batch.n_units)
         return oracle_engine(batch, flags)
 
     out = str(tmp_path / "out.vcf")
+    monkeypatch.setenv("SVT_BULK_BLOCK_UNITS", "17")
     if driver == "classic":
         monkeypatch.setattr(classic, "CHUNK_UNITS", 17)
-        run_classic(out, counting_engine)
+        run_classic(out, counting_engine, reader=reader)
     else:
         monkeypatch.setattr(singlesample, "CHUNK_UNITS", 17)
-        run_sso(out, counting_engine, None)
+        run_sso(out, counting_engine, None, reader=reader)
     same_vcf(EXPECTED, out)
-    assert len(calls) >= 12 and max(calls) <= 17
+    assert len(calls) >= 3 and max(calls) <= (17 if reader == "python" else 200)
 
 
 @pytest.mark.parametrize("driver", ["classic", "sso"])
 def test_bulk_sample_columns_and_general_path_write_the_same_bytes(tmp_path, monkeypatch, driver):
-    """The fixture is a sites-only VCF, so the drivers take the bulk formatter (svt_format_results); with it
+    """The fixture is a sites-only VCF, so the per-line route takes the bulk formatter (svt_format_results); with it
     switched off the per-sample Genotype path must produce the same file (== the reference's output)."""
     from svtyper_amd import pipeline
     calls = []
     orig = pipeline.SampleColumnWriter.columns
     monkeypatch.setattr(pipeline.SampleColumnWriter, "columns", lambda self, r: (calls.append(r.n_units), orig(self, r))[1])
-    run = (lambda out: run_classic(out, oracle_engine)) if driver == "classic" else (lambda out: run_sso(out, oracle_engine, None))
+    run = ((lambda out: run_classic(out, oracle_engine, reader="python")) if driver == "classic" else
+           (lambda out: run_sso(out, oracle_engine, None, reader="python")))
     bulk = str(tmp_path / "bulk.vcf")
     run(bulk)
     assert calls, "the bulk formatter was not used"
