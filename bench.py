@@ -409,7 +409,7 @@ def time_passes(dbatch, steps: int) -> float:
     return dbatch.genotype_timed(steps) / steps
 
 
-def _wgs_like_bam(path: str, genome: int = 1_200_000, coverage: float = 30.0, spacing: int = 4_000, seed: int = 1):
+def _wgs_like_bam(path: str, genome: int = 1_200_000, coverage: float = 30.0, spacing: int = 4_000, seed: int = 1, sample: str = "smp"):
     """A bounded BAM that looks like whole-genome sequencing (tests/bamwriter.py): 150-bp pairs at ~30x with random bases and
     binned qualities (BGZF blocks inflate at a realistic cost), one DEL site every few kb -- every site touches blocks nobody
     has inflated yet.  Returns (library info dict, breakpoint dicts)."""
@@ -417,7 +417,7 @@ def _wgs_like_bam(path: str, genome: int = 1_200_000, coverage: float = 30.0, sp
     import bamwriter as bw
     rng = np.random.default_rng(seed)
     n_pairs = int(genome * coverage / 300)
-    header = "@HD\tVN:1.5\tSO:coordinate\n@SQ\tSN:1\tLN:%d\n@RG\tID:rg\tSM:smp\tLB:lib\n" % genome
+    header = "@HD\tVN:1.5\tSO:coordinate\n@SQ\tSN:1\tLN:%d\n@RG\tID:rg\tSM:%s\tLB:lib\n" % (genome, sample)
     starts = rng.integers(0, genome - 1000, n_pairs)
     isz = np.clip(rng.normal(400, 60, n_pairs), 160, 900).astype(np.int64)
     seq_pool = rng.integers(0, 4, (4096, 75))
@@ -444,7 +444,7 @@ def _wgs_like_bam(path: str, genome: int = 1_200_000, coverage: float = 30.0, sp
     recs.sort(key=lambda r: r["pos"])
     bw.write_bam(path, header, [("1", genome)], recs, block_bytes=65280)
     hist = {str(k): int(1000 * np.exp(-((k - 400) / 85.0) ** 2)) + 1 for k in range(160, 900)}
-    info = {"smp": {"mapped": len(recs), "unmapped": 0, "bam": path, "sample_name": "smp", "libraryArray": [
+    info = {sample: {"mapped": len(recs), "unmapped": 0, "bam": path, "sample_name": sample, "libraryArray": [
         {"library_name": "lib", "readgroups": ["rg"], "read_length": 150, "histogram": hist, "mean": 400.0, "sd": 60.0, "prevalence": 1.0}]}}
     sites = []
     for pos in range(20_000, genome - 20_000, spacing):
@@ -632,6 +632,102 @@ def real_data_leg(device: int) -> dict:
         out["wgs_like_30x"]["device_geometry"] = {k: dg[k] for k in ("wall_ms", "sites_per_s", "stage_ms", "h2d_bytes") if k in dg}
         out["wgs_like_30x"]["device_geometry"]["same_genotypes"] = dg["gt_histogram"] == out["wgs_like_30x"]["gt_histogram"]
         nbam.close()
+    return out
+
+
+def driver_legs() -> dict:
+    """The PUBLIC drivers end to end, called with the reference's own positional arguments (svtyper/singlesample.py:764-778,
+    classic.py:107-120; no `reader=`, no `engine=`): VCF text in -> VCF text out through the bulk VCF route (svt_vcf_parse ->
+    svt_bam_evidence -> the device pass -> svt_vcf_emit).  `driver_sso`: the fixture's 212 variant lines x 100 through
+    sso_genotype; `driver_classic_8bam`: 8 WGS-like BAMs (300 kbp at 30x each, a sample of its own) x 10 500 DEL lines through
+    sv_genotype = 84 000 (site, sample) units with QUAL over the samples.  Best of three walls after one warm-up call; the
+    output is byte-compared with the per-line route's (SVT_BULK_VCF=0: one Variant object per line)."""
+    import io
+    import tempfile
+    from svtyper_amd import classic, singlesample
+
+    class Sink(io.StringIO):
+        def close(self):
+            pass
+
+    def quiet(fn):
+        with open(os.devnull, "w") as null:
+            old, sys.stderr = sys.stderr, null
+            try:
+                return fn()
+            finally:
+                sys.stderr = old
+
+    def timed(call, reps=3):
+        quiet(call)
+        best, text = None, None
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            text = quiet(call)
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        return best, text
+
+    def per_line(call):
+        os.environ["SVT_BULK_VCF"] = "0"
+        try:
+            t0 = time.perf_counter()
+            text = quiet(call)
+            return time.perf_counter() - t0, text
+        finally:
+            del os.environ["SVT_BULK_VCF"]
+
+    strip = lambda text: [l for l in text.split("\n") if not l.startswith("##fileDate")]
+    out = {}
+    data = os.path.join(ROOT, "tests", "data")
+    with open(os.path.join(data, "example.vcf")) as f:
+        lines = f.readlines()
+    head = [l for l in lines if l.startswith("#")]
+    body = [l for l in lines if not l.startswith("#")]
+    text_in = "".join(head) + "".join(body * 100)
+    bam_path, lib_json = os.path.join(data, "NA12878.target_loci.sorted.bam"), os.path.join(data, "NA12878.bam.json")
+
+    def sso():
+        sink = Sink()
+        singlesample.sso_genotype(bam_path, io.StringIO(text_in), sink, 20, 1, 1, 1000000, lib_json, False, None, False, 1000, 1e10, None, 1000)
+        return sink.getvalue()
+    wall, text = timed(sso)
+    pl_wall, pl_text = per_line(sso)
+    with open(os.path.join(data, "example.gt.vcf")) as f:
+        want = [l for l in strip(f.read()) if l and not l.startswith("#")]
+    got = [l for l in strip(text) if l and not l.startswith("#")]
+    n = len(body) * 100
+    out["driver_sso"] = {"what": "singlesample.sso_genotype(<the reference's 15 positional arguments>) over tests/data/example.vcf's %d variant lines x 100" % len(body),
+                         "variant_lines": n, "wall_ms": wall * 1e3, "sites_per_s": n / wall, "vcf_bytes_out": len(text),
+                         "every_repeat_equals_example_gt_vcf": bool(got == want * 100),
+                         "per_line_route": {"wall_ms": pl_wall * 1e3, "sites_per_s": n / pl_wall, "same_bytes": strip(pl_text) == strip(text)}}
+    with tempfile.TemporaryDirectory() as tmp:
+        paths, info, sites = [], {}, None
+        for k in range(8):
+            path = os.path.join(tmp, "s%d.bam" % k)
+            inf, sites, _ = _wgs_like_bam(path, genome=300_000, seed=40 + k, sample="smp%d" % k)
+            info.update(inf)
+            paths.append(path)
+        libs = os.path.join(tmp, "libs.json")
+        with open(libs, "w") as f:
+            json.dump(info, f)
+        vlines = ["1\t%d\t%s\tN\t<DEL>\t0\t.\tSVTYPE=DEL;SVLEN=-%d;END=%d;STR=+-:8;CIPOS=-10,10;CIEND=-10,10;SU=8;PE=6;SR=2\n"
+                  % (bp["A"]["pos"], bp["id"], bp["var_length"], bp["A"]["pos"] + bp["var_length"]) for bp in sites]
+        reps = -(-10_500 // len(vlines))
+        vtext = "".join(l for l in head if l.startswith("##")) + "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\n" + "".join(vlines * reps)
+
+        def joint():
+            sink = Sink()
+            classic.sv_genotype(",".join(paths), io.StringIO(vtext), sink, 20, 1, 1, 1000000, libs, False, None, None, False, None, 1e10)
+            return sink.getvalue()
+        wall, text = timed(joint)
+        pl_wall, pl_text = per_line(joint)
+        n = len(vlines) * reps
+        called = sum(1 for l in text.split("\n") if l and not l.startswith("#") and ("\t0/0:" in l or "\t0/1:" in l or "\t1/1:" in l))
+        out["driver_classic_8bam"] = {"what": "classic.sv_genotype(<the reference's 14 positional arguments>), 8 BAMs (300 kbp at 30x each) x %d DEL lines" % n,
+                                      "variant_lines": n, "samples": 8, "units": n * 8, "wall_ms": wall * 1e3, "sites_per_s": n / wall,
+                                      "units_per_s": n * 8 / wall, "vcf_bytes_out": len(text), "lines_with_a_called_genotype": called,
+                                      "per_line_route": {"wall_ms": pl_wall * 1e3, "units_per_s": n * 8 / pl_wall, "same_bytes": strip(pl_text) == strip(text)}}
     return out
 
 
@@ -1513,6 +1609,10 @@ def main():
                 out["real_data"] = real_data_leg(local_rank)
             except Exception as e:
                 out["real_data"] = {"error": repr(e)}
+            try:
+                out["real_data"].update(driver_legs())
+            except Exception as e:
+                out["real_data"]["driver_legs_error"] = repr(e)
 
         if more is not None:
             # ---- the same step at 4 M units per GPU: 6.5 GB of records, far beyond the 256 MiB Infinity Cache

@@ -8,9 +8,11 @@
 #include <sched.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <thread>
 #include <utility>
 #include <vector>
@@ -91,15 +93,52 @@ inline unsigned physical_cores()
     return cached;
 }
 
+// CPU seconds this process's host stages (the reader's calls) spent recently: a cgroup quota is CPU time per accounting period,
+// so a burst is only a burst while the calls before it have left something of the current period's allowance.  note_cpu_s()
+// after a call; recent_cpu_s(w) = what was noted within the last w seconds.
+struct CpuLedger {
+    std::mutex lock;
+    std::vector<std::pair<double, double>> spent;      // (when, CPU seconds)
+    static CpuLedger& get() { static CpuLedger l; return l; }
+    static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+};
+inline void note_cpu_s(double cpu_s)
+{
+    CpuLedger& l = CpuLedger::get();
+    std::lock_guard<std::mutex> g(l.lock);
+    const double t = CpuLedger::now_s();
+    size_t keep = 0;
+    for (size_t k = 0; k < l.spent.size(); ++k)
+        if (t - l.spent[k].first < 2.0) l.spent[keep++] = l.spent[k];
+    l.spent.resize(keep);
+    l.spent.emplace_back(t, cpu_s);
+}
+inline double recent_cpu_s(double window_s)
+{
+    CpuLedger& l = CpuLedger::get();
+    std::lock_guard<std::mutex> g(l.lock);
+    const double t = CpuLedger::now_s();
+    double sum = 0.0;
+    for (const auto& e : l.spent)
+        if (t - e.first < window_s) sum += e.second;
+    return sum;
+}
+
 // Threads for a burst of `est_cpu_s` seconds of CPU work.  A cgroup CPU quota is CPU time per accounting period (16 CPUs =
-// 1.6 s per 100 ms), not a number of threads: a call whose whole work fits well inside one period's allowance may run one
-// worker per physical core (at most `cap`) and be done sooner; a longer one is bound by the quota whatever it starts and
-// keeps to usable_cpus().  Without a quota usable_cpus() is the machine already.
+// 1.6 s per 100 ms), not a number of threads: a call whose whole work -- together with what the calls just before it spent
+// (CpuLedger: chunk after chunk of one run, sample after sample of a joint run) -- fits well inside one period's allowance may
+// run one worker per physical core (at most `cap`) and be done sooner; a longer one is bound by the quota whatever it starts
+// and keeps to usable_cpus().  Without a quota usable_cpus() is the machine already.
 inline unsigned burst_threads(double est_cpu_s, unsigned cap)
 {
     const unsigned base = usable_cpus();
     const CpuQuota q = cpu_quota();
-    if (q.period_s <= 0.0 || est_cpu_s > 0.6 * q.cpu_s) return base;
+    if (q.period_s <= 0.0) return base;
+    const double allowance = 0.6 * q.cpu_s - recent_cpu_s(q.period_s);
+    if (est_cpu_s > allowance) return base;
+    // a sustained run (more than two periods' allowance spent within the last ten: chunk after chunk of a long VCF, sample
+    // after sample of a joint run) is bound by the quota: bursts would only be paid for with throttled periods
+    if (recent_cpu_s(10.0 * q.period_s) + est_cpu_s > 2.0 * q.cpu_s) return base;
     return std::max(base, std::min(physical_cores(), cap));
 }
 

@@ -43,6 +43,8 @@ using svt::fail;
 using svt::guarded;
 using svt::run_threads;
 
+std::atomic<double> g_cpu_s_per_unit{0.0};   // CPU seconds per unit of the last svt_bam_summarise / svt_bam_evidence call on any file
+
 // ------------------------------------------------------------------------------------------
 // BGZF: random access through (compressed offset << 16 | in-block offset) addresses
 // ------------------------------------------------------------------------------------------
@@ -1471,7 +1473,10 @@ static int summarise_units(const svt_bam* bam, const svt_summarise_args* args, c
     // measured per unit (+ 30 %), or 350 us per unit when there is none yet -- a window pair at 30x costs 210 us on the
     // 9575F, mostly inflate.  (290 whole-genome-like sites: 97 ms of CPU time, 7.9 -> 2.4 ms; the fixture's 21 100 units:
     // 0.45 s, 31 -> ms -- 16 CPUs for a tenth of a second are the same allowance as 48 for a thirtieth.)
-    const double known = bam->cpu_s_per_unit.load(std::memory_order_relaxed);
+    // (a handle that has not measured anything yet -- every run of a driver opens its own -- goes by what the last call on
+    // ANY file of this process measured)
+    double known = bam->cpu_s_per_unit.load(std::memory_order_relaxed);
+    if (!(known > 0.0)) known = g_cpu_s_per_unit.load(std::memory_order_relaxed);
     const double est_cpu_s = (double)n * (known > 0.0 ? 1.3 * known : 350e-6);
     unsigned nt = args->n_threads > 0 ? (unsigned)args->n_threads : std::max(1u, svt::burst_threads(est_cpu_s, 48u) - 1u);
     nt = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(nt ? nt : 1, n ? n : 1));
@@ -1567,7 +1572,9 @@ static int summarise_units(const svt_bam* bam, const svt_summarise_args* args, c
         if (n && cpu > 0.0) {
             const double now = cpu / (double)n, before = bam->cpu_s_per_unit.load(std::memory_order_relaxed);
             bam->cpu_s_per_unit.store(before > 0.0 ? 0.5 * (before + now) : now, std::memory_order_relaxed);
+            g_cpu_s_per_unit.store(now, std::memory_order_relaxed);
         }
+        svt::note_cpu_s(cpu);
     }
     if (trace) {
         WorkerStat sum, longest;

@@ -423,14 +423,17 @@ class SampleColumnWriter:
         return hip.format_results(results, self.fields, self._skipped_as_dots)
 
 
-BULK_BLOCK_UNITS = 400_000   # (breakpoint, sample) units per device batch of the bulk route (SVT_BULK_BLOCK_UNITS)
+# Variant lines per block of the bulk route = per device batch (SVT_BULK_BLOCK_SITES).  Small enough that the stages of
+# neighbouring blocks overlap (parse / reader / device / text: ChunkPipeline), large enough that a block is not its fixed costs;
+# counted in sites, not units: every sample of a joint run is a reader call of its own per block.  Measured on the fixture x 100
+# through sso_genotype: 4 096 -> 46 ms, 16 384 -> 37 ms, 65 536 -> 46 ms, one block -> 49 ms (profiles/r06_block_sweep.txt).
+BULK_BLOCK_SITES = 16_384
 
 
 def text_blocks(first: str, source, n_samples: int):
     """Blocks of whole lines from `source` (a text file object) behind `first` (a line already read), each about
-    BULK_BLOCK_UNITS units' worth of lines, judged by the length of the first one."""
-    units = int(os.environ.get("SVT_BULK_BLOCK_UNITS", BULK_BLOCK_UNITS))
-    chars = min(max(units // max(1, n_samples) * max(64, len(first)), 1 << 10), 256 << 20)
+    BULK_BLOCK_SITES lines, judged by the length of the first one."""
+    chars = block_chars(len(first))
     carry = first
     while True:
         data = source.read(chars)
@@ -442,6 +445,11 @@ def text_blocks(first: str, source, n_samples: int):
             data += source.readline()
         yield carry + data
         carry = ""
+
+
+def block_chars(first_line_chars: int) -> int:
+    sites = int(os.environ.get("SVT_BULK_BLOCK_SITES", BULK_BLOCK_SITES))
+    return min(max(sites * max(64, first_line_chars), 1 << 10), 256 << 20)
 
 
 def split_lines(text: str) -> List[str]:

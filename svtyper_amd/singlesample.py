@@ -20,7 +20,7 @@ from . import __version__
 from . import evidence as ev
 from .bam import open_alignment_file
 from .library import Sample, setup_sample, write_sample_json
-from .pipeline import (BULK_BLOCK_UNITS, MIN_LIB_PREVALENCE, BulkFeeder, ChunkPipeline, NativeUnitCollector, split_lines, SampleColumnWriter, UnitCollector, add_read_to,
+from .pipeline import (MIN_LIB_PREVALENCE, BulkFeeder, block_chars, ChunkPipeline, NativeUnitCollector, split_lines, SampleColumnWriter, UnitCollector, add_read_to,
                        default_engine, fetch_window, resolve_reader)
 from .results import results_to_dicts
 from .vcf import Variant, Vcf
@@ -290,9 +290,8 @@ def sso_genotype(bam_string, vcf_in, vcf_out, min_aligned, split_weight, disc_we
         per_line(lines)
     else:
         def blocks():
-            units = int(os.environ.get("SVT_BULK_BLOCK_UNITS", BULK_BLOCK_UNITS))
             nl = text.find("\n", body_at)
-            chars = min(max(units * max(64, (nl if nl >= 0 else len(text)) - body_at), 1 << 10), 256 << 20)
+            chars = block_chars((nl if nl >= 0 else len(text)) - body_at)
             at = body_at
             while at < len(text):
                 cut = text.find("\n", at + chars)

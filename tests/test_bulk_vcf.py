@@ -45,10 +45,10 @@ class Sink(io.StringIO):
         pass
 
 
-def run_driver(driver, text, bulk, monkeypatch, sum_quals=False, max_ci_dist=1e10, block_units=None):
+def run_driver(driver, text, bulk, monkeypatch, sum_quals=False, max_ci_dist=1e10, block_sites=None):
     monkeypatch.setenv("SVT_BULK_VCF", "1" if bulk else "0")
-    if block_units is not None:
-        monkeypatch.setenv("SVT_BULK_BLOCK_UNITS", str(block_units))
+    if block_sites is not None:
+        monkeypatch.setenv("SVT_BULK_BLOCK_SITES", str(block_sites))
     out, err = Sink(), io.StringIO()
     import sys
     old, sys.stderr = sys.stderr, err
@@ -62,7 +62,8 @@ def run_driver(driver, text, bulk, monkeypatch, sum_quals=False, max_ci_dist=1e1
     finally:
         sys.stderr = old
     strip = lambda t: [l for l in t.split("\n") if not l.startswith("##fileDate=")]
-    warnings = [l for l in err.getvalue().split("\n") if "Warning" in l]
+    import re
+    warnings = [re.sub(r"^\[ [^\]]*\] ", "", l) for l in err.getvalue().split("\n") if "Warning" in l]   # (logit's time stamp)
     return strip(out.getvalue()), warnings
 
 
@@ -328,11 +329,11 @@ def odd_vcf(seed, n=260):
 
 
 @pytest.mark.parametrize("driver", ["sso", "classic"])
-@pytest.mark.parametrize("seed,block_units", [(1, None), (2, 16), (3, 64)])
-def test_odd_lines_and_split_bnd_pairs_bulk_equals_per_line(driver, seed, block_units, monkeypatch):
+@pytest.mark.parametrize("seed,block_sites", [(1, None), (2, 16), (3, 64)])
+def test_odd_lines_and_split_bnd_pairs_bulk_equals_per_line(driver, seed, block_sites, monkeypatch):
     text = odd_vcf(seed)
     want, want_warn = run_driver(driver, text, False, monkeypatch)
-    got, got_warn = run_driver(driver, text, True, monkeypatch, block_units=block_units)
+    got, got_warn = run_driver(driver, text, True, monkeypatch, block_sites=block_sites)
     assert got == want
     assert got_warn == want_warn
     assert len(want) > 200
@@ -352,7 +353,7 @@ def test_a_bnd_line_off_the_fast_route_hands_over_to_the_per_line_code(driver, m
     lines = plain[:30] + [early_first] + plain[30:60] + [odd_first] + plain[60:90] + [early_second, bnd[1]] + plain[90:120]
     text = "".join(head) + "".join(lines)
     want, _ = run_driver(driver, text, False, monkeypatch)
-    got, _ = run_driver(driver, text, True, monkeypatch, block_units=50)
+    got, _ = run_driver(driver, text, True, monkeypatch, block_sites=50)
     assert got == want
     assert sum(1 for l in got if "\te1\t" in l or "\te2\t" in l) == 2
 
