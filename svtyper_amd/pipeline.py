@@ -86,6 +86,40 @@ def default_engine() -> Engine:
     return HipEngine(0)
 
 
+MAX_BATCH_LIBS = 256     # libraries one device batch can name: svt_record carries an 8-bit index into svt_evidence_batch.libs
+
+
+def library_groups(samples: List[Sample]) -> List[List[int]]:
+    """Consecutive samples whose libraries fit ONE device batch.  The reference's `-B a.bam,b.bam,...` list is unbounded
+    (svtyper/classic.py:145-158; read group -> library: parsers.py:432-447) while an evidence record names its library with
+    eight bits, so a joint run over more libraries than that is several device batches -- one per group of samples, each
+    with its own library table and indices local to it -- whose result records are put back site-major over all samples
+    (units are independent; QUAL, the one quantity across a site's samples, is summed on the host afterwards)."""
+    groups: List[List[int]] = []
+    cur: List[int] = []
+    n = 0
+    for k, s in enumerate(samples):
+        c = len(s.lib_dict)
+        if c > MAX_BATCH_LIBS:
+            raise ValueError("sample %s has %d libraries: more than the %d one evidence batch can name" % (s.name, c, MAX_BATCH_LIBS))
+        if cur and n + c > MAX_BATCH_LIBS:
+            groups.append(cur)
+            cur, n = [], 0
+        cur.append(k)
+        n += c
+    if cur:
+        groups.append(cur)
+    return groups
+
+
+def _with_site_qual(res: Results, kw: dict) -> Results:
+    """QUAL over the samples of every site (classic.py:216-217,485,498) from merged, SQ-refined records"""
+    if "site_qual" in kw:
+        from . import hip
+        res.site_qual = hip.site_qual_host(res, kw["site_qual"][0], kw["site_qual"][1])
+    return res
+
+
 def resolve_reader(reader: Optional[str]) -> str:
     """`reader=None` (the drivers' default, i.e. what a caller with the reference's positional arguments gets): the C++
     reader of libsvtyper_hip.so when the library is there -- fetch, fragment assembly and the geometry predicates in its
@@ -113,56 +147,72 @@ class UnitCollector:
         self.geometry = geometry
         self.samples = samples
         self.min_aligned = min_aligned
-        self.lib_tables = []
-        self.lib_index: Dict[int, int] = {}
-        self.sample_libs = []          # per sample: svt_unit.libs hint (its libraries are contiguous in lib_tables)
-        for s in samples:
-            first = len(self.lib_tables)
-            for lib in s.lib_dict.values():
-                self.lib_index[id(lib)] = len(self.lib_tables)
-                self.lib_tables.append(lib.table())
-            self.sample_libs.append(ev.unit_libs(first, len(self.lib_tables) - first))   # (0 = no hint when it does not fit)
-        if len(self.lib_tables) > 256:
-            raise ValueError("more than 256 libraries in one run are not supported by the evidence record")
         self.split_weight = split_weight
         self.disc_weight = disc_weight
-        self.builder = self._new_builder()
+        # one device batch per group of samples (library_groups): its library table, the index of every library in it, and per
+        # sample the svt_unit.libs hint (a sample's libraries are contiguous in its group's table)
+        self.groups = library_groups(samples)
+        self.group_of = [g for g, members in enumerate(self.groups) for _ in members]
+        self.group_tables: List[list] = []
+        self.lib_index: Dict[int, int] = {}
+        self.sample_libs = []
+        for members in self.groups:
+            tables = []
+            for k in members:
+                first = len(tables)
+                for lib in samples[k].lib_dict.values():
+                    self.lib_index[id(lib)] = len(tables)
+                    tables.append(lib.table())
+                self.sample_libs.append(ev.unit_libs(first, len(tables) - first))   # (0 = no hint when it does not fit)
+            self.group_tables.append(tables)
+        self.lib_tables = [t for tables in self.group_tables for t in tables]
+        self._reset()
 
-    def _new_builder(self):
+    def _reset(self):
+        self.builders = [self._new_builder(tables) for tables in self.group_tables]
+        self.slots: List[List[int]] = [[] for _ in self.groups]      # per group: where its units go in the order they were added
+        self.n_units = 0
+
+    def _new_builder(self, tables):
         if self.geometry == "device":
             from .geometry import FragmentBatchBuilder
-            return FragmentBatchBuilder(self.lib_tables, self.split_weight, self.disc_weight, self.min_aligned,
-                                        SPLIT_SLOP)
-        return BatchBuilder(self.lib_tables, self.split_weight, self.disc_weight)
+            return FragmentBatchBuilder(tables, self.split_weight, self.disc_weight, self.min_aligned, SPLIT_SLOP)
+        return BatchBuilder(tables, self.split_weight, self.disc_weight)
 
     def add(self, breakpoint: dict, sample_index: int, fragments: Optional[Dict[str, SamFragment]],
             skip: bool = False) -> int:
+        g = self.group_of[sample_index]
         if self.geometry == "device":
             from .geometry import breakpoint_record, summarise_fragments
             tid_of = self.samples[sample_index].bam.gettid
             frs = None
             if fragments and not skip:
                 frs = summarise_fragments(fragments, breakpoint, self.lib_index, tid_of)
-            return self.builder.add(breakpoint_record(breakpoint, tid_of, sample_index, skip, self.sample_libs[sample_index]), frs)
-        unit = unit_header(breakpoint, sample_index, skip, self.sample_libs[sample_index])
-        recs = None
-        if fragments and not skip:
-            recs = pack_fragments(fragments, breakpoint, self.lib_index, self.min_aligned, SPLIT_SLOP)
-        return self.builder.add(unit, recs)
+            self.builders[g].add(breakpoint_record(breakpoint, tid_of, sample_index, skip, self.sample_libs[sample_index]), frs)
+        else:
+            unit = unit_header(breakpoint, sample_index, skip, self.sample_libs[sample_index])
+            recs = None
+            if fragments and not skip:
+                recs = pack_fragments(fragments, breakpoint, self.lib_index, self.min_aligned, SPLIT_SLOP)
+            self.builders[g].add(unit, recs)
+        self.slots[g].append(self.n_units)
+        self.n_units += 1
+        return self.n_units - 1
 
     def __len__(self):
-        return len(self.builder)
+        return self.n_units
 
     def take(self, engine: Engine, flags: int, site_quals=None):
         """Detach the units collected so far as a job (a callable returning their Results); the collector is
         empty again and can be filled while the job runs on another thread (ChunkPipeline).  `site_quals`
         (incoming QUAL of every site, units site-major over self.samples) asks an engine that can for
         Results.site_qual."""
-        builder, self.builder = self.builder, self._new_builder()
+        builders, slots, n_units = self.builders, self.slots, self.n_units
+        self._reset()
         geometry = self.geometry
         kw = _site_qual_kw(engine, len(self.samples), site_quals)
 
-        def job() -> Results:
+        def run_one(builder, **kw) -> Results:
             batch = builder.build()
             if batch.n_units == 0:
                 return Results.empty(0)
@@ -171,6 +221,16 @@ class UnitCollector:
                     raise TypeError("geometry='device' needs an engine with genotype_fragments (the HIP engine)")
                 return engine.genotype_fragments(batch, flags, **kw)
             return engine(batch, flags, **kw)
+
+        def job() -> Results:
+            if len(builders) == 1:
+                return run_one(builders[0], **kw)
+            import numpy as np
+            out = Results.empty(n_units)
+            for builder, where in zip(builders, slots):      # one device batch per group of samples, results back in add() order
+                if where:
+                    out.rec[np.asarray(where, dtype=np.int64)] = run_one(builder).rec
+            return _with_site_qual(out, kw)
         return job
 
     def run(self, engine: Engine, flags: int) -> Results:
@@ -199,19 +259,26 @@ class NativeUnitCollector:
         self.n_threads = n_threads or int(os.environ.get("SVT_READER_THREADS", "0"))   # 0 = the library's default
         self.split_weight = split_weight
         self.disc_weight = disc_weight
-        self.lib_tables = []
+        # one device batch per group of samples (library_groups): per group its library table; per sample the read groups
+        # with their library's index in the group's table (-1: not active) and the svt_unit.libs hint
+        self.groups = library_groups(samples)
+        self.group_of = [g for g, members in enumerate(self.groups) for _ in members]
+        self.group_tables: List[list] = []
         self.rg_tables = []          # per sample: (read group ids, library index or -1)
         self.sample_libs = []        # per sample: svt_unit.libs hint
-        for s in samples:
-            base = len(self.lib_tables)
-            libs = list(s.lib_dict.values())
-            self.lib_tables.extend(lib.table() for lib in libs)
-            self.sample_libs.append(ev.unit_libs(base, len(libs)))   # (0 = no hint when it does not fit)
-            rgs = list(s.rg_to_lib.keys())
-            idx = [base + libs.index(s.rg_to_lib[rg]) if s.rg_to_lib[rg].name in s.active_libs else -1 for rg in rgs]
-            self.rg_tables.append((rgs, idx))
-        if len(self.lib_tables) > 256:
-            raise ValueError("more than 256 libraries in one run are not supported by the evidence record")
+        for members in self.groups:
+            tables = []
+            for k in members:
+                s = samples[k]
+                base = len(tables)
+                libs = list(s.lib_dict.values())
+                tables.extend(lib.table() for lib in libs)
+                self.sample_libs.append(ev.unit_libs(base, len(libs)))   # (0 = no hint when it does not fit)
+                rgs = list(s.rg_to_lib.keys())
+                idx = [base + libs.index(s.rg_to_lib[rg]) if s.rg_to_lib[rg].name in s.active_libs else -1 for rg in rgs]
+                self.rg_tables.append((rgs, idx))
+            self.group_tables.append(tables)
+        self.lib_tables = [t for tables in self.group_tables for t in tables]
         self.sites: List[dict] = []
         self.site_arrays: list = []      # bulk_vcf.SiteArrays blocks, in front of the dict sites
 
@@ -311,8 +378,8 @@ class NativeUnitCollector:
                 off, frags, skipped = nbam.summarise(win, bps, rgs, idx, self.max_reads, self.count_mode, self.n_threads)
             lap("svt_bam_summarise")
             bps["flags"] |= np.where(skipped != 0, 4, 0).astype(np.uint8)   # SVT_BP_SKIP
-            fb = FragmentBatch(off, bps, frags, self.lib_tables, self.split_weight, self.disc_weight, self.min_aligned,
-                               SPLIT_SLOP)
+            fb = FragmentBatch(off, bps, frags, self.group_tables[self.group_of[k]], self.split_weight, self.disc_weight,
+                               self.min_aligned, SPLIT_SLOP)
             if n_samp == 1:
                 res = engine.genotype_fragments(fb, flags, **kw)
                 lap("device stages")
@@ -332,15 +399,16 @@ class NativeUnitCollector:
 
 
     def _run_records(self, prepared, engine: Engine, flags: int, kw: dict, lap) -> Results:
-        """geometry="reader": evidence records straight from the reader, ONE canonical batch over all samples (units
-        site-major, sample-minor: what UnitCollector builds, and what keeps QUAL on the device)."""
+        """geometry="reader": evidence records straight from the reader, ONE canonical batch over the samples of a library
+        group (units site-major, sample-minor: what UnitCollector builds) -- one batch in all unless the run names more
+        libraries than a batch can (library_groups)."""
         import numpy as np
         n_samp = len(self.samples)
         n_sites = int(prepared[0][0].shape[0])
-        flank = [float(t.mean) + float(t.sd) * 3 for t in self.lib_tables]       # (svt_batch_create_from_fragments' v_nondel)
         per_sample = []
         for k, (nbam, (bps, win)) in enumerate(zip(self.bams, prepared)):
             rgs, idx = self.rg_tables[k]
+            flank = [float(t.mean) + float(t.sd) * 3 for t in self.group_tables[self.group_of[k]]]   # (svt_batch_create_from_fragments' v_nondel)
             with _READER_TURN:
                 off, recs, skipped = nbam.evidence(win, bps, rgs, idx, self.max_reads, self.count_mode, flank, self.min_aligned,
                                                    SPLIT_SLOP, self.n_threads)
@@ -352,9 +420,22 @@ class NativeUnitCollector:
             units["flags"] = np.where(skipped != 0, ev.UNIT_SKIP, 0)
             units["libs"] = self.sample_libs[k]
             per_sample.append((off, units, recs))
+        if len(self.groups) == 1:
+            return self._run_group(per_sample, self.group_tables[0], n_sites, engine, flags, kw, lap)
+        out = Results.empty(n_sites * n_samp)
+        grid = out.rec.reshape(n_sites, n_samp)
+        for members, tables in zip(self.groups, self.group_tables):      # one device batch per group, its columns of the site x sample grid
+            res = self._run_group([per_sample[k] for k in members], tables, n_sites, engine, flags, {}, lap)
+            grid[:, members[0]:members[-1] + 1] = res.rec.reshape(n_sites, len(members))
+        return _with_site_qual(out, kw)
+
+    def _run_group(self, per_sample, tables, n_sites: int, engine: Engine, flags: int, kw: dict, lap) -> Results:
+        """the samples of one library group -> their result records, site-major over the group's samples"""
+        import numpy as np
+        n_samp = len(per_sample)
         if n_samp == 1:
             off, units, recs = per_sample[0]
-            batch = EvidenceBatch(off, units, recs, self.lib_tables, self.split_weight, self.disc_weight)
+            batch = EvidenceBatch(off, units, recs, tables, self.split_weight, self.disc_weight)
         elif getattr(engine, "accepts_sample_major", False):
             # the engine takes the units as the readers left them, sample after sample: the unit arrays concatenated (24 bytes
             # per unit), every sample's records from where its reader left them (evidence.SegmentedBatch ->
@@ -364,7 +445,7 @@ class NativeUnitCollector:
             off = np.zeros(n_sites * n_samp + 1, np.uint64)
             np.cumsum(counts, out=off[1:].view(np.int64))
             batch = SegmentedBatch(off, np.concatenate([p[1] for p in per_sample]), [p[2] for p in per_sample],
-                                   self.lib_tables, self.split_weight, self.disc_weight)
+                                   tables, self.split_weight, self.disc_weight)
             lap("sample-major unit arrays")
             res = engine(batch, flags, sample_major=n_samp, **kw)
             lap("engine (canonical batch, sample-major)")
@@ -383,7 +464,7 @@ class NativeUnitCollector:
                 if int(n_k.sum()):
                     dst = np.repeat(dst0[:, k] - soff[:-1].astype(np.int64), n_k) + np.arange(int(n_k.sum()), dtype=np.int64)
                     recs[dst] = srecs
-            batch = EvidenceBatch(off, units, recs, self.lib_tables, self.split_weight, self.disc_weight)
+            batch = EvidenceBatch(off, units, recs, tables, self.split_weight, self.disc_weight)
             lap("site-major interleave")
         res = engine(batch, flags, **kw)
         lap("engine (canonical batch)")
