@@ -256,6 +256,30 @@ def dist_leg(what, dbatch, counts, total_units, steps, warmup, rank, world, back
         compact = {"record_bytes": 48, "ms": c_s * 1e3, "GB/s_into_root": sum(c_sizes[1:] or c_sizes) / c_s / 1e9,
                    "fields": "GL, SQ, QR, QA, GQ, GT + the unit tag (what parsers.py:375-399 prints of a genotype; DP / RO / AO / RS / AS / ASC / RP / AP "
                              "need the 40 bytes of tallies)", "genotype_fields_equal_single_rank_pass": c_same}
+    # ---- the other way off the devices: every rank copies ITS records to page-locked host memory over its own PCIe link, all
+    # ranks at once (what one process does in svt_genotype_multi, one host thread per device; what the sharded drivers do before
+    # they format their share of the VCF: svtyper_amd/sharded.py gathers TEXT, not records) -- no root that has to take in N - 1 shards
+    d2h = None
+    try:
+        host = torch.empty(cur, dtype=torch.uint8).pin_memory()
+        host.copy_(res[:cur], non_blocking=True)          # (the first touch of the pinned pages)
+        torch.cuda.synchronize()
+        dist.barrier()
+        h0 = time.perf_counter()
+        host.copy_(res[:cur], non_blocking=True)
+        torch.cuda.synchronize()
+        dist.barrier()
+        h_s = time.perf_counter() - h0
+        t = torch.tensor([h_s, float(cur)], dtype=torch.float64, device=coll_device)
+        every_h = [torch.zeros(2, dtype=torch.float64, device=coll_device) for _ in range(world)]
+        dist.all_gather(every_h, t)
+        h_s = max(float(x[0].item()) for x in every_h)
+        d2h = {"ms": h_s * 1e3, "GB/s_aggregate": sum(float(x[1].item()) for x in every_h) / h_s / 1e9, "record_bytes": rec_bytes,
+               "what": "every rank's result records device -> its own page-locked host buffer, all ranks at once (barrier on both sides, "
+                       "maximum over the ranks)"}
+        del host
+    except Exception as e:
+        d2h = {"error": repr(e)}
     res = None
     # ---- steady state: pass of batch k+1 over the gather of batch k
     batches = max(8, steps)
@@ -277,7 +301,9 @@ def dist_leg(what, dbatch, counts, total_units, steps, warmup, rank, world, back
            "gather": {"record_bytes": rec_bytes, "bytes_per_rank": int(cur), "ms": g_s * 1e3, "GB/s_into_root": sum(sizes[1:] or sizes) / g_s / 1e9,
                       "collective": "rccl gather" if backend == "nccl" else "gloo gather (ranks share %d device(s))" % n_dev},
            "gather_compact": compact,
+           "d2h_parallel": d2h,
            "value_with_gather": total_units / (elapsed / steps + g_s),
+           "value_with_d2h_parallel": total_units / (elapsed / steps + d2h["ms"] * 1e-3) if d2h and "ms" in d2h else None,
            "batches_pipelined": batches,
            "pipelined_note": "two result buffers per rank; the gather of batch k runs under the pass of batch k + 1 (steady state over "
                              "`batches_pipelined` batches, barrier on both sides, maximum over the ranks): the N-GPU throughput of pass + gather",
@@ -1080,6 +1106,18 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
+            # which number answers north_star's ">= 6 x at 8 GPUs" and what the other N-rank numbers are
+            "scaling_answer": {
+                "number": "value",
+                "why": "north_star: the variants shard across the GPUs (no per-step collective) with a SINGLE gather at the END of the job, so the "
+                       "job's rate over many passes is `value` (per-rank passes, barrier + device sync on both sides, maximum over the ranks) and "
+                       "the gather is paid once -- reported separately under `gather`.  `value_with_gather` = one pass FOLLOWED BY its gather "
+                       "every step: bound by the root taking in N - 1 shards over its xGMI links (DESIGN.md 6: about 1.3 x one GPU for any N >= 2), "
+                       "it does not scale and is not the claim.  `value_pipelined` (in `strong` / `c5`) = pass of batch k + 1 over the gather of "
+                       "batch k, the steady state of a job that does want every batch's records on one rank; `value_with_d2h_parallel` = every "
+                       "rank bringing ITS records down over its own PCIe link instead (the sharded drivers format their share of the VCF locally "
+                       "and gather text)",
+            } if world > 1 else None,
             "config": {
                 "workload": workload,
                 "units_per_gpu": n,
@@ -1114,8 +1152,11 @@ def main():
                 "frac_untuned_median": None,
                 "timed_region_host": timed_region_host,
                 "timed_region_dispatches": {"first": first_timed_dispatch, "count": args.steps,
-                                            "note": "0-based index, among this process's dispatches of the headline kernel, of the timed region's first "
-                                                    "launch (null after a placement audition, whose launch count is not fixed)"},
+                                            "from_end": 0 if (not legs and not use_dist and more is None) else None,
+                                            "note": "`first`: 0-based index, among this process's dispatches of the headline kernel, of the timed region's "
+                                                    "first launch (null after a placement audition, whose launch count is not fixed); `from_end`: dispatches "
+                                                    "of that kernel BEHIND the timed region in this process (0 with --no-extra-legs: the timed region is the "
+                                                    "last `count` dispatches -- how tools/summarize_prof.py finds it behind an audition; null: other legs follow)"},
                 "placement_tuned": dict(tuned, what="svt_batch_tune_placement before the timed region (setup): the real pass over "
                                         "freshly allocated candidates for the result buffer and the record buffer, the fastest kept; "
                                         "before_ms / after_ms = the pass on the buffers svt_batch_create drew / on the kept ones. "
@@ -1322,7 +1363,7 @@ def main():
             t0 = time.perf_counter()
             c_oracle.genotype_batch(one, flags=o_flags, n_threads=1)
             one_thread = n1 / (time.perf_counter() - t0)
-            out["cpu_baseline"] = {
+            c_port = {
                 "value": sample_n * reps / cpu_s,
                 "unit": "breakpoints/s",
                 "cores": threads,
@@ -1346,21 +1387,27 @@ def main():
                 t0 = time.perf_counter()
                 py_oracle.genotype_batch_pool(batch.slice(0, npool), o_flags, processes=threads, batch_size=1000)
                 pool = npool / (time.perf_counter() - t0)
-                out["cpu_baseline_python"] = {
-                    "kind": "port", "unit": "breakpoints/s", "one_process": one, "pool": pool, "cores": threads,
-                    "sample": "oracle/py_oracle.py: first %d units (1 process), first %d units "
-                              "(multiprocessing.Pool(%d), batch_size=1000)" % (n1, npool, threads)}
-            except Exception as e:  # never let the extra baseline break the bench line
-                out["cpu_baseline_python"] = {"error": repr(e)}
+                py = {"value": pool, "unit": "breakpoints/s", "cores": threads, "kind": "port", "cpu_model": cpu_model(),
+                      "one_process": one, "pool": pool,
+                      "what": "SURVEY 8(d)(ii)'s denominator, the stand-in for `svtyper-sso --cores N` that can run on this box: the reference's own "
+                              "structure (per-fragment object walk, log_choose loop, a multiprocessing.Pool with batch_size=1000: "
+                              "svtyper/singlesample.py:246-473,723-751) restated in pure Python",
+                      "sample": "oracle/py_oracle.py: the workload's first %d units through multiprocessing.Pool(%d), batch_size=1000 "
+                                "(`value`); its first %d units in one process (`one_process`)" % (npool, threads, n1)}
+            except Exception as e:  # never let a baseline break the bench line
+                py = {"error": repr(e)}
+            # parsed.cpu_baseline = the Python pool (what north_star's ">= 100 x svtyper-sso CPU" is judged against); the same algorithm in
+            # C with OpenMP on the same cores -- a far stronger CPU line -- beside it as cpu_baseline_c
+            out["cpu_baseline"] = py if "value" in py else dict(c_port, python_pool_error=py.get("error"))
+            out["cpu_baseline_c"] = c_port
             # north_star: >= 100 x the svtyper-sso CPU path's breakpoints/s on one MI355X.  BASELINE.md publishes no number, so
             # `vs_baseline` stays null (the contract); the ratios against the two CPU restatements timed on THIS box's host cores:
-            py = out["cpu_baseline_python"]
             out["vs_cpu"] = {
                 "python_restatement_pool": value / py["pool"] if py.get("pool") else None,
-                "c_port": value / out["cpu_baseline"]["value"],
+                "c_port": value / c_port["value"],
                 "cores": threads,
-                "note": "value / cpu_baseline_python.pool (SURVEY 8d-ii's denominator: the reference's own structure -- a multiprocessing.Pool "
-                        "of pure-Python workers, singlesample.py:723-751 -- restated in oracle/py_oracle.py) and value / cpu_baseline.value "
+                "note": "value / cpu_baseline.value (SURVEY 8d-ii's denominator: the reference's own structure -- a multiprocessing.Pool "
+                        "of pure-Python workers, singlesample.py:723-751 -- restated in oracle/py_oracle.py) and value / cpu_baseline_c.value "
                         "(the same algorithm in C with OpenMP on the same cores); target >= 100",
             }
             ints_bad = int((got.counts[:sample_n] != want.counts).sum() + (got.gt[:sample_n] != want.gt).sum())

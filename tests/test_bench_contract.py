@@ -31,6 +31,17 @@ def test_bench_line_has_the_contract_keys(hip_device):
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in cpu, key
     assert cpu["kind"] == "port" and cpu["cores"] >= 1 and isinstance(cpu["cpu_model"], str) and cpu["cpu_model"]
+    # parsed.cpu_baseline is SURVEY 8(d)(ii)'s denominator (the pure-Python pool); the C port of the same algorithm beside it
+    assert cpu["value"] == cpu["pool"] > 0 and "multiprocessing.Pool" in cpu["sample"]
+    c = d["cpu_baseline_c"]
+    assert c["kind"] == "port" and c["value"] > cpu["value"] and c["one_thread"] > 0
+    assert abs(d["vs_cpu"]["python_restatement_pool"] - d["value"] / cpu["value"]) < 1e-6 * d["vs_cpu"]["python_restatement_pool"]
+    assert d["scaling_answer"] is None                     # (N = 1)
+    # the public drivers end to end, called with the reference's own positional arguments
+    for key, rate in (("driver_sso", "sites_per_s"), ("driver_classic_8bam", "units_per_s")):
+        leg = d["real_data"][key]
+        assert leg[rate] > 0 and leg["per_line_route"]["same_bytes"] is True
+    assert d["real_data"]["driver_sso"]["every_repeat_equals_example_gt_vcf"] is True
     assert d["value"] > 0 and abs(d["value"] - 30000 * 3 / (d["ms_per_step"] * 3 * 1e-3)) / d["value"] < 1e-6
     assert d["parity"]["integer_mismatches"] == 0 and d["parity"]["max_abs_dGL"] <= 1e-6 and d["parity"]["max_abs_dSQ"] <= 1e-6
     # the timed step is the whole path from the canonical input: the algorithmic rate cannot exceed the HBM peak

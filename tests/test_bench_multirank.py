@@ -51,6 +51,7 @@ def _common(d, n, total_units):
     assert 0 < d["roofline"]["frac"] <= 1.0 and d["roofline"]["kernel_ms_max_over_ranks"] >= d["roofline"]["kernel_ms"] * (1 - 1e-9)
     for leg in ("sso", "c5_multisample", "one_shot", "cpu_baseline", "large_batch"):
         assert leg not in d          # the extra legs and the CPU baseline are N = 1 only
+    assert d["scaling_answer"]["number"] == "value" and "single gather" in d["scaling_answer"]["why"].lower()
 
 
 @pytest.mark.gpu
@@ -73,6 +74,8 @@ def test_weak_scaling_line(hip_device, n):
         assert leg["value"] > leg["value_with_gather"] > 0 and leg["value_pipelined"] > 0 and leg["value_pipelined_compact"] > 0
         assert leg["batches_pipelined"] >= 8 and leg["gather"]["record_bytes"] == 96 and leg["gather_compact"]["record_bytes"] == 48
         assert leg["rccl_ranks"] == d["rccl_ranks"]
+        # the two ways off the devices: one gather onto rank 0 / every rank down its own PCIe link
+        assert leg["d2h_parallel"]["ms"] > 0 and leg["d2h_parallel"]["GB/s_aggregate"] > 0 and 0 < leg["value_with_d2h_parallel"] < leg["value"]
         if total is not None:
             assert leg["total_units"] == total and leg["equals_single_rank_pass"] is True
             assert leg["gather_compact"]["genotype_fields_equal_single_rank_pass"] is True

@@ -22,10 +22,11 @@ run_pass() {   # run_pass <subdir> <stdout file> <bench command> -- <rocprofv3 o
     done
     return 1
 }
-# A process of its own for the HEADLINE's timed region: no audition, no other leg -- every dispatch of the headline kernel is
-# accounted for (1 after create + steps cold + spin-up + warm-up, then the timed steps: roofline.timed_region_dispatches), so the
-# trace and the counter passes are averaged over exactly the launches bench.py times (tools/summarize_prof.py, "timed region")
-HEAD="python bench.py --steps ${HEAD_STEPS:-50} --warmup 3 --no-cpu-baseline --no-extra-legs --tune-placement 0,0 ${BENCH_ARGS:-}"
+# A process of its own for the HEADLINE's timed region, in the state the bench line is quoted in (svt_batch_tune_placement first,
+# as the default run; HEAD_TUNE="--tune-placement 0,0" for the untuned state): no other leg, so the timed region is the LAST `steps`
+# dispatches of the headline kernel (roofline.timed_region_dispatches.from_end = 0) and the trace and the counter passes are
+# averaged over exactly the launches bench.py times (tools/summarize_prof.py, "timed region")
+HEAD="python bench.py --steps ${HEAD_STEPS:-50} --warmup 3 --no-cpu-baseline --no-extra-legs ${HEAD_TUNE:-} ${BENCH_ARGS:-}"
 run_pass headstats $OUT/stats_headline.json "$HEAD" -- --kernel-trace --stats
 run_pass headfetch $OUT/fetch_headline.json "$HEAD" -- --pmc FETCH_SIZE
 run_pass headwrite $OUT/write_headline.json "$HEAD" -- --pmc WRITE_SIZE

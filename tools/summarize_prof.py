@@ -34,15 +34,26 @@ def _timed_rows(sub, line, query):
     return rows, tr
 
 
+def _first_of(tr, n):
+    """index of the timed region's first dispatch among the n dispatches of the headline kernel in the trace"""
+    if tr.get("first") is not None:
+        return tr["first"]
+    if tr.get("from_end") is not None:      # behind a placement audition: counted from the end of the process
+        return n - tr["from_end"] - tr["count"]
+    return None
+
+
 _hl = _headline_line("stats_headline.json")
-if _hl and _hl["roofline"]["timed_region_dispatches"]["first"] is not None:
+if _hl and _first_of(_hl["roofline"]["timed_region_dispatches"], 10 ** 9) is not None:
     rows, tr = _timed_rows("headstats", _hl, "select name, start, duration from kernels order by start")
     d = [r[2] / 1e3 for r in rows]
-    a, k = tr["first"], tr["count"]
-    if len(d) >= a + k:
+    a, k = _first_of(tr, len(d)), tr["count"]
+    if a >= 0 and len(d) >= a + k:
         timed = d[a:a + k]
         avg = sum(timed) / k
-        print("# TIMED REGION of the headline (own process: no audition, no other leg; `bench.py %s`)" % "--steps %d --tune-placement 0,0 --no-extra-legs" % k)
+        tuned = _hl["roofline"].get("placement_tuned")
+        print("# TIMED REGION of the headline (own process, no other leg, %s; `bench.py --steps %d --no-extra-legs%s`)" % (
+            "AFTER svt_batch_tune_placement -- the state the bench line is quoted in" if tuned else "no audition", k, "" if tuned else " --tune-placement 0,0"))
         print("# dispatches %d..%d of %d of the headline kernel = the %d launches between bench.py's HIP events" % (a, a + k - 1, len(d), k))
         print("timed_region_avg_us,%.3f" % avg)
         print("timed_region_min_us,%.3f" % min(timed))
@@ -55,12 +66,12 @@ if _hl and _hl["roofline"]["timed_region_dispatches"]["first"] is not None:
         print("all_dispatches_avg_us,%.3f   (cold passes + spin-up + warm-up + timed: what `top_kernels.average` shows)" % (sum(d) / len(d)))
     for sub, counter, fname in (("headfetch", "FETCH_SIZE", "fetch_headline.json"), ("headwrite", "WRITE_SIZE", "write_headline.json")):
         line = _headline_line(fname)
-        if not line or line["roofline"]["timed_region_dispatches"]["first"] is None:
+        if not line or _first_of(line["roofline"]["timed_region_dispatches"], 10 ** 9) is None:
             continue
         rows, tr = _timed_rows(sub, line, "select kernel_name, dispatch_id, value from counters_collection where counter_name = '%s' order by dispatch_id" % counter)
         v = [r[2] for r in rows]
-        a, k = tr["first"], tr["count"]
-        if len(v) >= a + k:
+        a, k = _first_of(tr, len(v)), tr["count"]
+        if a >= 0 and len(v) >= a + k:
             print("timed_region_%s_KB_mean,%.1f   (dispatches %d..%d; all %d dispatches: %.1f)" % (counter, sum(v[a:a + k]) / k, a, a + k - 1, len(v), sum(v) / len(v)))
 
 for f in dbs("stats"):
