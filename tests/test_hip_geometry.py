@@ -83,7 +83,7 @@ def test_fixture_sites_device_geometry(hip_device):
         frags, many = singlesample.gather_reads(sample, s["breakpoint"], 1000)
         assert not many
         coll.add(s["breakpoint"], 0, frags)
-    fb = coll.builder.build()
+    fb = coll.builders[0].build()
     with hip.DeviceBatch.from_fragments(fb, hip_device, 0, return_records=True) as d:
         want = np.concatenate([gio.records_from_rows(s["records"]) for s in g["sites"]])
         assert d.records.shape == want.shape
