@@ -432,8 +432,11 @@ void* svt_batch_stream(svt_batch* b);
 
 void svt_batch_destroy(svt_batch* b);
 
-/* Release the per-device scratch the library keeps between svt_batch_create calls (the device
- * copy of the canonical records; a large hipMalloc costs ~100 ms, so it is reused).           */
+/* Release what the library keeps between calls: the per-device scratch of svt_batch_create (the device
+ * copy of the canonical records; a large hipMalloc costs ~100 ms, so it is reused), the page-locked
+ * staging buffers, the encoder's arenas and the reader's pooled gather buffers (svtyper_reads.h: up to
+ * 1 GiB of idle huge-page mappings).  The parked worker threads of the host stages (at most 96, idle
+ * on a condition variable) stay for the life of the process.                                      */
 void svt_trim(void);
 
 /* Geometry + packing on the device: evaluates the predicates for every fragment summary of `in`

@@ -134,7 +134,9 @@ inline unsigned burst_threads(double est_cpu_s, unsigned cap)
     const unsigned base = usable_cpus();
     const CpuQuota q = cpu_quota();
     if (q.period_s <= 0.0) return base;
-    const double allowance = 0.6 * q.cpu_s - recent_cpu_s(q.period_s);
+    // (the calls of the last period and this one together within 80 % of a period's allowance: the rest is for the caller's
+    // other threads -- the next block's parse, the text of the one before)
+    const double allowance = 0.8 * q.cpu_s - recent_cpu_s(q.period_s);
     if (est_cpu_s > allowance) return base;
     // a sustained run (more than two periods' allowance spent within the last ten: chunk after chunk of a long VCF, sample
     // after sample of a joint run) is bound by the quota: bursts would only be paid for with throttled periods

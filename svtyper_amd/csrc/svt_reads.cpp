@@ -556,8 +556,11 @@ struct Record {               // one BAM alignment, decoded as far as the path n
 // Z-typed tag value or nullptr; walks the tag area like svtyper_amd/bam.py::_parse_tags.
 // A kept read is asked for RG and then for SA: the second search need not walk the tags in front of RG again.  `from`: where
 // the walk starts; `resume` (optional): set to the offset behind the found tag; `other` (optional, with o0 o1): the first Z
-// value of that other tag met ON THE WAY to the found one.  First-match semantics and the set of tags validated are those of
-// two full walks: search RG from 0 noting SA, then -- when SA was not met -- search SA from `resume`.
+// value of that other tag met ON THE WAY to the found one.  First-match semantics are those of two full walks (search RG from
+// 0 noting SA, then -- when SA was not met -- search SA from `resume`); the tags VALIDATED are every tag of the read either
+// way: the caller walks what lies behind the second tag it found as well (`validate_only`), so a malformed tag anywhere
+// fails the call with SVT_ERR_INVALID -- as svtyper_amd/bam.py::_parse_tags, which parses the whole tag area of every read it
+// keeps, raises (tests/test_native_reads.py::test_truncated_tag_behind_rg_is_malformed_in_both_tag_orders).
 const char* find_z_tag(const Record& r, char k0, char k1, bool* malformed, size_t from = 0, size_t* resume = nullptr,
                        char o0 = 0, char o1 = 0, const char** other = nullptr, bool validate_only = false)
 {
@@ -776,7 +779,11 @@ int split_candidate(const svt_bam& bam, const Record& r, Split& out, const char*
     bool malformed = false;
     const char* sa = sa_seen;
     if (sa_seen) (void)find_z_tag(r, 0, 0, &malformed, tags_from, nullptr, 0, 0, nullptr, /*validate_only=*/true);   // (the full walk looked at every tag)
-    else sa = find_z_tag(r, 'S', 'A', &malformed, tags_from);
+    else {
+        size_t behind_sa = 0;
+        sa = find_z_tag(r, 'S', 'A', &malformed, tags_from, &behind_sa);
+        if (sa && !malformed) (void)find_z_tag(r, 0, 0, &malformed, behind_sa, nullptr, 0, 0, nullptr, /*validate_only=*/true);   // (the tags behind SA, too)
+    }
     if (malformed) return -1;
     if (r.cigar.empty()) return 0;   // a mapped read without a CIGAR cannot be a split candidate (fragments.py: add_read)
     if (!sa) {   // the common read: no SA tag and no clipped end -> not a candidate, nothing to build
@@ -1147,6 +1154,17 @@ public:
         }
         return p;
     }
+    // unmap every idle mapping (svt_trim): a long-lived embedding process gives the pool's memory back
+    void trim()
+    {
+        std::vector<std::pair<void*, size_t>> idle;
+        {
+            std::lock_guard<std::mutex> g(lock_);
+            idle.swap(idle_);
+            idle_bytes_ = 0;
+        }
+        for (const auto& m : idle) munmap(m.first, m.second);
+    }
     bool release_tracked(void* p)
     {
         size_t cap = 0;
@@ -1312,6 +1330,9 @@ int process_unit(const svt_bam& bam, Bgzf& z, std::vector<uint8_t>& buf, const s
 // ------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------
+// svt_trim()'s share of this file: the pooled huge-page buffers of the gather (up to SVT_READER_POOL_MB, 1 GiB by default)
+extern "C" void svt_reads_trim() { BufferPool::get().trim(); }      // (internal: not in include/svtyper_reads.h)
+
 extern "C" {
 
 static int svt_bam_open_impl(const char* path, svt_bam** out)

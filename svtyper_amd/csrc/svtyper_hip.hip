@@ -2622,12 +2622,15 @@ extern "C" int svt_debug_bind_records(svt_batch* b, void* dev)
     });
 }
 
+void svt_reads_trim();      // svt_reads.cpp: the reader's pooled gather buffers
+
 void svt_trim(void)
 {
     g_pool.trim();
     g_pinned.trim();
     g_handles.trim();
     pack_trim();
+    svt_reads_trim();
 }
 
 static int svt_genotype_impl(const svt_evidence_batch* in, svt_result* out, int device, unsigned flags)

@@ -48,7 +48,11 @@ class HipEngine:
         self._hip = hip
         self.device = device
 
-    supports_site_qual = True   # QUAL over a site's samples (classic.py:485,498) can stay on the device
+    # `site_qual=(n_samples, incoming QUAL)` is accepted: Results.site_qual = QUAL over a site's samples (classic.py:485,498).
+    # The drivers' QUAL is summed on the HOST over the SQ the host libm refined from the bit-exact GL (hip.site_qual_host), so that
+    # the printed %0.2f is the reference's byte for byte; the device-side sum (svt_batch_site_qual, over the device's own SQ,
+    # <= 5e-13 away) serves callers that keep the records on the device (bench.py's configs[4] legs).
+    supports_site_qual = True
 
     # a joint run may hand its units over SAMPLE-major (unit = sample * n_sites + site: the order the per-sample readers
     # produce them in); the pass writes the result records site-major (svt_batch_result_order), so nobody interleaves
@@ -63,7 +67,7 @@ class HipEngine:
                 d.result_order(sample_major)
                 d.genotype(sync=True)
                 res = self._hip.host_sq(d.results())
-            if site_qual is not None:      # classic.py:485,498 over the refined SQ, as hip._finish does
+            if site_qual is not None:      # classic.py:485,498 over the refined SQ, on the host, as hip._finish does
                 res.site_qual = self._hip.site_qual_host(res, site_qual[0], site_qual[1])
             return res
         res = self._hip.genotype_batch(batch, device=self.device, flags=flags, site_qual=site_qual)
@@ -625,9 +629,13 @@ class ChunkPipeline:
     NativeUnitCollector holds a lock around svt_bam_summarise, whose own threads already fill the host).  `on_done(results)`
     is called on the caller's thread, in submission order: chunk k-depth's when chunk k is submitted, the rest at close()."""
 
-    def __init__(self, overlap: bool = True, depth: int = 2):
+    def __init__(self, overlap: bool = True, depth: Optional[int] = None):
+        """`depth`: jobs in flight (default 2, SVT_PIPELINE_DEPTH): chunk k on the device while chunk k + 1 is with the reader;
+        depth + 1 chunks' host and device buffers are alive at once."""
         from collections import deque
         from concurrent.futures import ThreadPoolExecutor
+        if depth is None:
+            depth = int(os.environ.get("SVT_PIPELINE_DEPTH", "2"))
         self._depth = max(1, int(depth))
         self._pool = ThreadPoolExecutor(self._depth) if overlap else None
         self._pending = deque()

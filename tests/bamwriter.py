@@ -52,6 +52,9 @@ def encode_record(r):
     else:
         body += b"\x00" * ((l_seq + 1) // 2) + b"\xff" * l_seq
     for key, typ, val in r.get("tags", ()):
+        if typ == "raw":        # bytes as they are (a malformed tag for the readers' error paths)
+            body += val
+            continue
         body += key.encode() + typ.encode()
         if typ == "Z":
             body += val.encode() + b"\0"

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 import goldenio as gio
-from svtyper_amd import bam, classic, geometry as geo, library, native_reads as nr, pipeline, singlesample
+from svtyper_amd import bam, classic, geometry as geo, hip, library, native_reads as nr, pipeline, singlesample
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 DATA = os.path.join(HERE, "data")
@@ -175,6 +175,40 @@ def test_tag_order_does_not_matter(tmp_path, seed, mode, max_reads):
     a = _synthetic_native_equals_python(tmp_path, seed, mode, max_reads, True)
     b = _synthetic_native_equals_python(tmp_path, seed, mode, max_reads, False)
     assert a == b
+
+
+@pytest.mark.parametrize("sa_first", [False, True])
+def test_truncated_tag_behind_rg_is_malformed_in_both_tag_orders(tmp_path, sa_first):
+    """a tag cut off at the end of the record, behind RG: both readers refuse the read whatever the order of RG and SA (the
+    native one walks the tags behind RG even when it met SA on the way to RG)"""
+    import bamwriter as bw
+    header = "@HD\tVN:1.5\tSO:coordinate\n@SQ\tSN:1\tLN:100000\n@RG\tID:rg\tSM:s\tLB:lib\n"
+    sa = ("SA", "Z", "1,52001,+,40S60M,60,0;")
+    rg = ("RG", "Z", "rg")
+    bad = ("XT", "raw", b"XTZno-terminator")
+    good = [dict(name="ok%d" % k, flag=0x1 | 0x40, tid=0, pos=50_000 + k, mapq=60, cigar="100M", mtid=0, mpos=50_300, tlen=400,
+                 tags=[rg]) for k in range(3)]
+    broken = dict(name="zz", flag=0x1 | 0x40, tid=0, pos=50_010, mapq=60, cigar="60M40S", mtid=0, mpos=50_300, tlen=400,
+                  tags=([sa, rg] if sa_first else [rg, sa]) + [bad])
+    site = {"id": "d", "svtype": "DEL", "var_length": 800, "A": {"chrom": "1", "pos": 50_050, "ci": [0, 0], "is_reverse": False},
+            "B": {"chrom": "1", "pos": 50_851, "ci": [0, 0], "is_reverse": True}}
+    hist = {str(k): 10 for k in range(200, 500)}
+    info = {"s": {"mapped": 4, "unmapped": 0, "bam": "x", "sample_name": "s", "libraryArray": [
+        {"library_name": "lib", "readgroups": ["rg"], "read_length": 100, "histogram": hist, "mean": 350.0, "sd": 50.0, "prevalence": 1.0}]}}
+    for name, recs in (("good.bam", good), ("bad.bam", sorted(good + [broken], key=lambda r: r["pos"]))):
+        path = str(tmp_path / name)
+        bw.write_bam(path, header, [("1", 100000)], recs)
+        sample = library.Sample.from_lib_info(bam.AlignmentFile(path), info, 1e-3)
+        nbam = nr.NativeBam(path)
+        if name == "good.bam":
+            assert len(_python_summaries([{"breakpoint": site}], sample, nr.COUNT_SSO, 1000)[1]) == 3
+            assert len(_native_summaries([{"breakpoint": site}], sample, nbam, nr.COUNT_SSO, 1000, 2)[1]) == 3
+            continue
+        with pytest.raises(Exception) as py_err:
+            _python_summaries([{"breakpoint": site}], sample, nr.COUNT_SSO, 1000)
+        with pytest.raises(hip.SvtyperHipError) as nat_err:
+            _native_summaries([{"breakpoint": site}], sample, nbam, nr.COUNT_SSO, 1000, 2)
+        assert "malformed" in str(nat_err.value) and not isinstance(py_err.value, hip.SvtyperHipError)
 
 
 def test_names_that_tie_in_the_sort_key(tmp_path):
