@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SVT_ABI_VERSION 16
+#define SVT_ABI_VERSION 17
 
 /* ---- error codes (0 = ok, <0 = error; text via svt_last_error()) ---------- */
 #define SVT_OK 0
@@ -590,6 +590,17 @@ int svt_genotype_multi(const svt_evidence_batch* in, svt_result* out, const int*
 /* The shard rule of svt_genotype_multi (and of svtyper_amd/distributed.py: shard_bounds, which ranks of a
  * torch.distributed job use): bounds[0 .. n_shards], shard r = units [bounds[r], bounds[r + 1]).          */
 int svt_shard_bounds(const uint64_t* rec_offset, uint64_t n_units, int n_shards, uint32_t group, uint64_t* bounds);
+
+/* Batches beyond one resident batch's 32-bit record index (2^32 - 17 records = 68 GB of the 288 GB of HBM; the same
+ * bound for units): the fewest contiguous chunks of at most `max_records` records (0 = the library's bound) cut at
+ * multiples of `group` units (samples per site: a site's samples, hence its QUAL, stay in one chunk; 0 / 1 = any unit).
+ * bounds[0 .. *n_chunks], chunk c = units [bounds[c], bounds[c + 1]); call with bounds = NULL first for the count
+ * (bounds needs *n_chunks + 1 entries; `max_chunks` = the chunks it has room for).  SVT_ERR_INVALID when one group of
+ * units alone exceeds the bound.  svt_batch_create refuses a larger batch; svt_genotype cuts it this way itself
+ * (group 1) and runs chunk after chunk, so its out[] never depends on the size.  Units are independent (the reference
+ * keeps no state across (site, sample) pairs: svtyper/classic.py:279-513).                                           */
+int svt_chunk_bounds(const uint64_t* rec_offset, uint64_t n_units, uint32_t group, uint64_t max_records, uint64_t* bounds,
+                     uint32_t max_chunks, uint32_t* n_chunks);
 
 #ifdef __cplusplus
 }

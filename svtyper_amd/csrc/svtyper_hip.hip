@@ -595,13 +595,29 @@ int ensure_result_slots(svt_batch* b, uint64_t slots)
 // svt_batch_create for the streaming layout: validate the unit arrays, build the tables, put the canonical
 // CSR in HBM as it is.  No scan, no tiling, no re-encoding: the pass reads the records where they lie.
 // `d_records_resident` (from the geometry stage) is adopted: the batch then owns that pool buffer.
+// records (and units) one resident batch may hold: the kernels index both with 32 bits.  SVT_MAX_BATCH_RECORDS lowers it (tests
+// of the chunked one-shot at sizes a test can afford).
+uint64_t max_batch_records()
+{
+    static const uint64_t cached = [] {
+        uint64_t v = 0xFFFFFFF0ull - 1;
+        if (const char* e = std::getenv("SVT_MAX_BATCH_RECORDS")) {
+            const uint64_t w = std::strtoull(e, nullptr, 10);
+            if (w > 0 && w < v) v = w;
+        }
+        return v;
+    }();
+    return cached;
+}
+
 int create_stream(const svt_evidence_batch* in, svt_batch* b, void* d_records_resident = nullptr, uint64_t resident_cap = 0,
                   bool defer_records = false)   // defer_records: the caller uploads the records itself (pipelined one-shot)
 {
     const uint64_t n = in->n_units;
     const uint64_t n_rec = n ? in->rec_offset[n] : 0;
     StageTimer tm;
-    if (n_rec >= 0xFFFFFFF0ull) return fail(SVT_ERR_INVALID, "too many records in one batch (< 2^32)");
+    if (n_rec > max_batch_records())
+        return fail(SVT_ERR_INVALID, "too many records in one batch (< 2^32): cut it with svt_chunk_bounds, or hand it to svt_genotype, which does");
     uint64_t max_f = 0;
     bool wide_var_length = false, all_hinted = n > 0;
     {   // the unit arrays, checked by several host threads
@@ -2633,8 +2649,35 @@ void svt_trim(void)
     svt_reads_trim();
 }
 
+static int svt_chunk_bounds_impl(const uint64_t* rec_offset, uint64_t n_units, uint32_t group, uint64_t max_records, uint64_t* bounds,
+                                 uint32_t max_chunks, uint32_t* n_chunks);
+
 static int svt_genotype_impl(const svt_evidence_batch* in, svt_result* out, int device, unsigned flags)
 {
+    // a batch beyond the 32-bit record index of one resident batch (68 GB of records): chunk after chunk of whole units
+    // (svt_chunk_bounds), each through this very entry point -- units are independent, so out[] is what one batch would give
+    if (in && out && in->rec_offset && in->units && in->n_units &&
+        (in->rec_offset[in->n_units] - in->rec_offset[0] > max_batch_records() || in->n_units > max_batch_records())) {
+        for (uint64_t u = 0; u < in->n_units; ++u)
+            if (in->rec_offset[u + 1] < in->rec_offset[u]) return fail(SVT_ERR_INVALID, "rec_offset not monotone");
+        uint32_t n_chunks = 0;
+        SVT_TRY(svt_chunk_bounds_impl(in->rec_offset, in->n_units, 1, 0, nullptr, 0, &n_chunks));
+        std::vector<uint64_t> bounds((size_t)n_chunks + 1);
+        SVT_TRY(svt_chunk_bounds_impl(in->rec_offset, in->n_units, 1, 0, bounds.data(), n_chunks, &n_chunks));
+        std::vector<uint64_t> off;
+        for (uint32_t c = 0; c < n_chunks; ++c) {
+            const uint64_t lo = bounds[c], hi = bounds[c + 1], r0 = in->rec_offset[lo];
+            off.resize(hi - lo + 1);
+            for (uint64_t u = lo; u <= hi; ++u) off[u - lo] = in->rec_offset[u] - r0;
+            svt_evidence_batch part = *in;
+            part.n_units = hi - lo;
+            part.rec_offset = off.data();
+            part.units = in->units + lo;
+            part.records = in->records ? in->records + r0 : nullptr;
+            SVT_TRY(svt_genotype_impl(&part, out + lo, device, flags));
+        }
+        return SVT_OK;
+    }
     // the streamed layout from host records: upload, pass and download overlap by unit ranges
     if (in && out && !(flags & ~kKnownFlags) && in->n_units >= kPipelineMinUnits &&
         in->n_units < 0xFFFFFFF0ull && in->rec_offset && in->units && in->records && in->n_libs >= 1 && in->n_libs <= 256 && in->libs &&
@@ -2723,6 +2766,42 @@ static int svt_shard_bounds_impl(const uint64_t* rec_offset, uint64_t n_units, i
 int svt_shard_bounds(const uint64_t* rec_offset, uint64_t n_units, int n_shards, uint32_t group, uint64_t* bounds)
 {
     return guarded([&] { return svt_shard_bounds_impl(rec_offset, n_units, n_shards, group, bounds); });
+}
+
+// greedy cut into the fewest chunks of at most `max_records` records (and units), at multiples of `group` units
+static int svt_chunk_bounds_impl(const uint64_t* rec_offset, uint64_t n_units, uint32_t group, uint64_t max_records, uint64_t* bounds,
+                                 uint32_t max_chunks, uint32_t* n_chunks)
+{
+    if (!n_chunks || (n_units && !rec_offset)) return fail(SVT_ERR_INVALID, "null argument");
+    if (group == 0) group = 1;
+    if (max_records == 0 || max_records > max_batch_records()) max_records = max_batch_records();
+    uint32_t count = 0;
+    uint64_t lo = 0;
+    if (bounds && max_chunks) bounds[0] = 0;
+    while (lo < n_units) {
+        // the last k <= n_units with records[lo, k) <= max_records and k - lo <= max_records: rec_offset is monotone
+        uint64_t a = lo, b = std::min<uint64_t>(n_units, lo + max_records);
+        while (a < b) {
+            const uint64_t mid = a + (b - a + 1) / 2;
+            if (rec_offset[mid] - rec_offset[lo] <= max_records) a = mid; else b = mid - 1;
+        }
+        uint64_t hi = a == n_units ? n_units : lo + (a - lo) / group * group;
+        if (hi <= lo) return fail(SVT_ERR_INVALID, "svt_chunk_bounds: the units of one site hold more records than a batch can");
+        ++count;
+        if (bounds) {
+            if (count > max_chunks) return fail(SVT_ERR_INVALID, "svt_chunk_bounds: bounds[] is too short");
+            bounds[count] = hi;
+        }
+        lo = hi;
+    }
+    *n_chunks = count;
+    return SVT_OK;
+}
+
+int svt_chunk_bounds(const uint64_t* rec_offset, uint64_t n_units, uint32_t group, uint64_t max_records, uint64_t* bounds,
+                     uint32_t max_chunks, uint32_t* n_chunks)
+{
+    return guarded([&] { return svt_chunk_bounds_impl(rec_offset, n_units, group, max_records, bounds, max_chunks, n_chunks); });
 }
 
 static int svt_genotype_multi_impl(const svt_evidence_batch* in, svt_result* out, const int* devices, int n_devices,

@@ -16,7 +16,7 @@ from .evidence import GT_BLANK, CEvidenceBatch, CPackedEvidence, EvidenceBatch, 
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SVTYPER_HIP_LIB") or os.path.join(_HERE, "csrc", "libsvtyper_hip.so")
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 EXPORTS = (
     "svt_version", "svt_device_count", "svt_last_error", "svt_batch_create", "svt_batch_create_segments", "svt_batch_create_from_fragments",
@@ -26,7 +26,7 @@ EXPORTS = (
     "svt_batch_stream", "svt_batch_destroy", "svt_trim", "svt_bayes_gt", "svt_genotype_counts", "svt_genotype", "svt_genotype_multi", "svt_shard_bounds",
     "svt_pinned_alloc", "svt_pinned_free", "svt_pack_evidence", "svt_packed_free", "svt_batch_create_packed", "svt_genotype_packed",
     "svt_format_results", "svt_format_free", "svt_results_host_sq", "svt_batch_result_bytes", "svt_batch_result_slots", "svt_results_expand96",
-    "svt_genotype_packed_from_records",
+    "svt_genotype_packed_from_records", "svt_chunk_bounds",
 )
 
 _lib: Optional[C.CDLL] = None
@@ -114,6 +114,8 @@ def load() -> C.CDLL:
     L.svt_genotype_multi.argtypes = [C.POINTER(CEvidenceBatch), C.c_void_p, C.POINTER(C.c_int), C.c_int, C.c_uint32, C.c_uint]
     L.svt_shard_bounds.restype = C.c_int
     L.svt_shard_bounds.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_uint32, C.c_void_p]
+    L.svt_chunk_bounds.restype = C.c_int
+    L.svt_chunk_bounds.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
     L.svt_pinned_alloc.restype = C.c_void_p
     L.svt_pinned_alloc.argtypes = [C.c_size_t]
     L.svt_pinned_free.restype = None
@@ -639,3 +641,19 @@ def shard_bounds(rec_offset, n_shards: int, group: int = 1):
     b = np.zeros(n_shards + 1, np.uint64)
     _check(L.svt_shard_bounds(off.ctypes.data, max(0, off.shape[0] - 1), int(n_shards), int(group), b.ctypes.data))
     return [(int(b[i]), int(b[i + 1])) for i in range(n_shards)]
+
+
+def chunk_bounds(rec_offset, group: int = 1, max_records: int = 0):
+    """svt_chunk_bounds: [(lo, hi)] unit ranges of the fewest chunks that each fit one resident batch (at most `max_records`
+    records, 0 = the library's 32-bit bound), cut at multiples of `group` units (samples per site).  Host only.  A batch
+    beyond the bound goes through DeviceBatch chunk by chunk (`batch.slice(lo, hi)`); genotype_batch / svt_genotype do it
+    themselves."""
+    import numpy as np
+    L = load()
+    off = np.ascontiguousarray(rec_offset, dtype=np.uint64)
+    n = max(0, off.shape[0] - 1)
+    count = C.c_uint32()
+    _check(L.svt_chunk_bounds(off.ctypes.data, n, int(group), int(max_records), None, 0, C.byref(count)))
+    b = np.zeros(count.value + 1, np.uint64)
+    _check(L.svt_chunk_bounds(off.ctypes.data, n, int(group), int(max_records), b.ctypes.data, count.value, C.byref(count)))
+    return [(int(b[i]), int(b[i + 1])) for i in range(count.value)]
