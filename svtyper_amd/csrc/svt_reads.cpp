@@ -958,7 +958,7 @@ struct Workspace {
     std::vector<Fragment> frags;       // [0, n_frags) are live
     size_t n_frags = 0;
     std::vector<char> names;
-    std::vector<uint32_t> table;       // fragment index + 1, 0 = empty; size is a power of two
+    std::vector<uint64_t> table;       // (name hash's high half) << 32 | fragment index + 1, 0 = empty; size is a power of two
     std::vector<uint32_t> order;
     std::vector<std::pair<uint64_t, uint32_t>> keys;
     std::vector<uint64_t> packed;
@@ -972,8 +972,8 @@ struct Workspace {
     {
         n_frags = 0;
         names.clear();
-        if (table.size() < 1024) table.assign(1024, 0u);
-        else std::fill(table.begin(), table.end(), 0u);
+        if (table.size() < 1024) table.assign(1024, 0ull);
+        else std::fill(table.begin(), table.end(), 0ull);
     }
     static uint64_t hash_name(const char* p, size_t n)
     {
@@ -1001,28 +1001,33 @@ struct Workspace {
     {
         if ((n_frags + 1) * 2 > table.size()) grow();
         const size_t mask = table.size() - 1;
-        for (size_t i = hash_name(name, len) & mask;; i = (i + 1) & mask) {
-            const uint32_t slot = table[i];
-            if (slot == 0u) {
+        const uint64_t h = hash_name(name, len), tag = h & 0xffffffff00000000ull;
+        // the slot carries the hash's high half: a probe that meets another name's slot moves on without touching that
+        // fragment (a big struct) or its name; the second read of a pair pays ONE memcmp
+        for (size_t i = h & mask;; i = (i + 1) & mask) {
+            const uint64_t e = table[i];
+            if (e == 0ull) {
                 if (n_frags == frags.size()) frags.emplace_back();
                 Fragment& f = frags[n_frags];
                 f.reset(lib, (uint32_t)names.size(), len);
                 names.insert(names.end(), name, name + len);
-                table[i] = (uint32_t)++n_frags;
+                table[i] = tag | (uint64_t)++n_frags;
                 return f;
             }
-            Fragment& f = frags[slot - 1];
+            if ((e & 0xffffffff00000000ull) != tag) continue;
+            Fragment& f = frags[(uint32_t)e - 1];
             if (f.name_len == len && std::memcmp(name_of(f), name, len) == 0) return f;
         }
     }
     void grow()
     {
-        table.assign(table.size() * 2, 0u);
+        table.assign(table.size() * 2, 0ull);
         const size_t mask = table.size() - 1;
         for (size_t k = 0; k < n_frags; ++k) {
-            size_t i = hash_name(name_of(frags[k]), frags[k].name_len) & mask;
+            const uint64_t h = hash_name(name_of(frags[k]), frags[k].name_len);
+            size_t i = h & mask;
             while (table[i]) i = (i + 1) & mask;
-            table[i] = (uint32_t)(k + 1);
+            table[i] = (h & 0xffffffff00000000ull) | (uint64_t)(k + 1);
         }
     }
     // live fragments in the order of Python's sorted() over their (ASCII) names.  Query names of one run share a long
