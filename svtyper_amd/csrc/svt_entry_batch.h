@@ -1,0 +1,631 @@
+// svt_entry_batch.h -- part of the single translation unit svtyper_hip.hip (included there, in order; not a stand-alone header):
+// C ABI: svt_version ... svt_batch_create* / genotype* / results / result order / device results / site QUAL.
+
+
+int svt_version(void) { return SVT_ABI_VERSION; }
+
+int svt_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char* svt_last_error(void) { return g_err.c_str(); }
+
+static int svt_batch_create_impl(const svt_evidence_batch* in, int device, unsigned flags, svt_batch** out)
+{
+    if (!in || !out) return fail(SVT_ERR_INVALID, "null argument");
+    *out = nullptr;
+    const uint64_t n = in->n_units;
+    if (flags & ~kKnownFlags) return fail(SVT_ERR_INVALID, "unknown flag bits");
+    if (n >= 0xFFFFFFF0ull) return fail(SVT_ERR_INVALID, "too many units in one batch (< 2^32)");
+    if (in->n_libs == 0 || in->n_libs > 256 || !in->libs) return fail(SVT_ERR_INVALID, "n_libs must be 1..256");
+    if (n && (!in->rec_offset || !in->units)) return fail(SVT_ERR_INVALID, "null unit arrays");
+    if (n && in->rec_offset[0] != 0) return fail(SVT_ERR_INVALID, "rec_offset[0] must be 0");
+    if (n && in->rec_offset[n] && !in->records) return fail(SVT_ERR_INVALID, "null records");
+    if (!(in->split_weight >= 0.0) || !(in->disc_weight >= 0.0) || !std::isfinite(in->split_weight) ||
+        !std::isfinite(in->disc_weight))
+        return fail(SVT_ERR_INVALID, "weights must be finite and >= 0");
+
+    const int ndev = svt_device_count();
+    if (ndev <= 0) return fail(SVT_ERR_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(SVT_ERR_NO_DEVICE, "device index out of range");
+    HIP_TRY(hipSetDevice(device));
+
+    svt_batch* b = new (std::nothrow) svt_batch();
+    if (!b) return fail(SVT_ERR_NOMEM, "out of host memory");
+    b->device = device;
+    b->flags = flags;
+    b->layout = kLayoutStream;
+    b->n_units = n;
+    b->n_records = n ? in->rec_offset[n] : 0;
+    const int rc = create_stream(in, b);
+    if (rc != SVT_OK) {
+        const std::string keep = g_err;
+        free_batch(b);
+        g_err = keep;
+        return rc;
+    }
+    *out = b;
+    return SVT_OK;
+}
+
+int svt_batch_create(const svt_evidence_batch* in, int device, unsigned flags, svt_batch** out)
+{
+    return guarded([&] { return svt_batch_create_impl(in, device, flags, out); });
+}
+
+// svt_batch_create with the records in pieces (include/svtyper_hip.h): create_stream leaves the record upload to this function
+// (as it does for the pipelined one-shot), every segment goes through the staging ring to its place in the device array.  A
+// batch whose library windows have to be read off the records (several libraries, units without hints) needs the records
+// while it is created: its segments are put together in page-locked scratch first -- the rare case.
+static int svt_batch_create_segments_impl(const svt_evidence_batch* in, const svt_record_segment* segments, uint32_t n_segments,
+                                          int device, unsigned flags, svt_batch** out)
+{
+    if (!in || !out || (n_segments && !segments)) return fail(SVT_ERR_INVALID, "null argument");
+    *out = nullptr;
+    const uint64_t n = in->n_units;
+    if (n && !in->rec_offset) return fail(SVT_ERR_INVALID, "null unit arrays");
+    const uint64_t n_rec = n ? in->rec_offset[n] : 0;
+    uint64_t have = 0;
+    for (uint32_t k = 0; k < n_segments; ++k) {
+        if (segments[k].n_records && !segments[k].records) return fail(SVT_ERR_INVALID, "svt_batch_create_segments: null segment");
+        if (segments[k].n_records > n_rec - have) return fail(SVT_ERR_INVALID, "svt_batch_create_segments: the segments hold more records than rec_offset[n_units]");
+        have += segments[k].n_records;
+    }
+    if (have != n_rec) return fail(SVT_ERR_INVALID, "svt_batch_create_segments: the segments hold fewer records than rec_offset[n_units]");
+    svt_evidence_batch eb = *in;
+    eb.records = nullptr;
+    bool hinted = true;      // (create_stream's rule: the windows come from the hints only when every unit has one)
+    if (in->n_libs > 1 && in->units && !(flags & SVT_FLAG_GENERAL_TABLES))
+        for (uint64_t u = 0; u < n && hinted; ++u) hinted = ((in->units[u].libs >> 8) & 0xffu) != 0u;
+    if (!hinted || (flags & ~kKnownFlags) || n_rec == 0) {
+        struct Scratch { void* p = nullptr; ~Scratch() { g_pinned.put(p); } } scratch;
+        if (n_rec) {
+            scratch.p = g_pinned.get(n_rec * sizeof(svt_record));
+            if (!scratch.p) return fail(SVT_ERR_NOMEM, "out of page-locked host memory");
+            char* at = static_cast<char*>(scratch.p);
+            for (uint32_t k = 0; k < n_segments; ++k) {
+                std::memcpy(at, segments[k].records, segments[k].n_records * sizeof(svt_record));
+                at += segments[k].n_records * sizeof(svt_record);
+            }
+            eb.records = static_cast<const svt_record*>(scratch.p);
+        }
+        return svt_batch_create_impl(&eb, device, flags, out);
+    }
+    // the checks of svt_batch_create_impl (the records are not looked at on the host: the pass itself checks their contract)
+    if (n >= 0xFFFFFFF0ull) return fail(SVT_ERR_INVALID, "too many units in one batch (< 2^32)");
+    if (in->n_libs == 0 || in->n_libs > 256 || !in->libs) return fail(SVT_ERR_INVALID, "n_libs must be 1..256");
+    if (n && !in->units) return fail(SVT_ERR_INVALID, "null unit arrays");
+    if (n && in->rec_offset[0] != 0) return fail(SVT_ERR_INVALID, "rec_offset[0] must be 0");
+    if (!(in->split_weight >= 0.0) || !(in->disc_weight >= 0.0) || !std::isfinite(in->split_weight) || !std::isfinite(in->disc_weight))
+        return fail(SVT_ERR_INVALID, "weights must be finite and >= 0");
+    const int ndev = svt_device_count();
+    if (ndev <= 0) return fail(SVT_ERR_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(SVT_ERR_NO_DEVICE, "device index out of range");
+    HIP_TRY(hipSetDevice(device));
+    svt_batch* b = new (std::nothrow) svt_batch();
+    if (!b) return fail(SVT_ERR_NOMEM, "out of host memory");
+    b->device = device;
+    b->flags = flags;
+    b->layout = kLayoutStream;
+    b->n_units = n;
+    b->n_records = n_rec;
+    int rc = create_stream(&eb, b, nullptr, 0, /*defer_records=*/true);
+    if (rc == SVT_OK && b->records_resident) rc = fail(SVT_ERR_INTERNAL, "svt_batch_create_segments: create_stream wanted the records");
+    if (rc == SVT_OK) {
+        Stager st(b->stream);
+        char* at = static_cast<char*>(b->d_records);
+        for (uint32_t k = 0; k < n_segments && rc == SVT_OK; ++k) {
+            rc = st.copy(at, segments[k].records, segments[k].n_records * sizeof(svt_record));
+            at += segments[k].n_records * sizeof(svt_record);
+        }
+        if (rc == SVT_OK) rc = st.finish();
+        if (rc == SVT_OK) b->records_resident = true;
+    }
+    if (rc != SVT_OK) {
+        const std::string keep = g_err;
+        free_batch(b);
+        g_err = keep;
+        return rc;
+    }
+    *out = b;
+    return SVT_OK;
+}
+
+int svt_batch_create_segments(const svt_evidence_batch* in, const svt_record_segment* segments, uint32_t n_segments, int device,
+                              unsigned flags, svt_batch** out)
+{
+    return guarded([&] { return svt_batch_create_segments_impl(in, segments, n_segments, device, flags, out); });
+}
+
+static int svt_batch_create_from_fragments_impl(const svt_fragment_batch* in, int device, unsigned flags,
+                                    svt_record* records_out, svt_batch** out)
+{
+    if (!in || !out) return fail(SVT_ERR_INVALID, "null argument");
+    *out = nullptr;
+    const uint64_t n = in->n_units;
+    if (flags & ~kKnownFlags) return fail(SVT_ERR_INVALID, "unknown flag bits");
+    if (n >= 0xFFFFFFF0ull) return fail(SVT_ERR_INVALID, "too many units in one batch (< 2^32)");
+    if (in->n_libs == 0 || in->n_libs > 256 || !in->libs) return fail(SVT_ERR_INVALID, "n_libs must be 1..256");
+    if (n && (!in->frag_offset || !in->breakpoints)) return fail(SVT_ERR_INVALID, "null unit arrays");
+    if (n && in->frag_offset[0] != 0) return fail(SVT_ERR_INVALID, "frag_offset[0] must be 0");
+    const uint64_t n_frag = n ? in->frag_offset[n] : 0;
+    if (n_frag && !in->fragments) return fail(SVT_ERR_INVALID, "null fragments");
+    const int ndev = svt_device_count();
+    if (ndev <= 0) return fail(SVT_ERR_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(SVT_ERR_NO_DEVICE, "device index out of range");
+    HIP_TRY(hipSetDevice(device));
+
+    // unit headers
+    std::vector<svt_unit> units(n);
+    for (uint64_t u = 0; u < n; ++u) {
+        const svt_breakpoint& bp = in->breakpoints[u];
+        if (in->frag_offset[u + 1] < in->frag_offset[u]) return fail(SVT_ERR_INVALID, "frag_offset not monotone");
+        if (bp.svtype > SVT_SVTYPE_BND) return fail(SVT_ERR_INVALID, "bad svtype");
+        svt_unit U{};
+        U.var_length = bp.svtype == SVT_SVTYPE_DEL ? bp.var_length : 0;
+        const int64_t delta = (int64_t)bp.pos_b - (int64_t)bp.pos_a;            // classic.py:339
+        U.pos_delta = (int32_t)std::max<int64_t>(INT32_MIN, std::min<int64_t>(INT32_MAX, delta));
+        U.sample = bp.sample;
+        U.svtype = bp.svtype;
+        U.flags = (bp.flags & SVT_BP_SKIP) ? SVT_UNIT_SKIP : 0;
+        U.libs = bp.reserved[0] & 0xffffu;      // SVT_UNIT_LIBS hint of the unit's sample
+        units[u] = U;
+    }
+    // library descriptors (the flank of is_pair_straddle is lib.mean + lib.sd * 3)
+    std::vector<LibDesc> libs(in->n_libs);
+    for (uint32_t l = 0; l < in->n_libs; ++l) {
+        if (!std::isfinite(in->libs[l].mean) || !std::isfinite(in->libs[l].sd)) return fail(SVT_ERR_INVALID, "library moments not finite");
+        libs[l].v_nondel = in->libs[l].mean + in->libs[l].sd * 3;
+    }
+
+    // geometry on the device
+    hipStream_t s = nullptr;
+    SVT_TRY(g_handles.get_stream(&s));
+    struct StreamGuard { hipStream_t s; ~StreamGuard() { (void)hipStreamSynchronize(s); g_handles.put_stream(s); } } sg{s};
+    StageTimer tm;
+    // the two big buffers of this stage come from the pool svt_batch_destroy refills (svt_host_transfer.h)
+    struct Pooled {
+        int device;
+        void* p = nullptr;
+        uint64_t cap = 0;
+        ~Pooled() { g_pool.put(device, p, cap); }
+        int get(uint64_t bytes, bool records = false) { return g_pool.get(device, bytes, &p, &cap, records); }
+        void* release() { void* q = p; p = nullptr; return q; }
+    } d_frags{device}, d_records{device};
+    DevScratch d_frag_off, d_bps, d_libs, d_err;
+    {
+        Stager st(s);
+        SVT_TRY(d_frags.get(n_frag * sizeof(svt_fragment)));
+        SVT_TRY(st.copy(d_frags.p, in->fragments, n_frag * sizeof(svt_fragment)));
+        SVT_TRY(d_frag_off.alloc((n + 1) * sizeof(uint64_t)));
+        if (n) SVT_TRY(st.copy(d_frag_off.p, in->frag_offset, (n + 1) * sizeof(uint64_t)));
+        SVT_TRY(d_bps.alloc(n * sizeof(svt_breakpoint)));
+        SVT_TRY(st.copy(d_bps.p, in->breakpoints, n * sizeof(svt_breakpoint)));
+        SVT_TRY(upload(d_libs, libs, st));
+        SVT_TRY(st.finish());
+        tm.mark("H2D fragment summaries + unit arrays (staged)");
+    }
+    SVT_TRY(d_records.get((n_frag + kBlockRecords) * sizeof(uint4), /*records=*/true));   // whole 128-byte blocks (kLayoutStream)
+    SVT_TRY(d_err.alloc(sizeof(uint32_t)));
+    HIP_TRY(hipMemsetAsync(d_err.p, 0, sizeof(uint32_t), s));
+    if (n_frag) {
+        GeomArgs g{};
+        g.frags = static_cast<const uint4*>(d_frags.p);
+        g.frag_offset = d_frag_off.as<uint64_t>();
+        g.n_units = n;
+        g.bps = d_bps.as<svt_breakpoint>();
+        g.libs = d_libs.as<LibDesc>();
+        g.n_frags = n_frag;
+        g.n_libs = in->n_libs;
+        g.min_aligned = in->min_aligned;
+        g.split_slop = in->split_slop;
+        g.records = static_cast<uint4*>(d_records.p);
+        g.err = d_err.as<uint32_t>();
+        hipLaunchKernelGGL(svt_geometry_kernel, dim3((unsigned)((n_frag + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, g);
+        HIP_TRY(hipGetLastError());
+    }
+    uint32_t err_bits = 0;
+    HIP_TRY(hipMemcpyAsync(&err_bits, d_err.p, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    if (records_out && n_frag) SVT_TRY(d2h_staged(records_out, d_records.p, n_frag * sizeof(uint4), s));
+    HIP_TRY(hipStreamSynchronize(s));
+    tm.mark("geometry kernel (+ copies)");
+    if (err_bits) return fail(SVT_ERR_INVALID, "invalid fragment summaries: library index >= n_libs");
+
+    // the resident batch, from the records that are already in HBM
+    svt_evidence_batch eb{};
+    eb.n_units = n;
+    eb.rec_offset = in->frag_offset;
+    eb.units = units.data();
+    eb.records = nullptr;
+    eb.n_libs = in->n_libs;
+    eb.libs = in->libs;
+    eb.split_weight = in->split_weight;
+    eb.disc_weight = in->disc_weight;
+    if (!(eb.split_weight >= 0.0) || !(eb.disc_weight >= 0.0) || !std::isfinite(eb.split_weight) ||
+        !std::isfinite(eb.disc_weight))
+        return fail(SVT_ERR_INVALID, "weights must be finite and >= 0");
+    svt_batch* b = new (std::nothrow) svt_batch();
+    if (!b) return fail(SVT_ERR_NOMEM, "out of host memory");
+    b->device = device;
+    b->flags = flags;
+    b->layout = kLayoutStream;
+    b->n_units = n;
+    b->n_records = n_frag;
+    const uint64_t cap = d_records.cap;
+    const int rc = create_stream(&eb, b, d_records.p, cap);
+    if (b->d_records == d_records.p) d_records.release();   // the batch owns the records now
+    if (rc != SVT_OK) {
+        const std::string keep = g_err;
+        free_batch(b);
+        g_err = keep;
+        return rc;
+    }
+    *out = b;
+    return SVT_OK;
+}
+
+int svt_batch_create_from_fragments(const svt_fragment_batch* in, int device, unsigned flags, svt_record* records_out, svt_batch** out)
+{
+    return guarded([&] { return svt_batch_create_from_fragments_impl(in, device, flags, records_out, out); });
+}
+
+static int svt_batch_genotype_impl(svt_batch* b, int sync)
+{
+    if (!b) return fail(SVT_ERR_INVALID, "null batch");
+    HIP_TRY(hipSetDevice(b->device));
+    SVT_TRY(launch_genotype(b));
+    b->have_results = true;
+    if (sync) {
+        HIP_TRY(hipStreamSynchronize(b->stream));
+        SVT_TRY(check_stream_errors(b));
+    }
+    return SVT_OK;
+}
+
+int svt_batch_genotype(svt_batch* b, int sync)
+{
+    return guarded([&] { return svt_batch_genotype_impl(b, sync); });
+}
+
+static int svt_batch_genotype_n_impl(svt_batch* b, int iters)
+{
+    if (!b || iters <= 0) return fail(SVT_ERR_INVALID, "bad arguments");
+    HIP_TRY(hipSetDevice(b->device));
+    for (int i = 0; i < iters; ++i) SVT_TRY(launch_genotype(b));
+    b->have_results = true;
+    return SVT_OK;
+}
+
+int svt_batch_genotype_n(svt_batch* b, int iters)
+{
+    return guarded([&] { return svt_batch_genotype_n_impl(b, iters); });
+}
+
+int svt_batch_sync(svt_batch* b)
+{
+    return guarded([&]() -> int {
+        if (!b) return fail(SVT_ERR_INVALID, "null batch");
+        HIP_TRY(hipSetDevice(b->device));
+        HIP_TRY(hipStreamSynchronize(b->stream));
+        return check_stream_errors(b);
+    });
+}
+
+static int svt_batch_genotype_timed_impl(svt_batch* b, int iters, float* ms_total)
+{
+    if (!b || !ms_total || iters <= 0) return fail(SVT_ERR_INVALID, "bad arguments");
+    HIP_TRY(hipSetDevice(b->device));
+    HIP_TRY(hipEventRecord(b->ev0, b->stream));
+    for (int i = 0; i < iters; ++i) SVT_TRY(launch_genotype(b));
+    HIP_TRY(hipEventRecord(b->ev1, b->stream));
+    HIP_TRY(hipEventSynchronize(b->ev1));
+    HIP_TRY(hipEventElapsedTime(ms_total, b->ev0, b->ev1));
+    b->have_results = true;
+    return check_stream_errors(b);
+}
+
+// svt_batch_tune_placement (include/svtyper_hip.h): audition device buffers for the result records and for the records.
+// Which physical blocks of HBM the two big buffers of a batch lie in moves the pass by up to 8 % (levels, stable
+// for the life of an allocation, that nothing at allocation time predicts): with 288 GB of HBM the cheap answer is to allocate a
+// handful of candidates, run the REAL pass over each once the clocks are up, keep the fastest and hand the others back.  The
+// kept buffers return to the pool with the batch, so the batches of a chunked run that follow inherit them.
+static int svt_batch_tune_placement_impl(svt_batch* b, int result_candidates, int record_candidates, float* before_ms, float* after_ms)
+{
+    if (!b) return fail(SVT_ERR_INVALID, "null batch");
+    if (result_candidates < 0 || record_candidates < 0 || result_candidates > 64 || record_candidates > 16) return fail(SVT_ERR_INVALID, "0..64 result and 0..16 record candidates");
+    if (before_ms) *before_ms = 0.f;
+    if (after_ms) *after_ms = 0.f;
+    if (b->n_units == 0) return SVT_OK;
+    if (b->out_dev != b->d_out) return fail(SVT_ERR_INVALID, "the result records are bound to a caller's buffer (svt_batch_bind_device_results)");
+    HIP_TRY(hipSetDevice(b->device));
+    // Whatever way this function is left -- an audition cut short by a failing launch or copy included -- the pass's arguments
+    // point at the batch's OWN buffers again (the candidate guards below synchronise the stream before they release anything),
+    // and a batch left half way has no results.
+    struct Restore {
+        svt_batch* b;
+        bool done = false;
+        ~Restore()
+        {
+            if (!done) {
+                (void)hipStreamSynchronize(b->stream);
+                b->have_results = false;
+            }
+            b->out_dev = b->d_out;
+            b->sargs.out = b->pargs.out = b->d_out;
+            if (b->layout == kLayoutStream && b->records_resident) b->sargs.records = static_cast<const uint4*>(b->d_records);
+        }
+    } restore{b};
+    auto pass_ms = [&](int iters, float* ms) -> int {      // `iters` back-to-back launches, per launch
+        float total = 0.f;
+        HIP_TRY(hipEventRecord(b->ev0, b->stream));
+        for (int i = 0; i < iters; ++i) SVT_TRY(launch_genotype(b));
+        HIP_TRY(hipEventRecord(b->ev1, b->stream));
+        HIP_TRY(hipEventSynchronize(b->ev1));
+        HIP_TRY(hipEventElapsedTime(&total, b->ev0, b->ev1));
+        *ms = total / (float)iters;
+        return SVT_OK;
+    };
+    auto best_of = [&](int groups, int iters, float* ms) -> int {
+        float best = 0.f;
+        for (int g = 0; g < groups; ++g) {
+            float t = 0.f;
+            SVT_TRY(pass_ms(iters, &t));
+            if (g == 0 || t < best) best = t;
+        }
+        *ms = best;
+        return SVT_OK;
+    };
+    // clocks up: ~40 ms of passes (a device that idled runs its first launches 5-8 % slow)
+    {
+        float one = 0.f;
+        SVT_TRY(pass_ms(2, &one));
+        const int n = (int)std::min(400.0, std::max(4.0, 40.0 / std::max(one, 0.01f)));
+        SVT_TRY(pass_ms(n, &one));
+    }
+    float current = 0.f;
+    SVT_TRY(best_of(3, 10, &current));
+    if (before_ms) *before_ms = current;
+    const bool resident_records = b->layout == kLayoutStream && b->records_resident && b->sargs.records == static_cast<const uint4*>(b->d_records);
+    struct Cand { void* p; uint64_t cap; float ms; };
+    // The whole audition stays within ~0.3 s of uninterrupted passes: beyond that the device alternates between its level and one
+    // ~4 % slower until it has idled (profiles/r04_placement_tuning.txt), and candidates measured in that state are ranked by the
+    // state, not by their placement (an audition of 48 + 12 candidates at ten launches each kept a 0.301 ms pair where 32 + 8 found
+    // 0.285 twice).  So the launches per measurement follow from the pass time and the number of candidates.
+    const int n_cand = result_candidates + (resident_records ? record_candidates : 0);
+    const int iters = std::max(3, std::min(10, (int)(250.0f / (float)std::max(n_cand, 1) / (2.0f * std::max(current, 1e-3f)))));
+    // ---- result records: plain allocations (they may be handed to RCCL or to another process)
+    if (result_candidates > 0) {
+        const uint64_t bytes = std::max<uint64_t>(b->cap_out, std::max<uint64_t>(b->out_slots, 1) * result_bytes(b));
+        std::vector<Cand> cands;
+        struct FreeAll { std::vector<Cand>& c; hipStream_t s; ~FreeAll() { (void)hipStreamSynchronize(s); for (Cand& x : c) if (x.p) (void)hipFree(x.p); } } guard{cands, b->stream};
+        for (int i = 0; i < result_candidates; ++i) {
+            void* p = nullptr;
+            if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); break; }     // (out of memory: audition what there is)
+            cands.push_back(Cand{p, bytes, 0.f});
+        }
+        size_t best = cands.size();
+        for (size_t i = 0; i < cands.size(); ++i) {
+            b->sargs.out = b->pargs.out = static_cast<svt_result*>(cands[i].p);
+            SVT_TRY(best_of(2, iters, &cands[i].ms));
+            if (best == cands.size() || cands[i].ms < cands[best].ms) best = i;
+        }
+        if (best != cands.size()) {      // the winner once more, against the incumbent measured the same way (a single fast group is not a level)
+            b->sargs.out = b->pargs.out = static_cast<svt_result*>(cands[best].p);
+            SVT_TRY(best_of(3, iters, &cands[best].ms));
+        }
+        if (best != cands.size() && cands[best].ms < current * 0.995f) {
+            HIP_TRY(hipStreamSynchronize(b->stream));
+            g_pool.put(b->device, b->d_out, b->cap_out);
+            b->d_out = static_cast<svt_result*>(cands[best].p);
+            b->cap_out = cands[best].cap;
+            current = cands[best].ms;
+            cands[best].p = nullptr;
+        }
+        b->out_dev = b->d_out;
+        b->sargs.out = b->pargs.out = b->d_out;
+    }
+    // ---- records (canonical records resident in the batch's own buffer): candidates of the pool's own kind, filled by device copies
+    if (record_candidates > 0 && resident_records) {
+        const uint64_t bytes = ((uint64_t)b->sargs.last_blk + 1) * 128;      // the records as the kernel reads them: whole 128-byte blocks
+        std::vector<Cand> cands;
+        struct FreeAll { std::vector<Cand>& c; int device; hipStream_t s; ~FreeAll() { (void)hipStreamSynchronize(s); for (Cand& x : c) if (x.p) g_pool.release(x.p, device); } } guard{cands, b->device, b->stream};
+        for (int i = 0; i < record_candidates; ++i) {
+            void* p = nullptr;
+            uint64_t cap = 0;
+            // (not from the pool's idle list: a buffer that sits there was this batch's neighbour in time, not a new draw)
+            if (!(bytes + bytes / 8 >= DevicePool::kChunkedMin && g_pool.chunked_available && g_pool.alloc_chunked(b->device, bytes + bytes / 8, &p, &cap))) {
+                if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); break; }
+                cap = bytes;
+            }
+            cands.push_back(Cand{p, cap, 0.f});
+            HIP_TRY(hipMemcpyAsync(p, b->d_records, bytes, hipMemcpyDeviceToDevice, b->stream));
+        }
+        size_t best = cands.size();
+        for (size_t i = 0; i < cands.size(); ++i) {
+            b->sargs.records = static_cast<const uint4*>(cands[i].p);
+            SVT_TRY(best_of(2, iters, &cands[i].ms));
+            if (best == cands.size() || cands[i].ms < cands[best].ms) best = i;
+        }
+        if (best != cands.size()) {
+            b->sargs.records = static_cast<const uint4*>(cands[best].p);
+            SVT_TRY(best_of(3, iters, &cands[best].ms));
+        }
+        if (best != cands.size() && cands[best].ms < current * 0.995f) {
+            HIP_TRY(hipStreamSynchronize(b->stream));
+            g_pool.put(b->device, b->d_records, b->cap_records);
+            b->d_records = cands[best].p;
+            b->cap_records = cands[best].cap;
+            current = cands[best].ms;
+            cands[best].p = nullptr;
+        }
+        b->sargs.records = static_cast<const uint4*>(b->d_records);
+    }
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    if (after_ms) *after_ms = current;
+    b->have_results = true;      // (the last pass ran over the kept buffers)
+    restore.done = true;
+    return check_stream_errors(b);
+}
+
+int svt_batch_tune_placement(svt_batch* b, int result_candidates, int record_candidates, float* before_ms, float* after_ms)
+{
+    return guarded([&] { return svt_batch_tune_placement_impl(b, result_candidates, record_candidates, before_ms, after_ms); });
+}
+
+int svt_batch_genotype_timed(svt_batch* b, int iters, float* ms_total)
+{
+    return guarded([&] { return svt_batch_genotype_timed_impl(b, iters, ms_total); });
+}
+
+static int svt_batch_results_impl(svt_batch* b, svt_result* out, uint64_t n_units)
+{
+    if (!b || (!out && n_units)) return fail(SVT_ERR_INVALID, "null argument");
+    if (!b->have_results) return fail(SVT_ERR_STATE, "svt_batch_genotype has not run");
+    if (n_units != b->n_units) return fail(SVT_ERR_INVALID, "results n_units mismatch");
+    HIP_TRY(hipSetDevice(b->device));
+    HIP_TRY(hipStreamSynchronize(b->stream));   // the pass that produced the records
+    SVT_TRY(check_stream_errors(b));
+    return d2h_results(b, out);
+}
+
+int svt_batch_results(svt_batch* b, svt_result* out, uint64_t n_units)
+{
+    return guarded([&] { return svt_batch_results_impl(b, out, n_units); });
+}
+
+uint32_t svt_batch_result_bytes(const svt_batch* b) { return b ? result_bytes(b) : 0u; }
+
+uint64_t svt_batch_result_slots(const svt_batch* b) { return b ? b->out_slots : 0; }
+
+int svt_results_expand96(const svt_result96* in, uint64_t n_records, svt_result* out, uint64_t n_units)
+{
+    return guarded([&]() -> int {
+        if ((n_records && !in) || (n_units && !out)) return fail(SVT_ERR_INVALID, "null argument");
+        Placed placed(n_units);
+        expand96(in, n_records, out, placed);
+        if (placed.bad) return fail(SVT_ERR_INVALID, "svt_results_expand96: a record's unit is beyond n_units");
+        if (!placed.covers(n_units)) return fail(SVT_ERR_INVALID, "svt_results_expand96: the records do not cover every unit exactly once");
+        return SVT_OK;
+    });
+}
+
+int svt_batch_result_order(svt_batch* b, uint32_t n_samples)
+{
+    if (!b) return fail(SVT_ERR_INVALID, "null batch");
+    if (b->layout != kLayoutStream) return fail(SVT_ERR_INVALID, "svt_batch_result_order: canonical records only (not packed evidence)");
+    if (n_samples <= 1) {
+        if (b->sargs.out_samples > 1) b->have_results = false;   // (site-major records are not results in unit order)
+        b->sargs.out_samples = 0;
+        b->sargs.out_sites = 0;
+        return SVT_OK;
+    }
+    if (b->n_units % n_samples) return fail(SVT_ERR_INVALID, "svt_batch_result_order: n_units is not a multiple of n_samples");
+    if (b->sargs.out_samples != n_samples) b->have_results = false;   // (records written in another order are not results of this one)
+    b->sargs.out_samples = n_samples;
+    b->sargs.out_sites = (uint32_t)(b->n_units / n_samples);
+    return SVT_OK;
+}
+
+int svt_batch_device_results(svt_batch* b, svt_result** dev)
+{
+    if (!b || !dev) return fail(SVT_ERR_INVALID, "null argument");
+    *dev = b->out_dev;
+    return SVT_OK;
+}
+
+static int svt_batch_bind_device_results_impl(svt_batch* b, svt_result* dev, uint64_t capacity_bytes, bool have_capacity)
+{
+    if (!b) return fail(SVT_ERR_INVALID, "null batch");
+    if (dev && (reinterpret_cast<uintptr_t>(dev) & 127u)) return fail(SVT_ERR_INVALID, "result buffer must be 128-byte aligned");
+    const uint64_t need = std::max<uint64_t>(b->out_slots, 1) * result_bytes(b);
+    if (dev && have_capacity && capacity_bytes < need)
+        return fail(SVT_ERR_INVALID, "result buffer too small: svt_batch_result_slots(b) * svt_batch_result_bytes(b) = " + std::to_string(need) + " bytes");
+    b->out_dev = dev ? dev : b->d_out;
+    b->sargs.out = b->out_dev;
+    b->pargs.out = b->out_dev;
+    b->bound_slots = dev ? (have_capacity ? capacity_bytes / result_bytes(b) : b->out_slots) : 0;   // what a later pass may write
+    b->have_results = false;
+
+    return SVT_OK;
+}
+
+int svt_batch_bind_device_results(svt_batch* b, svt_result* dev)
+{
+    return guarded([&] { return svt_batch_bind_device_results_impl(b, dev, 0, false); });
+}
+
+int svt_batch_bind_device_results2(svt_batch* b, void* dev, uint64_t capacity_bytes)
+{
+    return guarded([&] { return svt_batch_bind_device_results_impl(b, static_cast<svt_result*>(dev), capacity_bytes, true); });
+}
+
+int svt_batch_bytes(const svt_batch* b, uint64_t* algorithmic, uint64_t* resident)
+{
+    if (!b) return fail(SVT_ERR_INVALID, "null batch");
+    if (algorithmic) *algorithmic = 16 * b->n_records + (16 + 96) * b->n_units;
+    if (resident) *resident = b->layout == kLayoutPacked ? 16 * b->n_slots + (12 + 16) * b->n_units
+                                                         : 16 * b->n_records + (8 + 16) * b->n_units;
+    return SVT_OK;
+}
+
+int svt_batch_layout(const svt_batch* b, int* compact, int* table_mode)
+{
+    if (!b) return fail(SVT_ERR_INVALID, "null batch");
+    if (compact) *compact = b->layout;
+    if (table_mode) *table_mode = b->mode;
+    return SVT_OK;
+}
+
+static int svt_batch_site_qual_impl(svt_batch* b, uint32_t n_samples, const double* initial, double* qual_out, uint64_t n_sites)
+{
+    if (!b || (!qual_out && n_sites)) return fail(SVT_ERR_INVALID, "null argument");
+    if (!b->have_results) return fail(SVT_ERR_STATE, "svt_batch_genotype has not run");
+    if (n_samples == 0 || n_sites * n_samples != b->n_units) return fail(SVT_ERR_INVALID, "n_sites * n_samples != n_units");
+    // the records of a sample-major batch were written site-major for out_samples samples per site: QUAL over groups of
+    // another size would silently sum the wrong records
+    if (b->layout == kLayoutStream && b->sargs.out_samples > 1 && n_samples != b->sargs.out_samples)
+        return fail(SVT_ERR_INVALID, "svt_batch_site_qual: n_samples differs from the batch's svt_batch_result_order");
+    if (n_sites == 0) return SVT_OK;
+    HIP_TRY(hipSetDevice(b->device));
+    SVT_TRY(check_stream_errors(b));   // (after svt_batch_genotype(b, 0) / _n nobody has looked at the contract word yet)
+    DevScratch d_init, d_qual, d_entries, d_flag;
+    SVT_TRY(d_qual.alloc(n_sites * sizeof(double)));
+    if (initial) {
+        SVT_TRY(d_init.alloc(n_sites * sizeof(double)));
+        Stager st(b->stream);
+        SVT_TRY(st.copy(d_init.p, initial, n_sites * sizeof(double)));
+        SVT_TRY(st.finish());
+    }
+    if (b->flags & SVT_FLAG_RESULT96) {
+        // tagged records lie in the kernel's order, not site by site: SQ and GT of every slot go where its tag says (16 bytes per
+        // unit of device scratch), then the same running sum over a site's entries (svt_bayes_kernel.h) -- nothing but the
+        // QUAL values crosses PCIe (this used to bring every record down: 2 GB and 0.6 s for the 16 M units of configs[4])
+        SVT_TRY(d_entries.alloc(b->n_units * sizeof(QualEntry)));
+        SVT_TRY(d_flag.alloc(sizeof(uint32_t)));
+        HIP_TRY(hipMemsetAsync(d_flag.p, 0, sizeof(uint32_t), b->stream));
+        hipLaunchKernelGGL(svt_site_qual_scatter_kernel, dim3((unsigned)((b->out_slots + kBlock - 1) / kBlock)), dim3(kBlock), 0, b->stream,
+                           reinterpret_cast<const svt_result96*>(b->out_dev), b->out_slots, b->n_units, d_entries.as<QualEntry>(), d_flag.as<uint32_t>());
+        HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(svt_site_qual_entries_kernel, dim3((unsigned)((n_sites + kBlock - 1) / kBlock)), dim3(kBlock), 0, b->stream,
+                           d_entries.as<QualEntry>(), n_samples, initial ? d_init.as<double>() : nullptr, d_qual.as<double>(), n_sites);
+        HIP_TRY(hipGetLastError());
+        uint32_t bad = 0;
+        SVT_TRY(d2h_staged(&bad, d_flag.p, sizeof bad, b->stream));
+        if (bad) return fail(SVT_ERR_INTERNAL, "svt_batch_site_qual: a result record carries a unit beyond the batch");
+        return d2h_staged(qual_out, d_qual.p, n_sites * sizeof(double), b->stream);
+    }
+    hipLaunchKernelGGL(svt_site_qual_kernel, dim3((unsigned)((n_sites + kBlock - 1) / kBlock)), dim3(kBlock), 0, b->stream,
+                       reinterpret_cast<const unsigned char*>(b->out_dev), (uint32_t)sizeof(svt_result), (uint32_t)offsetof(svt_result, gt), n_samples,
+                       initial ? d_init.as<double>() : nullptr, d_qual.as<double>(), n_sites);
+    HIP_TRY(hipGetLastError());
+    return d2h_staged(qual_out, d_qual.p, n_sites * sizeof(double), b->stream);
+}
+
+int svt_batch_site_qual(svt_batch* b, uint32_t n_samples, const double* initial, double* qual_out, uint64_t n_sites)
+{
+    return guarded([&] { return svt_batch_site_qual_impl(b, n_samples, initial, qual_out, n_sites); });
+}
+
