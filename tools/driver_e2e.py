@@ -9,6 +9,33 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
+if "--r05-workload" in sys.argv:
+    # the workload profiles/r05_multisample_e2e.txt was measured on (146 k units/s through round 5's per-line driver): 8 BAMs of
+    # tests/test_native_reads.py::_synthetic_bam (900 pairs around four sites, two libraries each), the five-line VCF of
+    # tests/test_library_groups.py x 2000 = 10 000 variant lines (8 000 sites: a BND pair is two lines) x 8 samples
+    import io
+    import tempfile
+    import time
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import test_library_groups as G
+    from svtyper_amd import classic
+    with tempfile.TemporaryDirectory() as tmp:
+        import pathlib
+        paths, libs = G.cohort(pathlib.Path(tmp), 8, 900)
+        text = G.vcf_text(2000)
+        for bulk in ("1", "0"):
+            os.environ["SVT_BULK_VCF"] = bulk
+            best = None
+            for _ in range(3):
+                out = G.Sink()
+                t0 = time.perf_counter()
+                classic.sv_genotype(",".join(paths), io.StringIO(text), out, 20, 1, 1, 1000000, libs, False, None, None, False, None, 1e10)
+                dt = time.perf_counter() - t0
+                best = dt if best is None else min(best, dt)
+            print("8 samples x 10000 variant lines (8000 sites, 64000 units) | %s route: %.3f s wall = %.0f lines/s, %.0f units/s (r05 counted lines x samples: %.0f)"
+                  % ("bulk" if bulk == "1" else "per-line", best, 10000 / best, 64000 / best, 80000 / best), flush=True)
+    sys.exit(0)
+
 legs = bench.driver_legs()
 print(json.dumps(legs, indent=1))
 if "--trace" in sys.argv:
