@@ -46,7 +46,7 @@ def test_the_sanitizer_reports_through_this_setup(asan_env):
 def test_host_side_tests_under_asan_and_ubsan(asan_env):
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "not gpu", "-p", "no:cacheprovider",
                         "tests/test_native_reads.py", "tests/test_packed_evidence.py", "tests/test_cpp_helpers.py",
-                        "tests/test_host_entries.py"], cwd=ROOT, env=asan_env, capture_output=True, text=True, timeout=1500)
+                        "tests/test_host_entries.py", "tests/test_bulk_vcf.py"], cwd=ROOT, env=asan_env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-3000:])
     assert " passed" in r.stdout and "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr
 
