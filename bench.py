@@ -1007,7 +1007,7 @@ def main():
         gather = {"bytes_per_rank": int(cur), "record_bytes": rec_bytes, "ms": g_s * 1e3,
                   "GB/s_into_root": sum(g_sizes[1:] or g_sizes) / g_s / 1e9,
                   "collective": "rccl gather" if backend == "nccl" else "gloo gather (ranks share %d device(s))" % n_dev,
-                  "backend": backend, "units_per_rank": counts,
+                  "route": D.gather_route(), "backend": backend, "units_per_rank": counts,
                   # how many ranks the RCCL communicator of this run actually spanned (0: no RCCL in this run)
                   "rccl_ranks": dist.get_world_size() if backend == "nccl" else 0}
         if rank == 0 and args.scaling == "strong" and total is not None:

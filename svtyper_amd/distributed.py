@@ -57,7 +57,7 @@ def gather_bytes(local, sizes: List[int], dst: int = 0):
     rank = dist.get_rank()
     if local.numel() != sizes[rank]:
         raise ValueError("rank %d holds %d bytes, the sizes say %d" % (rank, local.numel(), sizes[rank]))
-    if os.environ.get("SVT_GATHER") == "collective":
+    if os.environ.get("SVT_GATHER") == "collective" or not _p2p_usable(local.device, dst):
         return _gather_bytes_collective(local, sizes, dst)
     if rank != dst:
         if sizes[rank]:
@@ -74,6 +74,43 @@ def gather_bytes(local, sizes: List[int], dst: int = 0):
     for req in reqs:
         req.wait()
     return out
+
+
+_P2P_OK = None
+
+
+def _p2p_usable(device, dst: int) -> bool:
+    """Once per process: one byte from every rank to `dst` over the same batched point-to-point calls; the ranks agree
+    (all-reduce, minimum) on whether that worked, so that a backend that cannot do it sends EVERY rank to the collective route
+    instead of leaving some of them behind."""
+    global _P2P_OK
+    if _P2P_OK is None:
+        import torch
+        import torch.distributed as dist
+        ok = 1
+        try:
+            rank, world = dist.get_rank(), dist.get_world_size()
+            if rank == dst:
+                box = torch.zeros(max(world, 1), dtype=torch.uint8, device=device)
+                ops = [dist.P2POp(dist.irecv, box[r:r + 1], r) for r in range(world) if r != dst]
+            else:
+                ops = [dist.P2POp(dist.isend, torch.ones(1, dtype=torch.uint8, device=device), dst)]
+            for req in (dist.batch_isend_irecv(ops) if ops else []):
+                req.wait()
+        except Exception:
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32, device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        _P2P_OK = bool(int(flag.item()))
+    return _P2P_OK
+
+
+def gather_route() -> str:
+    """which route gather_bytes takes in this process: point-to-point into one buffer, or the padded collective"""
+    import os
+    if os.environ.get("SVT_GATHER") == "collective" or _P2P_OK is False:
+        return "padded dist.gather + concatenation"
+    return "point-to-point into one buffer"
 
 
 def _gather_bytes_collective(local, sizes: List[int], dst: int = 0):

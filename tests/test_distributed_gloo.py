@@ -18,8 +18,10 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out_path, scenario="c3"):
+def _worker(rank, world, port, out_path, scenario="c3", route=""):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
+    if route:
+        os.environ["SVT_GATHER"] = route
     os.environ["MASTER_PORT"] = str(port)
     sys.path.insert(0, ROOT)
     import torch
@@ -45,6 +47,7 @@ def _worker(rank, world, port, out_path, scenario="c3"):
     local = c_oracle.genotype_batch(shard, n_threads=1)
     t = torch.from_numpy(local.rec.view(np.uint8).copy())
     gathered = D.gather_result_records(t, [b[1] - b[0] for b in bounds], dst=0)
+    assert D.gather_route() == ("padded dist.gather + concatenation" if route == "collective" else "point-to-point into one buffer")
     if rank == 0:
         got = D.results_from_bytes(gathered)
         want = c_oracle.genotype_batch(batch, n_threads=1)
@@ -55,11 +58,14 @@ def _worker(rank, world, port, out_path, scenario="c3"):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("scenario", ["c3", "c5", "empty"])
-def test_two_rank_shard_and_gather(tmp_path, scenario):
+@pytest.mark.parametrize("scenario,world,route", [("c3", 2, ""), ("c5", 2, ""), ("empty", 2, ""), ("c3", 3, ""), ("c3", 2, "collective"),
+                                                  ("empty", 2, "collective")])
+def test_shard_and_gather_over_gloo(tmp_path, scenario, world, route):
+    """every rank's records onto rank 0: point-to-point into one preallocated buffer (the default), or the padded collective
+    (SVT_GATHER=collective, also what the ranks agree to fall back to when the backend cannot do the first): same bytes"""
     import torch.multiprocessing as mp
     out = str(tmp_path / "result.txt")
-    mp.spawn(_worker, args=(2, _free_port(), out, scenario), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), out, scenario, route), nprocs=world, join=True)
     assert open(out).read() == "ok"
 
 
