@@ -713,11 +713,22 @@ def driver_legs() -> dict:
     text_in = "".join(head) + "".join(body * 100)
     bam_path, lib_json = os.path.join(data, "NA12878.target_loci.sorted.bam"), os.path.join(data, "NA12878.bam.json")
 
+    laps = {}
+
     def sso():
         sink = Sink()
-        singlesample.sso_genotype(bam_path, io.StringIO(text_in), sink, 20, 1, 1, 1000000, lib_json, False, None, False, 1000, 1e10, None, 1000)
+        laps.clear()
+        singlesample.sso_genotype(bam_path, io.StringIO(text_in), sink, 20, 1, 1, 1000000, lib_json, False, None, False, 1000, 1e10, None, 1000,
+                                  stats=laps)
         return sink.getvalue()
+
+    def host_stages():
+        """the caller's thread by stage (ms; pipeline.BulkFeeder.laps of the last call): what replaced `site_arrays_python` + `format_columns_host`"""
+        return {"route": laps.get("route"), "blocks": laps.get("blocks"), "lines_handed_back_to_python": laps.get("lines_handed_back"),
+                "vcf_parse_ms": laps.get("vcf_parse_s", 0.0) * 1e3, "site_arrays_ms": laps.get("site_arrays_s", 0.0) * 1e3,
+                "vcf_emit_ms": laps.get("vcf_emit_s", 0.0) * 1e3, "decode_write_ms": laps.get("decode_write_s", 0.0) * 1e3}
     wall, text = timed(sso)
+    sso_stages = host_stages()
     pl_wall, pl_text = per_line(sso)
     with open(os.path.join(data, "example.gt.vcf")) as f:
         want = [l for l in strip(f.read()) if l and not l.startswith("#")]
@@ -725,7 +736,7 @@ def driver_legs() -> dict:
     n = len(body) * 100
     out["driver_sso"] = {"what": "singlesample.sso_genotype(<the reference's 15 positional arguments>) over tests/data/example.vcf's %d variant lines x 100" % len(body),
                          "variant_lines": n, "wall_ms": wall * 1e3, "sites_per_s": n / wall, "vcf_bytes_out": len(text),
-                         "every_repeat_equals_example_gt_vcf": bool(got == want * 100),
+                         "every_repeat_equals_example_gt_vcf": bool(got == want * 100), "host_stage_ms": sso_stages,
                          "per_line_route": {"wall_ms": pl_wall * 1e3, "sites_per_s": n / pl_wall, "same_bytes": strip(pl_text) == strip(text)}}
     with tempfile.TemporaryDirectory() as tmp:
         paths, info, sites = [], {}, None
@@ -744,15 +755,17 @@ def driver_legs() -> dict:
 
         def joint():
             sink = Sink()
-            classic.sv_genotype(",".join(paths), io.StringIO(vtext), sink, 20, 1, 1, 1000000, libs, False, None, None, False, None, 1e10)
+            laps.clear()
+            classic.sv_genotype(",".join(paths), io.StringIO(vtext), sink, 20, 1, 1, 1000000, libs, False, None, None, False, None, 1e10, stats=laps)
             return sink.getvalue()
         wall, text = timed(joint)
+        joint_stages = host_stages()
         pl_wall, pl_text = per_line(joint)
         n = len(vlines) * reps
         called = sum(1 for l in text.split("\n") if l and not l.startswith("#") and ("\t0/0:" in l or "\t0/1:" in l or "\t1/1:" in l))
         out["driver_classic_8bam"] = {"what": "classic.sv_genotype(<the reference's 14 positional arguments>), 8 BAMs (300 kbp at 30x each) x %d DEL lines" % n,
                                       "variant_lines": n, "samples": 8, "units": n * 8, "wall_ms": wall * 1e3, "sites_per_s": n / wall,
-                                      "units_per_s": n * 8 / wall, "vcf_bytes_out": len(text), "lines_with_a_called_genotype": called,
+                                      "units_per_s": n * 8 / wall, "vcf_bytes_out": len(text), "lines_with_a_called_genotype": called, "host_stage_ms": joint_stages,
                                       "per_line_route": {"wall_ms": pl_wall * 1e3, "units_per_s": n * 8 / pl_wall, "same_bytes": strip(pl_text) == strip(text)}}
     return out
 

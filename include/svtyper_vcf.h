@@ -77,7 +77,7 @@ typedef struct svt_vcf_view {
     const int64_t* pos_b;
     const int64_t* ci;           /* n_sites * 4: A lo, A hi, B lo, B hi                                         */
     const int64_t* var_length;   /* DEL: END - POS; 0 otherwise                                                 */
-    const uint8_t* svtype;       /* SVT_DEL / SVT_DUP / SVT_INV / SVT_BND                                       */
+    const uint8_t* svtype;       /* SVT_SVTYPE_DEL / _DUP / _INV / _BND (svtyper_hip.h)                           */
     const uint8_t* strands;      /* bit 0: side A reverse, bit 1: side B reverse                                */
     const double* qual_in;       /* QUAL the site starts from                                                   */
 } svt_vcf_view;

@@ -66,7 +66,7 @@ def apply_result(var: Variant, sample_name: str, gt: int, res: dict) -> None:
 
 def sv_genotype(bam_string, vcf_in, vcf_out, min_aligned, split_weight, disc_weight, num_samp, lib_info_path,
                 debug, alignment_outpath, ref_fasta, sum_quals, max_reads, max_ci_dist, *, engine=None, geometry="host",
-                reader=None):
+                reader=None, stats=None):
     if alignment_outpath is not None:
         raise NotImplementedError("-w/--write_alignment (evidence BAM dump) is outside the MI355X hot path build")
     reader = resolve_reader(reader)
@@ -218,6 +218,7 @@ def sv_genotype(bam_string, vcf_in, vcf_out, min_aligned, split_weight, disc_wei
     # bulk route (reader="native"): blocks of lines -> breakpoint arrays -> output text in native calls (bulk_vcf.py); lines
     # it hands back, and everything once it stops in front of a BND line it cannot express, take the per-line route above
     bulk = None
+    bulk_stats = None
     unpaired = False        # first BND mates left in the bulk parser at the end
     if (reader == "native" and not debug and hasattr(vcf_in, "readline") and hasattr(vcf_in, "read")
             and os.environ.get("SVT_BULK_VCF", "1") != "0"):
@@ -258,9 +259,12 @@ def sv_genotype(bam_string, vcf_in, vcf_out, min_aligned, split_weight, disc_wei
                     per_line(vcf_in)
                 else:
                     unpaired = feeder.n_pending() > 0
+                bulk_stats = (feeder.laps, "bulk" if rest is None else "bulk, then per line")
 
     flush()
     pipe.close()
+    if stats is not None:       # (keyword-only extra: where the caller's thread spent its time, pipeline.BulkFeeder.laps)
+        stats.update(bulk_stats[0] if bulk_stats else {}, route=bulk_stats[1] if bulk_stats else "per line")
     if vcf._bnd_pending or unpaired:
         logging.warning("Unpaired breakends found in file. These will not be present in output.")
     vcf_in.close()

@@ -560,6 +560,10 @@ class BulkFeeder:
         self._n_samp, self._fast, self._qual_mode = n_samples, fast, qual_mode
         self._handle_line, self._render_actions, self._write = handle_line, render_actions, write
         self._skipped_as_dots = qual_mode == bulk.QUAL_CLASSIC
+        # seconds on the caller's thread, by stage (the drivers' `stats=` dict gets them): the native parse (+ encode), the
+        # per-line code for lines handed back, the site arrays per sample (collector.take), the native emit, decode + write
+        self.laps = {"blocks": 0, "lines": 0, "sites": 0, "lines_handed_back": 0, "vcf_parse_s": 0.0, "per_line_python_s": 0.0,
+                     "site_arrays_s": 0.0, "vcf_emit_s": 0.0, "decode_write_s": 0.0}
 
     def n_pending(self) -> int:
         return len(self.pending_lines())
@@ -580,8 +584,11 @@ class BulkFeeder:
         import numpy as np
         bulk = self._bulk
         enc = bulk.TEXT_ENCODING
+        laps = self.laps
+        t0 = time.perf_counter()
         raw = text.encode(*enc)
         chunk, used = self._parser.parse(raw)
+        t1 = time.perf_counter()
         n_bulk_units = chunk.n_sites * self._n_samp
         if chunk.n_sites:
             self._collector.add_site_arrays(chunk.sites)
@@ -591,7 +598,16 @@ class BulkFeeder:
             action = self._handle_line(raw[begin[i]:begin[i + 1]].decode(*enc), n_bulk_units)
             if action is not None:
                 actions.append((i, action))
+        t2 = time.perf_counter()
         job = self._collector.take(self._engine, self._flags)
+        t3 = time.perf_counter()
+        laps["blocks"] += 1
+        laps["lines"] += chunk.n_lines
+        laps["sites"] += chunk.n_sites
+        laps["lines_handed_back"] += len(actions)
+        laps["vcf_parse_s"] += t1 - t0
+        laps["per_line_python_s"] += t2 - t1
+        laps["site_arrays_s"] += t3 - t2
         self._pipe.submit(job, lambda results: self._write_block(chunk, actions, results))
         return None if used == len(raw) else split_lines(raw[used:].decode(*enc))
 
@@ -600,11 +616,15 @@ class BulkFeeder:
         bulk = self._bulk
         enc = bulk.TEXT_ENCODING
         fast = self._fast
+        t0 = time.perf_counter()
         text, off = chunk.emit(results, self._n_samp, self._qual_mode, fast.fields, self._skipped_as_dots, fast.format_string)
+        t1 = time.perf_counter()
+        self.laps["vcf_emit_s"] += t1 - t0
         if not actions:
             if text:
                 self._write(text.decode(*enc))
             chunk.close()
+            self.laps["decode_write_s"] += time.perf_counter() - t1
             return
         # lines handed back sit between the sites' lines: sites_before[i] = sites written by lines in front of line i
         sites_before = np.concatenate([[0], np.cumsum(chunk.line_kind == bulk.LINE_SITE)])

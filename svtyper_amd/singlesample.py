@@ -128,7 +128,7 @@ def assign_genotype(variant: Variant, sample_name: str, res: dict) -> None:
 
 def sso_genotype(bam_string, vcf_in, vcf_out, min_aligned, split_weight, disc_weight, num_samp, lib_info_path,
                  debug, ref_fasta, sum_quals, max_reads, max_ci_dist, cores, batch_size, *, engine=None, geometry="host",
-                 reader=None):
+                 reader=None, stats=None):
     if vcf_in is None:
         return
     reader = resolve_reader(reader)
@@ -286,6 +286,7 @@ def sso_genotype(bam_string, vcf_in, vcf_out, min_aligned, split_weight, disc_we
             if len(collector) >= CHUNK_UNITS:
                 flush()
 
+    bulk_stats = None
     if bulk is None:
         per_line(lines)
     else:
@@ -311,8 +312,11 @@ def sso_genotype(bam_string, vcf_in, vcf_out, min_aligned, split_weight, disc_we
             per_line(rest)
             for block in source:
                 per_line(split_lines(block))
+        bulk_stats = (feeder.laps, "bulk" if rest is None else "bulk, then per line")
     flush()
     pipe.close()
+    if stats is not None:       # (keyword-only extra: where the caller's thread spent its time, pipeline.BulkFeeder.laps)
+        stats.update(bulk_stats[0] if bulk_stats else {}, route=bulk_stats[1] if bulk_stats else "per line")
     sample.close()
 
 

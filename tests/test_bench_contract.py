@@ -41,6 +41,8 @@ def test_bench_line_has_the_contract_keys(hip_device):
     for key, rate in (("driver_sso", "sites_per_s"), ("driver_classic_8bam", "units_per_s")):
         leg = d["real_data"][key]
         assert leg[rate] > 0 and leg["per_line_route"]["same_bytes"] is True
+        st = leg["host_stage_ms"]
+        assert st["route"] == "bulk" and st["lines_handed_back_to_python"] == 0 and st["vcf_parse_ms"] > 0 and st["vcf_emit_ms"] > 0
     assert d["real_data"]["driver_sso"]["every_repeat_equals_example_gt_vcf"] is True
     assert d["value"] > 0 and abs(d["value"] - 30000 * 3 / (d["ms_per_step"] * 3 * 1e-3)) / d["value"] < 1e-6
     assert d["parity"]["integer_mismatches"] == 0 and d["parity"]["max_abs_dGL"] <= 1e-6 and d["parity"]["max_abs_dSQ"] <= 1e-6
