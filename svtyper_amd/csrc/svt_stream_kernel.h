@@ -215,10 +215,10 @@ struct WindowCtx {
     uint32_t lib_lo;       // first library of the workgroup's window
     uint32_t lib_last;     // libraries in the window - 1
     uint32_t winlibs_at;   // LDS byte address of the window's WinLib descriptors
-    uint32_t vl_or_never;  // DEL ? var_length : 0x80000000 - key_min is added per library
+    uint32_t vl_or_never;  // DEL ? var_length : 0x80000000 -- key_min is added per library (never in range for the latter)
     uint32_t wt0, wt1;
     uint32_t wh0;          // LDS address of w_alt_hi[del16]
-    uint32_t gated;        // bit l: the small-deletion gate of classic.py:339,383 is closed for the window's l-th library (DEL and
+    uint32_t gated;        // bit l CLEAR: the small-deletion gate of classic.py:339,383 is closed for the window's l-th library (DEL and
                            // pos_delta < 2 sd of that library) -- per unit and library, so it is formed once per unit, not per record
     bool is_del;
 };
@@ -234,9 +234,12 @@ __device__ __forceinline__ void record_window(const u32x4 w, const bool mine, co
     check.window_lib(EDGE && !mine ? 0u : SVT_REC_LIB(w.w) - c.lib_lo);
     const uint32_t la = c.winlibs_at + min(SVT_REC_LIB(w.w) - c.lib_lo, c.lib_last) * (uint32_t)sizeof(WinLib);
     const u32x4 d = *reinterpret_cast<lds_cu32x4*>((size_t)la);          // kmin, nb, thr_at, hist_at
-    const bool small_del = ((c.gated >> min(SVT_REC_LIB(w.w) - c.lib_lo, c.lib_last)) & 1u) != 0u;   // classic.py:339,383
-    const uint32_t f3 = small_del ? 0u : (w.w & 7u);
-    const uint32_t sub2 = c.is_del ? c.vl_or_never + d.x : 0x80000000u;
+    // the small-deletion gate (classic.py:339,383) as an all-ones / all-zeros word from one signed bit-field extract of the
+    // unit's `open` bits; no select on is_del: for another svtype vl_or_never is 0x80000000 and o - (0x80000000 + key_min)
+    // lies at or above 0x7fff0000 for every span the contract allows, i.e. in the sentinel bin as before
+    const uint32_t open = (uint32_t)__builtin_amdgcn_sbfe((int32_t)c.gated, min(SVT_REC_LIB(w.w) - c.lib_lo, c.lib_last), 1u);
+    const uint32_t f3 = w.w & 7u & open;
+    const uint32_t sub2 = c.vl_or_never + d.x;
     const uint32_t i1 = min(w.x - d.x, d.y), i2 = min(w.x - sub2, d.y);
     const int32_t thr1 = lds_i16(d.z + (i1 << 1));
     const uint32_t h2 = lds_u16(d.w + (i2 << 1));
@@ -454,7 +457,7 @@ __global__ __launch_bounds__(kBlock, MODE == kSingleLds ? SVT_STREAM_WAVES : MOD
         wc.lib_lo = wd.lib_lo;
         wc.lib_last = wd.lib_cnt - 1u;
         wc.winlibs_at = a.lds_winlibs;
-        wc.vl_or_never = (uint32_t)U.var_length;
+        wc.vl_or_never = c.is_del ? (uint32_t)U.var_length : 0x80000000u;
         wc.wt0 = sc.wt0;
         wc.wt1 = sc.wt1;
         wc.wh0 = sc.wh0;
@@ -464,6 +467,7 @@ __global__ __launch_bounds__(kBlock, MODE == kSingleLds ? SVT_STREAM_WAVES : MOD
             for (uint32_t l = 0; l < wd.lib_cnt; ++l)
                 wc.gated |= (c.pos_delta_d < reinterpret_cast<const WinLib*>(smem + a.lds_winlibs)[l].sd2 ? 1u : 0u) << l;
         }
+        wc.gated = ~wc.gated;      // (read as `open` bits by record_window)
         Acc acc = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
 
         // EDGE = false: every lane's eight records of this block are its own
