@@ -466,12 +466,14 @@ bool left_clipped(const Cigar& c)
     return (lc && !rc) || (lc && rc && c.front().second > c.back().second);
 }
 
-bool parse_cigar_string(const std::string& s, Cigar& out)
+bool parse_cigar_string(const char* s, size_t n, Cigar& out)
 {
     static const char* ops = "MIDNSHP=X";
     int64_t num = 0;
     bool have = false;
-    for (char ch : s) {
+    for (size_t i = 0; i < n; ++i) {
+        const char ch = s[i];
+        if (ch == 0) return false;      // (strchr would find the terminator of `ops`)
         if (ch >= '0' && ch <= '9') { num = num * 10 + (ch - '0'); have = true; continue; }
         const char* p = std::strchr(ops, ch);
         if (!p || !have) return false;
@@ -490,8 +492,8 @@ struct Piece {
     int64_t start = 0, end = 0;
     bool reverse = false;
     int64_t mapq = 0;
-    Cigar cigar;
-    QueryPos qp;
+    const Cigar* cigar = nullptr;   // not owned: the record's own operations, or split_candidate's scratch for an SA entry --
+    QueryPos qp;                    // a piece is copied around (left / right) and lives only until its PieceOut is taken
 };
 
 struct ReadInfo {                // what a primary read contributes to a summary (svt_read_summary)
@@ -795,8 +797,8 @@ int split_candidate(const svt_bam& bam, const Record& r, Split& out, const char*
     a.end = r.end;
     a.reverse = (r.flag & 0x10) != 0;
     a.mapq = r.mapq;
-    a.cigar = r.cigar;
-    a.qp = query_pos_from_cigar(a.cigar, a.reverse);
+    a.cigar = &r.cigar;
+    a.qp = query_pos_from_cigar(*a.cigar, a.reverse);
     if (!sa) {
         const bool fc = is_clip(r.cigar.front().first), lc = is_clip(r.cigar.back().first);
         if (!(fc || lc)) return 0;
@@ -810,51 +812,66 @@ int split_candidate(const svt_bam& bam, const Record& r, Split& out, const char*
             dummy.end = 1;
             dummy.reverse = a.reverse;
             dummy.mapq = 0;
-            dummy.cigar = r.cigar;
-            dummy.qp = query_pos_from_cigar(dummy.cigar, dummy.reverse);
+            dummy.cigar = &r.cigar;
+            dummy.qp = query_pos_from_cigar(*dummy.cigar, dummy.reverse);
             out.soft = true;
-            if (left_clipped(a.cigar)) { out.left = dummy; out.right = a; }
+            if (left_clipped(*a.cigar)) { out.left = dummy; out.right = a; }
             else { out.left = a; out.right = dummy; }
             return 1;
         }
         return 0;
     }
-    // SA:Z:chrom,pos,strand,CIGAR,mapQ,NM;...   more than one entry -> discarded (:992-993)
-    std::string s(sa);
-    while (!s.empty() && s.back() == ';') s.pop_back();
-    if (s.find(';') != std::string::npos) return 0;
-    std::vector<std::string> fld;
-    size_t p0 = 0;
-    for (;;) {
-        const size_t p1 = s.find(',', p0);
-        fld.push_back(s.substr(p0, p1 == std::string::npos ? std::string::npos : p1 - p0));
-        if (p1 == std::string::npos) break;
+    // SA:Z:chrom,pos,strand,CIGAR,mapQ,NM;...   more than one entry -> discarded (:992-993).  Fields are cut in place (no
+    // string per field: a read with an SA tag used to cost a dozen allocations here)
+    size_t len = std::strlen(sa);
+    while (len && sa[len - 1] == ';') --len;
+    if (std::memchr(sa, ';', len)) return 0;
+    const char* fb[8];
+    size_t fl[8];
+    size_t n_fld = 0;
+    for (size_t p0 = 0;;) {
+        const char* c = static_cast<const char*>(std::memchr(sa + p0, ',', len - p0));
+        const size_t p1 = c ? (size_t)(c - sa) : len;
+        if (n_fld < 8) { fb[n_fld] = sa + p0; fl[n_fld] = p1 - p0; }
+        ++n_fld;
+        if (!c) break;
         p0 = p1 + 1;
     }
-    if (fld.size() < 5) return -1;
-    char* endp = nullptr;
-    const long long mate_pos1 = std::strtoll(fld[1].c_str(), &endp, 10);
-    if (*endp || fld[1].empty()) return -1;
-    const long long mate_mapq = std::strtoll(fld[4].c_str(), &endp, 10);
-    if (*endp || fld[4].empty()) return -1;
+    if (n_fld < 5) return -1;
+    auto whole_number = [](const char* b, size_t n, long long& v) {      // strtoll over the whole field, as before
+        char buf[32];
+        if (n == 0 || n >= sizeof buf) return false;
+        std::memcpy(buf, b, n);
+        buf[n] = 0;
+        char* endp = nullptr;
+        v = std::strtoll(buf, &endp, 10);
+        return *endp == 0;
+    };
+    long long mate_pos1 = 0, mate_mapq = 0;
+    if (!whole_number(fb[1], fl[1], mate_pos1)) return -1;
+    if (!whole_number(fb[4], fl[4], mate_mapq)) return -1;
     Piece b;
-    auto it = bam.tid_of.find(fld[0]);
+    const std::string sa_chrom(fb[0], fl[0]);          // (chromosome names fit the small-string buffer)
+    auto it = bam.tid_of.find(sa_chrom);
     b.tid = it == bam.tid_of.end() ? -3 : it->second;
     b.start = mate_pos1 - 1;
-    b.reverse = fld[2] == "-";
-    if (!parse_cigar_string(fld[3], b.cigar)) return -1;
+    b.reverse = fl[2] == 1 && fb[2][0] == '-';
+    static thread_local Cigar sa_cigar;                // the SA entry's operations: scratch of this thread, alive while `out` is read
+    sa_cigar.clear();
+    if (!parse_cigar_string(fb[3], fl[3], sa_cigar)) return -1;
+    b.cigar = &sa_cigar;
     b.mapq = mate_mapq;
     b.end = b.start;
-    for (const auto& c : b.cigar) if (consumes_ref(c.first)) b.end += c.second;
-    b.qp = query_pos_from_cigar(b.cigar, b.reverse);
-    const bool same_chrom = r.tid >= 0 && bam.ref_names[r.tid] == fld[0];
+    for (const auto& c : sa_cigar) if (consumes_ref(c.first)) b.end += c.second;
+    b.qp = query_pos_from_cigar(sa_cigar, b.reverse);
+    const bool same_chrom = r.tid >= 0 && bam.ref_names[r.tid] == sa_chrom;
     out.soft = false;
     if (same_chrom) {
         if (r.pos > b.start) { out.left = b; out.right = a; }
         else { out.left = a; out.right = b; }
-    } else if (a.cigar.empty()) {
+    } else if (a.cigar->empty()) {
         return -1;
-    } else if (left_clipped(a.cigar)) {
+    } else if (left_clipped(*a.cigar)) {
         out.left = b; out.right = a;
     } else {
         out.left = a; out.right = b;
