@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SVT_ABI_VERSION 17
+#define SVT_ABI_VERSION 18
 
 /* ---- error codes (0 = ok, <0 = error; text via svt_last_error()) ---------- */
 #define SVT_OK 0
@@ -108,7 +108,7 @@ typedef struct svt_record {
                           same two gated MAPQs (the dummy piece has MAPQ 0,
                           parsers.py:976-981)                                  */
     uint8_t clip_r;
-    uint32_t flags;    /* SVT_REC_* bits, library index in bits 8..15         */
+    uint32_t flags;    /* SVT_REC_* bits, library index in bits 8..23         */
 } svt_record;
 
 #define SVT_REC_ALT_STRADDLE (1u << 0)   /* is_pair_straddle(A,B,o1,o2) OR, for INV, the
@@ -125,10 +125,14 @@ typedef struct svt_record {
                                             summation order                                */
 #define SVT_REC_HAS_PAIR (1u << 4)       /* num_primary == 2 (parsers.py:827): required by
                                             the three straddle bits                        */
-#define SVT_REC_LIB_SHIFT 8              /* bits 8..15: index into svt_evidence_batch.libs
-                                            (fragment.lib)                                 */
-#define SVT_REC_LIB(flags) (((flags) >> SVT_REC_LIB_SHIFT) & 0xffu)
-#define SVT_REC_FLAG_MASK 0x0000ff1fu    /* every other bit must be 0                      */
+#define SVT_REC_LIB_SHIFT 8              /* bits 8..23: index into svt_evidence_batch.libs
+                                            (fragment.lib).  ABI 18 widened it from eight
+                                            bits (bits 16..23 had to be 0 before, so records
+                                            written for an older library read the same): the
+                                            reference's `-B a.bam,b.bam,...` list is unbounded
+                                            (classic.py:145-158, parsers.py:432-447)        */
+#define SVT_REC_LIB(flags) (((flags) >> SVT_REC_LIB_SHIFT) & 0xffffu)
+#define SVT_REC_FLAG_MASK 0x00ffff1fu    /* every other bit must be 0                      */
 
 /* ---- unit header: one per (breakpoint, sample), 16 B ---------------------- */
 typedef struct svt_unit {
@@ -155,9 +159,12 @@ typedef struct svt_unit {
                            streaming pass on the device, ~0.3 ms per 1.6 GB); only the
                            pipelined one-shot (svt_genotype), which uploads while it
                            runs, then takes the slow general mode.
-                           Upper 16 bits must be 0.                               */
+                           first < 65536, count <= 255; bits 24..31 must be 0.    */
 } svt_unit;
-#define SVT_UNIT_LIBS(first, count) ((uint32_t)(first) | (uint32_t)(count) << 8)
+/* (first's low byte | count << 8 | first's high byte << 16: what ABI <= 17 wrote for first < 256, unchanged) */
+#define SVT_UNIT_LIBS(first, count) (((uint32_t)(first) & 0xffu) | ((uint32_t)(count) & 0xffu) << 8 | (((uint32_t)(first) >> 8) & 0xffu) << 16)
+#define SVT_UNIT_LIBS_FIRST(x) (((uint32_t)(x) & 0xffu) | (((uint32_t)(x) >> 16) & 0xffu) << 8)
+#define SVT_UNIT_LIBS_COUNT(x) (((uint32_t)(x) >> 8) & 0xffu)
 
 #define SVT_UNIT_SKIP (1u << 0) /* too many reads: GT './.' only (classic.py:282-284,
                                    singlesample.py:478-480)                      */
@@ -177,7 +184,7 @@ typedef struct svt_evidence_batch {
     const uint64_t* rec_offset; /* n_units + 1 entries, rec_offset[0] == 0        */
     const svt_unit* units;      /* n_units                                        */
     const svt_record* records;  /* rec_offset[n_units]                            */
-    uint32_t n_libs;            /* 1..256                                         */
+    uint32_t n_libs;            /* 1..65536 (packed evidence: 1..256)             */
     const svt_library* libs;
     double split_weight;        /* --split_weight (classic.py:38)                 */
     double disc_weight;         /* --disc_weight  (classic.py:39)                 */
@@ -224,7 +231,7 @@ typedef struct svt_fragment {
     svt_piece_summary seq[2];   /* valid non-soft-clip candidate: query_left, query_right        */
     svt_piece_summary clip[2];  /* valid soft-clip-only candidate: query_left, query_right       */
 } svt_fragment;
-/* fragment-level bits live in read[0].reserved (low byte = library index) and read[1].reserved */
+/* fragment-level bits live in read[0].reserved (the library index, 16 bits) and read[1].reserved */
 #define SVT_FRAG_PAIR (1u << 0)         /* read[1].reserved: num_primary == 2 (parsers.py:827)   */
 #define SVT_FRAG_CONTINUATION (1u << 1) /* read[1].reserved                                       */
 

@@ -83,7 +83,7 @@ void svt_summaries_free(svt_summaries* s);
  * those of the device stage, byte for byte (tests/test_hip_geometry.py).
  * Here every field of svt_summarise_args.breakpoints is read.                                      */
 typedef struct svt_evidence_params {
-    uint32_t n_libs;           /* 1..256: size of lib_flank; a fragment of a library beyond it is an error */
+    uint32_t n_libs;           /* 1..65536: size of lib_flank; a fragment of a library beyond it is an error */
     const double* lib_flank;   /* per library: mean + 3 sd, is_pair_straddle's flank (parsers.py:846-855)   */
     int32_t min_aligned;       /* -m / --min_aligned (classic.py:34)                                        */
     int32_t split_slop;        /* 3 (classic.py:184)                                                        */

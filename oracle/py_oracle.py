@@ -91,7 +91,7 @@ def tally_unit(unit, recs: Sequence, libs: List[_Lib], sso: bool):
     pos_delta = int(unit["pos_delta"])
     first = True
     for (ospan, mq_a, mq_b, rs_a, rs_b, seq_l, seq_r, clip_l, clip_r, flags) in recs:
-        lib = libs[(flags >> ev.REC_LIB_SHIFT) & 0xFF]
+        lib = libs[(flags >> ev.REC_LIB_SHIFT) & 0xFFFF]
         if sso and not (flags & ev.REC_CONTINUATION):
             if not first:                                            # singlesample.py:370-372
                 ref_seq += l_ref_seq

@@ -92,8 +92,8 @@ int create_stream(const svt_evidence_batch* in, svt_batch* b, void* d_records_re
                 if (f > 0x3FFFFFFFull) p.bad |= 2;
                 const svt_unit& U = in->units[u];
                 if (U.svtype > SVT_SVTYPE_BND) p.bad |= 4;
-                if ((U.libs >> 16) != 0 || (U.flags & ~SVT_UNIT_SKIP)) p.bad |= 8;
-                const uint32_t w_lo = U.libs & 0xffu, w_cnt = (U.libs >> 8) & 0xffu;
+                if ((U.libs >> 24) != 0 || (U.flags & ~SVT_UNIT_SKIP)) p.bad |= 8;
+                const uint32_t w_lo = SVT_UNIT_LIBS_FIRST(U.libs), w_cnt = SVT_UNIT_LIBS_COUNT(U.libs);
                 if (w_cnt && w_lo + w_cnt > in->n_libs) p.bad |= 16;
                 p.hinted = p.hinted && w_cnt != 0;
                 if (U.var_length < -(1 << 30) || U.var_length > (1 << 30)) p.wide = true;
@@ -149,31 +149,40 @@ int create_stream(const svt_evidence_batch* in, svt_batch* b, void* d_records_re
     for (const LibDesc& L : T.libs) all_bins += L.n_bins + 1;
     const bool whole_batch_window = !all_hinted && n > 0 && in->n_libs <= 255 &&
                                     kSBins + all_bins * 4 + in->n_libs * sizeof(WinLib) + 64 + kWavesPerBlock * kStreamRingBytes <= (160 * 1024 / 2);
-    const uint32_t whole_key = in->n_libs << 8;   // SVT_UNIT_LIBS(0, n_libs)
+    const uint32_t whole_key = SVT_UNIT_LIBS(0u, in->n_libs);   // (n_libs <= 255 here)
     const bool may_window = in->n_libs > 1 && T.fast_geometry && !(b->flags & SVT_FLAG_GENERAL_TABLES);
     bool windowed = may_window && (all_hinted || whole_batch_window);
     // No hints and too many libraries for one window: the windows are read off the records themselves, on the device,
     // right after the upload (svt_window_scan_kernel.h) -- not when the caller uploads the records later (pipelined one-shot)
-    const bool derive_windows = may_window && !windowed && n > 0 && in->n_libs <= 255 && T.narrow_bins;
+    const bool derive_windows = may_window && !windowed && n > 0 && T.narrow_bins;
     // (the pipelined one-shot of such a batch: its pass is a few tenths of a millisecond beside tens of milliseconds of upload, so
     // nothing is lost by uploading first and reading the windows -- the general mode it used to take instead runs at a third of
     // the window kernel's speed)
     if (derive_windows) defer_records = false;
     b->records_resident = !defer_records;
-    // group the units by window key (a counting sort: stable, original order inside a group) and cut the groups into chunks
-    auto group_units = [&](auto&& key_of) {
+    // group the units by window (a counting sort on the window's first library: stable, original order inside a group) and cut
+    // the groups into chunks.  `hint_of(u)` = the unit's window as SVT_UNIT_LIBS(first, count).  Units whose windows start at the
+    // same library but differ in length (scanned windows: the units of one sample need not all use its last library) share the
+    // longest of them: a window is what a workgroup STAGES, and the longer one holds every library the shorter ones name.
+    auto group_units = [&](auto&& hint_of) -> bool {
         std::vector<uint32_t> start(65537, 0u);
-        for (uint64_t u = 0; u < n; ++u) ++start[key_of(u) + 1];
+        std::vector<uint16_t> count_of(65536, 0);
+        for (uint64_t u = 0; u < n; ++u) {
+            const uint32_t h = hint_of(u), first = SVT_UNIT_LIBS_FIRST(h), cnt = SVT_UNIT_LIBS_COUNT(h);
+            if (cnt == 0) return false;
+            count_of[first] = std::max(count_of[first], (uint16_t)cnt);
+            ++start[first + 1];
+        }
         for (uint32_t k = 0; k < 65536u; ++k) start[k + 1] += start[k];
         perm.resize(n);
         groups.clear();
         {
             std::vector<uint32_t> at(start.begin(), start.end() - 1);
-            for (uint64_t u = 0; u < n; ++u) perm[at[key_of(u)]++] = (uint32_t)u;
+            for (uint64_t u = 0; u < n; ++u) perm[at[SVT_UNIT_LIBS_FIRST(hint_of(u))]++] = (uint32_t)u;
         }
         for (uint32_t k = 0; k < 65536u; ++k) {
             if (start[k + 1] == start[k]) continue;
-            const uint32_t lo = k & 0xffu, cnt = k >> 8;
+            const uint32_t lo = k, cnt = count_of[k];
             WgDesc w{};
             w.lib_lo = lo;
             w.lib_cnt = cnt;
@@ -183,6 +192,7 @@ int create_stream(const svt_evidence_batch* in, svt_batch* b, void* d_records_re
             max_win_libs = std::max(max_win_libs, w.lib_cnt);
             groups.push_back(Group{start[k], start[k + 1], w});
         }
+        return true;
     };
     // ... and the groups into workgroup chunks of at most `per_chunk` units, the chunks of a group of (nearly) equal size
     auto cut_chunks = [&](const uint32_t per_chunk) {
@@ -198,7 +208,7 @@ int create_stream(const svt_evidence_batch* in, svt_batch* b, void* d_records_re
         }
     };
     if (windowed) {
-        group_units([&](uint64_t u) -> uint32_t { return all_hinted ? in->units[u].libs & 0xffffu : whole_key; });
+        windowed = group_units([&](uint64_t u) -> uint32_t { return all_hinted ? in->units[u].libs : whole_key; });
         tm.mark("group units by library window");
     }
     const uint32_t n_l10 = (uint32_t)T.l10.size();
@@ -262,10 +272,9 @@ int create_stream(const svt_evidence_batch* in, svt_batch* b, void* d_records_re
         // (0: a unit whose libraries lie > 255 apart; a window beyond n_libs: some record names a library the batch does
         // not have -- the general mode reports it as the contract violation it is)
         bool all_seen = true;
-        for (uint64_t u = 0; u < n && all_seen; ++u) all_seen = seen[u] != 0u && (seen[u] & 0xffu) + ((seen[u] >> 8) & 0xffu) <= in->n_libs;
+        for (uint64_t u = 0; u < n && all_seen; ++u) all_seen = seen[u] != 0u && SVT_UNIT_LIBS_FIRST(seen[u]) + SVT_UNIT_LIBS_COUNT(seen[u]) <= in->n_libs;
         if (all_seen) {
-            group_units([&](uint64_t u) -> uint32_t { return seen[u] & 0xffffu; });
-            windowed = true;
+            windowed = group_units([&](uint64_t u) -> uint32_t { return seen[u]; });
             tm.mark("group units by library window");
         }
     }
@@ -282,6 +291,10 @@ int create_stream(const svt_evidence_batch* in, svt_batch* b, void* d_records_re
     // (a window of more than 32 libraries: the kernel keeps one small-deletion gate bit per library of the window in a register)
     windowed = windowed && T.narrow_bins && max_win_libs <= 32 && window_lds + kWavesPerBlock * kStreamRingBytes <= kStreamLdsPerWg2;
     b->mode = single ? kSingleLds : windowed ? kMultiLds : kGeneral;
+    // the general mode keeps one 32-byte descriptor per library in LDS: beyond 1 024 libraries a batch has to come with library
+    // windows (svt_unit.libs, one per sample -- what every producer in this repository writes) or with windows the scan can derive
+    if (b->mode == kGeneral && in->n_libs > 1024)
+        return fail(SVT_ERR_UNSUPPORTED, "more than 1024 libraries in a batch without usable library windows (svt_unit.libs)");
     // units that already come grouped by window (a sample-major batch, a one-window batch) need no permutation:
     // the kernel then walks the units themselves (no index loads in front of every unit header)
     bool identity = true;

@@ -20,7 +20,7 @@ static int svt_batch_create_impl(const svt_evidence_batch* in, int device, unsig
     const uint64_t n = in->n_units;
     if (flags & ~kKnownFlags) return fail(SVT_ERR_INVALID, "unknown flag bits");
     if (n >= 0xFFFFFFF0ull) return fail(SVT_ERR_INVALID, "too many units in one batch (< 2^32)");
-    if (in->n_libs == 0 || in->n_libs > 256 || !in->libs) return fail(SVT_ERR_INVALID, "n_libs must be 1..256");
+    if (in->n_libs == 0 || in->n_libs > 65536 || !in->libs) return fail(SVT_ERR_INVALID, "n_libs must be 1..65536");
     if (n && (!in->rec_offset || !in->units)) return fail(SVT_ERR_INVALID, "null unit arrays");
     if (n && in->rec_offset[0] != 0) return fail(SVT_ERR_INVALID, "rec_offset[0] must be 0");
     if (n && in->rec_offset[n] && !in->records) return fail(SVT_ERR_INVALID, "null records");
@@ -79,7 +79,7 @@ static int svt_batch_create_segments_impl(const svt_evidence_batch* in, const sv
     eb.records = nullptr;
     bool hinted = true;      // (create_stream's rule: the windows come from the hints only when every unit has one)
     if (in->n_libs > 1 && in->units && !(flags & SVT_FLAG_GENERAL_TABLES))
-        for (uint64_t u = 0; u < n && hinted; ++u) hinted = ((in->units[u].libs >> 8) & 0xffu) != 0u;
+        for (uint64_t u = 0; u < n && hinted; ++u) hinted = SVT_UNIT_LIBS_COUNT(in->units[u].libs) != 0u;
     if (!hinted || (flags & ~kKnownFlags) || n_rec == 0) {
         struct Scratch { void* p = nullptr; ~Scratch() { g_pinned.put(p); } } scratch;
         if (n_rec) {
@@ -96,7 +96,7 @@ static int svt_batch_create_segments_impl(const svt_evidence_batch* in, const sv
     }
     // the checks of svt_batch_create_impl (the records are not looked at on the host: the pass itself checks their contract)
     if (n >= 0xFFFFFFF0ull) return fail(SVT_ERR_INVALID, "too many units in one batch (< 2^32)");
-    if (in->n_libs == 0 || in->n_libs > 256 || !in->libs) return fail(SVT_ERR_INVALID, "n_libs must be 1..256");
+    if (in->n_libs == 0 || in->n_libs > 65536 || !in->libs) return fail(SVT_ERR_INVALID, "n_libs must be 1..65536");
     if (n && !in->units) return fail(SVT_ERR_INVALID, "null unit arrays");
     if (n && in->rec_offset[0] != 0) return fail(SVT_ERR_INVALID, "rec_offset[0] must be 0");
     if (!(in->split_weight >= 0.0) || !(in->disc_weight >= 0.0) || !std::isfinite(in->split_weight) || !std::isfinite(in->disc_weight))
@@ -148,7 +148,7 @@ static int svt_batch_create_from_fragments_impl(const svt_fragment_batch* in, in
     const uint64_t n = in->n_units;
     if (flags & ~kKnownFlags) return fail(SVT_ERR_INVALID, "unknown flag bits");
     if (n >= 0xFFFFFFF0ull) return fail(SVT_ERR_INVALID, "too many units in one batch (< 2^32)");
-    if (in->n_libs == 0 || in->n_libs > 256 || !in->libs) return fail(SVT_ERR_INVALID, "n_libs must be 1..256");
+    if (in->n_libs == 0 || in->n_libs > 65536 || !in->libs) return fail(SVT_ERR_INVALID, "n_libs must be 1..65536");
     if (n && (!in->frag_offset || !in->breakpoints)) return fail(SVT_ERR_INVALID, "null unit arrays");
     if (n && in->frag_offset[0] != 0) return fail(SVT_ERR_INVALID, "frag_offset[0] must be 0");
     const uint64_t n_frag = n ? in->frag_offset[n] : 0;
@@ -171,7 +171,7 @@ static int svt_batch_create_from_fragments_impl(const svt_fragment_batch* in, in
         U.sample = bp.sample;
         U.svtype = bp.svtype;
         U.flags = (bp.flags & SVT_BP_SKIP) ? SVT_UNIT_SKIP : 0;
-        U.libs = bp.reserved[0] & 0xffffu;      // SVT_UNIT_LIBS hint of the unit's sample
+        U.libs = bp.reserved[0] & 0xffffffu;    // SVT_UNIT_LIBS hint of the unit's sample
         units[u] = U;
     }
     // library descriptors (the flank of is_pair_straddle is lib.mean + lib.sd * 3)

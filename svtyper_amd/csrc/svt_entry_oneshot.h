@@ -43,7 +43,7 @@ static int svt_genotype_impl(const svt_evidence_batch* in, svt_result* out, int 
     }
     // the streamed layout from host records: upload, pass and download overlap by unit ranges
     if (in && out && !(flags & ~kKnownFlags) && in->n_units >= kPipelineMinUnits &&
-        in->n_units < 0xFFFFFFF0ull && in->rec_offset && in->units && in->records && in->n_libs >= 1 && in->n_libs <= 256 && in->libs &&
+        in->n_units < 0xFFFFFFF0ull && in->rec_offset && in->units && in->records && in->n_libs >= 1 && in->n_libs <= 65536 && in->libs &&
         in->rec_offset[0] == 0 && in->split_weight >= 0.0 && in->disc_weight >= 0.0 && std::isfinite(in->split_weight) &&
         std::isfinite(in->disc_weight)) {
         const int ndev = svt_device_count();

@@ -60,7 +60,7 @@ __global__ __launch_bounds__(kBlock) void svt_geometry_kernel(const GeomArgs g)
         if (g.frag_offset[mid] <= i) lo = mid; else hi = mid;
     }
     const svt_breakpoint bp = g.bps[lo];
-    const uint32_t lib = ra.extra & 0xffu;
+    const uint32_t lib = ra.extra & 0xffffu;
     uint32_t bad = 0;
     if (lib >= g.n_libs) bad |= 4u;
     const double flank = g.libs[min(lib, g.n_libs - 1)].v_nondel;

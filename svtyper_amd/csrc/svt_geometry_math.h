@@ -110,7 +110,7 @@ SVT_HD uint32_t split_weights(const PieceS& L, const PieceS& R, bool soft, const
 SVT_HD Record4 geometry_record(const ReadS& ra, const ReadS& rb, const PieceS& sl, const PieceS& sr, const PieceS& cl,
                                const PieceS& cr, const svt_breakpoint& bp, double flank, int32_t m, int32_t slop)
 {
-    const uint32_t lib = ra.extra & 0xffu;
+    const uint32_t lib = ra.extra & 0xffffu;
     const bool pair_ok = (rb.extra & SVT_FRAG_PAIR) != 0;
     const bool cont = (rb.extra & SVT_FRAG_CONTINUATION) != 0;
     const bool o1 = (bp.flags & SVT_BP_REV_A) != 0, o2 = (bp.flags & SVT_BP_REV_B) != 0;

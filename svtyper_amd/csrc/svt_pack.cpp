@@ -820,7 +820,8 @@ int encode_packed(const svt_evidence_batch* in, const PackAlloc& A, PackedArrays
     *out = PackedArrays{};
     const uint64_t n = in->n_units;
     if (n >= 0x55555550ull) return fail(SVT_ERR_INVALID, "too many units in one batch");
-    if (in->n_libs == 0 || in->n_libs > 256 || !in->libs) return fail(SVT_ERR_INVALID, "n_libs must be 1..256");
+    if (in->n_libs == 0 || in->n_libs > 65536 || !in->libs) return fail(SVT_ERR_INVALID, "n_libs must be 1..65536");
+    if (in->n_libs > 256) return fail(SVT_ERR_UNSUPPORTED, "packed evidence names a library with eight bits: a batch of more than 256 libraries stays canonical");
     if (n && (!in->rec_offset || !in->units)) return fail(SVT_ERR_INVALID, "null unit arrays");
     if (n && in->rec_offset[0] != 0) return fail(SVT_ERR_INVALID, "rec_offset[0] must be 0");
     if (!(in->split_weight >= 0.0) || !(in->disc_weight >= 0.0) || !std::isfinite(in->split_weight) || !std::isfinite(in->disc_weight))
@@ -973,7 +974,7 @@ int encode_packed(const svt_evidence_batch* in, const PackAlloc& A, PackedArrays
                 if (r1 < r0 || r1 > n_rec_claimed) ue = kUnitOffsets;
                 else if (r1 - r0 > 0x3FFFFFFFull) ue = kUnitTooLong;
                 else if (U.svtype > SVT_SVTYPE_BND) ue = kUnitSvtype;
-                else if ((U.libs >> 16) != 0 || (U.flags & ~SVT_UNIT_SKIP)) ue = kUnitReserved;
+                else if ((U.libs >> 24) != 0 || (U.flags & ~SVT_UNIT_SKIP)) ue = kUnitReserved;
                 else if (U.var_length < -(1 << 30) || U.var_length > (1 << 30)) ue = kUnitVarLength;
                 else if (U.svtype == SVT_SVTYPE_DEL && U.var_length < 0) ue = kUnitNegativeDel;
                 if (ue != kUnitOk) {
@@ -989,7 +990,7 @@ int encode_packed(const svt_evidence_batch* in, const PackAlloc& A, PackedArrays
                 M.is_del = U.svtype == SVT_SVTYPE_DEL;
                 M.vl = U.var_length;
                 M.pos_delta = (double)U.pos_delta;
-                if (multi && (U.libs & 0xffu) < n_libs) M.lo = U.libs & 0xffu;     // (the hint, where there is one: the sample's first library)
+                if (multi && SVT_UNIT_LIBS_FIRST(U.libs) < n_libs) M.lo = SVT_UNIT_LIBS_FIRST(U.libs);     // (the hint, where there is one: the sample's first library)
                 const uint64_t f = r1 - r0;
                 // worst case per stream: every record a wide pair entry behind a pad half-word (3 half-words; several libraries:
                 // and a library switch in front of it), one reference-read entry, two candidate entries; + two or three slots:
@@ -1021,7 +1022,7 @@ int encode_packed(const svt_evidence_batch* in, const PackAlloc& A, PackedArrays
                     encode_records_runs(recs, r0, r1, M, st, S, R, X);
                 }
                 const uint32_t lone = st.lone, or_flags = st.or_flags, or_span = st.or_span;
-                const uint32_t bad_bits = (lone ? kErrStraddleNoPair : 0u) | ((multi ? M.bad_lib : (or_flags & 0xff00u) != 0u) ? kErrLibIndex : 0u) |
+                const uint32_t bad_bits = (lone ? kErrStraddleNoPair : 0u) | ((multi ? M.bad_lib : (or_flags & 0xffff00u) != 0u) ? kErrLibIndex : 0u) |
                                           ((or_flags & ~SVT_REC_FLAG_MASK) ? kErrReservedBits : 0u) | ((int32_t)or_span < 0 ? kErrNegativeSpan : 0u);
                 if (bad_bits) W.bad.fetch_or(bad_bits, std::memory_order_relaxed);
                 const uint32_t ns = S.finish(), nr = R.finish(), nx = X.finish();

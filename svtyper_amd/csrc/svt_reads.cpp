@@ -1495,7 +1495,7 @@ static int summarise_units(const svt_bam* bam, const svt_summarise_args* args, c
     *out.offset = nullptr;
     *out.elements = nullptr;
     *out.skipped = nullptr;
-    if (geometry && (geometry->n_libs == 0 || geometry->n_libs > 256 || !geometry->lib_flank))
+    if (geometry && (geometry->n_libs == 0 || geometry->n_libs > 65536 || !geometry->lib_flank))
         return fail(SVT_ERR_INVALID, "n_libs must be 1..256 with a flank per library");
     const uint64_t n = args->n_units;
     if (n && (!args->windows || !args->breakpoints)) return fail(SVT_ERR_INVALID, "null unit arrays");
@@ -1578,7 +1578,7 @@ static int summarise_units(const svt_bam* bam, const svt_summarise_args* args, c
                     const svt_breakpoint& bp = args->breakpoints[u];
                     if (bp.svtype > SVT_SVTYPE_BND) { rc = SVT_ERR_INVALID; err = "bad svtype"; }
                     else rc = process_unit(*bam, z, buf, *args, rg_lib, u, ws, unit, err, [&](const svt_fragment& f) {
-                        const uint32_t lib = f.read[0].reserved & 0xffu;
+                        const uint32_t lib = f.read[0].reserved;
                         if (lib >= geometry->n_libs) { err = "library index of a fragment outside the library table"; return false; }
                         const svt::Record4 r = svt::geometry_record(svt::read_of(f.read[0]), svt::read_of(f.read[1]), svt::piece_of(f.seq[0]),
                                                                     svt::piece_of(f.seq[1]), svt::piece_of(f.clip[0]), svt::piece_of(f.clip[1]), bp,

@@ -127,7 +127,7 @@ struct RecordCheck {
         else flags_or |= w.w;                                // undefined bits; with one library also the library byte
         span_or |= w.x;                                      // sign bit: a negative ospan_len
         lone = max(lone, (w.w & 0x17u) ^ 0x10u);             // > 0x10: straddle bits without HAS_PAIR
-        if (MODE == kGeneral) lib_max = max(lib_max, w.w & 0xff00u);
+        if (MODE == kGeneral) lib_max = max(lib_max, w.w & 0xffff00u);
     }
     // kMultiLds, windows of several libraries: the consumer has `library - first library of the window` at hand
     // (unsigned: below the window = huge).  One more loop-carried value in see() costs the kernel its third wave.
@@ -136,8 +136,8 @@ struct RecordCheck {
     __device__ __forceinline__ uint32_t bits(const uint32_t limit) const
     {
         const uint32_t n_libs = limit;
-        const bool bad_lib = MODE == kSingleLds ? (flags_or & 0xff00u) != 0u
-                             : MODE == kMultiLds ? (limit == 1u ? (flags_or & 0xff00u) != 0u : lib_max >= limit)
+        const bool bad_lib = MODE == kSingleLds ? (flags_or & 0xffff00u) != 0u
+                             : MODE == kMultiLds ? (limit == 1u ? (flags_or & 0xffff00u) != 0u : lib_max >= limit)
                                                  : (lib_max >> SVT_REC_LIB_SHIFT) >= n_libs;
         return (lone > 0x10u ? kErrStraddleNoPair : 0u) | (bad_lib ? kErrLibIndex : 0u) |
                ((flags_or & ~SVT_REC_FLAG_MASK) ? kErrReservedBits : 0u) | ((int32_t)span_or < 0 ? kErrNegativeSpan : 0u);

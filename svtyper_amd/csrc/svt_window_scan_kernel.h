@@ -26,7 +26,7 @@ __global__ __launch_bounds__(kScanBlock) void svt_window_scan_kernel(const uint4
     const uint32_t* flags = reinterpret_cast<const uint32_t*>(records) + 3;   // dword 3 of record r: flags[4 r]
     for (uint32_t u = (blockIdx.x * kScanBlock + threadIdx.x) / kWave; u < n_units; u += n_waves) {
         const uint64_t r0 = rec_offset[u], r1 = rec_offset[u + 1];
-        uint32_t lo = 0xffu, hi = 0u;
+        uint32_t lo = 0xffffu, hi = 0u;
         uint64_t r = r0 + lane;
         for (; r + (uint64_t)kWave < r1; r += 2 * (uint64_t)kWave) {      // two loads in flight per lane
             const uint32_t a = SVT_REC_LIB(flags[4 * r]), b = SVT_REC_LIB(flags[4 * (r + kWave)]);
@@ -45,7 +45,7 @@ __global__ __launch_bounds__(kScanBlock) void svt_window_scan_kernel(const uint4
         }
         // a unit without records names no library: any window will do (the first library's)
         // (0 = no window: more than 255 libraries apart -- the hint's count field is eight bits)
-        if (lane == 0) out[u] = r1 <= r0 ? (1u << 8) : hi - lo + 1u <= 255u ? (lo | (hi - lo + 1u) << 8) : 0u;
+        if (lane == 0) out[u] = r1 <= r0 ? SVT_UNIT_LIBS(0u, 1u) : hi - lo + 1u <= 255u ? SVT_UNIT_LIBS(lo, hi - lo + 1u) : 0u;
     }
 }
 

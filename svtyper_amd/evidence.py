@@ -75,13 +75,23 @@ assert UNIT_DTYPE.itemsize == 16
 
 def unit_libs(first: int, count: int) -> int:
     """SVT_UNIT_LIBS(first, count): the libraries of a unit's sample are libs[first .. first + count) of the batch.
-    The hint stores both numbers in 8 bits: a sample that cannot be described (no library, more than 255 libraries, a
-    first index beyond 255) gets 0 = "no hint" -- the pass then takes such a batch without windows instead of
-    rejecting it."""
+    first < 65536 (its low byte | count << 8 | its high byte << 16: ABI 18, the same word as before for first < 256),
+    count <= 255: a sample that cannot be described (no library, more than 255 libraries, a first index beyond 65535)
+    gets 0 = "no hint" -- the pass then takes such a batch without windows instead of rejecting it."""
     first, count = int(first), int(count)
-    if count <= 0 or count > 255 or first > 255:
+    if count <= 0 or count > 255 or first < 0 or first > 65535:
         return 0
-    return first | (count << 8)
+    return (first & 0xFF) | (count << 8) | ((first >> 8) << 16)
+
+
+def unit_libs_first(hint):
+    """SVT_UNIT_LIBS_FIRST (scalars or numpy arrays)"""
+    return (hint & 0xFF) | (((hint >> 16) & 0xFF) << 8)
+
+
+def unit_libs_count(hint):
+    """SVT_UNIT_LIBS_COUNT"""
+    return (hint >> 8) & 0xFF
 
 RESULT_DTYPE = np.dtype(
     [

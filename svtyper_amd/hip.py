@@ -16,7 +16,7 @@ from .evidence import GT_BLANK, CEvidenceBatch, CPackedEvidence, EvidenceBatch, 
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SVTYPER_HIP_LIB") or os.path.join(_HERE, "csrc", "libsvtyper_hip.so")
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 EXPORTS = (
     "svt_version", "svt_device_count", "svt_last_error", "svt_batch_create", "svt_batch_create_segments", "svt_batch_create_from_fragments",

@@ -90,15 +90,16 @@ def default_engine() -> Engine:
     return HipEngine(0)
 
 
-MAX_BATCH_LIBS = 256     # libraries one device batch can name: svt_record carries an 8-bit index into svt_evidence_batch.libs
+MAX_BATCH_LIBS = 65536   # libraries one device batch can name: svt_record carries a 16-bit index into svt_evidence_batch.libs (ABI 18)
 
 
 def library_groups(samples: List[Sample]) -> List[List[int]]:
     """Consecutive samples whose libraries fit ONE device batch.  The reference's `-B a.bam,b.bam,...` list is unbounded
     (svtyper/classic.py:145-158; read group -> library: parsers.py:432-447) while an evidence record names its library with
-    eight bits, so a joint run over more libraries than that is several device batches -- one per group of samples, each
-    with its own library table and indices local to it -- whose result records are put back site-major over all samples
-    (units are independent; QUAL, the one quantity across a site's samples, is summed on the host afterwards)."""
+    sixteen bits (65 536 libraries per batch since ABI 18: a 130-sample cohort of 260 libraries is ONE batch), so a joint run
+    over more libraries than that is several device batches -- one per group of samples, each with its own library table and
+    indices local to it -- whose result records are put back site-major over all samples (units are independent; QUAL, the
+    one quantity across a site's samples, is summed on the host afterwards)."""
     groups: List[List[int]] = []
     cur: List[int] = []
     n = 0

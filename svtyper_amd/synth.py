@@ -66,7 +66,7 @@ def make_units(n_units: int, seed: int, libs: Sequence[LibraryTable], svtype_mix
     libs = list(libs)
     if lib_choices is None:
         lib_choices = list(range(len(libs)))
-    lib_choices = np.asarray(lib_choices, dtype=np.uint8)
+    lib_choices = np.asarray(lib_choices, dtype=np.uint16)      # (sixteen bits of library index: ABI 18)
 
     # ---- units
     svtype = rng.choice(4, size=n_units, p=np.asarray(svtype_mix, float) / np.sum(svtype_mix)).astype(np.uint8)

@@ -196,7 +196,7 @@ def test_invalid_records_rejected(hip_device, fixture_library):
     with pytest.raises(hip.SvtyperHipError):
         hip.genotype_batch(b)
     b = synth.make_units(100, 3, [fixture_library])
-    b.records["flags"][9] |= 1 << 20  # undefined flag bit
+    b.records["flags"][9] |= 1 << 28  # undefined flag bit
     with pytest.raises(hip.SvtyperHipError):
         hip.genotype_batch(b)
 
@@ -780,7 +780,7 @@ def test_library_windows_in_the_streaming_kernel(hip_device, fixture_library):
     got, want = run_both(wide)
     assert_parity(got, want)
     bad = synth.permute_units(batch, np.arange(640))
-    lo = int(bad.units["libs"][0]) & 0xff
+    lo = int(ev.unit_libs_first(int(bad.units["libs"][0])))
     bad.units["libs"][0] = ev.unit_libs(lo + 1, 1) if lo + 1 < len(batch.libs) else ev.unit_libs(lo - 1, 1)
     if bad.rec_offset[1] > bad.rec_offset[0]:
         with pytest.raises(hip.SvtyperHipError) as e:
@@ -847,7 +847,7 @@ def test_pipelined_one_shot_equals_the_resident_batch(hip_device, fixture_librar
     assert hip.genotype_batch(tiny, hip_device, 0).rec.tobytes() == want
     assert hip.genotype_batch(tiny, hip_device, 0, out=hip.pinned_results(tiny.n_units)).rec.tobytes() == want
     bad = synth.make_units(120_000, 91, [fixture_library], svtype_mix=(0.6, 0.2, 0.1, 0.1), mean_frags=60, sd_frags=30, min_frags=0)
-    bad.records["flags"][bad.n_records - 3] |= 1 << 20
+    bad.records["flags"][bad.n_records - 3] |= 1 << 28
     with pytest.raises(hip.SvtyperHipError) as e:
         hip.genotype_batch(bad, hip_device)
     assert "reserved/undefined bits" in str(e.value)

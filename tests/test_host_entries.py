@@ -45,14 +45,19 @@ def test_shard_bounds_balance_bytes_and_keep_groups_whole():
 
 
 def test_library_hint_that_does_not_fit_is_no_hint():
-    """SVT_UNIT_LIBS keeps first and count in 8 bits each: 256 libraries in one sample, or a sample whose first
-    library has index 256, must become `no hint` (0), never a value with reserved bits set."""
+    """SVT_UNIT_LIBS (ABI 18): first < 65536 as low byte | count << 8 | high byte << 16 -- the word ABI <= 17 wrote for
+    first < 256 --, count <= 255; 256 libraries in one sample, or a first library beyond 65535, must become `no hint` (0),
+    never a value with reserved bits (24..31) set."""
     assert ev.unit_libs(3, 2) == (3 | 2 << 8)
     assert ev.unit_libs(0, 255) == (255 << 8)
-    assert ev.unit_libs(0, 256) == 0 and ev.unit_libs(256, 1) == 0 and ev.unit_libs(5, 0) == 0
-    for first in range(0, 300, 37):
+    assert ev.unit_libs(256, 1) == (1 << 8 | 1 << 16) and ev.unit_libs(0x1234, 7) == (0x34 | 7 << 8 | 0x12 << 16)
+    assert ev.unit_libs(0, 256) == 0 and ev.unit_libs(65536, 1) == 0 and ev.unit_libs(5, 0) == 0
+    for first in list(range(0, 300, 37)) + [255, 256, 4095, 65535, 65536, 70000]:
         for count in (0, 1, 3, 255, 256, 300):
-            assert ev.unit_libs(first, count) >> 16 == 0
+            h = ev.unit_libs(first, count)
+            assert h >> 24 == 0
+            if h:
+                assert (ev.unit_libs_first(h), ev.unit_libs_count(h)) == (first, count)
 
 
 def test_pinned_results_memory_lives_as_long_as_any_view():

@@ -1,8 +1,9 @@
-"""More libraries in one joint run than an evidence record's 8-bit library index can name (the reference's `-B` list is
-unbounded: svtyper/classic.py:145-158, read group -> library parsers.py:432-447): pipeline.library_groups cuts the samples
-into groups that fit one device batch each and puts the result records back site-major over all samples.  CPU: the
-grouping itself against the one-batch run (cap lowered, oracle engine).  GPU: 130 samples x 2 libraries x 200 sites
-through the HIP engine against the oracle, bit-exact."""
+"""Many libraries in one joint run (the reference's `-B` list is unbounded: svtyper/classic.py:145-158, read group -> library
+parsers.py:432-447).  ABI 18: an evidence record names its library with sixteen bits and a unit's window hint carries a
+16-bit first library, so 130 samples x 2 libraries are ONE device batch of 260 libraries; beyond 65 536 libraries
+pipeline.library_groups cuts the samples into groups that fit one batch each and puts the result records back site-major.
+CPU: the grouping against the one-batch run (cap lowered, oracle engine).  GPU: 130 samples x 2 libraries x 200 sites
+through the HIP engine against the oracle, bit-exact -- as one batch and, cap lowered, as two."""
 import io
 import json
 import os
@@ -62,10 +63,13 @@ def run(paths, libs, text, engine, **kw):
     return [l for l in out.getvalue().split("\n") if not l.startswith("##fileDate=")]
 
 
-def test_groups_are_consecutive_and_fit():
+def test_groups_are_consecutive_and_fit(monkeypatch):
     class S:
         def __init__(self, n):
             self.lib_dict, self.name = dict.fromkeys(range(n)), "s"
+    assert pipeline.MAX_BATCH_LIBS == 65536
+    assert pipeline.library_groups([S(2)] * 130) == [list(range(130))]
+    monkeypatch.setattr(pipeline, "MAX_BATCH_LIBS", 256)
     assert pipeline.library_groups([S(2)] * 130) == [list(range(128)), [128, 129]]
     assert pipeline.library_groups([S(200), S(56), S(1), S(256)]) == [[0, 1], [2], [3]]
     assert pipeline.library_groups([S(1)]) == [[0]]
@@ -97,10 +101,13 @@ def test_grouped_batches_write_the_bytes_of_the_single_batch(tmp_path, monkeypat
 
 
 @pytest.mark.gpu
-def test_130_samples_of_two_libraries_against_the_oracle(tmp_path, hip_device):
-    """260 libraries in one joint run (the reference takes any number): two device batches (128 + 2 samples), every result
-    record of the HIP engine bit-identical to the oracle's on the same batch, the VCF identical to the oracle engine's and to
-    the per-line route's"""
+@pytest.mark.parametrize("cap", [65536, 256])
+def test_130_samples_of_two_libraries_against_the_oracle(tmp_path, hip_device, monkeypatch, cap):
+    """260 libraries in one joint run (the reference takes any number): ONE device batch of 260 libraries (16-bit library
+    index, 16-bit first library in the window hints), or -- the cap lowered to the eight bits of ABI <= 17 -- two batches
+    (128 + 2 samples); every result record of the HIP engine bit-identical to the oracle's on the same batch, the VCF
+    identical to the oracle engine's and to the per-line route's"""
+    monkeypatch.setattr(pipeline, "MAX_BATCH_LIBS", cap)
     from test_hip_parity import assert_parity
     paths, libs = cohort(tmp_path, 130, 120)
     text = vcf_text(50)                       # 200 sites (50 x DEL, DUP, INV, one BND pair)
@@ -118,7 +125,7 @@ def test_130_samples_of_two_libraries_against_the_oracle(tmp_path, hip_device):
             return got
 
     checked = run(paths, libs, text, Checked())
-    assert seen == [(200 * 128, 256), (200 * 2, 4)]
+    assert seen == ([(200 * 130, 260)] if cap > 256 else [(200 * 128, 256), (200 * 2, 4)])
     assert len([l for l in checked if l and not l.startswith("#")]) == 250
     assert all(len(l.split("\t")) == 9 + 130 for l in checked if l and not l.startswith("#"))
     default = run(paths, libs, text, None)                     # the default engine: the readers' segments, sample-major
@@ -131,3 +138,72 @@ def test_130_samples_of_two_libraries_against_the_oracle(tmp_path, hip_device):
     finally:
         del os.environ["SVT_BULK_VCF"]
     assert per_line == checked
+
+
+@pytest.mark.gpu
+def test_one_batch_of_more_than_256_libraries_through_every_mode(hip_device):
+    """400 samples x 1-3 libraries (~800 libraries) in ONE batch, straight through the C ABI against the oracle: with the
+    window hints (first library up to ~800: sixteen bits), sample-major with site-major results, without hints (windows read
+    off the records by svt_window_scan_kernel), and with every table through L2 (general mode: <= 1 024 libraries);
+    a record that names a library outside its unit's window, or beyond the batch, is still the contract violation it was"""
+    from svtyper_amd import evidence as ev, hip, synth
+    from oracle import c_oracle
+    from test_hip_parity import assert_parity
+    batch = synth.make_multisample(12, 400, seed=77, mean_frags=14, sd_frags=5, min_frags=0, max_frags=30)
+    assert 600 < len(batch.libs) <= 1024 and int(ev.unit_libs_first(batch.units["libs"]).max()) > 256
+    assert int((batch.records["flags"] >> ev.REC_LIB_SHIFT).max()) > 256
+    want = c_oracle.genotype_batch(batch)
+    assert_parity(hip.genotype_batch(batch, device=hip_device), want)
+    assert_parity(hip.genotype_batch(batch, device=hip_device, flags=ev.FLAG_GENERAL_TABLES), want)
+    for flags in (0, ev.FLAG_SSO_ASSOCIATION, ev.FLAG_RESULT96):
+        with hip.DeviceBatch(batch, hip_device, flags) as d:
+            assert d.table_mode() == 1          # library windows
+            d.genotype(sync=True)
+            assert_parity(d.results(), c_oracle.genotype_batch(batch, flags=flags & ev.FLAG_SSO_ASSOCIATION))
+    bare = synth.permute_units(batch, np.arange(batch.n_units))
+    bare.units["libs"] = 0                      # no hints: the scan finds every unit's window
+    with hip.DeviceBatch(bare, hip_device, 0) as d:
+        assert d.table_mode() == 1
+        d.genotype(sync=True)
+        assert_parity(d.results(), want)
+    by_sample, _ = synth.to_sample_major(batch, 400)
+    with hip.DeviceBatch(by_sample, hip_device, 0) as d:
+        d.result_order(400)
+        d.genotype(sync=True)
+        assert d.results().rec.tobytes() == hip.genotype_batch(batch, device=hip_device).rec.tobytes()
+    # contract violations
+    bad = synth.permute_units(batch, np.arange(batch.n_units))
+    u = int(np.nonzero(np.diff(bad.rec_offset.astype(np.int64)) > 0)[0][-1])          # a unit of a late sample that has records
+    first = int(ev.unit_libs_first(int(bad.units["libs"][u])))
+    bad.units["libs"][u] = ev.unit_libs(first - 5, 1)
+    with pytest.raises(hip.SvtyperHipError) as e:
+        hip.genotype_batch(bad, device=hip_device)
+    assert "lib index" in str(e.value)
+    beyond = synth.permute_units(batch, np.arange(batch.n_units))
+    r = int(beyond.rec_offset[u])
+    beyond.records["flags"][r] = (int(beyond.records["flags"][r]) & 0xFF) | (len(batch.libs) + 3) << ev.REC_LIB_SHIFT
+    for b2 in (beyond,):
+        with pytest.raises(hip.SvtyperHipError):
+            hip.genotype_batch(b2, device=hip_device)
+    reserved = synth.permute_units(batch, np.arange(batch.n_units))
+    reserved.records["flags"][r] |= 1 << 26
+    with pytest.raises(hip.SvtyperHipError) as e:
+        hip.genotype_batch(reserved, device=hip_device)
+    assert "reserved" in str(e.value) or "undefined" in str(e.value)
+    # packed evidence names a library with eight bits: such a batch stays canonical
+    assert hip.PackedEvidence.try_pack(batch) is None
+
+
+def test_more_than_256_libraries_on_the_cpu_side():
+    """the oracle (C and Python) and the batch validation read sixteen bits of library index"""
+    from svtyper_amd import evidence as ev, synth
+    from oracle import c_oracle, py_oracle
+    batch = synth.make_multisample(3, 300, seed=5, mean_frags=6, sd_frags=2, min_frags=0, max_frags=12)
+    assert len(batch.libs) > 400 and int((batch.records["flags"] >> ev.REC_LIB_SHIFT).max()) > 256
+    a, b = c_oracle.genotype_batch(batch), py_oracle.genotype_batch(batch, 0)
+    assert np.array_equal(a.gt, b.gt) and np.array_equal(a.counts, b.counts)
+    assert np.array_equal(a.gl.view(np.uint64), b.gl.view(np.uint64))
+    # the libraries matter: the same records against the FIRST sample's library give other answers somewhere
+    moved = synth.permute_units(batch, np.arange(batch.n_units))
+    moved.records["flags"] &= 0xFF
+    assert not np.array_equal(c_oracle.genotype_batch(moved).gl, a.gl)

@@ -92,7 +92,7 @@ def test_result_records_as_a_torch_view(hip_device):
 def test_genotype_multi_reports_the_failing_device(hip_device, fixture_library):
     from svtyper_amd import evidence as ev, hip, synth
     b = synth.make_units(3000, 3, [fixture_library])
-    b.records["flags"][b.n_records - 5] |= 1 << 20          # an undefined flag bit in the last shard
+    b.records["flags"][b.n_records - 5] |= 1 << 28          # an undefined flag bit in the last shard
     with pytest.raises(hip.SvtyperHipError) as e:
         hip.genotype_multi(b, [0, 0])
     assert "reserved/undefined bits" in str(e.value) and "device 0" in str(e.value)

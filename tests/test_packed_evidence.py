@@ -69,7 +69,7 @@ def test_pack_rejects_what_the_format_cannot_hold(fixture_library):
     neg.units["var_length"][3] = -7
     assert hip.PackedEvidence.try_pack(neg) is None
     bad = synth.make_units(50, 3, [fixture_library])
-    bad.records["flags"][5] |= 1 << 20
+    bad.records["flags"][5] |= 1 << 28
     with pytest.raises(hip.SvtyperHipError) as e:
         hip.PackedEvidence(bad)
     assert "reserved/undefined bits" in str(e.value)
@@ -283,7 +283,7 @@ def test_ranged_encoder_writes_the_same_arrays(fixture_library, monkeypatch):
     with hip.PackedEvidence(batch) as p:
         assert p.slots().tobytes() == want[0]
     bad = synth.make_units(9000, 3, [fixture_library])
-    bad.records["flags"][bad.n_records - 5] |= 1 << 20     # an undefined flag bit in the LAST range: reported, nothing leaks
+    bad.records["flags"][bad.n_records - 5] |= 1 << 28     # an undefined flag bit in the LAST range: reported, nothing leaks
     with pytest.raises(hip.SvtyperHipError) as e:
         hip.PackedEvidence(bad)
     assert "reserved/undefined bits" in str(e.value)
@@ -329,7 +329,7 @@ def test_from_records_route_overlaps_and_equals_the_canonical_pass(hip_device, f
     assert hip.genotype_packed_from_records(dense, hip_device, 0).rec.tobytes() == hip.genotype_batch(dense, hip_device, 0).rec.tobytes()
     # a contract violation in a late range is an error of the call; several libraries are not packable
     bad = synth.make_units(60_000, 3, [fixture_library])
-    bad.records["flags"][bad.n_records - 5] |= 1 << 20
+    bad.records["flags"][bad.n_records - 5] |= 1 << 28
     with pytest.raises(hip.SvtyperHipError) as e:
         hip.genotype_packed_from_records(bad, hip_device, 0)
     assert "reserved/undefined bits" in str(e.value)
