@@ -138,9 +138,10 @@ inline unsigned burst_threads(double est_cpu_s, unsigned cap)
     // other threads -- the next block's parse, the text of the one before)
     const double allowance = 0.8 * q.cpu_s - recent_cpu_s(q.period_s);
     if (est_cpu_s > allowance) return base;
-    // a sustained run (more than two periods' allowance spent within the last ten: chunk after chunk of a long VCF, sample
-    // after sample of a joint run) is bound by the quota: bursts would only be paid for with throttled periods
-    if (recent_cpu_s(10.0 * q.period_s) + est_cpu_s > 2.0 * q.cpu_s) return base;
+    // a run that has been spending more than three quarters of the quota over the last ten periods (sample after sample of a
+    // joint run, block after block of a long VCF with a slow reader) is bound by the quota: bursts would only be paid for with
+    // throttled periods.  (A run below that -- block after block of a VCF whose units are cheap -- gains from every burst.)
+    if (recent_cpu_s(10.0 * q.period_s) + est_cpu_s > 7.5 * q.cpu_s) return base;
     return std::max(base, std::min(physical_cores(), cap));
 }
 
