@@ -535,72 +535,41 @@ def real_data_leg(device: int) -> dict:
             return self._timed(lambda: hip.DeviceBatch.from_fragments(fb, device, flags), fb.n_fragments, fb.n_units,
                                128 * fb.n_fragments + 56 * fb.n_units)
 
-    def run(sample, nbam, sites, repeat, threads=0, geometry="reader"):
+    def run(sample, nbam, header_vcf, lines, repeat, threads=0, geometry="reader"):
+        """One block of variant lines through the stages the drivers' bulk route is made of, one after the other (driver_sso /
+        driver_classic_8bam below are the same stages overlapped by blocks): svt_vcf_parse -> site arrays per sample -> the
+        reader -> device -> svt_vcf_emit."""
+        from svtyper_amd import bulk_vcf
+        text = "".join(lines * repeat).encode()
+        fields = sorted(pipeline.SVTYPER_FORMAT_KEYS, key=lambda k: header_vcf.format_rank[k])
         best = None
         for _ in range(2):     # (the first run pays the pooled device buffers; keep the better one)
             eng = Timed()
             coll = pipeline.NativeUnitCollector([sample], [nbam], 1.0, 1.0, 20, nr.COUNT_SSO, 1000, n_threads=threads, geometry=geometry)
-            a0 = time.perf_counter()
-            for _r in range(repeat):
-                for bp in sites:
-                    coll.add_site(bp)
+            parser = bulk_vcf.VcfParser(header_vcf, 1e10, False, True)
             t0 = time.perf_counter()
-            add_ms = (t0 - a0) * 1e3
-            job = coll.take(eng, ev.FLAG_SSO_ASSOCIATION)     # (the sites' fields -> arrays, Python)
+            chunk, used = parser.parse(text)
+            assert used == len(text) and not (chunk.line_kind == bulk_vcf.LINE_PYTHON).any()
+            coll.add_site_arrays(chunk.sites)
+            job = coll.take(eng, ev.FLAG_SSO_ASSOCIATION)
             t_prep = time.perf_counter()
             res = job()
             t1 = time.perf_counter()
-            cols = hip.format_results(res, list(pipeline.SVTYPER_FORMAT_KEYS), False)
+            out_text, off = chunk.emit(res, 1, bulk_vcf.QUAL_SSO, fields, False, ":".join(fields))
             t2 = time.perf_counter()
             dev = sum(eng.t.values())
-            leg = {"sites": len(sites) * repeat, "fragments": eng.fragments, "wall_ms": (t2 - t0) * 1e3,
-                   "sites_per_s": len(sites) * repeat / (t2 - t0),
-                   "stage_ms": {"site_arrays_python": (t_prep - t0) * 1e3, "inflate_fetch_summarise_host": (t1 - t_prep - dev) * 1e3,
+            n_sites = chunk.n_sites
+            leg = {"sites": n_sites, "variant_lines": chunk.n_lines, "fragments": eng.fragments, "wall_ms": (t2 - t0) * 1e3,
+                   "sites_per_s": n_sites / (t2 - t0),
+                   "stage_ms": {"vcf_parse_and_site_arrays": (t_prep - t0) * 1e3, "inflate_fetch_summarise_host": (t1 - t_prep - dev) * 1e3,
                                 "h2d_plus_geometry_kernel": eng.t["create_h2d_geometry"] * 1e3, "genotype_pass": eng.t["pass"] * 1e3,
-                                "results_d2h": eng.t["results_d2h"] * 1e3, "format_columns_host": (t2 - t1) * 1e3},
-                   # (the collector's add_site() per site -- the driver's per-variant loop -- lies in front of `wall_ms`; the chunked run
-                   # below has it inside its wall time, so compare `overlapped_wall_ms` with `wall_incl_add_sites_ms`)
-                   "add_sites_python_ms": add_ms, "wall_incl_add_sites_ms": (t2 - t0) * 1e3 + add_ms,
-                   "geometry": geometry, "h2d_bytes": int(eng.h2d_bytes), "fragments_per_site": eng.fragments / max(1, len(sites) * repeat),
-                   "gt_histogram": {str(k): int(v) for k, v in zip(*np.unique(res.gt, return_counts=True))}, "columns": len(cols)}
+                                "results_d2h": eng.t["results_d2h"] * 1e3, "vcf_emit_lines": (t2 - t1) * 1e3},
+                   "geometry": geometry, "h2d_bytes": int(eng.h2d_bytes), "fragments_per_site": eng.fragments / max(1, n_sites),
+                   "gt_histogram": {str(k): int(v) for k, v in zip(*np.unique(res.gt, return_counts=True))},
+                   "lines_out": out_text.count(b"\n"), "vcf_bytes_out": len(out_text)}
+            chunk.close()
             if best is None or leg["wall_ms"] < best["wall_ms"]:
                 best = leg
-        # ---- the same sites in CHUNKS through the drivers' double buffering (pipeline.ChunkPipeline, what sso_genotype / sv_genotype
-        # run): chunk k's reader + device stages on a worker thread (C++ and HIP calls: outside the GIL) while the caller's thread
-        # formats the sample columns of chunk k-1 -- the wall time is the longer chain, not the sum of the stages
-        try:
-            all_sites = [bp for _r in range(repeat) for bp in sites]
-            per = max(256, -(-len(all_sites) // 6))     # (every chunk starts the reader's thread pool and a device batch of its own)
-            over = None
-            for _ in range(2):
-                eng = Timed()
-                pipe = pipeline.ChunkPipeline(True)
-                n_cols = [0]
-                fmt_s = [0.0]
-
-                def on_done(res):
-                    f0 = time.perf_counter()
-                    n_cols[0] += len(hip.format_results(res, list(pipeline.SVTYPER_FORMAT_KEYS), False))
-                    fmt_s[0] += time.perf_counter() - f0
-                t0 = time.perf_counter()
-                for lo in range(0, len(all_sites), per):
-                    coll = pipeline.NativeUnitCollector([sample], [nbam], 1.0, 1.0, 20, nr.COUNT_SSO, 1000, n_threads=threads, geometry=geometry)
-                    for bp in all_sites[lo:lo + per]:
-                        coll.add_site(bp)
-                    pipe.submit(coll.take(eng, ev.FLAG_SSO_ASSOCIATION), on_done)
-                pipe.close()
-                wall = time.perf_counter() - t0
-                if over is None or wall < over["overlapped_wall_ms"] * 1e-3:
-                    over = {"overlapped_wall_ms": wall * 1e3, "overlapped_sites_per_s": len(all_sites) / wall, "chunks": -(-len(all_sites) // per),
-                            "sites_per_chunk": per, "format_columns_host_ms": fmt_s[0] * 1e3, "device_stages_ms": sum(eng.t.values()) * 1e3,
-                            "columns": n_cols[0]}
-            assert over["columns"] == best["columns"]
-            best.update(over)
-            best["overlap_note"] = ("`stage_ms` / `wall_ms`: one chunk, the stages one after the other; `overlapped_*`: the same sites in %d chunks through "
-                                    "pipeline.ChunkPipeline (two chunks in flight: the reader of chunk k+1 while chunk k is on the device; the arrays of the next chunk "
-                                    "and the text of an earlier one on the caller's thread)" % over["chunks"])
-        except Exception as e:
-            best["overlapped_error"] = repr(e)
         return best
 
     # ---- (1) the reference's fixture: breakpoints of tests/data/example.vcf, the driver itself first (byte check), then x R
@@ -638,9 +607,12 @@ def real_data_leg(device: int) -> dict:
     with open(lib_json) as f:
         sample = library.Sample.from_lib_info(pybam.AlignmentFile(bam_path), json.load(f), 1e-3)
     nbam = nr.NativeBam(bam_path)
-    out["fixture_x100"] = dict(run(sample, nbam, bps, 100), what="the %d fixture breakpoints x 100 (cached blocks, repeated sites)" % len(bps))
-    dg = run(sample, nbam, bps, 100, geometry="device")
-    out["fixture_x100"]["device_geometry"] = {k: dg[k] for k in ("wall_ms", "sites_per_s", "stage_ms", "h2d_bytes", "overlapped_wall_ms", "overlapped_sites_per_s") if k in dg}
+    vcf.add_custom_svtyper_headers()
+    vcf.add_sample(sample.name)
+    body_lines = [l for l in lines if not l.startswith("#")]
+    out["fixture_x100"] = dict(run(sample, nbam, vcf, body_lines, 100), what="the fixture's %d variant lines (%d breakpoints) x 100 (cached blocks, repeated sites)" % (len(body_lines), len(bps)))
+    dg = run(sample, nbam, vcf, body_lines, 100, geometry="device")
+    out["fixture_x100"]["device_geometry"] = {k: dg[k] for k in ("wall_ms", "sites_per_s", "stage_ms", "h2d_bytes") if k in dg}
     out["fixture_x100"]["device_geometry"]["same_genotypes"] = dg["gt_histogram"] == out["fixture_x100"]["gt_histogram"]
     nbam.close()
     # ---- (2) a bounded WGS-like BAM: 1.2 Mbp at 30x, a DEL every 4 kb
@@ -651,8 +623,14 @@ def real_data_leg(device: int) -> dict:
         wrote = time.perf_counter() - t0
         sample = library.Sample.from_lib_info(pybam.AlignmentFile(path), info, 1e-3)
         nbam = nr.NativeBam(path)
-        dg = run(sample, nbam, sites, 1, geometry="device")
-        out["wgs_like_30x"] = dict(run(sample, nbam, sites, 1), bam_records=n_rec, bam_bytes=os.path.getsize(path), bam_written_s=wrote,
+        wvcf = Vcf()
+        wvcf.add_header([l for l in lines if l.startswith("##")])
+        wvcf.add_custom_svtyper_headers()
+        wvcf.add_sample(sample.name)
+        wlines = ["1\t%d\t%s\tN\t<DEL>\t0\t.\tSVTYPE=DEL;SVLEN=-%d;END=%d;STR=+-:8;CIPOS=-10,10;CIEND=-10,10;SU=8;PE=6;SR=2\n"
+                  % (bp["A"]["pos"], bp["id"], bp["var_length"], bp["A"]["pos"] + bp["var_length"]) for bp in sites]
+        dg = run(sample, nbam, wvcf, wlines, 1, geometry="device")
+        out["wgs_like_30x"] = dict(run(sample, nbam, wvcf, wlines, 1), bam_records=n_rec, bam_bytes=os.path.getsize(path), bam_written_s=wrote,
                                    what="1.2 Mbp at 30x (150-bp pairs, random bases, binned qualities), %d DEL sites 4 kb apart: every "
                                         "site inflates blocks of its own" % len(sites))
         out["wgs_like_30x"]["device_geometry"] = {k: dg[k] for k in ("wall_ms", "sites_per_s", "stage_ms", "h2d_bytes") if k in dg}

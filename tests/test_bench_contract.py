@@ -102,10 +102,9 @@ def test_bench_line_has_the_contract_keys(hip_device):
     assert real["fixture_driver"]["output_equals_example_gt_vcf"] is True
     for key in ("fixture_x100", "wgs_like_30x"):
         leg = real[key]
-        assert leg["sites"] > 0 and leg["fragments"] > 0 and leg["sites_per_s"] > 0 and leg["columns"] == leg["sites"]
-        assert set(leg["stage_ms"]) == {"site_arrays_python", "inflate_fetch_summarise_host", "h2d_plus_geometry_kernel", "genotype_pass", "results_d2h", "format_columns_host"}
+        assert leg["sites"] > 0 and leg["fragments"] > 0 and leg["sites_per_s"] > 0 and leg["lines_out"] >= leg["sites"]
+        assert set(leg["stage_ms"]) == {"vcf_parse_and_site_arrays", "inflate_fetch_summarise_host", "h2d_plus_geometry_kernel", "genotype_pass", "results_d2h", "vcf_emit_lines"}
         assert all(v >= 0 for v in leg["stage_ms"].values()) and leg["h2d_bytes"] == 16 * leg["fragments"] + 24 * leg["sites"]
-        assert leg["add_sites_python_ms"] >= 0 and leg["wall_incl_add_sites_ms"] >= leg["wall_ms"]      # (what the chunked run compares with)
         assert leg["geometry"] == "reader" and leg["device_geometry"]["same_genotypes"] is True and leg["device_geometry"]["h2d_bytes"] > 7 * leg["h2d_bytes"]
     assert real["fixture_x100"]["sites"] == 21100
     sh = d["shard_of_8"]
