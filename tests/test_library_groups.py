@@ -138,6 +138,9 @@ def test_130_samples_of_two_libraries_against_the_oracle(tmp_path, hip_device, m
     finally:
         del os.environ["SVT_BULK_VCF"]
     assert per_line == checked
+    # fragment summaries with the geometry predicates on the device (svt_bam_summarise -> svt_batch_create_from_fragments): the
+    # library index travels in the summaries' sixteen reserved bits
+    assert run(paths, libs, text, None, geometry="device") == checked
 
 
 @pytest.mark.gpu
